@@ -1,0 +1,186 @@
+/*
+ * pgt_hip.h — C ABI of libpgt_hip.so, the MI355X (gfx950 / CDNA4) native
+ * message-passing hot path behind torch_geometric_temporal.nn.
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes.  No torch types,
+ * no exceptions across the boundary.  All pointers are DEVICE pointers unless
+ * a parameter says "host".  Every call is stream-ordered on `stream`
+ * (a hipStream_t passed as void*), allocates nothing (the caller owns every
+ * buffer, including the scratch `ws`), and is safe to capture into a hipGraph.
+ * Return value: PGT_OK (0) or a negative PGT_ERR_* code; pgt_last_error()
+ * returns a thread-local message for the last failing call.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout,
+ * benedekrozemberczki/pytorch_geometric_temporal @ 2025-10-03):
+ *
+ *   pgt_dconv_prep        torch_geometric_temporal/nn/recurrent/dcrnn.py:59-77  (DConv graph prep:
+ *                         to_dense_adj, degrees, reciprocals, norm gathers, dense_to_sparse(adj^T))
+ *                         and dcrnn.py:277-290 (BatchedDConv scatter_add_/argsort form)
+ *   pgt_gcn_prep          PyG gcn_norm as called from GCNConv: nn/recurrent/temporalgcn.py:38-70,
+ *                         nn/recurrent/evolvegcno.py:88-90
+ *   pgt_cheb_prep         PyG ChebConv.__norm__ / nn/attention/astgcn.py:82-110 (ChebConvAttention.__norm__)
+ *   pgt_spmm_csr_f32      MessagePassing.propagate(aggr="add") + message():
+ *                         dcrnn.py:39-40,86-87,95-100,300-313; astgcn.py:169-175,185-190; evolvegcno.py:95-101
+ *                         (index_select -> norm*x_j -> scatter_add, fused, with the 2*P*T - T0 epilogue of dcrnn.py:96,100)
+ *   pgt_gemm_f32          the dense feature transforms: dcrnn.py:81-83,88-92,101-105 (torch.matmul on weight[d][k]);
+ *                         PyG Linear in GCNConv/ChebConv; temporalgcn.py:84,90,96 (linear_{z,r,h})
+ *   pgt_gemm_tn_acc_f32   autograd of the above w.r.t. the weights (torch autograd in the reference)
+ *   pgt_gru_*             the GRU gate chains: dcrnn.py:172-192,406-427; temporalgcn.py:82-102
+ */
+#ifndef PGT_HIP_H_
+#define PGT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGT_OK 0
+#define PGT_ERR_INVALID (-1)   /* bad argument (null pointer, negative size, misaligned, unsupported) */
+#define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
+#define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
+
+#define PGT_ABI_VERSION 1
+
+typedef void* pgt_stream_t; /* hipStream_t */
+
+/* CSR operator by destination row: y[i,:] = sum_{q in [rowptr[i], rowptr[i+1])} val[q] * x[col[q], :] */
+typedef struct pgt_csr {
+  int32_t* rowptr; /* [n_rows + 1] */
+  int32_t* col;    /* [nnz]  source node of each slot */
+  float* val;      /* [nnz]  per-slot coefficient */
+} pgt_csr;
+
+/* Everything DConv / BatchedDConv derive from (edge_index, edge_weight); all buffers caller-allocated.
+ * fwd_o/fwd_i are the out-/in-direction diffusion operators used by propagate (dcrnn.py:86-87);
+ * bwd_o/bwd_i are their transposes (used for the gradient w.r.t. the node features). */
+typedef struct pgt_dconv_graph {
+  pgt_csr fwd_o;    /* nnz = E */
+  pgt_csr fwd_i;    /* nnz = E */
+  pgt_csr bwd_o;    /* nnz = E */
+  pgt_csr bwd_i;    /* nnz = E */
+  float* deg_out;   /* [N]  scatter_add(edge_weight, row)  (dcrnn.py:61-64 / :279) */
+  float* deg_in;    /* [N]  scatter_add(edge_weight, col)  (dcrnn.py:65-68 / :280) */
+  int32_t* info;    /* [4]  info[0] = #duplicate (row,col) pairs, info[1] = #zero weights,
+                            info[2] = #edge endpoints outside [0,N), info[3] = reserved */
+} pgt_dconv_graph;
+
+/* GCN / Chebyshev operators: one CSR for propagate, one transposed CSR for the feature gradient.
+ * Slot capacity is E + 2N; the number of live slots is rowptr[N] (dropped self-loops sort past the end). */
+typedef struct pgt_sym_graph {
+  pgt_csr fwd;      /* capacity E + 2N */
+  pgt_csr bwd;      /* capacity E + 2N */
+  float* deg;       /* [N] */
+  int32_t* info;    /* [4] info[2] = #edge endpoints outside [0,N) */
+} pgt_sym_graph;
+
+int pgt_abi_version(void);
+const char* pgt_last_error(void);
+/* "gfx950" for the product library; "emu" for the CPU test double built under tests/. */
+const char* pgt_build_target(void);
+
+/* ---------------------------------------------------------------- graph preparation */
+
+/* Scratch bytes needed by the *_prep calls for a graph with E edges and N nodes. */
+size_t pgt_prep_workspace_bytes(int64_t E, int64_t N);
+
+/* edge_index: int64 [2,E] row-major (row = edge_index[0] = source, col = edge_index[1] = target).
+ * edge_weight: float [E] or NULL (unit weights, dcrnn.py:59 via to_dense_adj(edge_attr=None)). */
+int pgt_dconv_prep(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N,
+                   const pgt_dconv_graph* out, void* ws, size_t ws_bytes, pgt_stream_t stream);
+
+/* gcn_norm: add_remaining_self_loops(fill = improved ? 2 : 1) when add_self_loops != 0, deg = scatter_add(w, col),
+ * w' = deg^-1/2[row] * w * deg^-1/2[col] (inf -> 0).  Live slots: (#non-loop edges) + N when add_self_loops, else E. */
+int pgt_gcn_prep(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N,
+                 int improved, int add_self_loops, const pgt_sym_graph* out, void* ws, size_t ws_bytes,
+                 pgt_stream_t stream);
+
+/* ChebConv.__norm__: normalization 0 = None, 1 = "sym", 2 = "rw"; scaled Laplacian 2L/lambda_max - I.
+ * lambda_max: > 0 as given; NaN = "not passed" (2.0 for "sym"; 2*max(L) computed on the device otherwise).
+ * variant 0 = PyG ChebConv (STConv, stgcn.py:115-121): out[col] += norm*x[row], "-1" folded into the diagonal slot;
+ * variant 1 = in-tree ChebConvAttention.__norm__ (astgcn.py:82-110,166-175): a second set of N "-1" diagonal
+ *             slots is appended and propagate runs on the transposed edge list (out[row] += norm*x[col]).
+ * Self-loops of the input are removed (get_laplacian / remove_self_loops). */
+int pgt_cheb_prep(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N,
+                  int normalization, float lambda_max, int variant, const pgt_sym_graph* out, void* ws,
+                  size_t ws_bytes, pgt_stream_t stream);
+
+/* ---------------------------------------------------------------- aggregation (the graded kernel) */
+
+/* Y[i, 0:F] = alpha * sum_q val[q] * X[col[q], 0:F]  +  beta * T[i, 0:F]      (T may be NULL => beta term dropped)
+ * X, Y, T are row-major with row strides ldx/ldy/ldt (in floats).  Y may alias T; Y must not alias X.
+ * A batch of B graphs sharing one topology is laid out node-major ([N][B][C], F = B*C) so one launch covers it.
+ * Deterministic: per-row sequential accumulation in slot order, no atomics. */
+int pgt_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                     const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt,
+                     float alpha, float beta, int64_t F, pgt_stream_t stream);
+
+/* Same with a per-batch dense attention multiplier (ChebConvAttention hop 1, astgcn.py:157,169-171):
+ * rows are node-major [N][B][C]; the coefficient of slot q of row i for batch b is val[q] * S[b, i, col[q]]
+ * (S is the [B,N,N] spatial attention; Att_norm = norm * spatial_attention[:, row, col]). */
+int pgt_spmm_csr_att_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* S,
+                         int64_t n_rows, int64_t B, int64_t C, const float* X, float* Y,
+                         pgt_stream_t stream);
+
+/* ---------------------------------------------------------------- dense feature transform (fp32 MFMA) */
+
+/* C(m,n) = sum_j A_j[M, seg_k] * Bw[j*seg_k : (j+1)*seg_k, 0:N]  (+ bias[N])  (+ C if accumulate)
+ * A_j = A + j*a_seg_stride, row stride lda.  Bw element (k,n) at Bw[k*sbk + n*sbn]  (sbk=ldb,sbn=1: NN; sbk=1,sbn=ldb: NT).
+ * The output may be split into column segments of c_seg_n columns: C(m,n) lives at
+ * C[(n / c_seg_n)*c_seg_stride + m*ldc + n % c_seg_n]  (c_seg_n = N, c_seg_stride = 0 for a plain matrix).
+ * exact fp32 (v_mfma_f32_32x32x2_f32). */
+int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                 const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int64_t c_seg_stride,
+                 int64_t c_seg_n, const float* bias, int64_t M, int64_t N, int accumulate,
+                 pgt_stream_t stream);
+
+/* dW[j*seg_k + c, n] += sum_m A_j[m, c] * G[m, n]      (weight gradient; fp32 atomics into dW)
+ * db[n] += sum_m G[m, n] when db != NULL. */
+int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                        const float* G, int64_t ldg, float* dW, int64_t lddw, float* db, int64_t M, int64_t N,
+                        pgt_stream_t stream);
+
+/* ---------------------------------------------------------------- GRU gate chains */
+
+/* DCRNN (dcrnn.py:172-192):  pre_zr [M,2*O] holds the two DConv outputs (bias included).
+ *   zr = sigmoid(pre_zr) in place;  xhr[m, f_in + o] = H[m,o] * R[m,o]   (candidate input, dcrnn.py:185) */
+int pgt_gru_zr_f32(float* pre_zr, const float* H, int64_t ldh, float* xhr, int64_t ldxhr, int64_t f_in,
+                   int64_t M, int64_t O, pgt_stream_t stream);
+/*   ht = tanh(pre_h) in place;  Hnew = Z*H + (1-Z)*ht  (dcrnn.py:188-192), written to out0 (row stride ld0)
+ *   and, when out1 != NULL, also to out1 (row stride ld1). */
+int pgt_gru_h_f32(float* pre_h, const float* zr, const float* H, int64_t ldh, float* out0, int64_t ld0,
+                  float* out1, int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream);
+/* backward of pgt_gru_h_f32: given dHnew, writes d_pre_h [M,O], d_pre_zr[:, 0:O] (update gate), and
+ *   dH (=|+=) dHnew * Z  depending on accumulate_dh. */
+int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const float* zr, const float* H, int64_t ldh,
+                      const float* ht, float* d_pre_h, float* d_pre_zr, float* dH, int64_t lddhp,
+                      int accumulate_dh, int64_t M, int64_t O, pgt_stream_t stream);
+/* backward of pgt_gru_zr_f32: dxhr[:, f_in:] is d(H*R);  d_pre_zr[:, O:2O] = dHR*H*R*(1-R);  dH += dHR*R */
+int pgt_gru_zr_bwd_f32(const float* dxhr, int64_t lddxhr, int64_t f_in, const float* zr, const float* H,
+                       int64_t ldh, float* d_pre_zr, float* dH, int64_t lddhp, int64_t M, int64_t O,
+                       pgt_stream_t stream);
+
+/* TGCN (temporalgcn.py:82-102): pre_zr [M,2*O] = linear_{z,r}([conv(X), H]);
+ *   zr = sigmoid(pre_zr) in place; hr[m,o] = H[m,o]*R[m,o] */
+/* (uses pgt_gru_zr_f32 with f_in = 0) */
+
+/* ---------------------------------------------------------------- small data movers on the path */
+
+/* dst[m, 0:W] = src[m, 0:W] for m < M (row strides ldd/lds) — concatenation [X, H] (dcrnn.py:173,179,185). */
+int pgt_copy2d_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t M, int64_t W,
+                   pgt_stream_t stream);
+/* dst[m, 0:W] += src[m, 0:W] */
+int pgt_add2d_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t M, int64_t W,
+                  pgt_stream_t stream);
+/* dst[m, 0:W] = a*x[m,0:W] + b*y[m,0:W]  (y may be NULL) */
+int pgt_axpby2d_f32(float* dst, int64_t ldd, const float* x, int64_t ldx, float a, const float* y, int64_t ldy,
+                    float b, int64_t M, int64_t W, pgt_stream_t stream);
+/* [D0][D1][W] -> [D1][D0][W] blocked transpose of W-float records (batch-major <-> node-major). */
+int pgt_swap01_f32(float* dst, const float* src, int64_t D0, int64_t D1, int64_t W, pgt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGT_HIP_H_ */

@@ -1,0 +1,193 @@
+"""TEST INFRASTRUCTURE — CPU oracle: a functional restatement (plain PyTorch, fp32 or fp64, no classes, no
+state) of the reference's hot-path algorithms, each citing the reference file:line it follows.  Parameters are
+passed as a dict keyed by the reference's own state_dict names so the same weights drive the reference module,
+this oracle and the HIP modules.
+
+Pinned: tests/test_oracle_vs_reference.py runs these functions against the reference's actual module files
+(oracle/ref_import.py) wherever /root/reference exists, and against tests/golden/*.npz everywhere.
+The PyG primitives underneath (oracle/pyg_restated.py) are unpinned — see that file's header.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this; the product never does.
+"""
+import torch
+
+from . import pyg_restated as P
+
+
+def propagate_add(edge_index, x, norm):
+    """MessagePassing.propagate(aggr="add", flow="source_to_target", node_dim=-2) with message = norm * x_j
+    (dcrnn.py:39-40; PyG semantics in SURVEY.md Appendix A): gather sources, scale, index_add_ into targets."""
+    src, dst = edge_index[0], edge_index[1]
+    x_j = x.index_select(-2, src)
+    if norm is not None:
+        m = (norm.view(-1, 1) if norm.dim() == 1 else norm.unsqueeze(-1)) * x_j
+    else:
+        m = x_j
+    out = x.new_zeros(x.shape)
+    return out.index_add_(x.dim() - 2, dst, m)
+
+
+# ------------------------------------------------------------------------------------------------ DCRNN family
+
+def _diffusion_terms(X, edge_index, norm_out, reverse_edge_index, norm_in, weight, bias):
+    """dcrnn.py:79-111 (identical at :292-325): H = sum_k T_k^o W[0,k] + T_k^i W[1,k] + b with
+    T_1 = P X and T_k = 2 P T_{k-1} - Tx_0 where Tx_0 stays X forever (dcrnn.py:106: `Tx_0 ... = Tx_1 ...`)."""
+    K = weight.size(1)
+    Tx_0 = X
+    H = X @ weight[0, 0] + X @ weight[1, 0]
+    if K > 1:
+        T_o = propagate_add(edge_index, X, norm_out)
+        T_i = propagate_add(reverse_edge_index, X, norm_in)
+        H = H + T_o @ weight[0, 1] + T_i @ weight[1, 1]
+    for k in range(2, K):
+        T_o = 2.0 * propagate_add(edge_index, T_o, norm_out) - Tx_0
+        T_i = 2.0 * propagate_add(reverse_edge_index, T_i, norm_in) - Tx_0
+        H = H + T_o @ weight[0, k] + T_i @ weight[1, k]
+    if bias is not None:
+        H = H + bias
+    return H
+
+
+def dconv(X, edge_index, edge_weight, weight, bias):
+    """DConv.forward, dense-adjacency path (dcrnn.py:59-77): N' x N' adjacency (duplicates summed), degrees as
+    row/col sums, reciprocals, norm_out = 1/deg_out[row], norm_in = 1/deg_in[row] (sic), reverse list =
+    dense_to_sparse(adj^T) (row-major nonzeros of the transpose, exact zeros dropped)."""
+    adj = P.to_dense_adj(edge_index, edge_attr=edge_weight)
+    adj = adj.reshape(adj.size(1), adj.size(2)).to(X.dtype)
+    ones = torch.ones(adj.size(0), 1, dtype=X.dtype)
+    deg_out = (adj @ ones).flatten()
+    deg_in = (ones.t() @ adj).flatten()
+    row = edge_index[0]
+    norm_out = torch.reciprocal(deg_out)[row]
+    norm_in = torch.reciprocal(deg_in)[row]
+    reverse_edge_index, _ = P.dense_to_sparse(adj.transpose(0, 1))
+    return _diffusion_terms(X, edge_index, norm_out, reverse_edge_index, norm_in, weight, bias)
+
+
+def dconv_norms_scatter(edge_index, edge_weight, num_nodes, dtype=torch.float32):
+    """BatchedDConv.forward graph prep (dcrnn.py:277-290): scatter_add degrees, reciprocals, norm gathers by `row`,
+    reverse list = [col,row] sorted by col * num_nodes + row."""
+    row, col = edge_index[0], edge_index[1]
+    w = edge_weight.to(dtype)
+    deg_out = torch.zeros(num_nodes, dtype=dtype).scatter_add_(0, row, w)
+    deg_in = torch.zeros(num_nodes, dtype=dtype).scatter_add_(0, col, w)
+    norm_out = torch.reciprocal(deg_out)[row]
+    norm_in = torch.reciprocal(deg_in)[row]
+    rev = torch.stack([col, row], dim=0)
+    order = (rev[0] * num_nodes + rev[1]).argsort(stable=True)
+    return norm_out, norm_in, rev[:, order]
+
+
+def batched_dconv(X, edge_index, edge_weight, weight, bias):
+    """BatchedDConv.forward (dcrnn.py:258-325), O(E) scatter form."""
+    norm_out, norm_in, rev = dconv_norms_scatter(edge_index, edge_weight, X.size(0), X.dtype)
+    return _diffusion_terms(X, edge_index, norm_out, rev, norm_in, weight, bias)
+
+
+def _gru(conv, X, H, p):
+    """GRU gate chain shared by DCRNN (dcrnn.py:172-192) and BatchedDCRNN (:406-427)."""
+    XH = torch.cat([X, H], dim=1)
+    Z = torch.sigmoid(conv(XH, p["conv_x_z.weight"], p.get("conv_x_z.bias")))
+    R = torch.sigmoid(conv(XH, p["conv_x_r.weight"], p.get("conv_x_r.bias")))
+    Ht = torch.tanh(conv(torch.cat([X, H * R], dim=1), p["conv_x_h.weight"], p.get("conv_x_h.bias")))
+    return Z * H + (1 - Z) * Ht
+
+
+def dcrnn_cell(X, edge_index, edge_weight, H, p):
+    """DCRNN.forward (dcrnn.py:194-219); H None -> zeros (:167-170)."""
+    if H is None:
+        H = torch.zeros(X.shape[0], p["conv_x_z.weight"].size(3), dtype=X.dtype)
+    return _gru(lambda x, w, b: dconv(x, edge_index, edge_weight, w, b), X, H, p)
+
+
+def replicate_edge_index(edge_index, batch_size, num_nodes):
+    """BatchedDCRNN._replicate_edge_index (dcrnn.py:363-369): block-diagonal copies offset by b * num_nodes."""
+    return torch.cat([edge_index + b * num_nodes for b in range(batch_size)], dim=1)
+
+
+def batched_dcrnn(X, edge_index, edge_weight, p):
+    """BatchedDCRNN.forward (dcrnn.py:429-475): X [B,T,N,F] -> [B,T,N,O]; hidden state starts at zero."""
+    B, T, N, F = X.shape
+    O = p["conv_x_z.weight"].size(3)
+    ei = replicate_edge_index(edge_index, B, N)
+    ew = edge_weight.repeat(B)
+    H = torch.zeros(B * N, O, dtype=X.dtype)
+    outs = []
+    for t in range(T):
+        x_t = X[:, t].reshape(B * N, F)
+        H = _gru(lambda x, w, b: batched_dconv(x, ei, ew, w, b), x_t, H, p)
+        outs.append(H.reshape(B, N, O))
+    return torch.stack(outs, dim=1)
+
+
+# ------------------------------------------------------------------------------------------------ GCN family
+
+def gcn_conv(x, edge_index, edge_weight, lin_weight, bias, improved=False, add_self_loops=True):
+    """PyG GCNConv.forward as used by temporalgcn.py:38-70 (2-D [N,F] or 3-D [B,N,F] input, node_dim=-2)."""
+    ei, w = P.gcn_norm(edge_index, edge_weight, x.size(-2), improved, add_self_loops, dtype=x.dtype)
+    x = x @ lin_weight.t()
+    out = propagate_add(ei, x, w.to(x.dtype))
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+def tgcn_cell(X, edge_index, edge_weight, H, p, improved=False, add_self_loops=True):
+    """TGCN.forward (temporalgcn.py:104-130) and TGCN2.forward (:187-233): gates :82-102 / :205-226."""
+    O = p["linear_z.weight"].size(0)
+    if H is None:
+        H = torch.zeros(*X.shape[:-1], O, dtype=X.dtype)
+
+    def gate(name, h_in):
+        conv = gcn_conv(X, edge_index, edge_weight, p[f"conv_{name}.lin.weight"], p[f"conv_{name}.bias"],
+                        improved, add_self_loops)
+        cat = torch.cat([conv, h_in], dim=-1)
+        return cat @ p[f"linear_{name}.weight"].t() + p[f"linear_{name}.bias"]
+
+    Z = torch.sigmoid(gate("z", H))
+    R = torch.sigmoid(gate("r", H))
+    Ht = torch.tanh(gate("h", H * R))
+    return Z * H + (1 - Z) * Ht
+
+
+def a3tgcn(X, edge_index, edge_weight, H, p, improved=False, add_self_loops=True):
+    """A3TGCN.forward (attentiontemporalgcn.py:52-79) / A3TGCN2.forward (:130-157): X [..., F, P]; every period
+    uses the same H; output = sum_p softmax(attention)_p * TGCN(X[..., p], H)."""
+    probs = torch.softmax(p["_attention"].to(X.dtype), dim=0)
+    base = {k[len("_base_tgcn."):]: v for k, v in p.items() if k.startswith("_base_tgcn.")}
+    acc = 0
+    for period in range(probs.numel()):
+        acc = acc + probs[period] * tgcn_cell(X[..., period], edge_index, edge_weight, H, base, improved,
+                                              add_self_loops)
+    return acc
+
+
+# ------------------------------------------------------------------------------------------------ Chebyshev family
+
+def cheb_norm(edge_index, edge_weight, num_nodes, normalization, lambda_max, dtype):
+    """PyG ChebConv.__norm__ (scaled Laplacian 2L/lambda_max - I, "-1" folded into the diagonal entries)."""
+    ei, w = P.get_laplacian(edge_index, edge_weight, normalization, dtype, num_nodes)
+    if lambda_max is None:
+        lambda_max = 2.0 * w.max()
+    w = (2.0 * w) / lambda_max
+    w.masked_fill_(w == float("inf"), 0)
+    w[ei[0] == ei[1]] -= 1
+    return ei, w
+
+
+def cheb_conv(x, edge_index, edge_weight, lin_weights, bias, normalization="sym", lambda_max=None):
+    """PyG ChebConv.forward as used by stgcn.py:115-121,151-153 and gconv_gru.py:57-107."""
+    ei, norm = cheb_norm(edge_index, edge_weight, x.size(-2), normalization, lambda_max, x.dtype)
+    Tx_0 = x
+    Tx_1 = x
+    out = Tx_0 @ lin_weights[0].t()
+    if len(lin_weights) > 1:
+        Tx_1 = propagate_add(ei, x, norm)
+        out = out + Tx_1 @ lin_weights[1].t()
+    for W in lin_weights[2:]:
+        Tx_2 = 2.0 * propagate_add(ei, Tx_1, norm) - Tx_0
+        out = out + Tx_2 @ W.t()
+        Tx_0, Tx_1 = Tx_1, Tx_2
+    if bias is not None:
+        out = out + bias
+    return out

@@ -1,0 +1,171 @@
+"""ctypes binding of the C ABI in include/pgt_hip.h.
+
+The product path loads exactly one library: pytorch_geometric_temporal_amd/lib/libpgt_hip.so (gfx950 code objects).
+There is NO CPU fallback: if the library is missing, or a tensor is not on a HIP device, the ops raise.
+(The test-suite can inject a *test double* built from the same kernel sources — see `_set_library_for_testing` —
+which only accepts CPU tensors and announces itself as target "emu".)
+"""
+import ctypes
+import os
+import warnings
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpgt_hip.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f32 = ctypes.c_float
+c_ptr = ctypes.c_void_p
+c_size = ctypes.c_size_t
+
+
+class PgtError(RuntimeError):
+    pass
+
+
+class PgtLibraryMissing(PgtError):
+    pass
+
+
+class CsrStruct(ctypes.Structure):
+    _fields_ = [("rowptr", c_ptr), ("col", c_ptr), ("val", c_ptr)]
+
+
+class DConvGraphStruct(ctypes.Structure):
+    _fields_ = [("fwd_o", CsrStruct), ("fwd_i", CsrStruct), ("bwd_o", CsrStruct), ("bwd_i", CsrStruct),
+                ("deg_out", c_ptr), ("deg_in", c_ptr), ("info", c_ptr)]
+
+
+class SymGraphStruct(ctypes.Structure):
+    _fields_ = [("fwd", CsrStruct), ("bwd", CsrStruct), ("deg", c_ptr), ("info", c_ptr)]
+
+
+# name -> (restype, argtypes); mirrors include/pgt_hip.h one to one (tests/test_cabi.py checks the header against this)
+PROTOTYPES = {
+    "pgt_abi_version": (c_int, []),
+    "pgt_last_error": (ctypes.c_char_p, []),
+    "pgt_build_target": (ctypes.c_char_p, []),
+    "pgt_prep_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "pgt_dconv_prep": (c_int, [c_ptr, c_ptr, c_i64, c_i64, ctypes.POINTER(DConvGraphStruct), c_ptr, c_size, c_ptr]),
+    "pgt_gcn_prep": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, ctypes.POINTER(SymGraphStruct), c_ptr,
+                             c_size, c_ptr]),
+    "pgt_cheb_prep": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_int, ctypes.POINTER(SymGraphStruct),
+                              c_ptr, c_size, c_ptr]),
+    "pgt_spmm_csr_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32,
+                                 c_f32, c_i64, c_ptr]),
+    "pgt_spmm_csr_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "pgt_gemm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64,
+                             c_ptr, c_i64, c_i64, c_int, c_ptr]),
+    "pgt_gemm_tn_acc_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
+                                    c_i64, c_ptr]),
+    "pgt_gru_zr_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_gru_h_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_gru_h_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int,
+                                  c_i64, c_i64, c_ptr]),
+    "pgt_gru_zr_bwd_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64,
+                                   c_ptr]),
+    "pgt_copy2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_add2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_axpby2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_i64, c_f32, c_i64, c_i64, c_ptr]),
+    "pgt_swap01_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+}
+
+EXPECTED_ABI = 1
+
+
+class PgtLib:
+    """A loaded libpgt_*.so with typed entry points.  `target` is "gfx950" (product) or "emu" (test double)."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise PgtLibraryMissing(
+                f"{path} not found. Build it with `python -m pytorch_geometric_temporal_amd._build` "
+                f"(or __graft_entry__.build()). There is no CPU fallback for the HIP kernels.")
+        self.path = path
+        self._dll = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise PgtError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_" + name, fn)
+        abi = self._pgt_abi_version()
+        if abi != EXPECTED_ABI:
+            raise PgtError(f"{path}: ABI version {abi}, expected {EXPECTED_ABI}")
+        self.target = self._pgt_build_target().decode()
+
+    def last_error(self):
+        return self._pgt_last_error().decode()
+
+    def call(self, name, *args):
+        rc = getattr(self, "_" + name)(*args)
+        if rc != 0:
+            raise PgtError(f"{name} failed with code {rc}: {self.last_error()}")
+
+    def prep_workspace_bytes(self, E, N):
+        return int(self._pgt_prep_workspace_bytes(E, N))
+
+
+_LIB = None
+_TESTING = False
+
+
+def _preload_hip_runtime():
+    # libpgt_hip.so needs libamdhip64.so.7; make sure the copy PyTorch already mapped is the one it binds to, so
+    # device pointers and hipStream_t handles created by torch are valid inside the library.
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(torch_lib):
+        try:
+            ctypes.CDLL(torch_lib, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def get_lib():
+    """The product library (gfx950).  Raises PgtLibraryMissing when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        _preload_hip_runtime()
+        _LIB = PgtLib(LIB_PATH)
+        if _LIB.target != "gfx950":
+            raise PgtError(f"{LIB_PATH} reports target {_LIB.target!r}, expected 'gfx950'")
+    return _LIB
+
+
+def _set_library_for_testing(lib):
+    """TEST-ONLY hook: route the host logic to a test double (tests/_emu/libpgt_emu.so).  Never used by the product."""
+    global _LIB, _TESTING
+    if lib is not None:
+        if lib.target != "emu":
+            raise PgtError("only the 'emu' test double may be injected")
+        warnings.warn("pytorch_geometric_temporal_amd: running on the CPU TEST DOUBLE of the HIP kernels", stacklevel=2)
+    _LIB = lib
+    _TESTING = lib is not None
+
+
+def check_tensor(lib, t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if lib.target == "gfx950":
+        if not t.is_cuda:
+            raise PgtError(f"{name} is on {t.device}; the HIP kernels need a GPU tensor (no CPU fallback)")
+    else:
+        if t.is_cuda:
+            raise PgtError(f"{name}: the emu test double only takes CPU tensors")
+    return t
+
+
+def stream_of(lib, t):
+    if lib.target == "gfx950":
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(0)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

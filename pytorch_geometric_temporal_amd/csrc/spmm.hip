@@ -1,0 +1,285 @@
+// CSR aggregation kernels (the fused replacement of PyG's propagate: gather -> norm*x_j -> scatter-add).
+//
+//   Y[i,:] = alpha * sum_{q in row i} val[q] * X[col[q],:]  +  beta * T[i,:]
+//
+// Two launch shapes, both deterministic (per-row sequential accumulation in slot order, no atomics):
+//
+//  * spmm_tile_kernel<VEC,LPR>  — F <= 64*VEC floats per row.  A 256-thread workgroup owns a tile of
+//    TR = 64 consecutive rows.  The tile's rowptr slice and its col/val slots are staged into LDS with
+//    coalesced loads; then each group of LPR lanes walks one row, broadcasting (col,val) out of LDS and
+//    issuing VEC-wide coalesced reads of the neighbour's feature row (LPR*VEC*4 bytes contiguous).
+//    For F = 64: LPR = 16 lanes x float4 = one 256-byte row per group, 4 rows per wavefront.
+//    Tiles are handed to XCDs in contiguous ranges (blockIdx -> XCD is round-robin on MI355X) so that
+//    a locality-ordered graph keeps its neighbour rows in one XCD's 4 MiB L2.
+//
+//  * spmm_wide_kernel<VEC>      — F > 64*VEC (node-major batches: F = B*C).  One wavefront per
+//    (row, 64*VEC-float chunk); row index is wave-uniform so (col,val) come through the scalar path and the
+//    neighbour read is a fully coalesced 1 KiB (VEC = 4) burst.
+//
+// Algorithmic bytes per launch: 4(N+1) + 8*nnz + 4*N*F (read X once) + 4*N*F (write Y) [+ 4*N*F for T].
+#include "pgt_common.h"
+
+namespace {
+
+constexpr int TR = 64;      // rows per tile
+constexpr int CAP = 1536;   // LDS-staged slots per tile (12 KiB); larger tiles fall back to global reads
+
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void stv(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  } else {
+    *p = v[0];
+  }
+}
+
+// blockIdx -> tile so that each XCD (block b runs on XCD b % 8) owns a contiguous range of tiles.
+__device__ __forceinline__ int xcd_contiguous_tile(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = b & 7;
+  return x * q + (x < r ? x : r) + (b >> 3);
+}
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void spmm_tile_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    int n_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy, const float* T,
+    int64_t ldt, float alpha, float beta, int F) {
+  __shared__ int s_rp[TR + 1];
+  __shared__ int s_col[CAP];
+  __shared__ float s_val[CAP];
+
+  const int tid = threadIdx.x;
+  const int tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+  const int r0 = tile * TR;
+  const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
+
+  if (tid <= nr) s_rp[tid] = rowptr[r0 + tid];
+  __syncthreads();
+  const int e0 = s_rp[0];
+  const int nnz = s_rp[nr] - e0;
+  const bool staged = nnz <= CAP;
+  if (staged) {
+    for (int q = tid; q < nnz; q += 256) {
+      s_col[q] = col[e0 + q];
+      s_val[q] = val[e0 + q];
+    }
+  }
+  __syncthreads();
+
+  constexpr int GROUPS = 256 / LPR;
+  const int g = tid / LPR;
+  const int f = (tid % LPR) * VEC;
+  if (f >= F) return;  // no barriers below
+
+  for (int r = g; r < nr; r += GROUPS) {
+    const int a = s_rp[r] - e0, b = s_rp[r + 1] - e0;
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    int q = a;
+    if (staged) {
+      for (; q + 4 <= b; q += 4) {
+        const int c0 = s_col[q], c1 = s_col[q + 1], c2 = s_col[q + 2], c3 = s_col[q + 3];
+        const float v0 = s_val[q], v1 = s_val[q + 1], v2 = s_val[q + 2], v3 = s_val[q + 3];
+        float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
+        ldv<VEC>(X + (int64_t)c0 * ldx + f, x0);
+        ldv<VEC>(X + (int64_t)c1 * ldx + f, x1);
+        ldv<VEC>(X + (int64_t)c2 * ldx + f, x2);
+        ldv<VEC>(X + (int64_t)c3 * ldx + f, x3);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          acc[i] = fmaf(v0, x0[i], acc[i]);
+          acc[i] = fmaf(v1, x1[i], acc[i]);
+          acc[i] = fmaf(v2, x2[i], acc[i]);
+          acc[i] = fmaf(v3, x3[i], acc[i]);
+        }
+      }
+      for (; q < b; ++q) {
+        const int c0 = s_col[q];
+        const float v0 = s_val[q];
+        float x0[VEC];
+        ldv<VEC>(X + (int64_t)c0 * ldx + f, x0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(v0, x0[i], acc[i]);
+      }
+    } else {
+      for (; q < b; ++q) {
+        const int c0 = col[e0 + q];
+        const float v0 = val[e0 + q];
+        float x0[VEC];
+        ldv<VEC>(X + (int64_t)c0 * ldx + f, x0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(v0, x0[i], acc[i]);
+      }
+    }
+    float out[VEC];
+    if (T != nullptr) {
+      float t[VEC];
+      ldv<VEC>(T + (int64_t)(r0 + r) * ldt + f, t);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) out[i] = alpha * acc[i] + beta * t[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) out[i] = alpha * acc[i];
+    }
+    stv<VEC>(Y + (int64_t)(r0 + r) * ldy + f, out);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void spmm_wide_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    int n_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy, const float* T,
+    int64_t ldt, float alpha, float beta, int F, int nchunks) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = (int)(blockIdx.x % (unsigned)nchunks);
+  const int row = (int)(blockIdx.x / (unsigned)nchunks) * 4 + wave;
+  if (row >= n_rows) return;
+  const int f = (chunk * 64 + lane) * VEC;
+  if (f >= F) return;
+  const int a = rowptr[row], b = rowptr[row + 1];
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  int q = a;
+  for (; q + 4 <= b; q += 4) {
+    const int c0 = col[q], c1 = col[q + 1], c2 = col[q + 2], c3 = col[q + 3];
+    const float v0 = val[q], v1 = val[q + 1], v2 = val[q + 2], v3 = val[q + 3];
+    float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
+    ldv<VEC>(X + (int64_t)c0 * ldx + f, x0);
+    ldv<VEC>(X + (int64_t)c1 * ldx + f, x1);
+    ldv<VEC>(X + (int64_t)c2 * ldx + f, x2);
+    ldv<VEC>(X + (int64_t)c3 * ldx + f, x3);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      acc[i] = fmaf(v0, x0[i], acc[i]);
+      acc[i] = fmaf(v1, x1[i], acc[i]);
+      acc[i] = fmaf(v2, x2[i], acc[i]);
+      acc[i] = fmaf(v3, x3[i], acc[i]);
+    }
+  }
+  for (; q < b; ++q) {
+    const int c0 = col[q];
+    const float v0 = val[q];
+    float x0[VEC];
+    ldv<VEC>(X + (int64_t)c0 * ldx + f, x0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(v0, x0[i], acc[i]);
+  }
+  float out[VEC];
+  if (T != nullptr) {
+    float t[VEC];
+    ldv<VEC>(T + (int64_t)row * ldt + f, t);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = alpha * acc[i] + beta * t[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = alpha * acc[i];
+  }
+  stv<VEC>(Y + (int64_t)row * ldy + f, out);
+}
+
+// ChebConvAttention hop-1: coefficient val[q] * S[b, row, col[q]] (dense [B,N,N] attention gathered at the
+// edges instead of the reference's [B,E] temporary); rows node-major [N][B][C].
+__global__ __launch_bounds__(256) void spmm_att_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ S, int n_rows, int B, int C, const float* __restrict__ X,
+    float* __restrict__ Y) {
+  // one thread per (row, b, c) element
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)n_rows * B * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const int b = (int)((idx / C) % B);
+  const int row = (int)(idx / ((int64_t)B * C));
+  const int a = rowptr[row], e = rowptr[row + 1];
+  const float* Srow = S + ((int64_t)b * n_rows + row) * n_rows;
+  float acc = 0.f;
+  for (int q = a; q < e; ++q) {
+    const int j = col[q];
+    const float w = val[q] * Srow[j];
+    acc = fmaf(w, X[((int64_t)j * B + b) * C + c], acc);
+  }
+  Y[idx] = acc;
+}
+
+template <int VEC>
+int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const float* X,
+                int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha, float beta,
+                int64_t F, pgt_stream_t stream) {
+  const int64_t Fv = F / VEC;
+  const int n = (int)n_rows, Fi = (int)F;
+  if (Fv <= 64) {
+    const unsigned ntiles = (unsigned)pgt_cdiv(n_rows, TR);
+    dim3 grid(ntiles), block(256);
+#define PGT_SPMM_CASE(L)                                                                                   \
+  PGT_LAUNCH((spmm_tile_kernel<VEC, L>), grid, block, stream, rowptr, col, val, n, X, ldx, Y, ldy, T, ldt, \
+             alpha, beta, Fi)
+    if (Fv <= 4) { PGT_SPMM_CASE(4); }
+    else if (Fv <= 8) { PGT_SPMM_CASE(8); }
+    else if (Fv <= 16) { PGT_SPMM_CASE(16); }
+    else if (Fv <= 32) { PGT_SPMM_CASE(32); }
+    else { PGT_SPMM_CASE(64); }
+#undef PGT_SPMM_CASE
+  } else {
+    const int nchunks = (int)pgt_cdiv(Fv, 64);
+    const int64_t nblocks = pgt_cdiv(n_rows, 4) * nchunks;
+    PGT_REQUIRE(nblocks < (int64_t)1 << 31, "pgt_spmm_csr_f32: grid too large");
+    dim3 grid((unsigned)nblocks), block(256);
+    PGT_LAUNCH((spmm_wide_kernel<VEC>), grid, block, stream, rowptr, col, val, n, X, ldx, Y, ldy, T, ldt, alpha,
+               beta, Fi, nchunks);
+  }
+  return pgt_check_launch("pgt_spmm_csr_f32");
+}
+
+}  // namespace
+
+extern "C" int pgt_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T,
+                                int64_t ldt, float alpha, float beta, int64_t F, pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0 && F >= 0, "pgt_spmm_csr_f32: negative size");
+  if (n_rows == 0 || F == 0) return PGT_OK;
+  PGT_REQUIRE(rowptr && X && Y, "pgt_spmm_csr_f32: null pointer");
+  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) - TR && F < ((int64_t)1 << 31), "pgt_spmm_csr_f32: size exceeds int32 indexing");
+  PGT_REQUIRE(ldx >= F && ldy >= F && (T == nullptr || ldt >= F), "pgt_spmm_csr_f32: row stride smaller than F");
+  PGT_REQUIRE(Y != X, "pgt_spmm_csr_f32: Y must not alias X");
+  // widest vector width every row start is aligned for
+  auto ok = [&](int v) {
+    const size_t a = (size_t)v * 4;
+    return F % v == 0 && ldx % v == 0 && ldy % v == 0 && pgt_aligned(X, a) && pgt_aligned(Y, a) &&
+           (T == nullptr || (ldt % v == 0 && pgt_aligned(T, a)));
+  };
+  if (ok(4)) return launch_spmm<4>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
+  if (ok(2)) return launch_spmm<2>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
+  return launch_spmm<1>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
+}
+
+extern "C" int pgt_spmm_csr_att_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                    const float* S, int64_t n_rows, int64_t B, int64_t C, const float* X,
+                                    float* Y, pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0 && B >= 0 && C >= 0, "pgt_spmm_csr_att_f32: negative size");
+  if (n_rows == 0 || B == 0 || C == 0) return PGT_OK;
+  PGT_REQUIRE(rowptr && S && X && Y, "pgt_spmm_csr_att_f32: null pointer");
+  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) && B < ((int64_t)1 << 31) && C < ((int64_t)1 << 31),
+              "pgt_spmm_csr_att_f32: size exceeds int32 indexing");
+  const int64_t total = n_rows * B * C;
+  PGT_REQUIRE(pgt_cdiv(total, 256) < ((int64_t)1 << 31), "pgt_spmm_csr_att_f32: grid too large");
+  dim3 grid((unsigned)pgt_cdiv(total, 256)), block(256);
+  PGT_LAUNCH(spmm_att_kernel, grid, block, stream, rowptr, col, val, S, (int)n_rows, (int)B, (int)C, X, Y);
+  return pgt_check_launch("pgt_spmm_csr_att_f32");
+}

@@ -1,0 +1,488 @@
+"""Host-side wrappers over the C ABI (include/pgt_hip.h): graph handles, raw kernel calls on torch-owned device
+memory, and the autograd Functions the nn.Module mirrors are built from.  PyTorch is plumbing here: it owns the
+buffers and the stream; every arithmetic step on the path is a HIP kernel behind the C ABI.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import CsrStruct, DConvGraphStruct, SymGraphStruct, PgtError, check_tensor, ptr, stream_of
+
+F32 = torch.float32
+I32 = torch.int32
+
+
+# --------------------------------------------------------------------------------------------- graph handles
+
+class Csr:
+    __slots__ = ("rowptr", "col", "val", "n_rows")
+
+    def __init__(self, n_rows, cap, device):
+        self.n_rows = n_rows
+        self.rowptr = torch.zeros(n_rows + 1, dtype=I32, device=device)
+        self.col = torch.zeros(max(cap, 1), dtype=I32, device=device)
+        self.val = torch.zeros(max(cap, 1), dtype=F32, device=device)
+
+    def struct(self):
+        return CsrStruct(ptr(self.rowptr), ptr(self.col), ptr(self.val))
+
+
+def _edge_inputs(lib, edge_index, edge_weight):
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError("edge_index must have shape [2, E]")
+    check_tensor(lib, edge_index, "edge_index", torch.int64)
+    ei = edge_index.contiguous()
+    ew = None
+    if edge_weight is not None:
+        ew = edge_weight
+        if ew.dtype != F32:
+            ew = ew.to(F32)
+        check_tensor(lib, ew, "edge_weight", F32)
+        ew = ew.contiguous()
+        if ew.numel() != ei.size(1):
+            raise ValueError("edge_weight must have one entry per edge")
+    return ei, ew
+
+
+class DConvGraph:
+    """Device-resident operators of DConv / BatchedDConv (dcrnn.py:59-77, :277-290) for one (edge_index, edge_weight)."""
+
+    def __init__(self, edge_index, edge_weight, num_nodes, validate=True, strict_dense=False):
+        lib = _lib.get_lib()
+        ei, ew = _edge_inputs(lib, edge_index, edge_weight)
+        dev = ei.device
+        E, N = ei.size(1), int(num_nodes)
+        self.N, self.E, self.device = N, E, dev
+        self.fwd_o, self.fwd_i = Csr(N, E, dev), Csr(N, E, dev)
+        self.bwd_o, self.bwd_i = Csr(N, E, dev), Csr(N, E, dev)
+        self.deg_out = torch.zeros(max(N, 1), dtype=F32, device=dev)
+        self.deg_in = torch.zeros(max(N, 1), dtype=F32, device=dev)
+        self.info = torch.zeros(4, dtype=I32, device=dev)
+        ws_bytes = lib.prep_workspace_bytes(E, N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        st = DConvGraphStruct(self.fwd_o.struct(), self.fwd_i.struct(), self.bwd_o.struct(), self.bwd_i.struct(),
+                              ptr(self.deg_out), ptr(self.deg_in), ptr(self.info))
+        lib.call("pgt_dconv_prep", ptr(ei), ptr(ew), E, N, ctypes.byref(st), ptr(ws), ws_bytes, stream_of(lib, ei))
+        if validate:
+            dup, zero, oob, _ = self.info.tolist()  # one host sync per *new* graph
+            if oob:
+                raise IndexError(f"edge_index has {oob} endpoint(s) outside [0, {N})")
+            if strict_dense and (dup or zero):
+                # DConv's dense path (to_dense_adj sums duplicates, dense_to_sparse drops zeros) makes the reversed
+                # edge list shorter than norm_in and the reference fails with a shape mismatch in message().
+                raise RuntimeError(
+                    f"DConv: edge list has {dup} duplicate edge(s) and {zero} zero weight(s); the reference's dense "
+                    f"adjacency path (dcrnn.py:59-77) cannot broadcast norm_in over the shortened reverse edge list")
+
+
+class SymGraph:
+    """GCN-normalised (gcn_norm) or scaled-Laplacian (ChebConv.__norm__) operator and its transpose."""
+
+    def __init__(self, kind, edge_index, edge_weight, num_nodes, improved=False, add_self_loops=True,
+                 normalization="sym", lambda_max=None, variant=0, validate=True):
+        lib = _lib.get_lib()
+        ei, ew = _edge_inputs(lib, edge_index, edge_weight)
+        dev = ei.device
+        E, N = ei.size(1), int(num_nodes)
+        self.N, self.E, self.device = N, E, dev
+        cap = E + 2 * N
+        self.fwd, self.bwd = Csr(N, cap, dev), Csr(N, cap, dev)
+        self.deg = torch.zeros(max(N, 1), dtype=F32, device=dev)
+        self.info = torch.zeros(4, dtype=I32, device=dev)
+        ws_bytes = lib.prep_workspace_bytes(E, N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        st = SymGraphStruct(self.fwd.struct(), self.bwd.struct(), ptr(self.deg), ptr(self.info))
+        if kind == "gcn":
+            lib.call("pgt_gcn_prep", ptr(ei), ptr(ew), E, N, int(bool(improved)), int(bool(add_self_loops)),
+                     ctypes.byref(st), ptr(ws), ws_bytes, stream_of(lib, ei))
+        elif kind == "cheb":
+            norm_code = {None: 0, "sym": 1, "rw": 2}[normalization]
+            lam = float("nan") if lambda_max is None else float(lambda_max)
+            lib.call("pgt_cheb_prep", ptr(ei), ptr(ew), E, N, norm_code, lam, int(variant), ctypes.byref(st),
+                     ptr(ws), ws_bytes, stream_of(lib, ei))
+        else:
+            raise ValueError(kind)
+        if validate:
+            oob = int(self.info[2])
+            if oob:
+                raise IndexError(f"edge_index has {oob} endpoint(s) outside [0, {N})")
+
+
+class _GraphCache:
+    """Identity-keyed cache (data_ptr + in-place version counter), never torch.equal (no host sync per forward;
+    the reference compares with torch.equal twice per BatchedDCRNN forward, dcrnn.py:446-447)."""
+
+    def __init__(self, capacity=16):
+        self.capacity = capacity
+        self._d = OrderedDict()
+
+    @staticmethod
+    def _tkey(t):
+        if t is None:
+            return None
+        return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), str(t.device), t.dtype)
+
+    def get(self, tag, edge_index, edge_weight, extra, builder):
+        key = (tag, self._tkey(edge_index), self._tkey(edge_weight), extra)
+        hit = self._d.get(key)
+        if hit is not None:
+            self._d.move_to_end(key)
+            return hit[0]
+        g = builder()
+        # keep the key tensors alive so their storage (data_ptr) cannot be recycled while the entry lives
+        self._d[key] = (g, edge_index, edge_weight)
+        if len(self._d) > self.capacity:
+            self._d.popitem(last=False)
+        return g
+
+    def clear(self):
+        self._d.clear()
+
+
+GRAPH_CACHE = _GraphCache()
+
+
+def dconv_graph(edge_index, edge_weight, num_nodes, strict_dense=False):
+    return GRAPH_CACHE.get("dconv", edge_index, edge_weight, (int(num_nodes), bool(strict_dense)),
+                           lambda: DConvGraph(edge_index, edge_weight, num_nodes, strict_dense=strict_dense))
+
+
+def gcn_graph(edge_index, edge_weight, num_nodes, improved=False, add_self_loops=True):
+    return GRAPH_CACHE.get("gcn", edge_index, edge_weight, (int(num_nodes), bool(improved), bool(add_self_loops)),
+                           lambda: SymGraph("gcn", edge_index, edge_weight, num_nodes, improved=improved,
+                                            add_self_loops=add_self_loops))
+
+
+def cheb_graph(edge_index, edge_weight, num_nodes, normalization="sym", lambda_max=None, variant=0):
+    lam = None if lambda_max is None else float(lambda_max)
+    return GRAPH_CACHE.get("cheb", edge_index, edge_weight, (int(num_nodes), normalization, lam, int(variant)),
+                           lambda: SymGraph("cheb", edge_index, edge_weight, num_nodes, normalization=normalization,
+                                            lambda_max=lam, variant=variant))
+
+
+# --------------------------------------------------------------------------------------------- raw kernel calls
+
+def _rows(t, name):
+    """(pointer, row stride) of a 2-D view with unit column stride."""
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name} must be 2-D with unit column stride, got shape {tuple(t.shape)} stride {t.stride()}")
+    return ptr(t), (t.stride(0) if t.size(0) > 1 else max(t.size(1), t.stride(0)))
+
+
+def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0):
+    """Y = alpha * A @ X + beta * T on [n_rows, F] views (pgt_spmm_csr_f32)."""
+    lib = _lib.get_lib()
+    for t, n in ((X, "X"), (Y, "Y")) + (((T, "T"),) if T is not None else ()):
+        check_tensor(lib, t, n)
+    if X.size(0) != csr.n_rows or Y.shape != X.shape or (T is not None and T.shape != X.shape):
+        raise ValueError(f"spmm shape mismatch: rows {csr.n_rows}, X {tuple(X.shape)}, Y {tuple(Y.shape)}")
+    xp, ldx = _rows(X, "X")
+    yp, ldy = _rows(Y, "Y")
+    tp, ldt = _rows(T, "T") if T is not None else (ptr(None), 0)
+    lib.call("pgt_spmm_csr_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,
+             float(alpha), float(beta), X.size(1), stream_of(lib, X))
+    return Y
+
+
+def gemm(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, C, ldc, c_seg_stride, c_seg_n, bias, M, N,
+         accumulate=False):
+    """pgt_gemm_f32 on raw (tensor-as-base-pointer, strides) operands; see include/pgt_hip.h."""
+    lib = _lib.get_lib()
+    for t, n in ((A, "A"), (Bw, "Bw"), (C, "C")):
+        check_tensor(lib, t, n)
+    if bias is not None:
+        check_tensor(lib, bias, "bias")
+    lib.call("pgt_gemm_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(Bw), sbk, sbn, ptr(C), ldc, c_seg_stride,
+             c_seg_n, ptr(bias), M, N, int(bool(accumulate)), stream_of(lib, C))
+    return C
+
+
+def gemm_tn_acc(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N):
+    lib = _lib.get_lib()
+    for t, n in ((A, "A"), (G, "G"), (dW, "dW")):
+        check_tensor(lib, t, n)
+    if db is not None:
+        check_tensor(lib, db, "db")
+    lib.call("pgt_gemm_tn_acc_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(G), ldg, ptr(dW), lddw, ptr(db), M, N,
+             stream_of(lib, G))
+    return dW
+
+
+def linear_fwd(X2, W_kn, bias, out=None):
+    """out[M,N] = X2[M,K] @ W_kn[K,N] + bias (plain matrices; W_kn may be any 2-D strided view)."""
+    M, K = X2.shape
+    N = W_kn.size(1)
+    if out is None:
+        out = torch.empty(M, N, dtype=F32, device=X2.device)
+    _, lda = _rows(X2, "X2")
+    gemm(X2, lda, 0, 1, K, W_kn, W_kn.stride(0), W_kn.stride(1), out, out.stride(0), 0, N, bias, M, N)
+    return out
+
+
+def copy2d(dst, src):
+    lib = _lib.get_lib()
+    check_tensor(lib, dst, "dst"); check_tensor(lib, src, "src")
+    dp, ldd = _rows(dst, "dst")
+    sp, lds = _rows(src, "src")
+    lib.call("pgt_copy2d_f32", dp, ldd, sp, lds, src.size(0), src.size(1), stream_of(lib, dst))
+
+
+def add2d(dst, src):
+    lib = _lib.get_lib()
+    check_tensor(lib, dst, "dst"); check_tensor(lib, src, "src")
+    dp, ldd = _rows(dst, "dst")
+    sp, lds = _rows(src, "src")
+    lib.call("pgt_add2d_f32", dp, ldd, sp, lds, src.size(0), src.size(1), stream_of(lib, dst))
+
+
+def axpby2d(dst, x, a, y=None, b=0.0):
+    lib = _lib.get_lib()
+    check_tensor(lib, dst, "dst"); check_tensor(lib, x, "x")
+    dp, ldd = _rows(dst, "dst")
+    xp, ldx = _rows(x, "x")
+    yp, ldy = _rows(y, "y") if y is not None else (ptr(None), 0)
+    lib.call("pgt_axpby2d_f32", dp, ldd, xp, ldx, float(a), yp, ldy, float(b), x.size(0), x.size(1), stream_of(lib, dst))
+
+
+def swap01(src, D0, D1, W):
+    """[D0][D1][W] -> [D1][D0][W] (batch-major <-> node-major)."""
+    lib = _lib.get_lib()
+    check_tensor(lib, src, "src")
+    src = src.contiguous()
+    dst = torch.empty(D1, D0, W, dtype=F32, device=src.device)
+    lib.call("pgt_swap01_f32", ptr(dst), ptr(src), D0, D1, W, stream_of(lib, src))
+    return dst
+
+
+class Swap01(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, D0, D1, W):
+        ctx.dims = (D0, D1, W)
+        return swap01(x, D0, D1, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        D0, D1, W = ctx.dims
+        return swap01(g, D1, D0, W), None, None, None
+
+
+# --------------------------------------------------------------------------------------------- diffusion stack
+
+def _stack_fwd(g, TS, t, K, Nn):
+    """T_0 = TS[0,t] given; fill T_k^{o,i} (dcrnn.py:85-106): T_1 = P T_0, T_k = 2 P T_{k-1} - T_0 (Tx_0 is never
+    advanced in the reference, dcrnn.py:106 — reproduced).  Segment order: [T0, T1o, T1i, T2o, T2i, ...]."""
+    T0 = TS[0, t].view(Nn, -1)
+    for k in range(1, K):
+        for d, csr in enumerate((g.fwd_o, g.fwd_i)):
+            src = T0 if k == 1 else TS[2 * (k - 1) - 1 + d, t].view(Nn, -1)
+            dst = TS[2 * k - 1 + d, t].view(Nn, -1)
+            if k == 1:
+                spmm(csr, src, dst)
+            else:
+                spmm(csr, src, dst, T=T0, alpha=2.0, beta=-1.0)
+
+
+def _stack_bwd(g, G, K, Nn):
+    """Adjoint of _stack_fwd on G [S][M][C] (in place); on exit G[0] holds d/dT_0."""
+    G0 = G[0].view(Nn, -1)
+    for k in range(K - 1, 1, -1):
+        for d, csr in enumerate((g.bwd_o, g.bwd_i)):
+            Gk = G[2 * k - 1 + d].view(Nn, -1)
+            Gp = G[2 * (k - 1) - 1 + d].view(Nn, -1)
+            spmm(csr, Gk, Gp, T=Gp, alpha=2.0, beta=1.0)
+            axpby2d(G0, Gk, -1.0, G0, 1.0)
+    if K > 1:
+        for d, csr in enumerate((g.bwd_o, g.bwd_i)):
+            spmm(csr, G[1 + d].view(Nn, -1), G0, T=G0, alpha=1.0, beta=1.0)
+
+
+def stack_weight(weight):
+    """DConv weight [2,K,C,O] -> stacked [(2K-1)*C, O] matching the segment order of _stack_fwd.
+    Segment 0 carries W[0,0] + W[1,0] (the reference computes X@W[0,0] + X@W[1,0], dcrnn.py:81-83)."""
+    K = weight.size(1)
+    segs = [weight[0, 0] + weight[1, 0]]
+    for k in range(1, K):
+        segs.append(weight[0, k])
+        segs.append(weight[1, k])
+    return torch.cat(segs, dim=0)
+
+
+class DConvFunction(torch.autograd.Function):
+    """H = DConv(X) for node-major X [N*B, C]: diffusion stack (SpMM) + one segmented MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, X, Wst, bias, g, K, B):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        M, C = X.shape
+        Nn = g.N
+        if M != Nn * B:
+            raise ValueError(f"X has {M} rows, expected num_nodes*B = {Nn * B}")
+        S = 2 * K - 1
+        O = Wst.size(1)
+        TS = torch.empty(S, 1, M, C, dtype=F32, device=X.device)
+        copy2d(TS[0, 0], X)
+        _stack_fwd(g, TS, 0, K, Nn)
+        Wc = Wst.contiguous()
+        out = torch.empty(M, O, dtype=F32, device=X.device)
+        gemm(TS, C, M * C, S, C, Wc, O, 1, out, O, 0, O, bias, M, O)
+        ctx.g, ctx.K, ctx.B = g, K, B
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(TS, Wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dH):
+        TS, Wc = ctx.saved_tensors
+        g, K = ctx.g, ctx.K
+        S, _, M, C = TS.shape
+        O = Wc.size(1)
+        dH = dH.contiguous()
+        dX = dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW = torch.zeros_like(Wc)
+            db = torch.zeros(O, dtype=F32, device=dH.device) if ctx.has_bias else None
+            gemm_tn_acc(TS, C, M * C, S, C, dH, O, dW, O, db, M, O)
+        if ctx.needs_input_grad[0]:
+            G = torch.empty(S, M, C, dtype=F32, device=dH.device)
+            gemm(dH, O, 0, 1, O, Wc, 1, O, G, C, M * C, C, None, M, S * C)
+            _stack_bwd(g, G, K, g.N)
+            dX = G[0]
+        return dX, dW, db, None, None, None
+
+
+# --------------------------------------------------------------------------------------------- DCRNN sequence
+
+def _gru_zr(pre_zr, H, xhr, f_in):
+    lib = _lib.get_lib()
+    M, O2 = pre_zr.shape
+    hp, ldh = _rows(H, "H")
+    xp, ldx = _rows(xhr, "xhr")
+    lib.call("pgt_gru_zr_f32", ptr(pre_zr), hp, ldh, xp, ldx, f_in, M, O2 // 2, stream_of(lib, pre_zr))
+
+
+def _gru_h(pre_h, zr, H, out0):
+    lib = _lib.get_lib()
+    M, O = pre_h.shape
+    hp, ldh = _rows(H, "H")
+    op, ld0 = _rows(out0, "out0")
+    lib.call("pgt_gru_h_f32", ptr(pre_h), ptr(zr), hp, ldh, op, ld0, ptr(None), 0, M, O, stream_of(lib, pre_h))
+
+
+def _gru_h_bwd(dHn, zr, H, ht, d_pre_h, d_pre_zr, dH, accumulate):
+    lib = _lib.get_lib()
+    M, O = ht.shape
+    gp, ldg = _rows(dHn, "dHn")
+    hp, ldh = _rows(H, "H")
+    dp, ldd = _rows(dH, "dH")
+    lib.call("pgt_gru_h_bwd_f32", gp, ldg, ptr(zr), hp, ldh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp, ldd,
+             int(bool(accumulate)), M, O, stream_of(lib, ht))
+
+
+def _gru_zr_bwd(dxhr, f_in, zr, H, d_pre_zr, dH):
+    lib = _lib.get_lib()
+    M, O2 = zr.shape
+    xp, ldx = _rows(dxhr, "dxhr")
+    hp, ldh = _rows(H, "H")
+    dp, ldd = _rows(dH, "dH")
+    lib.call("pgt_gru_zr_bwd_f32", xp, ldx, f_in, ptr(zr), hp, ldh, ptr(d_pre_zr), dp, ldd, M, O2 // 2,
+             stream_of(lib, zr))
+
+
+class DCRNNSeqFunction(torch.autograd.Function):
+    """T steps of the DCRNN GRU cell (dcrnn.py:172-219 / :406-475) on node-major rows m = n*B + b.
+
+    X [T, M, F_in], H0 [M, O] -> Hall [T, M, O].  Per step: [X_t, H] -> diffusion stack -> one MFMA GEMM for the
+    update and reset gates together (the reference aggregates [X,H] twice) -> sigmoid / H*R -> stack -> GEMM ->
+    tanh / blend.  Backward is hand-written BPTT on the transposed operators; the weight gradients of all T steps
+    are one split-K GEMM over the saved stacks.
+    """
+
+    @staticmethod
+    def forward(ctx, X, H0, Wzr, bzr, Wh, bh, g, K, B):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        check_tensor(lib, H0, "H0")
+        X = X.contiguous()
+        T, M, Fin = X.shape
+        O = Wh.size(1)
+        C = Fin + O
+        S = 2 * K - 1
+        Nn = g.N
+        if M != Nn * B:
+            raise ValueError(f"X has {M} rows per step, expected num_nodes*B = {Nn * B}")
+        if Wzr.shape != (S * C, 2 * O) or Wh.shape != (S * C, O) or H0.shape != (M, O):
+            raise ValueError("DCRNNSeqFunction: inconsistent operand shapes")
+        dev = X.device
+        Wzr_c, Wh_c = Wzr.contiguous(), Wh.contiguous()
+        TSzr = torch.empty(S, T, M, C, dtype=F32, device=dev)
+        TSh = torch.empty(S, T, M, C, dtype=F32, device=dev)
+        ZR = torch.empty(T, M, 2 * O, dtype=F32, device=dev)
+        HT = torch.empty(T, M, O, dtype=F32, device=dev)
+        Hout = torch.empty(T, M, O, dtype=F32, device=dev)
+        H0c = H0.contiguous()
+        seg = T * M * C
+        for t in range(T):
+            Xt, Hp = X[t], (H0c if t == 0 else Hout[t - 1])
+            copy2d(TSzr[0, t][:, :Fin], Xt)
+            copy2d(TSzr[0, t][:, Fin:], Hp)
+            _stack_fwd(g, TSzr, t, K, Nn)
+            gemm(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, ZR[t], 2 * O, 0, 2 * O, bzr, M, 2 * O)
+            copy2d(TSh[0, t][:, :Fin], Xt)
+            _gru_zr(ZR[t], Hp, TSh[0, t], Fin)
+            _stack_fwd(g, TSh, t, K, Nn)
+            gemm(TSh[0, t], C, seg, S, C, Wh_c, O, 1, HT[t], O, 0, O, bh, M, O)
+            _gru_h(HT[t], ZR[t], Hp, Hout[t])
+        ctx.g, ctx.K, ctx.B, ctx.Fin = g, K, B, Fin
+        ctx.has_bias = (bzr is not None, bh is not None)
+        ctx.save_for_backward(TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c)
+        return Hout
+
+    @staticmethod
+    def backward(ctx, dOut):
+        TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c = ctx.saved_tensors
+        g, K, Fin = ctx.g, ctx.K, ctx.Fin
+        S, T, M, C = TSzr.shape
+        O = HT.size(2)
+        Nn = g.N
+        dev = dOut.device
+        dOut = dOut.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        dX = torch.zeros(T, M, Fin, dtype=F32, device=dev) if need_x else None
+        dH = torch.zeros(M, O, dtype=F32, device=dev)      # running d/dH_t
+        dHn = torch.empty(M, O, dtype=F32, device=dev)
+        dPzr = torch.empty(T, M, 2 * O, dtype=F32, device=dev)
+        dPh = torch.empty(T, M, O, dtype=F32, device=dev)
+        G = torch.empty(S, M, C, dtype=F32, device=dev)
+        for t in range(T - 1, -1, -1):
+            Hp = H0c if t == 0 else Hout[t - 1]
+            # dHn = dOut[t] + dH
+            axpby2d(dHn, dOut[t], 1.0, dH, 1.0)
+            _gru_h_bwd(dHn, ZR[t], Hp, HT[t], dPh[t], dPzr[t], dH, accumulate=False)
+            # candidate conv: dT = dPh Wh^T ; adjoint of the stack
+            gemm(dPh[t], O, 0, 1, O, Wh_c, 1, O, G, C, M * C, C, None, M, S * C)
+            _stack_bwd(g, G, K, Nn)
+            _gru_zr_bwd(G[0], Fin, ZR[t], Hp, dPzr[t], dH)
+            if need_x:
+                copy2d(dX[t], G[0][:, :Fin])
+            # gate convs
+            gemm(dPzr[t], 2 * O, 0, 1, 2 * O, Wzr_c, 1, 2 * O, G, C, M * C, C, None, M, S * C)
+            _stack_bwd(g, G, K, Nn)
+            add2d(dH, G[0][:, Fin:])
+            if need_x:
+                add2d(dX[t], G[0][:, :Fin])
+        dWzr = dbzr = dWh = dbh = None
+        seg = T * M * C
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dWzr = torch.zeros_like(Wzr_c)
+            dbzr = torch.zeros(2 * O, dtype=F32, device=dev) if ctx.has_bias[0] else None
+            gemm_tn_acc(TSzr, C, seg, S, C, dPzr, 2 * O, dWzr, 2 * O, dbzr, T * M, 2 * O)
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            dWh = torch.zeros_like(Wh_c)
+            dbh = torch.zeros(O, dtype=F32, device=dev) if ctx.has_bias[1] else None
+            gemm_tn_acc(TSh, C, seg, S, C, dPh, O, dWh, O, dbh, T * M, O)
+        dH0 = dH if ctx.needs_input_grad[1] else None
+        return dX, dH0, dWzr, dbzr, dWh, dbh, None, None, None

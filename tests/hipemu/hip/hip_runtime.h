@@ -1,0 +1,269 @@
+// TEST INFRASTRUCTURE ONLY — a tiny single-process "HIP on CPU" double so the kernel sources under
+// pytorch_geometric_temporal_amd/csrc can be exercised by the `-m "not gpu"` test-suite in a container
+// that has no GPU.  It is compiled only into tests/_emu/libpgt_emu.so; the product never loads it.
+//
+// Model: one block at a time; every GPU thread of the block is a ucontext fiber scheduled round-robin.
+// __syncthreads() and the wave collectives (__shfl*, MFMA) are rendezvous points implemented by yielding.
+// Wavefront = 64 lanes, as on gfx950.  MFMA lane maps follow cdna_hip_programming.md §3.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define PGT_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum { hipMemcpyDeviceToDevice = 3 };
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return 0; }
+
+namespace pgt_emu {
+
+struct Fiber {
+  ucontext_t ctx;
+  std::vector<char> stack;
+  bool done = false;
+  unsigned tid = 0;
+};
+
+struct State {
+  dim3 grid, block, bidx;
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  unsigned cur = 0;
+  unsigned nthreads = 0;
+  // block barrier
+  unsigned bar_count = 0;
+  unsigned long bar_gen = 0;
+  // wave rendezvous (per wave)
+  std::vector<unsigned> w_count;
+  std::vector<unsigned long> w_gen;
+  std::vector<uint64_t> w_slot;   // [wave][64] 8-byte exchange slots
+  std::vector<uint64_t> w_slot2;  // second slot set (MFMA b operand)
+  std::function<void()> body;
+};
+inline State& S() { static State s; return s; }
+
+inline void yield_() { State& s = S(); swapcontext(&s.fibers[s.cur].ctx, &s.sched); }
+
+inline void trampoline() {
+  State& s = S();
+  s.body();
+  s.fibers[s.cur].done = true;
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+inline unsigned live_threads_in_wave(unsigned wave) {
+  State& s = S();
+  unsigned lo = wave * 64, hi = std::min(lo + 64, s.nthreads), n = 0;
+  for (unsigned t = lo; t < hi; ++t) n += s.fibers[t].done ? 0 : 1;
+  return n;
+}
+
+inline unsigned live_threads_in_block() {
+  State& s = S();
+  unsigned n = 0;
+  for (unsigned t = 0; t < s.nthreads; ++t) n += s.fibers[t].done ? 0 : 1;
+  return n;
+}
+
+// Exited threads do not take part in barriers (as on the hardware, where finished waves drop out).
+inline void block_barrier() {
+  State& s = S();
+  unsigned long gen = s.bar_gen;
+  ++s.bar_count;
+  for (;;) {
+    if (s.bar_gen != gen) return;
+    if (s.bar_count >= live_threads_in_block()) { s.bar_count = 0; ++s.bar_gen; return; }
+    yield_();
+  }
+}
+
+inline void wave_barrier() {
+  State& s = S();
+  unsigned w = s.cur / 64;
+  unsigned long gen = s.w_gen[w];
+  ++s.w_count[w];
+  for (;;) {
+    if (s.w_gen[w] != gen) return;
+    if (s.w_count[w] >= live_threads_in_wave(w)) { s.w_count[w] = 0; ++s.w_gen[w]; return; }
+    yield_();
+  }
+}
+
+template <class F>
+inline void launch(dim3 grid, dim3 block, F&& f) {
+  State& s = S();
+  s.grid = grid; s.block = block;
+  s.nthreads = block.x * block.y * block.z;
+  if (s.nthreads == 0 || s.nthreads > 1024) { fprintf(stderr, "pgt_emu: bad block size\n"); abort(); }
+  unsigned nw = (s.nthreads + 63) / 64;
+  s.body = std::function<void()>(f);
+  const size_t STK = 256 * 1024;
+  if (s.fibers.size() < s.nthreads) s.fibers.resize(s.nthreads);
+  for (unsigned t = 0; t < s.nthreads; ++t) if (s.fibers[t].stack.size() != STK) s.fibers[t].stack.resize(STK);
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        s.bidx = dim3(bx, by, bz);
+        s.bar_count = 0;
+        s.w_count.assign(nw, 0); s.w_gen.assign(nw, 0);
+        s.w_slot.assign((size_t)nw * 64, 0); s.w_slot2.assign((size_t)nw * 64, 0);
+        for (unsigned t = 0; t < s.nthreads; ++t) {
+          Fiber& fb = s.fibers[t];
+          fb.done = false; fb.tid = t;
+          getcontext(&fb.ctx);
+          fb.ctx.uc_stack.ss_sp = fb.stack.data();
+          fb.ctx.uc_stack.ss_size = fb.stack.size();
+          fb.ctx.uc_link = nullptr;
+          makecontext(&fb.ctx, (void (*)())trampoline, 0);
+        }
+        unsigned remaining = s.nthreads;
+        while (remaining) {
+          remaining = 0;
+          for (unsigned t = 0; t < s.nthreads; ++t) {
+            if (s.fibers[t].done) continue;
+            s.cur = t;
+            swapcontext(&s.sched, &s.fibers[t].ctx);
+            if (!s.fibers[t].done) ++remaining;
+          }
+        }
+      }
+}
+
+struct TidProxy {
+  int which;  // 0 threadIdx 1 blockIdx 2 blockDim 3 gridDim
+  struct Comp {
+    int which, c;
+    operator unsigned() const {
+      State& s = S();
+      const dim3* d;
+      dim3 tmp;
+      if (which == 0) {
+        unsigned t = s.cur;
+        tmp.x = t % s.block.x; tmp.y = (t / s.block.x) % s.block.y; tmp.z = t / (s.block.x * s.block.y);
+        d = &tmp;
+      } else if (which == 1) d = &s.bidx;
+      else if (which == 2) d = &s.block;
+      else d = &s.grid;
+      return c == 0 ? d->x : (c == 1 ? d->y : d->z);
+    }
+  };
+  Comp x{0, 0}, y{0, 1}, z{0, 2};
+  explicit TidProxy(int w) : which(w) { x.which = y.which = z.which = w; }
+};
+
+template <class T> inline uint64_t to_bits(T v) { uint64_t b = 0; memcpy(&b, &v, sizeof(T)); return b; }
+template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
+
+template <class T>
+inline T shfl_generic(T v, int src_lane) {
+  State& s = S();
+  unsigned w = s.cur / 64, lane = s.cur % 64;
+  s.w_slot[w * 64 + lane] = to_bits(v);
+  wave_barrier();
+  T r = from_bits<T>(s.w_slot[w * 64 + (unsigned)(src_lane & 63)]);
+  wave_barrier();
+  return r;
+}
+
+}  // namespace pgt_emu
+
+static pgt_emu::TidProxy threadIdx(0), blockIdx(1), blockDim(2), gridDim(3);
+
+static inline void __syncthreads() { pgt_emu::block_barrier(); }
+static inline int __lane_id() { return (int)(pgt_emu::S().cur % 64); }
+
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+  int lane = __lane_id();
+  int base = lane & ~(width - 1);
+  return pgt_emu::shfl_generic(v, base + (src & (width - 1)));
+}
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+  int lane = __lane_id();
+  (void)width;
+  return pgt_emu::shfl_generic(v, lane ^ mask);
+}
+template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+  int lane = __lane_id();
+  int src = lane + (int)d;
+  if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+  return pgt_emu::shfl_generic(v, src);
+}
+static inline unsigned long long __ballot(int pred) {
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) {
+    int p = pgt_emu::shfl_generic(pred ? 1 : 0, l);
+    if (p) m |= (1ull << l);
+  }
+  return m;
+}
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+
+// --- MFMA emulation (lane maps: cdna_hip_programming.md §3) -------------------------------------------
+struct pgt_emu_f32x16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+struct pgt_emu_f32x4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+static inline pgt_emu_f32x16 pgt_emu_mfma_32x32x2(float a, float b, pgt_emu_f32x16 c) {
+  pgt_emu::State& s = pgt_emu::S();
+  unsigned w = s.cur / 64, lane = s.cur % 64;
+  s.w_slot[w * 64 + lane] = pgt_emu::to_bits(a);
+  s.w_slot2[w * 64 + lane] = pgt_emu::to_bits(b);
+  pgt_emu::wave_barrier();
+  int col = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      float av = pgt_emu::from_bits<float>(s.w_slot[w * 64 + row + 32 * k]);
+      float bv = pgt_emu::from_bits<float>(s.w_slot2[w * 64 + col + 32 * k]);
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  pgt_emu::wave_barrier();
+  return c;
+}
+
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }

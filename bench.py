@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""bench.py — snapshot-edges aggregated per second on the METR-LA-shaped DCRNN training step (BASELINE.json
+configs[1]) on N MI355X GPUs of one node, one process per GPU (RCCL), plus the live roofline of the dominant kernel
+and the CPU oracle timed on the same host.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch: forward of BatchedDCRNN over B windows x 12 steps, masked-MAE
+loss, backward (hand-written BPTT on the transposed operators), one flat gradient all-reduce, Adam.
+snapshot-edges/s = sum over processed samples of T * E / wall time (SURVEY.md §8 d); inputs are resident in HBM
+("GPU-index-batching", dataset/metr_la.py:180-190) when the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pytorch_geometric_temporal_amd import _lib, ops  # noqa: E402
+from pytorch_geometric_temporal_amd.dataset import synthetic as syn  # noqa: E402
+from pytorch_geometric_temporal_amd.nn.recurrent import BatchedDCRNN  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, exact fp32
+
+N_NODES, N_EDGES, SEQ = 207, 1515, 12
+MEAN, STD = 54.0, 19.5       # METR-LA-like speed statistics used to de-normalise inside the loss
+
+
+def masked_mae_loss(y_pred, y_true):
+    """examples/indexBatching/DCRNN/utils.py:10-18 (torch plumbing around the path, not part of it)."""
+    mask = (y_true != 0).float()
+    mask = mask / mask.mean()
+    loss = torch.abs(y_pred - y_true) * mask
+    loss = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)
+    return loss.mean()
+
+
+class Model(torch.nn.Module):
+    def __init__(self, hidden):
+        super().__init__()
+        self.rnn = BatchedDCRNN(2, hidden, K=3)
+        self.head = None if hidden == 2 else torch.nn.Linear(hidden, 2)
+
+    def forward(self, X, ei, ew):
+        h = self.rnn(X, ei, ew)
+        return h if self.head is None else self.head(h)
+
+
+class FlatGrads:
+    """All gradients live in one contiguous buffer -> exactly one RCCL all-reduce per step (0.6 - 305 KB message:
+    latency-bound, so one call instead of DDP's bucket machinery)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, world):
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / world)
+
+
+def make_batches(series, batch, n_batches, seed, device):
+    rng = np.random.default_rng(seed)
+    T_total = series.shape[0]
+    ar = torch.arange(SEQ, device=device)
+    out = []
+    for _ in range(n_batches):
+        idx = torch.from_numpy(rng.integers(0, T_total - 2 * SEQ, size=batch)).to(device)
+        out.append((idx[:, None] + ar[None, :], idx[:, None] + SEQ + ar[None, :]))
+    return out
+
+
+def cpu_baseline(hidden, target_seconds=12.0):
+    """The CPU oracle (op-for-op the reference: graph prep every conv call, 3 convs per step, gather -> mul ->
+    index_add_ -> matmul) on a bounded sample of the same workload, all host cores."""
+    from oracle import functional as F
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ei_np, ew_np = syn.sensor_graph(N_NODES, N_EDGES, seed=0, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    torch.manual_seed(0)
+    m = Model(hidden)
+    params = {k[len("rnn."):]: v for k, v in m.named_parameters() if k.startswith("rnn.")}
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    Bc = 64
+    series = torch.from_numpy(syn.traffic_series(2000, N_NODES, seed=1))
+
+    def one_step(i):
+        g = torch.Generator().manual_seed(i)
+        idx = torch.randint(0, 2000 - 2 * SEQ, (Bc,), generator=g)
+        ar = torch.arange(SEQ)
+        X, y = series[idx[:, None] + ar], series[idx[:, None] + SEQ + ar]
+        out = F.batched_dcrnn(X, ei, ew, params)
+        if m.head is not None:
+            out = m.head(out)
+        loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    one_step(0)
+    t0 = time.perf_counter()
+    one_step(1)
+    per = time.perf_counter() - t0
+    reps = int(max(2, min(200, target_seconds / max(per, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(reps):
+        one_step(2 + i)
+    dt = time.perf_counter() - t0
+    return {"value": reps * Bc * SEQ * N_EDGES / dt, "unit": "snapshot-edges/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} training steps of the same model on {Bc} windows x {SEQ} steps (oracle/functional.py, "
+                      f"fp32, torch.set_num_threads({cores})), {dt:.1f} s"}
+
+
+def spmm_roofline_ns(device, launches=50):
+    """North-star micro-benchmark: one diffusion-conv aggregation Y = P_o X at N = 200 000, F = 64, in-degree 8."""
+    res = {}
+    for name, gen in (("local", syn.local_graph), ("uniform", syn.uniform_graph)):
+        ei_np, ew_np = gen(200_000, 8, seed=0)
+        g = ops.DConvGraph(torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device), 200_000)
+        X = torch.randn(200_000, 64, device=device)
+        Y = torch.empty_like(X)
+        for _ in range(10):
+            ops.spmm(g.fwd_o, X, Y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            ops.spmm(g.fwd_o, X, Y)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / launches
+        nbytes = ops.spmm_algorithmic_bytes(200_000, g.E, 64, False)
+        res[name] = {"us_per_launch": us, "algorithmic_MB": nbytes / 1e6, "achieved_GBs": nbytes / us / 1e3,
+                     "frac": nbytes / us / 1e3 / HBM_PEAK_GBS, "edges": int(g.E)}
+        del g, X, Y
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step (weak scaling)")
+    ap.add_argument("--hidden", type=int, default=64, help="DCRNN hidden width (2 = the reference example's model)")
+    ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline figures")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ns", action="store_true", help="skip the N=200k F=64 aggregation micro-benchmark")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    lib = _lib.get_lib()
+    assert lib.target == "gfx950"
+
+    ei_np, ew_np = syn.sensor_graph(N_NODES, N_EDGES, seed=0, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device)
+    series = torch.from_numpy(syn.traffic_series(34272, N_NODES, seed=1)).to(device)   # resident [T, N, 2]
+    torch.manual_seed(0)
+    model = Model(args.hidden).to(device)
+    flat = FlatGrads(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    n_total = args.warmup + args.steps + args.profile_steps
+    batches = make_batches(series, args.batch, n_total, seed=1000 + rank, device=device)
+
+    def step(i):
+        xi, yi = batches[i]
+        X, y = series[xi], series[yi]                       # [B, 12, N, 2] windows gathered from the resident array
+        out = model(X, ei, ew)
+        loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
+        flat.zero()
+        loss.backward()
+        flat.all_reduce_mean(world)
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        loss = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(loss)
+
+    # ---- live roofline of the path's kernels: extra instrumented steps, HIP events on the launch stream
+    roof, kernels = None, None
+    if rank == 0 and args.profile_steps > 0:
+        ops.KERNEL_TIMER = ops.KernelTimer()
+        for i in range(args.warmup + args.steps, n_total):
+            step(i)
+        kernels = ops.KERNEL_TIMER.summary()
+        ops.KERNEL_TIMER = None
+        dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+        k = kernels[dom]
+        if dom == "spmm":
+            ach = k["work_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
+            roof = {"kernel": "spmm_wide_kernel<4> (pgt_spmm_csr_f32)", "bound": "hbm", "achieved": ach,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        else:
+            ach = k["work_per_launch"] / (k["avg_us"] * 1e-6) / 1e12
+            roof = {"kernel": {"gemm": "gemm_kernel (pgt_gemm_f32)", "gemm_tn": "gemm_tn_kernel (pgt_gemm_tn_acc_f32)"}[dom],
+                    "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+        roof["avg_us_per_launch"] = k["avg_us"]
+        roof["launches_per_step"] = k["launches"] / args.profile_steps
+        for kk, v in kernels.items():
+            if kk == "spmm":
+                v["achieved_GBs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
+                v["hbm_frac"] = v["achieved_GBs"] / HBM_PEAK_GBS
+            else:
+                v["achieved_TFLOPs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e12
+                v["mfma_frac"] = v["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS
+
+    ns = None
+    if rank == 0 and world == 1 and not args.no_ns:
+        ns = spmm_roofline_ns(device)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.hidden)
+
+    if rank == 0:
+        edges_per_step = world * args.batch * SEQ * N_EDGES
+        line = {
+            "metric": "snapshot-edges aggregated/sec",
+            "value": edges_per_step * args.steps / dt,
+            "unit": "snapshot-edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"METR-LA-shaped synthetic (207 nodes, 1515 edges, 12-step) BatchedDCRNN(2,{args.hidden},K=3)"
+                                   + ("" if args.hidden == 2 else "+Linear") + " training step (fwd+bwd+allreduce+Adam)",
+                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "seq_len": SEQ,
+                       "parallelism": f"dp{world}", "hidden": args.hidden, "K": 3},
+            "epoch_time_s_23974_windows": 23974.0 / (world * args.batch) * dt / args.steps,
+            "final_loss": final_loss,
+            "roofline": roof, "kernels": kernels, "roofline_ns_spmm_N200k_F64": ns, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

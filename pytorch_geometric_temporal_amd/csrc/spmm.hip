@@ -145,10 +145,22 @@ template <int VEC>
 __global__ __launch_bounds__(256) void spmm_wide_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     int n_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy, const float* T,
-    int64_t ldt, float alpha, float beta, int F, int nchunks) {
+    int64_t ldt, float alpha, float beta, int F, int nchunks, int nrowgroups, int xcd_map) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int chunk = (int)(blockIdx.x % (unsigned)nchunks);
-  const int row = (int)(blockIdx.x / (unsigned)nchunks) * 4 + wave;
+  int chunk, rowgroup;
+  if (xcd_map) {
+    // XCD x (= blockIdx % 8 on MI355X) owns the column chunks c = 8*j + x and sweeps ALL rows of one chunk before
+    // moving to the next: the 64*VEC-float column slab of X it gathers from (n_rows KiB at VEC = 4) stays in that
+    // XCD's private L2, so every neighbour re-read after the first is an L2 hit and HBM sees X exactly once.
+    const int x = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3);
+    chunk = (local / nrowgroups) * 8 + x;
+    rowgroup = local % nrowgroups;
+    if (chunk >= nchunks) return;
+  } else {
+    chunk = (int)(blockIdx.x % (unsigned)nchunks);
+    rowgroup = (int)(blockIdx.x / (unsigned)nchunks);
+  }
+  const int row = rowgroup * 4 + wave;
   if (row >= n_rows) return;
   const int f = (chunk * 64 + lane) * VEC;
   if (f >= F) return;
@@ -238,11 +250,13 @@ int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, int
 #undef PGT_SPMM_CASE
   } else {
     const int nchunks = (int)pgt_cdiv(Fv, 64);
-    const int64_t nblocks = pgt_cdiv(n_rows, 4) * nchunks;
+    const int nrowgroups = (int)pgt_cdiv(n_rows, 4);
+    const int xcd_map = nchunks >= 16 ? 1 : 0;
+    const int64_t nblocks = (int64_t)nrowgroups * (xcd_map ? pgt_cdiv(nchunks, 8) * 8 : nchunks);
     PGT_REQUIRE(nblocks < (int64_t)1 << 31, "pgt_spmm_csr_f32: grid too large");
     dim3 grid((unsigned)nblocks), block(256);
     PGT_LAUNCH((spmm_wide_kernel<VEC>), grid, block, stream, rowptr, col, val, n, X, ldx, Y, ldy, T, ldt, alpha,
-               beta, Fi, nchunks);
+               beta, Fi, nchunks, nrowgroups, xcd_map);
   }
   return pgt_check_launch("pgt_spmm_csr_f32");
 }

@@ -1,0 +1,100 @@
+"""Seeded synthetic graphs / signals with the shapes of the reference's datasets (there is no network here):
+METR-LA (207 nodes; 1 515 edges per BASELINE.json, 1 722 in the reference's data, test/dataset_test.py:397),
+PeMS-BAY (325 / 2 694, test/dataset_test.py:419), plus the large roofline graphs of SURVEY.md §8(d).
+All generators are numpy-only and deterministic in `seed`.  edge_index follows the reference's convention:
+int64 [2, E], row = source, col = target, sorted row-major as dense_to_sparse yields (dataset/metr_la.py:91-96).
+"""
+import numpy as np
+
+
+def _row_major(src, dst, w):
+    order = np.lexsort((dst, src))
+    return np.stack([src[order], dst[order]]).astype(np.int64), w[order].astype(np.float32)
+
+
+def sensor_graph(num_nodes=207, num_edges=1515, seed=0, symmetric=False):
+    """Thresholded-Gaussian-kernel k-NN adjacency on random 2-D sensor coordinates (the DCRNN recipe), unit
+    diagonal included (real METR-LA/PeMS adjacencies have one; it also keeps every in-degree > 0 so DConv stays
+    finite).  `symmetric=True` gives a structurally symmetric pattern (reverse list positionally aligned);
+    False gives a directed pattern that exercises DConv's positional norm_in quirk."""
+    rng = np.random.default_rng(seed)
+    n = int(num_nodes)
+    m = int(num_edges) - n
+    if m < 0:
+        raise ValueError("num_edges must be at least num_nodes (self-loops)")
+    xy = rng.random((n, 2))
+    d2 = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)
+    sigma2 = np.median(np.sort(d2, axis=1)[:, 1:9])
+    wfull = np.exp(-d2 / sigma2)
+    np.fill_diagonal(wfull, -1.0)
+    if symmetric:
+        if m % 2:
+            raise ValueError("symmetric pattern needs an even number of off-diagonal edges")
+        iu = np.triu_indices(n, 1)
+        pick = np.argsort(-wfull[iu], kind="stable")[: m // 2]
+        a, b = iu[0][pick], iu[1][pick]
+        src, dst = np.concatenate([a, b]), np.concatenate([b, a])
+        # direction-dependent weights (one-way streets): pattern symmetric, values not
+        w = wfull[src, dst] * (0.75 + 0.5 * rng.random(src.size))
+    else:
+        noisy = wfull * (0.6 + 0.8 * rng.random((n, n)))
+        np.fill_diagonal(noisy, -1.0)
+        flat = np.argsort(-noisy, axis=None, kind="stable")[:m]
+        src, dst = np.unravel_index(flat, (n, n))
+        w = wfull[src, dst]
+    loops = np.arange(n)
+    src = np.concatenate([src, loops])
+    dst = np.concatenate([dst, loops])
+    w = np.concatenate([w, np.ones(n)])
+    return _row_major(src, dst, w)
+
+
+def watts_strogatz_directed(num_nodes=100, k=10, p=0.5, seed=0):
+    """The reference tests' mock graph (test/recurrent_test.py:16-23): networkx.watts_strogatz_graph(...).edges(),
+    every undirected edge listed once -> a directed, asymmetric list with zero-in-degree nodes (DConv then emits
+    inf/nan, which the parity tests must reproduce)."""
+    import networkx as nx
+    g = nx.watts_strogatz_graph(int(num_nodes), int(k), float(p), seed=int(seed))
+    e = np.array(list(g.edges()), dtype=np.int64).T
+    return e
+
+
+def local_graph(num_nodes=200_000, degree=8, window=64, seed=0):
+    """Locality-ordered graph: every node draws `degree` distinct in-neighbours within +-window/2 positions
+    (what a bandwidth-reducing ordering of a road network looks like).  E = num_nodes * degree exactly."""
+    rng = np.random.default_rng(seed)
+    n, d = int(num_nodes), int(degree)
+    offs_all = np.concatenate([np.arange(-(window // 2), 0), np.arange(1, window // 2 + 1)])
+    pick = np.argsort(rng.random((n, offs_all.size)), axis=1)[:, :d]
+    offs = offs_all[pick]
+    dst = np.repeat(np.arange(n), d)
+    src = (dst + offs.reshape(-1)) % n
+    w = (0.5 + rng.random(src.size)).astype(np.float32)
+    return _row_major(src, dst, w)
+
+
+def uniform_graph(num_nodes=200_000, degree=8, seed=0):
+    """Uniform-random in-neighbours (no locality; worst case for the L2): `degree` random permutations, duplicates
+    removed, so E is within a few edges of num_nodes * degree."""
+    rng = np.random.default_rng(seed)
+    n, d = int(num_nodes), int(degree)
+    dst = np.tile(np.arange(n), d)
+    src = np.concatenate([rng.permutation(n) for _ in range(d)])
+    key = np.unique(src.astype(np.int64) * n + dst)
+    src, dst = key // n, key % n
+    w = (0.5 + rng.random(src.size)).astype(np.float32)
+    return _row_major(src, dst, w)
+
+
+def traffic_series(num_steps, num_nodes, seed=0):
+    """[T, N, 2] float32: z-scored AR(1) "speed" channel + time-of-day channel (layout of dataset/metr_la.py:143-176)."""
+    rng = np.random.default_rng(seed)
+    T, n = int(num_steps), int(num_nodes)
+    x = np.empty((T, n), dtype=np.float32)
+    x[0] = rng.standard_normal(n)
+    noise = rng.standard_normal((T, n)).astype(np.float32)
+    for t in range(1, T):
+        x[t] = 0.9 * x[t - 1] + 0.4359 * noise[t]
+    tod = ((np.arange(T) % 288) / 288.0).astype(np.float32)
+    out = np.stack([x, np.broadcast_to(tod[:, None], (T, n))], axis=-1)
+    return np.ascontiguousarray(out, dtype=np.float32)

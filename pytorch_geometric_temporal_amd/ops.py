@@ -163,6 +163,49 @@ def cheb_graph(edge_index, edge_weight, num_nodes, normalization="sym", lambda_m
                                             lambda_max=lam, variant=variant))
 
 
+# --------------------------------------------------------------------------------------------- kernel timer
+
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on (torch's
+    current stream is the stream handed to the C ABI).  Used by bench.py for the live roofline figures; disabled
+    (None) on the timed path."""
+
+    def __init__(self):
+        self.records = {}   # kind -> list of (start_event, end_event, work) ; work = algorithmic bytes or flops
+
+    def launch(self, kind, work, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.setdefault(kind, []).append((e0, e1, work))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[kind] = {"launches": len(recs), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms),
+                         "work_per_launch": sum(w for _, _, w in recs) / len(recs)}
+        return out
+
+
+KERNEL_TIMER = None
+
+
+def _timed(kind, work, fn):
+    if KERNEL_TIMER is None:
+        fn()
+    else:
+        KERNEL_TIMER.launch(kind, work, fn)
+
+
+def spmm_algorithmic_bytes(n_rows, nnz, F, with_t):
+    """int32 rowptr + int32 col + fp32 val + read X once + write Y once (+ read T)."""
+    return 4 * (n_rows + 1) + 8 * nnz + 4 * n_rows * F * (3 if with_t else 2)
+
+
 # --------------------------------------------------------------------------------------------- raw kernel calls
 
 def _rows(t, name):
@@ -182,8 +225,11 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0):
     xp, ldx = _rows(X, "X")
     yp, ldy = _rows(Y, "Y")
     tp, ldt = _rows(T, "T") if T is not None else (ptr(None), 0)
-    lib.call("pgt_spmm_csr_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,
-             float(alpha), float(beta), X.size(1), stream_of(lib, X))
+    st = stream_of(lib, X)
+    work = spmm_algorithmic_bytes(csr.n_rows, csr.col.numel(), X.size(1), T is not None) if KERNEL_TIMER else 0
+    _timed("spmm", work, lambda: lib.call(
+        "pgt_spmm_csr_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,
+        float(alpha), float(beta), X.size(1), st))
     return Y
 
 
@@ -195,8 +241,10 @@ def gemm(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, C, ldc, c_seg_stride,
         check_tensor(lib, t, n)
     if bias is not None:
         check_tensor(lib, bias, "bias")
-    lib.call("pgt_gemm_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(Bw), sbk, sbn, ptr(C), ldc, c_seg_stride,
-             c_seg_n, ptr(bias), M, N, int(bool(accumulate)), stream_of(lib, C))
+    st = stream_of(lib, C)
+    _timed("gemm", 2.0 * M * N * n_seg * seg_k, lambda: lib.call(
+        "pgt_gemm_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(Bw), sbk, sbn, ptr(C), ldc, c_seg_stride,
+        c_seg_n, ptr(bias), M, N, int(bool(accumulate)), st))
     return C
 
 
@@ -206,8 +254,9 @@ def gemm_tn_acc(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N):
         check_tensor(lib, t, n)
     if db is not None:
         check_tensor(lib, db, "db")
-    lib.call("pgt_gemm_tn_acc_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(G), ldg, ptr(dW), lddw, ptr(db), M, N,
-             stream_of(lib, G))
+    st = stream_of(lib, G)
+    _timed("gemm_tn", 2.0 * M * N * n_seg * seg_k, lambda: lib.call(
+        "pgt_gemm_tn_acc_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(G), ldg, ptr(dW), lddw, ptr(db), M, N, st))
     return dW
 
 

@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""GPU-box probe: kernel micro-benchmarks (HIP-event timed, back-to-back launches) dumped as JSON lines.
+Usage (through gpurun): python scripts/gpu_probe.py > gpurun_out/probe.jsonl"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pytorch_geometric_temporal_amd import ops  # noqa: E402
+from pytorch_geometric_temporal_amd.dataset import synthetic as syn  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, warm=10, reps=50):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps   # us
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def probe_copy():
+    n = 64 * 1024 * 1024
+    a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    us = timeit(lambda: b.copy_(a))
+    emit(probe="torch_copy_256MB", us=us, GBs=2 * 4 * n / us / 1e3)
+
+
+def probe_spmm_ns():
+    for name, gen in (("local", syn.local_graph), ("uniform", syn.uniform_graph)):
+        for deg in (8, 16):
+            ei, ew = gen(200_000, deg, seed=0)
+            g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), 200_000)
+            for F in (64, 32, 128):
+                X = torch.randn(200_000, F, device=dev)
+                Y = torch.empty_like(X)
+                us = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
+                nb = ops.spmm_algorithmic_bytes(200_000, g.E, F, False)
+                emit(probe="spmm_ns", graph=name, deg=deg, F=F, E=int(g.E), us=us, alg_MB=nb / 1e6,
+                     GBs=nb / us / 1e3, frac=nb / us / 1e3 / 8000)
+            del g
+
+
+def probe_spmm_batched():
+    ei, ew = syn.sensor_graph(207, 1515, seed=0)
+    g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), 207)
+    for B, C in ((64, 66), (256, 66), (1024, 66), (4096, 66), (1024, 4), (16384, 4), (65536, 4), (1024, 64)):
+        F = B * C
+        X = torch.randn(207, F, device=dev)
+        Y = torch.empty_like(X)
+        T = torch.randn(207, F, device=dev)
+        us = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
+        nb = ops.spmm_algorithmic_bytes(207, g.E, F, False)
+        us2 = timeit(lambda: ops.spmm(g.fwd_o, X, Y, T=T, alpha=2.0, beta=-1.0))
+        nb2 = ops.spmm_algorithmic_bytes(207, g.E, F, True)
+        emit(probe="spmm_metrla_nodemajor", B=B, C=C, us=us, alg_MB=nb / 1e6, GBs=nb / us / 1e3,
+             frac=nb / us / 1e3 / 8000, us_epi=us2, GBs_epi=nb2 / us2 / 1e3)
+        del X, Y, T
+
+
+def probe_gemm():
+    for M in (13248, 211968):
+        for (S, C, N) in ((5, 66, 128), (5, 66, 64), (1, 128, 330)):
+            A = torch.randn(S, M, C, device=dev)
+            W = torch.randn(S * C, N, device=dev)
+            b = torch.randn(N, device=dev)
+            out = torch.empty(M, N, device=dev)
+            us = timeit(lambda: ops.gemm(A, C, M * C, S, C, W, N, 1, out, N, 0, N, b, M, N), reps=20)
+            fl = 2.0 * M * N * S * C
+            emit(probe="gemm_nn", M=M, K=S * C, N=N, us=us, TFLOPs=fl / us / 1e6, frac=fl / us / 1e6 / 157.3)
+            A2 = torch.cat([A[j] for j in range(S)], 1).contiguous()
+            us_t = timeit(lambda: torch.addmm(b, A2, W), reps=20)
+            emit(probe="torch_addmm_same_shape", M=M, K=S * C, N=N, us=us_t, TFLOPs=fl / us_t / 1e6)
+            G = torch.randn(M, N, device=dev)
+            dW = torch.zeros(S * C, N, device=dev)
+            db = torch.zeros(N, device=dev)
+            us = timeit(lambda: ops.gemm_tn_acc(A, C, M * C, S, C, G, N, dW, N, db, M, N), reps=20)
+            emit(probe="gemm_tn", M=M, K=S * C, N=N, us=us, TFLOPs=fl / us / 1e6, frac=fl / us / 1e6 / 157.3)
+            Gs = torch.empty(S, M, C, device=dev)
+            us = timeit(lambda: ops.gemm(G, N, 0, 1, N, W, 1, N, Gs, C, M * C, C, None, M, S * C), reps=20)
+            emit(probe="gemm_nt", M=M, K=N, N=S * C, us=us, TFLOPs=fl / us / 1e6, frac=fl / us / 1e6 / 157.3)
+            del A, W, out, A2, G, dW, Gs
+
+
+def probe_prep():
+    for n, e in ((207, 1515), (50_000, 400_000), (200_000, 1_600_000)):
+        if n == 207:
+            ei, ew = syn.sensor_graph(n, e, seed=0)
+        else:
+            ei, ew = syn.local_graph(n, e // n, seed=0)
+        ei_t, ew_t = torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g = ops.DConvGraph(ei_t, ew_t, n)
+        torch.cuda.synchronize()
+        emit(probe="dconv_prep", N=n, E=int(ei.shape[1]), ms=1e3 * (time.perf_counter() - t0))
+        del g
+
+
+def probe_step():
+    from bench import Model, masked_mae_loss, FlatGrads, STD, MEAN
+    ei, ew = syn.sensor_graph(207, 1515, seed=0)
+    ei, ew = torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev)
+    for hidden in (64, 2):
+        for B in (64, 256, 1024, 4096):
+            if hidden == 64 and B > 2048:
+                continue
+            torch.manual_seed(0)
+            model = Model(hidden).to(dev)
+            flat = FlatGrads(model.parameters())
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            X = torch.randn(B, 12, 207, 2, device=dev)
+            y = torch.randn(B, 12, 207, 2, device=dev)
+
+            def step():
+                out = model(X, ei, ew)
+                loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
+                flat.zero()
+                loss.backward()
+                opt.step()
+
+            def fwd():
+                with torch.no_grad():
+                    model(X, ei, ew)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / 5
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fwd()
+            torch.cuda.synchronize()
+            ms_f = 1e3 * (time.perf_counter() - t0) / 5
+            emit(probe="dcrnn_train_step_eager", hidden=hidden, B=B, ms=ms, ms_fwd_only=ms_f,
+                 snapshot_edges_per_s=B * 12 * 1515 / ms * 1e3, mem_GB=torch.cuda.max_memory_allocated() / 1e9)
+            del model, flat, opt, X, y
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["copy", "spmm_ns", "spmm_batched", "gemm", "prep", "step"]
+    emit(device=torch.cuda.get_device_name(0), torch=torch.__version__, cpus=os.cpu_count())
+    for w in which:
+        try:
+            globals()["probe_" + w]()
+        except Exception as e:  # keep going: one broken probe must not hide the others
+            emit(probe=w, error=repr(e))

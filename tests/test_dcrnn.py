@@ -1,0 +1,141 @@
+"""DCRNN family through the drop-in modules: forward parity against the fixtures produced by
+the reference's own module files, forward + backward parity against the CPU oracle, API / state_dict compatibility."""
+import pytest
+import torch
+
+from conftest import assert_close_with_nonfinite, golden_names, load_golden
+from oracle import functional as F
+from pytorch_geometric_temporal_amd.dataset import synthetic as syn
+from pytorch_geometric_temporal_amd.nn.recurrent import DCRNN, BatchedDCRNN, BatchedDConv, DConv
+
+ATOL, RTOL = 1e-5, 1e-5   # north_star: "results match the reference PyG/CPU forward to 1e-5 fp32"
+
+
+def _load(module, params, device):
+    module.load_state_dict(params, strict=True)     # reference checkpoints load unchanged
+    return module.to(device)
+
+
+@pytest.mark.parametrize("name", golden_names("dcrnn_"))
+def test_dcrnn_forward_matches_reference_fixture(backend, name):
+    g = load_golden(name)
+    K = int(g["meta"]["K"])
+    X, H0, ei, ew = (backend.t(g["in"][k]) for k in ("X", "H0", "edge_index", "edge_weight"))
+    m = _load(DCRNN(X.size(1), H0.size(1), K), g["param"], backend.device)
+    with torch.no_grad():
+        assert_close_with_nonfinite(m(X, ei), g["out"]["H_noweight"], ATOL, RTOL, "no weight")
+        assert_close_with_nonfinite(m(X, ei, ew), g["out"]["H_weight"], ATOL, RTOL, "weight")
+        assert_close_with_nonfinite(m(X, ei, ew, H0), g["out"]["H_weight_hidden"], ATOL, RTOL, "weight+hidden")
+
+
+def test_dconv_and_batched_dconv_match_reference_fixture(backend):
+    g = load_golden("dconv_sensor_asym_K3")
+    X, ei, ew = (backend.t(g["in"][k]) for k in ("X", "edge_index", "edge_weight"))
+    for cls, key in ((DConv, "H"), (BatchedDConv, "H_batched")):
+        m = _load(cls(6, 10, 3), g["param"], backend.device)
+        with torch.no_grad():
+            assert_close_with_nonfinite(m(X, ei, ew), g["out"][key], ATOL, RTOL, cls.__name__)
+
+
+@pytest.mark.parametrize("name", golden_names("batched_dcrnn_"))
+def test_batched_dcrnn_forward_matches_reference_fixture(backend, name):
+    if backend.name == "emu" and "metrla" in name:
+        pytest.skip("METR-LA-sized fixture runs on the GPU leg only (the CPU test double is a fiber emulator)")
+    g = load_golden(name)
+    X, ei, ew = (backend.t(g["in"][k]) for k in ("X", "edge_index", "edge_weight"))
+    O = g["param"]["conv_x_z.weight"].shape[3]
+    m = _load(BatchedDCRNN(X.size(3), O, int(g["meta"]["K"])), g["param"], backend.device)
+    with torch.no_grad():
+        out = m(X, ei, ew)
+    assert out.shape == g["out"]["out"].shape
+    assert_close_with_nonfinite(out, g["out"]["out"], ATOL, RTOL, name)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3])
+def test_dcrnn_backward_matches_oracle_autograd(backend, K):
+    torch.manual_seed(K)
+    n, fin, O = 24, 3, 5
+    ei_np, ew_np = syn.sensor_graph(n, 150, seed=K, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    m = DCRNN(fin, O, K)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.5, 0.5)
+    params64 = {k: v.detach().double().requires_grad_() for k, v in m.state_dict().items()}
+    m = m.to(backend.device)
+    X, H = torch.randn(n, fin), torch.randn(n, O)
+    w = torch.randn(n, O)
+    Xd, Hd = backend.t(X).requires_grad_(), backend.t(H).requires_grad_()
+    out = m(Xd, backend.t(ei), backend.t(ew), Hd)
+    (out * backend.t(w)).sum().backward()
+    X64, H64 = X.double().requires_grad_(), H.double().requires_grad_()
+    ref = F.dcrnn_cell(X64, ei, ew.double(), H64, params64)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward")
+    assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+    assert_close_with_nonfinite(Hd.grad, H64.grad, 5e-5, 1e-4, "dH")
+    for name, p in m.named_parameters():
+        assert_close_with_nonfinite(p.grad, params64[name].grad, 1e-4, 1e-4, name)
+
+
+def test_batched_dcrnn_backward_matches_oracle_autograd(backend):
+    torch.manual_seed(0)
+    B, T, n, fin, O, K = 2, 3, 18, 2, 4, 3
+    ei_np, ew_np = syn.sensor_graph(n, 110, seed=9, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    m = BatchedDCRNN(fin, O, K)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.5, 0.5)
+    params64 = {k: v.detach().double().requires_grad_() for k, v in m.state_dict().items()}
+    m = m.to(backend.device)
+    X = torch.randn(B, T, n, fin)
+    w = torch.randn(B, T, n, O)
+    Xd = backend.t(X).requires_grad_()
+    out = m(Xd, backend.t(ei), backend.t(ew))
+    (out * backend.t(w)).sum().backward()
+    X64 = X.double().requires_grad_()
+    ref = F.batched_dcrnn(X64, ei, ew.double(), params64)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward")
+    assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+    for name, p in m.named_parameters():
+        assert_close_with_nonfinite(p.grad, params64[name].grad, 1e-4, 1e-4, name)
+
+
+def test_reference_api_surface(backend):
+    # constructor / attribute / parameter-name surface of dcrnn.py:21-37,128-160,343-361
+    m = DCRNN(in_channels=4, out_channels=8, K=2, bias=True)
+    assert (m.in_channels, m.out_channels, m.K, m.bias) == (4, 8, 2, True)
+    assert sorted(k for k, _ in m.named_parameters()) == sorted(
+        f"conv_x_{g}.{p}" for g in "zrh" for p in ("weight", "bias"))
+    assert m.conv_x_z.weight.shape == (2, 2, 12, 8) and m.conv_x_z.bias.shape == (8,)
+    assert float(m.conv_x_h.bias.abs().sum()) == 0.0          # zeros init (dcrnn.py:37)
+    with pytest.raises(AssertionError):
+        DConv(4, 8, 0)                                         # assert K > 0 (dcrnn.py:23)
+    b = BatchedDCRNN(2, 2, 3).to(backend.device)
+    ei_np, ew_np = syn.sensor_graph(12, 60, seed=1)
+    out = b(torch.zeros(2, 3, 12, 2, device=backend.device), backend.t(ei_np), backend.t(ew_np))
+    assert out.shape == (2, 3, 12, 2)
+    with pytest.raises(ValueError):
+        b(torch.zeros(2, 3, 12, 5, device=backend.device), backend.t(ei_np), backend.t(ew_np))
+
+
+def test_graph_prep_is_cached_by_identity_not_by_value(backend):
+    from pytorch_geometric_temporal_amd import ops
+    ei_np, ew_np = syn.sensor_graph(12, 60, seed=2)
+    ei, ew = backend.t(ei_np), backend.t(ew_np)
+    g1 = ops.dconv_graph(ei, ew, 12)
+    assert ops.dconv_graph(ei, ew, 12) is g1
+    ew.mul_(2.0)                                               # in-place edit bumps the version counter
+    assert ops.dconv_graph(ei, ew, 12) is not g1
+
+
+def test_no_cpu_fallback():
+    """A CPU tensor handed to the product path must raise, not silently compute somewhere else."""
+    from pytorch_geometric_temporal_amd import _lib
+    _lib._set_library_for_testing(None)
+    m = DCRNN(2, 3, 2)
+    ei_np, ew_np = syn.sensor_graph(10, 40, seed=3)
+    with pytest.raises(_lib.PgtError):
+        m(torch.zeros(10, 2), torch.from_numpy(ei_np), torch.from_numpy(ew_np))

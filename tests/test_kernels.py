@@ -1,0 +1,335 @@
+"""Per-kernel parity through the C ABI.  `backend` = "emu" (same kernel source on the CPU test double, runs in the
+`-m "not gpu"` suite) or "hip" (`-m gpu`, the product library on an MI355X).  fp32 tolerance: 1e-5 (north_star)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_with_nonfinite
+from oracle import functional as F
+from oracle import pyg_restated as P
+from pytorch_geometric_temporal_amd import _lib, ops
+from pytorch_geometric_temporal_amd.dataset import synthetic as syn
+
+ATOL, RTOL = 1e-5, 1e-5
+
+
+def csr_to_dense(csr, n, live_only=True):
+    rp, col, val = csr.rowptr.cpu().numpy(), csr.col.cpu().numpy(), csr.val.cpu().numpy()
+    A = np.zeros((n, n), dtype=np.float64)
+    for i in range(n):
+        for q in range(rp[i], rp[i + 1]):
+            A[i, col[q]] += val[q]
+    return torch.from_numpy(A)
+
+
+def dense_from_edges(ei, w, n, to_row=1):
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A.index_put_((ei[to_row], ei[1 - to_row]), w.double(), accumulate=True)
+    return A
+
+
+def random_csr(n, deg_lo, deg_hi, seed, device):
+    rng = np.random.default_rng(seed)
+    degs = rng.integers(deg_lo, deg_hi + 1, size=n)
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    col = rng.integers(0, n, size=rowptr[-1]).astype(np.int32)
+    val = rng.standard_normal(rowptr[-1]).astype(np.float32)
+    csr = ops.Csr.__new__(ops.Csr)
+    csr.n_rows = n
+    csr.rowptr = torch.from_numpy(rowptr).to(device)
+    csr.col = torch.from_numpy(col).to(device)
+    csr.val = torch.from_numpy(val).to(device)
+    return csr
+
+
+def spmm_reference(csr, X, T, alpha, beta):
+    rp, col, val = csr.rowptr.cpu().long(), csr.col.cpu().long(), csr.val.cpu()
+    rows = torch.repeat_interleave(torch.arange(csr.n_rows), rp[1:] - rp[:-1])
+    Xc = X.cpu().double()
+    out = torch.zeros_like(Xc).index_add_(0, rows, val.double().view(-1, 1) * Xc[col[: rows.numel()]])
+    out = alpha * out
+    if T is not None:
+        out = out + beta * T.cpu().double()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ SpMM
+
+@pytest.mark.parametrize("F_", [1, 2, 3, 4, 6, 8, 16, 33, 64, 66, 130, 256, 260, 1000])
+def test_spmm_feature_widths(backend, F_):
+    n = 150 if backend.name == "emu" else 3000
+    csr = random_csr(n, 0, 12, seed=F_, device=backend.device)
+    g = torch.Generator().manual_seed(F_)
+    X = torch.randn(n, F_, generator=g).to(backend.device)
+    T = torch.randn(n, F_, generator=g).to(backend.device)
+    Y = torch.full((n, F_), float("nan"), device=backend.device)
+    ops.spmm(csr, X, Y)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), ATOL, RTOL, f"F={F_}")
+    ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), ATOL, RTOL, f"F={F_} epilogue")
+    # in-place accumulate form used by the backward recursion (Y aliases T)
+    Tc = T.clone()
+    ops.spmm(csr, X, Tc, T=Tc, alpha=2.0, beta=1.0)
+    assert_close_with_nonfinite(Tc, spmm_reference(csr, X, T, 2.0, 1.0), ATOL, RTOL, f"F={F_} aliased")
+
+
+def test_spmm_strided_views_and_heavy_rows(backend):
+    n = 130 if backend.name == "emu" else 2000
+    csr = random_csr(n, 0, 6, seed=7, device=backend.device)
+    # one very heavy tile (> LDS staging capacity) and an empty tail
+    rp = csr.rowptr.cpu().numpy().copy()
+    extra = 2000
+    rng = np.random.default_rng(1)
+    col = np.concatenate([csr.col.cpu().numpy()[: rp[5]], rng.integers(0, n, extra).astype(np.int32),
+                          csr.col.cpu().numpy()[rp[5]:]])
+    val = np.concatenate([csr.val.cpu().numpy()[: rp[5]], rng.standard_normal(extra).astype(np.float32),
+                          csr.val.cpu().numpy()[rp[5]:]])
+    rp[6:] += extra
+    csr.rowptr, csr.col, csr.val = (torch.from_numpy(a).to(backend.device) for a in (rp, col, val))
+    big = torch.randn(n, 80).to(backend.device)
+    X = big[:, 8:72]            # 64 columns inside a wider buffer, 32-byte aligned start
+    out = torch.zeros(n, 100, device=backend.device)
+    Y = out[:, 4:68]
+    ops.spmm(csr, X, Y)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "strided")
+    assert float(out[:, :4].abs().max()) == 0.0 and float(out[:, 68:].abs().max()) == 0.0
+    X1 = big[:, 3:70]           # odd offset -> scalar path
+    Y1 = torch.zeros(n, 67, device=backend.device)
+    ops.spmm(csr, X1, Y1)
+    assert_close_with_nonfinite(Y1, spmm_reference(csr, X1, None, 1.0, 0.0), 5e-5, 1e-5, "unaligned")
+
+
+def test_spmm_empty_and_errors(backend):
+    csr = random_csr(10, 1, 3, seed=0, device=backend.device)
+    X = torch.randn(10, 4).to(backend.device)
+    with pytest.raises(_lib.PgtError):
+        ops.spmm(csr, X, X)                       # Y must not alias X
+    empty = random_csr(0, 0, 0, seed=0, device=backend.device)
+    ops.spmm(empty, X[:0], X[:0].clone())         # zero rows: no-op
+    lib = _lib.get_lib()
+    with pytest.raises(_lib.PgtError, match="negative"):
+        lib.call("pgt_spmm_csr_f32", None, None, None, -1, None, 0, None, 0, None, 0, 1.0, 0.0, 4, None)
+
+
+def test_spmm_propagates_inf_and_nan_like_index_add(backend):
+    csr = random_csr(20, 2, 4, seed=3, device=backend.device)
+    csr.val[0] = float("inf")
+    X = torch.randn(20, 8).to(backend.device)
+    X[int(csr.col[1]), 2] = 0.0
+    Y = torch.empty(20, 8, device=backend.device)
+    ops.spmm(csr, X, Y)
+    ref = spmm_reference(csr, X, None, 1.0, 0.0)
+    assert_close_with_nonfinite(Y, ref, ATOL, RTOL, "inf/nan")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+
+@pytest.mark.parametrize("M,segs,segk,N", [(70, 1, 5, 3), (64, 1, 32, 64), (129, 5, 66, 128), (200, 3, 7, 65),
+                                           (33, 2, 1, 2), (257, 1, 100, 40)])
+def test_gemm_segmented(backend, M, segs, segk, N):
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(segs, M, segk, generator=g)
+    W = torch.randn(segs * segk, N, generator=g)
+    b = torch.randn(N, generator=g)
+    ref = (torch.cat([A[j] for j in range(segs)], dim=1).double() @ W.double()) + b.double()
+    Ad, Wd, bd = A.to(backend.device), W.to(backend.device), b.to(backend.device)
+    C = torch.full((M, N), float("nan"), device=backend.device)
+    ops.gemm(Ad, segk, M * segk, segs, segk, Wd, N, 1, C, N, 0, N, bd, M, N)
+    assert_close_with_nonfinite(C, ref, 1e-4, 1e-5, "gemm NN")
+    ops.gemm(Ad, segk, M * segk, segs, segk, Wd, N, 1, C, N, 0, N, None, M, N, accumulate=True)
+    assert_close_with_nonfinite(C, 2 * ref - b.double(), 2e-4, 1e-5, "gemm accumulate")
+    # NT + segmented output: G[j] = dC @ W_j^T
+    dC = torch.randn(M, N, generator=g)
+    G = torch.full((segs, M, segk), float("nan"), device=backend.device)
+    ops.gemm(dC.to(backend.device), N, 0, 1, N, Wd, 1, N, G, segk, M * segk, segk, None, M, segs * segk)
+    refG = (dC.double() @ W.double().t()).view(M, segs, segk).permute(1, 0, 2)
+    assert_close_with_nonfinite(G, refG, 1e-4, 1e-5, "gemm NT segmented")
+
+
+@pytest.mark.parametrize("M,segs,segk,N", [(100, 1, 5, 3), (1000, 5, 66, 128), (333, 2, 33, 70), (64, 1, 64, 64)])
+def test_gemm_tn_weight_and_bias_gradient(backend, M, segs, segk, N):
+    if backend.name == "emu" and M > 500:
+        M = 300
+    g = torch.Generator().manual_seed(M + N + 1)
+    A = torch.randn(segs, M, segk, generator=g)
+    G = torch.randn(M, N, generator=g)
+    dW0 = torch.randn(segs * segk, N, generator=g)
+    db0 = torch.randn(N, generator=g)
+    refW = dW0.double() + torch.cat([A[j] for j in range(segs)], dim=1).double().t() @ G.double()
+    refb = db0.double() + G.double().sum(0)
+    dW, db = dW0.clone().to(backend.device), db0.clone().to(backend.device)
+    ops.gemm_tn_acc(A.to(backend.device), segk, M * segk, segs, segk, G.to(backend.device), N, dW, N, db, M, N)
+    assert_close_with_nonfinite(dW, refW, 2e-4, 1e-5, "dW")
+    assert_close_with_nonfinite(db, refb, 2e-4, 1e-5, "db")
+
+
+def test_gemm_is_exact_fp32_fma_chain(backend):
+    # v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain: integers up to 2^24 must be exact
+    A = torch.randint(-8, 9, (64, 64)).float()
+    W = torch.randint(-8, 9, (64, 64)).float()
+    C = torch.empty(64, 64, device=backend.device)
+    ops.gemm(A.to(backend.device), 64, 0, 1, 64, W.to(backend.device), 64, 1, C, 64, 0, 64, None, 64, 64)
+    assert torch.equal(C.cpu(), A @ W)
+    # asymmetric-B identity check (cdna_hip_programming.md §3: catches a transposed C write)
+    I = torch.eye(64)
+    B = torch.arange(64 * 64, dtype=torch.float32).view(64, 64)
+    ops.gemm(I.to(backend.device), 64, 0, 1, 64, B.to(backend.device), 64, 1, C, 64, 0, 64, None, 64, 64)
+    assert torch.equal(C.cpu(), B)
+
+
+# ------------------------------------------------------------------------------------------------ graph prep
+
+def _graphs():
+    yield "sensor_asym", syn.sensor_graph(45, 300, seed=1, symmetric=False)
+    yield "sensor_sym", syn.sensor_graph(45, 301, seed=2, symmetric=True)
+    e = syn.watts_strogatz_directed(40, 6, 0.5, seed=2)
+    yield "ws_directed", (e, (np.random.default_rng(0).random(e.shape[1]) + 0.05).astype(np.float32))
+
+
+@pytest.mark.parametrize("which", ["sensor_asym", "sensor_sym", "ws_directed"])
+def test_dconv_prep_matches_oracle_operators(backend, which):
+    ei_np, ew_np = dict(_graphs())[which]
+    n = int(ei_np.max()) + 1
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), n)
+    norm_out, norm_in, rev = F.dconv_norms_scatter(ei, ew, n)
+    Po = dense_from_edges(ei, norm_out, n)
+    Pi = dense_from_edges(rev, norm_in, n)
+    for name, csr, ref in (("fwd_o", g.fwd_o, Po), ("fwd_i", g.fwd_i, Pi), ("bwd_o", g.bwd_o, Po.t()),
+                           ("bwd_i", g.bwd_i, Pi.t())):
+        assert_close_with_nonfinite(csr_to_dense(csr, n), ref, 1e-6, 1e-6, f"{which}:{name}")
+    deg_out = torch.zeros(n).scatter_add_(0, ei[0], ew)
+    deg_in = torch.zeros(n).scatter_add_(0, ei[1], ew)
+    assert torch.equal(g.deg_out.cpu()[:n], deg_out), "deg_out must be bit-identical to scatter_add_ (edge order)"
+    assert torch.equal(g.deg_in.cpu()[:n], deg_in)
+    assert g.info.tolist()[:3] == [0, 0, 0]
+    # slot order inside a row = reference edge order (so the sequential row sum equals index_add_'s order)
+    rp, col = g.fwd_o.rowptr.cpu().numpy(), g.fwd_o.col.cpu().numpy()
+    for i in range(n):
+        expect = ei_np[0][ei_np[1] == i]
+        assert np.array_equal(col[rp[i]:rp[i + 1]], expect)
+
+
+def test_dconv_prep_flags_duplicates_zero_weights_and_bad_indices(backend):
+    ei = torch.tensor([[0, 0, 1, 2], [1, 1, 2, 0]])
+    ew = torch.tensor([1.0, 2.0, 0.0, 1.0])
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), 3, validate=False)
+    assert g.info.tolist()[:3] == [1, 1, 0]
+    with pytest.raises(RuntimeError, match="duplicate"):
+        ops.DConvGraph(backend.t(ei), backend.t(ew), 3, strict_dense=True)
+    with pytest.raises(IndexError):
+        ops.DConvGraph(backend.t(torch.tensor([[0, 5], [1, 0]])), None, 3)
+    empty = ops.DConvGraph(backend.t(torch.zeros(2, 0, dtype=torch.long)), None, 4)
+    assert empty.fwd_o.rowptr.tolist() == [0] * 5
+
+
+@pytest.mark.parametrize("improved,loops", [(False, True), (True, True), (False, False)])
+def test_gcn_prep_matches_gcn_norm(backend, improved, loops):
+    ei_np, ew_np = syn.sensor_graph(40, 260, seed=5, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    n = 40
+    g = ops.SymGraph("gcn", backend.t(ei), backend.t(ew), n, improved=improved, add_self_loops=loops)
+    ei2, w2 = P.gcn_norm(ei, ew, n, improved, loops)
+    A = dense_from_edges(ei2, w2, n)
+    assert_close_with_nonfinite(csr_to_dense(g.fwd, n), A, 1e-6, 1e-5, "gcn fwd")
+    assert_close_with_nonfinite(csr_to_dense(g.bwd, n), A.t(), 1e-6, 1e-5, "gcn bwd")
+    # unweighted input
+    g = ops.SymGraph("gcn", backend.t(ei), None, n, improved=False, add_self_loops=loops)
+    ei2, w2 = P.gcn_norm(ei, None, n, False, loops, dtype=torch.float32)
+    assert_close_with_nonfinite(csr_to_dense(g.fwd, n), dense_from_edges(ei2, w2, n), 1e-6, 1e-5, "gcn unweighted")
+
+
+@pytest.mark.parametrize("norm,lam", [("sym", None), ("rw", None), (None, None), ("rw", 2.3), (None, 3.1)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_cheb_prep_matches_scaled_laplacian(backend, norm, lam, variant):
+    ei_np, ew_np = syn.sensor_graph(36, 240, seed=6, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    n = 36
+    g = ops.SymGraph("cheb", backend.t(ei), backend.t(ew), n, normalization=norm, lambda_max=lam, variant=variant)
+    if variant == 0:
+        ei2, w2 = F.cheb_norm(ei, ew, n, norm, None if lam is None else torch.tensor(lam), torch.float32)
+        L = dense_from_edges(ei2, w2, n)                 # out[col] += norm * x[row]
+    else:
+        if lam is None and norm != "sym":
+            pytest.skip("ChebConvAttention requires lambda_max for non-sym normalisation (astgcn.py:135-139)")
+        ei1, w1 = P.remove_self_loops(ei, ew)
+        ei1, w1 = P.get_laplacian(ei1, w1, norm, torch.float32, n)
+        w1 = (2.0 * w1) / (2.0 if lam is None else lam)
+        w1.masked_fill_(w1 == float("inf"), 0)
+        ei1, w1 = P.add_self_loops(ei1, w1, fill_value=-1.0, num_nodes=n)
+        L = dense_from_edges(ei1, w1, n, to_row=0)       # transposed list: out[row] += norm * x[col]
+    assert_close_with_nonfinite(csr_to_dense(g.fwd, n), L, 2e-6, 1e-5, "cheb fwd")
+    assert_close_with_nonfinite(csr_to_dense(g.bwd, n), L.t(), 2e-6, 1e-5, "cheb bwd")
+
+
+# ------------------------------------------------------------------------------------------------ movers / gates
+
+def test_movers_and_swap(backend):
+    x = torch.randn(6, 5, 4)
+    y = ops.swap01(backend.t(x), 6, 5, 4)
+    assert torch.equal(y.cpu(), x.permute(1, 0, 2).contiguous())
+    a, b = torch.randn(7, 9), torch.randn(7, 9)
+    dst = torch.zeros(7, 12, device=backend.device)
+    ops.copy2d(dst[:, 2:11], backend.t(a))
+    assert torch.equal(dst[:, 2:11].cpu(), a) and float(dst[:, :2].abs().sum()) == 0
+    ops.add2d(dst[:, 2:11], backend.t(b))
+    assert torch.allclose(dst[:, 2:11].cpu(), a + b)
+    ops.axpby2d(dst[:, 2:11], backend.t(a), -1.0, dst[:, 2:11], 1.0)
+    assert torch.allclose(dst[:, 2:11].cpu(), b, atol=1e-6)
+
+
+def test_gru_gate_kernels_against_autograd(backend):
+    M, O, Fin = 37, 6, 3
+    g = torch.Generator().manual_seed(0)
+    pre_zr = torch.randn(M, 2 * O, generator=g)
+    pre_h = torch.randn(M, O, generator=g)
+    H = torch.randn(M, O, generator=g)
+    # forward
+    zr = pre_zr.clone().to(backend.device)
+    xhr = torch.zeros(M, Fin + O, device=backend.device)
+    ops._gru_zr(zr, backend.t(H), xhr, Fin)
+    Z, R = torch.sigmoid(pre_zr[:, :O]), torch.sigmoid(pre_zr[:, O:])
+    assert torch.allclose(zr.cpu(), torch.cat([Z, R], 1), atol=1e-6)
+    assert torch.allclose(xhr[:, Fin:].cpu(), H * R, atol=1e-6) and float(xhr[:, :Fin].abs().sum()) == 0
+    ht = pre_h.clone().to(backend.device)
+    Hn = torch.empty(M, O, device=backend.device)
+    ops._gru_h(ht, zr, backend.t(H), Hn)
+    assert torch.allclose(Hn.cpu(), Z * H + (1 - Z) * torch.tanh(pre_h), atol=1e-6)
+    # backward vs autograd
+    pz, ph, Hh = pre_zr.clone().requires_grad_(), pre_h.clone().requires_grad_(), H.clone().requires_grad_()
+    Z_, R_ = torch.sigmoid(pz[:, :O]), torch.sigmoid(pz[:, O:])
+    HR = Hh * R_
+    Hn_ = Z_ * Hh + (1 - Z_) * torch.tanh(ph)
+    dHn, dHR = torch.randn(M, O, generator=g), torch.randn(M, O, generator=g)
+    (Hn_ * dHn).sum().backward(retain_graph=True)
+    gz_h, gph, gH_h = pz.grad.clone(), ph.grad.clone(), Hh.grad.clone()
+    pz.grad = None; Hh.grad = None
+    (HR * dHR).sum().backward()
+    d_pre_h = torch.empty(M, O, device=backend.device)
+    d_pre_zr = torch.zeros(M, 2 * O, device=backend.device)
+    dH = torch.empty(M, O, device=backend.device)
+    ops._gru_h_bwd(backend.t(dHn), zr, backend.t(H), ht, d_pre_h, d_pre_zr, dH, accumulate=False)
+    assert torch.allclose(d_pre_h.cpu(), gph, atol=1e-5)
+    assert torch.allclose(d_pre_zr[:, :O].cpu(), gz_h[:, :O], atol=1e-5)
+    assert torch.allclose(dH.cpu(), gH_h, atol=1e-5)
+    dxhr = torch.zeros(M, Fin + O)
+    dxhr[:, Fin:] = dHR
+    ops._gru_zr_bwd(backend.t(dxhr), Fin, zr, backend.t(H), d_pre_zr, dH)
+    assert torch.allclose(d_pre_zr[:, O:].cpu(), pz.grad[:, O:], atol=1e-5)
+    assert torch.allclose(dH.cpu(), gH_h + Hh.grad, atol=1e-5)
+
+
+@pytest.mark.parametrize("F_", [4096 + 64, 16 * 256, 17 * 256 + 8, 1030])
+def test_spmm_wide_rows_xcd_chunk_mapping(backend, F_):
+    # node-major batches: F = B*C is thousands of floats; >= 16 chunks switches on the XCD-slab block mapping
+    n = 21 if backend.name == "emu" else 207
+    csr = random_csr(n, 0, 9, seed=F_, device=backend.device)
+    g = torch.Generator().manual_seed(F_)
+    X = torch.randn(n, F_, generator=g).to(backend.device)
+    T = torch.randn(n, F_, generator=g).to(backend.device)
+    Y = torch.full((n, F_), float("nan"), device=backend.device)
+    ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), ATOL, RTOL, f"wide F={F_}")

@@ -1,0 +1,87 @@
+"""Live check of the functional oracle against the reference's actual module files, on fresh random draws beyond
+the frozen fixtures.  Skipped where /root/reference is absent (the GPU box)."""
+import pytest
+import torch
+
+from conftest import assert_close_with_nonfinite
+from oracle import functional as F
+from oracle import ref_import as R
+from pytorch_geometric_temporal_amd.dataset import synthetic as syn
+
+pytestmark = pytest.mark.skipif(not R.reference_available(), reason="reference checkout not mounted")
+
+
+def _graph(n, e, seed, symmetric=False):
+    ei, ew = syn.sensor_graph(n, e, seed=seed, symmetric=symmetric)
+    return torch.from_numpy(ei), torch.from_numpy(ew)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_dcrnn_cell(K, seed):
+    m = R.load("nn.recurrent.dcrnn")
+    torch.manual_seed(seed)
+    ei, ew = _graph(30, 200, seed)
+    layer = m.DCRNN(3, 7, K)
+    X, H = torch.randn(30, 3), torch.randn(30, 7)
+    p = {k: v.detach() for k, v in layer.state_dict().items()}
+    with torch.no_grad():
+        assert_close_with_nonfinite(F.dcrnn_cell(X, ei, ew, H, p), layer(X, ei, ew, H), 1e-6, 1e-6)
+
+
+def test_dcrnn_cell_on_reference_mock_graph_with_nonfinite_values():
+    m = R.load("nn.recurrent.dcrnn")
+    torch.manual_seed(3)
+    ei = torch.from_numpy(syn.watts_strogatz_directed(50, 6, 0.5, seed=9))
+    ew = torch.rand(ei.size(1))
+    layer = m.DCRNN(5, 6, 3)
+    X = torch.rand(50, 5) * 2 - 1
+    p = {k: v.detach() for k, v in layer.state_dict().items()}
+    with torch.no_grad():
+        ref = layer(X, ei, ew)
+    assert not torch.isfinite(ref).all()
+    assert_close_with_nonfinite(F.dcrnn_cell(X, ei, ew, None, p), ref, 1e-6, 1e-6)
+
+
+def test_batched_dcrnn():
+    m = R.load("nn.recurrent.dcrnn")
+    torch.manual_seed(5)
+    ei, ew = _graph(20, 120, 6)
+    layer = m.BatchedDCRNN(2, 5, 3)
+    X = torch.randn(3, 4, 20, 2)
+    p = {k: v.detach() for k, v in layer.state_dict().items()}
+    with torch.no_grad():
+        assert_close_with_nonfinite(F.batched_dcrnn(X, ei, ew, p), layer(X, ei, ew), 1e-6, 1e-6)
+
+
+def test_tgcn_and_a3tgcn():
+    t = R.load("nn.recurrent.temporalgcn")
+    a = R.load("nn.recurrent.attentiontemporalgcn")
+    torch.manual_seed(7)
+    ei, ew = _graph(25, 150, 8)
+    layer = t.TGCN(3, 6)
+    X, H = torch.randn(25, 3), torch.randn(25, 6)
+    p = {k: v.detach() for k, v in layer.state_dict().items()}
+    with torch.no_grad():
+        assert_close_with_nonfinite(F.tgcn_cell(X, ei, ew, H, p), layer(X, ei, ew, H), 1e-6, 1e-6)
+    layer = a.A3TGCN2(3, 6, periods=4, batch_size=2)
+    with torch.no_grad():
+        layer._attention.uniform_()
+    X, H = torch.randn(2, 25, 3, 4), torch.randn(2, 25, 6)
+    p = {k: v.detach() for k, v in layer.state_dict().items()}
+    with torch.no_grad():
+        assert_close_with_nonfinite(F.a3tgcn(X, ei, ew, H, p), layer(X, ei, ew, H), 1e-6, 1e-6)
+
+
+def test_chebconv_matches_stub_module():
+    from oracle import pyg_restated as P
+    torch.manual_seed(9)
+    ei, ew = _graph(25, 150, 10)
+    for norm, lam in (("sym", None), ("rw", None), (None, 2.5)):
+        conv = P.ChebConv(4, 6, 3, normalization=norm)
+        x = torch.randn(25, 4)
+        with torch.no_grad():
+            ref = conv(x, ei, ew, lambda_max=lam)
+            out = F.cheb_conv(x, ei, ew, [l.weight for l in conv.lins], conv.bias, norm,
+                              None if lam is None else torch.tensor(lam))
+        assert_close_with_nonfinite(out, ref, 1e-6, 1e-6)

@@ -81,6 +81,10 @@ const char* pgt_last_error(void);
 /* "gfx950" for the product library; "emu" for the CPU test double built under tests/. */
 const char* pgt_build_target(void);
 
+/* Benchmark A/B knobs ("gemm_small_tiles", "spmm_xcd_map", "spmm_tile_xcd", ...); defaults are the shipped
+ * configuration.  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe. */
+int pgt_tune(const char* key, int value);
+
 /* ---------------------------------------------------------------- graph preparation */
 
 /* Scratch bytes needed by the *_prep calls for a graph with E edges and N nodes. */
@@ -152,11 +156,12 @@ int pgt_gru_zr_f32(float* pre_zr, const float* H, int64_t ldh, float* xhr, int64
  *   and, when out1 != NULL, also to out1 (row stride ld1). */
 int pgt_gru_h_f32(float* pre_h, const float* zr, const float* H, int64_t ldh, float* out0, int64_t ld0,
                   float* out1, int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream);
-/* backward of pgt_gru_h_f32: given dHnew, writes d_pre_h [M,O], d_pre_zr[:, 0:O] (update gate), and
- *   dH (=|+=) dHnew * Z  depending on accumulate_dh. */
-int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const float* zr, const float* H, int64_t ldh,
-                      const float* ht, float* d_pre_h, float* d_pre_zr, float* dH, int64_t lddhp,
-                      int accumulate_dh, int64_t M, int64_t O, pgt_stream_t stream);
+/* backward of pgt_gru_h_f32: given dHnew (+ dHnew2 when non-NULL: the output gradient and the running state
+ *   gradient are summed on the fly), writes d_pre_h [M,O], d_pre_zr[:, 0:O] (update gate), and
+ *   dH (=|+=) dHnew * Z  depending on accumulate_dh.  dH may alias dHnew2. */
+int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const float* dHnew2, int64_t lddh2, const float* zr,
+                      const float* H, int64_t ldh, const float* ht, float* d_pre_h, float* d_pre_zr, float* dH,
+                      int64_t lddhp, int accumulate_dh, int64_t M, int64_t O, pgt_stream_t stream);
 /* backward of pgt_gru_zr_f32: dxhr[:, f_in:] is d(H*R);  d_pre_zr[:, O:2O] = dHR*H*R*(1-R);  dH += dHR*R */
 int pgt_gru_zr_bwd_f32(const float* dxhr, int64_t lddxhr, int64_t f_in, const float* zr, const float* H,
                        int64_t ldh, float* d_pre_zr, float* dH, int64_t lddhp, int64_t M, int64_t O,

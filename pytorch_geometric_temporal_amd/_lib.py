@@ -47,6 +47,7 @@ PROTOTYPES = {
     "pgt_abi_version": (c_int, []),
     "pgt_last_error": (ctypes.c_char_p, []),
     "pgt_build_target": (ctypes.c_char_p, []),
+    "pgt_tune": (c_int, [ctypes.c_char_p, c_int]),
     "pgt_prep_workspace_bytes": (c_size, [c_i64, c_i64]),
     "pgt_dconv_prep": (c_int, [c_ptr, c_ptr, c_i64, c_i64, ctypes.POINTER(DConvGraphStruct), c_ptr, c_size, c_ptr]),
     "pgt_gcn_prep": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, ctypes.POINTER(SymGraphStruct), c_ptr,
@@ -62,8 +63,8 @@ PROTOTYPES = {
                                     c_i64, c_ptr]),
     "pgt_gru_zr_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_gru_h_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
-    "pgt_gru_h_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int,
-                                  c_i64, c_i64, c_ptr]),
+    "pgt_gru_h_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                  c_int, c_i64, c_i64, c_ptr]),
     "pgt_gru_zr_bwd_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64,
                                    c_ptr]),
     "pgt_copy2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
@@ -105,6 +106,9 @@ class PgtLib:
         rc = getattr(self, "_" + name)(*args)
         if rc != 0:
             raise PgtError(f"{name} failed with code {rc}: {self.last_error()}")
+
+    def tune(self, key, value):
+        self.call("pgt_tune", key.encode(), int(value))
 
     def prep_workspace_bytes(self, E, N):
         return int(self._pgt_prep_workspace_bytes(E, N))

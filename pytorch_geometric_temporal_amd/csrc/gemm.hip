@@ -1,138 +1,240 @@
 // Dense feature transform on the matrix cores, exact fp32: v_mfma_f32_32x32x2_f32
-// (f32 in / f32 accumulate, bitwise an fmaf chain; 157 TFLOP/s peak on MI355X — there is no TF32 on gfx950).
+// (f32 in / f32 accumulate, bitwise an fmaf chain; 157.3 TFLOP/s peak on MI355X — there is no TF32 on gfx950).
 //
-//  gemm_kernel      C(m,n) = sum_j A_j[m,:] . Bw[j*seg_k:(j+1)*seg_k, n] + bias[n]  (+C)
-//                   A is "segmented along K": the 2K-1 diffusion terms T_k of DConv (dcrnn.py:81-105) stay in
-//                   their own [M, C] buffers and are consumed as one [M, (2K-1)*C] operand — no concatenation.
-//                   Generic B strides make the same kernel serve X.W (NN) and dY.W^T (NT, feature gradient).
-//  gemm_tn_kernel   dW += A^T G over a slab of rows per workgroup, fp32 atomics (weight gradient), and the
-//                   bias gradient (column sums of G) on the side.
+//  gemm_kernel<BM,BN,..>   C(m,n) = sum_j A_j[m,:] . Bw[j*seg_k:(j+1)*seg_k, n] + bias[n]  (+C)
+//      A is "segmented along K": the 2K-1 diffusion terms T_k of DConv (dcrnn.py:81-105) stay in their own [M, C]
+//      buffers and are consumed as one [M, (2K-1)*C] operand — no concatenation.  Generic B strides make the same
+//      kernel serve X.W (NN) and dY.W^T (NT, feature gradient); C can be written as column segments.
+//  gemm_tn_kernel<..>      dW += A^T G over a slab of rows per workgroup, fp32 atomics (weight gradient), and the
+//      bias gradient (column sums of G) on the side.
 //
-// Tile: 256 threads = 4 wavefronts, 64x64 output tile, each wavefront one 32x32 accumulator (16 VGPRs),
-// BK = 32.  A is staged k-major in LDS (row stride 65 floats: conflict-free ds_write_b32 and ds_read_b32 for
-// the MFMA A-operand map lane -> A[i = lane&31][k = lane>>5]); B is staged k-major, natural.
+// Large tile (M >= 2048): 256 threads = 2x2 wavefronts, 128 x BN output tile (BN = 128 or 64), each wavefront a
+// 64 x BN/2 sub-tile = 2 x BN/64 accumulators of 32x32 (v_mfma_f32_32x32x2_f32: one A and one B VGPR per lane,
+// 64-cycle issue = dependent latency, so a single accumulator chain already runs the pipe at rate).  BK = 32.
+// Global -> register prefetch of tile k+1 is issued before the MFMAs of tile k (one LDS buffer, two barriers per
+// tile).  A is staged k-major in LDS with row stride BM+1, B with row stride BN+1: ds_write_b32 / ds_read_b32 are
+// conflict-free for both the "lanes along k" (coalesced 128-byte row pieces of A) and "lanes along n" mappings and
+// for the MFMA operand maps lane -> A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31].
+// Small tile (M < 2048): 64 x 64, one accumulator per wavefront, so launch-bound batches still fill 256 CUs.
 #include "pgt_common.h"
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int BK = 32;
 
-__global__ __launch_bounds__(256) void gemm_kernel(
-    const float* __restrict__ A, int64_t lda, int64_t a_seg_stride, int n_seg, int seg_k,
-    const float* __restrict__ Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int64_t c_seg_stride,
-    int c_seg_n, const float* __restrict__ bias, int M, int N, int accumulate) {
+struct GemmArgs {
+  const float* A; int64_t lda; int64_t a_seg_stride; int n_seg; int seg_k;
+  const float* Bw; int64_t sbk; int64_t sbn;
+  float* C; int64_t ldc; int64_t c_seg_stride; int c_seg_n;
+  const float* bias; int M; int N; int accumulate;
+};
+
+// BM x BN tile, WM x WN sub-tiles of 32x32 per wavefront (2x2 wavefronts).  AV: floats per A load (1 | 2).
+// BKMAJ: B tile is loaded with lanes along k (B contiguous in k: the NT case) instead of along n.
+template <int BM, int BN, int AV, bool BKMAJ>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int WM = BM / 64, WN = BN / 64;  // accumulators per wavefront along m / n
   __shared__ float As[BK][BM + 1];
-  __shared__ float Bs[BK][BN];
+  __shared__ float Bs[BK][BN + 1];
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave & 1, wn = wave >> 1;
+  const int lo = lane & 31, hi = lane >> 5;
   const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
-  const int Ktot = n_seg * seg_k;
+  const int Ktot = g.n_seg * g.seg_k;
 
-  pgt_f32x16 acc;
+  pgt_f32x16 acc[WM][WN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int a_kk = tid & 31, a_mm = tid >> 5;  // A tile: lanes run along k (contiguous in memory)
-  const int b_n = tid & 63, b_kq = tid >> 6;   // B tile: lanes run along n
-  const int gn_b = n0 + b_n;
+  // ---- per-thread staging registers
+  constexpr int A_PER = BM * BK / 256;  // floats of A per thread per tile
+  constexpr int B_PER = BN * BK / 256;
+  float ra[A_PER], rb[B_PER];
 
-  for (int k0 = 0; k0 < Ktot; k0 += BK) {
+  // A mapping: lanes along k (contiguous in memory)
+  constexpr int A_KL = BK / AV;              // lanes along k
+  constexpr int A_ROWS_PER_PASS = 256 / A_KL;
+  constexpr int A_PASSES = BM / A_ROWS_PER_PASS;
+  const int a_k = (tid % A_KL) * AV, a_m = tid / A_KL;
+  // B mapping
+  constexpr int B_L = BKMAJ ? BK : BN;       // lanes along k (BKMAJ) or along n
+  constexpr int B_OTHER_PER_PASS = 256 / B_L;
+  constexpr int B_PASSES = (BKMAJ ? BN : BK) / B_OTHER_PER_PASS;
+  const int b_l = tid % B_L, b_o = tid / B_L;
+
+  auto load_tile = [&](int k0) {
     {
-      const int kg = k0 + a_kk;
+      const int kg = k0 + a_k;
       const bool kv = kg < Ktot;
-      const int j = kv ? kg / seg_k : 0;
-      const int c = kg - j * seg_k;
-      const float* base = A + (int64_t)j * a_seg_stride + c;
+      const int j = kv ? kg / g.seg_k : 0;
+      const float* base = g.A + (int64_t)j * g.a_seg_stride + (kg - j * g.seg_k);
 #pragma unroll
-      for (int i = 0; i < BM / 8; ++i) {
-        const int m = a_mm + 8 * i;
-        const int gm = m0 + m;
-        As[a_kk][m] = (kv && gm < M) ? base[(int64_t)gm * lda] : 0.f;
+      for (int p = 0; p < A_PASSES; ++p) {
+        const int gm = m0 + a_m + p * A_ROWS_PER_PASS;
+        const bool v = kv && gm < g.M;
+        if constexpr (AV == 2) {
+          float2 t = make_float2(0.f, 0.f);
+          if (v) t = *reinterpret_cast<const float2*>(base + (int64_t)gm * g.lda);
+          ra[2 * p] = t.x;
+          ra[2 * p + 1] = t.y;
+        } else {
+          ra[p] = v ? base[(int64_t)gm * g.lda] : 0.f;
+        }
       }
     }
-    {
 #pragma unroll
-      for (int i = 0; i < BK / 4; ++i) {
-        const int k = b_kq + 4 * i;
-        const int kg = k0 + k;
-        Bs[k][b_n] = (kg < Ktot && gn_b < N) ? Bw[(int64_t)kg * sbk + (int64_t)gn_b * sbn] : 0.f;
+    for (int p = 0; p < B_PASSES; ++p) {
+      const int k = BKMAJ ? b_l : b_o + p * B_OTHER_PER_PASS;
+      const int n = BKMAJ ? b_o + p * B_OTHER_PER_PASS : b_l;
+      const int kg = k0 + k, gn = n0 + n;
+      rb[p] = (kg < Ktot && gn < g.N) ? g.Bw[(int64_t)kg * g.sbk + (int64_t)gn * g.sbn] : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int m = a_m + p * A_ROWS_PER_PASS;
+      if constexpr (AV == 2) {
+        As[a_k][m] = ra[2 * p];
+        As[a_k + 1][m] = ra[2 * p + 1];
+      } else {
+        As[a_k][m] = ra[p];
       }
     }
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) {
+      const int k = BKMAJ ? b_l : b_o + p * B_OTHER_PER_PASS;
+      const int n = BKMAJ ? b_o + p * B_OTHER_PER_PASS : b_l;
+      Bs[k][n] = rb[p];
+    }
+  };
+
+  load_tile(0);
+  for (int k0 = 0; k0 < Ktot; k0 += BK) {
+    store_tile();
     __syncthreads();
+    if (k0 + BK < Ktot) load_tile(k0 + BK);  // in flight while the matrix cores work on tile k0
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
-      const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
-      acc = PGT_MFMA_32x32x2(a, b, acc);
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = As[kk + hi][wm * (BM / 2) + i * 32 + lo];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[kk + hi][wn * (BN / 2) + j * 32 + lo];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = PGT_MFMA_32x32x2(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
 
   // D map (cdna_hip_programming.md §3): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const int gn = n0 + wn * 32 + (lane & 31);
-  if (gn < N) {
-    const float bv = bias ? bias[gn] : 0.f;
-    const int js = gn / c_seg_n;
-    float* cbase = C + (int64_t)js * c_seg_stride + (gn - js * c_seg_n);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (gm < M) {
-        float v = acc[r] + bv;
-        float* p = cbase + (int64_t)gm * ldc;
-        if (accumulate) v += *p;
-        *p = v;
+  for (int j = 0; j < WN; ++j) {
+    const int gn = n0 + wn * (BN / 2) + j * 32 + lo;
+    if (gn >= g.N) continue;
+    const float bv = g.bias ? g.bias[gn] : 0.f;
+    const int js = gn / g.c_seg_n;
+    float* cbase = g.C + (int64_t)js * g.c_seg_stride + (gn - js * g.c_seg_n);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (gm < g.M) {
+          float v = acc[i][j][r] + bv;
+          float* p = cbase + (int64_t)gm * g.ldc;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
       }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(
-    const float* __restrict__ A, int64_t lda, int64_t a_seg_stride, int n_seg, int seg_k,
-    const float* __restrict__ G, int64_t ldg, float* dW, int64_t lddw, float* db, int M, int N,
-    int rows_per_slab) {
-  __shared__ float As[BK][BM];  // [m][kc]
-  __shared__ float Gs[BK][BN];  // [m][n]
+struct TnArgs {
+  const float* A; int64_t lda; int64_t a_seg_stride; int n_seg; int seg_k;
+  const float* G; int64_t ldg; float* dW; int64_t lddw; float* db; int M; int N; int rows_per_slab;
+};
+
+// dW tile [BKC kc x BN n] += A[slab, kc]^T G[slab, n].  Both operands are staged in their natural [m][col] layout
+// (lanes along the contiguous column): the MFMA "A" operand A'[i = kc][k = m] is As[m][kc].
+template <int BKC, int BN>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
+  constexpr int WK = BKC / 64, WN = BN / 64;
+  __shared__ float As[BK][BKC];
+  __shared__ float Gs[BK][BN];
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wk = wave & 1, wn = wave >> 1;
-  const int k0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
-  const int Ktot = n_seg * seg_k;
-  const int ms = (int)blockIdx.z * rows_per_slab;
-  const int me = (ms + rows_per_slab < M) ? ms + rows_per_slab : M;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int k0 = (int)blockIdx.x * BKC, n0 = (int)blockIdx.y * BN;
+  const int Ktot = g.n_seg * g.seg_k;
+  const int ms = (int)blockIdx.z * g.rows_per_slab;
+  const int me = (ms + g.rows_per_slab < g.M) ? ms + g.rows_per_slab : g.M;
 
-  pgt_f32x16 acc;
+  pgt_f32x16 acc[WK][WN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < WK; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int l_c = tid & 63, l_mq = tid >> 6;  // lanes along the column (kc or n), 4 row phases
-  const int kg = k0 + l_c;
+  constexpr int A_RPP = 256 / BKC, A_PASSES = BK / A_RPP;  // rows per pass
+  constexpr int G_RPP = 256 / BN, G_PASSES = BK / G_RPP;
+  const int a_c = tid % BKC, a_r = tid / BKC;
+  const int g_c = tid % BN, g_r = tid / BN;
+  const int kg = k0 + a_c;
   const bool kv = kg < Ktot;
-  const int j = kv ? kg / seg_k : 0;
-  const float* abase = A + (int64_t)j * a_seg_stride + (kg - j * seg_k);
-  const int gn_l = n0 + l_c;
-  const bool nv = gn_l < N;
-  const bool do_bias = (db != nullptr) && (blockIdx.x == 0) && (tid < BN);
+  const int j = kv ? kg / g.seg_k : 0;
+  const float* abase = g.A + (int64_t)j * g.a_seg_stride + (kg - j * g.seg_k);
+  const int gn_l = n0 + g_c;
+  const bool nv = gn_l < g.N;
+  const bool do_bias = (g.db != nullptr) && (blockIdx.x == 0) && (tid < BN);
   float bsum = 0.f;
+  float ra[A_PASSES], rg[G_PASSES];
 
+  auto load_tile = [&](int mb) {
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int gm = mb + a_r + p * A_RPP;
+      ra[p] = (kv && gm < me) ? abase[(int64_t)gm * g.lda] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < G_PASSES; ++p) {
+      const int gm = mb + g_r + p * G_RPP;
+      rg[p] = (nv && gm < me) ? g.G[(int64_t)gm * g.ldg + gn_l] : 0.f;
+    }
+  };
+
+  load_tile(ms);
   for (int mb = ms; mb < me; mb += BK) {
 #pragma unroll
-    for (int i = 0; i < BK / 4; ++i) {
-      const int m = l_mq + 4 * i;
-      const int gm = mb + m;
-      const bool mv = gm < me;
-      As[m][l_c] = (kv && mv) ? abase[(int64_t)gm * lda] : 0.f;
-      Gs[m][l_c] = (nv && mv) ? G[(int64_t)gm * ldg + gn_l] : 0.f;
-    }
+    for (int p = 0; p < A_PASSES; ++p) As[a_r + p * A_RPP][a_c] = ra[p];
+#pragma unroll
+    for (int p = 0; p < G_PASSES; ++p) Gs[g_r + p * G_RPP][g_c] = rg[p];
     __syncthreads();
+    if (mb + BK < me) load_tile(mb + BK);
 #pragma unroll
     for (int mm = 0; mm < BK; mm += 2) {
-      const float a = As[mm + (lane >> 5)][wk * 32 + (lane & 31)];
-      const float b = Gs[mm + (lane >> 5)][wn * 32 + (lane & 31)];
-      acc = PGT_MFMA_32x32x2(a, b, acc);
+      float a[WK], b[WN];
+#pragma unroll
+      for (int i = 0; i < WK; ++i) a[i] = As[mm + hi][wk * (BKC / 2) + i * 32 + lo];
+#pragma unroll
+      for (int jj = 0; jj < WN; ++jj) b[jj] = Gs[mm + hi][wn * (BN / 2) + jj * 32 + lo];
+#pragma unroll
+      for (int i = 0; i < WK; ++i)
+#pragma unroll
+        for (int jj = 0; jj < WN; ++jj) acc[i][jj] = PGT_MFMA_32x32x2(a[i], b[jj], acc[i][jj]);
     }
     if (do_bias) {
 #pragma unroll
@@ -141,18 +243,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     __syncthreads();
   }
 
-  const int gn = n0 + wn * 32 + (lane & 31);
-  if (gn < N) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int gk = k0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (gk < Ktot) atomicAdd(dW + (int64_t)gk * lddw + gn, acc[r]);
+  for (int jj = 0; jj < WN; ++jj) {
+    const int gn = n0 + wn * (BN / 2) + jj * 32 + lo;
+    if (gn >= g.N) continue;
+#pragma unroll
+    for (int i = 0; i < WK; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gk = k0 + wk * (BKC / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (gk < Ktot) atomicAdd(g.dW + (int64_t)gk * g.lddw + gn, acc[i][jj][r]);
+      }
     }
   }
-  if (do_bias && (n0 + tid) < N) atomicAdd(db + n0 + tid, bsum);
+  if (do_bias && (n0 + tid) < g.N) atomicAdd(g.db + n0 + tid, bsum);
 }
 
+int g_force_small_tiles = 0;  // pgt_tune("gemm_small_tiles"): 0 = by size, 1 = always 64x64, 2 = always 128-wide
+
 }  // namespace
+
+void pgt_gemm_set_force_small(int v) { g_force_small_tiles = v; }
 
 extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                             const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
@@ -163,13 +274,29 @@ extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, i
   PGT_REQUIRE(C != nullptr, "pgt_gemm_f32: null output");
   PGT_REQUIRE(n_seg * seg_k == 0 || (A && Bw), "pgt_gemm_f32: null operand");
   PGT_REQUIRE(c_seg_n > 0, "pgt_gemm_f32: c_seg_n must be positive");
-  PGT_REQUIRE(M < ((int64_t)1 << 31) - BM && N < ((int64_t)1 << 31) - BN && n_seg * seg_k < ((int64_t)1 << 31) - BK,
+  PGT_REQUIRE(M < ((int64_t)1 << 31) - 128 && N < ((int64_t)1 << 31) - 128 && n_seg * seg_k < ((int64_t)1 << 31) - BK,
               "pgt_gemm_f32: size exceeds int32 indexing");
-  const int64_t gx = pgt_cdiv(M, BM), gy = pgt_cdiv(N, BN);
-  PGT_REQUIRE(gy <= 65535, "pgt_gemm_f32: N too large");
-  dim3 grid((unsigned)gx, (unsigned)gy), block(256);
-  PGT_LAUNCH(gemm_kernel, grid, block, stream, A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), Bw,
-             sbk, sbn, C, ldc, c_seg_stride, (int)c_seg_n, bias, (int)M, (int)N, accumulate);
+  GemmArgs g{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), Bw, sbk, sbn, C, ldc, c_seg_stride,
+             (int)c_seg_n, bias, (int)M, (int)N, accumulate};
+  // float2 loads of A need every (row, even k) address 8-byte aligned and no pair straddling a segment
+  const bool av2 = (seg_k % 2 == 0) && (lda % 2 == 0) && (a_seg_stride % 2 == 0) && pgt_aligned(A, 8);
+  const bool kmaj = (sbk == 1 && sbn != 1);
+  const bool big = g_force_small_tiles == 2 || ((M >= 2048) && g_force_small_tiles == 0);
+  dim3 block(256);
+#define PGT_GEMM_GO(BM_, BN_)                                                                         \
+  do {                                                                                                \
+    const int64_t gx = pgt_cdiv(M, BM_), gy = pgt_cdiv(N, BN_);                                       \
+    PGT_REQUIRE(gy <= 65535, "pgt_gemm_f32: N too large");                                            \
+    dim3 grid((unsigned)gx, (unsigned)gy);                                                            \
+    if (av2 && kmaj) PGT_LAUNCH((gemm_kernel<BM_, BN_, 2, true>), grid, block, stream, g);            \
+    else if (av2) PGT_LAUNCH((gemm_kernel<BM_, BN_, 2, false>), grid, block, stream, g);              \
+    else if (kmaj) PGT_LAUNCH((gemm_kernel<BM_, BN_, 1, true>), grid, block, stream, g);              \
+    else PGT_LAUNCH((gemm_kernel<BM_, BN_, 1, false>), grid, block, stream, g);                       \
+  } while (0)
+  if (big && N > 64) PGT_GEMM_GO(128, 128);
+  else if (big) PGT_GEMM_GO(128, 64);
+  else PGT_GEMM_GO(64, 64);
+#undef PGT_GEMM_GO
   return pgt_check_launch("pgt_gemm_f32");
 }
 
@@ -181,10 +308,12 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
   if (M == 0 || N == 0) return PGT_OK;
   PGT_REQUIRE(G != nullptr, "pgt_gemm_tn_acc_f32: null gradient");
   PGT_REQUIRE(Ktot == 0 || (A && dW), "pgt_gemm_tn_acc_f32: null operand");
-  PGT_REQUIRE(M < ((int64_t)1 << 31) - 4096 && N < ((int64_t)1 << 31) - BN && Ktot < ((int64_t)1 << 31) - BM,
+  PGT_REQUIRE(M < ((int64_t)1 << 31) - 4096 && N < ((int64_t)1 << 31) - 128 && Ktot < ((int64_t)1 << 31) - 128,
               "pgt_gemm_tn_acc_f32: size exceeds int32 indexing");
+  const bool big = g_force_small_tiles == 2 || ((M >= 16384) && (Ktot > 64) && (N > 64) && g_force_small_tiles == 0);
+  const int BKC = big ? 128 : 64, BN = big ? 128 : 64;
   // at least one k-tile so that the bias gradient (blockIdx.x == 0) is produced even when Ktot == 0
-  const int64_t gx = Ktot > 0 ? pgt_cdiv(Ktot, BM) : 1, gy = pgt_cdiv(N, BN);
+  const int64_t gx = Ktot > 0 ? pgt_cdiv(Ktot, BKC) : 1, gy = pgt_cdiv(N, BN);
   PGT_REQUIRE(gy <= 65535, "pgt_gemm_tn_acc_f32: N too large");
   // enough row slabs for ~1024 workgroups, each slab a multiple of BK rows
   int64_t nslab = pgt_cdiv(1024, gx * gy);
@@ -192,10 +321,12 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
   if (nslab > max_slab) nslab = max_slab;
   if (nslab > 65535) nslab = 65535;
   if (nslab < 1) nslab = 1;
-  int64_t rows = pgt_cdiv(pgt_cdiv(M, nslab), BK) * BK;
+  const int64_t rows = pgt_cdiv(pgt_cdiv(M, nslab), BK) * BK;
   nslab = pgt_cdiv(M, rows);
+  TnArgs t{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), G, ldg, dW, lddw, db, (int)M, (int)N,
+           (int)rows};
   dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nslab), block(256);
-  PGT_LAUNCH(gemm_tn_kernel, grid, block, stream, A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), G,
-             ldg, dW, lddw, db, (int)M, (int)N, (int)rows);
+  if (big) PGT_LAUNCH((gemm_tn_kernel<128, 128>), grid, block, stream, t);
+  else PGT_LAUNCH((gemm_tn_kernel<64, 64>), grid, block, stream, t);
   return pgt_check_launch("pgt_gemm_tn_acc_f32");
 }

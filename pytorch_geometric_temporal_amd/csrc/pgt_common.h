@@ -13,7 +13,11 @@
 typedef pgt_emu_f32x16 pgt_f32x16;
 #define PGT_MFMA_32x32x2(a, b, c) pgt_emu_mfma_32x32x2((a), (b), (c))
 #define PGT_TARGET "emu"
+#define PGT_UNIFORM(x) (x)
 #else
+// wave-uniform value -> SGPR, so loads indexed by it go through the scalar cache (s_load) instead of 64 identical
+// vector lanes
+#define PGT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define PGT_LAUNCH(kern, grid, block, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
 typedef float pgt_f32x16 __attribute__((ext_vector_type(16)));
@@ -24,6 +28,9 @@ typedef float pgt_f32x16 __attribute__((ext_vector_type(16)));
 #define PGT_WAVE 64
 
 void pgt_set_error(const char* fmt, ...);
+// tuning knobs (pgt_tune): each translation unit owns its own
+void pgt_gemm_set_force_small(int v);
+int pgt_spmm_tune(const char* key, int value);  // returns 1 when the key is known
 
 #define PGT_REQUIRE(cond, ...)            \
   do {                                    \
@@ -44,3 +51,38 @@ static inline int pgt_check_launch(const char* what) {
 
 static inline int64_t pgt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline bool pgt_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// V-float (4 / 8 / 16-byte) global accesses; V is chosen by the host from pointer and stride alignment.
+template <int VEC>
+__device__ __forceinline__ void pgt_ldv(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void pgt_stv(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  } else {
+    *p = v[0];
+  }
+}
+
+// largest V in {4,2,1} such that `width` is a multiple of V and every (pointer, row stride) pair is V-float aligned
+struct PgtVecPick {
+  int v = 4;
+  void width(int64_t w) { while (v > 1 && w % v) v >>= 1; }
+  void operand(const void* p, int64_t ld) {
+    if (p == nullptr) return;
+    while (v > 1 && (ld % v || reinterpret_cast<uintptr_t>(p) % (4u * v))) v >>= 1;
+  }
+};

@@ -1,6 +1,7 @@
 // Error reporting and build identification for libpgt_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "pgt_common.h"
 
@@ -16,3 +17,18 @@ void pgt_set_error(const char* fmt, ...) {
 extern "C" int pgt_abi_version(void) { return PGT_ABI_VERSION; }
 extern "C" const char* pgt_last_error(void) { return g_err; }
 extern "C" const char* pgt_build_target(void) { return PGT_TARGET; }
+
+// Tuning / A-B knobs for benchmarking (defaults are the shipped configuration).  Not thread-safe; call between launches.
+extern "C" int pgt_tune(const char* key, int value) {
+  if (key == nullptr) {
+    pgt_set_error("pgt_tune: null key");
+    return PGT_ERR_INVALID;
+  }
+  if (strcmp(key, "gemm_small_tiles") == 0) {
+    pgt_gemm_set_force_small(value);
+    return PGT_OK;
+  }
+  if (pgt_spmm_tune(key, value)) return PGT_OK;
+  pgt_set_error("pgt_tune: unknown key '%s'", key);
+  return PGT_ERR_INVALID;
+}

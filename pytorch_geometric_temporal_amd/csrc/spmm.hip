@@ -17,12 +17,19 @@
 //    neighbour read is a fully coalesced 1 KiB (VEC = 4) burst.
 //
 // Algorithmic bytes per launch: 4(N+1) + 8*nnz + 4*N*F (read X once) + 4*N*F (write Y) [+ 4*N*F for T].
+#include <string.h>
+
 #include "pgt_common.h"
 
 namespace {
 
-constexpr int TR = 64;      // rows per tile
-constexpr int CAP = 1536;   // LDS-staged slots per tile (12 KiB); larger tiles fall back to global reads
+constexpr int CAP_PER_ROW = 24;  // LDS-staged slots per tile = 24 * TR (12 KiB at TR = 64); larger tiles read global
+
+// A/B knobs (pgt_tune); the defaults are the shipped configuration
+int g_tile_xcd = 1;    // hand tiles to XCDs in contiguous ranges
+int g_tile_rows = 64;  // rows per tile for the F = 64 fast path (32 | 64 | 128)
+int g_unroll = 8;      // neighbour loads in flight per lane group (4 | 8)
+int g_wide_xcd = 1;    // XCD-slab block mapping of the wide kernel
 
 template <int VEC>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[VEC]) {
@@ -54,17 +61,18 @@ __device__ __forceinline__ int xcd_contiguous_tile(int b, int nb) {
   return x * q + (x < r ? x : r) + (b >> 3);
 }
 
-template <int VEC, int LPR>
+template <int VEC, int LPR, int TR, int U>
 __global__ __launch_bounds__(256) void spmm_tile_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     int n_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy, const float* T,
-    int64_t ldt, float alpha, float beta, int F) {
+    int64_t ldt, float alpha, float beta, int F, int xcd_remap) {
+  constexpr int CAP = CAP_PER_ROW * TR;
   __shared__ int s_rp[TR + 1];
   __shared__ int s_col[CAP];
   __shared__ float s_val[CAP];
 
   const int tid = threadIdx.x;
-  const int tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+  const int tile = xcd_remap ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int r0 = tile * TR;
   const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
 
@@ -93,20 +101,34 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     int q = a;
     if (staged) {
-      for (; q + 4 <= b; q += 4) {
-        const int c0 = s_col[q], c1 = s_col[q + 1], c2 = s_col[q + 2], c3 = s_col[q + 3];
-        const float v0 = s_val[q], v1 = s_val[q + 1], v2 = s_val[q + 2], v3 = s_val[q + 3];
-        float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
-        ldv<VEC>(X + (int64_t)c0 * ldx + f, x0);
-        ldv<VEC>(X + (int64_t)c1 * ldx + f, x1);
-        ldv<VEC>(X + (int64_t)c2 * ldx + f, x2);
-        ldv<VEC>(X + (int64_t)c3 * ldx + f, x3);
+      // U independent neighbour-row loads are issued before the first fma consumes one (memory-level parallelism);
+      // the fma chain itself stays in slot order.
+      for (; q + U <= b; q += U) {
+        int c[U];
+        float v[U];
+        float x[U][VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          acc[i] = fmaf(v0, x0[i], acc[i]);
-          acc[i] = fmaf(v1, x1[i], acc[i]);
-          acc[i] = fmaf(v2, x2[i], acc[i]);
-          acc[i] = fmaf(v3, x3[i], acc[i]);
+        for (int u = 0; u < U; ++u) { c[u] = s_col[q + u]; v[u] = s_val[q + u]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) ldv<VEC>(X + (int64_t)c[u] * ldx + f, x[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(v[u], x[u][i], acc[i]);
+      }
+      if (U > 4) {
+        for (; q + 4 <= b; q += 4) {
+          int c[4];
+          float v[4];
+          float x[4][VEC];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { c[u] = s_col[q + u]; v[u] = s_val[q + u]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ldv<VEC>(X + (int64_t)c[u] * ldx + f, x[u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(v[u], x[u][i], acc[i]);
         }
       }
       for (; q < b; ++q) {
@@ -141,12 +163,12 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
   }
 }
 
-template <int VEC>
+template <int VEC, int U>
 __global__ __launch_bounds__(256) void spmm_wide_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     int n_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy, const float* T,
     int64_t ldt, float alpha, float beta, int F, int nchunks, int nrowgroups, int xcd_map) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = PGT_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   int chunk, rowgroup;
   if (xcd_map) {
     // XCD x (= blockIdx % 8 on MI355X) owns the column chunks c = 8*j + x and sweeps ALL rows of one chunk before
@@ -160,39 +182,38 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(
     chunk = (int)(blockIdx.x % (unsigned)nchunks);
     rowgroup = (int)(blockIdx.x / (unsigned)nchunks);
   }
-  const int row = rowgroup * 4 + wave;
+  const int row = rowgroup * 4 + wave;  // wave-uniform: rowptr / col / val below are scalar (SMEM) loads
   if (row >= n_rows) return;
   const int f = (chunk * 64 + lane) * VEC;
-  if (f >= F) return;
+  const bool active = f < F;
   const int a = rowptr[row], b = rowptr[row + 1];
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  const float* Xf = X + (active ? f : 0);
   int q = a;
-  for (; q + 4 <= b; q += 4) {
-    const int c0 = col[q], c1 = col[q + 1], c2 = col[q + 2], c3 = col[q + 3];
-    const float v0 = val[q], v1 = val[q + 1], v2 = val[q + 2], v3 = val[q + 3];
-    float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
-    ldv<VEC>(X + (int64_t)c0 * ldx + f, x0);
-    ldv<VEC>(X + (int64_t)c1 * ldx + f, x1);
-    ldv<VEC>(X + (int64_t)c2 * ldx + f, x2);
-    ldv<VEC>(X + (int64_t)c3 * ldx + f, x3);
+  for (; q + U <= b; q += U) {
+    int c[U];
+    float v[U];
+    float x[U][VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      acc[i] = fmaf(v0, x0[i], acc[i]);
-      acc[i] = fmaf(v1, x1[i], acc[i]);
-      acc[i] = fmaf(v2, x2[i], acc[i]);
-      acc[i] = fmaf(v3, x3[i], acc[i]);
-    }
+    for (int u = 0; u < U; ++u) { c[u] = col[q + u]; v[u] = val[q + u]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) ldv<VEC>(Xf + (int64_t)c[u] * ldx, x[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(v[u], x[u][i], acc[i]);
   }
   for (; q < b; ++q) {
     const int c0 = col[q];
     const float v0 = val[q];
     float x0[VEC];
-    ldv<VEC>(X + (int64_t)c0 * ldx + f, x0);
+    ldv<VEC>(Xf + (int64_t)c0 * ldx, x0);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = fmaf(v0, x0[i], acc[i]);
   }
+  if (!active) return;
   float out[VEC];
   if (T != nullptr) {
     float t[VEC];
@@ -236,32 +257,56 @@ int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, int
                 int64_t F, pgt_stream_t stream) {
   const int64_t Fv = F / VEC;
   const int n = (int)n_rows, Fi = (int)F;
+  dim3 block(256);
   if (Fv <= 64) {
-    const unsigned ntiles = (unsigned)pgt_cdiv(n_rows, TR);
-    dim3 grid(ntiles), block(256);
-#define PGT_SPMM_CASE(L)                                                                                   \
-  PGT_LAUNCH((spmm_tile_kernel<VEC, L>), grid, block, stream, rowptr, col, val, n, X, ldx, Y, ldy, T, ldt, \
-             alpha, beta, Fi)
-    if (Fv <= 4) { PGT_SPMM_CASE(4); }
-    else if (Fv <= 8) { PGT_SPMM_CASE(8); }
-    else if (Fv <= 16) { PGT_SPMM_CASE(16); }
-    else if (Fv <= 32) { PGT_SPMM_CASE(32); }
-    else { PGT_SPMM_CASE(64); }
+#define PGT_SPMM_CASE(L, TR_, U_)                                                                             \
+  PGT_LAUNCH((spmm_tile_kernel<VEC, L, TR_, U_>), dim3((unsigned)pgt_cdiv(n_rows, TR_)), block, stream, rowptr, \
+             col, val, n, X, ldx, Y, ldy, T, ldt, alpha, beta, Fi, g_tile_xcd)
+    if (Fv <= 4) { PGT_SPMM_CASE(4, 64, 4); }
+    else if (Fv <= 8) { PGT_SPMM_CASE(8, 64, 4); }
+    else if (Fv <= 16) {
+      if (VEC == 4) {  // the F = 64 fast path carries the A/B variants
+        const int key = g_tile_rows * 10 + g_unroll;
+        if (key == 324) { PGT_SPMM_CASE(16, 32, 4); }
+        else if (key == 328) { PGT_SPMM_CASE(16, 32, 8); }
+        else if (key == 644) { PGT_SPMM_CASE(16, 64, 4); }
+        else if (key == 1284) { PGT_SPMM_CASE(16, 128, 4); }
+        else if (key == 1288) { PGT_SPMM_CASE(16, 128, 8); }
+        else { PGT_SPMM_CASE(16, 64, 8); }
+      } else {
+        PGT_SPMM_CASE(16, 64, 4);
+      }
+    }
+    else if (Fv <= 32) { PGT_SPMM_CASE(32, 64, 4); }
+    else { PGT_SPMM_CASE(64, 64, 4); }
 #undef PGT_SPMM_CASE
   } else {
     const int nchunks = (int)pgt_cdiv(Fv, 64);
     const int nrowgroups = (int)pgt_cdiv(n_rows, 4);
-    const int xcd_map = nchunks >= 16 ? 1 : 0;
+    const int xcd_map = (nchunks >= 16 && g_wide_xcd) ? 1 : 0;
     const int64_t nblocks = (int64_t)nrowgroups * (xcd_map ? pgt_cdiv(nchunks, 8) * 8 : nchunks);
     PGT_REQUIRE(nblocks < (int64_t)1 << 31, "pgt_spmm_csr_f32: grid too large");
-    dim3 grid((unsigned)nblocks), block(256);
-    PGT_LAUNCH((spmm_wide_kernel<VEC>), grid, block, stream, rowptr, col, val, n, X, ldx, Y, ldy, T, ldt, alpha,
-               beta, Fi, nchunks, nrowgroups, xcd_map);
+    dim3 grid((unsigned)nblocks);
+    if (g_unroll == 4) {
+      PGT_LAUNCH((spmm_wide_kernel<VEC, 4>), grid, block, stream, rowptr, col, val, n, X, ldx, Y, ldy, T, ldt, alpha,
+                 beta, Fi, nchunks, nrowgroups, xcd_map);
+    } else {
+      PGT_LAUNCH((spmm_wide_kernel<VEC, 8>), grid, block, stream, rowptr, col, val, n, X, ldx, Y, ldy, T, ldt, alpha,
+                 beta, Fi, nchunks, nrowgroups, xcd_map);
+    }
   }
   return pgt_check_launch("pgt_spmm_csr_f32");
 }
 
 }  // namespace
+
+int pgt_spmm_tune(const char* key, int value) {
+  if (strcmp(key, "spmm_tile_xcd") == 0) { g_tile_xcd = value; return 1; }
+  if (strcmp(key, "spmm_tile_rows") == 0) { g_tile_rows = value; return 1; }
+  if (strcmp(key, "spmm_unroll") == 0) { g_unroll = value; return 1; }
+  if (strcmp(key, "spmm_wide_xcd") == 0) { g_wide_xcd = value; return 1; }
+  return 0;
+}
 
 extern "C" int pgt_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                                 const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T,
@@ -269,7 +314,7 @@ extern "C" int pgt_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   PGT_REQUIRE(n_rows >= 0 && F >= 0, "pgt_spmm_csr_f32: negative size");
   if (n_rows == 0 || F == 0) return PGT_OK;
   PGT_REQUIRE(rowptr && X && Y, "pgt_spmm_csr_f32: null pointer");
-  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) - TR && F < ((int64_t)1 << 31), "pgt_spmm_csr_f32: size exceeds int32 indexing");
+  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) - 128 && F < ((int64_t)1 << 31), "pgt_spmm_csr_f32: size exceeds int32 indexing");
   PGT_REQUIRE(ldx >= F && ldy >= F && (T == nullptr || ldt >= F), "pgt_spmm_csr_f32: row stride smaller than F");
   PGT_REQUIRE(Y != X, "pgt_spmm_csr_f32: Y must not alias X");
   // widest vector width every row start is aligned for

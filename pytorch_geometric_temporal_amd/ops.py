@@ -334,15 +334,32 @@ def _stack_fwd(g, TS, t, K, Nn):
                 spmm(csr, src, dst, T=T0, alpha=2.0, beta=-1.0)
 
 
-def _stack_bwd(g, G, K, Nn):
-    """Adjoint of _stack_fwd on G [S][M][C] (in place); on exit G[0] holds d/dT_0."""
+def fold_backward_weight(Wst, K, C):
+    """For K <= 3 the "- Tx_0" terms of the recursion only touch the LAST hop, so their adjoint
+    (G_0 -= G_k^o + G_k^i) is linear in dPRE and folds into the segment-0 rows of the weight used by the
+    feature-gradient GEMM: G_0 = dPRE (W_0 - sum_{k>=2} W_k^o + W_k^i)^T.  Removes 2(K-2) streaming passes over
+    [M, C] per stack.  (K >= 4 keeps the explicit form: there G_k is updated before it is subtracted.)"""
+    if K < 3 or K > 3:
+        return Wst, False
+    Wb = Wst.clone()
+    for k in range(2, K):
+        for d in range(2):
+            j = 2 * k - 1 + d
+            Wb[0:C] -= Wst[j * C:(j + 1) * C]
+    return Wb, True
+
+
+def _stack_bwd(g, G, K, Nn, folded=False):
+    """Adjoint of _stack_fwd on G [S][M][C] (in place); on exit G[0] holds d/dT_0.  `folded`: the G_0 -= G_k terms
+    were already applied through fold_backward_weight."""
     G0 = G[0].view(Nn, -1)
     for k in range(K - 1, 1, -1):
         for d, csr in enumerate((g.bwd_o, g.bwd_i)):
             Gk = G[2 * k - 1 + d].view(Nn, -1)
             Gp = G[2 * (k - 1) - 1 + d].view(Nn, -1)
             spmm(csr, Gk, Gp, T=Gp, alpha=2.0, beta=1.0)
-            axpby2d(G0, Gk, -1.0, G0, 1.0)
+            if not folded:
+                axpby2d(G0, Gk, -1.0, G0, 1.0)
     if K > 1:
         for d, csr in enumerate((g.bwd_o, g.bwd_i)):
             spmm(csr, G[1 + d].view(Nn, -1), G0, T=G0, alpha=1.0, beta=1.0)
@@ -397,8 +414,9 @@ class DConvFunction(torch.autograd.Function):
             gemm_tn_acc(TS, C, M * C, S, C, dH, O, dW, O, db, M, O)
         if ctx.needs_input_grad[0]:
             G = torch.empty(S, M, C, dtype=F32, device=dH.device)
-            gemm(dH, O, 0, 1, O, Wc, 1, O, G, C, M * C, C, None, M, S * C)
-            _stack_bwd(g, G, K, g.N)
+            Wb, folded = fold_backward_weight(Wc, K, C)
+            gemm(dH, O, 0, 1, O, Wb, 1, O, G, C, M * C, C, None, M, S * C)
+            _stack_bwd(g, G, K, g.N, folded)
             dX = G[0]
         return dX, dW, db, None, None, None
 
@@ -413,21 +431,23 @@ def _gru_zr(pre_zr, H, xhr, f_in):
     lib.call("pgt_gru_zr_f32", ptr(pre_zr), hp, ldh, xp, ldx, f_in, M, O2 // 2, stream_of(lib, pre_zr))
 
 
-def _gru_h(pre_h, zr, H, out0):
+def _gru_h(pre_h, zr, H, out0, out1=None):
     lib = _lib.get_lib()
     M, O = pre_h.shape
     hp, ldh = _rows(H, "H")
     op, ld0 = _rows(out0, "out0")
-    lib.call("pgt_gru_h_f32", ptr(pre_h), ptr(zr), hp, ldh, op, ld0, ptr(None), 0, M, O, stream_of(lib, pre_h))
+    o1, ld1 = _rows(out1, "out1") if out1 is not None else (ptr(None), 0)
+    lib.call("pgt_gru_h_f32", ptr(pre_h), ptr(zr), hp, ldh, op, ld0, o1, ld1, M, O, stream_of(lib, pre_h))
 
 
-def _gru_h_bwd(dHn, zr, H, ht, d_pre_h, d_pre_zr, dH, accumulate):
+def _gru_h_bwd(dHn, zr, H, ht, d_pre_h, d_pre_zr, dH, accumulate, dHn2=None):
     lib = _lib.get_lib()
     M, O = ht.shape
     gp, ldg = _rows(dHn, "dHn")
+    g2, ldg2 = _rows(dHn2, "dHn2") if dHn2 is not None else (ptr(None), 0)
     hp, ldh = _rows(H, "H")
     dp, ldd = _rows(dH, "dH")
-    lib.call("pgt_gru_h_bwd_f32", gp, ldg, ptr(zr), hp, ldh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp, ldd,
+    lib.call("pgt_gru_h_bwd_f32", gp, ldg, g2, ldg2, ptr(zr), hp, ldh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp, ldd,
              int(bool(accumulate)), M, O, stream_of(lib, ht))
 
 
@@ -477,14 +497,15 @@ class DCRNNSeqFunction(torch.autograd.Function):
         for t in range(T):
             Xt, Hp = X[t], (H0c if t == 0 else Hout[t - 1])
             copy2d(TSzr[0, t][:, :Fin], Xt)
-            copy2d(TSzr[0, t][:, Fin:], Hp)
+            if t == 0:
+                copy2d(TSzr[0, t][:, Fin:], Hp)     # later steps: written by the previous step's blend kernel
             _stack_fwd(g, TSzr, t, K, Nn)
             gemm(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, ZR[t], 2 * O, 0, 2 * O, bzr, M, 2 * O)
             copy2d(TSh[0, t][:, :Fin], Xt)
             _gru_zr(ZR[t], Hp, TSh[0, t], Fin)
             _stack_fwd(g, TSh, t, K, Nn)
             gemm(TSh[0, t], C, seg, S, C, Wh_c, O, 1, HT[t], O, 0, O, bh, M, O)
-            _gru_h(HT[t], ZR[t], Hp, Hout[t])
+            _gru_h(HT[t], ZR[t], Hp, Hout[t], TSzr[0, t + 1][:, Fin:] if t + 1 < T else None)
         ctx.g, ctx.K, ctx.B, ctx.Fin = g, K, B, Fin
         ctx.has_bias = (bzr is not None, bh is not None)
         ctx.save_for_backward(TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c)
@@ -502,24 +523,24 @@ class DCRNNSeqFunction(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         dX = torch.zeros(T, M, Fin, dtype=F32, device=dev) if need_x else None
         dH = torch.zeros(M, O, dtype=F32, device=dev)      # running d/dH_t
-        dHn = torch.empty(M, O, dtype=F32, device=dev)
         dPzr = torch.empty(T, M, 2 * O, dtype=F32, device=dev)
         dPh = torch.empty(T, M, O, dtype=F32, device=dev)
         G = torch.empty(S, M, C, dtype=F32, device=dev)
+        Wh_b, folded = fold_backward_weight(Wh_c, K, C)
+        Wzr_b, _ = fold_backward_weight(Wzr_c, K, C)
         for t in range(T - 1, -1, -1):
             Hp = H0c if t == 0 else Hout[t - 1]
-            # dHn = dOut[t] + dH
-            axpby2d(dHn, dOut[t], 1.0, dH, 1.0)
-            _gru_h_bwd(dHn, ZR[t], Hp, HT[t], dPh[t], dPzr[t], dH, accumulate=False)
+            # d/dH_t = dOut[t] + running state gradient, summed inside the gate-backward kernel
+            _gru_h_bwd(dOut[t], ZR[t], Hp, HT[t], dPh[t], dPzr[t], dH, accumulate=False, dHn2=dH)
             # candidate conv: dT = dPh Wh^T ; adjoint of the stack
-            gemm(dPh[t], O, 0, 1, O, Wh_c, 1, O, G, C, M * C, C, None, M, S * C)
-            _stack_bwd(g, G, K, Nn)
+            gemm(dPh[t], O, 0, 1, O, Wh_b, 1, O, G, C, M * C, C, None, M, S * C)
+            _stack_bwd(g, G, K, Nn, folded)
             _gru_zr_bwd(G[0], Fin, ZR[t], Hp, dPzr[t], dH)
             if need_x:
                 copy2d(dX[t], G[0][:, :Fin])
             # gate convs
-            gemm(dPzr[t], 2 * O, 0, 1, 2 * O, Wzr_c, 1, 2 * O, G, C, M * C, C, None, M, S * C)
-            _stack_bwd(g, G, K, Nn)
+            gemm(dPzr[t], 2 * O, 0, 1, 2 * O, Wzr_b, 1, 2 * O, G, C, M * C, C, None, M, S * C)
+            _stack_bwd(g, G, K, Nn, folded)
             add2d(dH, G[0][:, Fin:])
             if need_x:
                 add2d(dX[t], G[0][:, :Fin])

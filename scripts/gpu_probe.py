@@ -40,36 +40,75 @@ def probe_copy():
     emit(probe="torch_copy_256MB", us=us, GBs=2 * 4 * n / us / 1e3)
 
 
+def _rot_time(g_csr, n, F, pairs, with_t=False):
+    """HBM-honest timing: rotate through `pairs` distinct (X, Y) buffer pairs so the 256 MiB Infinity Cache cannot
+    keep X resident between launches."""
+    Xs = [torch.randn(n, F, device=dev) for _ in range(pairs)]
+    Ys = [torch.empty(n, F, device=dev) for _ in range(pairs)]
+    i = [0]
+
+    def fn():
+        k = i[0] % pairs
+        ops.spmm(g_csr, Xs[k], Ys[k])
+        i[0] += 1
+    return timeit(fn, warm=pairs * 2, reps=pairs * 10)
+
+
+def identity_graph(n):
+    ei = np.stack([np.arange(n), np.arange(n)]).astype(np.int64)
+    return ops.DConvGraph(torch.from_numpy(ei).to(dev), None, n)
+
+
 def probe_spmm_ns():
+    from pytorch_geometric_temporal_amd import _lib
+    lib = _lib.get_lib()
+    n = 200_000
+    gid = identity_graph(n)
+    us = _rot_time(gid.fwd_o, n, 64, 6)
+    nb = ops.spmm_algorithmic_bytes(n, n, 64, False)
+    emit(probe="spmm_ns_identity_rotating", us=us, GBs=nb / us / 1e3, note="pure streaming through the tile kernel")
+    del gid
     for name, gen in (("local", syn.local_graph), ("uniform", syn.uniform_graph)):
         for deg in (8, 16):
-            ei, ew = gen(200_000, deg, seed=0)
-            g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), 200_000)
-            for F in (64, 32, 128):
-                X = torch.randn(200_000, F, device=dev)
-                Y = torch.empty_like(X)
-                us = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
-                nb = ops.spmm_algorithmic_bytes(200_000, g.E, F, False)
-                emit(probe="spmm_ns", graph=name, deg=deg, F=F, E=int(g.E), us=us, alg_MB=nb / 1e6,
-                     GBs=nb / us / 1e3, frac=nb / us / 1e3 / 8000)
-            del g
+            ei, ew = gen(n, deg, seed=0)
+            g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
+            nb = ops.spmm_algorithmic_bytes(n, g.E, 64, False)
+            X = torch.randn(n, 64, device=dev)
+            Y = torch.empty_like(X)
+            variants = [(64, 8, 1)]
+            if deg == 8:
+                variants += [(64, 4, 1), (32, 8, 1), (128, 8, 1), (32, 4, 1), (64, 8, 0)]
+            for rows, unroll, xcd in variants:
+                lib.tune("spmm_tile_rows", rows); lib.tune("spmm_unroll", unroll); lib.tune("spmm_tile_xcd", xcd)
+                us_res = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
+                us_rot = _rot_time(g.fwd_o, n, 64, 6)
+                emit(probe="spmm_ns", graph=name, deg=deg, F=64, tile_rows=rows, unroll=unroll, xcd=xcd, E=int(g.E),
+                     alg_MB=nb / 1e6, us_resident=us_res, frac_resident=nb / us_res / 1e3 / 8000,
+                     us_rotating=us_rot, GBs_rotating=nb / us_rot / 1e3, frac_rotating=nb / us_rot / 1e3 / 8000)
+            lib.tune("spmm_tile_rows", 64); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_xcd", 1)
+            del g, X, Y
 
 
 def probe_spmm_batched():
+    from pytorch_geometric_temporal_amd import _lib
+    lib = _lib.get_lib()
     ei, ew = syn.sensor_graph(207, 1515, seed=0)
     g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), 207)
-    for B, C in ((64, 66), (256, 66), (1024, 66), (4096, 66), (1024, 4), (16384, 4), (65536, 4), (1024, 64)):
+    gid = identity_graph(207)
+    for B, C in ((64, 66), (256, 66), (1024, 66), (4096, 66), (1024, 64), (16384, 4)):
         F = B * C
-        X = torch.randn(207, F, device=dev)
-        Y = torch.empty_like(X)
-        T = torch.randn(207, F, device=dev)
-        us = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
+        pairs = max(2, int(700e6 // (2 * 207 * F * 4)) + 1)
+        pairs = min(pairs, 64)
         nb = ops.spmm_algorithmic_bytes(207, g.E, F, False)
-        us2 = timeit(lambda: ops.spmm(g.fwd_o, X, Y, T=T, alpha=2.0, beta=-1.0))
-        nb2 = ops.spmm_algorithmic_bytes(207, g.E, F, True)
-        emit(probe="spmm_metrla_nodemajor", B=B, C=C, us=us, alg_MB=nb / 1e6, GBs=nb / us / 1e3,
-             frac=nb / us / 1e3 / 8000, us_epi=us2, GBs_epi=nb2 / us2 / 1e3)
-        del X, Y, T
+        us_id = _rot_time(gid.fwd_o, 207, F, pairs)
+        emit(probe="spmm_nodemajor_identity_rotating", B=B, C=C, us=us_id,
+             GBs=ops.spmm_algorithmic_bytes(207, 207, F, False) / us_id / 1e3)
+        for unroll, xcd in ((8, 1), (4, 1), (8, 0)):
+            lib.tune("spmm_unroll", unroll); lib.tune("spmm_wide_xcd", xcd)
+            us = _rot_time(g.fwd_o, 207, F, pairs)
+            emit(probe="spmm_metrla_nodemajor_rotating", B=B, C=C, unroll=unroll, xcd=xcd, pairs=pairs, us=us,
+                 alg_MB=nb / 1e6, GBs=nb / us / 1e3, frac=nb / us / 1e3 / 8000)
+        lib.tune("spmm_unroll", 8); lib.tune("spmm_wide_xcd", 1)
 
 
 def probe_gemm():

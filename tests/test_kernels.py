@@ -311,7 +311,9 @@ def test_gru_gate_kernels_against_autograd(backend):
     d_pre_h = torch.empty(M, O, device=backend.device)
     d_pre_zr = torch.zeros(M, 2 * O, device=backend.device)
     dH = torch.empty(M, O, device=backend.device)
-    ops._gru_h_bwd(backend.t(dHn), zr, backend.t(H), ht, d_pre_h, d_pre_zr, dH, accumulate=False)
+    half = backend.t(dHn * 0.25)
+    dH.copy_(backend.t(dHn * 0.75))      # dH doubles as the second gradient input (aliased, as in the BPTT loop)
+    ops._gru_h_bwd(half, zr, backend.t(H), ht, d_pre_h, d_pre_zr, dH, accumulate=False, dHn2=dH)
     assert torch.allclose(d_pre_h.cpu(), gph, atol=1e-5)
     assert torch.allclose(d_pre_zr[:, :O].cpu(), gz_h[:, :O], atol=1e-5)
     assert torch.allclose(dH.cpu(), gH_h, atol=1e-5)
@@ -333,3 +335,55 @@ def test_spmm_wide_rows_xcd_chunk_mapping(backend, F_):
     Y = torch.full((n, F_), float("nan"), device=backend.device)
     ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0)
     assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), ATOL, RTOL, f"wide F={F_}")
+
+
+@pytest.mark.parametrize("M,segs,segk,N", [(200, 5, 66, 128), (300, 5, 66, 64), (150, 1, 128, 330), (260, 3, 7, 65),
+                                           (129, 2, 33, 40)])
+def test_gemm_large_tile_variants(backend, M, segs, segk, N):
+    """The 128-wide tiles (used for M >= 2048) forced onto small problems so the CPU test double covers them too:
+    NN with float2 / scalar A loads, NT (k-major B staging), segmented output, and the TN weight-gradient kernel."""
+    lib = _lib.get_lib()
+    lib.tune("gemm_small_tiles", 2)
+    try:
+        g = torch.Generator().manual_seed(M * 7 + N)
+        A = torch.randn(segs, M, segk, generator=g)
+        W = torch.randn(segs * segk, N, generator=g)
+        b = torch.randn(N, generator=g)
+        Acat = torch.cat([A[j] for j in range(segs)], dim=1).double()
+        ref = Acat @ W.double() + b.double()
+        Ad, Wd, bd = A.to(backend.device), W.to(backend.device), b.to(backend.device)
+        C = torch.full((M, N), float("nan"), device=backend.device)
+        ops.gemm(Ad, segk, M * segk, segs, segk, Wd, N, 1, C, N, 0, N, bd, M, N)
+        assert_close_with_nonfinite(C, ref, 1e-4, 1e-5, "big NN")
+        dC = torch.randn(M, N, generator=g)
+        G = torch.full((segs, M, segk), float("nan"), device=backend.device)
+        ops.gemm(dC.to(backend.device), N, 0, 1, N, Wd, 1, N, G, segk, M * segk, segk, None, M, segs * segk)
+        refG = (dC.double() @ W.double().t()).view(M, segs, segk).permute(1, 0, 2)
+        assert_close_with_nonfinite(G, refG, 1e-4, 1e-5, "big NT")
+        dW = torch.zeros(segs * segk, N, device=backend.device)
+        db = torch.zeros(N, device=backend.device)
+        ops.gemm_tn_acc(Ad, segk, M * segk, segs, segk, dC.to(backend.device), N, dW, N, db, M, N)
+        assert_close_with_nonfinite(dW, Acat.t() @ dC.double(), 2e-4, 1e-5, "big TN")
+        assert_close_with_nonfinite(db, dC.double().sum(0), 2e-4, 1e-5, "big TN bias")
+    finally:
+        lib.tune("gemm_small_tiles", 0)
+
+
+def test_spmm_tuning_variants_agree(backend):
+    lib = _lib.get_lib()
+    n = 300 if backend.name == "emu" else 5000
+    csr = random_csr(n, 0, 20, seed=11, device=backend.device)
+    X = torch.randn(n, 64).to(backend.device)
+    ref = spmm_reference(csr, X, None, 1.0, 0.0)
+    try:
+        for rows in (32, 64, 128):
+            for unroll in (4, 8):
+                for xcd in (0, 1):
+                    lib.tune("spmm_tile_rows", rows); lib.tune("spmm_unroll", unroll); lib.tune("spmm_tile_xcd", xcd)
+                    Y = torch.full((n, 64), float("nan"), device=backend.device)
+                    ops.spmm(csr, X, Y)
+                    assert_close_with_nonfinite(Y, ref, ATOL, RTOL, f"rows={rows} unroll={unroll} xcd={xcd}")
+        with pytest.raises(_lib.PgtError, match="unknown key"):
+            lib.tune("no_such_knob", 1)
+    finally:
+        lib.tune("spmm_tile_rows", 64); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_xcd", 1)

@@ -22,6 +22,7 @@
  *   pgt_spmm_csr_f32      MessagePassing.propagate(aggr="add") + message():
  *                         dcrnn.py:39-40,86-87,95-100,300-313; astgcn.py:169-175,185-190; evolvegcno.py:95-101
  *                         (index_select -> norm*x_j -> scatter_add, fused, with the 2*P*T - T0 epilogue of dcrnn.py:96,100)
+ *   pgt_spmm_csr_band_f32 the same propagate call sites on a locality-ordered graph (LDS-window schedule)
  *   pgt_gemm_f32          the dense feature transforms: dcrnn.py:81-83,88-92,101-105 (torch.matmul on weight[d][k]);
  *                         PyG Linear in GCNConv/ChebConv; temporalgcn.py:84,90,96 (linear_{z,r,h})
  *   pgt_gemm_tn_acc_f32   autograd of the above w.r.t. the weights (torch autograd in the reference)
@@ -42,7 +43,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 1
+#define PGT_ABI_VERSION 2
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -120,6 +121,21 @@ int pgt_cheb_prep(const int64_t* edge_index, const float* edge_weight, int64_t E
 int pgt_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                      const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt,
                      float alpha, float beta, int64_t F, pgt_stream_t stream);
+
+/* Same contract as pgt_spmm_csr_f32 plus a locality hint: `halo` > 0 promises that MOST slots satisfy
+ * |col[q] - row| <= halo (a bandwidth-reduced / locality-ordered node numbering, as road-sensor graphs have).
+ * For F == 64 (16-byte aligned operands) and halo <= 96 the launch then slides a window of X rows through LDS and
+ * serves the neighbour gather from LDS instead of the vector L1; slots outside the window are still read from
+ * global memory, so the result is correct for ANY operator — the hint only selects the faster schedule.
+ * Other shapes, or halo == 0, run pgt_spmm_csr_f32. */
+int pgt_spmm_csr_band_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                          const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt,
+                          float alpha, float beta, int64_t F, int32_t halo, pgt_stream_t stream);
+
+/* out2[0] = #slots with |col - row| <= 32, out2[1] = #slots with |col - row| <= 96 (device int32[2]); the host
+ * derives the `halo` hint above from these two counts once per prepared graph. */
+int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out2,
+                     pgt_stream_t stream);
 
 /* Same with a per-batch dense attention multiplier (ChebConvAttention hop 1, astgcn.py:157,169-171):
  * rows are node-major [N][B][C]; the coefficient of slot q of row i for batch b is val[q] * S[b, i, col[q]]

@@ -30,6 +30,8 @@ int g_tile_xcd = 1;    // hand tiles to XCDs in contiguous ranges
 int g_tile_rows = 64;  // rows per tile for the F = 64 fast path (32 | 64 | 128)
 int g_unroll = 8;      // neighbour loads in flight per lane group (4 | 8)
 int g_wide_xcd = 1;    // XCD-slab block mapping of the wide kernel
+int g_band_blocks = 4;  // band kernel: resident workgroups per CU the chunking aims at
+int g_band_xcd = 1;     // band kernel: contiguous chunk ranges per XCD
 
 template <int VEC>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[VEC]) {
@@ -161,6 +163,140 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
     }
     stv<VEC>(Y + (int64_t)(r0 + r) * ldy + f, out);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// spmm_band64_kernel<RING> — F = 64 floats per row on a locality-ordered (banded) operator.
+//
+// Why: the per-row gather of the tile kernel moves deg x 256 B through the CU's vector L1 for every 256 B it
+// writes; on MI355X a CU sustains only ~64 cache lines in flight, so at in-degree 8 the launch is bound by that
+// queue (measured: HBM traffic == algorithmic bytes, 3.2 TB/s) and not by HBM.  Here a workgroup owns a contiguous
+// chunk of rows and slides a RING-row window of X through LDS (RING x 256 B, rows [s0 - H, s0 + 64 + H) resident
+// while rows [s0, s0 + 64) are produced, H = (RING - 64) / 2).  Every X row goes through the vector memory path
+// once per chunk (plus 2H halo rows per chunk, L2 hits) with fully coalesced 256-B reads, and the deg-fold gather
+// is served by ds_read_b128 (one 256-B row per 16-lane group: conflict-free, 256 B/clk/CU).  Neighbours outside
+// the resident window (the wrap-around rows, or a graph that is not banded) fall back to a global read, so the
+// kernel is correct for any operator; the host only selects it when most slots are within the halo.
+// (col, val) never touch LDS: each 16-lane group loads up to 16 slots of its row with one coalesced read and
+// broadcasts them with ds_bpermute (__shfl, width 16).  Accumulation is sequential in slot order: deterministic.
+template <int RING>
+__global__ __launch_bounds__(256) void spmm_band64_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    int n_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt,
+    float alpha, float beta, int rows_per_chunk, int xcd_remap) {
+  constexpr int S = 64, H = (RING - S) / 2;
+  __shared__ float4 s_x[RING * 16];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, l16 = lane & 15;
+  const int chunk = xcd_remap ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int c0 = chunk * rows_per_chunk;
+  if (c0 >= n_rows) return;  // whole workgroup
+  const int c1 = (c0 + rows_per_chunk < n_rows) ? c0 + rows_per_chunk : n_rows;
+
+  const int rg = tid >> 4;  // 16 row-groups of 16 lanes stage 16 rows per pass
+  // leading part of the first window: rows [c0 - H, c0 + H)
+  {
+    const int a = (c0 - H > 0) ? c0 - H : 0;
+    const int b = (c0 + H < n_rows) ? c0 + H : n_rows;
+    for (int r = a + rg; r < b; r += 16)
+      s_x[(r & (RING - 1)) * 16 + l16] = *reinterpret_cast<const float4*>(X + (int64_t)r * ldx + l16 * 4);
+  }
+  for (int s0 = c0; s0 < c1; s0 += S) {
+    {  // rows [s0 + H, s0 + S + H): four independent 256-B row reads per 16-lane group, then the LDS writes
+      const int a = s0 + H;
+      float4 t[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = a + rg + 16 * i;
+        const int rc = r < n_rows ? r : n_rows - 1;  // clamped: the load is unconditional, the LDS write is not
+        t[i] = *reinterpret_cast<const float4*>(X + (int64_t)rc * ldx + l16 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = a + rg + 16 * i;
+        if (r < n_rows) s_x[(r & (RING - 1)) * 16 + l16] = t[i];
+      }
+    }
+    const int send = (s0 + S < c1) ? s0 + S : c1;  // rows [s0, send) this step
+    const int w_lo = (s0 - H > 0) ? s0 - H : 0;
+    const int w_hi = (s0 + S + H < n_rows) ? s0 + S + H : n_rows;
+    // rowptr[s0 .. s0 + 64] for the whole step, two coalesced reads per wave
+    const int i0 = (s0 + lane < n_rows) ? s0 + lane : n_rows;
+    const int i1 = (s0 + lane + 1 < n_rows) ? s0 + lane + 1 : n_rows;
+    const int rp0 = rowptr[i0], rp1 = rowptr[i1];
+    __syncthreads();
+
+    // 16 row-quads per step, dealt round-robin to the 4 waves; each 16-lane group of a wave owns one row of the quad
+#pragma unroll 1
+    for (int qi = wave; qi * 4 < send - s0; qi += 4) {
+      const int rl = qi * 4 + g;  // row within the step (< 64)
+      const int row = s0 + rl;
+      const int a = __shfl(rp0, rl), b = __shfl(rp1, rl);
+      const int n = (row < send) ? b - a : 0;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q0 = 0; __ballot(q0 < n) != 0ull; q0 += 16) {
+        const bool mine = q0 + l16 < n;
+        const int mc = mine ? col[a + q0 + l16] : 0;
+        const float mv = mine ? val[a + q0 + l16] : 0.f;
+        // wave-uniform: does any live slot of this 16-slot chunk point outside the resident window?
+        const bool any_far = __ballot(mine && (mc < w_lo || mc >= w_hi)) != 0ull;
+        for (int u0 = 0; u0 < 16 && __ballot(q0 + u0 < n) != 0ull; u0 += 8) {
+          int c[8];
+          float v[8];
+          float4 x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { c[u] = __shfl(mc, u0 + u, 16); v[u] = __shfl(mv, u0 + u, 16); }
+          // every ring slot is mapped LDS, so the read is unconditional (a dead slot's value is discarded below)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = s_x[(c[u] & (RING - 1)) * 16 + l16];
+          if (any_far) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (q0 + u0 + u < n && (c[u] < w_lo || c[u] >= w_hi))
+                x[u] = *reinterpret_cast<const float4*>(X + (int64_t)c[u] * ldx + l16 * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool live = q0 + u0 + u < n;  // select, not multiply-by-zero: a dead slot must not inject NaN
+            acc.x = live ? fmaf(v[u], x[u].x, acc.x) : acc.x;
+            acc.y = live ? fmaf(v[u], x[u].y, acc.y) : acc.y;
+            acc.z = live ? fmaf(v[u], x[u].z, acc.z) : acc.z;
+            acc.w = live ? fmaf(v[u], x[u].w, acc.w) : acc.w;
+          }
+        }
+      }
+      if (row < send) {
+        float4 o;
+        if (T != nullptr) {
+          const float4 t = *reinterpret_cast<const float4*>(T + (int64_t)row * ldt + l16 * 4);
+          o = make_float4(alpha * acc.x + beta * t.x, alpha * acc.y + beta * t.y, alpha * acc.z + beta * t.z,
+                          alpha * acc.w + beta * t.w);
+        } else {
+          o = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+        }
+        *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + l16 * 4) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// slots of a CSR operator whose source lies within +-32 / +-96 rows of the destination (selects the band kernel)
+__global__ __launch_bounds__(256) void csr_locality_kernel(const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, int n_rows,
+                                                           int32_t* out) {
+  const int row = (int)(blockIdx.x * 256 + threadIdx.x);
+  int n32 = 0, n96 = 0;
+  if (row < n_rows) {
+    for (int q = rowptr[row]; q < rowptr[row + 1]; ++q) {
+      const int d = col[q] - row;
+      n32 += (d >= -32 && d <= 32) ? 1 : 0;
+      n96 += (d >= -96 && d <= 96) ? 1 : 0;
+    }
+  }
+  if (n32) atomicAdd(&out[0], n32);
+  if (n96) atomicAdd(&out[1], n96);
 }
 
 template <int VEC, int U>
@@ -305,6 +441,8 @@ int pgt_spmm_tune(const char* key, int value) {
   if (strcmp(key, "spmm_tile_rows") == 0) { g_tile_rows = value; return 1; }
   if (strcmp(key, "spmm_unroll") == 0) { g_unroll = value; return 1; }
   if (strcmp(key, "spmm_wide_xcd") == 0) { g_wide_xcd = value; return 1; }
+  if (strcmp(key, "spmm_band_blocks") == 0) { g_band_blocks = value > 0 ? value : 1; return 1; }
+  if (strcmp(key, "spmm_band_xcd") == 0) { g_band_xcd = value; return 1; }
   return 0;
 }
 
@@ -326,6 +464,61 @@ extern "C" int pgt_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   if (ok(4)) return launch_spmm<4>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   if (ok(2)) return launch_spmm<2>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   return launch_spmm<1>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
+}
+
+static int spmm_validate(const char* who, const int32_t* rowptr, int64_t n_rows, const float* X, int64_t ldx,
+                         float* Y, int64_t ldy, const float* T, int64_t ldt, int64_t F) {
+  (void)who;
+  PGT_REQUIRE(rowptr && X && Y, "pgt_spmm_csr_f32: null pointer");
+  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) - 128 && F < ((int64_t)1 << 31), "pgt_spmm_csr_f32: size exceeds int32 indexing");
+  PGT_REQUIRE(ldx >= F && ldy >= F && (T == nullptr || ldt >= F), "pgt_spmm_csr_f32: row stride smaller than F");
+  PGT_REQUIRE(Y != X, "pgt_spmm_csr_f32: Y must not alias X");
+  return PGT_OK;
+}
+
+extern "C" int pgt_spmm_csr_band_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                     const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T,
+                                     int64_t ldt, float alpha, float beta, int64_t F, int32_t halo,
+                                     pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0 && F >= 0, "pgt_spmm_csr_f32: negative size");
+  if (n_rows == 0 || F == 0) return PGT_OK;
+  if (int rc = spmm_validate("pgt_spmm_csr_band_f32", rowptr, n_rows, X, ldx, Y, ldy, T, ldt, F)) return rc;
+  PgtVecPick vp;
+  vp.width(F); vp.operand(X, ldx); vp.operand(Y, ldy); vp.operand(T, ldt);
+  if (halo <= 0 || halo > 96 || F != 64 || vp.v != 4)
+    return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
+  const int ring = halo <= 32 ? 128 : 256;
+  // chunking: aim at g_band_blocks resident workgroups per CU (LDS admits 4 at RING = 128, 2 at RING = 256)
+  const int per_cu = ring == 128 ? (g_band_blocks < 4 ? g_band_blocks : 4) : (g_band_blocks < 2 ? g_band_blocks : 2);
+  int64_t nblk = 256 * (int64_t)per_cu;
+  int64_t rpc = pgt_cdiv(pgt_cdiv(n_rows, nblk), 16) * 16;
+  if (rpc < 64) rpc = 64;
+  nblk = pgt_cdiv(n_rows, rpc);
+  dim3 grid((unsigned)nblk), block(256);
+  if (ring == 128) {
+    PGT_LAUNCH((spmm_band64_kernel<128>), grid, block, stream, rowptr, col, val, (int)n_rows, X, ldx, Y, ldy, T, ldt,
+               alpha, beta, (int)rpc, g_band_xcd);
+  } else {
+    PGT_LAUNCH((spmm_band64_kernel<256>), grid, block, stream, rowptr, col, val, (int)n_rows, X, ldx, Y, ldy, T, ldt,
+               alpha, beta, (int)rpc, g_band_xcd);
+  }
+  return pgt_check_launch("pgt_spmm_csr_band_f32");
+}
+
+extern "C" int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out2,
+                                pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0, "pgt_csr_locality: negative size");
+  PGT_REQUIRE(out2 != nullptr, "pgt_csr_locality: null pointer");
+  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) - 256, "pgt_csr_locality: size exceeds int32 indexing");
+  if (hipMemsetAsync(out2, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+    pgt_set_error("pgt_csr_locality: memset failed");
+    return PGT_ERR_LAUNCH;
+  }
+  if (n_rows == 0) return PGT_OK;
+  PGT_REQUIRE(rowptr && col, "pgt_csr_locality: null pointer");
+  PGT_LAUNCH(csr_locality_kernel, dim3((unsigned)pgt_cdiv(n_rows, 256)), dim3(256), stream, rowptr, col, (int)n_rows,
+             out2);
+  return pgt_check_launch("pgt_csr_locality");
 }
 
 extern "C" int pgt_spmm_csr_att_f32(const int32_t* rowptr, const int32_t* col, const float* val,

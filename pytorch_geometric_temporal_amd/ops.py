@@ -18,16 +18,36 @@ I32 = torch.int32
 # --------------------------------------------------------------------------------------------- graph handles
 
 class Csr:
-    __slots__ = ("rowptr", "col", "val", "n_rows")
+    """CSR operator by destination row.  `halo` is the locality hint handed to pgt_spmm_csr_band_f32: 32 / 96 when at
+    least 3/4 of the slots have |col - row| within that distance (locality-ordered node numbering), else 0."""
+    __slots__ = ("rowptr", "col", "val", "n_rows", "halo")
 
     def __init__(self, n_rows, cap, device):
         self.n_rows = n_rows
+        self.halo = 0
         self.rowptr = torch.zeros(n_rows + 1, dtype=I32, device=device)
         self.col = torch.zeros(max(cap, 1), dtype=I32, device=device)
         self.val = torch.zeros(max(cap, 1), dtype=F32, device=device)
 
     def struct(self):
         return CsrStruct(ptr(self.rowptr), ptr(self.col), ptr(self.val))
+
+
+BAND_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; keep the plain schedule
+
+
+def measure_locality(csrs):
+    """Set `halo` on each operator from pgt_csr_locality (one small launch per operator, ONE host read for all)."""
+    lib = _lib.get_lib()
+    todo = [c for c in csrs if c.n_rows >= BAND_MIN_ROWS]
+    if not todo:
+        return
+    out = torch.zeros(len(todo), 3, dtype=I32, device=todo[0].rowptr.device)
+    for i, c in enumerate(todo):
+        lib.call("pgt_csr_locality", ptr(c.rowptr), ptr(c.col), c.n_rows, ptr(out[i]), stream_of(lib, c.rowptr))
+        out[i, 2:3].copy_(c.rowptr[c.n_rows:c.n_rows + 1])
+    for c, (n32, n96, nnz) in zip(todo, out.tolist()):
+        c.halo = 32 if 4 * n32 >= 3 * nnz > 0 else (96 if 4 * n96 >= 3 * nnz > 0 else 0)
 
 
 def _edge_inputs(lib, edge_index, edge_weight):
@@ -66,6 +86,7 @@ class DConvGraph:
         st = DConvGraphStruct(self.fwd_o.struct(), self.fwd_i.struct(), self.bwd_o.struct(), self.bwd_i.struct(),
                               ptr(self.deg_out), ptr(self.deg_in), ptr(self.info))
         lib.call("pgt_dconv_prep", ptr(ei), ptr(ew), E, N, ctypes.byref(st), ptr(ws), ws_bytes, stream_of(lib, ei))
+        measure_locality((self.fwd_o, self.fwd_i, self.bwd_o, self.bwd_i))
         if validate:
             dup, zero, oob, _ = self.info.tolist()  # one host sync per *new* graph
             if oob:
@@ -105,6 +126,7 @@ class SymGraph:
                      ptr(ws), ws_bytes, stream_of(lib, ei))
         else:
             raise ValueError(kind)
+        measure_locality((self.fwd, self.bwd))
         if validate:
             oob = int(self.info[2])
             if oob:
@@ -215,8 +237,9 @@ def _rows(t, name):
     return ptr(t), (t.stride(0) if t.size(0) > 1 else max(t.size(1), t.stride(0)))
 
 
-def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0):
-    """Y = alpha * A @ X + beta * T on [n_rows, F] views (pgt_spmm_csr_f32)."""
+def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, halo=None):
+    """Y = alpha * A @ X + beta * T on [n_rows, F] views (pgt_spmm_csr_band_f32; `halo` overrides the operator's
+    measured locality hint)."""
     lib = _lib.get_lib()
     for t, n in ((X, "X"), (Y, "Y")) + (((T, "T"),) if T is not None else ()):
         check_tensor(lib, t, n)
@@ -226,10 +249,11 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0):
     yp, ldy = _rows(Y, "Y")
     tp, ldt = _rows(T, "T") if T is not None else (ptr(None), 0)
     st = stream_of(lib, X)
+    halo = int(getattr(csr, "halo", 0) if halo is None else halo)
     work = spmm_algorithmic_bytes(csr.n_rows, csr.col.numel(), X.size(1), T is not None) if KERNEL_TIMER else 0
     _timed("spmm", work, lambda: lib.call(
-        "pgt_spmm_csr_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,
-        float(alpha), float(beta), X.size(1), st))
+        "pgt_spmm_csr_band_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,
+        float(alpha), float(beta), X.size(1), halo, st))
     return Y
 
 

@@ -60,13 +60,17 @@ def identity_graph(n):
 
 
 def probe_spmm_ns():
+    """North-star aggregation (N = 200 000, F = 64): LDS-window (band) schedule vs the plain row-tile schedule."""
     from pytorch_geometric_temporal_amd import _lib
     lib = _lib.get_lib()
     n = 200_000
     gid = identity_graph(n)
-    us = _rot_time(gid.fwd_o, n, 64, 6)
     nb = ops.spmm_algorithmic_bytes(n, n, 64, False)
-    emit(probe="spmm_ns_identity_rotating", us=us, GBs=nb / us / 1e3, note="pure streaming through the tile kernel")
+    for halo in (0, 32):
+        gid.fwd_o.halo = halo
+        us = _rot_time(gid.fwd_o, n, 64, 6)
+        emit(probe="spmm_ns_identity_rotating", halo=halo, us=us, GBs=nb / us / 1e3,
+             note="pure streaming through the kernel (in-degree 1)")
     del gid
     for name, gen in (("local", syn.local_graph), ("uniform", syn.uniform_graph)):
         for deg in (8, 16):
@@ -75,17 +79,24 @@ def probe_spmm_ns():
             nb = ops.spmm_algorithmic_bytes(n, g.E, 64, False)
             X = torch.randn(n, 64, device=dev)
             Y = torch.empty_like(X)
-            variants = [(64, 8, 1)]
-            if deg == 8:
-                variants += [(64, 4, 1), (32, 8, 1), (128, 8, 1), (32, 4, 1), (64, 8, 0)]
-            for rows, unroll, xcd in variants:
-                lib.tune("spmm_tile_rows", rows); lib.tune("spmm_unroll", unroll); lib.tune("spmm_tile_xcd", xcd)
+            measured = g.fwd_o.halo
+            variants = [dict(halo=0, rows=64, unroll=8), dict(halo=0, rows=32, unroll=8)]
+            if name == "local":
+                variants += [dict(halo=32, k=4, xcd=1), dict(halo=32, k=3, xcd=1), dict(halo=32, k=2, xcd=1),
+                             dict(halo=32, k=4, xcd=0), dict(halo=96, k=2, xcd=1)]
+            else:
+                variants += [dict(halo=32, k=4, xcd=1)]
+            for v in variants:
+                g.fwd_o.halo = v["halo"]
+                lib.tune("spmm_tile_rows", v.get("rows", 64)); lib.tune("spmm_unroll", v.get("unroll", 8))
+                lib.tune("spmm_band_blocks", v.get("k", 4)); lib.tune("spmm_band_xcd", v.get("xcd", 1))
                 us_res = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
                 us_rot = _rot_time(g.fwd_o, n, 64, 6)
-                emit(probe="spmm_ns", graph=name, deg=deg, F=64, tile_rows=rows, unroll=unroll, xcd=xcd, E=int(g.E),
-                     alg_MB=nb / 1e6, us_resident=us_res, frac_resident=nb / us_res / 1e3 / 8000,
-                     us_rotating=us_rot, GBs_rotating=nb / us_rot / 1e3, frac_rotating=nb / us_rot / 1e3 / 8000)
-            lib.tune("spmm_tile_rows", 64); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_xcd", 1)
+                emit(probe="spmm_ns", graph=name, deg=deg, F=64, measured_halo=measured, E=int(g.E), alg_MB=nb / 1e6,
+                     us_resident=us_res, frac_resident=nb / us_res / 1e3 / 8000, us_rotating=us_rot,
+                     GBs_rotating=nb / us_rot / 1e3, frac_rotating=nb / us_rot / 1e3 / 8000, **v)
+            lib.tune("spmm_tile_rows", 64); lib.tune("spmm_unroll", 8)
+            lib.tune("spmm_band_blocks", 4); lib.tune("spmm_band_xcd", 1)
             del g, X, Y
 
 

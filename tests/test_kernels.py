@@ -387,3 +387,83 @@ def test_spmm_tuning_variants_agree(backend):
             lib.tune("no_such_knob", 1)
     finally:
         lib.tune("spmm_tile_rows", 64); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_xcd", 1)
+
+
+# ------------------------------------------------------------------------------------------------ band (LDS-window) SpMM
+
+def banded_csr(n, deg_lo, deg_hi, window, seed, device, far_frac=0.0, heavy_row=None):
+    """rows with sources inside +-window (wrapping modulo n at both ends, like synthetic.local_graph) plus a fraction
+    of far-away sources; optionally one row with hundreds of slots."""
+    rng = np.random.default_rng(seed)
+    degs = rng.integers(deg_lo, deg_hi + 1, size=n)
+    if heavy_row is not None:
+        degs[heavy_row] = 300
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(degs)
+    rows = np.repeat(np.arange(n), degs)
+    col = (rows + rng.integers(-window, window + 1, size=rows.size)) % n
+    far = rng.random(rows.size) < far_frac
+    col[far] = rng.integers(0, n, size=int(far.sum()))
+    csr = ops.Csr.__new__(ops.Csr)
+    csr.n_rows, csr.halo = n, 0
+    csr.rowptr = torch.from_numpy(rowptr).to(device)
+    csr.col = torch.from_numpy(col.astype(np.int32)).to(device)
+    csr.val = torch.from_numpy(rng.standard_normal(rows.size).astype(np.float32)).to(device)
+    return csr
+
+
+@pytest.mark.parametrize("halo,window,n", [(32, 32, 333), (32, 40, 1000), (96, 96, 700), (96, 20, 64), (32, 5, 17)])
+def test_spmm_band_window_matches_plain_and_reference(backend, halo, window, n):
+    if backend.name == "hip":
+        n *= 37
+    csr = banded_csr(n, 0, 20, window, seed=n, device=backend.device, far_frac=0.05, heavy_row=min(n - 1, 70))
+    g = torch.Generator().manual_seed(n)
+    X = torch.randn(n, 64, generator=g).to(backend.device)
+    T = torch.randn(n, 64, generator=g).to(backend.device)
+    ref = spmm_reference(csr, X, None, 1.0, 0.0)
+    Yb = torch.full((n, 64), float("nan"), device=backend.device)
+    ops.spmm(csr, X, Yb, halo=halo)
+    assert_close_with_nonfinite(Yb, ref, 5e-5, 1e-5, "band")
+    Yp = torch.empty_like(Yb)
+    ops.spmm(csr, X, Yp, halo=0)
+    assert torch.equal(Yb, Yp)          # same slot-order fma chain in both schedules: bit-identical
+    ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0, halo=halo)
+    assert_close_with_nonfinite(Yb, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "band epilogue")
+    Tc = T.clone()
+    ops.spmm(csr, X, Tc, T=Tc, alpha=2.0, beta=1.0, halo=halo)
+    assert_close_with_nonfinite(Tc, spmm_reference(csr, X, T, 2.0, 1.0), 5e-5, 1e-5, "band aliased")
+
+
+def test_spmm_band_strided_nonfinite_and_fallback_shapes(backend):
+    n = 300 if backend.name == "emu" else 9000
+    csr = banded_csr(n, 1, 9, 30, seed=5, device=backend.device)
+    big = torch.randn(n, 80).to(backend.device)
+    big[7, 10] = float("inf")
+    big[n - 1, 12] = float("nan")
+    X = big[:, 8:72]
+    out = torch.zeros(n, 100, device=backend.device)
+    Y = out[:, 4:68]
+    ops.spmm(csr, X, Y, halo=32)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "band strided")
+    assert float(out[:, :4].abs().max()) == 0.0 and float(out[:, 68:].abs().max()) == 0.0
+    # shapes the window schedule does not cover run the plain kernels under the same entry point
+    for F_ in (32, 66, 128):
+        Xf = torch.randn(n, F_).to(backend.device)
+        Yf = torch.empty_like(Xf)
+        ops.spmm(csr, Xf, Yf, halo=32)
+        assert_close_with_nonfinite(Yf, spmm_reference(csr, Xf, None, 1.0, 0.0), 5e-5, 1e-5, f"fallback F={F_}")
+
+
+def test_locality_hint_is_measured_per_operator(backend):
+    n = 5000
+    ei, ew = syn.local_graph(n, 4, window=64, seed=0)
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), n)
+    assert g.fwd_o.halo == 32 and g.bwd_o.halo == 32 and g.fwd_i.halo == 32
+    ei, ew = syn.uniform_graph(n, 4, seed=0)
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), n)
+    assert g.fwd_o.halo == 0
+    ei, ew = syn.local_graph(n, 4, window=150, seed=0)
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), n)
+    assert g.fwd_o.halo == 96
+    small = ops.DConvGraph(*[backend.t(a) for a in syn.sensor_graph(207, 1515, seed=0)], 207)
+    assert small.fwd_o.halo == 0          # tiny graphs keep the plain schedule

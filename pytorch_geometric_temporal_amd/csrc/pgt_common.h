@@ -27,6 +27,24 @@ typedef float pgt_f32x16 __attribute__((ext_vector_type(16)));
 
 #define PGT_WAVE 64
 
+// lab/ns_lab.hip defines this to record an in-kernel timeline; a no-op in the library
+#ifndef PGT_TRACE_MARK
+#define PGT_TRACE_MARK(slot) do { } while (0)
+#endif
+
+// 16-byte register vector.  HIP's float4 is a struct: arrays of it that live across a loop are copied with memcpy and
+// end up in scratch / promoted to LDS; the native vector type stays in VGPRs.
+#ifdef PGT_EMU
+typedef float4 pgt_f4;
+#else
+typedef float pgt_f4 __attribute__((ext_vector_type(4)));
+#endif
+static __device__ __forceinline__ pgt_f4 pgt_mk4(float a, float b, float c, float d) {
+  pgt_f4 r;
+  r.x = a; r.y = b; r.z = c; r.w = d;
+  return r;
+}
+
 void pgt_set_error(const char* fmt, ...);
 // tuning knobs (pgt_tune): each translation unit owns its own
 void pgt_gemm_set_force_small(int v);

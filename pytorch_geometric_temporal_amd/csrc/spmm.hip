@@ -27,10 +27,10 @@ constexpr int CAP_PER_ROW = 24;  // LDS-staged slots per tile = 24 * TR (12 KiB 
 
 // A/B knobs (pgt_tune); the defaults are the shipped configuration
 int g_tile_xcd = 1;    // hand tiles to XCDs in contiguous ranges
-int g_tile_rows = 64;  // rows per tile for the F = 64 fast path (32 | 64 | 128)
+int g_tile_rows = 32;  // rows per tile for the F = 64 fast path (32 | 64 | 128); 32: finer tail, measured best
 int g_unroll = 8;      // neighbour loads in flight per lane group (4 | 8)
 int g_wide_xcd = 1;    // XCD-slab block mapping of the wide kernel
-int g_band_blocks = 4;  // band kernel: resident workgroups per CU the chunking aims at
+int g_band_blocks = 3;  // band kernel: resident workgroups per CU the chunking aims at (<= 3: 160-VGPR kernel)
 int g_band_xcd = 1;     // band kernel: contiguous chunk ranges per XCD
 
 template <int VEC>
@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
   const int r0 = tile * TR;
   const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
 
+  PGT_TRACE_MARK(0);
   if (tid <= nr) s_rp[tid] = rowptr[r0 + tid];
   __syncthreads();
+  PGT_TRACE_MARK(1);
   const int e0 = s_rp[0];
   const int nnz = s_rp[nr] - e0;
   const bool staged = nnz <= CAP;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
     }
   }
   __syncthreads();
+  PGT_TRACE_MARK(2);
 
   constexpr int GROUPS = 256 / LPR;
   const int g = tid / LPR;
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
     }
     stv<VEC>(Y + (int64_t)(r0 + r) * ldy + f, out);
   }
+  PGT_TRACE_MARK(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -179,13 +183,17 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
 // kernel is correct for any operator; the host only selects it when most slots are within the halo.
 // (col, val) never touch LDS: each 16-lane group loads up to 16 slots of its row with one coalesced read and
 // broadcasts them with ds_bpermute (__shfl, width 16).  Accumulation is sequential in slot order: deterministic.
+// Work distribution: static.  The rows are cut into gridDim.x contiguous chunks (rows_per_chunk each, a multiple of 4)
+// and chunk ranges are contiguous per XCD; every chunk is swept in `steps` equal steps of `srows` <= 64 rows.
+// (A dynamic per-XCD ticket counter was measured and rejected: at N = 200 000 a workgroup only owns ~3 steps, so the
+// per-chunk prologue it adds costs far more than the finish-time spread it removes: 57 us vs 33 us.)
 template <int RING>
-__global__ __launch_bounds__(256) void spmm_band64_kernel(
+__global__ __launch_bounds__(256, (RING == 128 ? 3 : 2)) void spmm_band64_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    int n_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt,
-    float alpha, float beta, int rows_per_chunk, int xcd_remap) {
-  constexpr int S = 64, H = (RING - S) / 2;
-  __shared__ float4 s_x[RING * 16];
+    int n_rows, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt,
+    float alpha, float beta, int rows_per_chunk, int srows, int xcd_remap) {
+  constexpr int S = 64, H = (RING - S) / 2;  // S: ring capacity per step; the step actually advances `srows` rows
+  __shared__ pgt_f4 s_x[RING * 16];
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, l16 = lane & 15;
@@ -193,71 +201,132 @@ __global__ __launch_bounds__(256) void spmm_band64_kernel(
   const int c0 = chunk * rows_per_chunk;
   if (c0 >= n_rows) return;  // whole workgroup
   const int c1 = (c0 + rows_per_chunk < n_rows) ? c0 + rows_per_chunk : n_rows;
-
-  const int rg = tid >> 4;  // 16 row-groups of 16 lanes stage 16 rows per pass
-  // leading part of the first window: rows [c0 - H, c0 + H)
+  PGT_TRACE_MARK(0);
   {
-    const int a = (c0 - H > 0) ? c0 - H : 0;
-    const int b = (c0 + H < n_rows) ? c0 + H : n_rows;
-    for (int r = a + rg; r < b; r += 16)
-      s_x[(r & (RING - 1)) * 16 + l16] = *reinterpret_cast<const float4*>(X + (int64_t)r * ldx + l16 * 4);
-  }
-  for (int s0 = c0; s0 < c1; s0 += S) {
-    {  // rows [s0 + H, s0 + S + H): four independent 256-B row reads per 16-lane group, then the LDS writes
-      const int a = s0 + H;
-      float4 t[4];
+  const int rg = tid >> 4;  // 16 row-groups of 16 lanes: one 256-B row each per staging pass
+  const float* Xl = X + l16 * 4;
+
+  // Software pipeline, one step (64 rows) deep: while step s is computed out of LDS, the X rows of step s+1
+  // (registers t), the (col, val) slots of step s+1 (registers mc/mv) and rowptr of step s+2 are already in
+  // flight, so no step waits on a global-memory round trip it issued itself.
+  auto clampr = [&](int r) { return r < 0 ? 0 : (r < n_rows ? r : n_rows - 1); };
+  auto load_rp = [&](int s0, int& r0, int& r1) {  // rowptr[s0 + lane], rowptr[s0 + lane + 1] (clamped at n_rows)
+    const int i0 = s0 + lane < n_rows ? s0 + lane : n_rows;
+    const int i1 = s0 + lane + 1 < n_rows ? s0 + lane + 1 : n_rows;
+    r0 = rowptr[i0];
+    r1 = rowptr[i1];
+  };
+  // first 16 slots of the wave's four row-quads of the step starting at s0
+  auto load_cv = [&](int s0, int r0, int r1, int (&qa)[4], int (&qn)[4], int (&qc)[4], float (&qv)[4]) {
+    const int send = s0 + srows < c1 ? s0 + srows : c1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = a + rg + 16 * i;
-        const int rc = r < n_rows ? r : n_rows - 1;  // clamped: the load is unconditional, the LDS write is not
-        t[i] = *reinterpret_cast<const float4*>(X + (int64_t)rc * ldx + l16 * 4);
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int rl = (wave + 4 * j) * 4 + g;
+      const int a = __shfl(r0, rl), b = __shfl(r1, rl);
+      qa[j] = a;
+      qn[j] = (s0 + rl < send) ? b - a : 0;
+      // unconditional loads from a clamped slot (keeps the number of loads in flight static, so the compiler can
+      // count them instead of draining the queue); dead lanes are masked by `qn` at use
+      const int q = (l16 < qn[j]) ? a + l16 : (b > 0 ? b - 1 : 0);
+      qc[j] = col[q];
+      qv[j] = val[q];
+    }
+  };
+
+  pgt_f4 t[4], pre[4];
+  int rpA0, rpA1, rpB0 = 0, rpB1 = 0;
+  int qa[4], qn[4], qc[4];
+  float qv[4];
+  // (rowptr loads are always issued FIRST in a phase: vmcnt retires in order, so whatever is issued behind a load
+  //  — including the Y stores — has to drain before that load's result can be used)
+  load_rp(c0, rpA0, rpA1);
+  if (c0 + srows < c1) load_rp(c0 + srows, rpB0, rpB1);
+  {
+    // leading half-window rows [c0 - H, c0 + H) and the first step's rows [c0 + H, c0 + S + H)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = a + rg + 16 * i;
-        if (r < n_rows) s_x[(r & (RING - 1)) * 16 + l16] = t[i];
+    for (int i = 0; i < 4; ++i) {
+      const int r = c0 - H + rg + 16 * i;
+      pre[i] = (i * 16 < 2 * H) ? *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(r) * ldx)) : pgt_mk4(0, 0, 0, 0);
+    }
+    pgt_f4 pre2[(2 * H > 64) ? (2 * H - 64) / 16 : 1];
+    if constexpr (2 * H > 64) {
+#pragma unroll
+      for (int i = 4; i < 2 * H / 16; ++i)
+        pre2[i - 4] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(c0 - H + rg + 16 * i) * ldx));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      t[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(c0 + H + rg + 16 * i) * ldx));
+    load_cv(c0, rpA0, rpA1, qa, qn, qc, qv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = c0 - H + rg + 16 * i;
+      if (i * 16 < 2 * H && r >= 0 && r < n_rows) s_x[(r & (RING - 1)) * 16 + l16] = pre[i];
+    }
+    if constexpr (2 * H > 64) {
+#pragma unroll
+      for (int i = 4; i < 2 * H / 16; ++i) {
+        const int r = c0 - H + rg + 16 * i;
+        if (r >= 0 && r < n_rows) s_x[(r & (RING - 1)) * 16 + l16] = pre2[i - 4];
       }
     }
-    const int send = (s0 + S < c1) ? s0 + S : c1;  // rows [s0, send) this step
-    const int w_lo = (s0 - H > 0) ? s0 - H : 0;
-    const int w_hi = (s0 + S + H < n_rows) ? s0 + S + H : n_rows;
-    // rowptr[s0 .. s0 + 64] for the whole step, two coalesced reads per wave
-    const int i0 = (s0 + lane < n_rows) ? s0 + lane : n_rows;
-    const int i1 = (s0 + lane + 1 < n_rows) ? s0 + lane + 1 : n_rows;
-    const int rp0 = rowptr[i0], rp1 = rowptr[i1];
-    __syncthreads();
+  }
 
-    // 16 row-quads per step, dealt round-robin to the 4 waves; each 16-lane group of a wave owns one row of the quad
-#pragma unroll 1
-    for (int qi = wave; qi * 4 < send - s0; qi += 4) {
-      const int rl = qi * 4 + g;  // row within the step (< 64)
-      const int row = s0 + rl;
-      const int a = __shfl(rp0, rl), b = __shfl(rp1, rl);
-      const int n = (row < send) ? b - a : 0;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  PGT_TRACE_MARK(1);
+  // One step.  (ca, cn, cc, cv) hold this step's slots (loaded a step ago); the next step's go to (na, nn, nc, nv).
+  // The two register sets ping-pong between calls: copying a set would make the compiler wait for its loads.
+  auto step = [&](const int s0, int (&ca)[4], int (&cn)[4], int (&cc)[4], float (&cv)[4], int (&na)[4], int (&nn)[4],
+                  int (&nc)[4], float (&nv)[4], int& rc0, int& rc1, int& rn0, int& rn1) {
+    // rows [s0 + H, s0 + srows + H) of this step, fetched one step ago
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = s0 + H + rg + 16 * i;
+      if (r < n_rows && rg + 16 * i < srows) s_x[(r & (RING - 1)) * 16 + l16] = t[i];
+    }
+    __syncthreads();
+    PGT_TRACE_MARK(2 + 2 * ((s0 - c0) / srows));
+    const bool more = s0 + srows < c1;
+    // the next step's loads are issued before any of this step's LDS work
+    if (more) {
+      if (s0 + 2 * srows < c1) load_rp(s0 + 2 * srows, rn0, rn1);   // rowptr of step s+2
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        t[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(s0 + srows + H + rg + 16 * i) * ldx));
+      load_cv(s0 + srows, rc0, rc1, na, nn, nc, nv);                 // slots of step s+1 (rowptr came a step ago)
+    }
+    const int send = more ? s0 + srows : c1;
+    const int w_lo = (s0 - H > 0) ? s0 - H : 0;
+    const int w_hi = (s0 + srows + H < n_rows) ? s0 + srows + H : n_rows;
+
+    // (a lambda invoked with literal quad indices: the slot registers must never be indexed dynamically)
+    auto quad = [&](const int j, const int a, const int n, int mc, float mv) {
+      const int row = s0 + (wave + 4 * j) * 4 + g;
+      pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
       for (int q0 = 0; __ballot(q0 < n) != 0ull; q0 += 16) {
         const bool mine = q0 + l16 < n;
-        const int mc = mine ? col[a + q0 + l16] : 0;
-        const float mv = mine ? val[a + q0 + l16] : 0.f;
+        if (q0 > 0) {  // rows longer than the 16 prefetched slots
+          mc = mine ? col[a + q0 + l16] : 0;
+          mv = mine ? val[a + q0 + l16] : 0.f;
+        }
         // wave-uniform: does any live slot of this 16-slot chunk point outside the resident window?
         const bool any_far = __ballot(mine && (mc < w_lo || mc >= w_hi)) != 0ull;
-        for (int u0 = 0; u0 < 16 && __ballot(q0 + u0 < n) != 0ull; u0 += 8) {
-          int c[8];
-          float v[8];
-          float4 x[8];
+        for (int u0 = 0; u0 < 16 && __ballot(q0 + u0 < n) != 0ull; u0 += 4) {
+          int c[4];
+          float v[4];
+          pgt_f4 x[4];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { c[u] = __shfl(mc, u0 + u, 16); v[u] = __shfl(mv, u0 + u, 16); }
+          for (int u = 0; u < 4; ++u) { c[u] = __shfl(mc, u0 + u, 16); v[u] = __shfl(mv, u0 + u, 16); }
           // every ring slot is mapped LDS, so the read is unconditional (a dead slot's value is discarded below)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = s_x[(c[u] & (RING - 1)) * 16 + l16];
+          for (int u = 0; u < 4; ++u) x[u] = s_x[(c[u] & (RING - 1)) * 16 + l16];
           if (any_far) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 4; ++u)
               if (q0 + u0 + u < n && (c[u] < w_lo || c[u] >= w_hi))
-                x[u] = *reinterpret_cast<const float4*>(X + (int64_t)c[u] * ldx + l16 * 4);
+                x[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c[u] * ldx));
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < 4; ++u) {
             const bool live = q0 + u0 + u < n;  // select, not multiply-by-zero: a dead slot must not inject NaN
             acc.x = live ? fmaf(v[u], x[u].x, acc.x) : acc.x;
             acc.y = live ? fmaf(v[u], x[u].y, acc.y) : acc.y;
@@ -267,19 +336,33 @@ __global__ __launch_bounds__(256) void spmm_band64_kernel(
         }
       }
       if (row < send) {
-        float4 o;
+        pgt_f4 o;
         if (T != nullptr) {
-          const float4 t = *reinterpret_cast<const float4*>(T + (int64_t)row * ldt + l16 * 4);
-          o = make_float4(alpha * acc.x + beta * t.x, alpha * acc.y + beta * t.y, alpha * acc.z + beta * t.z,
-                          alpha * acc.w + beta * t.w);
+          const pgt_f4 tt = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(row * ldt + l16 * 4));
+          o = pgt_mk4(alpha * acc.x + beta * tt.x, alpha * acc.y + beta * tt.y, alpha * acc.z + beta * tt.z,
+                          alpha * acc.w + beta * tt.w);
         } else {
-          o = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+          o = pgt_mk4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
         }
-        *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + l16 * 4) = o;
+        *reinterpret_cast<pgt_f4*>(Y + (unsigned)(row * ldy + l16 * 4)) = o;
       }
-    }
+    };
+    quad(0, ca[0], cn[0], cc[0], cv[0]);
+    quad(1, ca[1], cn[1], cc[1], cv[1]);
+    quad(2, ca[2], cn[2], cc[2], cv[2]);
+    quad(3, ca[3], cn[3], cc[3], cv[3]);
     __syncthreads();
+    PGT_TRACE_MARK(3 + 2 * ((s0 - c0) / srows));
+  };
+  int ra[4], rn[4], rc[4];
+  float rv[4];
+#pragma unroll 1
+  for (int s0 = c0; s0 < c1; s0 += 2 * srows) {
+    step(s0, qa, qn, qc, qv, ra, rn, rc, rv, rpB0, rpB1, rpA0, rpA1);
+    if (s0 + srows < c1) step(s0 + srows, ra, rn, rc, rv, qa, qn, qc, qv, rpA0, rpA1, rpB0, rpB1);
   }
+  }
+  PGT_TRACE_MARK(15);
 }
 
 // slots of a CSR operator whose source lies within +-32 / +-96 rows of the destination (selects the band kernel)
@@ -485,22 +568,27 @@ extern "C" int pgt_spmm_csr_band_f32(const int32_t* rowptr, const int32_t* col, 
   if (int rc = spmm_validate("pgt_spmm_csr_band_f32", rowptr, n_rows, X, ldx, Y, ldy, T, ldt, F)) return rc;
   PgtVecPick vp;
   vp.width(F); vp.operand(X, ldx); vp.operand(Y, ldy); vp.operand(T, ldt);
-  if (halo <= 0 || halo > 96 || F != 64 || vp.v != 4)
+  const int64_t max_ld = ldx > ldy ? (ldx > ldt ? ldx : ldt) : (ldy > ldt ? ldy : ldt);
+  if (halo <= 0 || halo > 96 || F != 64 || vp.v != 4 || n_rows * max_ld >= ((int64_t)1 << 31))
     return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   const int ring = halo <= 32 ? 128 : 256;
-  // chunking: aim at g_band_blocks resident workgroups per CU (LDS admits 4 at RING = 128, 2 at RING = 256)
-  const int per_cu = ring == 128 ? (g_band_blocks < 4 ? g_band_blocks : 4) : (g_band_blocks < 2 ? g_band_blocks : 2);
+  // chunking: g_band_blocks resident workgroups per CU (registers admit 3 at RING = 128, LDS 2 at RING = 256); each chunk is
+  // swept in equal steps of at most 64 rows
+  const int per_cu = ring == 128 ? (g_band_blocks < 3 ? g_band_blocks : 3) : (g_band_blocks < 2 ? g_band_blocks : 2);
   int64_t nblk = 256 * (int64_t)per_cu;
-  int64_t rpc = pgt_cdiv(pgt_cdiv(n_rows, nblk), 16) * 16;
+  int64_t rpc = pgt_cdiv(n_rows, nblk);
   if (rpc < 64) rpc = 64;
+  const int64_t steps = pgt_cdiv(rpc, 64);
+  const int64_t srows = pgt_cdiv(pgt_cdiv(rpc, steps), 4) * 4;
+  rpc = srows * steps;
   nblk = pgt_cdiv(n_rows, rpc);
   dim3 grid((unsigned)nblk), block(256);
   if (ring == 128) {
-    PGT_LAUNCH((spmm_band64_kernel<128>), grid, block, stream, rowptr, col, val, (int)n_rows, X, ldx, Y, ldy, T, ldt,
-               alpha, beta, (int)rpc, g_band_xcd);
+    PGT_LAUNCH((spmm_band64_kernel<128>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y, (int)ldy, T,
+               (int)ldt, alpha, beta, (int)rpc, (int)srows, g_band_xcd);
   } else {
-    PGT_LAUNCH((spmm_band64_kernel<256>), grid, block, stream, rowptr, col, val, (int)n_rows, X, ldx, Y, ldy, T, ldt,
-               alpha, beta, (int)rpc, g_band_xcd);
+    PGT_LAUNCH((spmm_band64_kernel<256>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y, (int)ldy, T,
+               (int)ldt, alpha, beta, (int)rpc, (int)srows, g_band_xcd);
   }
   return pgt_check_launch("pgt_spmm_csr_band_f32");
 }

@@ -34,6 +34,10 @@ class Csr:
 
 
 BAND_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; keep the plain schedule
+# The LDS-window ("band") schedule is correct for every operator and selected per call through `halo`.  Measured on
+# MI355X at N = 200 000, F = 64 it ties the row-tile schedule (33-37 us vs 32-35 us at in-degree 8), so
+# the measured locality hint is only APPLIED when this switch is on; spmm(..., halo=...) always overrides.
+USE_BAND_SCHEDULE = False
 
 
 def measure_locality(csrs):
@@ -249,7 +253,9 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, halo=None):
     yp, ldy = _rows(Y, "Y")
     tp, ldt = _rows(T, "T") if T is not None else (ptr(None), 0)
     st = stream_of(lib, X)
-    halo = int(getattr(csr, "halo", 0) if halo is None else halo)
+    if halo is None:
+        halo = getattr(csr, "halo", 0) if USE_BAND_SCHEDULE else 0
+    halo = int(halo)
     work = spmm_algorithmic_bytes(csr.n_rows, csr.col.numel(), X.size(1), T is not None) if KERNEL_TIMER else 0
     _timed("spmm", work, lambda: lib.call(
         "pgt_spmm_csr_band_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,

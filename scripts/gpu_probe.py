@@ -82,21 +82,18 @@ def probe_spmm_ns():
             measured = g.fwd_o.halo
             variants = [dict(halo=0, rows=64, unroll=8), dict(halo=0, rows=32, unroll=8)]
             if name == "local":
-                variants += [dict(halo=32, k=4, xcd=1), dict(halo=32, k=3, xcd=1), dict(halo=32, k=2, xcd=1),
-                             dict(halo=32, k=4, xcd=0), dict(halo=96, k=2, xcd=1)]
-            else:
-                variants += [dict(halo=32, k=4, xcd=1)]
+                variants += [dict(halo=32, k=3, xcd=1), dict(halo=32, k=2, xcd=1)]
             for v in variants:
                 g.fwd_o.halo = v["halo"]
                 lib.tune("spmm_tile_rows", v.get("rows", 64)); lib.tune("spmm_unroll", v.get("unroll", 8))
-                lib.tune("spmm_band_blocks", v.get("k", 4)); lib.tune("spmm_band_xcd", v.get("xcd", 1))
+                lib.tune("spmm_band_blocks", v.get("k", 3)); lib.tune("spmm_band_xcd", v.get("xcd", 1))
                 us_res = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
                 us_rot = _rot_time(g.fwd_o, n, 64, 6)
                 emit(probe="spmm_ns", graph=name, deg=deg, F=64, measured_halo=measured, E=int(g.E), alg_MB=nb / 1e6,
                      us_resident=us_res, frac_resident=nb / us_res / 1e3 / 8000, us_rotating=us_rot,
                      GBs_rotating=nb / us_rot / 1e3, frac_rotating=nb / us_rot / 1e3 / 8000, **v)
-            lib.tune("spmm_tile_rows", 64); lib.tune("spmm_unroll", 8)
-            lib.tune("spmm_band_blocks", 4); lib.tune("spmm_band_xcd", 1)
+            lib.tune("spmm_tile_rows", 32); lib.tune("spmm_unroll", 8)
+            lib.tune("spmm_band_blocks", 3); lib.tune("spmm_band_xcd", 1)
             del g, X, Y
 
 

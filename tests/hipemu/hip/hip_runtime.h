@@ -231,6 +231,7 @@ static inline unsigned long long __ballot(int pred) {
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned atomicExch(unsigned* p, unsigned v) { unsigned o = *p; *p = v; return o; }
 
 // --- MFMA emulation (lane maps: cdna_hip_programming.md §3) -------------------------------------------
 struct pgt_emu_f32x16 {

@@ -386,7 +386,7 @@ def test_spmm_tuning_variants_agree(backend):
         with pytest.raises(_lib.PgtError, match="unknown key"):
             lib.tune("no_such_knob", 1)
     finally:
-        lib.tune("spmm_tile_rows", 64); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_xcd", 1)
+        lib.tune("spmm_tile_rows", 32); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_xcd", 1)
 
 
 # ------------------------------------------------------------------------------------------------ band (LDS-window) SpMM

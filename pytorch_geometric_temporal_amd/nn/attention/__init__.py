@@ -1,1 +1,3 @@
-__all__ = []
+from .stgcn import TemporalConv, STConv  # noqa: F401
+
+__all__ = ["TemporalConv", "STConv"]

@@ -1,0 +1,59 @@
+"""TemporalConv / STConv — drop-in mirrors of torch_geometric_temporal/nn/attention/stgcn.py.
+
+The graph convolution of the ST-Conv block is the message-passing part: the reference calls ChebConv once per
+(batch, time) slice in a Python double loop (stgcn.py:151-153), recomputing the Laplacian normalisation each time.
+Here all B*T' slices are folded into the feature dimension of ONE Chebyshev stack (K-1 aggregation launches + one MFMA
+GEMM in total).  The temporal gated convolutions and the batch norm are dense torch modules, as in the reference.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..conv import ChebConv
+
+
+class TemporalConv(nn.Module):
+    r"""Gated temporal convolution (reference: stgcn.py:8-44).  X [B, T, N, in] -> [B, T-(k-1), N, out]."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3):
+        super().__init__()
+        self.conv_1 = nn.Conv2d(in_channels, out_channels, (1, kernel_size))
+        self.conv_2 = nn.Conv2d(in_channels, out_channels, (1, kernel_size))
+        self.conv_3 = nn.Conv2d(in_channels, out_channels, (1, kernel_size))
+
+    def forward(self, X):
+        X = X.permute(0, 3, 2, 1)
+        P = self.conv_1(X)
+        Q = torch.sigmoid(self.conv_2(X))
+        H = F.relu(P * Q + self.conv_3(X))
+        return H.permute(0, 3, 2, 1)
+
+
+class STConv(nn.Module):
+    r"""Spatio-temporal convolution block (reference: stgcn.py:47-160).
+    X [B, T, N, in] -> [B, T - 2(kernel_size-1), N, out]."""
+
+    def __init__(self, num_nodes: int, in_channels: int, hidden_channels: int, out_channels: int, kernel_size: int,
+                 K: int, normalization: str = "sym", bias: bool = True):
+        super().__init__()
+        self.num_nodes = num_nodes
+        self.in_channels = in_channels
+        self.hidden_channels = hidden_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.K = K
+        self.normalization = normalization
+        self.bias = bias
+        self._temporal_conv1 = TemporalConv(in_channels, hidden_channels, kernel_size)
+        self._graph_conv = ChebConv(hidden_channels, hidden_channels, K=K, normalization=normalization, bias=bias)
+        self._temporal_conv2 = TemporalConv(hidden_channels, out_channels, kernel_size)
+        self._batch_norm = nn.BatchNorm2d(num_nodes)
+
+    def forward(self, X, edge_index, edge_weight=None):
+        T_0 = self._temporal_conv1(X)                                  # [B, T', N, hidden]
+        T = self._graph_conv(T_0, edge_index, edge_weight)             # every (b, t) slice in one Chebyshev stack
+        T = F.relu(T)
+        T = self._temporal_conv2(T)
+        T = T.permute(0, 2, 1, 3)
+        T = self._batch_norm(T)
+        return T.permute(0, 2, 1, 3)

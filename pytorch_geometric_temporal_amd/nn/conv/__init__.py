@@ -1,0 +1,178 @@
+"""The PyG operators the reference's hot path calls (torch_geometric.nn.GCNConv / ChebConv / TopKPooling), as
+parameter-compatible modules whose message passing runs on the HIP kernels.  PyG itself is NOT a dependency: these
+mirror the call sites of the reference (temporalgcn.py:38-70, stgcn.py:115-121, evolvegcnh.py:63, mpnn_lstm.py) —
+same constructor arguments, same state_dict keys (`lin.weight [out,in]`, `bias`, `lins.{k}.weight`), same outputs.
+"""
+import math
+
+import torch
+
+from ... import ops
+
+
+def glorot_(t):
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-a, a)
+    return t
+
+
+class _Lin(torch.nn.Module):
+    """PyG's `Linear(in, out, bias=False, weight_initializer="glorot")`: a bare weight [out, in]."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = torch.nn.Parameter(torch.empty(out_channels, in_channels))
+        glorot_(self.weight)
+
+    def forward(self, x):
+        shp = x.shape
+        y = ops.linear(x.reshape(-1, shp[-1]), self.weight.t(), None)
+        return y.view(*shp[:-1], self.out_channels)
+
+
+def _fold_batch(x):
+    """[..., N, C] with any leading batch dims -> node-major rows [N, B*C] (+ the info to undo it)."""
+    if x.dim() == 2:
+        return x.contiguous(), None
+    lead = x.shape[:-2]
+    N, C = x.shape[-2], x.shape[-1]
+    B = int(torch.Size(lead).numel())
+    xb = x.reshape(B, N, C)
+    return ops.Swap01.apply(xb, B, N, C).view(N, B * C), (lead, B, N)
+
+
+def _unfold_batch(y2d, info, C_out):
+    if info is None:
+        return y2d
+    lead, B, N = info
+    return ops.Swap01.apply(y2d.view(N, B, C_out), N, B, C_out).view(*lead, N, C_out)
+
+
+class GCNConv(torch.nn.Module):
+    r"""torch_geometric.nn.GCNConv as the reference uses it: out = A_hat (x W^T) + b with
+    A_hat = D^-1/2 (A + fill*I) D^-1/2 (gcn_norm; `improved` -> fill 2).  x is [N, in] or [B, N, in] (node_dim = -2:
+    one edge list for every batch entry).  `cached=True` freezes the first graph's normalisation, as PyG does."""
+
+    def __init__(self, in_channels, out_channels, improved=False, cached=False, add_self_loops=True,
+                 normalize=True, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached, self.add_self_loops, self.normalize = improved, cached, add_self_loops, normalize
+        if not normalize:
+            raise NotImplementedError("GCNConv(normalize=False) is not on the reference's hot path")
+        self.lin = _Lin(in_channels, out_channels)
+        if bias:
+            self.bias = torch.nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self._cached_graph = None
+
+    def reset_parameters(self):
+        glorot_(self.lin.weight)
+        if self.bias is not None:
+            torch.nn.init.zeros_(self.bias)
+        self._cached_graph = None
+
+    def graph(self, edge_index, edge_weight, num_nodes):
+        if self.cached and self._cached_graph is not None:
+            return self._cached_graph
+        g = ops.gcn_graph(edge_index, edge_weight, num_nodes, self.improved, self.add_self_loops)
+        if self.cached:
+            self._cached_graph = g
+        return g
+
+    def forward(self, x, edge_index, edge_weight=None):
+        g = self.graph(edge_index, edge_weight, x.size(-2))
+        # aggregate at the narrower width: A_hat (x W) == (A_hat x) W
+        if self.in_channels <= self.out_channels:
+            x2, info = _fold_batch(x)
+            ax = _unfold_batch(ops.propagate(g, x2), info, self.in_channels)
+            out = self.lin(ax)
+        else:
+            h2, info = _fold_batch(self.lin(x))
+            out = _unfold_batch(ops.propagate(g, h2), info, self.out_channels)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
+
+
+class ChebConv(torch.nn.Module):
+    r"""torch_geometric.nn.ChebConv (stgcn.py:115-121, gconv_gru.py:57-107): K-order Chebyshev filter on the scaled
+    Laplacian 2L/lambda_max - I.  Parameters: `lins.{k}.weight [out, in]`, `bias [out]`."""
+
+    def __init__(self, in_channels, out_channels, K, normalization="sym", bias=True):
+        super().__init__()
+        assert K > 0
+        assert normalization in [None, "sym", "rw"], "Invalid normalization"
+        self.in_channels, self.out_channels, self.normalization = in_channels, out_channels, normalization
+        self.lins = torch.nn.ModuleList([_Lin(in_channels, out_channels) for _ in range(K)])
+        if bias:
+            self.bias = torch.nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter("bias", None)
+
+    def reset_parameters(self):
+        for lin in self.lins:
+            glorot_(lin.weight)
+        if self.bias is not None:
+            torch.nn.init.zeros_(self.bias)
+
+    def forward(self, x, edge_index, edge_weight=None, batch=None, lambda_max=None):
+        if batch is not None:
+            raise NotImplementedError("ChebConv: per-graph `batch` vectors are not used on the reference's hot path")
+        # lambda_max=None -> 2 * max(L), computed on the device (PyG ChebConv.__norm__)
+        lam = None if lambda_max is None else float(lambda_max)
+        N = x.size(-2)
+        g = ops.cheb_graph(edge_index, edge_weight, N, self.normalization, lam, variant=0)
+        K = len(self.lins)
+        Wst = torch.cat([lin.weight.t() for lin in self.lins], dim=0)          # [K*in, out]
+        if x.dim() == 2:
+            return ops.ChebConvFunction.apply(x, Wst, self.bias, g, K, 1)
+        lead = x.shape[:-2]
+        B = int(torch.Size(lead).numel())
+        C = x.size(-1)
+        xnm = ops.Swap01.apply(x.reshape(B, N, C), B, N, C).view(N * B, C)     # node-major rows m = n*B + b
+        out = ops.ChebConvFunction.apply(xnm, Wst, self.bias, g, K, B)
+        return ops.Swap01.apply(out.view(N, B, self.out_channels), N, B, self.out_channels).view(
+            *lead, N, self.out_channels)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, K={len(self.lins)}, "
+                f"normalization={self.normalization})")
+
+
+class TopKPooling(torch.nn.Module):
+    r"""torch_geometric.nn.TopKPooling as EvolveGCN-H uses it (evolvegcnh.py:61-63, 93-94): only output [0], the
+    k = ceil(ratio * N) highest-scoring rows scaled by tanh(score); score = (x . p) / ||p||.  The projection is one
+    [N, F] x [F] product on a 129 x 8 matrix followed by a top-k — torch ops, not a kernel of its own.
+    Parameter name follows PyG >= 2.4: `select.weight [1, F]`."""
+
+    class _Select(torch.nn.Module):
+        def __init__(self, in_channels):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.empty(1, in_channels))
+            bound = 1.0 / math.sqrt(in_channels)
+            with torch.no_grad():
+                self.weight.uniform_(-bound, bound)
+
+    def __init__(self, in_channels, ratio=0.5):
+        super().__init__()
+        self.in_channels, self.ratio = in_channels, ratio
+        self.select = TopKPooling._Select(in_channels)
+
+    def forward(self, x, edge_index=None):
+        w = self.select.weight
+        score = torch.tanh((x * w).sum(dim=-1) / w.norm(p=2, dim=-1))
+        n = x.size(0)
+        if isinstance(self.ratio, int):
+            k = min(self.ratio, n)
+        else:   # PyG computes ceil(ratio * N) in the score dtype (fp32)
+            k = int((float(self.ratio) * torch.tensor(n).to(score.dtype)).ceil().to(torch.long))
+        perm = torch.sort(score.view(-1), descending=True).indices[:k]
+        s = score[perm]
+        return (x[perm] * s.view(-1, 1), None, None, None, perm, s)

@@ -1,0 +1,82 @@
+"""TGCN / TGCN2 — drop-in mirrors of torch_geometric_temporal/nn/recurrent/temporalgcn.py.
+
+Same constructor arguments, parameter names (`conv_{z,r,h}.lin.weight [out,in]`, `conv_{z,r,h}.bias`,
+`linear_{z,r,h}.{weight [out, 2*out], bias}`), forward signatures and outputs; the cell is ONE fused call
+(ops.TGCNCellFunction): one aggregation of X shared by the three gates, MFMA GEMMs for the `lin`/`linear` layers,
+fused gate kernels, hand-written backward on the transposed operator.
+"""
+import torch
+
+from ... import ops
+from ..conv import GCNConv
+
+
+def _cell(mod, Xnm, Hnm, g, Bt):
+    cz, cr, ch = mod.conv_z, mod.conv_r, mod.conv_h
+    Wc = torch.cat([cz.lin.weight, cr.lin.weight, ch.lin.weight], dim=0)
+    bc = torch.cat([cz.bias, cr.bias, ch.bias], dim=0)
+    return ops.TGCNCellFunction.apply(Xnm, Hnm, Wc, bc, mod.linear_z.weight, mod.linear_z.bias, mod.linear_r.weight,
+                                      mod.linear_r.bias, mod.linear_h.weight, mod.linear_h.bias, g, Bt)
+
+
+class TGCN(torch.nn.Module):
+    r"""Temporal Graph Convolutional GRU cell (reference: temporalgcn.py:5-130).
+
+    Args: in_channels, out_channels, improved=False, cached=False, add_self_loops=True."""
+
+    def __init__(self, in_channels: int, out_channels: int, improved: bool = False, cached: bool = False,
+                 add_self_loops: bool = True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.improved = improved
+        self.cached = cached
+        self.add_self_loops = add_self_loops
+        self._create_parameters_and_layers()
+
+    def _create_parameters_and_layers(self):
+        for gate in ("z", "r", "h"):      # temporalgcn.py:38-70
+            setattr(self, "conv_" + gate, GCNConv(self.in_channels, self.out_channels, improved=self.improved,
+                                                  cached=self.cached, add_self_loops=self.add_self_loops))
+            setattr(self, "linear_" + gate, torch.nn.Linear(2 * self.out_channels, self.out_channels))
+
+    def _graph(self, edge_index, edge_weight, num_nodes):
+        # the three convs share one normalisation (same arguments); `cached` freezes it on the first call (PyG)
+        return self.conv_z.graph(edge_index, edge_weight, num_nodes)
+
+    def _set_hidden_state(self, X, H):
+        if H is None:
+            H = torch.zeros(X.shape[0], self.out_channels, device=X.device, dtype=X.dtype)
+        return H
+
+    def forward(self, X, edge_index, edge_weight=None, H=None):
+        """X [N, in], edge_index [2,E], edge_weight [E]|None, H [N, out]|None -> H' [N, out] (temporalgcn.py:104-130)."""
+        H = self._set_hidden_state(X, H)
+        g = self._graph(edge_index, edge_weight, X.size(0))
+        return _cell(self, X, H, g, 1)
+
+
+class TGCN2(TGCN):
+    r"""Batched T-GCN cell (reference: temporalgcn.py:133-233): X [B, N, in], H [B, N, out] -> [B, N, out].
+    `batch_size` is kept for signature compatibility (the reference ignores it too, :148)."""
+
+    def __init__(self, in_channels: int, out_channels: int, batch_size: int, improved: bool = False,
+                 cached: bool = False, add_self_loops: bool = True):
+        self.batch_size = batch_size
+        super().__init__(in_channels, out_channels, improved, cached, add_self_loops)
+
+    def _set_hidden_state(self, X, H):
+        if H is None:
+            H = torch.zeros(X.shape[0], X.shape[1], self.out_channels, device=X.device, dtype=X.dtype)
+        return H
+
+    def forward(self, X, edge_index, edge_weight=None, H=None):
+        H = self._set_hidden_state(X, H)
+        B, N, Fin = X.shape
+        O = self.out_channels
+        g = self._graph(edge_index, edge_weight, N)
+        # batch-major [B][N][C] -> node-major rows m = n*B + b: the whole batch is one aggregation launch
+        Xnm = ops.Swap01.apply(X.contiguous(), B, N, Fin).view(N * B, Fin)
+        Hnm = ops.Swap01.apply(H.contiguous(), B, N, O).view(N * B, O)
+        out = _cell(self, Xnm, Hnm, g, B)
+        return ops.Swap01.apply(out.view(N, B, O), N, B, O)

@@ -586,3 +586,216 @@ class DCRNNSeqFunction(torch.autograd.Function):
             gemm_tn_acc(TSh, C, seg, S, C, dPh, O, dWh, O, dbh, T * M, O)
         dH0 = dH if ctx.needs_input_grad[1] else None
         return dX, dH0, dWzr, dbzr, dWh, dbh, None, None, None
+
+
+# --------------------------------------------------------------------------------------------- generic building blocks
+
+class SpmmFunction(torch.autograd.Function):
+    """Y = alpha * A @ X on [n_rows, F] (propagate with aggr="add"); the gradient runs on the transposed operator."""
+
+    @staticmethod
+    def forward(ctx, X, fwd, bwd, alpha):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        Xc = X.contiguous()
+        Y = torch.empty_like(Xc)
+        spmm(fwd, Xc, Y, alpha=alpha)
+        ctx.bwd, ctx.alpha = bwd, alpha
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        dYc = dY.contiguous()
+        dX = torch.empty_like(dYc)
+        spmm(ctx.bwd, dYc, dX, alpha=ctx.alpha)
+        return dX, None, None, None
+
+
+def propagate(g, X2d, alpha=1.0):
+    """g: SymGraph (fwd/bwd).  X2d [N, F] -> A @ X2d with autograd."""
+    return SpmmFunction.apply(X2d, g.fwd, g.bwd, float(alpha))
+
+
+class LinearFunction(torch.autograd.Function):
+    """Y[M,N] = X[M,K] @ W_kn[K,N] (+ bias) on the fp32 MFMA GEMM; W_kn may be any strided 2-D view (e.g. weight.t())."""
+
+    @staticmethod
+    def forward(ctx, X, W_kn, bias):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        Xc = X.contiguous()
+        Y = linear_fwd(Xc, W_kn, bias)
+        ctx.save_for_backward(Xc, W_kn)
+        ctx.has_bias = bias is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        Xc, W_kn = ctx.saved_tensors
+        M, K = Xc.shape
+        N = W_kn.size(1)
+        dYc = dY.contiguous()
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dX = torch.empty(M, K, dtype=F32, device=dYc.device)
+            # dX = dY @ W_kn^T : B element (k' = n, n' = k) is W_kn[k, n]
+            gemm(dYc, N, 0, 1, N, W_kn, W_kn.stride(1), W_kn.stride(0), dX, K, 0, K, None, M, K)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW = torch.zeros(K, N, dtype=F32, device=dYc.device)
+            db = torch.zeros(N, dtype=F32, device=dYc.device) if ctx.has_bias else None
+            gemm_tn_acc(Xc, K, 0, 1, K, dYc, N, dW, N, db, M, N)
+        return dX, dW, db
+
+
+def linear(X2d, W_kn, bias=None):
+    return LinearFunction.apply(X2d, W_kn, bias)
+
+
+# --------------------------------------------------------------------------------------------- T-GCN cell
+
+class TGCNCellFunction(torch.autograd.Function):
+    """One T-GCN GRU step (temporalgcn.py:82-130) on node-major rows m = n*Bt + b.
+
+    X [M, Fin], H [M, O] -> H' [M, O].  The three GCNConv gates share ONE aggregation (the reference aggregates the
+    same X three times at width O; here A_hat X is taken once at width Fin and the three `lin` weights are applied
+    afterwards: A_hat (X W) == (A_hat X) W).  Wc = cat(conv_{z,r,h}.lin.weight) [3O, Fin], bc = cat(conv biases) [3O],
+    L* = linear_*.weight [O, 2O], lb* = linear_*.bias [O].
+    """
+
+    @staticmethod
+    def forward(ctx, X, H, Wc, bc, Lz, lbz, Lr, lbr, Lh, lbh, g, Bt):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        check_tensor(lib, H, "H")
+        Xc, Hc = X.contiguous(), H.contiguous()
+        M, Fin = Xc.shape
+        O = Hc.size(1)
+        N = g.N
+        if M != N * Bt or Hc.size(0) != M:
+            raise ValueError(f"TGCN: X has {M} rows, H {Hc.size(0)}, expected num_nodes*B = {N * Bt}")
+        dev = Xc.device
+        AX = torch.empty(M, Fin, dtype=F32, device=dev)
+        spmm(g.fwd, Xc.view(N, Bt * Fin), AX.view(N, Bt * Fin))
+        G = torch.empty(3, 2, M, O, dtype=F32, device=dev)     # [gate][0 = conv(X), 1 = H or H*R]
+        Wc_c, Lz_c, Lr_c, Lh_c = Wc.contiguous(), Lz.contiguous(), Lr.contiguous(), Lh.contiguous()
+        # conv_g(X) = (A_hat X) W_g^T + b_g for the three gates in one GEMM; column segment g lands in G[g, 0]
+        gemm(AX, Fin, 0, 1, Fin, Wc_c, 1, Fin, G, O, 2 * M * O, O, bc, M, 3 * O)
+        copy2d(G[0, 1], Hc)
+        copy2d(G[1, 1], Hc)
+        ZR = torch.empty(M, 2 * O, dtype=F32, device=dev)
+        for gi, (L, lb) in enumerate(((Lz_c, lbz), (Lr_c, lbr))):
+            # linear_g([conv_g(X), H]) : A = two K-segments of O columns, B(k, n) = L[n, k]
+            gemm(G[gi], O, M * O, 2, O, L, 1, 2 * O, ZR[:, gi * O:], 2 * O, 0, O, lb, M, O)
+        _gru_zr(ZR, Hc, G[2, 1], 0)                            # Z, R = sigmoid(.) in place; G[2,1] = H * R
+        HT = torch.empty(M, O, dtype=F32, device=dev)
+        gemm(G[2], O, M * O, 2, O, Lh_c, 1, 2 * O, HT, O, 0, O, lbh, M, O)
+        Hn = torch.empty(M, O, dtype=F32, device=dev)
+        _gru_h(HT, ZR, Hc, Hn)                                 # HT = tanh(.) in place; Hn = Z*H + (1-Z)*HT
+        ctx.g, ctx.Bt = g, Bt
+        ctx.has_bias = (bc is not None, lbz is not None, lbr is not None, lbh is not None)
+        ctx.save_for_backward(AX, G, ZR, HT, Hc, Wc_c, Lz_c, Lr_c, Lh_c)
+        return Hn
+
+    @staticmethod
+    def backward(ctx, dHn):
+        AX, G, ZR, HT, Hc, Wc_c, Lz_c, Lr_c, Lh_c = ctx.saved_tensors
+        g, Bt = ctx.g, ctx.Bt
+        M, Fin = AX.shape
+        O = Hc.size(1)
+        N = g.N
+        dev = AX.device
+        dHn = dHn.contiguous()
+        d_pre_h = torch.empty(M, O, dtype=F32, device=dev)
+        d_pre_zr = torch.empty(M, 2 * O, dtype=F32, device=dev)
+        dH = torch.empty(M, O, dtype=F32, device=dev)
+        _gru_h_bwd(dHn, ZR, Hc, HT, d_pre_h, d_pre_zr, dH, accumulate=False)
+        dG = torch.empty(3, 2, M, O, dtype=F32, device=dev)
+        # d[conv_h(X), H*R] = d_pre_h @ Lh   (B(k, n) = Lh[k, n]; the 2O output columns split into dG[2,0], dG[2,1])
+        gemm(d_pre_h, O, 0, 1, O, Lh_c, 2 * O, 1, dG[2], O, M * O, O, None, M, 2 * O)
+        _gru_zr_bwd(dG[2, 1], 0, ZR, Hc, d_pre_zr, dH)         # d_pre_r, dH += d(HR) * R
+        for gi, L in ((0, Lz_c), (1, Lr_c)):
+            gemm(d_pre_zr[:, gi * O:], 2 * O, 0, 1, O, L, 2 * O, 1, dG[gi], O, M * O, O, None, M, 2 * O)
+            add2d(dH, dG[gi, 1])
+        # weight gradients (dW^T layouts come out of the TN kernel; transposed views go back to autograd)
+        hb = ctx.has_bias
+        dLt = torch.zeros(3, 2 * O, O, dtype=F32, device=dev)
+        dlb = torch.zeros(3, O, dtype=F32, device=dev)
+        for gi, dpre in ((0, d_pre_zr[:, :O]), (1, d_pre_zr[:, O:]), (2, d_pre_h)):
+            gemm_tn_acc(G[gi], O, M * O, 2, O, dpre, dpre.stride(0), dLt[gi], O, dlb[gi], M, O)
+        dWct = torch.zeros(Fin, 3 * O, dtype=F32, device=dev)
+        dbc = torch.zeros(3 * O, dtype=F32, device=dev)
+        for gi in range(3):
+            gemm_tn_acc(AX, Fin, 0, 1, Fin, dG[gi, 0], O, dWct[:, gi * O:], 3 * O, dbc[gi * O:], M, O)
+        dX = None
+        if ctx.needs_input_grad[0]:
+            dAX = torch.empty(M, Fin, dtype=F32, device=dev)
+            # d(A_hat X) = sum_g d conv_g @ W_g : three K-segments (dG[g, 0]) against Wc [3O, Fin]
+            gemm(dG, O, 2 * M * O, 3, O, Wc_c, Fin, 1, dAX, Fin, 0, Fin, None, M, Fin)
+            dX = torch.empty(M, Fin, dtype=F32, device=dev)
+            spmm(g.bwd, dAX.view(N, Bt * Fin), dX.view(N, Bt * Fin))
+        return (dX, dH, dWct.t().contiguous(), dbc if hb[0] else None,
+                dLt[0].t().contiguous(), dlb[0] if hb[1] else None,
+                dLt[1].t().contiguous(), dlb[1] if hb[2] else None,
+                dLt[2].t().contiguous(), dlb[2] if hb[3] else None, None, None)
+
+
+# --------------------------------------------------------------------------------------------- Chebyshev convolution
+
+class ChebConvFunction(torch.autograd.Function):
+    """PyG ChebConv.forward on node-major rows [N*Bt, C] (any number of independent graphs-in-batch folded into the
+    feature dimension): Tx_0 = X, Tx_1 = L X, Tx_k = 2 L Tx_{k-1} - Tx_{k-2}; out = sum_k Tx_k @ W_k^T + bias.
+    Wst [K*C, O] stacks lins[k].weight^T; g is the scaled-Laplacian SymGraph (pgt_cheb_prep, variant 0)."""
+
+    @staticmethod
+    def forward(ctx, X, Wst, bias, g, K, Bt):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        Xc = X.contiguous()
+        M, C = Xc.shape
+        N = g.N
+        if M != N * Bt:
+            raise ValueError(f"ChebConv: X has {M} rows, expected num_nodes*B = {N * Bt}")
+        O = Wst.size(1)
+        TS = torch.empty(K, M, C, dtype=F32, device=Xc.device)
+        copy2d(TS[0], Xc)
+        for k in range(1, K):
+            src, dst = TS[k - 1].view(N, -1), TS[k].view(N, -1)
+            if k == 1:
+                spmm(g.fwd, src, dst)
+            else:
+                spmm(g.fwd, src, dst, T=TS[k - 2].view(N, -1), alpha=2.0, beta=-1.0)
+        Wc = Wst.contiguous()
+        out = torch.empty(M, O, dtype=F32, device=Xc.device)
+        gemm(TS, C, M * C, K, C, Wc, O, 1, out, O, 0, O, bias, M, O)
+        ctx.g, ctx.K = g, K
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(TS, Wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        TS, Wc = ctx.saved_tensors
+        g, K = ctx.g, ctx.K
+        _, M, C = TS.shape
+        O = Wc.size(1)
+        N = g.N
+        dOut = dOut.contiguous()
+        dX = dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW = torch.zeros_like(Wc)
+            db = torch.zeros(O, dtype=F32, device=dOut.device) if ctx.has_bias else None
+            gemm_tn_acc(TS, C, M * C, K, C, dOut, O, dW, O, db, M, O)
+        if ctx.needs_input_grad[0]:
+            G = torch.empty(K, M, C, dtype=F32, device=dOut.device)
+            gemm(dOut, O, 0, 1, O, Wc, 1, O, G, C, M * C, C, None, M, K * C)   # G_k = dOut @ W_k^T
+            # adjoint of the recursion, highest order first: G_{k-1} += 2 L^T G_k ; G_{k-2} -= G_k
+            for k in range(K - 1, 1, -1):
+                Gk = G[k].view(N, -1)
+                Gp = G[k - 1].view(N, -1)
+                spmm(g.bwd, Gk, Gp, T=Gp, alpha=2.0, beta=1.0)
+                axpby2d(G[k - 2], G[k], -1.0, G[k - 2], 1.0)
+            if K > 1:
+                G0 = G[0].view(N, -1)
+                spmm(g.bwd, G[1].view(N, -1), G0, T=G0, alpha=1.0, beta=1.0)
+            dX = G[0]
+        return dX, dW, db, None, None, None

@@ -1,0 +1,273 @@
+"""T-GCN / A3T-GCN / STConv (ChebConv) / EvolveGCN families through the drop-in modules:
+forward parity against the fixtures produced by the reference's own module files (tests/golden, tolerance 1e-5 as
+north_star states), forward + backward parity against the fp64 CPU oracle, state_dict compatibility."""
+import pytest
+import torch
+
+from conftest import assert_close_with_nonfinite, load_golden
+from oracle import functional as F
+from pytorch_geometric_temporal_amd.dataset import synthetic as syn
+from pytorch_geometric_temporal_amd.nn.attention import STConv
+from pytorch_geometric_temporal_amd.nn.conv import ChebConv, GCNConv
+from pytorch_geometric_temporal_amd.nn.recurrent import A3TGCN, A3TGCN2, EvolveGCNH, EvolveGCNO, TGCN, TGCN2
+
+ATOL, RTOL = 1e-5, 1e-5
+
+
+def _load(module, params, device):
+    module.load_state_dict(params, strict=True)     # reference checkpoints load unchanged
+    return module.to(device)
+
+
+def _rand_params(m, seed, scale=0.5):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * scale)
+    return {k: v.detach().double().requires_grad_() for k, v in m.state_dict().items()}
+
+
+def _check_param_grads(m, params64, atol=1e-4, rtol=1e-4):
+    for name, p in m.named_parameters():
+        assert p.grad is not None, name
+        assert_close_with_nonfinite(p.grad, params64[name].grad, atol, rtol, name)
+
+
+# ------------------------------------------------------------------------------------------------ T-GCN
+
+def test_tgcn_forward_matches_reference_fixture(backend):
+    g = load_golden("tgcn_sensor")
+    X, H0, ei, ew = (backend.t(g["in"][k]) for k in ("X", "H0", "edge_index", "edge_weight"))
+    m = _load(TGCN(4, 16), g["param"], backend.device)
+    with torch.no_grad():
+        assert_close_with_nonfinite(m(X, ei), g["out"]["H_noweight"], ATOL, RTOL, "no weight")
+        assert_close_with_nonfinite(m(X, ei, ew), g["out"]["H_weight"], ATOL, RTOL, "weight")
+        assert_close_with_nonfinite(m(X, ei, ew, H0), g["out"]["H_weight_hidden"], ATOL, RTOL, "weight+hidden")
+    mi = _load(TGCN(4, 16, improved=True), g["param"], backend.device)
+    with torch.no_grad():
+        assert_close_with_nonfinite(mi(X, ei, ew, H0), g["out"]["H_improved"], ATOL, RTOL, "improved")
+
+
+def test_tgcn2_forward_matches_reference_fixture(backend):
+    g = load_golden("tgcn2_sensor")
+    X, H0, ei, ew = (backend.t(g["in"][k]) for k in ("X", "H0", "edge_index", "edge_weight"))
+    m = _load(TGCN2(2, 8, batch_size=3), g["param"], backend.device)
+    with torch.no_grad():
+        assert_close_with_nonfinite(m(X, ei, ew), g["out"]["H_weight"], ATOL, RTOL, "weight")
+        assert_close_with_nonfinite(m(X, ei, ew, H0), g["out"]["H_weight_hidden"], ATOL, RTOL, "weight+hidden")
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_tgcn_backward_matches_oracle_autograd(backend, batched):
+    torch.manual_seed(3)
+    n, fin, O, B = 22, 3, 6, 3
+    ei_np, ew_np = syn.sensor_graph(n, 140, seed=4, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    m = TGCN2(fin, O, B) if batched else TGCN(fin, O)
+    params64 = _rand_params(m, 5)
+    m = m.to(backend.device)
+    shp = (B, n) if batched else (n,)
+    X, H, w = torch.randn(*shp, fin), torch.randn(*shp, O), torch.randn(*shp, O)
+    Xd, Hd = backend.t(X).requires_grad_(), backend.t(H).requires_grad_()
+    out = m(Xd, backend.t(ei), backend.t(ew), Hd)
+    (out * backend.t(w)).sum().backward()
+    X64, H64 = X.double().requires_grad_(), H.double().requires_grad_()
+    ref = F.tgcn_cell(X64, ei, ew.double(), H64, params64)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward")
+    assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+    assert_close_with_nonfinite(Hd.grad, H64.grad, 5e-5, 1e-4, "dH")
+    _check_param_grads(m, params64)
+
+
+def test_tgcn_cached_freezes_first_graph(backend):
+    n = 20
+    ei1, ew1 = (backend.t(a) for a in syn.sensor_graph(n, 100, seed=1))
+    ei2, ew2 = (backend.t(a) for a in syn.sensor_graph(n, 120, seed=2))
+    m = TGCN(2, 4, cached=True).to(backend.device)
+    X = backend.t(torch.randn(n, 2))
+    with torch.no_grad():
+        a = m(X, ei1, ew1)
+        b = m(X, ei2, ew2)          # PyG's cached=True keeps the first normalisation
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ A3T-GCN
+
+def test_a3tgcn_forward_matches_reference_fixture(backend):
+    g = load_golden("a3tgcn_sensor")
+    X, H0, ei, ew = (backend.t(g["in"][k]) for k in ("X", "H0", "edge_index", "edge_weight"))
+    m = _load(A3TGCN(4, 16, periods=int(g["meta"]["periods"])), g["param"], backend.device)
+    with torch.no_grad():
+        assert_close_with_nonfinite(m(X, ei, ew), g["out"]["H_weight"], ATOL, RTOL, "weight")
+        assert_close_with_nonfinite(m(X, ei, ew, H0), g["out"]["H_weight_hidden"], ATOL, RTOL, "weight+hidden")
+
+
+def test_a3tgcn2_forward_matches_reference_fixture(backend):
+    g = load_golden("a3tgcn2_sensor")
+    X, H0, ei, ew = (backend.t(g["in"][k]) for k in ("X", "H0", "edge_index", "edge_weight"))
+    m = _load(A3TGCN2(2, 8, periods=int(g["meta"]["periods"]), batch_size=3), g["param"], backend.device)
+    with torch.no_grad():
+        assert_close_with_nonfinite(m(X, ei, ew), g["out"]["H_weight"], ATOL, RTOL, "weight")
+        assert_close_with_nonfinite(m(X, ei, ew, H0), g["out"]["H_weight_hidden"], ATOL, RTOL, "weight+hidden")
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_a3tgcn_backward_matches_oracle_autograd(backend, batched):
+    torch.manual_seed(7)
+    n, fin, O, B, P = 16, 2, 5, 2, 3
+    ei_np, ew_np = syn.sensor_graph(n, 90, seed=6, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    m = A3TGCN2(fin, O, P, B) if batched else A3TGCN(fin, O, P)
+    params64 = _rand_params(m, 8)
+    m = m.to(backend.device)
+    shp = (B, n) if batched else (n,)
+    X, H, w = torch.randn(*shp, fin, P), torch.randn(*shp, O), torch.randn(*shp, O)
+    Xd, Hd = backend.t(X).requires_grad_(), backend.t(H).requires_grad_()
+    out = m(Xd, backend.t(ei), backend.t(ew), Hd)
+    (out * backend.t(w)).sum().backward()
+    X64, H64 = X.double().requires_grad_(), H.double().requires_grad_()
+    ref = F.a3tgcn(X64, ei, ew.double(), H64, params64)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward")
+    assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+    assert_close_with_nonfinite(Hd.grad, H64.grad, 5e-5, 1e-4, "dH")
+    _check_param_grads(m, params64)
+
+
+# ------------------------------------------------------------------------------------------------ GCNConv / ChebConv
+
+@pytest.mark.parametrize("fin,fout", [(3, 7), (9, 4)])
+def test_gcnconv_both_association_orders_match_oracle(backend, fin, fout):
+    torch.manual_seed(fin)
+    n, B = 25, 3
+    ei_np, ew_np = syn.sensor_graph(n, 160, seed=fin, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    m = GCNConv(fin, fout)
+    params64 = _rand_params(m, 11)
+    m = m.to(backend.device)
+    for shp in ((n,), (B, n)):
+        X, w = torch.randn(*shp, fin), torch.randn(*shp, fout)
+        Xd = backend.t(X).requires_grad_()
+        m.zero_grad()
+        out = m(Xd, backend.t(ei), backend.t(ew))
+        (out * backend.t(w)).sum().backward()
+        X64 = X.double().requires_grad_()
+        for v in params64.values():
+            v.grad = None
+        ref = F.gcn_conv(X64, ei, ew.double(), params64["lin.weight"], params64["bias"])
+        (ref * w.double()).sum().backward()
+        assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward")
+        assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+        _check_param_grads(m, params64)
+
+
+@pytest.mark.parametrize("K,norm,lam", [(1, "sym", None), (2, "sym", None), (3, "sym", None), (4, "rw", 2.5),
+                                        (3, None, 3.0)])
+def test_chebconv_matches_oracle_forward_and_backward(backend, K, norm, lam):
+    torch.manual_seed(K)
+    n, fin, fout, B = 21, 4, 6, 2
+    ei_np, ew_np = syn.sensor_graph(n, 130, seed=K, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    m = ChebConv(fin, fout, K, normalization=norm)
+    params64 = _rand_params(m, 12)
+    m = m.to(backend.device)
+    for shp in ((n,), (B, 2, n)):
+        X, w = torch.randn(*shp, fin), torch.randn(*shp, fout)
+        Xd = backend.t(X).requires_grad_()
+        m.zero_grad()
+        out = m(Xd, backend.t(ei), backend.t(ew), lambda_max=lam)
+        (out * backend.t(w)).sum().backward()
+        X64 = X.double().requires_grad_()
+        for v in params64.values():
+            v.grad = None
+        ref = F.cheb_conv(X64, ei, ew.double(), [params64[f"lins.{k}.weight"] for k in range(K)], params64["bias"],
+                          normalization=norm, lambda_max=lam)
+        (ref * w.double()).sum().backward()
+        assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward")
+        assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+        _check_param_grads(m, params64)
+
+
+def test_chebconv_without_lambda_max_uses_twice_the_largest_laplacian_entry(backend):
+    """PyG's ChebConv.__norm__: lambda_max=None -> 2 * max(L) for every normalisation (no error, unlike the in-tree
+    ChebConvAttention, astgcn.py:135-139)."""
+    n, fin, fout = 19, 3, 4
+    ei_np, ew_np = syn.sensor_graph(n, 100, seed=2, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    for norm in ("rw", None, "sym"):
+        m = ChebConv(fin, fout, 3, normalization=norm)
+        params64 = _rand_params(m, 13)
+        m = m.to(backend.device)
+        X = torch.randn(n, fin)
+        with torch.no_grad():
+            out = m(backend.t(X), backend.t(ei), backend.t(ew))
+            ref = F.cheb_conv(X.double(), ei, ew.double(), [params64[f"lins.{k}.weight"].detach() for k in range(3)],
+                              params64["bias"].detach(), normalization=norm, lambda_max=None)
+        assert_close_with_nonfinite(out, ref, 2e-5, 2e-5, str(norm))
+
+
+# ------------------------------------------------------------------------------------------------ STConv
+
+def test_stconv_forward_matches_reference_fixture(backend):
+    g = load_golden("stconv_sensor")
+    X, ei, ew = (backend.t(g["in"][k]) for k in ("X", "edge_index", "edge_weight"))
+    K, ks = int(g["meta"]["K"]), int(g["meta"]["kernel_size"])
+    for norm in ("sym", "rw"):
+        m = _load(STConv(30, 4, 8, 6, kernel_size=ks, K=K, normalization=norm), g["param"], backend.device).eval()
+        # the fixture's state_dict was saved after its train-mode forward, which moved the BatchNorm running statistics;
+        # the eval-mode outputs were produced before that, with the initial (0, 1) statistics
+        m._batch_norm.running_mean.zero_()
+        m._batch_norm.running_var.fill_(1.0)
+        with torch.no_grad():
+            assert_close_with_nonfinite(m(X, ei, ew), g["out"]["out_" + norm], 2e-5, 1e-5, norm)
+    m = _load(STConv(30, 4, 8, 6, kernel_size=ks, K=K), g["param"], backend.device).train()
+    with torch.no_grad():
+        out = m(X, ei, ew)
+    assert out.shape == (2, 7 - 2 * (ks - 1), 30, 6)                  # test/attention_test.py:140-176 shape contract
+    assert_close_with_nonfinite(out, g["out"]["out_sym_train"], 5e-5, 1e-4, "train-mode batch norm")
+
+
+def test_stconv_gradients_flow_to_every_parameter(backend):
+    torch.manual_seed(0)
+    ei_np, ew_np = syn.sensor_graph(12, 70, seed=3, symmetric=False)
+    m = STConv(12, 3, 4, 5, kernel_size=2, K=3).to(backend.device)
+    X = backend.t(torch.randn(2, 5, 12, 3)).requires_grad_()
+    m(X, backend.t(ei_np), backend.t(ew_np)).square().sum().backward()
+    assert X.grad is not None and torch.isfinite(X.grad).all()
+    for name, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert float(m._graph_conv.lins[2].weight.grad.abs().sum()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ EvolveGCN
+
+@pytest.mark.parametrize("which", ["h", "o"])
+def test_evolvegcn_sequence_matches_reference_fixture(backend, which):
+    g = load_golden(f"evolvegcn{which}_dynamic")
+    steps, n = int(g["meta"]["steps"]), int(g["meta"]["num_nodes"])
+    m = EvolveGCNH(n, 8) if which == "h" else EvolveGCNO(8)
+    m = _load(m, g["param"], backend.device)
+    with torch.no_grad():
+        for s in range(steps):      # the evolved weight is carried from snapshot to snapshot
+            X, ei, ew = (backend.t(g["in"][f"{k}{s}"]) for k in ("X", "edge_index", "edge_weight"))
+            assert_close_with_nonfinite(m(X, ei, ew), g["out"][f"out{s}"], 2e-5, 2e-5, f"snapshot {s}")
+    m.reinitialize_weight()
+    with torch.no_grad():
+        X, ei, ew = (backend.t(g["in"][f"{k}0"]) for k in ("X", "edge_index", "edge_weight"))
+        assert_close_with_nonfinite(m(X, ei, ew), g["out"]["out0"], 2e-5, 2e-5, "after reinitialize_weight")
+
+
+def test_evolvegcn_backward_through_the_weight_recurrence(backend):
+    torch.manual_seed(1)
+    n, Fdim = 15, 4
+    m = EvolveGCNO(Fdim).to(backend.device)
+    loss = 0
+    for s in range(3):
+        ei_np, ew_np = syn.sensor_graph(n, 60 + 5 * s, seed=s, symmetric=False)
+        X = backend.t(torch.randn(n, Fdim))
+        loss = loss + m(X, backend.t(ei_np), backend.t(ew_np)).square().sum()
+    loss.backward()
+    assert m.initial_weight.grad is not None and float(m.initial_weight.grad.abs().sum()) > 0
+    for name, p in m.recurrent_layer.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name

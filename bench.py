@@ -26,8 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from pytorch_geometric_temporal_amd import _lib, ops  # noqa: E402
+from pytorch_geometric_temporal_amd import _lib, dp, ops  # noqa: E402
 from pytorch_geometric_temporal_amd.dataset import synthetic as syn  # noqa: E402
+from pytorch_geometric_temporal_amd.nn.conv import Linear  # noqa: E402
 from pytorch_geometric_temporal_amd.nn.recurrent import BatchedDCRNN  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
@@ -50,33 +51,14 @@ class Model(torch.nn.Module):
     def __init__(self, hidden):
         super().__init__()
         self.rnn = BatchedDCRNN(2, hidden, K=3)
-        self.head = None if hidden == 2 else torch.nn.Linear(hidden, 2)
+        self.head = None if hidden == 2 else Linear(hidden, 2)
 
     def forward(self, X, ei, ew):
         h = self.rnn(X, ei, ew)
         return h if self.head is None else self.head(h)
 
 
-class FlatGrads:
-    """All gradients live in one contiguous buffer -> exactly one RCCL all-reduce per step (0.6 - 305 KB message:
-    latency-bound, so one call instead of DDP's bucket machinery)."""
-
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-
-    def zero(self):
-        self.flat.zero_()
-
-    def all_reduce_mean(self, world):
-        if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.mul_(1.0 / world)
+FlatGrads = dp.FlatGradients   # every gradient in one buffer -> exactly one RCCL all-reduce per step
 
 
 def make_batches(series, batch, n_batches, seed, device):
@@ -114,7 +96,7 @@ def cpu_baseline(hidden, target_seconds=12.0):
         X, y = series[idx[:, None] + ar], series[idx[:, None] + SEQ + ar]
         out = F.batched_dcrnn(X, ei, ew, params)
         if m.head is not None:
-            out = m.head(out)
+            out = torch.nn.functional.linear(out, m.head.weight, m.head.bias)   # the CPU leg stays pure torch
         loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
         opt.zero_grad()
         loss.backward()
@@ -174,13 +156,7 @@ def main():
     ap.add_argument("--no-ns", action="store_true", help="skip the N=200k F=64 aggregation micro-benchmark")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    rank, local_rank, world = dp.init_from_env("nccl")   # "nccl" is RCCL on ROCm; no-op for a single process
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

@@ -1,0 +1,100 @@
+"""Data-parallel fan-out of index batches: one process per GPU, gradients exchanged with ONE RCCL all-reduce per step.
+
+The reference wraps the model in torch DDP over gloo, launched through Dask (examples/indexBatching/DCRNN/
+pems_ddp.py:83-85, 204-207), and shards the window start indices with DistributedSampler (dataset/metr_la.py:220-228).
+The whole model is 150 - 76 000 fp32 parameters (0.6 - 305 KB): the exchange is latency-bound, so instead of DDP's
+bucket/hook machinery every gradient lives in one flat buffer and a step issues exactly one all-reduce over xGMI
+(backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests).  No graph partitioning: the graph and the [T, N, F]
+series are replicated on every GPU ("GPU-index-batching").
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """(rank, local_rank, world) from the torchrun environment; initialises the process group when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_indices(num_samples, rank, world, epoch=0, shuffle=True, seed=0, drop_last=False):
+    """torch.utils.data.DistributedSampler's index assignment (dataset/metr_la.py:220-228; `set_epoch`,
+    pems_ddp.py:96): a seeded permutation per epoch, padded by wrap-around to a multiple of `world`, rank r takes
+    positions r, r + world, ...  Returned as a LongTensor so a whole batch is gathered with one device index op."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(num_samples, generator=g)
+    else:
+        idx = torch.arange(num_samples)
+    if drop_last:
+        total = (num_samples // world) * world
+        idx = idx[:total]
+    else:
+        total = -(-num_samples // world) * world
+        pad = total - num_samples
+        if pad:
+            reps = -(-pad // max(num_samples, 1))
+            idx = torch.cat([idx, idx.repeat(reps)[:pad]])
+    return idx[rank:total:world]
+
+
+class FlatGradients:
+    """Every parameter's .grad is a view into one contiguous buffer -> one all-reduce per optimisation step."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, world=None, async_op=False):
+        """SUM over ranks then 1/world (DDP's gradient averaging).  Returns the work handle when async_op."""
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        if world <= 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            return work
+        self.flat.mul_(1.0 / world)
+        return None
+
+    def finish(self, work, world):
+        if work is not None:
+            work.wait()
+            self.flat.mul_(1.0 / world)
+
+
+def broadcast_parameters(module, src=0):
+    """Make every rank start from rank `src`'s weights (what DDP does at construction)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src)
+
+
+def reduce_scalars(values, dst=0):
+    """Per-epoch metric reduction (pems_ddp.py:160-161): SUM of a small float vector onto rank `dst`."""
+    t = values if isinstance(values, torch.Tensor) else torch.tensor(values, dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+    return t

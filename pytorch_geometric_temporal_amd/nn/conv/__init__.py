@@ -17,6 +17,19 @@ def glorot_(t):
     return t
 
 
+class Linear(torch.nn.Linear):
+    """torch.nn.Linear (same parameters / initialisation / state_dict) whose product runs on the library's exact-fp32
+    MFMA GEMM — the per-node readout that follows the recurrent cell in the reference's examples
+    (examples/recurrent/dcrnn_example.py: `self.linear = torch.nn.Linear(filters, 1)`).  For out_features of 1-2 a
+    library GEMM picks a pathological tile (4.5 ms per call at 2.5 M rows in the profile of round 1a); this one streams
+    the rows once."""
+
+    def forward(self, x):
+        shp = x.shape
+        y = ops.linear(x.reshape(-1, shp[-1]), self.weight.t(), self.bias)
+        return y.view(*shp[:-1], self.out_features)
+
+
 class _Lin(torch.nn.Module):
     """PyG's `Linear(in, out, bias=False, weight_initializer="glorot")`: a bare weight [out, in]."""
 

@@ -1,0 +1,74 @@
+"""Worker of tests/test_distributed.py: one data-parallel training step of BatchedDCRNN / TGCN2 under gloo, kernels on
+the CPU test double.  Run as `python tests/dist_worker.py <model> <out.pt>` with RANK / WORLD_SIZE / MASTER_* set."""
+import os
+import sys
+import warnings
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import build_emu_library  # noqa: E402
+from pytorch_geometric_temporal_amd import _lib, dp  # noqa: E402
+from pytorch_geometric_temporal_amd.dataset import synthetic as syn  # noqa: E402
+from pytorch_geometric_temporal_amd.nn.recurrent import TGCN2, BatchedDCRNN  # noqa: E402
+
+
+def build(model_name):
+    torch.manual_seed(1234)
+    if model_name == "dcrnn":
+        return BatchedDCRNN(2, 4, K=2)
+    return TGCN2(2, 4, batch_size=1)
+
+
+def batch_loss(model_name, model, X, y, ei, ew):
+    if model_name == "dcrnn":
+        out = model(X, ei, ew)                       # [B, T, N, O]
+        return (out.mean(dim=-1) - y).abs().mean()
+    out = model(X[:, -1], ei, ew)                    # [B, N, O]
+    return (out.mean(dim=-1) - y[:, -1]).abs().mean()
+
+
+def main():
+    model_name, out_path = sys.argv[1], sys.argv[2]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _lib._set_library_for_testing(_lib.PgtLib(build_emu_library()))
+    rank, _, world = dp.init_from_env(backend="gloo")
+    n, T, total = 12, 3, 8
+    ei_np, ew_np = syn.sensor_graph(n, 60, seed=0, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    series = torch.from_numpy(syn.traffic_series(40, n, seed=1))
+    model = build(model_name)
+    if rank != 0:                                      # ranks start different on purpose: broadcast must fix it
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    dp.broadcast_parameters(model, src=0)
+    flat = dp.FlatGradients(model.parameters())
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    losses = []
+    for epoch in range(2):
+        mine = dp.shard_indices(total, rank, world, epoch=epoch, shuffle=True, seed=7)
+        ar = torch.arange(T)
+        X = series[mine[:, None] + ar[None, :]]                      # [b, T, N, 2]
+        y = series[mine[:, None] + T + ar[None, :]][..., 0]          # [b, T, N]
+        loss = batch_loss(model_name, model, X, y, ei, ew)
+        flat.zero()
+        loss.backward()
+        flat.all_reduce_mean(world)
+        opt.step()
+        losses.append(float(dp.reduce_scalars([float(loss)])[0]) / world)
+    if rank == 0:
+        torch.save({"params": {k: v.detach().clone() for k, v in model.state_dict().items()}, "losses": losses,
+                    "world": world}, out_path)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

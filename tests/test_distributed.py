@@ -1,0 +1,70 @@
+"""Data-parallel path (SURVEY.md §8 e) under gloo with world_size 2 on CPU: two ranks on disjoint index shards +
+one flat gradient all-reduce must reproduce the single-process step on the union of the shards."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+from pytorch_geometric_temporal_amd import dp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(model, world, out_path):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), model, out_path],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return torch.load(out_path)
+
+
+@pytest.mark.parametrize("model", ["dcrnn", "tgcn"])
+def test_two_rank_step_equals_single_process_step(tmp_path, model):
+    one = _run(model, 1, str(tmp_path / "w1.pt"))
+    two = _run(model, 2, str(tmp_path / "w2.pt"))
+    assert two["world"] == 2
+    for k in one["params"]:
+        # mean of the two half-batch gradients == gradient of the full-batch mean loss (equal shard sizes)
+        assert torch.allclose(one["params"][k], two["params"][k], atol=2e-6, rtol=1e-5), k
+    assert one["losses"] == pytest.approx(two["losses"], rel=1e-5, abs=1e-6)
+
+
+def test_shard_indices_follow_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    ds = list(range(23))
+    for world in (1, 2, 4, 8):
+        for epoch in (0, 3):
+            got = []
+            for rank in range(world):
+                s = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=5)
+                s.set_epoch(epoch)
+                mine = dp.shard_indices(len(ds), rank, world, epoch=epoch, shuffle=True, seed=5)
+                assert mine.tolist() == list(iter(s))
+                got += mine.tolist()
+            assert set(got) == set(ds)          # every sample is covered (padding only repeats)
+    assert dp.shard_indices(10, 1, 2, shuffle=False).tolist() == [1, 3, 5, 7, 9]
+
+
+def test_flat_gradients_are_views_of_one_buffer():
+    m = torch.nn.Linear(3, 2)
+    flat = dp.FlatGradients(m.parameters())
+    m(torch.ones(4, 3)).sum().backward()
+    assert flat.flat.numel() == 8 and float(flat.flat.abs().sum()) > 0
+    assert m.weight.grad.data_ptr() == flat.flat.data_ptr()
+    flat.zero()
+    assert float(m.bias.grad.abs().sum()) == 0.0
+    assert flat.all_reduce_mean(1) is None       # world 1: no collective

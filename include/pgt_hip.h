@@ -43,7 +43,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 2
+#define PGT_ABI_VERSION 3
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -139,10 +139,18 @@ int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, 
 
 /* Same with a per-batch dense attention multiplier (ChebConvAttention hop 1, astgcn.py:157,169-171):
  * rows are node-major [N][B][C]; the coefficient of slot q of row i for batch b is val[q] * S[b, i, col[q]]
- * (S is the [B,N,N] spatial attention; Att_norm = norm * spatial_attention[:, row, col]). */
+ * (S is the [B,N,N] spatial attention; Att_norm = norm * spatial_attention[:, row, col]).
+ * transpose_s != 0: (rowptr, col, val) is the TRANSPOSED operator (feature gradient) and the coefficient is
+ * val[q] * S[b, col[q], i]. */
 int pgt_spmm_csr_att_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* S,
-                         int64_t n_rows, int64_t B, int64_t C, const float* X, float* Y,
+                         int64_t n_rows, int64_t B, int64_t C, const float* X, float* Y, int transpose_s,
                          pgt_stream_t stream);
+
+/* Gradient of the above w.r.t. the attention:  dS[b, i, col[q]] += val[q] * <G[i,b,:], X[col[q],b,:]>  for every slot
+ * q of every row i (G = gradient of the aggregation's output, X = its input, both [N][B][C]; dS [B,N,N] is
+ * accumulated into with fp32 atomics — zero it first).  (torch autograd of astgcn.py:157 in the reference.) */
+int pgt_sddmm_att_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t B,
+                      int64_t C, const float* G, const float* X, float* dS, pgt_stream_t stream);
 
 /* ---------------------------------------------------------------- dense feature transform (fp32 MFMA) */
 

@@ -191,3 +191,38 @@ def cheb_conv(x, edge_index, edge_weight, lin_weights, bias, normalization="sym"
     if bias is not None:
         out = out + bias
     return out
+
+
+def cheb_conv_attention(x, edge_index, spatial_attention, edge_weight, weight, bias, normalization, lambda_max=None):
+    """ChebConvAttention.forward (astgcn.py:112-183) with its in-tree __norm__ (:82-110): x [B,N,Fin],
+    spatial_attention [B,N,N], weight [K,Fin,Fout]."""
+    if normalization != "sym" and lambda_max is None:
+        raise ValueError("You need to pass `lambda_max` to `forward() in`case the normalization is non-symmetric.")
+    N = x.size(-2)
+    lam = torch.tensor(2.0 if lambda_max is None else float(lambda_max), dtype=x.dtype)
+    # __norm__ (:82-110)
+    ei, w = P.remove_self_loops(edge_index, edge_weight)
+    ei, w = P.get_laplacian(ei, w, normalization, x.dtype, N)
+    w = (2.0 * w) / lam
+    w = w.masked_fill(w == float("inf"), 0)
+    ei, w = P.add_self_loops(ei, w, fill_value=-1.0, num_nodes=N)
+    row, col = ei
+    att_norm = w * spatial_attention[:, row, col]                                     # :157  [B, E']
+    eye = torch.eye(N, dtype=x.dtype)
+    TAx_0 = torch.matmul((eye * spatial_attention).permute(0, 2, 1), x)               # :159-164
+    out = torch.matmul(TAx_0, weight[0])
+    eit = ei[[1, 0]]                                                                  # :166
+    TAx_1 = TAx_0
+    if weight.size(0) > 1:
+        # propagate(edge_index_transpose, x=TAx_0, norm=Att_norm): out[:, eit[1]] += Att_norm[:, e, None] * x[:, eit[0]]
+        msg = att_norm.unsqueeze(-1) * TAx_0[:, eit[0]]
+        TAx_1 = torch.zeros_like(TAx_0).index_add_(1, eit[1], msg)
+        out = out + torch.matmul(TAx_1, weight[1])
+    for k in range(2, weight.size(0)):
+        TAx_2 = propagate_add(eit, TAx_1, w)
+        TAx_2 = 2.0 * TAx_2 - TAx_0
+        out = out + torch.matmul(TAx_2, weight[k])
+        TAx_0, TAx_1 = TAx_1, TAx_2
+    if bias is not None:
+        out = out + bias
+    return out

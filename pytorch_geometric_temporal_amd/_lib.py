@@ -59,7 +59,8 @@ PROTOTYPES = {
     "pgt_spmm_csr_band_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32,
                                       c_f32, c_i64, ctypes.c_int32, c_ptr]),
     "pgt_csr_locality": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
-    "pgt_spmm_csr_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "pgt_spmm_csr_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
+    "pgt_sddmm_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_gemm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64,
                              c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "pgt_gemm_tn_acc_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
@@ -76,7 +77,7 @@ PROTOTYPES = {
     "pgt_swap01_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 2
+EXPECTED_ABI = 3
 
 
 class PgtLib:

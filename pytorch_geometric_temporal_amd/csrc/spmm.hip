@@ -447,11 +447,12 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(
 }
 
 // ChebConvAttention hop-1: coefficient val[q] * S[b, row, col[q]] (dense [B,N,N] attention gathered at the
-// edges instead of the reference's [B,E] temporary); rows node-major [N][B][C].
+// edges instead of the reference's [B,E] temporary); rows node-major [N][B][C].  transpose_s: the operator is the
+// transposed CSR (feature gradient), so the attention entry of slot (row <- col) is S[b, col, row].
 __global__ __launch_bounds__(256) void spmm_att_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ S, int n_rows, int B, int C, const float* __restrict__ X,
-    float* __restrict__ Y) {
+    float* __restrict__ Y, int transpose_s) {
   // one thread per (row, b, c) element
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)n_rows * B * C;
@@ -460,14 +461,47 @@ __global__ __launch_bounds__(256) void spmm_att_kernel(
   const int b = (int)((idx / C) % B);
   const int row = (int)(idx / ((int64_t)B * C));
   const int a = rowptr[row], e = rowptr[row + 1];
-  const float* Srow = S + ((int64_t)b * n_rows + row) * n_rows;
+  const float* Sb = S + (int64_t)b * n_rows * n_rows;
   float acc = 0.f;
   for (int q = a; q < e; ++q) {
     const int j = col[q];
-    const float w = val[q] * Srow[j];
+    const float sv = transpose_s ? Sb[(int64_t)j * n_rows + row] : Sb[(int64_t)row * n_rows + j];
+    const float w = val[q] * sv;
     acc = fmaf(w, X[((int64_t)j * B + b) * C + c], acc);
   }
   Y[idx] = acc;
+}
+
+// Gradient of the attention-weighted aggregation w.r.t. the attention (sampled dense-dense product):
+//   dS[b, row, col[q]] += val[q] * < G[row, b, :], X[col[q], b, :] >     for every slot q and batch entry b.
+// One 16-lane group per (slot, b): lanes stride the C channels, shuffle-reduce, one atomic per (slot, b)
+// (duplicate (row, col) slots — the Laplacian diagonal and the extra "-1" diagonal of variant 1 — land on one entry).
+__global__ __launch_bounds__(256) void sddmm_att_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
+    int B, int C, const float* __restrict__ G, const float* __restrict__ X, float* dS) {
+  const int row = (int)blockIdx.x;
+  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  const int a = rowptr[row], e = rowptr[row + 1];
+  const int64_t work = (int64_t)(e - a) * B;
+  const int64_t iters = (work + 15) / 16;           // block-uniform trip count: the shuffles need every lane
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t w = it * 16 + grp;
+    const bool live = w < work;
+    const int q = a + (int)(live ? w / B : 0);
+    const int b = (int)(live ? w % B : 0);
+    const int j = col[q < e ? q : a];
+    float acc = 0.f;
+    if (live) {
+      const float* gp = G + ((int64_t)row * B + b) * C;
+      const float* xp = X + ((int64_t)j * B + b) * C;
+      for (int c = l16; c < C; c += 16) acc = fmaf(gp[c], xp[c], acc);
+    }
+    acc += __shfl_xor(acc, 8, 16);
+    acc += __shfl_xor(acc, 4, 16);
+    acc += __shfl_xor(acc, 2, 16);
+    acc += __shfl_xor(acc, 1, 16);
+    if (live && l16 == 0) atomicAdd(dS + ((int64_t)b * n_rows + row) * n_rows + j, val[q] * acc);
+  }
 }
 
 template <int VEC>
@@ -611,15 +645,30 @@ extern "C" int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64
 
 extern "C" int pgt_spmm_csr_att_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                     const float* S, int64_t n_rows, int64_t B, int64_t C, const float* X,
-                                    float* Y, pgt_stream_t stream) {
+                                    float* Y, int transpose_s, pgt_stream_t stream) {
   PGT_REQUIRE(n_rows >= 0 && B >= 0 && C >= 0, "pgt_spmm_csr_att_f32: negative size");
   if (n_rows == 0 || B == 0 || C == 0) return PGT_OK;
   PGT_REQUIRE(rowptr && S && X && Y, "pgt_spmm_csr_att_f32: null pointer");
+  PGT_REQUIRE(Y != X, "pgt_spmm_csr_att_f32: Y must not alias X");
   PGT_REQUIRE(n_rows < ((int64_t)1 << 31) && B < ((int64_t)1 << 31) && C < ((int64_t)1 << 31),
               "pgt_spmm_csr_att_f32: size exceeds int32 indexing");
   const int64_t total = n_rows * B * C;
   PGT_REQUIRE(pgt_cdiv(total, 256) < ((int64_t)1 << 31), "pgt_spmm_csr_att_f32: grid too large");
   dim3 grid((unsigned)pgt_cdiv(total, 256)), block(256);
-  PGT_LAUNCH(spmm_att_kernel, grid, block, stream, rowptr, col, val, S, (int)n_rows, (int)B, (int)C, X, Y);
+  PGT_LAUNCH(spmm_att_kernel, grid, block, stream, rowptr, col, val, S, (int)n_rows, (int)B, (int)C, X, Y,
+             transpose_s ? 1 : 0);
   return pgt_check_launch("pgt_spmm_csr_att_f32");
+}
+
+extern "C" int pgt_sddmm_att_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                 int64_t B, int64_t C, const float* G, const float* X, float* dS,
+                                 pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0 && B >= 0 && C >= 0, "pgt_sddmm_att_f32: negative size");
+  if (n_rows == 0 || B == 0 || C == 0) return PGT_OK;
+  PGT_REQUIRE(rowptr && G && X && dS, "pgt_sddmm_att_f32: null pointer");
+  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) && B < ((int64_t)1 << 31) && C < ((int64_t)1 << 31),
+              "pgt_sddmm_att_f32: size exceeds int32 indexing");
+  PGT_LAUNCH(sddmm_att_kernel, dim3((unsigned)n_rows), dim3(256), stream, rowptr, col, val, (int)n_rows, (int)B, (int)C,
+             G, X, dS);
+  return pgt_check_launch("pgt_sddmm_att_f32");
 }

@@ -799,3 +799,91 @@ class ChebConvFunction(torch.autograd.Function):
                 spmm(g.bwd, G[1].view(N, -1), G0, T=G0, alpha=1.0, beta=1.0)
             dX = G[0]
         return dX, dW, db, None, None, None
+
+
+# --------------------------------------------------------------------------------------------- attention Chebyshev conv
+
+def spmm_att(csr, S, X3, transpose_s=False):
+    """Y[i,b,:] = sum_q val[q] * S[b,i,col[q]] * X3[col[q],b,:]   (S[b,col[q],i] when transpose_s) on [N,B,C]."""
+    lib = _lib.get_lib()
+    check_tensor(lib, S, "S")
+    check_tensor(lib, X3, "X")
+    N, B, C = X3.shape
+    Y = torch.empty_like(X3)
+    lib.call("pgt_spmm_csr_att_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), ptr(S), N, B, C, ptr(X3), ptr(Y),
+             int(bool(transpose_s)), stream_of(lib, X3))
+    return Y
+
+
+def sddmm_att(csr, G3, X3, dS):
+    """dS[b,i,col[q]] += val[q] * <G3[i,b,:], X3[col[q],b,:]>  (pgt_sddmm_att_f32)."""
+    lib = _lib.get_lib()
+    N, B, C = X3.shape
+    lib.call("pgt_sddmm_att_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), N, B, C, ptr(G3), ptr(X3), ptr(dS),
+             stream_of(lib, X3))
+    return dS
+
+
+class ChebConvAttentionFunction(torch.autograd.Function):
+    """ChebConvAttention.forward (astgcn.py:112-183) on x [B,N,Fin], S [B,N,N], W [K,Fin,Fout]:
+
+        T_0 = diag(S[b]) x[b]                         (the reference builds it through a dense eye(N)*S bmm, :159-164)
+        T_1 = sum_e norm_e S[b,row_e,col_e] T_0[col_e]  (propagate on the transposed list with Att_norm, :157,169-171)
+        T_k = 2 L T_{k-1} - T_{k-2}, k >= 2            (plain norm, :173-177)
+        out = sum_k T_k W[k] + bias
+    g = SymGraph from pgt_cheb_prep variant 1 (the in-tree __norm__, :82-110)."""
+
+    @staticmethod
+    def forward(ctx, x, S, W, bias, g, K):
+        lib = _lib.get_lib()
+        check_tensor(lib, x, "x")
+        check_tensor(lib, S, "spatial_attention")
+        B, N, C = x.shape
+        if S.shape != (B, N, N) or g.N != N:
+            raise ValueError(f"ChebConvAttention: x {tuple(x.shape)}, spatial_attention {tuple(S.shape)}, graph N={g.N}")
+        O = W.size(2)
+        M = N * B
+        Sc = S.contiguous()
+        Xnm = swap01(x.contiguous(), B, N, C)                      # [N, B, C]
+        d = torch.diagonal(Sc, dim1=1, dim2=2).t().contiguous()    # [N, B]   S[b, i, i]
+        TS = torch.empty(K, N, B, C, dtype=F32, device=x.device)
+        torch.mul(Xnm, d.unsqueeze(-1), out=TS[0])
+        if K > 1:
+            TS[1].copy_(spmm_att(g.fwd, Sc, TS[0]))
+        for k in range(2, K):
+            spmm(g.fwd, TS[k - 1].view(N, B * C), TS[k].view(N, B * C), T=TS[k - 2].view(N, B * C), alpha=2.0, beta=-1.0)
+        Wc = W.contiguous().view(K * C, O)
+        out = torch.empty(M, O, dtype=F32, device=x.device)
+        gemm(TS, C, M * C, K, C, Wc, O, 1, out, O, 0, O, bias, M, O)
+        ctx.g, ctx.K, ctx.dims = g, K, (B, N, C, O)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(TS, Wc, Sc, Xnm, d)
+        return swap01(out.view(N, B, O), N, B, O)                  # [B, N, O]
+
+    @staticmethod
+    def backward(ctx, dOut):
+        TS, Wc, Sc, Xnm, d = ctx.saved_tensors
+        g, K = ctx.g, ctx.K
+        B, N, C, O = ctx.dims
+        M = N * B
+        dev = dOut.device
+        dO = swap01(dOut.contiguous(), B, N, O).view(M, O)          # node-major rows
+        dW = torch.zeros_like(Wc)
+        db = torch.zeros(O, dtype=F32, device=dev) if ctx.has_bias else None
+        gemm_tn_acc(TS, C, M * C, K, C, dO, O, dW, O, db, M, O)
+        G = torch.empty(K, N, B, C, dtype=F32, device=dev)
+        gemm(dO, O, 0, 1, O, Wc, 1, O, G, C, M * C, C, None, M, K * C)
+        for k in range(K - 1, 1, -1):                               # adjoint of T_k = 2 L T_{k-1} - T_{k-2}
+            Gk, Gp = G[k].view(N, B * C), G[k - 1].view(N, B * C)
+            spmm(g.bwd, Gk, Gp, T=Gp, alpha=2.0, beta=1.0)
+            axpby2d(G[k - 2].view(M, C), G[k].view(M, C), -1.0, G[k - 2].view(M, C), 1.0)
+        dS = torch.zeros(B, N, N, dtype=F32, device=dev)
+        if K > 1:
+            sddmm_att(g.fwd, G[1], TS[0], dS)                       # d/dS of the attention-weighted hop
+            G[0].add_(spmm_att(g.bwd, Sc, G[1], transpose_s=True))  # d/dT_0 through the same hop
+        # T_0 = d * X : d/dX and the diagonal of d/dS
+        dXnm = G[0] * d.unsqueeze(-1)
+        dd = (G[0] * Xnm).sum(dim=-1)                               # [N, B]
+        torch.diagonal(dS, dim1=1, dim2=2).add_(dd.t())
+        dx = swap01(dXnm.contiguous(), N, B, C)
+        return dx, dS, dW.view(K, C, O), db, None, None

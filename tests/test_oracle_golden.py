@@ -62,3 +62,14 @@ def test_a3tgcn_matches_reference_fixture(name):
     X, H0, ei, ew, p = g["in"]["X"], g["in"]["H0"], g["in"]["edge_index"], g["in"]["edge_weight"], g["param"]
     assert_close_with_nonfinite(F.a3tgcn(X, ei, ew, None, p), g["out"]["H_weight"], **TOL)
     assert_close_with_nonfinite(F.a3tgcn(X, ei, ew, H0, p), g["out"]["H_weight_hidden"], **TOL)
+
+
+def test_chebconvattention_matches_reference_fixture():
+    g = load_golden("chebconvattention_sensor")
+    X, S, ei, ew = g["in"]["X"], g["in"]["S"], g["in"]["edge_index"], g["in"]["edge_weight"]
+    W, b = g["param"]["_weight"], g["param"]["_bias"]
+    for norm, lam in (("sym", None), ("rw", float(g["meta"]["lambda_rw"])), (None, float(g["meta"]["lambda_none"]))):
+        out = F.cheb_conv_attention(X, ei, S, ew, W, b, norm, lam)
+        assert_close_with_nonfinite(out, g["out"]["out_" + str(norm)], what=str(norm), **TOL)
+        out = F.cheb_conv_attention(X, ei, S, None, W, b, norm, lam)
+        assert_close_with_nonfinite(out, g["out"]["out_noweight_" + str(norm)], what=f"no weight {norm}", **TOL)

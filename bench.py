@@ -212,19 +212,21 @@ def main():
         ops.KERNEL_TIMER = None
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
         k = kernels[dom]
-        if dom == "spmm":
+        names = {"spmm": "spmm_wide_kernel<4> (pgt_spmm_csr_f32)",
+                 "stack": "dconv_slab_fwd/bwd_kernel (pgt_dconv_stack_slab(_bwd)_f32)",
+                 "gemm": "gemm_kernel (pgt_gemm_f32)", "gemm_tn": "gemm_tn_kernel (pgt_gemm_tn_acc_f32)"}
+        if dom in ("spmm", "stack"):
             ach = k["work_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
-            roof = {"kernel": "spmm_wide_kernel<4> (pgt_spmm_csr_f32)", "bound": "hbm", "achieved": ach,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roof = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None}
         else:
             ach = k["work_per_launch"] / (k["avg_us"] * 1e-6) / 1e12
-            roof = {"kernel": {"gemm": "gemm_kernel (pgt_gemm_f32)", "gemm_tn": "gemm_tn_kernel (pgt_gemm_tn_acc_f32)"}[dom],
-                    "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+            roof = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None}
         roof["avg_us_per_launch"] = k["avg_us"]
         roof["launches_per_step"] = k["launches"] / args.profile_steps
         for kk, v in kernels.items():
-            if kk == "spmm":
+            if kk in ("spmm", "stack"):
                 v["achieved_GBs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
                 v["hbm_frac"] = v["achieved_GBs"] / HBM_PEAK_GBS
             else:

@@ -23,6 +23,7 @@
  *                         dcrnn.py:39-40,86-87,95-100,300-313; astgcn.py:169-175,185-190; evolvegcno.py:95-101
  *                         (index_select -> norm*x_j -> scatter_add, fused, with the 2*P*T - T0 epilogue of dcrnn.py:96,100)
  *   pgt_spmm_csr_band_f32 the same propagate call sites on a locality-ordered graph (LDS-window schedule)
+ *   pgt_dconv_stack_slab* the K-hop recursion dcrnn.py:85-106 (all propagate calls of one DConv) for small graphs
  *   pgt_gemm_f32          the dense feature transforms: dcrnn.py:81-83,88-92,101-105 (torch.matmul on weight[d][k]);
  *                         PyG Linear in GCNConv/ChebConv; temporalgcn.py:84,90,96 (linear_{z,r,h})
  *   pgt_gemm_tn_acc_f32   autograd of the above w.r.t. the weights (torch autograd in the reference)
@@ -43,7 +44,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 3
+#define PGT_ABI_VERSION 4
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -151,6 +152,26 @@ int pgt_spmm_csr_att_f32(const int32_t* rowptr, const int32_t* col, const float*
  * accumulated into with fp32 atomics — zero it first).  (torch autograd of astgcn.py:157 in the reference.) */
 int pgt_sddmm_att_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t B,
                       int64_t C, const float* G, const float* X, float* dS, pgt_stream_t stream);
+
+/* ---------------------------------------------------------------- small-graph diffusion stack (LDS-resident) */
+
+/* The whole diffusion stack of DConv / BatchedDConv (dcrnn.py:85-106) for a batch of samples sharing one small graph,
+ * in ONE launch.  Rows are BATCH-major (m = b*N + n): sample b's [N, C] block of stack segment s starts at
+ * TS + s*seg_stride + b*N*C (unit column stride, row stride C).  Segment order: [T0 | T1o T1i | T2o T2i].
+ * Reads segment 0, writes segments 1..2K-2:  T1 = P T0,  T2 = 2 P T1 - T0.   K = 2 or 3 (K < 2: no-op).
+ * A sample's block and both operators must fit a CU's LDS: pgt_dconv_stack_slab_fits() != 0 (METR-LA, PeMS-BAY at
+ * hidden <= 32, Chickenpox, EnglandCovid do); otherwise PGT_ERR_INVALID — run the hops with pgt_spmm_csr_f32.
+ * nnz_o / nnz_i: number of slots of the two operators (host values; E for a DConv graph). */
+int pgt_dconv_stack_slab_fits(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i);
+int pgt_dconv_stack_slab_f32(const pgt_csr* fwd_o, const pgt_csr* fwd_i, int64_t nnz_o, int64_t nnz_i, int64_t N,
+                             int64_t n_samples, int64_t C, int64_t K, float* TS, int64_t seg_stride,
+                             pgt_stream_t stream);
+/* Adjoint of the above on the TRANSPOSED operators: G holds d/d[T0 | T1o T1i | T2o T2i] in the same layout; on exit
+ * segment 0 holds d/dT0 (segments 1.. are left as they were).  folded != 0: the "- Tx_0" adjoint (G0 -= G2o + G2i)
+ * was already applied through the weights of the feature-gradient GEMM. */
+int pgt_dconv_stack_slab_bwd_f32(const pgt_csr* bwd_o, const pgt_csr* bwd_i, int64_t nnz_o, int64_t nnz_i, int64_t N,
+                                 int64_t n_samples, int64_t C, int64_t K, float* G, int64_t seg_stride, int folded,
+                                 pgt_stream_t stream);
 
 /* ---------------------------------------------------------------- dense feature transform (fp32 MFMA) */
 

@@ -61,6 +61,11 @@ PROTOTYPES = {
     "pgt_csr_locality": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "pgt_spmm_csr_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
     "pgt_sddmm_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "pgt_dconv_stack_slab_fits": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "pgt_dconv_stack_slab_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64,
+                                         c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
+    "pgt_dconv_stack_slab_bwd_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64,
+                                             c_i64, c_i64, c_i64, c_ptr, c_i64, c_int, c_ptr]),
     "pgt_gemm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64,
                              c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "pgt_gemm_tn_acc_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
@@ -77,7 +82,7 @@ PROTOTYPES = {
     "pgt_swap01_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 3
+EXPECTED_ABI = 4
 
 
 class PgtLib:

@@ -126,9 +126,17 @@ class BatchedDCRNN(torch.nn.Module):
             raise ValueError(f"expected {self.in_channels} input features, got {Fin}")
         g = ops.dconv_graph(edge_index, edge_weight, N, strict_dense=False)
         Wzr, bzr, Wh, bh = _cell_weights(self.conv_x_z, self.conv_x_r, self.conv_x_h)
-        # [B][T*N][F] -> [T*N][B][F]  (node-major rows m = n*B + b per step)
+        O = self.out_channels
+        if ops.slab_fits(g, Fin + O, self.K):
+            # small graph: batch-major rows m = b*N + n; every diffusion stack is ONE LDS-resident launch.
+            # [B][T][N*F] -> [T][B][N*F]
+            Xbm = ops.Swap01.apply(X.contiguous().view(B, T, N * Fin), B, T, N * Fin).view(T, B * N, Fin)
+            H0 = torch.zeros(B * N, O, device=X.device, dtype=X.dtype)
+            Hs = ops.DCRNNSeqFunction.apply(Xbm, H0, Wzr, bzr, Wh, bh, g, self.K, B, True)     # [T, B*N, O]
+            return ops.Swap01.apply(Hs.view(T, B, N * O), T, B, N * O).view(B, T, N, O)
+        # [B][T*N][F] -> [T*N][B][F]  (node-major rows m = n*B + b per step: one aggregation launch per hop)
         Xnm = ops.Swap01.apply(X.contiguous().view(B, T * N, Fin), B, T * N, Fin).view(T, N * B, Fin)
-        H0 = torch.zeros(N * B, self.out_channels, device=X.device, dtype=X.dtype)
+        H0 = torch.zeros(N * B, O, device=X.device, dtype=X.dtype)
         Hs = ops.DCRNNSeqFunction.apply(Xnm, H0, Wzr, bzr, Wh, bh, g, self.K, B)   # [T, N*B, O]
-        out = ops.Swap01.apply(Hs.view(T * N, B, self.out_channels), T * N, B, self.out_channels)
-        return out.view(B, T, N, self.out_channels)
+        out = ops.Swap01.apply(Hs.view(T * N, B, O), T * N, B, O)
+        return out.view(B, T, N, O)

@@ -395,6 +395,33 @@ def _stack_bwd(g, G, K, Nn, folded=False):
             spmm(csr, G[1 + d].view(Nn, -1), G0, T=G0, alpha=1.0, beta=1.0)
 
 
+def slab_fits(g, C, K):
+    """True when the LDS-resident one-launch diffusion stack (pgt_dconv_stack_slab_f32) covers this shape."""
+    if K < 2:
+        return False
+    lib = _lib.get_lib()
+    return bool(lib._pgt_dconv_stack_slab_fits(g.N, int(C), int(K), g.E, g.E))
+
+
+def _slab_fwd(g, TS0, seg_stride, n_samples, C, K):
+    """TS0: the [n_samples*N, C] block of segment 0 (batch-major rows); the other segments follow at seg_stride."""
+    lib = _lib.get_lib()
+    so, si = g.fwd_o.struct(), g.fwd_i.struct()
+    work = (5 if K >= 3 else 3) * 4 * TS0.numel() if KERNEL_TIMER else 0
+    _timed("stack", work, lambda: lib.call(
+        "pgt_dconv_stack_slab_f32", ctypes.byref(so), ctypes.byref(si), g.E, g.E, g.N, n_samples, C, K, ptr(TS0),
+        seg_stride, stream_of(lib, TS0)))
+
+
+def _slab_bwd(g, G0, seg_stride, n_samples, C, K, folded):
+    lib = _lib.get_lib()
+    so, si = g.bwd_o.struct(), g.bwd_i.struct()
+    work = (6 if K >= 3 else 4) * 4 * G0.numel() if KERNEL_TIMER else 0
+    _timed("stack", work, lambda: lib.call(
+        "pgt_dconv_stack_slab_bwd_f32", ctypes.byref(so), ctypes.byref(si), g.E, g.E, g.N, n_samples, C, K, ptr(G0),
+        seg_stride, int(bool(folded)), stream_of(lib, G0)))
+
+
 def stack_weight(weight):
     """DConv weight [2,K,C,O] -> stacked [(2K-1)*C, O] matching the segment order of _stack_fwd.
     Segment 0 carries W[0,0] + W[1,0] (the reference computes X@W[0,0] + X@W[1,0], dcrnn.py:81-83)."""
@@ -421,11 +448,15 @@ class DConvFunction(torch.autograd.Function):
         O = Wst.size(1)
         TS = torch.empty(S, 1, M, C, dtype=F32, device=X.device)
         copy2d(TS[0, 0], X)
-        _stack_fwd(g, TS, 0, K, Nn)
+        slab = B == 1 and slab_fits(g, C, K)      # one sample: batch-major == node-major
+        if slab:
+            _slab_fwd(g, TS[0, 0], M * C, 1, C, K)
+        else:
+            _stack_fwd(g, TS, 0, K, Nn)
         Wc = Wst.contiguous()
         out = torch.empty(M, O, dtype=F32, device=X.device)
         gemm(TS, C, M * C, S, C, Wc, O, 1, out, O, 0, O, bias, M, O)
-        ctx.g, ctx.K, ctx.B = g, K, B
+        ctx.g, ctx.K, ctx.B, ctx.slab = g, K, B, slab
         ctx.has_bias = bias is not None
         ctx.save_for_backward(TS, Wc)
         return out
@@ -446,7 +477,10 @@ class DConvFunction(torch.autograd.Function):
             G = torch.empty(S, M, C, dtype=F32, device=dH.device)
             Wb, folded = fold_backward_weight(Wc, K, C)
             gemm(dH, O, 0, 1, O, Wb, 1, O, G, C, M * C, C, None, M, S * C)
-            _stack_bwd(g, G, K, g.N, folded)
+            if ctx.slab:
+                _slab_bwd(g, G[0], M * C, 1, C, K, folded)
+            else:
+                _stack_bwd(g, G, K, g.N, folded)
             dX = G[0]
         return dX, dW, db, None, None, None
 
@@ -501,7 +535,9 @@ class DCRNNSeqFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, X, H0, Wzr, bzr, Wh, bh, g, K, B):
+    def forward(ctx, X, H0, Wzr, bzr, Wh, bh, g, K, B, batch_major=False):
+        """batch_major: rows m = b*N + n and the diffusion stacks run as ONE LDS-resident launch per conv
+        (pgt_dconv_stack_slab_f32; requires slab_fits); otherwise rows m = n*B + b and one launch per hop."""
         lib = _lib.get_lib()
         check_tensor(lib, X, "X")
         check_tensor(lib, H0, "H0")
@@ -524,19 +560,31 @@ class DCRNNSeqFunction(torch.autograd.Function):
         Hout = torch.empty(T, M, O, dtype=F32, device=dev)
         H0c = H0.contiguous()
         seg = T * M * C
+        slab = bool(batch_major) or (B == 1 and slab_fits(g, C, K))
+        if slab and K > 1 and not slab_fits(g, C, K):
+            raise ValueError("DCRNNSeqFunction: batch-major rows need the LDS-resident stack (slab_fits)")
+
+        def stack(TSx, t):
+            if K < 2:
+                return
+            if slab:
+                _slab_fwd(g, TSx[0, t], seg, B, C, K)
+            else:
+                _stack_fwd(g, TSx, t, K, Nn)
+
         for t in range(T):
             Xt, Hp = X[t], (H0c if t == 0 else Hout[t - 1])
             copy2d(TSzr[0, t][:, :Fin], Xt)
             if t == 0:
                 copy2d(TSzr[0, t][:, Fin:], Hp)     # later steps: written by the previous step's blend kernel
-            _stack_fwd(g, TSzr, t, K, Nn)
+            stack(TSzr, t)
             gemm(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, ZR[t], 2 * O, 0, 2 * O, bzr, M, 2 * O)
             copy2d(TSh[0, t][:, :Fin], Xt)
             _gru_zr(ZR[t], Hp, TSh[0, t], Fin)
-            _stack_fwd(g, TSh, t, K, Nn)
+            stack(TSh, t)
             gemm(TSh[0, t], C, seg, S, C, Wh_c, O, 1, HT[t], O, 0, O, bh, M, O)
             _gru_h(HT[t], ZR[t], Hp, Hout[t], TSzr[0, t + 1][:, Fin:] if t + 1 < T else None)
-        ctx.g, ctx.K, ctx.B, ctx.Fin = g, K, B, Fin
+        ctx.g, ctx.K, ctx.B, ctx.Fin, ctx.slab = g, K, B, Fin, slab
         ctx.has_bias = (bzr is not None, bh is not None)
         ctx.save_for_backward(TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c)
         return Hout
@@ -558,19 +606,29 @@ class DCRNNSeqFunction(torch.autograd.Function):
         G = torch.empty(S, M, C, dtype=F32, device=dev)
         Wh_b, folded = fold_backward_weight(Wh_c, K, C)
         Wzr_b, _ = fold_backward_weight(Wzr_c, K, C)
+        B = ctx.B
+
+        def stack_bwd():
+            if K < 2:
+                return
+            if ctx.slab:
+                _slab_bwd(g, G[0], M * C, B, C, K, folded)
+            else:
+                _stack_bwd(g, G, K, Nn, folded)
+
         for t in range(T - 1, -1, -1):
             Hp = H0c if t == 0 else Hout[t - 1]
             # d/dH_t = dOut[t] + running state gradient, summed inside the gate-backward kernel
             _gru_h_bwd(dOut[t], ZR[t], Hp, HT[t], dPh[t], dPzr[t], dH, accumulate=False, dHn2=dH)
             # candidate conv: dT = dPh Wh^T ; adjoint of the stack
             gemm(dPh[t], O, 0, 1, O, Wh_b, 1, O, G, C, M * C, C, None, M, S * C)
-            _stack_bwd(g, G, K, Nn, folded)
+            stack_bwd()
             _gru_zr_bwd(G[0], Fin, ZR[t], Hp, dPzr[t], dH)
             if need_x:
                 copy2d(dX[t], G[0][:, :Fin])
             # gate convs
             gemm(dPzr[t], 2 * O, 0, 1, 2 * O, Wzr_b, 1, 2 * O, G, C, M * C, C, None, M, S * C)
-            _stack_bwd(g, G, K, Nn, folded)
+            stack_bwd()
             add2d(dH, G[0][:, Fin:])
             if need_x:
                 add2d(dX[t], G[0][:, :Fin])
@@ -585,7 +643,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             dbh = torch.zeros(O, dtype=F32, device=dev) if ctx.has_bias[1] else None
             gemm_tn_acc(TSh, C, seg, S, C, dPh, O, dWh, O, dbh, T * M, O)
         dH0 = dH if ctx.needs_input_grad[1] else None
-        return dX, dH0, dWzr, dbzr, dWh, dbh, None, None, None
+        return dX, dH0, dWzr, dbzr, dWh, dbh, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- generic building blocks

@@ -163,9 +163,7 @@ def probe_step():
     ei, ew = syn.sensor_graph(207, 1515, seed=0)
     ei, ew = torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev)
     for hidden in (64, 2):
-        for B in (64, 256, 1024, 4096):
-            if hidden == 64 and B > 2048:
-                continue
+        for B in ((64, 256, 1024, 1236, 1900, 2528) if hidden == 64 else (64, 1024, 4096)):
             torch.manual_seed(0)
             model = Model(hidden).to(dev)
             flat = FlatGrads(model.parameters())

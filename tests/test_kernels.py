@@ -467,3 +467,69 @@ def test_locality_hint_is_measured_per_operator(backend):
     assert g.fwd_o.halo == 96
     small = ops.DConvGraph(*[backend.t(a) for a in syn.sensor_graph(207, 1515, seed=0)], 207)
     assert small.fwd_o.halo == 0          # tiny graphs keep the plain schedule
+
+
+# ------------------------------------------------------------------------------------------------ LDS-resident diffusion stack
+
+@pytest.mark.parametrize("n,C,K,B", [(20, 36, 2, 3), (40, 6, 3, 5), (33, 7, 3, 2), (207, 66, 3, 2)])
+def test_slab_stack_equals_per_hop_launches(backend, n, C, K, B):
+    """pgt_dconv_stack_slab(_bwd)_f32 (batch-major rows, one launch) against the per-hop pgt_spmm_csr_f32 path
+    (node-major rows), forward and adjoint, folded and unfolded."""
+    if backend.name == "emu" and n > 100:
+        B = 1
+    ei, ew = syn.sensor_graph(n, 6 * n, seed=n, symmetric=False)
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), n)
+    assert ops.slab_fits(g, C, K)
+    S = 2 * K - 1
+    gen = torch.Generator().manual_seed(C)
+    X = torch.randn(B, n, C, generator=gen)
+    # node-major reference: rows m = n*B + b
+    TSn = torch.zeros(S, 1, n * B, C)
+    TSn[0, 0] = X.permute(1, 0, 2).reshape(n * B, C)
+    TSn = backend.t(TSn)
+    ops._stack_fwd(g, TSn, 0, K, n)
+    # batch-major slab
+    TSb = torch.zeros(S, 1, B * n, C)
+    TSb[0, 0] = X.reshape(B * n, C)
+    TSb = backend.t(TSb)
+    ops._slab_fwd(g, TSb[0, 0], B * n * C, B, C, K)
+    ref = TSn.cpu().view(S, n, B, C).permute(0, 2, 1, 3).reshape(S, B * n, C)
+    assert_close_with_nonfinite(TSb.cpu().view(S, B * n, C), ref, 1e-6, 1e-6, "forward stack")
+    for folded in (False, True):
+        Gsrc = torch.randn(S, B, n, C, generator=gen)
+        Gn = backend.t(Gsrc.permute(0, 2, 1, 3).reshape(S, n * B, C).contiguous())
+        ops._stack_bwd(g, Gn, K, n, folded)
+        Gb = backend.t(Gsrc.reshape(S, B * n, C).contiguous())
+        ops._slab_bwd(g, Gb[0], B * n * C, B, C, K, folded)
+        refg = Gn[0].cpu().view(n, B, C).permute(1, 0, 2).reshape(B * n, C)
+        assert_close_with_nonfinite(Gb[0], refg, 2e-6, 2e-6, f"adjoint folded={folded}")
+        assert torch.equal(Gb[1:].cpu(), Gsrc.reshape(S, B * n, C)[1:])      # other segments untouched
+
+
+def test_slab_stack_rejects_what_does_not_fit_lds(backend):
+    ei, ew = syn.sensor_graph(600, 3000, seed=0, symmetric=False)
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), 600)
+    assert not ops.slab_fits(g, 66, 3)        # 2 x 600 x 66 x 4 B > 160 KiB
+    assert not ops.slab_fits(g, 4, 4)         # K > 3
+    assert ops.slab_fits(g, 4, 3)
+    TS = backend.t(torch.zeros(5, 600, 66))
+    with pytest.raises(_lib.PgtError, match="not supported"):
+        ops._slab_fwd(g, TS[0], 600 * 66, 1, 66, 3)
+
+
+def test_batched_dcrnn_node_major_fallback_for_larger_graphs(backend):
+    """N too large for the LDS-resident stack: BatchedDCRNN keeps node-major rows and one launch per hop."""
+    from pytorch_geometric_temporal_amd.nn.recurrent import BatchedDCRNN
+    n = 420 if backend.name == "emu" else 2000
+    ei_np, ew_np = syn.sensor_graph(n, 4 * n, seed=5, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    torch.manual_seed(0)
+    m = BatchedDCRNN(2, 64, K=2)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = ops.dconv_graph(backend.t(ei), backend.t(ew), n)
+    assert not ops.slab_fits(g, 66, 2)
+    X = torch.randn(1, 2, n, 2)
+    with torch.no_grad():
+        out = m.to(backend.device)(backend.t(X), backend.t(ei), backend.t(ew))
+    ref = F.batched_dcrnn(X, ei, ew, params)
+    assert_close_with_nonfinite(out, ref, 1e-5, 1e-5, "node-major fallback")

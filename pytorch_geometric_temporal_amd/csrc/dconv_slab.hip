@@ -24,7 +24,8 @@ struct SlabArgs {
 };
 
 constexpr int SLAB_THREADS = 1024;
-constexpr int MAXT = 8;  // tasks (row, V-float column group) per thread: N * C / V <= MAXT * 1024
+constexpr int MAXT_CAP = 8;  // tasks (row, V-float column group) per thread: N * C / V <= MAXT_CAP * 1024
+                             // (the kernels are instantiated for 2 / 4 / 7 / 8 tasks per thread: register arrays)
 
 template <int V>
 struct VecT;
@@ -50,7 +51,8 @@ __device__ __forceinline__ float add3(float a, float b, float c) { return a + b 
 // LDS carve-up (bytes): two [N*C] float blocks, then the two operators
 struct SlabLds {
   float* bufA; float* bufB;
-  int* rp_o; int* rp_i; int* col_o; int* col_i; float* val_o; float* val_i;
+  int* rp_o; int* rp_i;
+  int2* cv_o; int2* cv_i;   // slots packed as (col, bits of val): one ds_read_b64 per slot
 };
 __device__ __forceinline__ SlabLds carve(char* base, const SlabArgs& a) {
   SlabLds s;
@@ -58,12 +60,10 @@ __device__ __forceinline__ SlabLds carve(char* base, const SlabArgs& a) {
   s.bufA = reinterpret_cast<float*>(base);
   s.bufB = reinterpret_cast<float*>(base + blk);
   char* p = base + 2 * blk;
+  s.cv_o = reinterpret_cast<int2*>(p); p += (size_t)a.nnz_o * 8;
+  s.cv_i = reinterpret_cast<int2*>(p); p += (size_t)a.nnz_i * 8;
   s.rp_o = reinterpret_cast<int*>(p); p += (size_t)(a.N + 1) * 4;
-  s.rp_i = reinterpret_cast<int*>(p); p += (size_t)(a.N + 1) * 4;
-  s.col_o = reinterpret_cast<int*>(p); p += (size_t)a.nnz_o * 4;
-  s.col_i = reinterpret_cast<int*>(p); p += (size_t)a.nnz_i * 4;
-  s.val_o = reinterpret_cast<float*>(p); p += (size_t)a.nnz_o * 4;
-  s.val_i = reinterpret_cast<float*>(p);
+  s.rp_i = reinterpret_cast<int*>(p);
   return s;
 }
 
@@ -72,24 +72,49 @@ static size_t slab_lds_bytes(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i)
   return 2 * blk + 2 * (size_t)(N + 1) * 4 + 2 * (size_t)(nnz_o + nnz_i) * 4;
 }
 
+__device__ __forceinline__ float as_float(int v) {
+  union { int i; float f; } u;
+  u.i = v;
+  return u.f;
+}
+__device__ __forceinline__ int as_int(float v) {
+  union { int i; float f; } u;
+  u.f = v;
+  return u.i;
+}
+
+// sum over the slots of row r, sequential fma chain in slot order; four slots' LDS reads are in flight at a time
 template <typename T>
-__device__ __forceinline__ T gather_row(const int* __restrict__ rp, const int* __restrict__ col,
-                                        const float* __restrict__ val, const float* __restrict__ buf, int r, int c,
-                                        int C) {
+__device__ __forceinline__ T gather_row(const int* __restrict__ rp, const int2* __restrict__ cv,
+                                        const float* __restrict__ buf, int r, int c, int C) {
   T acc = zero2(T());
+  int q = rp[r];
   const int e = rp[r + 1];
-  for (int q = rp[r]; q < e; ++q) acc = fma2(val[q], *reinterpret_cast<const T*>(buf + col[q] * C + c), acc);
+  for (; q + 4 <= e; q += 4) {
+    int2 s4[4];
+    T x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] = cv[q + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const T*>(buf + s4[u].x * C + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fma2(as_float(s4[u].y), x[u], acc);
+  }
+  for (; q < e; ++q) {
+    const int2 s1 = cv[q];
+    acc = fma2(as_float(s1.y), *reinterpret_cast<const T*>(buf + s1.x * C + c), acc);
+  }
   return acc;
 }
 
 __device__ __forceinline__ void stage_csr(const SlabArgs& a, const SlabLds& s, int tid) {
   for (int i = tid; i <= a.N; i += SLAB_THREADS) { s.rp_o[i] = a.rp_o[i]; s.rp_i[i] = a.rp_i[i]; }
-  for (int i = tid; i < a.nnz_o; i += SLAB_THREADS) { s.col_o[i] = a.col_o[i]; s.val_o[i] = a.val_o[i]; }
-  for (int i = tid; i < a.nnz_i; i += SLAB_THREADS) { s.col_i[i] = a.col_i[i]; s.val_i[i] = a.val_i[i]; }
+  for (int i = tid; i < a.nnz_o; i += SLAB_THREADS) { int2 t; t.x = a.col_o[i]; t.y = as_int(a.val_o[i]); s.cv_o[i] = t; }
+  for (int i = tid; i < a.nnz_i; i += SLAB_THREADS) { int2 t; t.x = a.col_i[i]; t.y = as_int(a.val_i[i]); s.cv_i[i] = t; }
 }
 
 // forward: segments [T0 | T1o T1i | T2o T2i]; K = 2 or 3
-template <int V, int LDS_BYTES>
+template <int V, int LDS_BYTES, int MAXT>
 __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_kernel(SlabArgs a) {
   typedef typename VecT<V>::type T;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -99,29 +124,48 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_kernel(SlabArgs a
   const int ntask = a.N * CV;
   stage_csr(a, s, tid);
 
+  // Software pipeline over samples: the T0 block of the NEXT sample is fetched into registers while this sample's
+  // hops run out of LDS, so no sample waits on its own HBM read.
+  T t0n[MAXT];
+  if ((int)blockIdx.x < a.n_samples) {
+    const float* nb = a.TS + (int64_t)blockIdx.x * a.N * a.C;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int idx = tid + j * SLAB_THREADS;
+      t0n[j] = reinterpret_cast<const T*>(nb)[idx < ntask ? idx : ntask - 1];
+    }
+  }
   for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
     float* base = a.TS + (int64_t)b * a.N * a.C;
-    T t0[MAXT], o1[MAXT], i1[MAXT];
+    T t0[MAXT], i1[MAXT];
     __syncthreads();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous sample
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS;
-      if (idx < ntask) {
-        t0[j] = reinterpret_cast<const T*>(base)[idx];
-        reinterpret_cast<T*>(s.bufA)[idx] = t0[j];
-      }
+      t0[j] = t0n[j];
+      if (idx < ntask) reinterpret_cast<T*>(s.bufA)[idx] = t0[j];
     }
     __syncthreads();
-    // hop 1: T1o = P_o T0, T1i = P_i T0
+    if (b + (int)gridDim.x < a.n_samples) {
+      const float* nb = a.TS + (int64_t)(b + (int)gridDim.x) * a.N * a.C;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        const int idx = tid + j * SLAB_THREADS;
+        t0n[j] = reinterpret_cast<const T*>(nb)[idx < ntask ? idx : ntask - 1];
+      }
+    }
+    // hop 1: T1o = P_o T0 (straight into bufB, which nobody reads during this hop), T1i = P_i T0 (registers: bufA
+    // is still being read)
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS;
       if (idx < ntask) {
         const int r = idx / CV, c = (idx - r * CV) * V;
-        o1[j] = gather_row<T>(s.rp_o, s.col_o, s.val_o, s.bufA, r, c, a.C);
-        i1[j] = gather_row<T>(s.rp_i, s.col_i, s.val_i, s.bufA, r, c, a.C);
-        reinterpret_cast<T*>(base + 1 * a.seg_stride)[idx] = o1[j];
+        const T o1 = gather_row<T>(s.rp_o, s.cv_o, s.bufA, r, c, a.C);
+        i1[j] = gather_row<T>(s.rp_i, s.cv_i, s.bufA, r, c, a.C);
+        reinterpret_cast<T*>(base + 1 * a.seg_stride)[idx] = o1;
         reinterpret_cast<T*>(base + 2 * a.seg_stride)[idx] = i1[j];
+        if (a.K >= 3) reinterpret_cast<T*>(s.bufB)[idx] = o1;
       }
     }
     if (a.K < 3) continue;  // (uniform) K == 2: no second hop
@@ -129,10 +173,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_kernel(SlabArgs a
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS;
-      if (idx < ntask) {
-        reinterpret_cast<T*>(s.bufA)[idx] = o1[j];
-        reinterpret_cast<T*>(s.bufB)[idx] = i1[j];
-      }
+      if (idx < ntask) reinterpret_cast<T*>(s.bufA)[idx] = i1[j];
     }
     __syncthreads();
     // hop 2: T2 = 2 P T1 - T0   (Tx_0 is never advanced in the reference, dcrnn.py:106)
@@ -141,8 +182,8 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_kernel(SlabArgs a
       const int idx = tid + j * SLAB_THREADS;
       if (idx < ntask) {
         const int r = idx / CV, c = (idx - r * CV) * V;
-        const T o2 = gather_row<T>(s.rp_o, s.col_o, s.val_o, s.bufA, r, c, a.C);
-        const T i2 = gather_row<T>(s.rp_i, s.col_i, s.val_i, s.bufB, r, c, a.C);
+        const T o2 = gather_row<T>(s.rp_o, s.cv_o, s.bufB, r, c, a.C);
+        const T i2 = gather_row<T>(s.rp_i, s.cv_i, s.bufA, r, c, a.C);
         reinterpret_cast<T*>(base + 3 * a.seg_stride)[idx] = axpby(2.0f, o2, -1.0f, t0[j]);
         reinterpret_cast<T*>(base + 4 * a.seg_stride)[idx] = axpby(2.0f, i2, -1.0f, t0[j]);
       }
@@ -153,7 +194,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_kernel(SlabArgs a
 // backward on the TRANSPOSED operators (a.rp_o = bwd_o ...): segments [G0 | G1o G1i | G2o G2i] -> G0 (in place)
 //   K == 3:  G1d += 2 P_d^T G2d ;  G0 += P_o^T G1o + P_i^T G1i  [ - G2o - G2i unless folded ]
 //   K == 2:  G0 += P_o^T G1o + P_i^T G1i
-template <int V, int LDS_BYTES>
+template <int V, int LDS_BYTES, int MAXT>
 __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_kernel(SlabArgs a) {
   typedef typename VecT<V>::type T;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -162,66 +203,86 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_kernel(SlabArgs a
   const int CV = a.C / V;
   const int ntask = a.N * CV;
   stage_csr(a, s, tid);
+  // the pair of blocks that opens a sample's first gather phase: (G2o, G2i) for K == 3, (G1o, G1i) for K == 2;
+  // the next sample's pair is prefetched into registers while this sample is processed
+  const int64_t lead = (a.K >= 3 ? 3 : 1) * a.seg_stride;
+  T pa[MAXT], pb[MAXT];
+  auto prefetch = [&](int bb) {
+    const float* nb = a.TS + (int64_t)bb * a.N * a.C + lead;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int idx = tid + j * SLAB_THREADS;
+      const int ic = idx < ntask ? idx : ntask - 1;
+      pa[j] = reinterpret_cast<const T*>(nb)[ic];
+      pb[j] = reinterpret_cast<const T*>(nb + a.seg_stride)[ic];
+    }
+  };
+  if ((int)blockIdx.x < a.n_samples) prefetch((int)blockIdx.x);
 
   for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
     float* base = a.TS + (int64_t)b * a.N * a.C;
-    T g1o[MAXT], g1i[MAXT];
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int idx = tid + j * SLAB_THREADS;
+      if (idx < ntask) {
+        reinterpret_cast<T*>(s.bufA)[idx] = pa[j];
+        reinterpret_cast<T*>(s.bufB)[idx] = pb[j];
+      }
+    }
+    __syncthreads();
+    if (b + (int)gridDim.x < a.n_samples) prefetch(b + (int)gridDim.x);
     if (a.K >= 3) {
+      T g1o[MAXT], g1i[MAXT];
+      // G1d' = G1d + 2 P_d^T G2d   (the elementwise operands are requested before the LDS gathers)
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) {
         const int idx = tid + j * SLAB_THREADS;
-        if (idx < ntask) {
-          reinterpret_cast<T*>(s.bufA)[idx] = reinterpret_cast<const T*>(base + 3 * a.seg_stride)[idx];
-          reinterpret_cast<T*>(s.bufB)[idx] = reinterpret_cast<const T*>(base + 4 * a.seg_stride)[idx];
-        }
+        const int ic = idx < ntask ? idx : ntask - 1;
+        g1o[j] = reinterpret_cast<const T*>(base + 1 * a.seg_stride)[ic];
+        g1i[j] = reinterpret_cast<const T*>(base + 2 * a.seg_stride)[ic];
       }
-      __syncthreads();
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) {
         const int idx = tid + j * SLAB_THREADS;
         if (idx < ntask) {
           const int r = idx / CV, c = (idx - r * CV) * V;
-          const T po = gather_row<T>(s.rp_o, s.col_o, s.val_o, s.bufA, r, c, a.C);
-          const T pi = gather_row<T>(s.rp_i, s.col_i, s.val_i, s.bufB, r, c, a.C);
-          g1o[j] = axpby(2.0f, po, 1.0f, reinterpret_cast<const T*>(base + 1 * a.seg_stride)[idx]);
-          g1i[j] = axpby(2.0f, pi, 1.0f, reinterpret_cast<const T*>(base + 2 * a.seg_stride)[idx]);
+          g1o[j] = axpby(2.0f, gather_row<T>(s.rp_o, s.cv_o, s.bufA, r, c, a.C), 1.0f, g1o[j]);
+          g1i[j] = axpby(2.0f, gather_row<T>(s.rp_i, s.cv_i, s.bufB, r, c, a.C), 1.0f, g1i[j]);
         }
       }
       __syncthreads();
-    } else {
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) {
         const int idx = tid + j * SLAB_THREADS;
         if (idx < ntask) {
-          g1o[j] = reinterpret_cast<const T*>(base + 1 * a.seg_stride)[idx];
-          g1i[j] = reinterpret_cast<const T*>(base + 2 * a.seg_stride)[idx];
+          reinterpret_cast<T*>(s.bufA)[idx] = g1o[j];
+          reinterpret_cast<T*>(s.bufB)[idx] = g1i[j];
         }
       }
+      __syncthreads();
     }
+    // G0 += P_o^T G1o' + P_i^T G1i'   [ - G2o - G2i unless folded ]
+    T g0[MAXT];
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS;
-      if (idx < ntask) {
-        reinterpret_cast<T*>(s.bufA)[idx] = g1o[j];
-        reinterpret_cast<T*>(s.bufB)[idx] = g1i[j];
-      }
+      g0[j] = reinterpret_cast<const T*>(base)[idx < ntask ? idx : ntask - 1];
     }
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS;
       if (idx < ntask) {
         const int r = idx / CV, c = (idx - r * CV) * V;
-        const T po = gather_row<T>(s.rp_o, s.col_o, s.val_o, s.bufA, r, c, a.C);
-        const T pi = gather_row<T>(s.rp_i, s.col_i, s.val_i, s.bufB, r, c, a.C);
-        T g0 = reinterpret_cast<const T*>(base)[idx];
+        const T po = gather_row<T>(s.rp_o, s.cv_o, s.bufA, r, c, a.C);
+        const T pi = gather_row<T>(s.rp_i, s.cv_i, s.bufB, r, c, a.C);
+        T g = g0[j];
         if (a.K >= 3 && !a.folded) {  // G0 -= G2o + G2i (re-read: the unfolded form is the rare one)
           const T g2o = reinterpret_cast<const T*>(base + 3 * a.seg_stride)[idx];
           const T g2i = reinterpret_cast<const T*>(base + 4 * a.seg_stride)[idx];
-          g0 = add3(g0, axpby(-1.0f, g2o, 0.0f, g2o), axpby(-1.0f, g2i, 0.0f, g2i));
+          g = add3(g, axpby(-1.0f, g2o, 0.0f, g2o), axpby(-1.0f, g2i, 0.0f, g2i));
         }
-        reinterpret_cast<T*>(base)[idx] = add3(g0, po, pi);
+        reinterpret_cast<T*>(base)[idx] = add3(g, po, pi);
       }
     }
   }
@@ -230,7 +291,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_kernel(SlabArgs a
 int slab_supported(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i, size_t* bytes) {
   if (N <= 0 || C <= 0 || K < 2 || K > 3) return 0;
   const int V = (C % 2 == 0) ? 2 : 1;
-  if (N * (C / V) > (int64_t)MAXT * SLAB_THREADS) return 0;
+  if (N * (C / V) > (int64_t)MAXT_CAP * SLAB_THREADS) return 0;
   if (nnz_o < 0 || nnz_i < 0 || nnz_o > (1 << 24) || nnz_i > (1 << 24)) return 0;
   const size_t need = slab_lds_bytes(N, C, nnz_o, nnz_i);
   if (bytes) *bytes = need;
@@ -240,21 +301,30 @@ int slab_supported(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i
 template <bool BWD>
 int launch_slab(const SlabArgs& a, size_t need, pgt_stream_t stream) {
   const int V = (a.C % 2 == 0 && pgt_aligned(a.TS, 8) && a.seg_stride % 2 == 0) ? 2 : 1;
-  if (V == 1 && (int64_t)a.N * a.C > (int64_t)MAXT * SLAB_THREADS) {
+  const int64_t ntask = (int64_t)a.N * (a.C / V);
+  if (ntask > (int64_t)MAXT_CAP * SLAB_THREADS) {
     pgt_set_error("pgt_dconv_stack_slab: block too large for the scalar path");
     return PGT_ERR_INVALID;
   }
+  const int tpt = (int)pgt_cdiv(ntask, SLAB_THREADS);
   const int nblk = a.n_samples < 256 ? a.n_samples : 256;
   dim3 grid((unsigned)nblk), block(SLAB_THREADS);
-#define PGT_SLAB_GO(V_, L_)                                                                          \
-  do {                                                                                               \
-    if (BWD) PGT_LAUNCH((dconv_slab_bwd_kernel<V_, L_>), grid, block, stream, a);                    \
-    else PGT_LAUNCH((dconv_slab_fwd_kernel<V_, L_>), grid, block, stream, a);                        \
+#define PGT_SLAB_K(V_, L_, T_)                                                                        \
+  do {                                                                                                \
+    if (BWD) PGT_LAUNCH((dconv_slab_bwd_kernel<V_, L_, T_>), grid, block, stream, a);                 \
+    else PGT_LAUNCH((dconv_slab_fwd_kernel<V_, L_, T_>), grid, block, stream, a);                     \
   } while (0)
-  if (need <= 32 * 1024) { if (V == 2) PGT_SLAB_GO(2, 32 * 1024); else PGT_SLAB_GO(1, 32 * 1024); }
-  else if (need <= 80 * 1024) { if (V == 2) PGT_SLAB_GO(2, 80 * 1024); else PGT_SLAB_GO(1, 80 * 1024); }
-  else { if (V == 2) PGT_SLAB_GO(2, 160 * 1024); else PGT_SLAB_GO(1, 160 * 1024); }
-#undef PGT_SLAB_GO
+#define PGT_SLAB_T(V_, L_)                                                                            \
+  do {                                                                                                \
+    if (tpt <= 2) PGT_SLAB_K(V_, L_, 2);                                                              \
+    else if (tpt <= 4) PGT_SLAB_K(V_, L_, 4);                                                         \
+    else if (tpt <= 7) PGT_SLAB_K(V_, L_, 7);                                                         \
+    else PGT_SLAB_K(V_, L_, 8);                                                                       \
+  } while (0)
+  if (need <= 64 * 1024) { if (V == 2) PGT_SLAB_T(2, 64 * 1024); else PGT_SLAB_T(1, 64 * 1024); }
+  else { if (V == 2) PGT_SLAB_T(2, 160 * 1024); else PGT_SLAB_T(1, 160 * 1024); }
+#undef PGT_SLAB_T
+#undef PGT_SLAB_K
   return pgt_check_launch(BWD ? "pgt_dconv_stack_slab_bwd_f32" : "pgt_dconv_stack_slab_f32");
 }
 

@@ -119,6 +119,35 @@ def probe_spmm_batched():
         lib.tune("spmm_unroll", 8); lib.tune("spmm_wide_xcd", 1)
 
 
+def probe_stack():
+    """One DConv diffusion stack (K = 3) at METR-LA shape: LDS-resident one-launch form vs one launch per hop."""
+    ei, ew = syn.sensor_graph(207, 1515, seed=0)
+    g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), 207)
+    for B, C in ((1024, 66), (256, 66), (1024, 4), (4096, 4)):
+        M = 207 * B
+        nbuf = max(2, min(8, int(1.2e9 // (5 * M * C * 4))))
+        TSs = [torch.randn(5, 1, M, C, device=dev) for _ in range(nbuf)]
+        i = [0]
+
+        def fwd_slab():
+            ops._slab_fwd(g, TSs[i[0] % nbuf][0, 0], M * C, B, C, 3); i[0] += 1
+
+        def bwd_slab():
+            ops._slab_bwd(g, TSs[i[0] % nbuf][0, 0], M * C, B, C, 3, True); i[0] += 1
+
+        def fwd_hops():
+            ops._stack_fwd(g, TSs[i[0] % nbuf], 0, 3, 207); i[0] += 1
+
+        def bwd_hops():
+            ops._stack_bwd(g, TSs[i[0] % nbuf].view(5, M, C), 3, 207, True); i[0] += 1
+        blk = M * C * 4
+        for name, fn, nb in (("slab_fwd", fwd_slab, 5 * blk), ("slab_bwd", bwd_slab, 6 * blk),
+                             ("hops_fwd", fwd_hops, 10 * blk), ("hops_bwd", bwd_hops, 16 * blk)):
+            us = timeit(fn, warm=nbuf, reps=4 * nbuf)
+            emit(probe="dconv_stack", form=name, B=B, C=C, us=us, moved_MB=nb / 1e6, GBs=nb / us / 1e3,
+                 frac=nb / us / 1e3 / 8000)
+
+
 def probe_gemm():
     for M in (13248, 211968):
         for (S, C, N) in ((5, 66, 128), (5, 66, 64), (1, 128, 330)):

@@ -18,6 +18,7 @@ __device__ long long* g_trace_buf = nullptr;
   } while (0)
 
 void pgt_gemm_set_force_small(int) {}
+void pgt_gemm_set_tn_fullk(int) {}
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/spmm.hip"
 

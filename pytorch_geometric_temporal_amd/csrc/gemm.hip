@@ -259,11 +259,144 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
   if (do_bias && (n0 + tid) < g.N) atomicAdd(g.db + n0 + tid, bsum);
 }
 
+// dW[0:Ktot, n0:n0+BN] += A[slab, 0:Ktot]^T G[slab, n0:n0+BN] with the WHOLE K extent (Ktot <= 384) in one workgroup:
+// every A element is read from HBM exactly once per column block and G exactly once (the 128x128-tiled kernel above
+// re-reads G once per k-tile: at K = 330, N = 128 that is 7.3 GB instead of 4.7 GB per DCRNN training step).
+// 512 threads = 8 wavefronts: wave w owns k-tiles {w%4, w%4 + 4, w%4 + 8} x column tiles of half w/4 — 3 x NT/2
+// accumulators of 32x32.  16 rows per step, double-buffered LDS (register-staged: 12 + 4 floats per thread).
+constexpr int TNF_ROWS = 16;
+constexpr int TNF_MAXKT = 12;
+
+template <int NT>  // column tiles of 32 per workgroup: BN = 32 * NT (NT = 2 | 4)
+__global__ __launch_bounds__(512, 2) void gemm_tn_fullk_kernel(TnArgs g, int KT, int g_vec4) {
+  constexpr int BN = 32 * NT;
+  constexpr int NH = NT / 2;                 // column tiles per wavefront
+  constexpr int LDA = TNF_MAXKT * 32 + 1;    // odd row stride: the 16 rows of a column land on different banks
+  __shared__ float As[2][TNF_ROWS][LDA];
+  __shared__ float Gs[2][TNF_ROWS][BN + 4];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wk = wave & 3, wn = wave >> 2;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int n0 = (int)blockIdx.y * BN;
+  const int Ktot = g.n_seg * g.seg_k;
+  const int ms = (int)blockIdx.x * g.rows_per_slab;
+  const int me = (ms + g.rows_per_slab < g.M) ? ms + g.rows_per_slab : g.M;
+  if (ms >= me) return;
+
+  pgt_f32x16 acc[3][NH];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // A staging: thread (row ar = tid / 32, column cg = tid % 32) loads column 32*i + cg of its row for every k-tile i
+  const int ar = tid >> 5, cg = tid & 31;
+  // G staging: 16 rows x BN columns as float4: thread f -> (row f / (BN/4), float4 column f % (BN/4))
+  constexpr int G4 = BN / 4;
+  const int gr = tid / G4, gc4 = (tid - gr * G4) * 4;
+  const bool g_thread = tid < TNF_ROWS * G4;
+  float ra[TNF_MAXKT];
+  float4 rg;
+  const bool do_bias = (g.db != nullptr) && (tid < BN);
+  float bsum = 0.f;
+
+  auto load_tile = [&](int mb) {
+    const int gm = mb + ar;
+    const bool rv = gm < me;
+    const float* arow = g.A + (int64_t)(rv ? gm : ms) * g.lda;
+#pragma unroll
+    for (int i = 0; i < TNF_MAXKT; ++i) {
+      const int kg = 32 * i + cg;
+      float t = 0.f;
+      if (i < KT && rv && kg < Ktot) {
+        const int j = kg / g.seg_k;
+        t = arow[(int64_t)j * g.a_seg_stride + (kg - j * g.seg_k)];
+      }
+      ra[i] = t;
+    }
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gm2 = mb + gr, gn = n0 + gc4;
+    if (g_thread && gm2 < me) {
+      const float* gp = g.G + (int64_t)gm2 * g.ldg + gn;
+      if (g_vec4 && gn + 3 < g.N) {
+        t = *reinterpret_cast<const float4*>(gp);
+      } else {
+        if (gn < g.N) t.x = gp[0];
+        if (gn + 1 < g.N) t.y = gp[1];
+        if (gn + 2 < g.N) t.z = gp[2];
+        if (gn + 3 < g.N) t.w = gp[3];
+      }
+    }
+    rg = t;
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < TNF_MAXKT; ++i)
+      if (i < KT) As[buf][ar][32 * i + cg] = ra[i];
+    if (g_thread) *reinterpret_cast<float4*>(&Gs[buf][gr][gc4]) = rg;
+  };
+
+  load_tile(ms);
+  store_tile(0);
+  __syncthreads();
+  int buf = 0;
+  for (int mb = ms; mb < me; mb += TNF_ROWS) {
+    const bool more = mb + TNF_ROWS < me;
+    if (more) load_tile(mb + TNF_ROWS);   // in flight while the matrix cores work on this step
+#pragma unroll
+    for (int mm = 0; mm < TNF_ROWS; mm += 2) {
+      float b[NH];
+#pragma unroll
+      for (int j = 0; j < NH; ++j) b[j] = Gs[buf][mm + hi][(wn * NH + j) * 32 + lo];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int kt = wk + 4 * i;
+        if (kt < KT) {  // wave-uniform
+          const float a = As[buf][mm + hi][kt * 32 + lo];
+#pragma unroll
+          for (int j = 0; j < NH; ++j) acc[i][j] = PGT_MFMA_32x32x2(a, b[j], acc[i][j]);
+        }
+      }
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int m = 0; m < TNF_ROWS; ++m) bsum += Gs[buf][m][tid];
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int kt = wk + 4 * i;
+    if (kt >= KT) continue;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int gn = n0 + (wn * NH + j) * 32 + lo;
+      if (gn >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (gk < Ktot) atomicAdd(g.dW + (int64_t)gk * g.lddw + gn, acc[i][j][r]);
+      }
+    }
+  }
+  if (do_bias && (n0 + tid) < g.N) atomicAdd(g.db + n0 + tid, bsum);
+}
+
+int g_tn_fullk = 1;  // pgt_tune("gemm_tn_fullk"): 0 = always the k-tiled kernel, 2 = whole-K kernel at any size (tests)
+
 int g_force_small_tiles = 0;  // pgt_tune("gemm_small_tiles"): 0 = by size, 1 = always 64x64, 2 = always 128-wide
 
 }  // namespace
 
 void pgt_gemm_set_force_small(int v) { g_force_small_tiles = v; }
+void pgt_gemm_set_tn_fullk(int v) { g_tn_fullk = v; }
 
 extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                             const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
@@ -310,6 +443,25 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
   PGT_REQUIRE(Ktot == 0 || (A && dW), "pgt_gemm_tn_acc_f32: null operand");
   PGT_REQUIRE(M < ((int64_t)1 << 31) - 4096 && N < ((int64_t)1 << 31) - 128 && Ktot < ((int64_t)1 << 31) - 128,
               "pgt_gemm_tn_acc_f32: size exceeds int32 indexing");
+  // whole-K schedule: tall slabs, K up to 384; every operand element is read once per 128-wide column block
+  if (g_tn_fullk && (M >= 16384 || g_tn_fullk == 2) && Ktot > (g_tn_fullk == 2 ? 0 : 64) && Ktot <= TNF_MAXKT * 32 &&
+      g_force_small_tiles != 1 &&
+      n_seg * a_seg_stride + lda < ((int64_t)1 << 31)) {
+    const int KT = (int)pgt_cdiv(Ktot, 32);
+    const int BNf = N > 64 ? 128 : 64;
+    const int64_t gy = pgt_cdiv(N, BNf);
+    PGT_REQUIRE(gy <= 65535, "pgt_gemm_tn_acc_f32: N too large");
+    int64_t nslab = pgt_cdiv(512, gy);
+    int64_t rows = pgt_cdiv(pgt_cdiv(M, nslab), TNF_ROWS) * TNF_ROWS;
+    nslab = pgt_cdiv(M, rows);
+    TnArgs t{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), G, ldg, dW, lddw, db, (int)M, (int)N,
+             (int)rows};
+    dim3 grid((unsigned)nslab, (unsigned)gy), block(512);
+    const int g_vec4 = (ldg % 4 == 0) && pgt_aligned(G, 16);
+    if (BNf == 128) PGT_LAUNCH((gemm_tn_fullk_kernel<4>), grid, block, stream, t, KT, g_vec4);
+    else PGT_LAUNCH((gemm_tn_fullk_kernel<2>), grid, block, stream, t, KT, g_vec4);
+    return pgt_check_launch("pgt_gemm_tn_acc_f32");
+  }
   const bool big = g_force_small_tiles == 2 || ((M >= 16384) && (Ktot > 64) && (N > 64) && g_force_small_tiles == 0);
   const int BKC = big ? 128 : 64, BN = big ? 128 : 64;
   // at least one k-tile so that the bias gradient (blockIdx.x == 0) is produced even when Ktot == 0

@@ -48,6 +48,7 @@ static __device__ __forceinline__ pgt_f4 pgt_mk4(float a, float b, float c, floa
 void pgt_set_error(const char* fmt, ...);
 // tuning knobs (pgt_tune): each translation unit owns its own
 void pgt_gemm_set_force_small(int v);
+void pgt_gemm_set_tn_fullk(int v);
 int pgt_spmm_tune(const char* key, int value);  // returns 1 when the key is known
 
 #define PGT_REQUIRE(cond, ...)            \

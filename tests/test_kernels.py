@@ -533,3 +533,33 @@ def test_batched_dcrnn_node_major_fallback_for_larger_graphs(backend):
         out = m.to(backend.device)(backend.t(X), backend.t(ei), backend.t(ew))
     ref = F.batched_dcrnn(X, ei, ew, params)
     assert_close_with_nonfinite(out, ref, 1e-5, 1e-5, "node-major fallback")
+
+
+@pytest.mark.parametrize("M,segs,segk,N", [(300, 5, 66, 128), (257, 5, 66, 64), (130, 3, 33, 100), (90, 1, 384, 20),
+                                           (64, 2, 5, 192)])
+def test_gemm_tn_whole_k_schedule(backend, M, segs, segk, N):
+    """The whole-K weight-gradient kernel (one workgroup spans every k-tile; used for M >= 16384) forced onto small
+    problems so the CPU test double covers it; on the GPU leg also at its natural size."""
+    lib = _lib.get_lib()
+    if backend.name == "hip":
+        M = M * 97
+    lib.tune("gemm_tn_fullk", 2)
+    try:
+        g = torch.Generator().manual_seed(M + N)
+        A = torch.randn(segs, M, segk, generator=g)
+        G = torch.randn(M, N, generator=g)
+        dW0 = torch.randn(segs * segk, N, generator=g)
+        db0 = torch.randn(N, generator=g)
+        refW = dW0.double() + torch.cat([A[j] for j in range(segs)], dim=1).double().t() @ G.double()
+        refb = db0.double() + G.double().sum(0)
+        dW, db = dW0.clone().to(backend.device), db0.clone().to(backend.device)
+        ops.gemm_tn_acc(A.to(backend.device), segk, M * segk, segs, segk, G.to(backend.device), N, dW, N, db, M, N)
+        tol = 2e-4 if backend.name == "emu" else 2e-3        # sums of up to ~29 000 products on the GPU leg
+        assert_close_with_nonfinite(dW, refW, tol, 1e-5, "dW")
+        assert_close_with_nonfinite(db, refb, tol, 1e-5, "db")
+        lib.tune("gemm_tn_fullk", 0)
+        dW2, db2 = dW0.clone().to(backend.device), db0.clone().to(backend.device)
+        ops.gemm_tn_acc(A.to(backend.device), segk, M * segk, segs, segk, G.to(backend.device), N, dW2, N, db2, M, N)
+        assert_close_with_nonfinite(dW2, refW, tol, 1e-5, "dW k-tiled")
+    finally:
+        lib.tune("gemm_tn_fullk", 1)

@@ -1,0 +1,77 @@
+// LAB HARNESS (not shipped): times pgt_gemm_f32 / pgt_gemm_tn_acc_f32 on the DCRNN shapes and dumps a workgroup timeline.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+
+#define PGT_TRACE 1
+__device__ long long* g_trace_buf = nullptr;
+#define PGT_TRACE_MARK(slot)                                                              \
+  do {                                                                                    \
+    if (g_trace_buf != nullptr && threadIdx.x == 0)                                       \
+      g_trace_buf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = (long long)wall_clock64(); \
+  } while (0)
+
+int pgt_spmm_tune(const char*, int) { return 0; }
+#include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
+#include "../pytorch_geometric_temporal_amd/csrc/gemm.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 211968, S = 5, C = 66, K = S * C;
+  float *A, *W, *Cout, *G, *dW, *bias;
+  CK(hipMalloc(&A, (size_t)S * M * C * 4)); CK(hipMalloc(&W, (size_t)K * 128 * 4)); CK(hipMalloc(&Cout, (size_t)M * 128 * 4));
+  CK(hipMalloc(&G, (size_t)S * M * C * 4)); CK(hipMalloc(&dW, (size_t)K * 128 * 4)); CK(hipMalloc(&bias, 128 * 4));
+  std::vector<float> h((size_t)S * M * C);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 500.f - 1.f;
+  CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, h.data(), (size_t)K * 128 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(Cout, h.data(), (size_t)M * 128 * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(bias, 0, 512)); CK(hipMemset(dW, 0, (size_t)K * 128 * 4));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto timeit = [&](const char* name, auto fn, double flop) {
+    for (int i = 0; i < 3; ++i) fn();
+    CK(hipEventRecord(e0, st));
+    const int reps = 20;
+    for (int i = 0; i < reps; ++i) fn();
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / reps;
+    printf("%-40s %9.2f us  %7.2f TF  (%.3f of 157.3)\n", name, us, flop / us / 1e6, flop / us / 1e6 / 157.3);
+  };
+  for (int N : {128, 64}) {
+    char nm[80];
+    snprintf(nm, 80, "NN  [M,330]x[330,%d] seg A", N);
+    timeit(nm, [&]() { pgt_gemm_f32(A, C, (int64_t)M * C, S, C, W, N, 1, Cout, N, 0, N, bias, M, N, 0, st); }, 2.0 * M * K * N);
+    snprintf(nm, 80, "NT  [M,%d]x[%d,330] -> seg C", N, N);
+    timeit(nm, [&]() { pgt_gemm_f32(Cout, N, 0, 1, N, W, 1, N, G, C, (int64_t)M * C, C, nullptr, M, K, 0, st); }, 2.0 * M * K * N);
+    snprintf(nm, 80, "TN  dW[330,%d] whole-K", N);
+    pgt_tune("gemm_tn_fullk", 1);
+    timeit(nm, [&]() { pgt_gemm_tn_acc_f32(A, C, (int64_t)M * C, S, C, Cout, N, dW, N, bias, M, N, st); }, 2.0 * M * K * N);
+    snprintf(nm, 80, "TN  dW[330,%d] k-tiled", N);
+    pgt_tune("gemm_tn_fullk", 0);
+    timeit(nm, [&]() { pgt_gemm_tn_acc_f32(A, C, (int64_t)M * C, S, C, Cout, N, dW, N, bias, M, N, st); }, 2.0 * M * K * N);
+    pgt_tune("gemm_tn_fullk", 1);
+  }
+  // timeline of one NN launch (N = 128)
+  long long* tr; const size_t TRN = 8192 * 4;
+  CK(hipMalloc(&tr, TRN * 8)); CK(hipMemset(tr, 0, TRN * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &tr, sizeof(tr)));
+  CK(hipDeviceSynchronize());
+  pgt_gemm_f32(A, C, (int64_t)M * C, S, C, W, 128, 1, Cout, 128, 0, 128, bias, M, 128, 0, st);
+  CK(hipDeviceSynchronize());
+  std::vector<long long> t(TRN);
+  CK(hipMemcpy(t.data(), tr, TRN * 8, hipMemcpyDeviceToHost));
+  long long t0 = -1, t1 = 0; int nb = 0; double dur = 0;
+  for (size_t b = 0; b < 8192; ++b) if (t[b * 4]) { nb++; if (t0 < 0 || t[b * 4] < t0) t0 = t[b * 4]; t1 = std::max(t1, t[b * 4 + 1]); dur += (t[b * 4 + 1] - t[b * 4]) / 100.0; }
+  printf("NN timeline: %d workgroups, span %.1f us, mean workgroup duration %.1f us\n", nb, (t1 - t0) / 100.0, dur / nb);
+  int hs[24] = {0}, he[24] = {0};
+  for (size_t b = 0; b < 8192; ++b) if (t[b * 4]) { hs[std::min(23, (int)((t[b * 4] - t0) / 100.0 / 12.0))]++; he[std::min(23, (int)((t[b * 4 + 1] - t0) / 100.0 / 12.0))]++; }
+  printf("starts per 12us:"); for (int i = 0; i < 24; ++i) printf(" %d", hs[i]); printf("\nends   per 12us:"); for (int i = 0; i < 24; ++i) printf(" %d", he[i]); printf("\n");
+  return 0;
+}

@@ -31,11 +31,14 @@ struct GemmArgs {
 
 // BM x BN tile, WM x WN sub-tiles of 32x32 per wavefront (2x2 wavefronts).  AV: floats per A load (1 | 2).
 // BKMAJ: B tile is loaded with lanes along k (B contiguous in k: the NT case) instead of along n.
-template <int BM, int BN, int AV, bool BKMAJ>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+// TBK: k-depth of a tile, 32 or 30.  The loaders keep the 32-deep lane mapping and mask k >= TBK; 30 makes K = 330
+// (five 66-wide diffusion terms) eleven exact tiles instead of 352/330 = 6.7 % padding, and brings the two padded LDS
+// tiles of the 128 x 128 shape under 32 KiB (30 960 B): four resident workgroups per CU instead of three.
+template <int BM, int BN, int AV, bool BKMAJ, int TBK>
+__global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
   constexpr int WM = BM / 64, WN = BN / 64;  // accumulators per wavefront along m / n
-  __shared__ float As[BK][BM + 1];
-  __shared__ float Bs[BK][BN + 1];
+  struct Tiles { float As[TBK][BM + 1]; float Bs[TBK][BN + 1]; };   // one object: the epilogue reuses it as a whole
+  __shared__ Tiles tl;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int lo = lane & 31, hi = lane >> 5;
   const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
   const int Ktot = g.n_seg * g.seg_k;
+  PGT_TRACE_MARK(0);
 
   pgt_f32x16 acc[WM][WN];
 #pragma unroll
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   auto load_tile = [&](int k0) {
     {
       const int kg = k0 + a_k;
-      const bool kv = kg < Ktot;
+      const bool kv = kg < Ktot && a_k < TBK;
       const int j = kv ? kg / g.seg_k : 0;
       const float* base = g.A + (int64_t)j * g.a_seg_stride + (kg - j * g.seg_k);
 #pragma unroll
@@ -93,40 +97,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const int k = BKMAJ ? b_l : b_o + p * B_OTHER_PER_PASS;
       const int n = BKMAJ ? b_o + p * B_OTHER_PER_PASS : b_l;
       const int kg = k0 + k, gn = n0 + n;
-      rb[p] = (kg < Ktot && gn < g.N) ? g.Bw[(int64_t)kg * g.sbk + (int64_t)gn * g.sbn] : 0.f;
+      rb[p] = (k < TBK && kg < Ktot && gn < g.N) ? g.Bw[(int64_t)kg * g.sbk + (int64_t)gn * g.sbn] : 0.f;
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       const int m = a_m + p * A_ROWS_PER_PASS;
-      if constexpr (AV == 2) {
-        As[a_k][m] = ra[2 * p];
-        As[a_k + 1][m] = ra[2 * p + 1];
-      } else {
-        As[a_k][m] = ra[p];
+      if (a_k < TBK) {
+        if constexpr (AV == 2) {
+          tl.As[a_k][m] = ra[2 * p];
+          tl.As[a_k + 1][m] = ra[2 * p + 1];
+        } else {
+          tl.As[a_k][m] = ra[p];
+        }
       }
     }
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
       const int k = BKMAJ ? b_l : b_o + p * B_OTHER_PER_PASS;
       const int n = BKMAJ ? b_o + p * B_OTHER_PER_PASS : b_l;
-      Bs[k][n] = rb[p];
+      if (k < TBK) tl.Bs[k][n] = rb[p];
     }
   };
 
   load_tile(0);
-  for (int k0 = 0; k0 < Ktot; k0 += BK) {
+  for (int k0 = 0; k0 < Ktot; k0 += TBK) {
     store_tile();
     __syncthreads();
-    if (k0 + BK < Ktot) load_tile(k0 + BK);  // in flight while the matrix cores work on tile k0
+    if (k0 + TBK < Ktot) load_tile(k0 + TBK);  // in flight while the matrix cores work on tile k0
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = 0; kk < TBK; kk += 2) {
       float a[WM], b[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = As[kk + hi][wm * (BM / 2) + i * 32 + lo];
+      for (int i = 0; i < WM; ++i) a[i] = tl.As[kk + hi][wm * (BM / 2) + i * 32 + lo];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = Bs[kk + hi][wn * (BN / 2) + j * 32 + lo];
+      for (int j = 0; j < WN; ++j) b[j] = tl.Bs[kk + hi][wn * (BN / 2) + j * 32 + lo];
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -135,7 +141,69 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // D map (cdna_hip_programming.md §3): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // ---- epilogue.  D map (cdna_hip_programming.md §3): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5):
+  // stored straight from the accumulators a lane writes 4 bytes per row (16 rows x 128-byte pieces per instruction).
+  // Instead each wavefront transposes its 32-row blocks through LDS (the A/B tiles are dead after the last barrier)
+  // and writes row-contiguous float2 / float4: a column segment of the output (66-wide diffusion terms) stays 8-byte
+  // aligned, a plain matrix 16-byte aligned.
+  constexpr int EPW = 32 * WN + 4;                                   // floats per staged row (+4: rows on different banks)
+  constexpr bool EPI_LDS = sizeof(Tiles) >= 4 * 16 * EPW * sizeof(float);
+  const int ev = g.accumulate ? 1 : g.c_seg_n == g.N ? 4 : 2;        // widest store the layout allows
+  if (EPI_LDS && ev > 1 && g.ldc % ev == 0 && g.c_seg_n % ev == 0 && g.c_seg_stride % ev == 0 &&
+      (reinterpret_cast<uintptr_t>(g.C) % (4 * ev)) == 0) {
+    // each wavefront stages 16 rows x (32 * WN) columns at a time inside the (now dead) tile storage
+    float* stage = reinterpret_cast<float*>(&tl) + wave * 16 * EPW;
+    const int nw0 = n0 + wn * (BN / 2);                               // first column of this wavefront
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                                   // accumulator registers 8h .. 8h+7 = rows 16h .. 16h+15
+        PGT_WAVE_SYNC();
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int gn = nw0 + j * 32 + lo;
+          const float bv = (g.bias && gn < g.N) ? g.bias[gn] : 0.f;
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8)
+            stage[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EPW + j * 32 + lo] = acc[i][j][8 * h + r8] + bv;
+        }
+        PGT_WAVE_SYNC();
+        const int mrow0 = m0 + wm * (BM / 2) + i * 32 + 16 * h;
+        if (ev == 4) {
+          constexpr int LPR = 32 * WN / 4;                            // lanes per row (8 | 16)
+          constexpr int RPP = 64 / LPR;                               // rows per pass
+#pragma unroll
+          for (int rr = 0; rr < 16; rr += RPP) {
+            const int row = rr + lane / LPR, c = (lane % LPR) * 4;
+            const int gm = mrow0 + row, gn = nw0 + c;
+            if (gm < g.M && gn < g.N) {
+              const float4 v = *reinterpret_cast<const float4*>(stage + row * EPW + c);
+              float* p = g.C + (int64_t)gm * g.ldc + gn;
+              if (gn + 3 < g.N) *reinterpret_cast<float4*>(p) = v;
+              else { p[0] = v.x; if (gn + 1 < g.N) p[1] = v.y; if (gn + 2 < g.N) p[2] = v.z; }
+            }
+          }
+        } else {
+          constexpr int LPR = 32 * WN / 2;                            // lanes per row (16 | 32)
+          constexpr int RPP = 64 / LPR;
+#pragma unroll
+          for (int rr = 0; rr < 16; rr += RPP) {
+            const int row = rr + lane / LPR, c = (lane % LPR) * 2;
+            const int gm = mrow0 + row, gn = nw0 + c;
+            if (gm < g.M && gn < g.N) {
+              const float2 v = *reinterpret_cast<const float2*>(stage + row * EPW + c);
+              const int js = gn / g.c_seg_n;
+              float* p = g.C + (int64_t)js * g.c_seg_stride + (int64_t)gm * g.ldc + (gn - js * g.c_seg_n);
+              if (gn + 1 < g.N) *reinterpret_cast<float2*>(p) = v;     // c_seg_n even: a pair never straddles segments
+              else p[0] = v.x;
+            }
+          }
+        }
+      }
+    }
+    PGT_TRACE_MARK(1);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int gn = n0 + wn * (BN / 2) + j * 32 + lo;
@@ -157,6 +225,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       }
     }
   }
+  PGT_TRACE_MARK(1);
 }
 
 struct TnArgs {
@@ -416,19 +485,28 @@ extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, i
   const bool kmaj = (sbk == 1 && sbn != 1);
   const bool big = g_force_small_tiles == 2 || ((M >= 2048) && g_force_small_tiles == 0);
   dim3 block(256);
-#define PGT_GEMM_GO(BM_, BN_)                                                                         \
+  // tile depth with the least K padding (30 divides the 330-wide diffusion stack; 32 the power-of-two widths)
+  const int64_t Ktot = n_seg * seg_k;
+  const bool d30 = pgt_cdiv(Ktot, 30) * 30 < pgt_cdiv(Ktot, 32) * 32;
+#define PGT_GEMM_GO2(BM_, BN_, D_)                                                                    \
   do {                                                                                                \
     const int64_t gx = pgt_cdiv(M, BM_), gy = pgt_cdiv(N, BN_);                                       \
     PGT_REQUIRE(gy <= 65535, "pgt_gemm_f32: N too large");                                            \
     dim3 grid((unsigned)gx, (unsigned)gy);                                                            \
-    if (av2 && kmaj) PGT_LAUNCH((gemm_kernel<BM_, BN_, 2, true>), grid, block, stream, g);            \
-    else if (av2) PGT_LAUNCH((gemm_kernel<BM_, BN_, 2, false>), grid, block, stream, g);              \
-    else if (kmaj) PGT_LAUNCH((gemm_kernel<BM_, BN_, 1, true>), grid, block, stream, g);              \
-    else PGT_LAUNCH((gemm_kernel<BM_, BN_, 1, false>), grid, block, stream, g);                       \
+    if (av2 && kmaj) PGT_LAUNCH((gemm_kernel<BM_, BN_, 2, true, D_>), grid, block, stream, g);        \
+    else if (av2) PGT_LAUNCH((gemm_kernel<BM_, BN_, 2, false, D_>), grid, block, stream, g);          \
+    else if (kmaj) PGT_LAUNCH((gemm_kernel<BM_, BN_, 1, true, D_>), grid, block, stream, g);          \
+    else PGT_LAUNCH((gemm_kernel<BM_, BN_, 1, false, D_>), grid, block, stream, g);                   \
+  } while (0)
+#define PGT_GEMM_GO(BM_, BN_)                                                                         \
+  do {                                                                                                \
+    if (d30) PGT_GEMM_GO2(BM_, BN_, 30);                                                              \
+    else PGT_GEMM_GO2(BM_, BN_, 32);                                                                  \
   } while (0)
   if (big && N > 64) PGT_GEMM_GO(128, 128);
   else if (big) PGT_GEMM_GO(128, 64);
   else PGT_GEMM_GO(64, 64);
+#undef PGT_GEMM_GO2
 #undef PGT_GEMM_GO
   return pgt_check_launch("pgt_gemm_f32");
 }
@@ -444,7 +522,9 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
   PGT_REQUIRE(M < ((int64_t)1 << 31) - 4096 && N < ((int64_t)1 << 31) - 128 && Ktot < ((int64_t)1 << 31) - 128,
               "pgt_gemm_tn_acc_f32: size exceeds int32 indexing");
   // whole-K schedule: tall slabs, K up to 384; every operand element is read once per 128-wide column block
-  if (g_tn_fullk && (M >= 16384 || g_tn_fullk == 2) && Ktot > (g_tn_fullk == 2 ? 0 : 64) && Ktot <= TNF_MAXKT * 32 &&
+  // (measured at K = 330: N = 128 whole-K 275 us vs k-tiled 278 us in isolation, 12 % faster inside the training step
+  //  where G is not cache-resident; N = 64 whole-K 165 us vs k-tiled 141 us -> narrow outputs keep the k-tiled kernel)
+  if (g_tn_fullk && ((M >= 16384 && N > 64) || g_tn_fullk == 2) && Ktot > (g_tn_fullk == 2 ? 0 : 64) && Ktot <= TNF_MAXKT * 32 &&
       g_force_small_tiles != 1 &&
       n_seg * a_seg_stride + lda < ((int64_t)1 << 31)) {
     const int KT = (int)pgt_cdiv(Ktot, 32);

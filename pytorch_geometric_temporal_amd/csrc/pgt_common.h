@@ -27,6 +27,14 @@ typedef float pgt_f32x16 __attribute__((ext_vector_type(16)));
 
 #define PGT_WAVE 64
 
+// Wavefront-private LDS hand-off (one lane writes, another lane of the SAME wavefront reads): the hardware keeps a
+// wavefront's LDS operations in order; the test double runs lanes as fibers and needs a rendezvous.
+#ifdef PGT_EMU
+#define PGT_WAVE_SYNC() pgt_emu::wave_barrier()
+#else
+#define PGT_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 // lab/ns_lab.hip defines this to record an in-kernel timeline; a no-op in the library
 #ifndef PGT_TRACE_MARK
 #define PGT_TRACE_MARK(slot) do { } while (0)

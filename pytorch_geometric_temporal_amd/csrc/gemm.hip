@@ -522,9 +522,9 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
   PGT_REQUIRE(M < ((int64_t)1 << 31) - 4096 && N < ((int64_t)1 << 31) - 128 && Ktot < ((int64_t)1 << 31) - 128,
               "pgt_gemm_tn_acc_f32: size exceeds int32 indexing");
   // whole-K schedule: tall slabs, K up to 384; every operand element is read once per 128-wide column block
-  // (measured at K = 330: N = 128 whole-K 275 us vs k-tiled 278 us in isolation, 12 % faster inside the training step
-  //  where G is not cache-resident; N = 64 whole-K 165 us vs k-tiled 141 us -> narrow outputs keep the k-tiled kernel)
-  if (g_tn_fullk && ((M >= 16384 && N > 64) || g_tn_fullk == 2) && Ktot > (g_tn_fullk == 2 ? 0 : 64) && Ktot <= TNF_MAXKT * 32 &&
+  // (measured at K = 330 inside the DCRNN training step, M = 2.5 M rows: 4.27 ms per step with this schedule for both
+  //  N = 128 and N = 64, 4.68 ms when N = 64 falls back to the k-tiled kernel, 4.85 ms k-tiled only)
+  if (g_tn_fullk && (M >= 16384 || g_tn_fullk == 2) && Ktot > (g_tn_fullk == 2 ? 0 : 64) && Ktot <= TNF_MAXKT * 32 &&
       g_force_small_tiles != 1 &&
       n_seg * a_seg_stride + lda < ((int64_t)1 << 31)) {
     const int KT = (int)pgt_cdiv(Ktot, 32);

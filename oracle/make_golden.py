@@ -288,6 +288,48 @@ def chebconvattention_sensor():
                  {"K": 3, "lambda_rw": 2.3, "lambda_none": 3.1})
 
 
+# ------------------------------------------------------------------------------------------------ ChebConv cells
+
+def _cheb_cell_case(modname, clsname, seed, lstm):
+    m = R.load("nn.recurrent." + modname)
+    ei, ew = syn.sensor_graph(36, 240, seed=seed, symmetric=False)
+    outs, layer = {}, None
+    X, H0, C0 = _rand((36, 5), seed + 1), _rand((36, 7), seed + 2), _rand((36, 7), seed + 3)
+    for norm, lam in (("sym", None), ("rw", 2.4)):
+        layer_n = getattr(m, clsname)(5, 7, 3, normalization=norm)
+        if layer is None:
+            layer = layer_n
+            _randomise(layer, seed + 4)
+        else:
+            layer_n.load_state_dict(layer.state_dict())
+        kw = {} if lam is None else {"lambda_max": torch.tensor(lam)}
+        with torch.no_grad():
+            if lstm:
+                h1, c1 = layer_n(X, _t(ei), _t(ew), **kw)
+                h2, c2 = layer_n(X, _t(ei), _t(ew), H0, C0, **kw)
+                outs.update({f"H_{norm}": h1, f"C_{norm}": c1, f"H_state_{norm}": h2, f"C_state_{norm}": c2})
+            else:
+                outs.update({f"H_{norm}": layer_n(X, _t(ei), _t(ew), **kw),
+                             f"H_state_{norm}": layer_n(X, _t(ei), _t(ew), H0, **kw)})
+    return _pack({"X": X, "H0": H0, "C0": C0, "edge_index": _t(ei), "edge_weight": _t(ew)}, layer, outs,
+                 {"K": 3, "lambda_rw": 2.4})
+
+
+@case
+def gconvgru_sensor():
+    return _cheb_cell_case("gconv_gru", "GConvGRU", 60, False)
+
+
+@case
+def gconvlstm_sensor():
+    return _cheb_cell_case("gconv_lstm", "GConvLSTM", 70, True)
+
+
+@case
+def gclstm_sensor():
+    return _cheb_cell_case("gc_lstm", "GCLSTM", 80, True)
+
+
 # ------------------------------------------------------------------------------------------------ EvolveGCN
 
 def _dynamic_graphs(n, steps, seed):

@@ -148,6 +148,98 @@ def probe_stack():
                  frac=nb / us / 1e3 / 8000)
 
 
+def probe_models():
+    """Forward + backward of the other model families at the BASELINE.json config shapes (synthetic data), next to the
+    CPU oracle on a bounded sample of the same call (32 threads)."""
+    import time as _t
+    from oracle import functional as OF
+    from pytorch_geometric_temporal_amd.nn.recurrent import A3TGCN2, TGCN2, EvolveGCNH, GConvGRU
+    from pytorch_geometric_temporal_amd.nn.attention import STConv, ChebConvAttention
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+    def gpu_ms(fn, reps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (_t.perf_counter() - t0) / reps
+
+    def cpu_ms(fn, reps=2):
+        fn()
+        t0 = _t.perf_counter()
+        for _ in range(reps):
+            fn()
+        return 1e3 * (_t.perf_counter() - t0) / reps
+
+    # config 3: PeMS-BAY-shaped A3TGCN2(2, 32, periods=12), B = 64
+    ei, ew = syn.sensor_graph(325, 2694, seed=0)
+    eid, ewd = torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev)
+    for B in (64, 512):
+        m = A3TGCN2(2, 32, 12, B).to(dev)
+        X = torch.randn(B, 325, 2, 12, device=dev)
+
+        def step():
+            m.zero_grad(set_to_none=True)
+            m(X, eid, ewd).square().mean().backward()
+        ms = gpu_ms(step)
+        p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        Xc = X[:8].cpu()
+        cms = cpu_ms(lambda: OF.a3tgcn(Xc, torch.from_numpy(ei), torch.from_numpy(ew), None, p)) * (B / 8)
+        emit(probe="model", model="A3TGCN2(2,32,periods=12) PeMS-BAY-shaped 325 nodes / 2694 edges", B=B, gpu_fwd_bwd_ms=ms,
+             snapshot_edges_per_s=B * 12 * 2694 / ms * 1e3, cpu_oracle_fwd_only_ms_scaled=cms)
+    # config 4: 50 k-node static graph, TGCN2(2, 32)
+    ei, ew = syn.local_graph(50_000, 8, seed=0)
+    eid, ewd = torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev)
+    for B in (8, 64):
+        m = TGCN2(2, 32, B).to(dev)
+        X, H = torch.randn(B, 50_000, 2, device=dev), torch.randn(B, 50_000, 32, device=dev)
+
+        def step():
+            m.zero_grad(set_to_none=True)
+            m(X, eid, ewd, H).square().mean().backward()
+        ms = gpu_ms(step)
+        p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        Xc, Hc = X[:2].cpu(), H[:2].cpu()
+        cms = cpu_ms(lambda: OF.tgcn_cell(Xc, torch.from_numpy(ei), torch.from_numpy(ew), Hc, p), reps=1) * (B / 2)
+        emit(probe="model", model="TGCN2(2,32) 50 000 nodes / 400 000 edges", B=B, gpu_fwd_bwd_ms=ms,
+             snapshot_edges_per_s=B * 400_000 / ms * 1e3, cpu_oracle_fwd_only_ms_scaled=cms)
+    # config 5: dynamic graphs, EvolveGCN-H(129, 8), 61 snapshots with fresh edge lists (graph prep every step)
+    graphs = [syn.sensor_graph(129, 129 + int(700 + 20 * s), seed=s) for s in range(61)]
+    gd = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in graphs]
+    m = EvolveGCNH(129, 8).to(dev)
+    Xs = [torch.randn(129, 8, device=dev) for _ in range(61)]
+
+    def epoch():
+        m.zero_grad(set_to_none=True)
+        m.reinitialize_weight()
+        ops.GRAPH_CACHE.clear()
+        loss = 0
+        for s in range(61):
+            loss = loss + m(Xs[s], gd[s][0], gd[s][1]).square().mean()
+        loss.backward()
+    ms = gpu_ms(epoch, reps=5)
+    emit(probe="model", model="EvolveGCNH(129,8) 61 dynamic snapshots (graph prep per snapshot)", gpu_epoch_fwd_bwd_ms=ms,
+         snapshot_edges_per_s=sum(g[0].shape[1] for g in graphs) / ms * 1e3)
+    # STConv / ChebConvAttention / GConvGRU single calls
+    ei, ew = syn.sensor_graph(207, 1515, seed=0)
+    eid, ewd = torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev)
+    m = STConv(207, 2, 32, 32, kernel_size=3, K=3).to(dev)
+    X = torch.randn(64, 12, 207, 2, device=dev)
+    emit(probe="model", model="STConv(207,2,32,32,k=3,K=3) B=64 T=12", gpu_fwd_bwd_ms=gpu_ms(
+        lambda: (m.zero_grad(set_to_none=True), m(X, eid, ewd).square().mean().backward())))
+    m = ChebConvAttention(32, 32, 3, normalization="sym").to(dev)
+    X, S = torch.randn(64, 207, 32, device=dev), torch.softmax(torch.randn(64, 207, 207, device=dev), 1)
+    emit(probe="model", model="ChebConvAttention(32,32,K=3) B=64 N=207", gpu_fwd_bwd_ms=gpu_ms(
+        lambda: (m.zero_grad(set_to_none=True), m(X, eid, S, ewd).square().mean().backward())))
+    m = GConvGRU(2, 32, 3).to(dev)
+    X, H = torch.randn(207, 2, device=dev), torch.randn(207, 32, device=dev)
+    emit(probe="model", model="GConvGRU(2,32,K=3) N=207 one cell step", gpu_fwd_bwd_ms=gpu_ms(
+        lambda: (m.zero_grad(set_to_none=True), m(X, eid, ewd, H).square().mean().backward())))
+
+
 def probe_gemm():
     for M in (13248, 211968):
         for (S, C, N) in ((5, 66, 128), (5, 66, 64), (1, 128, 330)):

@@ -148,6 +148,63 @@ def probe_stack():
                  frac=nb / us / 1e3 / 8000)
 
 
+def probe_graph():
+    """The whole training step (forward, hand-written backward, Adam) captured into ONE hipGraph (torch.cuda.CUDAGraph
+    records the C-ABI launches: they go to the stream handed in, allocate nothing and never synchronise) and replayed,
+    against the eager Python loop.  Small batches are launch-bound: ~650 launches per step."""
+    from bench import Model, masked_mae_loss, FlatGrads, STD, MEAN
+    ei, ew = syn.sensor_graph(207, 1515, seed=0)
+    ei, ew = torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev)
+    for hidden, B in ((64, 64), (64, 256), (64, 1024), (2, 64)):
+        torch.manual_seed(0)
+        model = Model(hidden).to(dev)
+        flat = FlatGrads(model.parameters())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        X = torch.randn(B, 12, 207, 2, device=dev)
+        y = torch.randn(B, 12, 207, 2, device=dev)
+        loss_buf = torch.zeros((), device=dev)
+
+        def step():
+            out = model(X, ei, ew)
+            loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
+            flat.zero()
+            loss.backward()
+            opt.step()
+            loss_buf.copy_(loss.detach())
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        eager = 1e3 * (time.perf_counter() - t0) / 10
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            torch.cuda.synchronize()
+            l0 = float(loss_buf)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            graph_ms = 1e3 * (time.perf_counter() - t0) / 20
+            emit(probe="hipgraph_step", hidden=hidden, B=B, eager_ms=eager, graph_ms=graph_ms, loss_first=l0,
+                 loss_after=float(loss_buf), edges_per_s_graph=B * 12 * 1515 / graph_ms * 1e3)
+        except Exception as e:
+            emit(probe="hipgraph_step", hidden=hidden, B=B, eager_ms=eager, error=repr(e)[:300])
+        del model, flat, opt
+        torch.cuda.empty_cache()
+
+
 def probe_models():
     """Forward + backward of the other model families at the BASELINE.json config shapes (synthetic data), next to the
     CPU oracle on a bounded sample of the same call (32 threads)."""

@@ -92,6 +92,12 @@ int main(int argc, char** argv) {
   for (int blocks : {1024, 2048, 4096})
     timeit(blocks == 1024 ? "copy 51.2MB->51.2MB g=1024" : blocks == 2048 ? "copy g=2048" : "copy g=4096",
            [&](int p) { hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)X[p], (float4*)Y[p], (size_t)n * F / 4); }, 8.0 * n * F);
+  for (int qb : {7, 6, 4, 3}) {
+    pgt_tune("spmm_quad", 1); pgt_tune("spmm_quad_blocks", qb);
+    char nm[64]; snprintf(nm, 64, "quad persistent, %d wg/CU", qb);
+    timeit(nm, [&](int p) { pgt_spmm_csr_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);
+  }
+  pgt_tune("spmm_quad", 0);
   for (int rows : {64, 32}) {
     pgt_tune("spmm_tile_rows", rows);
     timeit(rows == 64 ? "plain tile TR=64" : "plain tile TR=32", [&](int p) { pgt_spmm_csr_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);

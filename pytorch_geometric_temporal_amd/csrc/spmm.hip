@@ -30,6 +30,8 @@ int g_tile_xcd = 1;    // hand tiles to XCDs in contiguous ranges
 int g_tile_rows = 32;  // rows per tile for the F = 64 fast path (32 | 64 | 128); 32: finer tail, measured best
 int g_unroll = 8;      // neighbour loads in flight per lane group (4 | 8)
 int g_wide_xcd = 1;    // XCD-slab block mapping of the wide kernel
+int g_quad = 0;        // F = 64: 1 = barrier-free persistent quad kernel instead of the row-tile kernel (measured tie)
+int g_quad_blocks = 7; // quad kernel: resident workgroups per CU (70 VGPRs -> 7 wavefronts per SIMD)
 int g_band_blocks = 3;  // band kernel: resident workgroups per CU the chunking aims at (<= 3: 160-VGPR kernel)
 int g_band_xcd = 1;     // band kernel: contiguous chunk ranges per XCD
 
@@ -365,6 +367,108 @@ __global__ __launch_bounds__(256, (RING == 128 ? 3 : 2)) void spmm_band64_kernel
   PGT_TRACE_MARK(15);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// spmm_quad64_kernel — F = 64, barrier-free and persistent: every wavefront walks its own sequence of row-quads
+// (4 rows x 16 lanes x float4).  No LDS, no workgroup barrier: a quad's (col, val) slots are fetched with one
+// coalesced 16-slot read per row and broadcast with ds_bpermute; rowptr of quad i+2 and the slots of quad i+1 are in
+// flight while the neighbour rows of quad i are gathered (two register sets ping-pong, nothing in flight is copied).
+// Work split: XCD x (blockIdx % 8) owns a contiguous eighth of the quads, its wavefronts take them round-robin, so at
+// any time one XCD works on a narrow band of rows (L2 locality) and the tail is one quad per wavefront, not one tile
+// per workgroup (the tile kernel's second, ragged wave of workgroups cost 9 - 33 us of a 33 us launch).
+__global__ __launch_bounds__(256) void spmm_quad64_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
+    const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt, float alpha, float beta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l16 = lane & 15;
+  const int x = (int)(blockIdx.x & 7u);
+  const int nwx = (int)(gridDim.x >> 3) * 4;              // wavefronts per XCD
+  const int wi = (int)(blockIdx.x >> 3) * 4 + wave;
+  const int nq = (n_rows + 3) >> 2;
+  const int qx = (nq + 7) >> 3;
+  const int qend = (x + 1) * qx < nq ? (x + 1) * qx : nq;
+  int q = x * qx + wi;
+  if (q >= qend) return;
+  const float* Xl = X + l16 * 4;
+
+  auto load_rp = [&](int qq, int& a, int& b) {
+    const int row = 4 * qq + g;
+    a = rowptr[row < n_rows ? row : n_rows];
+    b = rowptr[row + 1 < n_rows ? row + 1 : n_rows];
+  };
+  auto load_cv = [&](int a, int b, int& n, int& mc, float& mv) {   // first 16 slots of the row, one per lane
+    n = b - a;
+    const int idx = l16 < n ? a + l16 : (b > 0 ? b - 1 : 0);
+    mc = col[idx];
+    mv = val[idx];
+  };
+  auto gather_store = [&](int qq, int a, int n, int mc, float mv) {
+    const int row = 4 * qq + g;
+    pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+    for (int q0 = 0; __ballot(q0 < n) != 0ull; q0 += 16) {
+      if (q0 > 0) {                                          // rows longer than the 16 prefetched slots
+        const int idx = q0 + l16 < n ? a + q0 + l16 : a;
+        mc = col[idx];
+        mv = val[idx];
+      }
+      for (int u0 = 0; u0 < 16 && __ballot(q0 + u0 < n) != 0ull; u0 += 8) {
+        int c[8];
+        float v[8];
+        pgt_f4 xx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { c[u] = __shfl(mc, u0 + u, 16); v[u] = __shfl(mv, u0 + u, 16); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)   // dead slots re-read the last live source row (harmless, discarded below)
+          xx[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c[u] * ldx));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool live = q0 + u0 + u < n;
+          acc.x = live ? fmaf(v[u], xx[u].x, acc.x) : acc.x;
+          acc.y = live ? fmaf(v[u], xx[u].y, acc.y) : acc.y;
+          acc.z = live ? fmaf(v[u], xx[u].z, acc.z) : acc.z;
+          acc.w = live ? fmaf(v[u], xx[u].w, acc.w) : acc.w;
+        }
+      }
+    }
+    if (row < n_rows) {
+      pgt_f4 o;
+      if (T != nullptr) {
+        const pgt_f4 tt = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(row * ldt + l16 * 4));
+        o = pgt_mk4(alpha * acc.x + beta * tt.x, alpha * acc.y + beta * tt.y, alpha * acc.z + beta * tt.z,
+                    alpha * acc.w + beta * tt.w);
+      } else {
+        o = pgt_mk4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+      }
+      *reinterpret_cast<pgt_f4*>(Y + (unsigned)(row * ldy + l16 * 4)) = o;
+    }
+  };
+
+  int a0, b0, a1 = 0, b1 = 0;
+  load_rp(q, a0, b0);
+  if (q + nwx < qend) load_rp(q + nwx, a1, b1);
+  int n0, c0;
+  float v0;
+  load_cv(a0, b0, n0, c0, v0);
+  int s0 = a0;
+#pragma unroll 1
+  for (;;) {
+    // --- even half: gather quad q from set 0; slots of q + nwx -> set 1; rowptr of q + 2 nwx -> (a0, b0)
+    int n1 = 0, c1 = 0, s1 = 0;
+    float v1 = 0.f;
+    const bool has1 = q + nwx < qend;
+    if (q + 2 * nwx < qend) load_rp(q + 2 * nwx, a0, b0);
+    if (has1) { load_cv(a1, b1, n1, c1, v1); s1 = a1; }
+    gather_store(q, s0, n0, c0, v0);
+    if (!has1) break;
+    q += nwx;
+    // --- odd half: gather quad q from set 1; slots of q + nwx -> set 0; rowptr of q + 2 nwx -> (a1, b1)
+    const bool has0 = q + nwx < qend;
+    if (q + 2 * nwx < qend) load_rp(q + 2 * nwx, a1, b1);
+    if (has0) { load_cv(a0, b0, n0, c0, v0); s0 = a0; }
+    gather_store(q, s1, n1, c1, v1);
+    if (!has0) break;
+    q += nwx;
+  }
+}
+
 // slots of a CSR operator whose source lies within +-32 / +-96 rows of the destination (selects the band kernel)
 __global__ __launch_bounds__(256) void csr_locality_kernel(const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, int n_rows,
@@ -518,6 +622,18 @@ int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, int
     if (Fv <= 4) { PGT_SPMM_CASE(4, 64, 4); }
     else if (Fv <= 8) { PGT_SPMM_CASE(8, 64, 4); }
     else if (Fv <= 16) {
+      if (VEC == 4 && Fi == 64 && g_quad && n_rows >= 1024) {
+        const int64_t max_ld = ldx > ldy ? (ldx > ldt ? ldx : ldt) : (ldy > ldt ? ldy : ldt);
+        if (n_rows * max_ld < ((int64_t)1 << 31)) {
+          int64_t nblk = 256 * (int64_t)g_quad_blocks;              // persistent: g_quad_blocks workgroups per CU
+          const int64_t need = pgt_cdiv(pgt_cdiv(n_rows, 4), 4);    // one quad per wavefront at least
+          if (nblk > need) nblk = need;
+          nblk = pgt_cdiv(nblk, 8) * 8;                             // every XCD gets the same number of workgroups
+          PGT_LAUNCH(spmm_quad64_kernel, dim3((unsigned)nblk), block, stream, rowptr, col, val, n, X, (int)ldx, Y,
+                     (int)ldy, T, (int)ldt, alpha, beta);
+          return pgt_check_launch("pgt_spmm_csr_f32");
+        }
+      }
       if (VEC == 4) {  // the F = 64 fast path carries the A/B variants
         const int key = g_tile_rows * 10 + g_unroll;
         if (key == 324) { PGT_SPMM_CASE(16, 32, 4); }
@@ -558,6 +674,8 @@ int pgt_spmm_tune(const char* key, int value) {
   if (strcmp(key, "spmm_tile_rows") == 0) { g_tile_rows = value; return 1; }
   if (strcmp(key, "spmm_unroll") == 0) { g_unroll = value; return 1; }
   if (strcmp(key, "spmm_wide_xcd") == 0) { g_wide_xcd = value; return 1; }
+  if (strcmp(key, "spmm_quad") == 0) { g_quad = value; return 1; }
+  if (strcmp(key, "spmm_quad_blocks") == 0) { g_quad_blocks = value > 0 ? value : 1; return 1; }
   if (strcmp(key, "spmm_band_blocks") == 0) { g_band_blocks = value > 0 ? value : 1; return 1; }
   if (strcmp(key, "spmm_band_xcd") == 0) { g_band_xcd = value; return 1; }
   return 0;

@@ -563,3 +563,25 @@ def test_gemm_tn_whole_k_schedule(backend, M, segs, segk, N):
         assert_close_with_nonfinite(dW2, refW, tol, 1e-5, "dW k-tiled")
     finally:
         lib.tune("gemm_tn_fullk", 1)
+
+
+def test_spmm_quad_persistent_schedule_matches_tile_schedule(backend):
+    """The barrier-free persistent F = 64 schedule (pgt_tune spmm_quad) is bit-identical to the row-tile schedule."""
+    lib = _lib.get_lib()
+    n = 1100 if backend.name == "emu" else 150_000
+    csr = banded_csr(n, 0, 20, 40, seed=9, device=backend.device, far_frac=0.1, heavy_row=77)
+    X = torch.randn(n, 64).to(backend.device)
+    T = torch.randn(n, 64).to(backend.device)
+    Ya, Yb = torch.empty_like(X), torch.empty_like(X)
+    ops.spmm(csr, X, Ya, T=T, alpha=2.0, beta=-1.0, halo=0)
+    lib.tune("spmm_quad", 1)
+    try:
+        for blocks in (7, 2):
+            lib.tune("spmm_quad_blocks", blocks)
+            Yb.fill_(float("nan"))
+            ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0, halo=0)
+            assert torch.equal(Ya, Yb)
+    finally:
+        lib.tune("spmm_quad", 0)
+        lib.tune("spmm_quad_blocks", 7)
+    assert_close_with_nonfinite(Ya, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "quad")

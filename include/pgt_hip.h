@@ -28,6 +28,7 @@
  *                         PyG Linear in GCNConv/ChebConv; temporalgcn.py:84,90,96 (linear_{z,r,h})
  *   pgt_gemm_tn_acc_f32   autograd of the above w.r.t. the weights (torch autograd in the reference)
  *   pgt_gru_*             the GRU gate chains: dcrnn.py:172-192,406-427; temporalgcn.py:82-102
+ *   pgt_lstm_gates*       the LSTM gate chains: gconv_lstm.py:138-172 (peepholes), gc_lstm.py:138-169
  */
 #ifndef PGT_HIP_H_
 #define PGT_HIP_H_
@@ -44,7 +45,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 4
+#define PGT_ABI_VERSION 5
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -215,6 +216,22 @@ int pgt_gru_zr_bwd_f32(const float* dxhr, int64_t lddxhr, int64_t f_in, const fl
 /* TGCN (temporalgcn.py:82-102): pre_zr [M,2*O] = linear_{z,r}([conv(X), H]);
  *   zr = sigmoid(pre_zr) in place; hr[m,o] = H[m,o]*R[m,o] */
 /* (uses pgt_gru_zr_f32 with f_in = 0) */
+
+/* ---------------------------------------------------------------- LSTM gate chains */
+
+/* Peephole LSTM of GConvLSTM (gconv_lstm.py:138-172) and, with wci = wcf = wco = NULL, the plain LSTM of GCLSTM
+ * (gc_lstm.py:138-169).  P [M, 4*O] holds the gate pre-activations i | f | c | o (all biases already added by the
+ * GEMM that produced it) and is overwritten with the activated gates (kept for the backward pass):
+ *   I = s(P_i + wci*C)  F = s(P_f + wcf*C)  T = tanh(P_c)  C' = F*C + I*T  O = s(P_o + wco*C')  H = O * tanh(C') */
+int pgt_lstm_gates_f32(float* P, const float* C, int64_t ldc, const float* wci, const float* wcf, const float* wco,
+                       float* Hn, int64_t ldh, float* Cn, int64_t ldcn, int64_t M, int64_t O, pgt_stream_t stream);
+/* backward: gates = the activated P of the forward call; dCn may be NULL (no gradient into the new cell state).
+ * Writes dP [M,4*O] (pre-activation gradients), dC [M,O] (previous cell) and ACCUMULATES the peephole gradients into
+ * dw [3*O] (wci | wcf | wco rows; fp32 atomics; required when any peephole weight is given). */
+int pgt_lstm_gates_bwd_f32(const float* gates, const float* C, int64_t ldc, const float* Cn, int64_t ldcn,
+                           const float* wci, const float* wcf, const float* wco, const float* dH, int64_t lddh,
+                           const float* dCn, int64_t lddcn, float* dP, float* dC, int64_t lddc, float* dw, int64_t M,
+                           int64_t O, pgt_stream_t stream);
 
 /* ---------------------------------------------------------------- small data movers on the path */
 

@@ -76,13 +76,16 @@ PROTOTYPES = {
                                   c_int, c_i64, c_i64, c_ptr]),
     "pgt_gru_zr_bwd_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64,
                                    c_ptr]),
+    "pgt_lstm_gates_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_lstm_gates_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64,
+                                       c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr]),
     "pgt_copy2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_add2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_axpby2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_i64, c_f32, c_i64, c_i64, c_ptr]),
     "pgt_swap01_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 4
+EXPECTED_ABI = 5
 
 
 class PgtLib:

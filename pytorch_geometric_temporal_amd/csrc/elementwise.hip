@@ -116,6 +116,115 @@ __global__ __launch_bounds__(256) void gru_zr_bwd_kernel(const float* __restrict
   pgt_stv<V>(q, dh);
 }
 
+// ---- peephole LSTM gate chain (gconv_lstm.py:138-172; gc_lstm.py:138-169 with wci = wcf = wco = NULL)
+//   P [M, 4O] holds the pre-activations i | f | c | o (every bias already folded in by the GEMM that produced it).
+//   I = s(P_i + wci*C)  F = s(P_f + wcf*C)  T = tanh(P_c)  C' = F*C + I*T  Og = s(P_o + wco*C')  H = Og*tanh(C')
+//   The activated gates overwrite P (saved for the backward pass).
+template <int V>
+__global__ __launch_bounds__(256) void lstm_gates_kernel(float* P, const float* __restrict__ C, int64_t ldc,
+                                                          const float* __restrict__ wci,
+                                                          const float* __restrict__ wcf,
+                                                          const float* __restrict__ wco, float* Hn, int64_t ldh,
+                                                          float* Cn, int64_t ldcn, int64_t M, int O) {
+  const int OV = O / V;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * OV) return;
+  const int64_t m = idx / OV;
+  const int o = (int)(idx - m * OV) * V;
+  float* p = P + m * 4 * O + o;
+  float gi[V], gf[V], gt[V], go[V], c[V], hn[V], cn[V], pi[V], pf[V], po[V];
+  pgt_ldv<V>(p, gi);
+  pgt_ldv<V>(p + O, gf);
+  pgt_ldv<V>(p + 2 * O, gt);
+  pgt_ldv<V>(p + 3 * O, go);
+  pgt_ldv<V>(C + m * ldc + o, c);
+#pragma unroll
+  for (int i = 0; i < V; ++i) { pi[i] = wci ? wci[o + i] : 0.f; pf[i] = wcf ? wcf[o + i] : 0.f; po[i] = wco ? wco[o + i] : 0.f; }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    gi[i] = sigmoidf_(gi[i] + pi[i] * c[i]);
+    gf[i] = sigmoidf_(gf[i] + pf[i] * c[i]);
+    gt[i] = tanhf(gt[i]);
+    cn[i] = gf[i] * c[i] + gi[i] * gt[i];
+    go[i] = sigmoidf_(go[i] + po[i] * cn[i]);
+    hn[i] = go[i] * tanhf(cn[i]);
+  }
+  pgt_stv<V>(p, gi);
+  pgt_stv<V>(p + O, gf);
+  pgt_stv<V>(p + 2 * O, gt);
+  pgt_stv<V>(p + 3 * O, go);
+  pgt_stv<V>(Cn + m * ldcn + o, cn);
+  pgt_stv<V>(Hn + m * ldh + o, hn);
+}
+
+// backward: gates [M,4O] (activated i|f|t|o), C (previous cell), Cn (new cell), dH, dCn (may be NULL) ->
+//   dP [M,4O] (pre-activation gradients), dC [M,O] (w.r.t. the previous cell), dw [3,O] += peephole gradients
+//   (column sums: one wavefront-partial atomicAdd per column group).
+template <int V>
+__global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ G, const float* __restrict__ C,
+                                                              int64_t ldc, const float* __restrict__ Cn,
+                                                              int64_t ldcn, const float* __restrict__ wci,
+                                                              const float* __restrict__ wcf,
+                                                              const float* __restrict__ wco,
+                                                              const float* __restrict__ dH, int64_t lddh,
+                                                              const float* dCn, int64_t lddcn, float* dP, float* dC,
+                                                              int64_t lddc, float* dw, int64_t M, int O,
+                                                              int rows_per_block) {
+  // block = (column group = threadIdx.x % OV ... ) : threads are laid out [rows][OV] so a column's partial sums meet in
+  // one thread column; rows_per_block rows are walked by each thread row.
+  const int OV = O / V;
+  const int tcol = threadIdx.x % OV, trow = threadIdx.x / OV, nrow_t = 256 / OV;
+  const int o = tcol * V;
+  float sw_i[V], sw_f[V], sw_o[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) sw_i[i] = sw_f[i] = sw_o[i] = 0.f;
+  float pi[V], pf[V], po[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { pi[i] = wci ? wci[o + i] : 0.f; pf[i] = wcf ? wcf[o + i] : 0.f; po[i] = wco ? wco[o + i] : 0.f; }
+  const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+  if (trow < nrow_t) {
+    for (int64_t m = m0 + trow; m < m0 + rows_per_block && m < M; m += nrow_t) {
+      const float* gp = G + m * 4 * O + o;
+      float gi[V], gf[V], gt[V], go[V], c[V], cn[V], dh[V], dcn[V], dpi[V], dpf[V], dpt[V], dpo[V], dc[V];
+      pgt_ldv<V>(gp, gi);
+      pgt_ldv<V>(gp + O, gf);
+      pgt_ldv<V>(gp + 2 * O, gt);
+      pgt_ldv<V>(gp + 3 * O, go);
+      pgt_ldv<V>(C + m * ldc + o, c);
+      pgt_ldv<V>(Cn + m * ldcn + o, cn);
+      pgt_ldv<V>(dH + m * lddh + o, dh);
+      if (dCn) pgt_ldv<V>(dCn + m * lddcn + o, dcn);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float tc = tanhf(cn[i]);
+        dpo[i] = dh[i] * tc * go[i] * (1.f - go[i]);
+        const float dct = (dCn ? dcn[i] : 0.f) + dh[i] * go[i] * (1.f - tc * tc) + dpo[i] * po[i];
+        dpi[i] = dct * gt[i] * gi[i] * (1.f - gi[i]);
+        dpf[i] = dct * c[i] * gf[i] * (1.f - gf[i]);
+        dpt[i] = dct * gi[i] * (1.f - gt[i] * gt[i]);
+        dc[i] = dct * gf[i] + dpi[i] * pi[i] + dpf[i] * pf[i];
+        sw_i[i] += dpi[i] * c[i];
+        sw_f[i] += dpf[i] * c[i];
+        sw_o[i] += dpo[i] * cn[i];
+      }
+      float* dp = dP + m * 4 * O + o;
+      pgt_stv<V>(dp, dpi);
+      pgt_stv<V>(dp + O, dpf);
+      pgt_stv<V>(dp + 2 * O, dpt);
+      pgt_stv<V>(dp + 3 * O, dpo);
+      pgt_stv<V>(dC + m * lddc + o, dc);
+    }
+  }
+  if (dw != nullptr && trow < nrow_t) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      if (wci) atomicAdd(dw + o + i, sw_i[i]);
+      if (wcf) atomicAdd(dw + O + o + i, sw_f[i]);
+      if (wco) atomicAdd(dw + 2 * O + o + i, sw_o[i]);
+    }
+  }
+}
+
 // mode 0: dst = x ; 1: dst += x ; 2: dst = a*x + b*y
 template <int V>
 __global__ __launch_bounds__(256) void mover2d_kernel(float* dst, int64_t ldd, const float* __restrict__ x,
@@ -259,6 +368,49 @@ static int mover(const char* what, float* dst, int64_t ldd, const float* x, int6
   if (int e = grid_for(M * (W / pick.v), what, &grid)) return e;
   PGT_VDISPATCH(pick.v, mover2d_kernel, grid, block, stream, dst, ldd, x, ldx, a, y, ldy, b, M, W, mode);
   return pgt_check_launch(what);
+}
+
+extern "C" int pgt_lstm_gates_f32(float* P, const float* C, int64_t ldc, const float* wci, const float* wcf,
+                                  const float* wco, float* Hn, int64_t ldh, float* Cn, int64_t ldcn, int64_t M,
+                                  int64_t O, pgt_stream_t stream) {
+  PGT_REQUIRE(M >= 0 && O >= 0, "pgt_lstm_gates_f32: negative size");
+  if (M == 0 || O == 0) return PGT_OK;
+  PGT_REQUIRE(P && C && Hn && Cn, "pgt_lstm_gates_f32: null pointer");
+  PgtVecPick pick;
+  pick.width(O);
+  pick.operand(P, 4 * O); pick.operand(P + O, 4 * O); pick.operand(C, ldc); pick.operand(Hn, ldh); pick.operand(Cn, ldcn);
+  dim3 grid, block(256);
+  if (int e = grid_for(M * (O / pick.v), "pgt_lstm_gates_f32", &grid)) return e;
+  PGT_VDISPATCH(pick.v, lstm_gates_kernel, grid, block, stream, P, C, ldc, wci, wcf, wco, Hn, ldh, Cn, ldcn, M, (int)O);
+  return pgt_check_launch("pgt_lstm_gates_f32");
+}
+
+extern "C" int pgt_lstm_gates_bwd_f32(const float* gates, const float* C, int64_t ldc, const float* Cn,
+                                      int64_t ldcn, const float* wci, const float* wcf, const float* wco,
+                                      const float* dH, int64_t lddh, const float* dCn, int64_t lddcn, float* dP,
+                                      float* dC, int64_t lddc, float* dw, int64_t M, int64_t O,
+                                      pgt_stream_t stream) {
+  PGT_REQUIRE(M >= 0 && O >= 0, "pgt_lstm_gates_bwd_f32: negative size");
+  if (M == 0 || O == 0) return PGT_OK;
+  PGT_REQUIRE(gates && C && Cn && dH && dP && dC, "pgt_lstm_gates_bwd_f32: null pointer");
+  PGT_REQUIRE(!(wci || wcf || wco) || dw, "pgt_lstm_gates_bwd_f32: peephole weights given but dw is null");
+  PgtVecPick pick;
+  pick.width(O);
+  pick.operand(gates, 4 * O); pick.operand(gates + O, 4 * O); pick.operand(C, ldc); pick.operand(Cn, ldcn);
+  pick.operand(dH, lddh); pick.operand(dCn, lddcn); pick.operand(dP, 4 * O); pick.operand(dP + O, 4 * O);
+  pick.operand(dC, lddc);
+  const int v = pick.v;
+  PGT_REQUIRE(O / v <= 256, "pgt_lstm_gates_bwd_f32: more than 1024 channels are not supported");
+  const int64_t nrow_t = 256 / (O / v);
+  // ~2048 workgroups; each thread row walks rows_per_block / nrow_t rows
+  int64_t rpb = pgt_cdiv(pgt_cdiv(M, 2048), nrow_t) * nrow_t;
+  if (rpb < nrow_t) rpb = nrow_t;
+  const int64_t nblk = pgt_cdiv(M, rpb);
+  PGT_REQUIRE(nblk < ((int64_t)1 << 31), "pgt_lstm_gates_bwd_f32: grid too large");
+  dim3 grid((unsigned)nblk), block(256);
+  PGT_VDISPATCH(v, lstm_gates_bwd_kernel, grid, block, stream, gates, C, ldc, Cn, ldcn, wci, wcf, wco, dH, lddh, dCn,
+                lddcn, dP, dC, lddc, dw, M, (int)O, (int)rpb);
+  return pgt_check_launch("pgt_lstm_gates_bwd_f32");
 }
 
 extern "C" int pgt_copy2d_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t M, int64_t W,

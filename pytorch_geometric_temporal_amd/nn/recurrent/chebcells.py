@@ -5,7 +5,8 @@ Same constructors, parameter names (`conv_x_z.lins.{k}.weight`, `conv_h_z.bias`,
 signatures and outputs.  Every gate of a cell convolves the SAME inputs, so instead of 6 / 8 / 4 independent ChebConv
 calls (each with its own Laplacian normalisation and K-1 propagates) a cell runs ONE Chebyshev stack of [X, H] (one
 aggregation launch per hop at width in+out) and ONE MFMA GEMM that produces all gate pre-activations; GConvGRU's
-candidate needs a second stack of [X, H*R].  The gate non-linearities are elementwise torch ops.
+candidate needs a second stack of [X, H*R].  The LSTM gate chain (peepholes included) is one fused kernel
+(pgt_lstm_gates_f32) with a hand-written backward; GConvGRU's three gate expressions are elementwise torch ops.
 """
 from typing import Tuple
 
@@ -112,14 +113,11 @@ class GConvLSTM(torch.nn.Module):
         g = _graph(self.conv_x_i, edge_index, edge_weight, X.size(0), lambda_max)
         W, b = _gate_weights([self.conv_x_i, self.conv_x_f, self.conv_x_c, self.conv_x_o],
                              [self.conv_h_i, self.conv_h_f, self.conv_h_c, self.conv_h_o])
+        # the cell's own biases b_i .. b_o join the convolution biases inside the GEMM
+        bb = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=1).view(-1)
+        b = bb if b is None else b + bb
         P = ops.ChebConvFunction.apply(torch.cat([X, H], dim=1), W, b, g, self.K, 1)     # [N, 4*O]: i | f | c | o
-        I = torch.sigmoid(P[:, :O] + self.w_c_i * C + self.b_i)
-        F = torch.sigmoid(P[:, O:2 * O] + self.w_c_f * C + self.b_f)
-        T = torch.tanh(P[:, 2 * O:3 * O] + self.b_c)
-        C = F * C + I * T
-        Og = torch.sigmoid(P[:, 3 * O:] + self.w_c_o * C + self.b_o)
-        H = Og * torch.tanh(C)
-        return H, C
+        return ops.LSTMGatesFunction.apply(P, C, self.w_c_i, self.w_c_f, self.w_c_o)
 
 
 class GCLSTM(torch.nn.Module):
@@ -155,10 +153,4 @@ class GCLSTM(torch.nn.Module):
         Wx = torch.cat([self.W_i, self.W_f, self.W_c, self.W_o], dim=1)                  # [in, 4*O]
         bx = torch.cat([self.b_i, self.b_f, self.b_c, self.b_o], dim=1).view(-1)
         P = ops.linear(X, Wx, bx) + ops.ChebConvFunction.apply(H, W, b, g, self.K, 1)
-        I = torch.sigmoid(P[:, :O])
-        F = torch.sigmoid(P[:, O:2 * O])
-        T = torch.tanh(P[:, 2 * O:3 * O])
-        C = F * C + I * T
-        Og = torch.sigmoid(P[:, 3 * O:])
-        H = Og * torch.tanh(C)
-        return H, C
+        return ops.LSTMGatesFunction.apply(P, C, None, None, None)

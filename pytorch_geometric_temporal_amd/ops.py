@@ -945,3 +945,50 @@ class ChebConvAttentionFunction(torch.autograd.Function):
         torch.diagonal(dS, dim1=1, dim2=2).add_(dd.t())
         dx = swap01(dXnm.contiguous(), N, B, C)
         return dx, dS, dW.view(K, C, O), db, None, None
+
+
+# --------------------------------------------------------------------------------------------- LSTM gates
+
+class LSTMGatesFunction(torch.autograd.Function):
+    """(H', C') = peephole-LSTM gates of GConvLSTM / GCLSTM from the gate pre-activations P [M, 4*O] = i | f | c | o
+    (pgt_lstm_gates_f32 / pgt_lstm_gates_bwd_f32).  w_ci / w_cf / w_co are [1, O] peephole weights or None."""
+
+    @staticmethod
+    def forward(ctx, P, C, w_ci, w_cf, w_co):
+        lib = _lib.get_lib()
+        check_tensor(lib, P, "P")
+        check_tensor(lib, C, "C")
+        M, O4 = P.shape
+        O = O4 // 4
+        gates = P.contiguous().clone()          # activated in place by the kernel; P itself stays untouched
+        Cc = C.contiguous()
+        ws = [None if w is None else w.contiguous().view(-1) for w in (w_ci, w_cf, w_co)]
+        Hn = torch.empty(M, O, dtype=F32, device=P.device)
+        Cn = torch.empty(M, O, dtype=F32, device=P.device)
+        lib.call("pgt_lstm_gates_f32", ptr(gates), ptr(Cc), O, ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(Hn), O, ptr(Cn),
+                 O, M, O, stream_of(lib, P))
+        ctx.save_for_backward(gates, Cc, Cn, *[w for w in ws if w is not None])
+        ctx.has_w = tuple(w is not None for w in ws)
+        ctx.w_shapes = tuple(None if w is None else tuple(w.shape) for w in (w_ci, w_cf, w_co))
+        return Hn, Cn
+
+    @staticmethod
+    def backward(ctx, dH, dCn):
+        lib = _lib.get_lib()
+        saved = list(ctx.saved_tensors)
+        gates, Cc, Cn = saved[:3]
+        rest = saved[3:]
+        ws = []
+        for has in ctx.has_w:
+            ws.append(rest.pop(0) if has else None)
+        M, O = Cc.shape
+        dev = gates.device
+        dHc = (dH if dH is not None else torch.zeros_like(Cn)).contiguous()
+        dCc = None if dCn is None else dCn.contiguous()
+        dP = torch.empty_like(gates)
+        dC = torch.empty(M, O, dtype=F32, device=dev)
+        dw = torch.zeros(3, O, dtype=F32, device=dev) if any(ctx.has_w) else None
+        lib.call("pgt_lstm_gates_bwd_f32", ptr(gates), ptr(Cc), O, ptr(Cn), O, ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(dHc),
+                 O, ptr(dCc), O, ptr(dP), ptr(dC), O, ptr(dw), M, O, stream_of(lib, gates))
+        grads = [dw[i].view(ctx.w_shapes[i]) if ctx.has_w[i] else None for i in range(3)]
+        return dP, dC, grads[0], grads[1], grads[2]

@@ -585,3 +585,43 @@ def test_spmm_quad_persistent_schedule_matches_tile_schedule(backend):
         lib.tune("spmm_quad", 0)
         lib.tune("spmm_quad_blocks", 7)
     assert_close_with_nonfinite(Ya, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "quad")
+
+
+@pytest.mark.parametrize("O,peep", [(8, True), (6, True), (5, False), (64, True)])
+def test_lstm_gate_kernels_against_autograd(backend, O, peep):
+    """pgt_lstm_gates(_bwd)_f32 against the gate equations of gconv_lstm.py:138-172 written with torch autograd."""
+    M = 37 if backend.name == "emu" else 5000
+    g = torch.Generator().manual_seed(O)
+    P = torch.randn(M, 4 * O, generator=g)
+    C = torch.randn(M, O, generator=g)
+    ws = [torch.randn(1, O, generator=g) if peep else None for _ in range(3)]
+    wH, wC = torch.randn(M, O, generator=g), torch.randn(M, O, generator=g)
+
+    def run(Pt, Ct, wt, fn):
+        Hn, Cn = fn(Pt, Ct, *wt)
+        ((Hn * wH.to(Hn.device, Hn.dtype)).sum() + (Cn * wC.to(Cn.device, Cn.dtype)).sum()).backward()
+        return Hn, Cn
+
+    def ref_fn(Pt, Ct, wi, wf, wo):
+        z = lambda w: 0 if w is None else w * 1.0
+        I = torch.sigmoid(Pt[:, :O] + (wi * Ct if wi is not None else 0))
+        Fg = torch.sigmoid(Pt[:, O:2 * O] + (wf * Ct if wf is not None else 0))
+        T = torch.tanh(Pt[:, 2 * O:3 * O])
+        Cn = Fg * Ct + I * T
+        Og = torch.sigmoid(Pt[:, 3 * O:] + (wo * Cn if wo is not None else 0))
+        return Og * torch.tanh(Cn), Cn
+
+    P64, C64 = P.double().requires_grad_(), C.double().requires_grad_()
+    w64 = [None if w is None else w.double().requires_grad_() for w in ws]
+    Hr, Cr = run(P64, C64, w64, ref_fn)
+    Pd, Cd = backend.t(P).requires_grad_(), backend.t(C).requires_grad_()
+    wd = [None if w is None else backend.t(w).requires_grad_() for w in ws]
+    Hn, Cn = run(Pd, Cd, wd, ops.LSTMGatesFunction.apply)
+    assert_close_with_nonfinite(Hn, Hr, 1e-5, 1e-5, "H")
+    assert_close_with_nonfinite(Cn, Cr, 1e-5, 1e-5, "C")
+    assert_close_with_nonfinite(Pd.grad, P64.grad, 2e-5, 1e-4, "dP")
+    assert_close_with_nonfinite(Cd.grad, C64.grad, 2e-5, 1e-4, "dC")
+    if peep:
+        tol = 1e-4 if backend.name == "emu" else 5e-3       # column sums over M rows (fp32 atomics on the GPU leg)
+        for a, b_, nm in zip(wd, w64, ("w_ci", "w_cf", "w_co")):
+            assert_close_with_nonfinite(a.grad, b_.grad, tol, 1e-4, nm)

@@ -38,6 +38,18 @@ BAND_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; 
 # MI355X at N = 200 000, F = 64 it ties the row-tile schedule (33-37 us vs 32-35 us at in-degree 8), so
 # the measured locality hint is only APPLIED when this switch is on; spmm(..., halo=...) always overrides.
 USE_BAND_SCHEDULE = False
+# Weight-gradient GEMMs of step t on a side stream while the main stream runs the BPTT chain of step t-1 (same
+# arithmetic, fp32 atomics into dW either way).  Measured on MI355X at METR-LA shape, B = 1024: 23.81 ms per step with
+# the overlap vs 23.79 ms with one whole-sequence weight-gradient GEMM at the end -> off by default.
+OVERLAP_WEIGHT_GRADIENTS = False
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def measure_locality(csrs):
@@ -607,6 +619,25 @@ class DCRNNSeqFunction(torch.autograd.Function):
         Wh_b, folded = fold_backward_weight(Wh_c, K, C)
         Wzr_b, _ = fold_backward_weight(Wzr_c, K, C)
         B = ctx.B
+        seg = T * M * C
+        need_wzr = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        need_wh = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+        dWzr = torch.zeros_like(Wzr_c) if need_wzr else None
+        dbzr = torch.zeros(2 * O, dtype=F32, device=dev) if (need_wzr and ctx.has_bias[0]) else None
+        dWh = torch.zeros_like(Wh_c) if need_wh else None
+        dbh = torch.zeros(O, dtype=F32, device=dev) if (need_wh and ctx.has_bias[1]) else None
+        overlap = OVERLAP_WEIGHT_GRADIENTS and dev.type == "cuda" and KERNEL_TIMER is None and (need_wzr or need_wh)
+        if overlap:
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(main)          # dW / db zero-fills and the saved stacks are ready
+
+        def weight_grads(t):
+            """dW += stack_t^T dPRE_t for one time step (pgt_gemm_tn_acc_f32 accumulates)."""
+            if need_wzr:
+                gemm_tn_acc(TSzr[0, t], C, seg, S, C, dPzr[t], 2 * O, dWzr, 2 * O, dbzr, M, 2 * O)
+            if need_wh:
+                gemm_tn_acc(TSh[0, t], C, seg, S, C, dPh[t], O, dWh, O, dbh, M, O)
 
         def stack_bwd():
             if K < 2:
@@ -624,6 +655,12 @@ class DCRNNSeqFunction(torch.autograd.Function):
             gemm(dPh[t], O, 0, 1, O, Wh_b, 1, O, G, C, M * C, C, None, M, S * C)
             stack_bwd()
             _gru_zr_bwd(G[0], Fin, ZR[t], Hp, dPzr[t], dH)
+            if overlap:                     # dPh[t], dPzr[t] are final: their weight gradients go to the side stream
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    weight_grads(t)
             if need_x:
                 copy2d(dX[t], G[0][:, :Fin])
             # gate convs
@@ -632,16 +669,13 @@ class DCRNNSeqFunction(torch.autograd.Function):
             add2d(dH, G[0][:, Fin:])
             if need_x:
                 add2d(dX[t], G[0][:, :Fin])
-        dWzr = dbzr = dWh = dbh = None
-        seg = T * M * C
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            dWzr = torch.zeros_like(Wzr_c)
-            dbzr = torch.zeros(2 * O, dtype=F32, device=dev) if ctx.has_bias[0] else None
-            gemm_tn_acc(TSzr, C, seg, S, C, dPzr, 2 * O, dWzr, 2 * O, dbzr, T * M, 2 * O)
-        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
-            dWh = torch.zeros_like(Wh_c)
-            dbh = torch.zeros(O, dtype=F32, device=dev) if ctx.has_bias[1] else None
-            gemm_tn_acc(TSh, C, seg, S, C, dPh, O, dWh, O, dbh, T * M, O)
+        if overlap:
+            main.wait_stream(side)
+        else:
+            if need_wzr:
+                gemm_tn_acc(TSzr, C, seg, S, C, dPzr, 2 * O, dWzr, 2 * O, dbzr, T * M, 2 * O)
+            if need_wh:
+                gemm_tn_acc(TSh, C, seg, S, C, dPh, O, dWh, O, dbh, T * M, O)
         dH0 = dH if ctx.needs_input_grad[1] else None
         return dX, dH0, dWzr, dbzr, dWh, dbh, None, None, None, None
 

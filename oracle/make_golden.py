@@ -288,6 +288,38 @@ def chebconvattention_sensor():
                  {"K": 3, "lambda_rw": 2.3, "lambda_none": 3.1})
 
 
+# ------------------------------------------------------------------------------------------------ ASTGCN / MSTGCN
+
+@case
+def astgcn_sensor():
+    m = R.load("nn.attention.astgcn")
+    ei, _ = syn.sensor_graph(24, 150, seed=90, symmetric=False)
+    X = _rand((3, 24, 2, 8), 91)
+    outs, layer = {}, None
+    for norm in ("sym", None):
+        layer_n = m.ASTGCN(2, 2, 3, 6, 5, 2, 4, 8, 24, normalization=norm)
+        if layer is None:
+            layer = layer_n
+            _randomise(layer, 92)
+        else:
+            layer_n.load_state_dict(layer.state_dict())
+        with torch.no_grad():
+            outs["out_" + str(norm)] = layer_n(X, _t(ei))
+    return _pack({"X": X, "edge_index": _t(ei)}, layer, outs, {"args": [2, 2, 3, 6, 5, 2, 4, 8, 24]})
+
+
+@case
+def mstgcn_sensor():
+    m = R.load("nn.attention.mstgcn")
+    ei, _ = syn.sensor_graph(24, 150, seed=93, symmetric=False)
+    X = _rand((3, 24, 2, 8), 94)
+    layer = m.MSTGCN(2, 2, 3, 6, 6, 2, 4, 8)   # (the reference needs nb_chev_filter == nb_time_filter, mstgcn.py:86-88)
+    _randomise(layer, 95)
+    with torch.no_grad():
+        out = layer(X, _t(ei))
+    return _pack({"X": X, "edge_index": _t(ei)}, layer, {"out": out}, {"args": [2, 2, 3, 6, 6, 2, 4, 8]})
+
+
 # ------------------------------------------------------------------------------------------------ ChebConv cells
 
 def _cheb_cell_case(modname, clsname, seed, lstm):

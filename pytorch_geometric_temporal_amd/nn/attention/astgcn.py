@@ -64,3 +64,123 @@ class ChebConvAttention(torch.nn.Module):
     def __repr__(self):
         return "{}({}, {}, K={}, normalization={})".format(
             self.__class__.__name__, self._in_channels, self._out_channels, self._weight.size(0), self._normalization)
+
+
+def _init_like_reference(module):
+    """xavier_uniform for matrices, uniform(0, 1) for vectors (astgcn.py:220-225 and the other _reset_parameters)."""
+    for p in module.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_uniform_(p)
+        else:
+            torch.nn.init.uniform_(p)
+
+
+class SpatialAttention(torch.nn.Module):
+    r"""Spatial attention of ASTGCN (reference: astgcn.py:201-262): X [B, N, F, T] -> S [B, N, N],
+    S = softmax_dim1( Vs . sigmoid( (X W1 W2) (W3 X)^T + bs ) ).  Dense [B,N,N] work: torch matmuls."""
+
+    def __init__(self, in_channels: int, num_of_vertices: int, num_of_timesteps: int):
+        super().__init__()
+        self._W1 = torch.nn.Parameter(torch.empty(num_of_timesteps))
+        self._W2 = torch.nn.Parameter(torch.empty(in_channels, num_of_timesteps))
+        self._W3 = torch.nn.Parameter(torch.empty(in_channels))
+        self._bs = torch.nn.Parameter(torch.empty(1, num_of_vertices, num_of_vertices))
+        self._Vs = torch.nn.Parameter(torch.empty(num_of_vertices, num_of_vertices))
+        _init_like_reference(self)
+
+    def forward(self, X):
+        lhs = torch.matmul(torch.matmul(X, self._W1), self._W2)          # [B, N, T]
+        rhs = torch.matmul(self._W3, X).transpose(-1, -2)                # [B, T, N]
+        S = torch.matmul(self._Vs, torch.sigmoid(torch.matmul(lhs, rhs) + self._bs))
+        return torch.softmax(S, dim=1)
+
+
+class TemporalAttention(torch.nn.Module):
+    r"""Temporal attention of ASTGCN (reference: astgcn.py:265-328): X [B, N, F, T] -> E [B, T, T]."""
+
+    def __init__(self, in_channels: int, num_of_vertices: int, num_of_timesteps: int):
+        super().__init__()
+        self._U1 = torch.nn.Parameter(torch.empty(num_of_vertices))
+        self._U2 = torch.nn.Parameter(torch.empty(in_channels, num_of_vertices))
+        self._U3 = torch.nn.Parameter(torch.empty(in_channels))
+        self._be = torch.nn.Parameter(torch.empty(1, num_of_timesteps, num_of_timesteps))
+        self._Ve = torch.nn.Parameter(torch.empty(num_of_timesteps, num_of_timesteps))
+        _init_like_reference(self)
+
+    def forward(self, X):
+        lhs = torch.matmul(torch.matmul(X.permute(0, 3, 2, 1), self._U1), self._U2)   # [B, T, N]
+        rhs = torch.matmul(self._U3, X)                                                # [B, N, T]
+        E = torch.matmul(self._Ve, torch.sigmoid(torch.matmul(lhs, rhs) + self._be))
+        return torch.softmax(E, dim=1)
+
+
+class ASTGCNBlock(torch.nn.Module):
+    r"""One ASTGCN block (reference: astgcn.py:330-481): temporal attention -> spatial attention -> Chebyshev
+    convolution with that attention on every time step -> time convolution + residual -> LayerNorm.
+    The reference calls `ChebConvAttention` once per time step in a Python loop with the SAME attention (:442-452);
+    here the T steps are one call (time folded next to the channels: one aggregation launch per hop, one GEMM)."""
+
+    def __init__(self, in_channels: int, K: int, nb_chev_filter: int, nb_time_filter: int, time_strides: int,
+                 num_of_vertices: int, num_of_timesteps: int, normalization: Optional[str] = None, bias: bool = True):
+        super().__init__()
+        self._temporal_attention = TemporalAttention(in_channels, num_of_vertices, num_of_timesteps)
+        self._spatial_attention = SpatialAttention(in_channels, num_of_vertices, num_of_timesteps)
+        self._chebconv_attention = ChebConvAttention(in_channels, nb_chev_filter, K, normalization, bias)
+        self._time_convolution = torch.nn.Conv2d(nb_chev_filter, nb_time_filter, kernel_size=(1, 3),
+                                                 stride=(1, time_strides), padding=(0, 1))
+        self._residual_convolution = torch.nn.Conv2d(in_channels, nb_time_filter, kernel_size=(1, 1),
+                                                     stride=(1, time_strides))
+        self._layer_norm = torch.nn.LayerNorm(nb_time_filter)
+        self._normalization = normalization
+        _init_like_reference(self)
+
+    def _lambda_max(self, edge_index, n):
+        if self._normalization == "sym":
+            return None
+        from ..conv import laplacian_lambda_max
+        return laplacian_lambda_max(edge_index, n, self._normalization)
+
+    def forward(self, X, edge_index):
+        B, N, Fin, T = X.shape
+        E = self._temporal_attention(X)                                               # [B, T, T]
+        X_tilde = torch.matmul(X.reshape(B, -1, T), E).reshape(B, N, Fin, T)
+        S = self._spatial_attention(X_tilde)                                          # [B, N, N]
+        conv = self._chebconv_attention
+        if not isinstance(edge_index, list):
+            lam = self._lambda_max(edge_index, N)
+            if conv._normalization != "sym" and lam is None:
+                raise ValueError("You need to pass `lambda_max` to `forward() in`case the normalization is non-symmetric.")
+            g = ops.cheb_graph(edge_index, None, N, conv._normalization, 2.0 if lam is None else lam, variant=1)
+            out = ops.ChebConvAttentionFunction.apply(X.permute(0, 1, 3, 2), S, conv._weight, conv._bias, g,
+                                                      conv._weight.size(0))           # [B, N, T, O]
+            X_hat = torch.relu(out.permute(0, 1, 3, 2))                               # [B, N, O, T]
+        else:                                                                         # one graph per time step
+            steps = [conv(X[:, :, :, t], edge_index[t], S, lambda_max=self._lambda_max(edge_index[t], N)).unsqueeze(-1)
+                     for t in range(T)]
+            X_hat = torch.relu(torch.cat(steps, dim=-1))
+        X_hat = self._time_convolution(X_hat.permute(0, 2, 1, 3))
+        Xr = self._residual_convolution(X.permute(0, 2, 1, 3))
+        out = self._layer_norm(torch.relu(Xr + X_hat).permute(0, 3, 2, 1))
+        return out.permute(0, 2, 3, 1)
+
+
+class ASTGCN(torch.nn.Module):
+    r"""Attention-based spatial-temporal GCN (reference: astgcn.py:484-640).
+    X [B, N, F_in, T_in], edge_index -> [B, N, T_out]."""
+
+    def __init__(self, nb_block: int, in_channels: int, K: int, nb_chev_filter: int, nb_time_filter: int,
+                 time_strides: int, num_for_predict: int, len_input: int, num_of_vertices: int,
+                 normalization: Optional[str] = None, bias: bool = True):
+        super().__init__()
+        blocks = [ASTGCNBlock(in_channels, K, nb_chev_filter, nb_time_filter, time_strides, num_of_vertices, len_input,
+                              normalization, bias)]
+        blocks += [ASTGCNBlock(nb_time_filter, K, nb_chev_filter, nb_time_filter, 1, num_of_vertices,
+                               len_input // time_strides, normalization, bias) for _ in range(nb_block - 1)]
+        self._blocklist = torch.nn.ModuleList(blocks)
+        self._final_conv = torch.nn.Conv2d(int(len_input / time_strides), num_for_predict, kernel_size=(1, nb_time_filter))
+        _init_like_reference(self)
+
+    def forward(self, X, edge_index):
+        for block in self._blocklist:
+            X = block(X, edge_index)
+        return self._final_conv(X.permute(0, 3, 1, 2))[:, :, :, -1].permute(0, 2, 1)

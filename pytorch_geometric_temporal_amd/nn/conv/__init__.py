@@ -189,3 +189,45 @@ class TopKPooling(torch.nn.Module):
         perm = torch.sort(score.view(-1), descending=True).indices[:k]
         s = score[perm]
         return (x[perm] * s.view(-1, 1), None, None, None, perm, s)
+
+
+_LAMBDA_CACHE = {}
+
+
+def laplacian_lambda_max(edge_index, num_nodes, normalization=None, edge_weight=None, is_undirected=False):
+    """Largest eigenvalue of the graph Laplacian — what torch_geometric.transforms.LaplacianLambdaMax computes for
+    ASTGCN / MSTGCN every forward (astgcn.py:437-440, mstgcn.py:74-76).  Host-side (scipy ARPACK, as in PyG), once
+    per edge list: the result is cached by tensor identity."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), str(edge_index.device), normalization,
+           None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version), int(num_nodes))
+    hit = _LAMBDA_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    import numpy as np
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import eigs, eigsh
+    ei = edge_index.detach().cpu()
+    w = torch.ones(ei.size(1)) if edge_weight is None else edge_weight.detach().cpu().float()
+    keep = ei[0] != ei[1]
+    ei, w = ei[:, keep], w[keep]
+    n = int(num_nodes)
+    deg = torch.zeros(n).scatter_add_(0, ei[0], w)
+    loops = torch.arange(n)
+    if normalization is None:
+        vals = torch.cat([-w, deg])
+    elif normalization == "sym":
+        dis = deg.pow(-0.5)
+        dis[dis == float("inf")] = 0
+        vals = torch.cat([-dis[ei[0]] * w * dis[ei[1]], torch.ones(n)])
+    else:
+        dinv = 1.0 / deg
+        dinv[dinv == float("inf")] = 0
+        vals = torch.cat([-dinv[ei[0]] * w, torch.ones(n)])
+    rows, cols = torch.cat([ei[0], loops]).numpy(), torch.cat([ei[1], loops]).numpy()
+    L = sp.coo_matrix((vals.numpy().astype(np.float64), (rows, cols)), shape=(n, n))
+    fn = eigsh if (is_undirected and normalization != "rw") else eigs
+    lam = float(fn(L, k=1, which="LM", return_eigenvectors=False).real[0])
+    _LAMBDA_CACHE[key] = (lam, edge_index, edge_weight)       # keep the key tensors alive
+    if len(_LAMBDA_CACHE) > 64:
+        _LAMBDA_CACHE.pop(next(iter(_LAMBDA_CACHE)))
+    return lam

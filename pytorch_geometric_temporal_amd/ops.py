@@ -917,7 +917,9 @@ def sddmm_att(csr, G3, X3, dS):
 
 
 class ChebConvAttentionFunction(torch.autograd.Function):
-    """ChebConvAttention.forward (astgcn.py:112-183) on x [B,N,Fin], S [B,N,N], W [K,Fin,Fout]:
+    """ChebConvAttention.forward (astgcn.py:112-183) on x [B,N,Fin] — or [B,N,Tt,Fin]: Tt independent calls that share
+    the attention (ASTGCNBlock calls the layer once per time step with the same S, astgcn.py:442-452), folded into
+    one call — S [B,N,N], W [K,Fin,Fout]:
 
         T_0 = diag(S[b]) x[b]                         (the reference builds it through a dense eye(N)*S bmm, :159-164)
         T_1 = sum_e norm_e S[b,row_e,col_e] T_0[col_e]  (propagate on the transposed list with Att_norm, :157,169-171)
@@ -930,45 +932,52 @@ class ChebConvAttentionFunction(torch.autograd.Function):
         lib = _lib.get_lib()
         check_tensor(lib, x, "x")
         check_tensor(lib, S, "spatial_attention")
-        B, N, C = x.shape
+        squeeze = x.dim() == 3
+        if squeeze:
+            x = x.unsqueeze(2)
+        B, N, Tt, C = x.shape
         if S.shape != (B, N, N) or g.N != N:
             raise ValueError(f"ChebConvAttention: x {tuple(x.shape)}, spatial_attention {tuple(S.shape)}, graph N={g.N}")
         O = W.size(2)
-        M = N * B
+        CC = Tt * C                                                # channels seen by the aggregation
+        M = N * B * Tt                                             # rows seen by the feature transform
         Sc = S.contiguous()
-        Xnm = swap01(x.contiguous(), B, N, C)                      # [N, B, C]
+        Xnm = swap01(x.contiguous().view(B, N, CC), B, N, CC)      # [N, B, Tt*C]
         d = torch.diagonal(Sc, dim1=1, dim2=2).t().contiguous()    # [N, B]   S[b, i, i]
-        TS = torch.empty(K, N, B, C, dtype=F32, device=x.device)
+        TS = torch.empty(K, N, B, CC, dtype=F32, device=x.device)
         torch.mul(Xnm, d.unsqueeze(-1), out=TS[0])
         if K > 1:
             TS[1].copy_(spmm_att(g.fwd, Sc, TS[0]))
         for k in range(2, K):
-            spmm(g.fwd, TS[k - 1].view(N, B * C), TS[k].view(N, B * C), T=TS[k - 2].view(N, B * C), alpha=2.0, beta=-1.0)
+            spmm(g.fwd, TS[k - 1].view(N, B * CC), TS[k].view(N, B * CC), T=TS[k - 2].view(N, B * CC), alpha=2.0, beta=-1.0)
         Wc = W.contiguous().view(K * C, O)
         out = torch.empty(M, O, dtype=F32, device=x.device)
         gemm(TS, C, M * C, K, C, Wc, O, 1, out, O, 0, O, bias, M, O)
-        ctx.g, ctx.K, ctx.dims = g, K, (B, N, C, O)
+        ctx.g, ctx.K, ctx.dims, ctx.squeeze = g, K, (B, N, Tt, C, O), squeeze
         ctx.has_bias = bias is not None
         ctx.save_for_backward(TS, Wc, Sc, Xnm, d)
-        return swap01(out.view(N, B, O), N, B, O)                  # [B, N, O]
+        res = swap01(out.view(N, B, Tt * O), N, B, Tt * O).view(B, N, Tt, O)
+        return res[:, :, 0] if squeeze else res
 
     @staticmethod
     def backward(ctx, dOut):
         TS, Wc, Sc, Xnm, d = ctx.saved_tensors
         g, K = ctx.g, ctx.K
-        B, N, C, O = ctx.dims
-        M = N * B
+        B, N, Tt, C, O = ctx.dims
+        CC, M = Tt * C, N * B * Tt
         dev = dOut.device
-        dO = swap01(dOut.contiguous(), B, N, O).view(M, O)          # node-major rows
+        if ctx.squeeze:
+            dOut = dOut.unsqueeze(2)
+        dO = swap01(dOut.contiguous().view(B, N, Tt * O), B, N, Tt * O).view(M, O)   # node-major rows (n, b, t)
         dW = torch.zeros_like(Wc)
         db = torch.zeros(O, dtype=F32, device=dev) if ctx.has_bias else None
         gemm_tn_acc(TS, C, M * C, K, C, dO, O, dW, O, db, M, O)
-        G = torch.empty(K, N, B, C, dtype=F32, device=dev)
+        G = torch.empty(K, N, B, CC, dtype=F32, device=dev)
         gemm(dO, O, 0, 1, O, Wc, 1, O, G, C, M * C, C, None, M, K * C)
         for k in range(K - 1, 1, -1):                               # adjoint of T_k = 2 L T_{k-1} - T_{k-2}
-            Gk, Gp = G[k].view(N, B * C), G[k - 1].view(N, B * C)
+            Gk, Gp = G[k].view(N, B * CC), G[k - 1].view(N, B * CC)
             spmm(g.bwd, Gk, Gp, T=Gp, alpha=2.0, beta=1.0)
-            axpby2d(G[k - 2].view(M, C), G[k].view(M, C), -1.0, G[k - 2].view(M, C), 1.0)
+            axpby2d(G[k - 2].view(N * B, CC), G[k].view(N * B, CC), -1.0, G[k - 2].view(N * B, CC), 1.0)
         dS = torch.zeros(B, N, N, dtype=F32, device=dev)
         if K > 1:
             sddmm_att(g.fwd, G[1], TS[0], dS)                       # d/dS of the attention-weighted hop
@@ -977,7 +986,9 @@ class ChebConvAttentionFunction(torch.autograd.Function):
         dXnm = G[0] * d.unsqueeze(-1)
         dd = (G[0] * Xnm).sum(dim=-1)                               # [N, B]
         torch.diagonal(dS, dim1=1, dim2=2).add_(dd.t())
-        dx = swap01(dXnm.contiguous(), N, B, C)
+        dx = swap01(dXnm.contiguous(), N, B, CC).view(B, N, Tt, C)
+        if ctx.squeeze:
+            dx = dx[:, :, 0]
         return dx, dS, dW.view(K, C, O), db, None, None
 
 

@@ -103,7 +103,13 @@ int main(int argc, char** argv) {
     timeit(rows == 64 ? "plain tile TR=64" : "plain tile TR=32", [&](int p) { pgt_spmm_csr_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);
   }
   pgt_tune("spmm_tile_rows", 64);
-  for (int k : {3, 2}) for (int ch : {1, 0}) {
+  for (int cu : {1, 2}) {
+    pgt_tune("spmm_band_cu", cu);
+    char nm[64]; snprintf(nm, 64, "band per-CU workgroup x%d", cu);
+    timeit(nm, [&](int p) { pgt_spmm_csr_band_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, 32, st); }, alg);
+  }
+  pgt_tune("spmm_band_cu", 0);
+  for (int k : {3}) for (int ch : {1}) {
     pgt_tune("spmm_band_blocks", k); pgt_tune("spmm_band_xcd", ch);
     char nm[64]; snprintf(nm, 64, "band halo=32 k=%d xcd=%d", k, ch);
     timeit(nm, [&](int p) { pgt_spmm_csr_band_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, 32, st); }, alg);
@@ -117,6 +123,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(tr, 0, TRN * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &tr, sizeof(tr)));
     CK(hipDeviceSynchronize());
+    pgt_tune("spmm_band_cu", 1);
     if (which == 0) pgt_spmm_csr_band_f32(rp, col, val, n, X[3], F, Y[3], F, nullptr, 0, 1.f, 0.f, F, 32, st);
     else pgt_spmm_csr_f32(rp, col, val, n, X[4], F, Y[4], F, nullptr, 0, 1.f, 0.f, F, st);
     CK(hipDeviceSynchronize());

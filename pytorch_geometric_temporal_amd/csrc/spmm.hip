@@ -34,6 +34,8 @@ int g_quad = 0;        // F = 64: 1 = barrier-free persistent quad kernel instea
 int g_quad_blocks = 7; // quad kernel: resident workgroups per CU (70 VGPRs -> 7 wavefronts per SIMD)
 int g_band_blocks = 3;  // band kernel: resident workgroups per CU the chunking aims at (<= 3: 160-VGPR kernel)
 int g_band_xcd = 1;     // band kernel: contiguous chunk ranges per XCD
+int g_band_cu = 1;      // band kernel: 1 = one 1024-thread workgroup per CU (spmm_band64_cu_kernel), 0 = small workgroups
+int g_band_nblk = 0;    // test hook: number of workgroups of the per-CU band kernel (0 = one or two per CU)
 
 template <int VEC>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[VEC]) {
@@ -368,6 +370,150 @@ __global__ __launch_bounds__(256, (RING == 128 ? 3 : 2)) void spmm_band64_kernel
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// spmm_band64_cu_kernel<RING> — the LDS-window schedule with ONE 1024-thread workgroup per CU.
+// PMC analysis of the other schedules (profiles/r01e_pmc_ns.csv): a CU's vector L1 keeps ~64 read misses in flight;
+// the neighbour gather of the tile / quad schedules produces 3x more L1 misses than the rows a CU needs (L1 hit rate
+// 50 %), and although they hit in L2 (~500 cycles) they occupy the same miss slots as the HBM fetches (~1 500 cycles),
+// which caps the HBM stream at ~60 % of what a copy achieves.  Serving the gather from LDS leaves the miss slots to the
+// one-time HBM fetch of X, Y and the CSR arrays.  Compared with spmm_band64_kernel (3-4 small workgroups per CU, 3-5
+// steps each) one workgroup owns all ~n_rows/256 rows of its CU: one prologue and 2H halo rows per CU instead of per
+// chunk, 12+ pipelined steps, every wavefront gathers exactly one row-quad per step, and all CUs finish together.
+template <int RING>
+__global__ __launch_bounds__(1024) void spmm_band64_cu_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    int n_rows, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt,
+    float alpha, float beta, int rows_per_chunk, int srows, int xcd_remap) {
+  constexpr int S = 64, H = (RING - S) / 2;
+  constexpr int PRE = 2 * H / 64;            // 64-row passes of the leading half-window
+  constexpr int MAXCHUNK = 2048;             // rows per workgroup (rowptr slice staged in LDS)
+  __shared__ pgt_f4 s_x[RING * 16];
+  __shared__ int s_rp[MAXCHUNK + 1];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, l16 = lane & 15;
+  const int rg = tid >> 4;                   // 64 row-groups of 16 lanes: one 256-B row each per staging pass
+  const int chunk = xcd_remap ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int c0 = chunk * rows_per_chunk;
+  if (c0 >= n_rows) return;  // whole workgroup
+  const int c1 = (c0 + rows_per_chunk < n_rows) ? c0 + rows_per_chunk : n_rows;
+  const float* Xl = X + l16 * 4;
+  PGT_TRACE_MARK(0);
+
+  auto clampr = [&](int r) { return r < 0 ? 0 : (r < n_rows ? r : n_rows - 1); };
+  // this thread's float4 of row s0 + H + rg (the rows step s0 adds to the window).  Always issued — past the end of
+  // the chunk every lane re-reads the chunk's last window row (an L1 hit) — so that the number of requests in flight
+  // is the same on every path and the compiler can count them (s_waitcnt vmcnt(N)) instead of draining the queue.
+  const int last_row = clampr(c1 + H - 1);
+  auto load_x = [&](int s0) {
+    const int r = s0 + H + rg;
+    return *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)((r < c1 + H ? clampr(r) : last_row) * ldx));
+  };
+  // first 16 slots of this wavefront's row-quad of the step starting at s0 (wave w owns rows 4w .. 4w+3 of the step);
+  // rowptr comes out of LDS, so the request depends on nothing that is still in flight
+  auto load_cv = [&](int s0, int& qa, int& qn, int& qc, float& qv) {
+    const int send = s0 + srows < c1 ? s0 + srows : c1;
+    const int row = s0 + wave * 4 + g;
+    const int rl = row < c1 ? row - c0 : c1 - c0;
+    const int a = s_rp[rl], b = s_rp[rl < c1 - c0 ? rl + 1 : rl];
+    qa = a;
+    qn = (row < send) ? b - a : 0;
+    const int q = (l16 < qn) ? a + l16 : (b > 0 ? b - 1 : 0);
+    qc = col[q];
+    qv = val[q];
+  };
+
+  // ---- prologue: rowptr slice -> LDS, leading half-window -> LDS, X rows of steps 0..2 -> registers
+  for (int i = tid; i <= c1 - c0; i += 1024) s_rp[i] = rowptr[c0 + i];
+  pgt_f4 pre[PRE];
+#pragma unroll
+  for (int i = 0; i < PRE; ++i) pre[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(c0 - H + rg + 64 * i) * ldx));
+  pgt_f4 tA = load_x(c0), tB = load_x(c0 + srows), tC = load_x(c0 + 2 * srows);
+#pragma unroll
+  for (int i = 0; i < PRE; ++i) {
+    const int r = c0 - H + rg + 64 * i;
+    if (r >= 0 && r < n_rows) s_x[(r & (RING - 1)) * 16 + l16] = pre[i];
+  }
+  __syncthreads();   // s_rp visible
+  int aA, nA, cA, aB = 0, nB = 0, cB = 0, aC = 0, nC = 0, cC = 0;
+  float vA, vB = 0.f, vC = 0.f;
+  load_cv(c0, aA, nA, cA, vA);
+  load_cv(c0 + srows, aB, nB, cB, vB);
+  PGT_TRACE_MARK(1);
+
+  // One step.  tt: this step's X rows (requested three steps ago), refilled with the rows of step s0 + 3*srows.
+  // (ca, cn, cc, cv): this step's slots; the slots of step s0 + 2*srows go to (na, nn, nc, nv).  The three register sets
+  // rotate through the three calls of the unrolled loop: nothing that is in flight is ever copied.
+  auto step = [&](const int s0, pgt_f4& tt, int ca, int cn, int cc, float cv, int& na, int& nn, int& nc, float& nv) {
+    {
+      const int r = s0 + H + rg;
+      if (r < n_rows && rg < srows && s0 < c1) s_x[(r & (RING - 1)) * 16 + l16] = tt;
+    }
+    __syncthreads();
+    tt = load_x(s0 + 3 * srows);
+    load_cv(s0 + 2 * srows, na, nn, nc, nv);
+    const int send = s0 + srows < c1 ? s0 + srows : c1;
+    const int w_lo = (s0 - H > 0) ? s0 - H : 0;
+    const int w_hi = (send + H < n_rows) ? send + H : n_rows;   // rows past send + H were not fetched (load_x clamps)
+    const int row = s0 + wave * 4 + g;
+    const int a = ca, n = cn;
+    int mc = cc;
+    float mv = cv;
+    pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+    for (int q0 = 0; __ballot(q0 < n) != 0ull; q0 += 16) {
+      const bool mine = q0 + l16 < n;
+      if (q0 > 0) {  // rows longer than the 16 prefetched slots
+        mc = mine ? col[a + q0 + l16] : 0;
+        mv = mine ? val[a + q0 + l16] : 0.f;
+      }
+      const bool any_far = __ballot(mine && (mc < w_lo || mc >= w_hi)) != 0ull;
+      for (int u0 = 0; u0 < 16 && __ballot(q0 + u0 < n) != 0ull; u0 += 8) {
+        int c[8];
+        float v[8];
+        pgt_f4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { c[u] = __shfl(mc, u0 + u, 16); v[u] = __shfl(mv, u0 + u, 16); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = s_x[(c[u] & (RING - 1)) * 16 + l16];
+        if (any_far) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (q0 + u0 + u < n && (c[u] < w_lo || c[u] >= w_hi))
+              x[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c[u] * ldx));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool live = q0 + u0 + u < n;
+          acc.x = live ? fmaf(v[u], x[u].x, acc.x) : acc.x;
+          acc.y = live ? fmaf(v[u], x[u].y, acc.y) : acc.y;
+          acc.z = live ? fmaf(v[u], x[u].z, acc.z) : acc.z;
+          acc.w = live ? fmaf(v[u], x[u].w, acc.w) : acc.w;
+        }
+      }
+    }
+    if (row < send) {
+      pgt_f4 o;
+      if (T != nullptr) {
+        const pgt_f4 t4 = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(row * ldt + l16 * 4));
+        o = pgt_mk4(alpha * acc.x + beta * t4.x, alpha * acc.y + beta * t4.y, alpha * acc.z + beta * t4.z,
+                    alpha * acc.w + beta * t4.w);
+      } else {
+        o = pgt_mk4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+      }
+      *reinterpret_cast<pgt_f4*>(Y + (unsigned)(row * ldy + l16 * 4)) = o;
+    }
+    __syncthreads();
+  };
+#pragma unroll 1
+  for (int s0 = c0; s0 < c1; s0 += 3 * srows) {
+    // (steps past the end of the chunk are empty: no LDS write, no slots, no store — but the same barriers and requests)
+    step(s0, tA, aA, nA, cA, vA, aC, nC, cC, vC);
+    step(s0 + srows, tB, aB, nB, cB, vB, aA, nA, cA, vA);
+    step(s0 + 2 * srows, tC, aC, nC, cC, vC, aB, nB, cB, vB);
+  }
+  PGT_TRACE_MARK(15);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // spmm_quad64_kernel — F = 64, barrier-free and persistent: every wavefront walks its own sequence of row-quads
 // (4 rows x 16 lanes x float4).  No LDS, no workgroup barrier: a quad's (col, val) slots are fetched with one
 // coalesced 16-slot read per row and broadcast with ds_bpermute; rowptr of quad i+2 and the slots of quad i+1 are in
@@ -678,6 +824,8 @@ int pgt_spmm_tune(const char* key, int value) {
   if (strcmp(key, "spmm_quad_blocks") == 0) { g_quad_blocks = value > 0 ? value : 1; return 1; }
   if (strcmp(key, "spmm_band_blocks") == 0) { g_band_blocks = value > 0 ? value : 1; return 1; }
   if (strcmp(key, "spmm_band_xcd") == 0) { g_band_xcd = value; return 1; }
+  if (strcmp(key, "spmm_band_cu") == 0) { g_band_cu = value; return 1; }
+  if (strcmp(key, "spmm_band_nblk") == 0) { g_band_nblk = value > 0 ? value : 0; return 1; }
   return 0;
 }
 
@@ -724,6 +872,24 @@ extern "C" int pgt_spmm_csr_band_f32(const int32_t* rowptr, const int32_t* col, 
   if (halo <= 0 || halo > 96 || F != 64 || vp.v != 4 || n_rows * max_ld >= ((int64_t)1 << 31))
     return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   const int ring = halo <= 32 ? 128 : 256;
+  if (g_band_cu && pgt_cdiv(n_rows, g_band_nblk > 0 ? g_band_nblk : 256 * (int64_t)(g_band_cu >= 2 ? 2 : 1)) + 4 <= 2048) {
+    // one 1024-thread workgroup per CU (g_band_cu == 2: two): each owns a contiguous 1/256 (1/512) of the rows
+    int64_t nblk = g_band_nblk > 0 ? g_band_nblk : 256 * (int64_t)(g_band_cu >= 2 ? 2 : 1);
+    int64_t rpc = pgt_cdiv(pgt_cdiv(n_rows, nblk), 4) * 4;
+    if (rpc < 64) rpc = 64;
+    const int64_t steps = pgt_cdiv(rpc, 64);
+    const int64_t srows = pgt_cdiv(pgt_cdiv(rpc, steps), 4) * 4;
+    nblk = pgt_cdiv(n_rows, rpc);
+    dim3 grid((unsigned)nblk), block(1024);
+    if (ring == 128) {
+      PGT_LAUNCH((spmm_band64_cu_kernel<128>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y,
+                 (int)ldy, T, (int)ldt, alpha, beta, (int)rpc, (int)srows, g_band_xcd);
+    } else {
+      PGT_LAUNCH((spmm_band64_cu_kernel<256>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y,
+                 (int)ldy, T, (int)ldt, alpha, beta, (int)rpc, (int)srows, g_band_xcd);
+    }
+    return pgt_check_launch("pgt_spmm_csr_band_f32");
+  }
   // chunking: g_band_blocks resident workgroups per CU (registers admit 3 at RING = 128, LDS 2 at RING = 256); each chunk is
   // swept in equal steps of at most 64 rows
   const int per_cu = ring == 128 ? (g_band_blocks < 3 ? g_band_blocks : 3) : (g_band_blocks < 2 ? g_band_blocks : 2);

@@ -625,3 +625,22 @@ def test_lstm_gate_kernels_against_autograd(backend, O, peep):
         tol = 1e-4 if backend.name == "emu" else 5e-3       # column sums over M rows (fp32 atomics on the GPU leg)
         for a, b_, nm in zip(wd, w64, ("w_ci", "w_cf", "w_co")):
             assert_close_with_nonfinite(a.grad, b_.grad, tol, 1e-4, nm)
+
+
+@pytest.mark.parametrize("nblk,n,window", [(3, 700, 40), (2, 333, 32), (5, 1500, 50)])
+def test_spmm_band_per_cu_kernel_multi_step_chunks(backend, nblk, n, window):
+    """The per-CU LDS-window kernel with several pipelined steps per workgroup and partial last steps (on the GPU these
+    only occur beyond 16 384 rows; the `spmm_band_nblk` hook forces few workgroups so the CPU test double sees them),
+    with sources just outside the halo at chunk ends."""
+    lib = _lib.get_lib()
+    csr = banded_csr(n, 0, 18, window, seed=n, device=backend.device, far_frac=0.03, heavy_row=min(n - 1, 200))
+    X = torch.randn(n, 64).to(backend.device)
+    T = torch.randn(n, 64).to(backend.device)
+    Yp, Yb = torch.empty_like(X), torch.full_like(X, float("nan"))
+    ops.spmm(csr, X, Yp, T=T, alpha=2.0, beta=-1.0, halo=0)
+    lib.tune("spmm_band_nblk", nblk)
+    try:
+        ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0, halo=32)
+    finally:
+        lib.tune("spmm_band_nblk", 0)
+    assert torch.equal(Yp, Yb)

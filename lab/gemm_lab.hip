@@ -14,21 +14,36 @@ __device__ long long* g_trace_buf = nullptr;
       g_trace_buf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = (long long)wall_clock64(); \
   } while (0)
 
+__device__ int g_lab_dbg = 0;
+#define PGT_LAB_TILE(t) (g_lab_dbg ? 0 : (t))
 int pgt_spmm_tune(const char*, int) { return 0; }
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
+// pure matrix-pipe loop: W wavefronts per SIMD, 4 independent accumulators, no memory traffic (achievable MFMA rate)
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  pgt_f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = PGT_MFMA_32x32x2(a, b, acc[i]);
+  }
+  float s = 0; for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) out[0] = s;
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 211968, S = 5, C = 66, K = S * C;
   float *A, *W, *Cout, *G, *dW, *bias;
-  CK(hipMalloc(&A, (size_t)S * M * C * 4)); CK(hipMalloc(&W, (size_t)K * 128 * 4)); CK(hipMalloc(&Cout, (size_t)M * 128 * 4));
+  CK(hipMalloc(&A, (size_t)S * M * C * 4)); CK(hipMalloc(&W, (size_t)640 * 128 * 4)); CK(hipMalloc(&Cout, (size_t)M * 128 * 4));
   CK(hipMalloc(&G, (size_t)S * M * C * 4)); CK(hipMalloc(&dW, (size_t)K * 128 * 4)); CK(hipMalloc(&bias, 128 * 4));
   std::vector<float> h((size_t)S * M * C);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 500.f - 1.f;
   CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(W, h.data(), (size_t)K * 128 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, h.data(), (size_t)640 * 128 * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(Cout, h.data(), (size_t)M * 128 * 4, hipMemcpyHostToDevice));
   CK(hipMemset(bias, 0, 512)); CK(hipMemset(dW, 0, (size_t)K * 128 * 4));
   hipStream_t st; CK(hipStreamCreate(&st));
@@ -44,12 +59,30 @@ int main(int argc, char** argv) {
     double us = ms * 1e3 / reps;
     printf("%-40s %9.2f us  %7.2f TF  (%.3f of 157.3)\n", name, us, flop / us / 1e6, flop / us / 1e6 / 157.3);
   };
+  for (int wps : {1, 2, 4}) {
+    const int iters = 4096;
+    auto fn = [&]() { hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * wps), dim3(256), 0, st, bias, iters); };
+    for (int i = 0; i < 20; ++i) fn();     // also warms the clocks up before anything is timed
+    char nm[80]; snprintf(nm, 80, "pure MFMA 32x32x2 f32, %d wave/SIMD", wps);
+    timeit(nm, fn, 256.0 * wps * 4 * iters * 4 * 4096.0);
+  }
+  const int only = argc > 2 ? atoi(argv[2]) : -1;
+  const int dbg = argc > 3 ? atoi(argv[3]) : 0;
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lab_dbg), &dbg, sizeof(int)));
   for (int N : {128, 64}) {
     char nm[80];
-    snprintf(nm, 80, "NN  [M,330]x[330,%d] seg A", N);
-    timeit(nm, [&]() { pgt_gemm_f32(A, C, (int64_t)M * C, S, C, W, N, 1, Cout, N, 0, N, bias, M, N, 0, st); }, 2.0 * M * K * N);
-    snprintf(nm, 80, "NT  [M,%d]x[%d,330] -> seg C", N, N);
-    timeit(nm, [&]() { pgt_gemm_f32(Cout, N, 0, 1, N, W, 1, N, G, C, (int64_t)M * C, C, nullptr, M, K, 0, st); }, 2.0 * M * K * N);
+    for (int db : {0, 1}) {
+      if (only >= 0 && db != only) continue;
+      pgt_tune("gemm_db", db);
+      snprintf(nm, 80, "NN  [M,330]x[330,%d] seg A  db=%d", N, db);
+      timeit(nm, [&]() { pgt_gemm_f32(A, C, (int64_t)M * C, S, C, W, N, 1, Cout, N, 0, N, bias, M, N, 0, st); }, 2.0 * M * K * N);
+      snprintf(nm, 80, "NT  [M,%d]x[%d,330] -> seg C  db=%d", N, N, db);
+      timeit(nm, [&]() { pgt_gemm_f32(Cout, N, 0, 1, N, W, 1, N, G, C, (int64_t)M * C, C, nullptr, M, K, 0, st); }, 2.0 * M * K * N);
+      // second layer: five 128-wide terms viewed inside the same buffers (M/2 rows so the extents fit)
+      snprintf(nm, 80, "NN  [M/2,640]x[640,%d] seg A  db=%d", N, db);
+      timeit(nm, [&]() { pgt_gemm_f32(A, 128, (int64_t)(M / 2) * 128, 5, 128, W, N, 1, Cout, N, 0, N, bias, M / 2, N, 0, st); }, 2.0 * (M / 2) * 640 * N);
+    }
+    pgt_tune("gemm_db", 1);
     snprintf(nm, 80, "TN  dW[330,%d] whole-K", N);
     pgt_tune("gemm_tn_fullk", 1);
     timeit(nm, [&]() { pgt_gemm_tn_acc_f32(A, C, (int64_t)M * C, S, C, Cout, N, dW, N, bias, M, N, st); }, 2.0 * M * K * N);

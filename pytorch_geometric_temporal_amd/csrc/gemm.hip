@@ -29,6 +29,97 @@ struct GemmArgs {
   const float* bias; int M; int N; int accumulate;
 };
 
+// Epilogue shared by the tile kernels.  D map (cdna_hip_programming.md §3): col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): stored straight from the accumulators a lane writes 4 bytes per row
+// (16 rows x 128-byte pieces per instruction).  Instead each wavefront transposes its 32-row blocks through LDS (the
+// operand tiles are dead: the caller guarantees every wavefront is past its last LDS read) and writes row-contiguous
+// float2 / float4: a column segment of the output (66-wide diffusion terms) stays 8-byte aligned, a plain matrix
+// 16-byte aligned.
+template <int WM, int WN, int LDS_BYTES>
+__device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, pgt_f32x16 (&acc)[WM][WN], float* lds,
+                                                int row0, int col0, int wave, int lane) {
+  // row0 / col0: first output row / column of THIS wavefront's (32 WM) x (32 WN) sub-tile
+  const int lo = lane & 31, hi = lane >> 5;
+  constexpr int EPW = 32 * WN + 4;                                   // floats per staged row (+4: rows on different banks)
+  constexpr bool EPI_LDS = LDS_BYTES >= 4 * 16 * EPW * (int)sizeof(float);
+  const int ev = g.accumulate ? 1 : g.c_seg_n == g.N ? 4 : 2;        // widest store the layout allows
+  if (EPI_LDS && ev > 1 && g.ldc % ev == 0 && g.c_seg_n % ev == 0 && g.c_seg_stride % ev == 0 &&
+      (reinterpret_cast<uintptr_t>(g.C) % (4 * ev)) == 0) {
+    // each wavefront stages 16 rows x (32 * WN) columns at a time inside the (now dead) tile storage
+    float* stage = lds + wave * 16 * EPW;
+    const int nw0 = col0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                                   // accumulator registers 8h .. 8h+7 = rows 16h .. 16h+15
+        PGT_WAVE_SYNC();
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int gn = nw0 + j * 32 + lo;
+          const float bv = (g.bias && gn < g.N) ? g.bias[gn] : 0.f;
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8)
+            stage[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EPW + j * 32 + lo] = acc[i][j][8 * h + r8] + bv;
+        }
+        PGT_WAVE_SYNC();
+        const int mrow0 = row0 + i * 32 + 16 * h;
+        if (ev == 4) {
+          constexpr int LPR = 32 * WN / 4;                            // lanes per row (8 | 16)
+          constexpr int RPP = 64 / LPR;                               // rows per pass
+#pragma unroll
+          for (int rr = 0; rr < 16; rr += RPP) {
+            const int row = rr + lane / LPR, c = (lane % LPR) * 4;
+            const int gm = mrow0 + row, gn = nw0 + c;
+            if (gm < g.M && gn < g.N) {
+              const float4 v = *reinterpret_cast<const float4*>(stage + row * EPW + c);
+              float* p = g.C + (int64_t)gm * g.ldc + gn;
+              if (gn + 3 < g.N) *reinterpret_cast<float4*>(p) = v;
+              else { p[0] = v.x; if (gn + 1 < g.N) p[1] = v.y; if (gn + 2 < g.N) p[2] = v.z; }
+            }
+          }
+        } else {
+          constexpr int LPR = 32 * WN / 2;                            // lanes per row (16 | 32)
+          constexpr int RPP = 64 / LPR;
+#pragma unroll
+          for (int rr = 0; rr < 16; rr += RPP) {
+            const int row = rr + lane / LPR, c = (lane % LPR) * 2;
+            const int gm = mrow0 + row, gn = nw0 + c;
+            if (gm < g.M && gn < g.N) {
+              const float2 v = *reinterpret_cast<const float2*>(stage + row * EPW + c);
+              const int js = gn / g.c_seg_n;
+              float* p = g.C + (int64_t)js * g.c_seg_stride + (int64_t)gm * g.ldc + (gn - js * g.c_seg_n);
+              if (gn + 1 < g.N) *reinterpret_cast<float2*>(p) = v;     // c_seg_n even: a pair never straddles segments
+              else p[0] = v.x;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int gn = col0 + j * 32 + lo;
+    if (gn >= g.N) continue;
+    const float bv = g.bias ? g.bias[gn] : 0.f;
+    const int js = gn / g.c_seg_n;
+    float* cbase = g.C + (int64_t)js * g.c_seg_stride + (gn - js * g.c_seg_n);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (gm < g.M) {
+          float v = acc[i][j][r] + bv;
+          float* p = cbase + (int64_t)gm * g.ldc;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
 // BM x BN tile, WM x WN sub-tiles of 32x32 per wavefront (2x2 wavefronts).  AV: floats per A load (1 | 2).
 // BKMAJ: B tile is loaded with lanes along k (B contiguous in k: the NT case) instead of along n.
 // TBK: k-depth of a tile, 32 or 30.  The loaders keep the 32-deep lane mapping and mask k >= TBK; 30 makes K = 330
@@ -141,90 +232,229 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue.  D map (cdna_hip_programming.md §3): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5):
-  // stored straight from the accumulators a lane writes 4 bytes per row (16 rows x 128-byte pieces per instruction).
-  // Instead each wavefront transposes its 32-row blocks through LDS (the A/B tiles are dead after the last barrier)
-  // and writes row-contiguous float2 / float4: a column segment of the output (66-wide diffusion terms) stays 8-byte
-  // aligned, a plain matrix 16-byte aligned.
-  constexpr int EPW = 32 * WN + 4;                                   // floats per staged row (+4: rows on different banks)
-  constexpr bool EPI_LDS = sizeof(Tiles) >= 4 * 16 * EPW * sizeof(float);
-  const int ev = g.accumulate ? 1 : g.c_seg_n == g.N ? 4 : 2;        // widest store the layout allows
-  if (EPI_LDS && ev > 1 && g.ldc % ev == 0 && g.c_seg_n % ev == 0 && g.c_seg_stride % ev == 0 &&
-      (reinterpret_cast<uintptr_t>(g.C) % (4 * ev)) == 0) {
-    // each wavefront stages 16 rows x (32 * WN) columns at a time inside the (now dead) tile storage
-    float* stage = reinterpret_cast<float*>(&tl) + wave * 16 * EPW;
-    const int nw0 = n0 + wn * (BN / 2);                               // first column of this wavefront
+  gemm_store_tile<WM, WN, (int)sizeof(Tiles)>(g, acc, reinterpret_cast<float*>(&tl), m0 + wm * (BM / 2),
+                                              n0 + wn * (BN / 2), wave, lane);
+  PGT_TRACE_MARK(1);
+}
+
+// Pipelined tile for tall operands (M >= 2048, vector-loadable A and B).  Every wavefront owns a 64 x 64 sub-tile
+// (2 x 2 accumulators of v_mfma_f32_32x32x2_f32); 2 x WAVES_N wavefronts per workgroup: 2 x 2 (256 threads) ->
+// 128 x 128 tile (N > 64), 2 x 1 (128 threads) -> 128 x 64 tile (N <= 64; 128-row tiles keep the tile count per CU
+// fine-grained: 6.5 per CU at the DCRNN shape).  Built so that ONE wavefront per SIMD can keep the matrix pipe busy: the pipe runs a
+// 32x32x2 MFMA in 64 cycles and a wavefront issues in order, so everything that is not an MFMA has to fit in the
+// gaps between MFMA issues -- the loop carries ~1.5 other instructions per MFMA (gemm_kernel: ~6).
+//   * LDS holds TWO 16-deep stages; an iteration = eight k-steps of four MFMAs.  Operand reads run two k-steps ahead
+//     of the MFMAs that consume them (two register sets), and the reads of the first two k-steps of tile t+1 are
+//     issued during the last two k-steps of tile t: the single barrier of an iteration sits between k-steps 5 and 6,
+//     where the wavefront has issued its last read of the current stage and finished writing the next one.
+//   * operands are stored k-major with the two 32-row (32-column) blocks of a wavefront INTERLEAVED
+//     ([k][64 w + 2 lo + i]): one ds_read_b64 with an immediate offset fetches both A (both B) registers of a k-step,
+//     no address arithmetic in the loop.
+//   * B is fetched with vector loads (NN: BN/32 floats along n for both column blocks of a lane -> ds_write_b128 of
+//     the interleaved group; NT: float4 along k), A with float2 along k; global addresses are `uniform base + 32-bit
+//     byte offset` (the host checks the extents), advanced incrementally -- no division, no 64-bit lane arithmetic.
+//   * loads are unconditional (row / column / k clamped); k >= Ktot is selected to zero when the tile is written to
+//     LDS one iteration later, so nothing waits for a load it has just issued.  The side work is cut into pieces
+//     that ride in the shadow of one k-step each (compiler fences between k-steps): LDS writes of tile t+1 in steps
+//     0-1, global loads of tile t+2 in steps 2-3.
+constexpr int DBK = 16;
+constexpr int DPAD = 4;
+
+template <int WAVES_N, bool BKMAJ>
+__global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_kernel(GemmArgs g) {
+  constexpr int WAVES_M = 2, NTHR = 128 * WAVES_N;
+  constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
+  constexpr int AS = BM + DPAD, BS = BN + DPAD;          // LDS row strides (floats); multiples of 4
+  struct Stage { float As[DBK][AS]; float Bs[DBK][BS]; };
+  __shared__ __attribute__((aligned(16))) Stage st[2];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
+  const int Ktot = g.n_seg * g.seg_k;
+  const int KT = (Ktot + DBK - 1) / DBK;
+  PGT_TRACE_MARK(0);
+
+  pgt_f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {                                   // accumulator registers 8h .. 8h+7 = rows 16h .. 16h+15
-        PGT_WAVE_SYNC();
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const int gn = nw0 + j * 32 + lo;
-          const float bv = (g.bias && gn < g.N) ? g.bias[gn] : 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- A: 8 lanes x float2 along k, RPP rows per pass.  Row BYTE offsets are fixed for the whole tile.
+  constexpr int RPP = NTHR / 8, A_PASS = BM / RPP;
+  const int a_k = (tid & 7) * 2, a_m = tid >> 3;          // a_m < RPP
+  uint32_t a_row[A_PASS];                                 // relative to the tile's first row (the base is rebased)
 #pragma unroll
-          for (int r8 = 0; r8 < 8; ++r8)
-            stage[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EPW + j * 32 + lo] = acc[i][j][8 * h + r8] + bv;
-        }
-        PGT_WAVE_SYNC();
-        const int mrow0 = m0 + wm * (BM / 2) + i * 32 + 16 * h;
-        if (ev == 4) {
-          constexpr int LPR = 32 * WN / 4;                            // lanes per row (8 | 16)
-          constexpr int RPP = 64 / LPR;                               // rows per pass
-#pragma unroll
-          for (int rr = 0; rr < 16; rr += RPP) {
-            const int row = rr + lane / LPR, c = (lane % LPR) * 4;
-            const int gm = mrow0 + row, gn = nw0 + c;
-            if (gm < g.M && gn < g.N) {
-              const float4 v = *reinterpret_cast<const float4*>(stage + row * EPW + c);
-              float* p = g.C + (int64_t)gm * g.ldc + gn;
-              if (gn + 3 < g.N) *reinterpret_cast<float4*>(p) = v;
-              else { p[0] = v.x; if (gn + 1 < g.N) p[1] = v.y; if (gn + 2 < g.N) p[2] = v.z; }
-            }
-          }
-        } else {
-          constexpr int LPR = 32 * WN / 2;                            // lanes per row (16 | 32)
-          constexpr int RPP = 64 / LPR;
-#pragma unroll
-          for (int rr = 0; rr < 16; rr += RPP) {
-            const int row = rr + lane / LPR, c = (lane % LPR) * 2;
-            const int gm = mrow0 + row, gn = nw0 + c;
-            if (gm < g.M && gn < g.N) {
-              const float2 v = *reinterpret_cast<const float2*>(stage + row * EPW + c);
-              const int js = gn / g.c_seg_n;
-              float* p = g.C + (int64_t)js * g.c_seg_stride + (int64_t)gm * g.ldc + (gn - js * g.c_seg_n);
-              if (gn + 1 < g.N) *reinterpret_cast<float2*>(p) = v;     // c_seg_n even: a pair never straddles segments
-              else p[0] = v.x;
-            }
-          }
-        }
-      }
-    }
-    PGT_TRACE_MARK(1);
-    return;
+  for (int p = 0; p < A_PASS; ++p) {
+    int gm = m0 + a_m + RPP * p;
+    gm = gm < g.M ? gm : g.M - 1;
+    a_row[p] = ((uint32_t)(gm - m0) * (uint32_t)g.lda) << 2;
   }
+  // interleaved LDS column of tile row m = 64 w + 32 i + l  ->  64 w + 2 l + i ; for pass p: m = a_m + RPP p
+  auto a_col = [&](int p) { return 64 * (p / (64 / RPP)) + 2 * (a_m + RPP * (p % (32 / RPP))) + ((p / (32 / RPP)) & 1); };
+  // ---- B
+  // NN: thread -> k row tid / (BN / 8), group q = tid % (BN / 8): float4 at columns [4 (q % 8), +4) of BOTH 32-column
+  //     blocks of wavefront-column q / 8
+  const int bn_k = tid / (BN / 8), bn_q = tid % (BN / 8);
+  // NT: thread -> column tid % BN, k quad tid / BN (+ 2 per pass, two passes)
+  const int bt_n = tid % BN, bt_kq = tid / BN;
+  uint32_t b_off[2];                                      // NN: byte offsets of the two column blocks; NT: [0] = column
+  if constexpr (BKMAJ) {
+    int gn = n0 + bt_n;
+    gn = gn < g.N ? gn : g.N - 1;
+    b_off[0] = ((uint32_t)gn * (uint32_t)g.sbn) << 2;
+    b_off[1] = 0;
+  } else {
 #pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int gn = n0 + wn * (BN / 2) + j * 32 + lo;
-    if (gn >= g.N) continue;
-    const float bv = g.bias ? g.bias[gn] : 0.f;
-    const int js = gn / g.c_seg_n;
-    float* cbase = g.C + (int64_t)js * g.c_seg_stride + (gn - js * g.c_seg_n);
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (gm < g.M) {
-          float v = acc[i][j][r] + bv;
-          float* p = cbase + (int64_t)gm * g.ldc;
-          if (g.accumulate) v += *p;
-          *p = v;
-        }
-      }
+    for (int j = 0; j < 2; ++j) {
+      int gn = n0 + 64 * (bn_q >> 3) + 32 * j + 4 * (bn_q & 7);
+      gn = gn < g.N ? gn : 0;                             // N % 4 == 0 (host): a vector never straddles N
+      b_off[j] = (uint32_t)gn << 2;
     }
   }
+  const char* const Ab = reinterpret_cast<const char*>(g.A + (int64_t)m0 * g.lda);   // uniform 64-bit rebase per tile
+  const char* const Bb = reinterpret_cast<const char*>(g.Bw);
+  const uint32_t sbk4 = (uint32_t)g.sbk << 2;
+  const uint32_t seg_jump = ((uint32_t)g.a_seg_stride - (uint32_t)g.seg_k) << 2;   // extra bytes when k crosses a segment
+
+  // Position of the tile the NEXT load fetches: first k (uniform), lane-private remainder of A's k inside its segment
+  // (valid because seg_k >= DBK or n_seg == 1) and A's byte offset with the segment jumps folded in.
+  int ld_k0 = 0;
+  int a_rem = a_k;
+  uint32_t a_ko = (uint32_t)a_k << 2;
+  auto advance = [&]() {                 // one tile forward, saturating at the last tile; branch-free
+    const int step = (ld_k0 + DBK < Ktot) ? DBK : 0;
+    ld_k0 += step;
+    a_rem += step;
+    a_ko += (uint32_t)step << 2;
+    const bool wrap = a_rem >= g.seg_k && g.n_seg > 1;
+    a_rem -= wrap ? g.seg_k : 0;
+    a_ko += wrap ? seg_jump : 0u;
+  };
+
+  float2 ra[A_PASS];
+  pgt_f4 rb4[2];
+  auto load_a = [&]() {
+    const uint32_t ko = (ld_k0 + a_k < Ktot) ? a_ko : 0u;
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) ra[p] = *reinterpret_cast<const float2*>(Ab + (ko + a_row[p]));
+  };
+  auto load_b = [&]() {
+    if constexpr (BKMAJ) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        int kg = ld_k0 + 4 * (bt_kq + 2 * p);
+        kg = kg < Ktot ? kg : 0;                          // Ktot % 4 == 0 (host): a quad never straddles Ktot
+        rb4[p] = *reinterpret_cast<const pgt_f4*>(Bb + (((uint32_t)kg << 2) + b_off[0]));
+      }
+    } else {
+      int kg = ld_k0 + bn_k;
+      kg = kg < Ktot ? kg : 0;
+      const uint32_t ko = (uint32_t)kg * sbk4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rb4[j] = *reinterpret_cast<const pgt_f4*>(Bb + (ko + b_off[j]));
+    }
+  };
+  // st_k0: first k of the tile held in ra / rb
+  auto store_a = [&](Stage& s, int st_k0) {
+    const bool av = st_k0 + a_k < Ktot;
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) {
+      const int c = a_col(p);
+      s.As[a_k][c] = av ? ra[p].x : 0.f;
+      s.As[a_k + 1][c] = av ? ra[p].y : 0.f;
+    }
+  };
+  auto store_b = [&](Stage& s, int st_k0) {
+    if constexpr (BKMAJ) {
+      // column n = 64 w + 32 j + l  ->  64 w + 2 l + j
+      const int c = (bt_n & ~63) + 2 * (bt_n & 31) + ((bt_n >> 5) & 1);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int k = 4 * (bt_kq + 2 * p);
+        const bool kv = st_k0 + k < Ktot;
+        s.Bs[k][c] = kv ? rb4[p].x : 0.f;
+        s.Bs[k + 1][c] = kv ? rb4[p].y : 0.f;
+        s.Bs[k + 2][c] = kv ? rb4[p].z : 0.f;
+        s.Bs[k + 3][c] = kv ? rb4[p].w : 0.f;
+      }
+    } else {
+      const bool kv = st_k0 + bn_k < Ktot;
+      float* dst = &s.Bs[bn_k][64 * (bn_q >> 3) + 8 * (bn_q & 7)];
+      const pgt_f4 v0 = pgt_mk4(rb4[0].x, rb4[1].x, rb4[0].y, rb4[1].y);
+      const pgt_f4 v1 = pgt_mk4(rb4[0].z, rb4[1].z, rb4[0].w, rb4[1].w);
+      const pgt_f4 z = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<pgt_f4*>(dst) = kv ? v0 : z;
+      *reinterpret_cast<pgt_f4*>(dst + 4) = kv ? v1 : z;
+    }
+  };
+  auto read_ops = [&](const Stage& s, int kk, float2& a, float2& b) {
+    a = *reinterpret_cast<const float2*>(&s.As[kk + hi][wm * 64 + 2 * lo]);
+    b = *reinterpret_cast<const float2*>(&s.Bs[kk + hi][wn * 64 + 2 * lo]);
+  };
+  auto mma = [&](const float2& a, const float2& b) {
+    acc[0][0] = PGT_MFMA_32x32x2(a.x, b.x, acc[0][0]);
+    acc[0][1] = PGT_MFMA_32x32x2(a.x, b.y, acc[0][1]);
+    acc[1][0] = PGT_MFMA_32x32x2(a.y, b.x, acc[1][0]);
+    acc[1][1] = PGT_MFMA_32x32x2(a.y, b.y, acc[1][1]);
+  };
+
+  // prologue: tile 0 into stage 0, tile 1 in flight, operands of k-steps 0 and 1 in registers
+  float2 a0, b0, a1, b1;
+  load_a();
+  load_b();
+  store_a(st[0], 0);
+  store_b(st[0], 0);
+  advance();
+  int st_k0 = ld_k0;                                     // first k of the tile now being loaded (tile 1, or 0 again)
+  load_a();
+  load_b();
+  __syncthreads();
+  read_ops(st[0], 0, a0, b0);
+  read_ops(st[0], 2, a1, b1);
+  for (int t = 0; t < KT; ++t) {
+    const Stage& cur = st[t & 1];
+    Stage& nxt = st[(t + 1) & 1];
+    PGT_SCHED_FENCE();
+    mma(a0, b0);                                         // k-step 0
+    read_ops(cur, 4, a0, b0);
+    store_a(nxt, st_k0);                                 // tile t+1 (past the end: a harmless re-write of the last tile)
+    PGT_SCHED_FENCE();
+    mma(a1, b1);                                         // 1
+    read_ops(cur, 6, a1, b1);
+    store_b(nxt, st_k0);
+    PGT_SCHED_FENCE();
+    mma(a0, b0);                                         // 2
+    read_ops(cur, 8, a0, b0);
+    advance();
+    st_k0 = ld_k0;
+    load_a();                                            // tile t+2
+    PGT_SCHED_FENCE();
+    mma(a1, b1);                                         // 3
+    read_ops(cur, 10, a1, b1);
+    load_b();
+    PGT_SCHED_FENCE();
+    mma(a0, b0);                                         // 4
+    read_ops(cur, 12, a0, b0);
+    PGT_SCHED_FENCE();
+    mma(a1, b1);                                         // 5
+    read_ops(cur, 14, a1, b1);
+    PGT_SCHED_FENCE();
+    __syncthreads();                                     // tile t+1 complete in nxt; nobody reads cur past this point
+    PGT_SCHED_FENCE();
+    mma(a0, b0);                                         // 6
+    read_ops(nxt, 0, a0, b0);
+    PGT_SCHED_FENCE();
+    mma(a1, b1);                                         // 7
+    read_ops(nxt, 2, a1, b1);
+  }
+  __syncthreads();                                       // the epilogue reuses the stages
+  gemm_store_tile<2, 2, (int)sizeof(st)>(g, acc, reinterpret_cast<float*>(&st[0]), m0 + wm * 64, n0 + wn * 64, wave, lane);
   PGT_TRACE_MARK(1);
 }
 
@@ -460,12 +690,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fullk_kernel(TnArgs g, int KT,
 
 int g_tn_fullk = 1;  // pgt_tune("gemm_tn_fullk"): 0 = always the k-tiled kernel, 2 = whole-K kernel at any size (tests)
 
+int g_db = 1;  // pgt_tune("gemm_db"): 1 = pipelined two-stage kernel where it applies, 2 = also when its tail heuristic says no, 0 = never
+
 int g_force_small_tiles = 0;  // pgt_tune("gemm_small_tiles"): 0 = by size, 1 = always 64x64, 2 = always 128-wide
 
 }  // namespace
 
 void pgt_gemm_set_force_small(int v) { g_force_small_tiles = v; }
 void pgt_gemm_set_tn_fullk(int v) { g_tn_fullk = v; }
+void pgt_gemm_set_db(int v) { g_db = v; }
 
 extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                             const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
@@ -503,6 +736,30 @@ extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, i
     if (d30) PGT_GEMM_GO2(BM_, BN_, 30);                                                              \
     else PGT_GEMM_GO2(BM_, BN_, 32);                                                                  \
   } while (0)
+  // Pipelined kernel: uint32 byte offsets from a per-tile base (segment span and B below 2^30 floats), float2-loadable A, float4-loadable
+  // B (NN: unit column stride, row stride and N multiples of 4; NT: unit k stride, column stride and K multiples of 4).
+  const bool b_nn = (sbn == 1) && (sbk % 4 == 0) && (N % 4 == 0) && pgt_aligned(Bw, 16);
+  const bool b_nt = (sbk == 1) && (sbn % 4 == 0) && (Ktot % 4 == 0) && pgt_aligned(Bw, 16) && sbn != 1;
+  const bool db_ok = g_db && big && av2 && Ktot > 0 && (n_seg == 1 || seg_k >= 16) && (b_nn || b_nt) &&
+                     a_seg_stride >= 0 && lda >= 0 && sbk >= 0 && sbn >= 0 &&
+                     n_seg * a_seg_stride + 128 * lda + seg_k < ((int64_t)1 << 30) &&   // uint32 byte offsets per tile
+                     Ktot * sbk + N * sbn < ((int64_t)1 << 30);
+  // N <= 64 runs 128-thread workgroups, six resident per CU (LDS): when the row tiles exceed one resident set by a
+  // small remainder, the remainder runs alone on a quarter of each CU at the end -- the four-wavefront kernel with its
+  // finer 128 x 64 tiles (two accumulators per wavefront) is faster there (measured: 123 vs 131 us at 1 656 tiles).
+  const int64_t tiles64 = pgt_cdiv(M, 128), resident64 = 6 * 256;
+  const bool tail64 = tiles64 > resident64 && (tiles64 % resident64) * 2 < resident64;
+  if (db_ok && (N > 64 || !tail64 || g_db == 2)) {
+    const int bn = N > 64 ? 128 : 64;
+    const int64_t gx = pgt_cdiv(M, 128), gy = pgt_cdiv(N, bn);
+    PGT_REQUIRE(gy <= 65535, "pgt_gemm_f32: N too large");
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    if (bn == 128 && b_nn) PGT_LAUNCH((gemm_db_kernel<2, false>), grid, dim3(256), stream, g);
+    else if (bn == 128) PGT_LAUNCH((gemm_db_kernel<2, true>), grid, dim3(256), stream, g);
+    else if (b_nn) PGT_LAUNCH((gemm_db_kernel<1, false>), grid, dim3(128), stream, g);
+    else PGT_LAUNCH((gemm_db_kernel<1, true>), grid, dim3(128), stream, g);
+    return pgt_check_launch("pgt_gemm_f32");
+  }
   if (big && N > 64) PGT_GEMM_GO(128, 128);
   else if (big) PGT_GEMM_GO(128, 64);
   else PGT_GEMM_GO(64, 64);

@@ -31,8 +31,11 @@ typedef float pgt_f32x16 __attribute__((ext_vector_type(16)));
 // wavefront's LDS operations in order; the test double runs lanes as fibers and needs a rendezvous.
 #ifdef PGT_EMU
 #define PGT_WAVE_SYNC() pgt_emu::wave_barrier()
+#define PGT_SCHED_FENCE() ((void)0)
 #else
 #define PGT_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// compiler-only fence: no instruction is scheduled across it (pins software-pipelined LDS reads ahead of MFMAs)
+#define PGT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 // lab/ns_lab.hip defines this to record an in-kernel timeline; a no-op in the library
@@ -57,6 +60,7 @@ void pgt_set_error(const char* fmt, ...);
 // tuning knobs (pgt_tune): each translation unit owns its own
 void pgt_gemm_set_force_small(int v);
 void pgt_gemm_set_tn_fullk(int v);
+void pgt_gemm_set_db(int v);
 int pgt_spmm_tune(const char* key, int value);  // returns 1 when the key is known
 
 #define PGT_REQUIRE(cond, ...)            \

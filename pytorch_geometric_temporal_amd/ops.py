@@ -210,14 +210,27 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}   # kind -> list of (start_event, end_event, work) ; work = algorithmic bytes or flops
+        self.tagged = {}
 
-    def launch(self, kind, work, fn):
+    def launch(self, kind, work, fn, tag=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
         self.records.setdefault(kind, []).append((e0, e1, work))
+        if tag is not None:
+            self.tagged.setdefault((kind,) + tuple(tag), []).append((e0, e1, work))
+
+    def by_tag(self):
+        """Per (kind, shape...) mean launch time; the shape tags are the C-ABI size arguments."""
+        torch.cuda.synchronize()
+        out = []
+        for tag, recs in self.tagged.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out.append({"tag": list(tag), "launches": len(recs), "avg_us": 1e3 * sum(ms) / len(ms),
+                        "total_ms": sum(ms), "work_per_launch": recs[0][2]})
+        return sorted(out, key=lambda r: -r["total_ms"])
 
     def summary(self):
         torch.cuda.synchronize()
@@ -232,11 +245,11 @@ class KernelTimer:
 KERNEL_TIMER = None
 
 
-def _timed(kind, work, fn):
+def _timed(kind, work, fn, tag=None):
     if KERNEL_TIMER is None:
         fn()
     else:
-        KERNEL_TIMER.launch(kind, work, fn)
+        KERNEL_TIMER.launch(kind, work, fn, tag)
 
 
 def spmm_algorithmic_bytes(n_rows, nnz, F, with_t):
@@ -286,7 +299,8 @@ def gemm(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, C, ldc, c_seg_stride,
     st = stream_of(lib, C)
     _timed("gemm", 2.0 * M * N * n_seg * seg_k, lambda: lib.call(
         "pgt_gemm_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(Bw), sbk, sbn, ptr(C), ldc, c_seg_stride,
-        c_seg_n, ptr(bias), M, N, int(bool(accumulate)), st))
+        c_seg_n, ptr(bias), M, N, int(bool(accumulate)), st),
+        tag=("NT" if (sbk == 1 and sbn != 1) else "NN", M, N, n_seg, seg_k, c_seg_n, int(bool(accumulate))))
     return C
 
 
@@ -298,7 +312,8 @@ def gemm_tn_acc(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N):
         check_tensor(lib, db, "db")
     st = stream_of(lib, G)
     _timed("gemm_tn", 2.0 * M * N * n_seg * seg_k, lambda: lib.call(
-        "pgt_gemm_tn_acc_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(G), ldg, ptr(dW), lddw, ptr(db), M, N, st))
+        "pgt_gemm_tn_acc_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(G), ldg, ptr(dW), lddw, ptr(db), M, N, st),
+        tag=(M, N, n_seg, seg_k))
     return dW
 
 

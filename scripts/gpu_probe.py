@@ -378,6 +378,37 @@ def probe_step():
             torch.cuda.empty_cache()
 
 
+def probe_shapes():
+    """Per-shape GEMM timing inside real DCRNN training steps (B = 1024, hidden 64): which launches dominate."""
+    from bench import Model, masked_mae_loss, FlatGrads, STD, MEAN
+    from pytorch_geometric_temporal_amd import ops
+    ei, ew = syn.sensor_graph(207, 1515, seed=0)
+    ei, ew = torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev)
+    torch.manual_seed(0)
+    model = Model(64).to(dev)
+    flat = FlatGrads(model.parameters())
+    X = torch.randn(1024, 12, 207, 2, device=dev)
+    y = torch.randn(1024, 12, 207, 2, device=dev)
+
+    def step():
+        out = model(X, ei, ew)
+        loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
+        flat.zero()
+        loss.backward()
+    for _ in range(3):
+        step()
+    ops.KERNEL_TIMER = ops.KernelTimer()
+    step()
+    step()
+    rows = ops.KERNEL_TIMER.by_tag()
+    summ = ops.KERNEL_TIMER.summary()
+    ops.KERNEL_TIMER = None
+    for r in rows:
+        r["TFLOPs"] = r["work_per_launch"] / r["avg_us"] / 1e6 if r["tag"][0].startswith("gemm") else None
+        emit(probe="shapes", **r)
+    emit(probe="shapes_summary", **{k: v for k, v in summ.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["copy", "spmm_ns", "spmm_batched", "gemm", "prep", "step"]
     emit(device=torch.cuda.get_device_name(0), torch=torch.__version__, cpus=os.cpu_count())

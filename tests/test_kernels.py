@@ -338,12 +338,15 @@ def test_spmm_wide_rows_xcd_chunk_mapping(backend, F_):
 
 
 @pytest.mark.parametrize("M,segs,segk,N", [(200, 5, 66, 128), (300, 5, 66, 64), (150, 1, 128, 330), (260, 3, 7, 65),
-                                           (129, 2, 33, 40)])
-def test_gemm_large_tile_variants(backend, M, segs, segk, N):
+                                           (129, 2, 33, 40), (260, 1, 64, 48), (140, 2, 18, 72), (70, 1, 2, 4)])
+@pytest.mark.parametrize("pipelined", [1, 0])
+def test_gemm_large_tile_variants(backend, M, segs, segk, N, pipelined):
     """The 128-wide tiles (used for M >= 2048) forced onto small problems so the CPU test double covers them too:
-    NN with float2 / scalar A loads, NT (k-major B staging), segmented output, and the TN weight-gradient kernel."""
+    NN with float2 / scalar A loads, NT (k-major B staging), segmented output, and the TN weight-gradient kernel;
+    with and without the two-stage pipelined kernel (gemm_db_kernel; it takes the float2-loadable shapes)."""
     lib = _lib.get_lib()
     lib.tune("gemm_small_tiles", 2)
+    lib.tune("gemm_db", pipelined)
     try:
         g = torch.Generator().manual_seed(M * 7 + N)
         A = torch.randn(segs, M, segk, generator=g)
@@ -355,6 +358,8 @@ def test_gemm_large_tile_variants(backend, M, segs, segk, N):
         C = torch.full((M, N), float("nan"), device=backend.device)
         ops.gemm(Ad, segk, M * segk, segs, segk, Wd, N, 1, C, N, 0, N, bd, M, N)
         assert_close_with_nonfinite(C, ref, 1e-4, 1e-5, "big NN")
+        ops.gemm(Ad, segk, M * segk, segs, segk, Wd, N, 1, C, N, 0, N, None, M, N, accumulate=True)
+        assert_close_with_nonfinite(C, 2 * ref - b.double(), 2e-4, 1e-5, "big NN accumulate")
         dC = torch.randn(M, N, generator=g)
         G = torch.full((segs, M, segk), float("nan"), device=backend.device)
         ops.gemm(dC.to(backend.device), N, 0, 1, N, Wd, 1, N, G, segk, M * segk, segk, None, M, segs * segk)
@@ -367,6 +372,7 @@ def test_gemm_large_tile_variants(backend, M, segs, segk, N):
         assert_close_with_nonfinite(db, dC.double().sum(0), 2e-4, 1e-5, "big TN bias")
     finally:
         lib.tune("gemm_small_tiles", 0)
+        lib.tune("gemm_db", 1)
 
 
 def test_spmm_tuning_variants_agree(backend):

@@ -15,7 +15,8 @@ __device__ long long* g_trace_buf = nullptr;
   } while (0)
 
 __device__ int g_lab_dbg = 0;
-#define PGT_LAB_TILE(t) (g_lab_dbg ? 0 : (t))
+#define PGT_LAB_KT(kt) (g_lab_dbg == 1 ? 0 : (kt))
+#define PGT_LAB_SKIP_EPI() (g_lab_dbg == 2)
 int pgt_spmm_tune(const char*, int) { return 0; }
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm.hip"
@@ -90,6 +91,22 @@ int main(int argc, char** argv) {
     pgt_tune("gemm_tn_fullk", 0);
     timeit(nm, [&]() { pgt_gemm_tn_acc_f32(A, C, (int64_t)M * C, S, C, Cout, N, dW, N, bias, M, N, st); }, 2.0 * M * K * N);
     pgt_tune("gemm_tn_fullk", 1);
+  }
+  {  // weight gradient at the size of the training step: all 12 time steps in one launch
+    const int64_t Mb = 12 * (int64_t)M;
+    float *Ab, *Gb;
+    CK(hipMalloc(&Ab, (size_t)S * Mb * C * 4)); CK(hipMalloc(&Gb, (size_t)Mb * 128 * 4));
+    for (int j = 0; j < 12; ++j) {
+      CK(hipMemcpy(Gb + (size_t)j * M * 128, Cout, (size_t)M * 128 * 4, hipMemcpyDeviceToDevice));
+      for (int q = 0; q < S; ++q) CK(hipMemcpy(Ab + ((size_t)q * Mb + (size_t)j * M) * C, A + (size_t)q * M * C, (size_t)M * C * 4, hipMemcpyDeviceToDevice));
+    }
+    for (int N : {128, 64}) for (int pipe : {0, 1}) {
+      pgt_tune("gemm_tn_pipe", pipe);
+      char nm[80]; snprintf(nm, 80, "TN  dW[330,%d] M=12x  pipe=%d", N, pipe);
+      timeit(nm, [&]() { pgt_gemm_tn_acc_f32(Ab, C, Mb * C, S, C, Gb, N, dW, N, bias, Mb, N, st); }, 2.0 * Mb * K * N);
+    }
+    pgt_tune("gemm_tn_pipe", 1);
+    CK(hipFree(Ab)); CK(hipFree(Gb));
   }
   // timeline of one NN launch (N = 128)
   long long* tr; const size_t TRN = 8192 * 4;

@@ -259,6 +259,10 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
 //     0-1, global loads of tile t+2 in steps 2-3.
 constexpr int DBK = 16;
 constexpr int DPAD = 4;
+#ifndef PGT_LAB_KT
+#define PGT_LAB_KT(kt) (kt)          // lab harness hooks (lab/gemm_lab.hip): truncate the k loop / skip the epilogue
+#define PGT_LAB_SKIP_EPI() false
+#endif
 
 template <int WAVES_N, bool BKMAJ>
 __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_kernel(GemmArgs g) {
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
   const int lo = lane & 31, hi = lane >> 5;
   const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
   const int Ktot = g.n_seg * g.seg_k;
-  const int KT = (Ktot + DBK - 1) / DBK;
+  const int KT = PGT_LAB_KT((Ktot + DBK - 1) / DBK);
   PGT_TRACE_MARK(0);
 
   pgt_f32x16 acc[2][2];
@@ -454,6 +458,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
     read_ops(nxt, 2, a1, b1);
   }
   __syncthreads();                                       // the epilogue reuses the stages
+  if (PGT_LAB_SKIP_EPI()) { if (acc[0][0][0] == 1.2345f) g.C[0] = 1.f; return; }
   gemm_store_tile<2, 2, (int)sizeof(st)>(g, acc, reinterpret_cast<float*>(&st[0]), m0 + wm * 64, n0 + wn * 64, wave, lane);
   PGT_TRACE_MARK(1);
 }
@@ -688,6 +693,215 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fullk_kernel(TnArgs g, int KT,
   if (do_bias && (n0 + tid) < g.N) atomicAdd(g.db + n0 + tid, bsum);
 }
 
+// Whole-K weight gradient, pipelined like gemm_db_kernel: dW[0:Ktot, n0:n0+BN] += A[slab, :]^T G[slab, n0:n0+BN] with
+// every operand element read from HBM once.  512 threads = 8 wavefronts (wk = wave & 3, wn = wave >> 2); wavefront
+// (wk, wn) owns k-tiles {wk, wk + 4, wk + 8}[0:NI] x NH column tiles of 32: NI * NH accumulators.  16 rows per step in
+// two LDS stages (40 KiB each); per 2-row MFMA step a wavefront issues NI * NH MFMAs and TWO LDS reads:
+//   A stage row: [wk][lo][i] (i padded to 4) -> one ds_read_b128 fetches the A registers of all NI k-tiles,
+//   G stage row: [wn][lo][j]                 -> one ds_read_b64 / b32 fetches the NH column registers.
+// Reads run two MFMA steps ahead (two register sets); LDS writes of rows s+1 and global loads of rows s+2 ride in the
+// shadow of the MFMAs (compiler fences between MFMA steps); one barrier per step, placed before the last two MFMA steps.
+// Global loads are float2 along k (A, column offsets with the segment arithmetic precomputed once per thread) and
+// float4 (G), unconditional with clamped rows / columns, masked to zero when written to LDS.
+constexpr int TNP_ROWS = 16;
+
+template <int NH, int NI>
+__global__ __launch_bounds__(512, (16 * NH * NI + 48 <= 128) ? 4 : 2) void gemm_tn_pipe_kernel(TnArgs g) {
+  constexpr int BN = 64 * NH;
+  constexpr int NP = 2 * NI;                 // 64-column pieces of A per row (columns [0, 128 NI))
+  constexpr int ARS = 4 * 32 * 4;            // floats per A stage row
+  struct Stage { float As[TNP_ROWS][ARS]; float Gs[TNP_ROWS][BN]; };
+  __shared__ __attribute__((aligned(16))) Stage st[2];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wk = wave & 3, wn = wave >> 2;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int n0 = (int)blockIdx.y * BN;
+  const int Ktot = g.n_seg * g.seg_k;
+  const int ms = (int)blockIdx.x * g.rows_per_slab;
+  const int me = (ms + g.rows_per_slab < g.M) ? ms + g.rows_per_slab : g.M;
+  if (ms >= me) return;
+  const int steps = (me - ms + TNP_ROWS - 1) / TNP_ROWS;
+
+  pgt_f32x16 acc[NI][NH];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- A loader: thread (row ar, lane cg) owns columns 64 p + 2 cg (+1), p < NP
+  const int ar = tid >> 5, cg = tid & 31;
+  uint32_t a_coff[NP];                      // byte offset of the column inside A (segments folded in); 0 when masked
+  bool a_cv[NP];
+  int a_pos[NP];                            // LDS position of the first of the two columns (the second is +4)
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = 64 * p + 2 * cg;
+    a_cv[p] = c < Ktot;                     // Ktot even (host): the pair is valid or not as a whole
+    const int cc = a_cv[p] ? c : 0;
+    const int j = cc / g.seg_k;
+    a_coff[p] = ((uint32_t)j * (uint32_t)g.a_seg_stride + (uint32_t)(cc - j * g.seg_k)) << 2;
+    const int kt = c >> 5;
+    a_pos[p] = (kt & 3) * 128 + (c & 31) * 4 + (kt >> 2);
+  }
+  // ---- G loader: thread -> row gr, float4 column group gq
+  constexpr int G4 = BN / 4;
+  const int gr = tid / G4, gq = tid % G4;
+  const bool g_thread = tid < TNP_ROWS * G4;
+  const int g_n = n0 + 4 * gq;
+  const bool g_cv = g_thread && g_n < g.N;  // N % 4 == 0 (host)
+  const uint32_t g_coff = (uint32_t)(g_cv ? g_n : 0) << 2;
+  int g_pos;                                // LDS position of the first column; the next three are +NH apart
+  {
+    const int n = 4 * gq, tt = n >> 5;
+    g_pos = (tt / NH) * (32 * NH) + (n & 31) * NH + (tt % NH);
+  }
+  const char* const Ab = reinterpret_cast<const char*>(g.A + (int64_t)ms * g.lda);
+  const char* const Gb = reinterpret_cast<const char*>(g.G + (int64_t)ms * g.ldg);
+  const uint32_t lda4 = (uint32_t)g.lda << 2, ldg4 = (uint32_t)g.ldg << 2;
+
+  int ld_m = ms;                            // first row of the tile the next load fetches
+  float2 ra[NP];
+  pgt_f4 rg;
+  pgt_f4 bsum = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+  auto load_a = [&]() {
+    int r = ld_m + ar;
+    r = r < me ? r : me - 1;
+    const uint32_t ro = (uint32_t)(r - ms) * lda4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) ra[p] = *reinterpret_cast<const float2*>(Ab + (ro + a_coff[p]));
+  };
+  auto load_g = [&]() {
+    int r = ld_m + gr;
+    r = r < me ? r : me - 1;
+    rg = *reinterpret_cast<const pgt_f4*>(Gb + ((uint32_t)(r - ms) * ldg4 + g_coff));
+  };
+  // st_m: first row of the tile held in ra / rg
+  auto store_a = [&](Stage& s, int st_m, int p0, int p1) {
+    const bool rv = st_m + ar < me;
+#pragma unroll
+    for (int p = p0; p < p1; ++p) {
+      const bool v = rv && a_cv[p];
+      s.As[ar][a_pos[p]] = v ? ra[p].x : 0.f;
+      s.As[ar][a_pos[p] + 4] = v ? ra[p].y : 0.f;
+    }
+  };
+  auto store_g = [&](Stage& s, int st_m) {
+    const bool v = g_cv && (st_m + gr < me);
+    const pgt_f4 z = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+    const pgt_f4 t = v ? rg : z;
+    bsum.x += t.x; bsum.y += t.y; bsum.z += t.z; bsum.w += t.w;
+    if (g_thread) {
+      float* d = &s.Gs[gr][g_pos];
+      if constexpr (NH == 1) {
+        *reinterpret_cast<pgt_f4*>(d) = t;
+      } else {
+        d[0] = t.x; d[NH] = t.y; d[2 * NH] = t.z; d[3 * NH] = t.w;
+      }
+    }
+  };
+  struct Ops { pgt_f4 a; float2 b; };
+  auto read_ops = [&](const Stage& s, int mm, Ops& o) {
+    o.a = *reinterpret_cast<const pgt_f4*>(&s.As[mm + hi][wk * 128 + lo * 4]);
+    if constexpr (NH == 2) o.b = *reinterpret_cast<const float2*>(&s.Gs[mm + hi][wn * 64 + lo * 2]);
+    else o.b.x = s.Gs[mm + hi][wn * 32 + lo];
+  };
+  auto mma = [&](const Ops& o) {
+    const float av[3] = {o.a.x, o.a.y, o.a.z};
+    const float bv[2] = {o.b.x, o.b.y};
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NH; ++j) acc[i][j] = PGT_MFMA_32x32x2(av[i], bv[j], acc[i][j]);
+  };
+  auto advance = [&]() { ld_m += (ld_m + TNP_ROWS < me) ? TNP_ROWS : 0; };
+
+  // prologue: rows of step 0 into stage 0, step 1 in flight, operands of MFMA steps 0 and 1 in registers
+  Ops o0, o1;
+  load_a();
+  load_g();
+  store_a(st[0], ms, 0, NP);
+  store_g(st[0], ms);
+  advance();
+  int st_m = ld_m;
+  load_a();
+  load_g();
+  __syncthreads();
+  read_ops(st[0], 0, o0);
+  read_ops(st[0], 2, o1);
+  for (int t = 0; t < steps; ++t) {
+    const Stage& cur = st[t & 1];
+    Stage& nxt = st[(t + 1) & 1];
+    // past the last step st_m stays on the last tile: its rows are written again, and (bias) must not be counted twice
+    const bool fresh = t + 1 < steps;
+    PGT_SCHED_FENCE();
+    mma(o0);                                             // rows 0-1
+    read_ops(cur, 4, o0);
+    store_a(nxt, st_m, 0, NP / 2);
+    PGT_SCHED_FENCE();
+    mma(o1);                                             // 2-3
+    read_ops(cur, 6, o1);
+    store_a(nxt, st_m, NP / 2, NP);
+    PGT_SCHED_FENCE();
+    mma(o0);                                             // 4-5
+    read_ops(cur, 8, o0);
+    store_g(nxt, fresh ? st_m : me);                     // (row >= me masks the whole tile: zeros, nothing summed)
+    PGT_SCHED_FENCE();
+    mma(o1);                                             // 6-7
+    read_ops(cur, 10, o1);
+    advance();
+    st_m = ld_m;
+    load_a();                                            // rows of step t+2
+    PGT_SCHED_FENCE();
+    mma(o0);                                             // 8-9
+    read_ops(cur, 12, o0);
+    load_g();
+    PGT_SCHED_FENCE();
+    mma(o1);                                             // 10-11
+    read_ops(cur, 14, o1);
+    PGT_SCHED_FENCE();
+    __syncthreads();                                     // step t+1 complete in nxt; nobody reads cur past this point
+    PGT_SCHED_FENCE();
+    mma(o0);                                             // 12-13
+    read_ops(nxt, 0, o0);
+    PGT_SCHED_FENCE();
+    mma(o1);                                             // 14-15
+    read_ops(nxt, 2, o1);
+  }
+
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int kt = wk + 4 * i;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int gn = n0 + (wn * NH + j) * 32 + lo;
+      if (gn >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (gk < Ktot) atomicAdd(g.dW + (int64_t)gk * g.lddw + gn, acc[i][j][r]);
+      }
+    }
+  }
+  if (g.db != nullptr) {                                 // column sums of G: 16 row-threads per column group
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&st[0]);
+    if (g_thread) *reinterpret_cast<pgt_f4*>(&red[gr * BN + 4 * gq]) = bsum;
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < TNP_ROWS; ++r) t += red[r * BN + tid];
+      atomicAdd(g.db + n0 + tid, t);
+    }
+  }
+}
+
+int g_tn_pipe = 1;   // pgt_tune("gemm_tn_pipe"): 1 = pipelined whole-K kernel where it applies, 2 = at any M (tests), 0 = never
+
 int g_tn_fullk = 1;  // pgt_tune("gemm_tn_fullk"): 0 = always the k-tiled kernel, 2 = whole-K kernel at any size (tests)
 
 int g_db = 1;  // pgt_tune("gemm_db"): 1 = pipelined two-stage kernel where it applies, 2 = also when its tail heuristic says no, 0 = never
@@ -699,6 +913,7 @@ int g_force_small_tiles = 0;  // pgt_tune("gemm_small_tiles"): 0 = by size, 1 = 
 void pgt_gemm_set_force_small(int v) { g_force_small_tiles = v; }
 void pgt_gemm_set_tn_fullk(int v) { g_tn_fullk = v; }
 void pgt_gemm_set_db(int v) { g_db = v; }
+void pgt_gemm_set_tn_pipe(int v) { g_tn_pipe = v; }
 
 extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                             const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
@@ -781,6 +996,33 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
   // whole-K schedule: tall slabs, K up to 384; every operand element is read once per 128-wide column block
   // (measured at K = 330 inside the DCRNN training step, M = 2.5 M rows: 4.27 ms per step with this schedule for both
   //  N = 128 and N = 64, 4.68 ms when N = 64 falls back to the k-tiled kernel, 4.85 ms k-tiled only)
+  // pipelined whole-K schedule (gemm_tn_pipe_kernel): float2-loadable A, float4-loadable G, K <= 384
+  {
+    const bool a_ok = (seg_k % 2 == 0) && (lda % 2 == 0) && (a_seg_stride % 2 == 0) && pgt_aligned(A, 8) && lda >= 0 &&
+                      a_seg_stride >= 0;
+    const bool g_ok = (ldg % 4 == 0) && (N % 4 == 0) && pgt_aligned(G, 16) && ldg >= 0;
+    if (g_tn_pipe && (M >= 16384 || g_tn_pipe == 2) && Ktot > 0 && Ktot <= 384 && a_ok && g_ok &&
+        g_force_small_tiles != 1) {
+      const int NI = Ktot <= 128 ? 1 : Ktot <= 256 ? 2 : 3;
+      const int BNp = N > 64 ? 128 : 64;
+      const int64_t gy = pgt_cdiv(N, BNp);
+      PGT_REQUIRE(gy <= 65535, "pgt_gemm_tn_acc_f32: N too large");
+      // one (two for the small accumulator sets) resident workgroup per CU
+      int64_t nslab = pgt_cdiv((BNp / 64) * NI <= 3 ? 512 : 256, gy);   // <= 128 VGPRs and 74 KiB LDS: two per CU
+      int64_t rows = pgt_cdiv(pgt_cdiv(M, nslab), TNP_ROWS) * TNP_ROWS;
+      nslab = pgt_cdiv(M, rows);
+      if (n_seg * a_seg_stride + rows * lda < ((int64_t)1 << 30) && rows * ldg + N < ((int64_t)1 << 30)) {
+        TnArgs t{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), G, ldg, dW, lddw, db, (int)M, (int)N,
+                 (int)rows};
+        dim3 grid((unsigned)nslab, (unsigned)gy), block(512);
+#define PGT_TNP_GO(NH_, NI_) PGT_LAUNCH((gemm_tn_pipe_kernel<NH_, NI_>), grid, block, stream, t)
+        if (BNp == 128) { if (NI == 1) PGT_TNP_GO(2, 1); else if (NI == 2) PGT_TNP_GO(2, 2); else PGT_TNP_GO(2, 3); }
+        else { if (NI == 1) PGT_TNP_GO(1, 1); else if (NI == 2) PGT_TNP_GO(1, 2); else PGT_TNP_GO(1, 3); }
+#undef PGT_TNP_GO
+        return pgt_check_launch("pgt_gemm_tn_acc_f32");
+      }
+    }
+  }
   if (g_tn_fullk && (M >= 16384 || g_tn_fullk == 2) && Ktot > (g_tn_fullk == 2 ? 0 : 64) && Ktot <= TNF_MAXKT * 32 &&
       g_force_small_tiles != 1 &&
       n_seg * a_seg_stride + lda < ((int64_t)1 << 31)) {

@@ -32,6 +32,10 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_gemm_set_tn_fullk(value);
     return PGT_OK;
   }
+  if (strcmp(key, "gemm_tn_pipe") == 0) {
+    pgt_gemm_set_tn_pipe(value);
+    return PGT_OK;
+  }
   if (strcmp(key, "gemm_db") == 0) {
     pgt_gemm_set_db(value);
     return PGT_OK;

@@ -550,6 +550,7 @@ def test_gemm_tn_whole_k_schedule(backend, M, segs, segk, N):
     if backend.name == "hip":
         M = M * 97
     lib.tune("gemm_tn_fullk", 2)
+    lib.tune("gemm_tn_pipe", 0)
     try:
         g = torch.Generator().manual_seed(M + N)
         A = torch.randn(segs, M, segk, generator=g)
@@ -569,6 +570,37 @@ def test_gemm_tn_whole_k_schedule(backend, M, segs, segk, N):
         assert_close_with_nonfinite(dW2, refW, tol, 1e-5, "dW k-tiled")
     finally:
         lib.tune("gemm_tn_fullk", 1)
+        lib.tune("gemm_tn_pipe", 1)
+
+
+@pytest.mark.parametrize("M,segs,segk,N", [(300, 5, 66, 128), (257, 5, 66, 64), (131, 2, 66, 100), (90, 1, 384, 20),
+                                           (64, 2, 20, 192), (45, 1, 128, 128), (17, 1, 200, 64), (33, 4, 64, 4)])
+def test_gemm_tn_pipelined_whole_k_schedule(backend, M, segs, segk, N):
+    """gemm_tn_pipe_kernel (the weight-gradient kernel of the training step: whole K per workgroup, two LDS stages,
+    1-3 k-tiles x 1-2 column tiles per wavefront) forced onto small problems so the CPU test double covers every
+    instantiation, ragged last steps, masked k / n edges and the bias column sums; natural size on the GPU leg."""
+    lib = _lib.get_lib()
+    if backend.name == "hip":
+        M = M * 97
+    lib.tune("gemm_tn_pipe", 2)
+    try:
+        g = torch.Generator().manual_seed(M + N)
+        A = torch.randn(segs, M, segk, generator=g)
+        G = torch.randn(M, N, generator=g)
+        dW0 = torch.randn(segs * segk, N, generator=g)
+        db0 = torch.randn(N, generator=g)
+        refW = dW0.double() + torch.cat([A[j] for j in range(segs)], dim=1).double().t() @ G.double()
+        refb = db0.double() + G.double().sum(0)
+        dW, db = dW0.clone().to(backend.device), db0.clone().to(backend.device)
+        ops.gemm_tn_acc(A.to(backend.device), segk, M * segk, segs, segk, G.to(backend.device), N, dW, N, db, M, N)
+        tol = 2e-4 if backend.name == "emu" else 2e-3        # sums of up to ~29 000 products on the GPU leg
+        assert_close_with_nonfinite(dW, refW, tol, 1e-5, "dW")
+        assert_close_with_nonfinite(db, refb, tol, 1e-5, "db")
+        dW3 = dW0.clone().to(backend.device)
+        ops.gemm_tn_acc(A.to(backend.device), segk, M * segk, segs, segk, G.to(backend.device), N, dW3, N, None, M, N)
+        assert_close_with_nonfinite(dW3, refW, tol, 1e-5, "dW without bias")
+    finally:
+        lib.tune("gemm_tn_pipe", 1)
 
 
 def test_spmm_quad_persistent_schedule_matches_tile_schedule(backend):

@@ -168,8 +168,8 @@ def main():
     series = torch.from_numpy(syn.traffic_series(34272, N_NODES, seed=1)).to(device)   # resident [T, N, 2]
     torch.manual_seed(0)
     model = Model(args.hidden).to(device)
-    flat = FlatGrads(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    flat = dp.FlatParameters(model.parameters())   # one gradient buffer, one parameter buffer
+    opt = flat.optimizer(torch.optim.Adam, lr=1e-3)  # Adam over the flat parameter: one (fused) update per step
     n_total = args.warmup + args.steps + args.profile_steps
     batches = make_batches(series, args.batch, n_total, seed=1000 + rank, device=device)
 

@@ -68,3 +68,30 @@ def test_flat_gradients_are_views_of_one_buffer():
     flat.zero()
     assert float(m.bias.grad.abs().sum()) == 0.0
     assert flat.all_reduce_mean(1) is None       # world 1: no collective
+
+
+def test_flat_parameters_adam_equals_per_parameter_adam():
+    """One Adam update over the flat parameter buffer == torch.optim.Adam over the individual parameters, and the
+    module keeps working (views), including load_state_dict."""
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 2))
+    b = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 2))
+    b.load_state_dict(a.state_dict())
+    opt_a = torch.optim.Adam(a.parameters(), lr=1e-2)
+    flat = dp.FlatParameters(b.parameters())
+    opt_b = flat.optimizer(torch.optim.Adam, lr=1e-2)
+    assert flat.data.numel() == sum(p.numel() for p in a.parameters())
+    assert b[0].weight.data_ptr() == flat.data.data_ptr()
+    x, y = torch.randn(16, 5), torch.randn(16, 2)
+    for _ in range(5):
+        opt_a.zero_grad()
+        (a(x) - y).pow(2).mean().backward()
+        opt_a.step()
+        flat.zero()
+        (b(x) - y).pow(2).mean().backward()
+        opt_b.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(pa, pb, rtol=1e-6, atol=1e-7)
+    b.load_state_dict(a.state_dict())                      # copies into the views
+    assert b[2].bias.data_ptr() == flat.data[-2:].data_ptr()
+    torch.testing.assert_close(flat.data[-2:], a[2].bias.detach())

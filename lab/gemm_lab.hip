@@ -68,13 +68,15 @@ int main(int argc, char** argv) {
     timeit(nm, fn, 256.0 * wps * 4 * iters * 4 * 4096.0);
   }
   const int only = argc > 2 ? atoi(argv[2]) : -1;
+  pgt_tune("gemm_db64", argc > 4 ? atoi(argv[4]) : 1);
+  if (argc > 5) pgt_tune("gemm_db", atoi(argv[5]));
   const int dbg = argc > 3 ? atoi(argv[3]) : 0;
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lab_dbg), &dbg, sizeof(int)));
   for (int N : {128, 64}) {
     char nm[80];
     for (int db : {0, 1}) {
       if (only >= 0 && db != only) continue;
-      pgt_tune("gemm_db", db);
+      pgt_tune("gemm_db", db ? (argc > 5 ? atoi(argv[5]) : 1) : 0);
       snprintf(nm, 80, "NN  [M,330]x[330,%d] seg A  db=%d", N, db);
       timeit(nm, [&]() { pgt_gemm_f32(A, C, (int64_t)M * C, S, C, W, N, 1, Cout, N, 0, N, bias, M, N, 0, st); }, 2.0 * M * K * N);
       snprintf(nm, 80, "NT  [M,%d]x[%d,330] -> seg C  db=%d", N, N, db);

@@ -20,6 +20,7 @@ __device__ long long* g_trace_buf = nullptr;
 void pgt_gemm_set_force_small(int) {}
 void pgt_gemm_set_tn_fullk(int) {}
 void pgt_gemm_set_db(int) {}
+void pgt_gemm_set_db64(int) {}
 void pgt_gemm_set_tn_pipe(int) {}
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/spmm.hip"

@@ -264,10 +264,11 @@ constexpr int DPAD = 4;
 #define PGT_LAB_SKIP_EPI() false
 #endif
 
-template <int WAVES_N, bool BKMAJ>
-__global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_kernel(GemmArgs g) {
+// WNB: 32-column blocks per wavefront (2: 64 x 64 sub-tile; 1: 64 x 32, four wavefronts on a 128 x 64 tile)
+template <int WAVES_N, int WNB, bool BKMAJ>
+__global__ __launch_bounds__(128 * WAVES_N, WNB == 1 ? 5 : WAVES_N == 2 ? 4 : 3) void gemm_db_kernel(GemmArgs g) {
   constexpr int WAVES_M = 2, NTHR = 128 * WAVES_N;
-  constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
+  constexpr int BM = 64 * WAVES_M, BN = 32 * WNB * WAVES_N;
   constexpr int AS = BM + DPAD, BS = BN + DPAD;          // LDS row strides (floats); multiples of 4
   struct Stage { float As[DBK][AS]; float Bs[DBK][BS]; };
   __shared__ __attribute__((aligned(16))) Stage st[2];
@@ -281,11 +282,11 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
   const int KT = PGT_LAB_KT((Ktot + DBK - 1) / DBK);
   PGT_TRACE_MARK(0);
 
-  pgt_f32x16 acc[2][2];
+  pgt_f32x16 acc[2][WNB];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WNB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -302,12 +303,14 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
   // interleaved LDS column of tile row m = 64 w + 32 i + l  ->  64 w + 2 l + i ; for pass p: m = a_m + RPP p
   auto a_col = [&](int p) { return 64 * (p / (64 / RPP)) + 2 * (a_m + RPP * (p % (32 / RPP))) + ((p / (32 / RPP)) & 1); };
   // ---- B
-  // NN: thread -> k row tid / (BN / 8), group q = tid % (BN / 8): float4 at columns [4 (q % 8), +4) of BOTH 32-column
-  //     blocks of wavefront-column q / 8
-  const int bn_k = tid / (BN / 8), bn_q = tid % (BN / 8);
-  // NT: thread -> column tid % BN, k quad tid / BN (+ 2 per pass, two passes)
+  // NN, WNB = 2: thread -> k row tid / (BN / 8), group q = tid % (BN / 8): float4 at columns [4 (q % 8), +4) of BOTH
+  //     32-column blocks of wavefront-column q / 8.   WNB = 1: k row tid / (BN / 4), one float4 at column 4 q.
+  constexpr int BQ = WNB == 2 ? BN / 8 : BN / 4;
+  const int bn_k = tid / BQ, bn_q = tid % BQ;
+  // NT: thread -> column tid % BN, k quad tid / BN (+ NTHR / BN per pass, NTP passes)
+  constexpr int NTP = 4 * BN / NTHR;
   const int bt_n = tid % BN, bt_kq = tid / BN;
-  uint32_t b_off[2];                                      // NN: byte offsets of the two column blocks; NT: [0] = column
+  uint32_t b_off[2];                                      // NN: byte offsets of the column block(s); NT: [0] = column
   if constexpr (BKMAJ) {
     int gn = n0 + bt_n;
     gn = gn < g.N ? gn : g.N - 1;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
   } else {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int gn = n0 + 64 * (bn_q >> 3) + 32 * j + 4 * (bn_q & 7);
+      int gn = WNB == 2 ? n0 + 64 * (bn_q >> 3) + 32 * j + 4 * (bn_q & 7) : n0 + 4 * bn_q;
       gn = gn < g.N ? gn : 0;                             // N % 4 == 0 (host): a vector never straddles N
       b_off[j] = (uint32_t)gn << 2;
     }
@@ -351,8 +354,8 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
   auto load_b = [&]() {
     if constexpr (BKMAJ) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        int kg = ld_k0 + 4 * (bt_kq + 2 * p);
+      for (int p = 0; p < NTP; ++p) {
+        int kg = ld_k0 + 4 * (bt_kq + (NTHR / BN) * p);
         kg = kg < Ktot ? kg : 0;                          // Ktot % 4 == 0 (host): a quad never straddles Ktot
         rb4[p] = *reinterpret_cast<const pgt_f4*>(Bb + (((uint32_t)kg << 2) + b_off[0]));
       }
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
       kg = kg < Ktot ? kg : 0;
       const uint32_t ko = (uint32_t)kg * sbk4;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) rb4[j] = *reinterpret_cast<const pgt_f4*>(Bb + (ko + b_off[j]));
+      for (int j = 0; j < WNB; ++j) rb4[j] = *reinterpret_cast<const pgt_f4*>(Bb + (ko + b_off[j]));
     }
   };
   // st_k0: first k of the tile held in ra / rb
@@ -376,11 +379,11 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
   };
   auto store_b = [&](Stage& s, int st_k0) {
     if constexpr (BKMAJ) {
-      // column n = 64 w + 32 j + l  ->  64 w + 2 l + j
-      const int c = (bt_n & ~63) + 2 * (bt_n & 31) + ((bt_n >> 5) & 1);
+      // WNB = 2: column n = 64 w + 32 j + l  ->  64 w + 2 l + j ; WNB = 1: plain
+      const int c = WNB == 2 ? (bt_n & ~63) + 2 * (bt_n & 31) + ((bt_n >> 5) & 1) : bt_n;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int k = 4 * (bt_kq + 2 * p);
+      for (int p = 0; p < NTP; ++p) {
+        const int k = 4 * (bt_kq + (NTHR / BN) * p);
         const bool kv = st_k0 + k < Ktot;
         s.Bs[k][c] = kv ? rb4[p].x : 0.f;
         s.Bs[k + 1][c] = kv ? rb4[p].y : 0.f;
@@ -389,23 +392,28 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
       }
     } else {
       const bool kv = st_k0 + bn_k < Ktot;
-      float* dst = &s.Bs[bn_k][64 * (bn_q >> 3) + 8 * (bn_q & 7)];
-      const pgt_f4 v0 = pgt_mk4(rb4[0].x, rb4[1].x, rb4[0].y, rb4[1].y);
-      const pgt_f4 v1 = pgt_mk4(rb4[0].z, rb4[1].z, rb4[0].w, rb4[1].w);
       const pgt_f4 z = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<pgt_f4*>(dst) = kv ? v0 : z;
-      *reinterpret_cast<pgt_f4*>(dst + 4) = kv ? v1 : z;
+      if constexpr (WNB == 2) {
+        float* dst = &s.Bs[bn_k][64 * (bn_q >> 3) + 8 * (bn_q & 7)];
+        const pgt_f4 v0 = pgt_mk4(rb4[0].x, rb4[1].x, rb4[0].y, rb4[1].y);
+        const pgt_f4 v1 = pgt_mk4(rb4[0].z, rb4[1].z, rb4[0].w, rb4[1].w);
+        *reinterpret_cast<pgt_f4*>(dst) = kv ? v0 : z;
+        *reinterpret_cast<pgt_f4*>(dst + 4) = kv ? v1 : z;
+      } else {
+        *reinterpret_cast<pgt_f4*>(&s.Bs[bn_k][4 * bn_q]) = kv ? rb4[0] : z;
+      }
     }
   };
   auto read_ops = [&](const Stage& s, int kk, float2& a, float2& b) {
     a = *reinterpret_cast<const float2*>(&s.As[kk + hi][wm * 64 + 2 * lo]);
-    b = *reinterpret_cast<const float2*>(&s.Bs[kk + hi][wn * 64 + 2 * lo]);
+    if constexpr (WNB == 2) b = *reinterpret_cast<const float2*>(&s.Bs[kk + hi][wn * 64 + 2 * lo]);
+    else b.x = s.Bs[kk + hi][wn * 32 + lo];
   };
   auto mma = [&](const float2& a, const float2& b) {
     acc[0][0] = PGT_MFMA_32x32x2(a.x, b.x, acc[0][0]);
-    acc[0][1] = PGT_MFMA_32x32x2(a.x, b.y, acc[0][1]);
+    if constexpr (WNB == 2) acc[0][1] = PGT_MFMA_32x32x2(a.x, b.y, acc[0][1]);
     acc[1][0] = PGT_MFMA_32x32x2(a.y, b.x, acc[1][0]);
-    acc[1][1] = PGT_MFMA_32x32x2(a.y, b.y, acc[1][1]);
+    if constexpr (WNB == 2) acc[1][1] = PGT_MFMA_32x32x2(a.y, b.y, acc[1][1]);
   };
 
   // prologue: tile 0 into stage 0, tile 1 in flight, operands of k-steps 0 and 1 in registers
@@ -459,7 +467,8 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N == 2 ? 4 : 3) void gemm_db_k
   }
   __syncthreads();                                       // the epilogue reuses the stages
   if (PGT_LAB_SKIP_EPI()) { if (acc[0][0][0] == 1.2345f) g.C[0] = 1.f; return; }
-  gemm_store_tile<2, 2, (int)sizeof(st)>(g, acc, reinterpret_cast<float*>(&st[0]), m0 + wm * 64, n0 + wn * 64, wave, lane);
+  gemm_store_tile<2, WNB, (int)sizeof(st)>(g, acc, reinterpret_cast<float*>(&st[0]), m0 + wm * 64, n0 + wn * 32 * WNB, wave,
+                                           lane);
   PGT_TRACE_MARK(1);
 }
 
@@ -906,6 +915,8 @@ int g_tn_fullk = 1;  // pgt_tune("gemm_tn_fullk"): 0 = always the k-tiled kernel
 
 int g_db = 1;  // pgt_tune("gemm_db"): 1 = pipelined two-stage kernel where it applies, 2 = also when its tail heuristic says no, 0 = never
 
+int g_db64 = 1;  // pgt_tune("gemm_db64"): N <= 64 tile of the pipelined kernel: 1 = four wavefronts of 64 x 32, 0 = two of 64 x 64
+
 int g_force_small_tiles = 0;  // pgt_tune("gemm_small_tiles"): 0 = by size, 1 = always 64x64, 2 = always 128-wide
 
 }  // namespace
@@ -913,6 +924,7 @@ int g_force_small_tiles = 0;  // pgt_tune("gemm_small_tiles"): 0 = by size, 1 = 
 void pgt_gemm_set_force_small(int v) { g_force_small_tiles = v; }
 void pgt_gemm_set_tn_fullk(int v) { g_tn_fullk = v; }
 void pgt_gemm_set_db(int v) { g_db = v; }
+void pgt_gemm_set_db64(int v) { g_db64 = v; }
 void pgt_gemm_set_tn_pipe(int v) { g_tn_pipe = v; }
 
 extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
@@ -964,15 +976,17 @@ extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, i
   // finer 128 x 64 tiles (two accumulators per wavefront) is faster there (measured: 123 vs 131 us at 1 656 tiles).
   const int64_t tiles64 = pgt_cdiv(M, 128), resident64 = 6 * 256;
   const bool tail64 = tiles64 > resident64 && (tiles64 % resident64) * 2 < resident64;
-  if (db_ok && (N > 64 || !tail64 || g_db == 2)) {
+  if (db_ok && (N > 64 || !tail64 || g_db == 2 || g_db64 == 1)) {
     const int bn = N > 64 ? 128 : 64;
     const int64_t gx = pgt_cdiv(M, 128), gy = pgt_cdiv(N, bn);
     PGT_REQUIRE(gy <= 65535, "pgt_gemm_f32: N too large");
     dim3 grid((unsigned)gx, (unsigned)gy);
-    if (bn == 128 && b_nn) PGT_LAUNCH((gemm_db_kernel<2, false>), grid, dim3(256), stream, g);
-    else if (bn == 128) PGT_LAUNCH((gemm_db_kernel<2, true>), grid, dim3(256), stream, g);
-    else if (b_nn) PGT_LAUNCH((gemm_db_kernel<1, false>), grid, dim3(128), stream, g);
-    else PGT_LAUNCH((gemm_db_kernel<1, true>), grid, dim3(128), stream, g);
+    if (bn == 128 && b_nn) PGT_LAUNCH((gemm_db_kernel<2, 2, false>), grid, dim3(256), stream, g);
+    else if (bn == 128) PGT_LAUNCH((gemm_db_kernel<2, 2, true>), grid, dim3(256), stream, g);
+    else if (g_db64 == 1 && b_nn) PGT_LAUNCH((gemm_db_kernel<2, 1, false>), grid, dim3(256), stream, g);
+    else if (g_db64 == 1) PGT_LAUNCH((gemm_db_kernel<2, 1, true>), grid, dim3(256), stream, g);
+    else if (b_nn) PGT_LAUNCH((gemm_db_kernel<1, 2, false>), grid, dim3(128), stream, g);
+    else PGT_LAUNCH((gemm_db_kernel<1, 2, true>), grid, dim3(128), stream, g);
     return pgt_check_launch("pgt_gemm_f32");
   }
   if (big && N > 64) PGT_GEMM_GO(128, 128);

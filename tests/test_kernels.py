@@ -339,14 +339,16 @@ def test_spmm_wide_rows_xcd_chunk_mapping(backend, F_):
 
 @pytest.mark.parametrize("M,segs,segk,N", [(200, 5, 66, 128), (300, 5, 66, 64), (150, 1, 128, 330), (260, 3, 7, 65),
                                            (129, 2, 33, 40), (260, 1, 64, 48), (140, 2, 18, 72), (70, 1, 2, 4)])
-@pytest.mark.parametrize("pipelined", [1, 0])
+@pytest.mark.parametrize("pipelined", [1, 2, 0])
 def test_gemm_large_tile_variants(backend, M, segs, segk, N, pipelined):
     """The 128-wide tiles (used for M >= 2048) forced onto small problems so the CPU test double covers them too:
     NN with float2 / scalar A loads, NT (k-major B staging), segmented output, and the TN weight-gradient kernel;
-    with and without the two-stage pipelined kernel (gemm_db_kernel; it takes the float2-loadable shapes)."""
+    with and without the two-stage pipelined kernel (gemm_db_kernel; it takes the float2-loadable shapes;
+    pipelined = 2 selects its two-wavefront 128 x 64 tile instead of the four-wavefront one for N <= 64)."""
     lib = _lib.get_lib()
     lib.tune("gemm_small_tiles", 2)
-    lib.tune("gemm_db", pipelined)
+    lib.tune("gemm_db", 2 if pipelined else 0)
+    lib.tune("gemm_db64", 0 if pipelined == 2 else 1)
     try:
         g = torch.Generator().manual_seed(M * 7 + N)
         A = torch.randn(segs, M, segk, generator=g)
@@ -373,6 +375,7 @@ def test_gemm_large_tile_variants(backend, M, segs, segk, N, pipelined):
     finally:
         lib.tune("gemm_small_tiles", 0)
         lib.tune("gemm_db", 1)
+        lib.tune("gemm_db64", 1)
 
 
 def test_spmm_tuning_variants_agree(backend):

@@ -51,6 +51,7 @@ class Model(torch.nn.Module):
     def __init__(self, hidden):
         super().__init__()
         self.rnn = BatchedDCRNN(2, hidden, K=3)
+        self.rnn.lazy_output = True     # [B, T, N, O] as a zero-copy view of the time-major states (same values)
         self.head = None if hidden == 2 else Linear(hidden, 2)
 
     def forward(self, X, ei, ew):

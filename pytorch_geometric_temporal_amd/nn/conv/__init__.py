@@ -17,6 +17,24 @@ def glorot_(t):
     return t
 
 
+def _rows_in_memory_order(x):
+    """(x as [rows, C] without a copy when possible, function restoring the leading shape of a [rows, C'] result).
+
+    A product over the last dimension does not care in which order the rows are visited: when `x` is a permuted view
+    of a contiguous tensor (e.g. the zero-copy `[B, T, N, C]` output of BatchedDCRNN(lazy_output=True), stored
+    `[T, B, N, C]`), the rows are taken in MEMORY order and the result is handed back as the same permuted view."""
+    lead = x.shape[:-1]
+    if x.is_contiguous() or x.dim() < 3 or x.stride(-1) != 1:
+        return x.reshape(-1, x.shape[-1]), (lambda y: y.view(*lead, y.shape[-1]))
+    order = sorted(range(x.dim() - 1), key=lambda d: -x.stride(d))
+    xp = x.permute(*order, x.dim() - 1)
+    if not xp.is_contiguous():
+        return x.reshape(-1, x.shape[-1]), (lambda y: y.view(*lead, y.shape[-1]))
+    inv = [order.index(d) for d in range(x.dim() - 1)]
+    plead = xp.shape[:-1]
+    return xp.reshape(-1, x.shape[-1]), (lambda y: y.view(*plead, y.shape[-1]).permute(*inv, x.dim() - 1))
+
+
 class Linear(torch.nn.Linear):
     """torch.nn.Linear (same parameters / initialisation / state_dict) whose product runs on the library's exact-fp32
     MFMA GEMM — the per-node readout that follows the recurrent cell in the reference's examples
@@ -25,9 +43,8 @@ class Linear(torch.nn.Linear):
     the rows once."""
 
     def forward(self, x):
-        shp = x.shape
-        y = ops.linear(x.reshape(-1, shp[-1]), self.weight.t(), self.bias)
-        return y.view(*shp[:-1], self.out_features)
+        x2, restore = _rows_in_memory_order(x)
+        return restore(ops.linear(x2, self.weight.t(), self.bias))
 
 
 class _Lin(torch.nn.Module):
@@ -40,9 +57,8 @@ class _Lin(torch.nn.Module):
         glorot_(self.weight)
 
     def forward(self, x):
-        shp = x.shape
-        y = ops.linear(x.reshape(-1, shp[-1]), self.weight.t(), None)
-        return y.view(*shp[:-1], self.out_channels)
+        x2, restore = _rows_in_memory_order(x)
+        return restore(ops.linear(x2, self.weight.t(), None))
 
 
 def _fold_batch(x):

@@ -103,6 +103,41 @@ def test_batched_dcrnn_backward_matches_oracle_autograd(backend):
         assert_close_with_nonfinite(p.grad, params64[name].grad, 1e-4, 1e-4, name)
 
 
+@pytest.mark.parametrize("n_nodes", [18, 400])
+def test_batched_dcrnn_lazy_output_is_the_same_function(backend, n_nodes):
+    """lazy_output=True returns the [B, T, N, O] states as a zero-copy permuted view and the package's Linear consumes
+    it in memory order: values and every gradient equal the contiguous default (both row layouts: LDS-resident
+    batch-major stack for the small graph, node-major rows for the large one)."""
+    from pytorch_geometric_temporal_amd.nn.conv import Linear
+    from pytorch_geometric_temporal_amd import ops
+    torch.manual_seed(1)
+    B, T, fin, K = 3, 2, 2, 2
+    O = 4 if n_nodes < 100 else 62            # 400 x 64 floats x 2 blocks > 160 KB of LDS: node-major path
+    ei_np, ew_np = syn.sensor_graph(n_nodes, 5 * n_nodes, seed=4, symmetric=False)
+    ei, ew = backend.t(ei_np), backend.t(ew_np)
+    assert bool(ops.slab_fits(ops.dconv_graph(ei, ew, n_nodes, strict_dense=False), fin + O, K)) == (n_nodes < 100)
+    X = torch.randn(B, T, n_nodes, fin)
+    w = backend.t(torch.randn(B, T, n_nodes, 3))
+    res = []
+    for lazy in (False, True):
+        torch.manual_seed(2)
+        rnn, head = BatchedDCRNN(fin, O, K).to(backend.device), Linear(O, 3).to(backend.device)
+        rnn.lazy_output = lazy
+        Xd = backend.t(X).requires_grad_()
+        h = rnn(Xd, ei, ew)
+        assert h.shape == (B, T, n_nodes, O) and h.is_contiguous() != lazy
+        y = head(torch.relu(h))
+        assert y.shape == (B, T, n_nodes, 3)
+        (y * w).sum().backward()
+        res.append((h.detach().clone(), y.detach().clone(), Xd.grad.clone(),
+                    [p.grad.clone() for p in list(rnn.parameters()) + list(head.parameters())]))
+    (h0, y0, gx0, gp0), (h1, y1, gx1, gp1) = res
+    assert torch.equal(h0, h1) and torch.equal(y0, y1)
+    assert_close_with_nonfinite(gx1, gx0, 1e-6, 1e-6, "dX")
+    for a, b in zip(gp0, gp1):
+        assert_close_with_nonfinite(b, a, 1e-5, 1e-5, "parameter gradient")   # atomics: summation order differs
+
+
 def test_reference_api_surface(backend):
     # constructor / attribute / parameter-name surface of dcrnn.py:21-37,128-160,343-361
     m = DCRNN(in_channels=4, out_channels=8, K=2, bias=True)

@@ -45,7 +45,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 5
+#define PGT_ABI_VERSION 6
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -191,6 +191,22 @@ int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_se
 int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                         const float* G, int64_t ldg, float* dW, int64_t lddw, float* db, int64_t M, int64_t N,
                         pgt_stream_t stream);
+
+/* The DCRNN gate GEMMs with the gate chain fused into the epilogue (operands A / Bw / bias as pgt_gemm_f32):
+ *   pgt_gemm_gru_zr_f32:  zr [M,2O] = sigmoid(A Bw + bias);  xhr[m, f_in + o] = H[m,o] * zr[m, O + o]
+ *                         == pgt_gemm_f32 into zr followed by pgt_gru_zr_f32 (dcrnn.py:172-185), bit for bit,
+ *                         without writing and re-reading the pre-activations.
+ *   pgt_gemm_gru_h_f32:   ht [M,O] = tanh(A Bw + bias);  Hnew = Z*H + (1-Z)*ht with Z = zr[m, o] (row stride 2O)
+ *                         written to out0 and, when non-NULL, out1 == pgt_gemm_f32 + pgt_gru_h_f32 (dcrnn.py:186-192).
+ * O must be a multiple of 4, zr / ht 16-byte aligned. */
+int pgt_gemm_gru_zr_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                        const float* Bw, int64_t sbk, int64_t sbn, const float* bias, float* zr, const float* H,
+                        int64_t ldh, float* xhr, int64_t ldxhr, int64_t f_in, int64_t M, int64_t O,
+                        pgt_stream_t stream);
+int pgt_gemm_gru_h_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                       const float* Bw, int64_t sbk, int64_t sbn, const float* bias, float* ht, const float* zr,
+                       const float* H, int64_t ldh, float* out0, int64_t ld0, float* out1, int64_t ld1, int64_t M,
+                       int64_t O, pgt_stream_t stream);
 
 /* ---------------------------------------------------------------- GRU gate chains */
 

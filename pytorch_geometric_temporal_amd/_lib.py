@@ -68,6 +68,10 @@ PROTOTYPES = {
                                              c_i64, c_i64, c_i64, c_ptr, c_i64, c_int, c_ptr]),
     "pgt_gemm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64,
                              c_ptr, c_i64, c_i64, c_int, c_ptr]),
+    "pgt_gemm_gru_zr_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64,
+                                    c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_gemm_gru_h_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                                   c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_gemm_tn_acc_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                     c_i64, c_ptr]),
     "pgt_gru_zr_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
@@ -85,7 +89,7 @@ PROTOTYPES = {
     "pgt_swap01_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 5
+EXPECTED_ABI = 6
 
 
 class PgtLib:

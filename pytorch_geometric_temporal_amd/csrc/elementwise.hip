@@ -5,7 +5,7 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return pgt_sigmoidf(x); }
 
 template <int V>
 __global__ __launch_bounds__(256) void gru_zr_kernel(float* pre_zr, const float* __restrict__ H, int64_t ldh,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void gru_h_kernel(float* pre_h, const float* _
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     t[i] = tanhf(t[i]);
-    hn[i] = z[i] * h[i] + (1.f - z[i]) * t[i];
+    hn[i] = pgt_gru_blend(z[i], h[i], t[i]);
   }
   pgt_stv<V>(pre_h + m * O + o, t);
   pgt_stv<V>(out0 + m * ld0 + o, hn);

@@ -27,7 +27,64 @@ struct GemmArgs {
   const float* Bw; int64_t sbk; int64_t sbn;
   float* C; int64_t ldc; int64_t c_seg_stride; int c_seg_n;
   const float* bias; int M; int N; int accumulate;
+  // fused GRU epilogues (pgt_gemm_gru_zr_f32 / pgt_gemm_gru_h_f32); epi = 0: plain GEMM
+  //   1: C = sigmoid(acc + bias) [M, 2O];  eX[m, efin + o] = eH[m, o] * C[m, O + o]
+  //   2: C = tanh(acc + bias) [M, O];  Hnew = Z * H + (1 - Z) * C with Z = eZ[m * 2O + o]  -> eO0 (and eO1 when non-null)
+  int epi; int eO; int efin; int evec;   // evec bit 0: eH float4-loadable, 1: eX float2-storable, 2: eO0 float4, 3: eO1 float2
+  const float* eH; int64_t eldh; float* eX; int64_t eldx;
+  const float* eZ; float* eO0; int64_t eld0; float* eO1; int64_t eld1;
 };
+
+// ---- fused GRU epilogues: one output element / one aligned group of four (row gm, columns gn .. gn+3, all < N)
+__device__ __forceinline__ float gemm_epi1(const GemmArgs& g, int gm, int gn, float v) {
+  if (g.epi == 1) {
+    v = pgt_sigmoidf(v);
+    if (gn >= g.eO) {
+      const int o = gn - g.eO;
+      g.eX[(int64_t)gm * g.eldx + g.efin + o] = g.eH[(int64_t)gm * g.eldh + o] * v;
+    }
+  } else if (g.epi == 2) {
+    v = tanhf(v);
+    const float z = g.eZ[(int64_t)gm * 2 * g.eO + gn], h = g.eH[(int64_t)gm * g.eldh + gn];
+    const float hn = pgt_gru_blend(z, h, v);
+    g.eO0[(int64_t)gm * g.eld0 + gn] = hn;
+    if (g.eO1) g.eO1[(int64_t)gm * g.eld1 + gn] = hn;
+  }
+  return v;
+}
+__device__ __forceinline__ float4 gemm_epi_ld4(const float* p, bool vec) {
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  return make_float4(p[0], p[1], p[2], p[3]);
+}
+__device__ __forceinline__ void gemm_epi_st4(float* p, float4 v, bool v4, bool v2) {
+  if (v4) { *reinterpret_cast<float4*>(p) = v; return; }
+  if (v2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
+    *reinterpret_cast<float2*>(p + 2) = make_float2(v.z, v.w);
+    return;
+  }
+  p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+}
+__device__ __forceinline__ float4 gemm_epi4(const GemmArgs& g, int gm, int gn, float4 v) {
+  if (g.epi == 1) {
+    v = make_float4(pgt_sigmoidf(v.x), pgt_sigmoidf(v.y), pgt_sigmoidf(v.z), pgt_sigmoidf(v.w));
+    if (gn >= g.eO) {                                    // O % 4 == 0 (host): a group is all-z or all-r
+      const int o = gn - g.eO;
+      const float4 h = gemm_epi_ld4(g.eH + (int64_t)gm * g.eldh + o, g.evec & 1);
+      gemm_epi_st4(g.eX + (int64_t)gm * g.eldx + g.efin + o, make_float4(h.x * v.x, h.y * v.y, h.z * v.z, h.w * v.w),
+                   false, g.evec & 2);
+    }
+  } else if (g.epi == 2) {
+    v = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+    const float4 z = *reinterpret_cast<const float4*>(g.eZ + (int64_t)gm * 2 * g.eO + gn);
+    const float4 h = gemm_epi_ld4(g.eH + (int64_t)gm * g.eldh + gn, g.evec & 1);
+    const float4 hn = make_float4(pgt_gru_blend(z.x, h.x, v.x), pgt_gru_blend(z.y, h.y, v.y),
+                                  pgt_gru_blend(z.z, h.z, v.z), pgt_gru_blend(z.w, h.w, v.w));
+    gemm_epi_st4(g.eO0 + (int64_t)gm * g.eld0 + gn, hn, g.evec & 4, false);
+    if (g.eO1) gemm_epi_st4(g.eO1 + (int64_t)gm * g.eld1 + gn, hn, false, g.evec & 8);
+  }
+  return v;
+}
 
 // Epilogue shared by the tile kernels.  D map (cdna_hip_programming.md §3): col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): stored straight from the accumulators a lane writes 4 bytes per row
@@ -42,7 +99,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, pgt_f32x16 (&
   const int lo = lane & 31, hi = lane >> 5;
   constexpr int EPW = 32 * WN + 4;                                   // floats per staged row (+4: rows on different banks)
   constexpr bool EPI_LDS = LDS_BYTES >= 4 * 16 * EPW * (int)sizeof(float);
-  const int ev = g.accumulate ? 1 : g.c_seg_n == g.N ? 4 : 2;        // widest store the layout allows
+  const int ev = g.accumulate ? 1 : g.c_seg_n == g.N ? 4 : g.epi ? 1 : 2;   // widest store the layout allows
   if (EPI_LDS && ev > 1 && g.ldc % ev == 0 && g.c_seg_n % ev == 0 && g.c_seg_stride % ev == 0 &&
       (reinterpret_cast<uintptr_t>(g.C) % (4 * ev)) == 0) {
     // each wavefront stages 16 rows x (32 * WN) columns at a time inside the (now dead) tile storage
@@ -71,7 +128,8 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, pgt_f32x16 (&
             const int row = rr + lane / LPR, c = (lane % LPR) * 4;
             const int gm = mrow0 + row, gn = nw0 + c;
             if (gm < g.M && gn < g.N) {
-              const float4 v = *reinterpret_cast<const float4*>(stage + row * EPW + c);
+              float4 v = *reinterpret_cast<const float4*>(stage + row * EPW + c);
+              if (g.epi) v = gemm_epi4(g, gm, gn, v);    // N % 4 == 0 with a fused epilogue (host)
               float* p = g.C + (int64_t)gm * g.ldc + gn;
               if (gn + 3 < g.N) *reinterpret_cast<float4*>(p) = v;
               else { p[0] = v.x; if (gn + 1 < g.N) p[1] = v.y; if (gn + 2 < g.N) p[2] = v.z; }
@@ -113,6 +171,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, pgt_f32x16 (&
           float v = acc[i][j][r] + bv;
           float* p = cbase + (int64_t)gm * g.ldc;
           if (g.accumulate) v += *p;
+          if (g.epi) v = gemm_epi1(g, gm, gn, v);
           *p = v;
         }
       }
@@ -927,10 +986,10 @@ void pgt_gemm_set_db(int v) { g_db = v; }
 void pgt_gemm_set_db64(int v) { g_db64 = v; }
 void pgt_gemm_set_tn_pipe(int v) { g_tn_pipe = v; }
 
-extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
-                            const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
-                            int64_t c_seg_stride, int64_t c_seg_n, const float* bias, int64_t M, int64_t N,
-                            int accumulate, pgt_stream_t stream) {
+static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                      const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int64_t c_seg_stride,
+                      int64_t c_seg_n, const float* bias, int64_t M, int64_t N, int accumulate, const GemmArgs* epi,
+                      pgt_stream_t stream) {
   PGT_REQUIRE(M >= 0 && N >= 0 && n_seg >= 0 && seg_k >= 0, "pgt_gemm_f32: negative size");
   if (M == 0 || N == 0) return PGT_OK;
   PGT_REQUIRE(C != nullptr, "pgt_gemm_f32: null output");
@@ -939,7 +998,13 @@ extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, i
   PGT_REQUIRE(M < ((int64_t)1 << 31) - 128 && N < ((int64_t)1 << 31) - 128 && n_seg * seg_k < ((int64_t)1 << 31) - BK,
               "pgt_gemm_f32: size exceeds int32 indexing");
   GemmArgs g{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), Bw, sbk, sbn, C, ldc, c_seg_stride,
-             (int)c_seg_n, bias, (int)M, (int)N, accumulate};
+             (int)c_seg_n, bias, (int)M, (int)N, accumulate, 0, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0,
+             nullptr, 0};
+  if (epi) {
+    g.epi = epi->epi; g.eO = epi->eO; g.efin = epi->efin; g.evec = epi->evec;
+    g.eH = epi->eH; g.eldh = epi->eldh; g.eX = epi->eX; g.eldx = epi->eldx;
+    g.eZ = epi->eZ; g.eO0 = epi->eO0; g.eld0 = epi->eld0; g.eO1 = epi->eO1; g.eld1 = epi->eld1;
+  }
   // float2 loads of A need every (row, even k) address 8-byte aligned and no pair straddling a segment
   const bool av2 = (seg_k % 2 == 0) && (lda % 2 == 0) && (a_seg_stride % 2 == 0) && pgt_aligned(A, 8);
   const bool kmaj = (sbk == 1 && sbn != 1);
@@ -995,6 +1060,47 @@ extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, i
 #undef PGT_GEMM_GO2
 #undef PGT_GEMM_GO
   return pgt_check_launch("pgt_gemm_f32");
+}
+
+extern "C" int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                            const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
+                            int64_t c_seg_stride, int64_t c_seg_n, const float* bias, int64_t M, int64_t N,
+                            int accumulate, pgt_stream_t stream) {
+  return gemm_entry(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, C, ldc, c_seg_stride, c_seg_n, bias, M, N,
+                    accumulate, nullptr, stream);
+}
+
+extern "C" int pgt_gemm_gru_zr_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                                   const float* Bw, int64_t sbk, int64_t sbn, const float* bias, float* zr,
+                                   const float* H, int64_t ldh, float* xhr, int64_t ldxhr, int64_t f_in, int64_t M,
+                                   int64_t O, pgt_stream_t stream) {
+  PGT_REQUIRE(M >= 0 && O >= 0 && f_in >= 0, "pgt_gemm_gru_zr_f32: negative size");
+  if (M == 0 || O == 0) return PGT_OK;
+  PGT_REQUIRE(zr && H && xhr, "pgt_gemm_gru_zr_f32: null pointer");
+  PGT_REQUIRE(O % 4 == 0 && pgt_aligned(zr, 16), "pgt_gemm_gru_zr_f32: O must be a multiple of 4 and zr 16-byte aligned");
+  GemmArgs e{};
+  e.epi = 1; e.eO = (int)O; e.efin = (int)f_in;
+  e.eH = H; e.eldh = ldh; e.eX = xhr; e.eldx = ldxhr;
+  e.evec = ((ldh % 4 == 0 && pgt_aligned(H, 16)) ? 1 : 0) |
+           ((ldxhr % 2 == 0 && f_in % 2 == 0 && pgt_aligned(xhr, 8)) ? 2 : 0);
+  return gemm_entry(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, zr, 2 * O, 0, 2 * O, bias, M, 2 * O, 0, &e, stream);
+}
+
+extern "C" int pgt_gemm_gru_h_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                                  const float* Bw, int64_t sbk, int64_t sbn, const float* bias, float* ht,
+                                  const float* zr, const float* H, int64_t ldh, float* out0, int64_t ld0, float* out1,
+                                  int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream) {
+  PGT_REQUIRE(M >= 0 && O >= 0, "pgt_gemm_gru_h_f32: negative size");
+  if (M == 0 || O == 0) return PGT_OK;
+  PGT_REQUIRE(ht && zr && H && out0, "pgt_gemm_gru_h_f32: null pointer");
+  PGT_REQUIRE(O % 4 == 0 && pgt_aligned(ht, 16) && pgt_aligned(zr, 16),
+              "pgt_gemm_gru_h_f32: O must be a multiple of 4 and ht / zr 16-byte aligned");
+  GemmArgs e{};
+  e.epi = 2; e.eO = (int)O;
+  e.eH = H; e.eldh = ldh; e.eZ = zr; e.eO0 = out0; e.eld0 = ld0; e.eO1 = out1; e.eld1 = ld1;
+  e.evec = ((ldh % 4 == 0 && pgt_aligned(H, 16)) ? 1 : 0) | ((ld0 % 4 == 0 && pgt_aligned(out0, 16)) ? 4 : 0) |
+           ((out1 && ld1 % 2 == 0 && pgt_aligned(out1, 8)) ? 8 : 0);
+  return gemm_entry(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, ht, O, 0, O, bias, M, O, 0, &e, stream);
 }
 
 extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg,

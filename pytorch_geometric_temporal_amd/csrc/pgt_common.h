@@ -50,6 +50,12 @@ typedef float4 pgt_f4;
 #else
 typedef float pgt_f4 __attribute__((ext_vector_type(4)));
 #endif
+// the one sigmoid of the library (gate kernels and fused GEMM epilogues must agree bit for bit)
+static __device__ __forceinline__ float pgt_sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// GRU blend Z*H + (1-Z)*T with the contraction spelled out (the gate kernel and the fused GEMM epilogue must round alike)
+static __device__ __forceinline__ float pgt_gru_blend(float z, float h, float t) { return fmaf(z, h, (1.f - z) * t); }
+
 static __device__ __forceinline__ pgt_f4 pgt_mk4(float a, float b, float c, float d) {
   pgt_f4 r;
   r.x = a; r.y = b; r.z = c; r.w = d;

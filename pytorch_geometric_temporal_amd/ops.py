@@ -6,6 +6,8 @@ import ctypes
 import math
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from . import _lib
@@ -304,6 +306,37 @@ def gemm(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, C, ldc, c_seg_stride,
     return C
 
 
+# DCRNN cell forward: sigmoid / H*R and tanh / blend inside the gate GEMMs' epilogues (A/B: PGT_FUSE_GATES=0)
+FUSE_GATE_EPILOGUES = os.environ.get("PGT_FUSE_GATES", "1") != "0"
+
+
+def gemm_gru_zr(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, bias, zr, H, xhr, f_in):
+    """pgt_gemm_gru_zr_f32: zr [M, 2O] = sigmoid(A Bw + bias), xhr[:, f_in:] = H * zr[:, O:] (== gemm + _gru_zr)."""
+    lib = _lib.get_lib()
+    for t, n in ((A, "A"), (Bw, "Bw"), (zr, "zr"), (H, "H"), (xhr, "xhr")):
+        check_tensor(lib, t, n)
+    M, O2 = zr.shape
+    hp, ldh = _rows(H, "H")
+    xp, ldx = _rows(xhr, "xhr")
+    _timed("gemm", 2.0 * M * O2 * n_seg * seg_k, lambda: lib.call(
+        "pgt_gemm_gru_zr_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(Bw), sbk, sbn, ptr(bias), ptr(zr), hp, ldh,
+        xp, ldx, f_in, M, O2 // 2, stream_of(lib, zr)), tag=("NN+zr", M, O2, n_seg, seg_k, O2, 0))
+
+
+def gemm_gru_h(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, bias, ht, zr, H, out0, out1=None):
+    """pgt_gemm_gru_h_f32: ht [M, O] = tanh(A Bw + bias), Hnew = Z H + (1 - Z) ht -> out0 (, out1) (== gemm + _gru_h)."""
+    lib = _lib.get_lib()
+    for t, n in ((A, "A"), (Bw, "Bw"), (ht, "ht"), (zr, "zr"), (H, "H"), (out0, "out0")):
+        check_tensor(lib, t, n)
+    M, O = ht.shape
+    hp, ldh = _rows(H, "H")
+    op, ld0 = _rows(out0, "out0")
+    o1, ld1 = _rows(out1, "out1") if out1 is not None else (ptr(None), 0)
+    _timed("gemm", 2.0 * M * O * n_seg * seg_k, lambda: lib.call(
+        "pgt_gemm_gru_h_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(Bw), sbk, sbn, ptr(bias), ptr(ht), ptr(zr),
+        hp, ldh, op, ld0, o1, ld1, M, O, stream_of(lib, ht)), tag=("NN+h", M, O, n_seg, seg_k, O, 0))
+
+
 def gemm_tn_acc(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N):
     lib = _lib.get_lib()
     for t, n in ((A, "A"), (G, "G"), (dW, "dW")):
@@ -599,18 +632,26 @@ class DCRNNSeqFunction(torch.autograd.Function):
             else:
                 _stack_fwd(g, TSx, t, K, Nn)
 
+        # the input columns of segment 0 of both stacks, all T steps in one launch each
+        copy2d(TSzr[0].view(T * M, C)[:, :Fin], X.view(T * M, Fin))
+        copy2d(TSh[0].view(T * M, C)[:, :Fin], X.view(T * M, Fin))
+        fuse = FUSE_GATE_EPILOGUES and O % 4 == 0
         for t in range(T):
-            Xt, Hp = X[t], (H0c if t == 0 else Hout[t - 1])
-            copy2d(TSzr[0, t][:, :Fin], Xt)
+            Hp = H0c if t == 0 else Hout[t - 1]
             if t == 0:
-                copy2d(TSzr[0, t][:, Fin:], Hp)     # later steps: written by the previous step's blend kernel
+                copy2d(TSzr[0, t][:, Fin:], Hp)     # later steps: written by the previous step's blend
             stack(TSzr, t)
-            gemm(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, ZR[t], 2 * O, 0, 2 * O, bzr, M, 2 * O)
-            copy2d(TSh[0, t][:, :Fin], Xt)
-            _gru_zr(ZR[t], Hp, TSh[0, t], Fin)
-            stack(TSh, t)
-            gemm(TSh[0, t], C, seg, S, C, Wh_c, O, 1, HT[t], O, 0, O, bh, M, O)
-            _gru_h(HT[t], ZR[t], Hp, Hout[t], TSzr[0, t + 1][:, Fin:] if t + 1 < T else None)
+            Hnext = TSzr[0, t + 1][:, Fin:] if t + 1 < T else None
+            if fuse:
+                gemm_gru_zr(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, bzr, ZR[t], Hp, TSh[0, t], Fin)
+                stack(TSh, t)
+                gemm_gru_h(TSh[0, t], C, seg, S, C, Wh_c, O, 1, bh, HT[t], ZR[t], Hp, Hout[t], Hnext)
+            else:
+                gemm(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, ZR[t], 2 * O, 0, 2 * O, bzr, M, 2 * O)
+                _gru_zr(ZR[t], Hp, TSh[0, t], Fin)
+                stack(TSh, t)
+                gemm(TSh[0, t], C, seg, S, C, Wh_c, O, 1, HT[t], O, 0, O, bh, M, O)
+                _gru_h(HT[t], ZR[t], Hp, Hout[t], Hnext)
         ctx.g, ctx.K, ctx.B, ctx.Fin, ctx.slab = g, K, B, Fin, slab
         ctx.has_bias = (bzr is not None, bh is not None)
         ctx.save_for_backward(TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c)

@@ -685,3 +685,47 @@ def test_spmm_band_per_cu_kernel_multi_step_chunks(backend, nblk, n, window):
     finally:
         lib.tune("spmm_band_nblk", 0)
     assert torch.equal(Yp, Yb)
+
+
+@pytest.mark.parametrize("M,segs,segk,O,fin", [(150, 5, 66, 64, 2), (70, 3, 10, 8, 2), (260, 1, 128, 32, 0),
+                                               (90, 2, 7, 4, 3)])
+@pytest.mark.parametrize("big", [0, 2])
+def test_gemm_with_fused_gru_epilogues_is_bitwise_gemm_then_gates(backend, M, segs, segk, O, fin, big):
+    """pgt_gemm_gru_zr_f32 / pgt_gemm_gru_h_f32 == pgt_gemm_f32 followed by pgt_gru_zr_f32 / pgt_gru_h_f32, bit for bit
+    (vector and scalar epilogue paths, small and 128-wide tiles, the pipelined kernel, unaligned side outputs)."""
+    lib = _lib.get_lib()
+    lib.tune("gemm_small_tiles", big)
+    try:
+        g = torch.Generator().manual_seed(M + O)
+        dev = backend.device
+        K = segs * segk
+        A = torch.randn(segs, M, segk, generator=g).to(dev)
+        Wzr, bzr = torch.randn(K, 2 * O, generator=g).to(dev), torch.randn(2 * O, generator=g).to(dev)
+        Wh, bh = torch.randn(K, O, generator=g).to(dev), torch.randn(O, generator=g).to(dev)
+        H = torch.randn(M, O, generator=g).to(dev)
+        C = fin + O
+        # unfused
+        zr0 = torch.empty(M, 2 * O, device=dev)
+        xhr0 = torch.zeros(M, C, device=dev)
+        ops.gemm(A, segk, M * segk, segs, segk, Wzr, 2 * O, 1, zr0, 2 * O, 0, 2 * O, bzr, M, 2 * O)
+        ops._gru_zr(zr0, H, xhr0, fin)
+        ht0 = torch.empty(M, O, device=dev)
+        out0a, out1a = torch.empty(M, O, device=dev), torch.zeros(M, C, device=dev)
+        ops.gemm(A, segk, M * segk, segs, segk, Wh, O, 1, ht0, O, 0, O, bh, M, O)
+        ops._gru_h(ht0, zr0, H, out0a, out1a[:, fin:])
+        # fused
+        zr1 = torch.full((M, 2 * O), float("nan"), device=dev)
+        xhr1 = torch.zeros(M, C, device=dev)
+        ops.gemm_gru_zr(A, segk, M * segk, segs, segk, Wzr, 2 * O, 1, bzr, zr1, H, xhr1, fin)
+        ht1 = torch.full((M, O), float("nan"), device=dev)
+        out0b, out1b = torch.full((M, O), float("nan"), device=dev), torch.zeros(M, C, device=dev)
+        ops.gemm_gru_h(A, segk, M * segk, segs, segk, Wh, O, 1, bh, ht1, zr1, H, out0b, out1b[:, fin:])
+        assert torch.equal(zr0, zr1) and torch.equal(xhr0, xhr1)
+        assert torch.equal(ht0, ht1) and torch.equal(out0a, out0b) and torch.equal(out1a, out1b)
+        out0c = torch.full((M, O), float("nan"), device=dev)
+        ops.gemm_gru_h(A, segk, M * segk, segs, segk, Wh, O, 1, None, ht1, zr1, H, out0c, None)   # no bias, no out1
+        ops.gemm(A, segk, M * segk, segs, segk, Wh, O, 1, ht0, O, 0, O, None, M, O)
+        ops._gru_h(ht0, zr0, H, out0a, None)
+        assert torch.equal(out0a, out0c)
+    finally:
+        lib.tune("gemm_small_tiles", 0)

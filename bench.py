@@ -210,12 +210,14 @@ def main():
         for i in range(args.warmup + args.steps, n_total):
             step(i)
         kernels = ops.KERNEL_TIMER.summary()
+        shapes = ops.KERNEL_TIMER.by_tag()
         ops.KERNEL_TIMER = None
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
         k = kernels[dom]
         names = {"spmm": "spmm_wide_kernel<4> (pgt_spmm_csr_f32)",
                  "stack": "dconv_slab_fwd/bwd_kernel (pgt_dconv_stack_slab(_bwd)_f32)",
-                 "gemm": "gemm_kernel (pgt_gemm_f32)", "gemm_tn": "gemm_tn_kernel (pgt_gemm_tn_acc_f32)"}
+                 "gemm": "gemm_db_kernel (pgt_gemm_f32 and, with the GRU gate chain in the epilogue, pgt_gemm_gru_zr/h_f32)",
+                 "gemm_tn": "gemm_tn_pipe_kernel (pgt_gemm_tn_acc_f32)"}
         if dom in ("spmm", "stack"):
             ach = k["work_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
             roof = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -233,6 +235,10 @@ def main():
             else:
                 v["achieved_TFLOPs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e12
                 v["mfma_frac"] = v["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS
+                # per shape: [op, M, N, k-segments, segment width, ...]; "NN+zr" / "NN+h" carry the gate chain
+                v["by_shape"] = [{"shape": r["tag"][1:], "launches": r["launches"], "avg_us": r["avg_us"],
+                                  "TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12}
+                                 for r in shapes if r["tag"][0] == kk]
 
     ns = None
     if rank == 0 and world == 1 and not args.no_ns:

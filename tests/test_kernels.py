@@ -89,12 +89,13 @@ def test_spmm_strided_views_and_heavy_rows(backend):
                           csr.val.cpu().numpy()[rp[5]:]])
     rp[6:] += extra
     csr.rowptr, csr.col, csr.val = (torch.from_numpy(a).to(backend.device) for a in (rp, col, val))
-    big = torch.randn(n, 80).to(backend.device)
+    big = torch.randn(n, 80, generator=torch.Generator().manual_seed(3)).to(backend.device)
     X = big[:, 8:72]            # 64 columns inside a wider buffer, 32-byte aligned start
     out = torch.zeros(n, 100, device=backend.device)
     Y = out[:, 4:68]
     ops.spmm(csr, X, Y)
-    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "strided")
+    # row 5 sums 2 000 products in fp32 (sequential, like index_add_): its rounding error is ~1e-4, not 1e-5
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 3e-4, 1e-5, "strided")
     assert float(out[:, :4].abs().max()) == 0.0 and float(out[:, 68:].abs().max()) == 0.0
     X1 = big[:, 3:70]           # odd offset -> scalar path
     Y1 = torch.zeros(n, 67, device=backend.device)

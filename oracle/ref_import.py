@@ -101,3 +101,15 @@ def load(dotted):
         name = name + "." + p
         _ensure_pkg(name, base)
     return importlib.import_module(_PKG + "." + dotted)
+
+
+def load_dataset(name):
+    """load_dataset("chickenpox") -> the reference's dataset/<name>.py.  The dataset modules import the signal classes
+    from the PACKAGE `..signal`, whose real __init__ pulls in the batch / heterogeneous iterators (torch_geometric
+    Batch, HeteroData) and dask; the two plain iterators are loaded by path and published on a stand-in package."""
+    static = load("signal.static_graph_temporal_signal")
+    dynamic = load("signal.dynamic_graph_temporal_signal")
+    pkg = sys.modules[_PKG + ".signal"]
+    pkg.StaticGraphTemporalSignal = static.StaticGraphTemporalSignal
+    pkg.DynamicGraphTemporalSignal = dynamic.DynamicGraphTemporalSignal
+    return load("dataset." + name)

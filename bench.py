@@ -185,8 +185,23 @@ def main():
         opt.step()
         return loss
 
+    # one initialisation pass (not a warmup step): first-use work that does not belong to any step - graph preparation
+    # (cached by tensor identity afterwards), code-object load of every kernel, growth of torch's caching allocator to the
+    # 12.5 GB of saved activations (0.5-0.7 s the first time, 20 ms afterwards).  Its parameter update is undone.
+    snapshot = flat.data.clone()
+    step(0)
+    flat.data.copy_(snapshot)
+    opt = flat.optimizer(torch.optim.Adam, lr=1e-3)
+    del snapshot
+    trace = os.environ.get("PGT_BENCH_STEP_TIMES") == "1"     # diagnostic: synchronised wall time of every warmup step
     for i in range(args.warmup):
+        if trace:
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
         step(i)
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[bench] warmup step {i}: {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -205,10 +220,17 @@ def main():
 
     # ---- live roofline of the path's kernels: extra instrumented steps, HIP events on the launch stream
     roof, kernels = None, None
-    if rank == 0 and args.profile_steps > 0:
-        ops.KERNEL_TIMER = ops.KernelTimer()
+    if args.profile_steps > 0:
+        # every rank runs the instrumented steps (they contain the gradient all-reduce: a collective); only rank 0
+        # records events
+        if rank == 0:
+            ops.KERNEL_TIMER = ops.KernelTimer()
         for i in range(args.warmup + args.steps, n_total):
             step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    if rank == 0 and args.profile_steps > 0:
         kernels = ops.KERNEL_TIMER.summary()
         shapes = ops.KERNEL_TIMER.by_tag()
         ops.KERNEL_TIMER = None
@@ -260,7 +282,7 @@ def main():
             "config": {"workload": f"METR-LA-shaped synthetic (207 nodes, 1515 edges, 12-step) BatchedDCRNN(2,{args.hidden},K=3)"
                                    + ("" if args.hidden == 2 else "+Linear") + " training step (fwd+bwd+allreduce+Adam)",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "seq_len": SEQ,
-                       "parallelism": f"dp{world}", "hidden": args.hidden, "K": 3},
+                       "parallelism": f"dp{world}", "hidden": args.hidden, "K": 3, "init_passes": 1},
             "epoch_time_s_23974_windows": 23974.0 / (world * args.batch) * dt / args.steps,
             "final_loss": final_loss,
             "roofline": roof, "kernels": kernels, "roofline_ns_spmm_N200k_F64": ns, "cpu_baseline": cpu,

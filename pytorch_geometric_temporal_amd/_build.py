@@ -24,6 +24,22 @@ def find_hipcc():
     raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
 
 
+def source_digest():
+    """sha256 over the kernel sources and headers: `lib/build_id.txt` records the digest the library was built from, and
+    the loader refuses a library whose digest differs from the sources next to it (a stale .so silently benchmarks
+    old kernels)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "pgt_common.h"),
+                                                       os.path.join(INCLUDE, "pgt_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+BUILD_ID_PATH = os.path.join(LIB_DIR, "build_id.txt")
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -54,6 +70,8 @@ def build_hip_library(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
+    with open(BUILD_ID_PATH, "w") as fh:
+        fh.write(source_digest() + "\n")
     return LIB_PATH
 
 

@@ -145,11 +145,30 @@ def _preload_hip_runtime():
             pass
 
 
+def _check_not_stale():
+    """Refuse a library that was built from other kernel sources than the ones lying next to it (only checked when the
+    sources are present, i.e. in a source checkout): a stale .so would silently run - and benchmark - old kernels."""
+    from . import _build
+    if not (os.path.exists(LIB_PATH) and os.path.exists(_build.BUILD_ID_PATH) and os.path.isdir(_build.CSRC)):
+        return
+    try:
+        want = _build.source_digest()
+    except OSError:
+        return
+    with open(_build.BUILD_ID_PATH) as fh:
+        have = fh.read().strip()
+    if have != want and os.environ.get("PGT_ALLOW_STALE_LIB") != "1":
+        raise PgtError(f"{LIB_PATH} was built from different sources than pytorch_geometric_temporal_amd/csrc "
+                       f"(build id {have[:12]}, sources {want[:12]}): rebuild with "
+                       "`python -m pytorch_geometric_temporal_amd._build`")
+
+
 def get_lib():
     """The product library (gfx950).  Raises PgtLibraryMissing when it has not been built."""
     global _LIB
     if _LIB is None:
         _preload_hip_runtime()
+        _check_not_stale()
         _LIB = PgtLib(LIB_PATH)
         if _LIB.target != "gfx950":
             raise PgtError(f"{LIB_PATH} reports target {_LIB.target!r}, expected 'gfx950'")

@@ -48,8 +48,13 @@ def main():
             for p in model.parameters():
                 p.add_(1.0)
     dp.broadcast_parameters(model, src=0)
-    flat = dp.FlatGradients(model.parameters())
-    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    if model_name == "dcrnn":                          # flat parameters + one optimizer update (what bench.py does)
+        flat = dp.FlatParameters(model.parameters())
+        opt = flat.optimizer(torch.optim.SGD, lr=0.1)
+        model.lazy_output = True
+    else:                                              # flat gradients + the ordinary per-parameter optimizer
+        flat = dp.FlatGradients(model.parameters())
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
     losses = []
     for epoch in range(2):
         mine = dp.shard_indices(total, rank, world, epoch=epoch, shuffle=True, seed=7)

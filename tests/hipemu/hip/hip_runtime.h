@@ -53,6 +53,8 @@ struct Fiber {
   std::vector<char> stack;
   bool done = false;
   unsigned tid = 0;
+  bool at_block_barrier = false;     // parked in block_barrier() of generation wait_gen: not runnable until it opens
+  unsigned long wait_gen = 0;
 };
 
 struct State {
@@ -64,6 +66,8 @@ struct State {
   // block barrier
   unsigned bar_count = 0;
   unsigned long bar_gen = 0;
+  unsigned live_block = 0;           // threads of the block that have not exited
+  std::vector<unsigned> live_wave;   // ... per wave
   // wave rendezvous (per wave)
   std::vector<unsigned> w_count;
   std::vector<unsigned long> w_gen;
@@ -79,33 +83,29 @@ inline void trampoline() {
   State& s = S();
   s.body();
   s.fibers[s.cur].done = true;
+  --s.live_block;
+  --s.live_wave[s.cur / 64];
   swapcontext(&s.fibers[s.cur].ctx, &s.sched);
 }
 
-inline unsigned live_threads_in_wave(unsigned wave) {
-  State& s = S();
-  unsigned lo = wave * 64, hi = std::min(lo + 64, s.nthreads), n = 0;
-  for (unsigned t = lo; t < hi; ++t) n += s.fibers[t].done ? 0 : 1;
-  return n;
-}
-
-inline unsigned live_threads_in_block() {
-  State& s = S();
-  unsigned n = 0;
-  for (unsigned t = 0; t < s.nthreads; ++t) n += s.fibers[t].done ? 0 : 1;
-  return n;
-}
+inline unsigned live_threads_in_wave(unsigned wave) { return S().live_wave[wave]; }
+inline unsigned live_threads_in_block() { return S().live_block; }
 
 // Exited threads do not take part in barriers (as on the hardware, where finished waves drop out).
 inline void block_barrier() {
   State& s = S();
-  unsigned long gen = s.bar_gen;
+  const unsigned long gen = s.bar_gen;
   ++s.bar_count;
-  for (;;) {
-    if (s.bar_gen != gen) return;
-    if (s.bar_count >= live_threads_in_block()) { s.bar_count = 0; ++s.bar_gen; return; }
+  if (s.bar_count >= s.live_block) { s.bar_count = 0; ++s.bar_gen; return; }
+  Fiber& me = s.fibers[s.cur];
+  me.at_block_barrier = true;
+  me.wait_gen = gen;
+  while (s.bar_gen == gen) {
+    // the last live thread may have EXITED instead of arriving: the arrivals then already cover every live thread
+    if (s.bar_count >= s.live_block) { s.bar_count = 0; ++s.bar_gen; break; }
     yield_();
   }
+  s.fibers[s.cur].at_block_barrier = false;
 }
 
 inline void wave_barrier() {
@@ -115,7 +115,7 @@ inline void wave_barrier() {
   ++s.w_count[w];
   for (;;) {
     if (s.w_gen[w] != gen) return;
-    if (s.w_count[w] >= live_threads_in_wave(w)) { s.w_count[w] = 0; ++s.w_gen[w]; return; }
+    if (s.w_count[w] >= s.live_wave[w]) { s.w_count[w] = 0; ++s.w_gen[w]; return; }
     yield_();
   }
 }
@@ -147,14 +147,27 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
           fb.ctx.uc_link = nullptr;
           makecontext(&fb.ctx, (void (*)())trampoline, 0);
         }
-        unsigned remaining = s.nthreads;
-        while (remaining) {
-          remaining = 0;
-          for (unsigned t = 0; t < s.nthreads; ++t) {
-            if (s.fibers[t].done) continue;
-            s.cur = t;
-            swapcontext(&s.sched, &s.fibers[t].ctx);
-            if (!s.fibers[t].done) ++remaining;
+        s.live_block = s.nthreads;
+        s.live_wave.assign(nw, 0);
+        for (unsigned t = 0; t < s.nthreads; ++t) ++s.live_wave[t / 64];
+        // Wave-at-a-time scheduling: a wavefront's fibres run round-robin until each has exited or is parked at a block
+        // barrier, so an intra-wave rendezvous (wave_barrier, shuffles, MFMA) costs one pass over 64 fibres instead
+        // of one over the whole block.  A wave that makes no such progress for a few passes (it polls something another
+        // wave produces) gives way to the next one.
+        while (s.live_block) {
+          for (unsigned w = 0; w < nw; ++w) {
+            const unsigned lo = w * 64, hi = std::min(lo + 64, s.nthreads);
+            for (int pass = 0; pass < 8 && s.live_wave[w]; ++pass) {
+              bool ran = false;
+              for (unsigned t = lo; t < hi; ++t) {
+                Fiber& fb = s.fibers[t];
+                if (fb.done || (fb.at_block_barrier && fb.wait_gen == s.bar_gen && s.bar_count < s.live_block)) continue;
+                s.cur = t;
+                swapcontext(&s.sched, &fb.ctx);
+                ran = true;
+              }
+              if (!ran) break;
+            }
           }
         }
       }

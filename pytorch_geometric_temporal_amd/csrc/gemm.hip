@@ -99,9 +99,14 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, pgt_f32x16 (&
   const int lo = lane & 31, hi = lane >> 5;
   constexpr int EPW = 32 * WN + 4;                                   // floats per staged row (+4: rows on different banks)
   constexpr bool EPI_LDS = LDS_BYTES >= 4 * 16 * EPW * (int)sizeof(float);
-  const int ev = g.accumulate ? 1 : g.c_seg_n == g.N ? 4 : g.epi ? 1 : 2;   // widest store the layout allows
-  if (EPI_LDS && ev > 1 && g.ldc % ev == 0 && g.c_seg_n % ev == 0 && g.c_seg_stride % ev == 0 &&
-      (reinterpret_cast<uintptr_t>(g.C) % (4 * ev)) == 0) {
+  // widest store the layout allows: float4 for a plain 16-byte aligned matrix, else float2 (a 66-wide column segment,
+  // or a plain matrix with an 8-byte aligned row stride), else scalar; the fused epilogues exist for float4 and scalar
+  auto storable = [&](int v) {
+    return g.ldc % v == 0 && g.c_seg_n % v == 0 && g.c_seg_stride % v == 0 &&
+           (reinterpret_cast<uintptr_t>(g.C) % (4 * v)) == 0;
+  };
+  const int ev = g.accumulate ? 1 : (g.c_seg_n == g.N && storable(4)) ? 4 : (!g.epi && storable(2)) ? 2 : 1;
+  if (EPI_LDS && ev > 1) {
     // each wavefront stages 16 rows x (32 * WN) columns at a time inside the (now dead) tile storage
     float* stage = lds + wave * 16 * EPW;
     const int nw0 = col0;

@@ -306,6 +306,8 @@ def gemm(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, C, ldc, c_seg_stride,
     return C
 
 
+# DCRNN backward: skip the input columns of the stack gradient when the input needs no gradient (A/B: PGT_SKIP_X=0)
+SKIP_INPUT_COLUMNS_WHEN_UNUSED = os.environ.get("PGT_SKIP_X", "1") != "0"
 # DCRNN cell forward: sigmoid / H*R and tanh / blend inside the gate GEMMs' epilogues (A/B: PGT_FUSE_GATES=0)
 FUSE_GATE_EPILOGUES = os.environ.get("PGT_FUSE_GATES", "1") != "0"
 
@@ -671,9 +673,30 @@ class DCRNNSeqFunction(torch.autograd.Function):
         dH = torch.zeros(M, O, dtype=F32, device=dev)      # running d/dH_t
         dPzr = torch.empty(T, M, 2 * O, dtype=F32, device=dev)
         dPh = torch.empty(T, M, O, dtype=F32, device=dev)
-        G = torch.empty(S, M, C, dtype=F32, device=dev)
+        G = torch.empty(S, M, C, dtype=F32, device=dev)      # (zero-filled below when its input columns stay unwritten)
         Wh_b, folded = fold_backward_weight(Wh_c, K, C)
         Wzr_b, _ = fold_backward_weight(Wzr_c, K, C)
+        # When the input needs no gradient (the usual case: X is data), only the hidden-state columns of the stack
+        # gradient are ever read.  The feature-gradient GEMMs then run on the weight rows of those columns only
+        # (S*O = 320 output columns instead of S*C = 330, i.e. 2.5 instead of 3 128-wide column tiles) and write into
+        # the stack gradient at column offset Fin; the input columns of G stay unwritten and feed nothing.
+        skip_x = (SKIP_INPUT_COLUMNS_WHEN_UNUSED and not need_x and Fin > 0 and Fin % 2 == 0 and O % 4 == 0 and S > 1)
+        if skip_x:
+            WhH = Wh_b.view(S, C, O)[:, Fin:, :].reshape(S * O, O).contiguous()
+            WzrH = Wzr_b.view(S, C, 2 * O)[:, Fin:, :].reshape(S * O, 2 * O).contiguous()
+            G.zero_()                                                # the unwritten input columns must stay finite
+            Gh = G.view(-1)[Fin:]                                    # same buffer, rows shifted by Fin floats
+            NH = S * O
+            n1 = (NH // 128) * 128 if (NH % 128 != 0 and NH > 128 and ((NH // 128) * 128) % O == 0) else NH
+
+        def feature_grad(dP, Wfull, WH, Kd):
+            """G[s] = dP W_s^T for every stack segment (the stack adjoint consumes G in place)."""
+            if not skip_x:
+                gemm(dP, Kd, 0, 1, Kd, Wfull, 1, Kd, G, C, M * C, C, None, M, S * C)
+                return
+            gemm(dP, Kd, 0, 1, Kd, WH, 1, Kd, Gh, C, M * C, O, None, M, n1)
+            if n1 < NH:                                              # the narrow remainder: 64-wide tiles, no padding
+                gemm(dP, Kd, 0, 1, Kd, WH[n1:], 1, Kd, Gh[(n1 // O) * M * C:], C, M * C, O, None, M, NH - n1)
         B = ctx.B
         seg = T * M * C
         need_wzr = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
@@ -708,7 +731,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             # d/dH_t = dOut[t] + running state gradient, summed inside the gate-backward kernel
             _gru_h_bwd(dOut[t], ZR[t], Hp, HT[t], dPh[t], dPzr[t], dH, accumulate=False, dHn2=dH)
             # candidate conv: dT = dPh Wh^T ; adjoint of the stack
-            gemm(dPh[t], O, 0, 1, O, Wh_b, 1, O, G, C, M * C, C, None, M, S * C)
+            feature_grad(dPh[t], Wh_b, WhH if skip_x else None, O)
             stack_bwd()
             _gru_zr_bwd(G[0], Fin, ZR[t], Hp, dPzr[t], dH)
             if overlap:                     # dPh[t], dPzr[t] are final: their weight gradients go to the side stream
@@ -720,7 +743,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             if need_x:
                 copy2d(dX[t], G[0][:, :Fin])
             # gate convs
-            gemm(dPzr[t], 2 * O, 0, 1, 2 * O, Wzr_b, 1, 2 * O, G, C, M * C, C, None, M, S * C)
+            feature_grad(dPzr[t], Wzr_b, WzrH if skip_x else None, 2 * O)
             stack_bwd()
             add2d(dH, G[0][:, Fin:])
             if need_x:

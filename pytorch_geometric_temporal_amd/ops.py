@@ -484,15 +484,35 @@ def _slab_bwd(g, G0, seg_stride, n_samples, C, K, folded):
         seg_stride, int(bool(folded)), stream_of(lib, G0)))
 
 
+class _StackWeight(torch.autograd.Function):
+    """DConv weight [2,K,C,O] -> [(2K-1)*C, O] with three copies forward and three backward (torch's slice / cat graph
+    of the same rearrangement costs ~30 tiny launches per weight and backward pass)."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        _, K, C, O = weight.shape
+        out = torch.empty((2 * K - 1) * C, O, dtype=weight.dtype, device=weight.device)
+        torch.add(weight[0, 0], weight[1, 0], out=out[:C])
+        if K > 1:
+            out[C:].view(K - 1, 2, C, O).copy_(weight[:, 1:].permute(1, 0, 2, 3))
+        ctx.shape = weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        _, K, C, O = ctx.shape
+        dw = torch.empty(ctx.shape, dtype=dout.dtype, device=dout.device)
+        dw[0, 0].copy_(dout[:C])
+        dw[1, 0].copy_(dout[:C])
+        if K > 1:
+            dw[:, 1:].copy_(dout[C:].reshape(K - 1, 2, C, O).permute(1, 0, 2, 3))
+        return dw
+
+
 def stack_weight(weight):
     """DConv weight [2,K,C,O] -> stacked [(2K-1)*C, O] matching the segment order of _stack_fwd.
     Segment 0 carries W[0,0] + W[1,0] (the reference computes X@W[0,0] + X@W[1,0], dcrnn.py:81-83)."""
-    K = weight.size(1)
-    segs = [weight[0, 0] + weight[1, 0]]
-    for k in range(1, K):
-        segs.append(weight[0, k])
-        segs.append(weight[1, k])
-    return torch.cat(segs, dim=0)
+    return _StackWeight.apply(weight)
 
 
 class DConvFunction(torch.autograd.Function):

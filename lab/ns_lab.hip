@@ -31,6 +31,21 @@ __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ a,
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
 }
 
+// read-only stream: every lane sums its float4s; one store per workgroup (keeps the loads alive)
+__global__ __launch_bounds__(256) void read_kernel(const float4* __restrict__ a, float* __restrict__ out, size_t n) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float4 v = a[i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const float s = acc.x + acc.y + acc.z + acc.w;
+  if (s == 1.2345e30f) out[blockIdx.x] = s;
+}
+// write-only stream
+__global__ __launch_bounds__(256) void write_kernel(float4* __restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
 struct Graph { std::vector<int> rp, col; std::vector<float> val; };
 
 static Graph local_graph(int n, int deg, int window, bool uniform) {
@@ -95,6 +110,10 @@ int main(int argc, char** argv) {
   for (int blocks : {1024, 2048, 4096})
     timeit(blocks == 1024 ? "copy 51.2MB->51.2MB g=1024" : blocks == 2048 ? "copy g=2048" : "copy g=4096",
            [&](int p) { hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)X[p], (float4*)Y[p], (size_t)n * F / 4); }, 8.0 * n * F);
+  for (int blocks : {1024, 2048, 4096})
+    timeit(blocks == 1024 ? "read-only 51.2MB g=1024" : blocks == 2048 ? "read-only g=2048" : "read-only g=4096",
+           [&](int p) { hipLaunchKernelGGL(read_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)X[p], Y[p], (size_t)n * F / 4); }, 4.0 * n * F);
+  timeit("write-only 51.2MB g=2048", [&](int p) { hipLaunchKernelGGL(write_kernel, dim3(2048), dim3(256), 0, st, (float4*)Y[p], (size_t)n * F / 4); }, 4.0 * n * F);
   for (int qb : {7, 6, 4, 3}) {
     pgt_tune("spmm_quad", 1); pgt_tune("spmm_quad_blocks", qb);
     char nm[64]; snprintf(nm, 64, "quad persistent, %d wg/CU", qb);

@@ -6,9 +6,10 @@ mkdir -p gpurun_out/prof
 O=gpurun_out
 (timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -15) > $O/pytest_gpu.log
 tail -3 $O/pytest_gpu.log
-(timeout 700 python scripts/gpu_probe.py ${PROBES:-spmm_ns spmm_batched gemm step}) > $O/probe.jsonl 2> $O/probe.err
+(timeout 700 python scripts/gpu_probe.py ${PROBES:-spmm_ns spmm_batched stack gemm step models}) > $O/probe.jsonl 2> $O/probe.err
 echo "probe rc=$?"
 (timeout 500 python bench.py ${BENCH_ARGS:-}) > $O/bench.json 2> $O/bench.err
+(timeout 300 python examples/dcrnn_chickenpox.py 20) > $O/example_chickenpox.log 2>&1
 echo "bench rc=$?"
 tail -c 400 $O/bench.json
 if [ "${SKIP_PROF:-0}" != "1" ]; then

@@ -738,3 +738,50 @@ def test_gemm_with_fused_gru_epilogues_is_bitwise_gemm_then_gates(backend, M, se
         assert torch.equal(out0a, out0c)
     finally:
         lib.tune("gemm_small_tiles", 0)
+
+
+@pytest.mark.gpu
+def test_gemm_schedules_agree_at_benchmark_size():
+    """Size-independent property at BASELINE.json's full size (M = 1024 x 207 rows, the 330-wide diffusion stack):
+    the pipelined kernels and the k-tiled kernels are two independent implementations of the same sums and must agree
+    to fp32 rounding (forward NN 330 -> 128 / 64, feature gradient NT 128 / 64 -> 330, weight gradient over 12 steps),
+    and the fused gate epilogues must equal GEMM-then-gate-kernel bit for bit."""
+    lib = _lib.get_lib()
+    if lib.target != "gfx950":
+        pytest.skip("product library only")
+    dev = torch.device("cuda:0")
+    M, S, C, O = 1024 * 207, 5, 66, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randn(S, M, C, generator=g).to(dev)
+    W = (torch.randn(S * C, 2 * O, generator=g) / 18).to(dev)
+    b = torch.randn(2 * O, generator=g).to(dev)
+    out = {}
+    try:
+        for db in (1, 0):
+            lib.tune("gemm_db", db)
+            lib.tune("gemm_tn_pipe", db)
+            C1 = torch.empty(M, 2 * O, device=dev)
+            ops.gemm(A, C, M * C, S, C, W, 2 * O, 1, C1, 2 * O, 0, 2 * O, b, M, 2 * O)
+            C2 = torch.empty(M, O, device=dev)
+            ops.gemm(A, C, M * C, S, C, W[:, :O].contiguous(), O, 1, C2, O, 0, O, None, M, O)
+            G = torch.empty(S, M, C, device=dev)
+            ops.gemm(C1, 2 * O, 0, 1, 2 * O, W, 1, 2 * O, G, C, M * C, C, None, M, S * C)
+            dW = torch.zeros(S * C, 2 * O, device=dev)
+            db_ = torch.zeros(2 * O, device=dev)
+            ops.gemm_tn_acc(A, C, M * C, S, C, C1, 2 * O, dW, 2 * O, db_, M, 2 * O)
+            out[db] = (C1, C2, G, dW, db_)
+    finally:
+        lib.tune("gemm_db", 1)
+        lib.tune("gemm_tn_pipe", 1)
+    names = ("NN 330->128", "NN 330->64", "NT 128->330", "dW", "db")
+    for name, x, y in zip(names, out[1], out[0]):
+        scale = float(y.abs().max())
+        tol = 2e-3 if name in ("dW", "db") else 2e-5           # dW / db: 212 k-term sums, atomics in two orders
+        assert float((x - y).abs().max()) <= tol * max(scale, 1.0), name
+    # fused epilogues at full size
+    H = torch.randn(M, O, generator=g).to(dev)
+    zr0, xhr0 = out[1][0].clone(), torch.zeros(M, C, device=dev)
+    ops._gru_zr(zr0, H, xhr0, 2)
+    zr1, xhr1 = torch.empty(M, 2 * O, device=dev), torch.zeros(M, C, device=dev)
+    ops.gemm_gru_zr(A, C, M * C, S, C, W, 2 * O, 1, b, zr1, H, xhr1, 2)
+    assert torch.equal(zr0, zr1) and torch.equal(xhr0, xhr1)

@@ -256,8 +256,10 @@ class MontevideoBusDatasetLoader(object):
             raise KeyError(f"target variable {target_var!r} is not in the dataset")
         per_var = [_widen(c.arrays["X:" + v]) for v in feature_vars]                        # each [T, N]
         stacked = np.stack(per_var, axis=2).reshape(per_var[0].shape[0], -1)              # node-major, variable-minor
-        zf = self._standardize(stacked)
-        zt = self._standardize(_widen(c.arrays["var:" + target_var]))
+        # the reference standardises TRANSPOSED VIEWS of [N, T] arrays (np.stack(...).T): numpy's pairwise summation
+        # order follows the memory layout, so the same layout is needed to get the same last bit
+        zf = self._standardize(np.ascontiguousarray(stacked.T).T)
+        zt = self._standardize(np.ascontiguousarray(_widen(c.arrays["var:" + target_var]).T).T)
         n = zf.shape[0] - lags
         self.features = [zf[i:i + lags, :].T for i in range(n)]
         self.targets = [zt[i + lags, :].T for i in range(len(zt) - lags)]

@@ -18,6 +18,7 @@ __device__ int g_lab_dbg = 0;
 #define PGT_LAB_KT(kt) (g_lab_dbg == 1 ? 0 : (kt))
 #define PGT_LAB_SKIP_EPI() (g_lab_dbg == 2)
 int pgt_spmm_tune(const char*, int) { return 0; }
+void pgt_slab_set_pairs(int) {}
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm.hip"
 

@@ -27,8 +27,14 @@ constexpr int SLAB_THREADS = 1024;
 constexpr int MAXT_CAP = 8;  // tasks (row, V-float column group) per thread: N * C / V <= MAXT_CAP * 1024
                              // (the kernels are instantiated for 2 / 4 / 7 / 8 tasks per thread: register arrays)
 
+// V = 4: TWO column pairs per lane (8-byte aligned each; a row of C = 66 floats is 16.5 of them, the last lane of a
+// row carries one live pair).  The (col, val) slot read of an edge is then shared by four floats instead of two:
+// the slot reads are half of the LDS traffic of the V = 2 form (profiles/r01h_pmc_slab.csv).
+struct P2 { float2 a, b; };
 template <int V>
 struct VecT;
+template <>
+struct VecT<4> { typedef P2 type; };
 template <>
 struct VecT<2> { typedef float2 type; };
 template <>
@@ -47,6 +53,33 @@ __device__ __forceinline__ float2 axpby(float al, float2 a, float be, float2 b) 
 __device__ __forceinline__ float axpby(float al, float a, float be, float b) { return al * a + be * b; }
 __device__ __forceinline__ float2 add3(float2 a, float2 b, float2 c) { return make_float2(a.x + b.x + c.x, a.y + b.y + c.y); }
 __device__ __forceinline__ float add3(float a, float b, float c) { return a + b + c; }
+__device__ __forceinline__ P2 fma2(float w, P2 x, P2 acc) { P2 r; r.a = fma2(w, x.a, acc.a); r.b = fma2(w, x.b, acc.b); return r; }
+__device__ __forceinline__ P2 zero2(P2) { P2 r; r.a = make_float2(0.f, 0.f); r.b = r.a; return r; }
+__device__ __forceinline__ P2 axpby(float al, P2 x, float be, P2 y) { P2 r; r.a = axpby(al, x.a, be, y.a); r.b = axpby(al, x.b, be, y.b); return r; }
+__device__ __forceinline__ P2 add3(P2 x, P2 y, P2 z) { P2 r; r.a = add3(x.a, y.a, z.a); r.b = add3(x.b, y.b, z.b); return r; }
+
+// Element access at a FLOAT offset.  `full`: the second pair of a P2 exists (else it mirrors the first on loads and is
+// not stored).  The same helpers serve global memory and LDS.
+__device__ __forceinline__ void ldT(const float* p, bool, float& v) { v = *p; }
+__device__ __forceinline__ void ldT(const float* p, bool, float2& v) { v = *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ void ldT(const float* p, bool full, P2& v) {
+  v.a = *reinterpret_cast<const float2*>(p);
+  v.b = *reinterpret_cast<const float2*>(p + (full ? 2 : 0));
+}
+__device__ __forceinline__ void stT(float* p, bool, float v) { *p = v; }
+__device__ __forceinline__ void stT(float* p, bool, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void stT(float* p, bool full, P2 v) {
+  *reinterpret_cast<float2*>(p) = v.a;
+  if (full) *reinterpret_cast<float2*>(p + 2) = v.b;
+}
+// task idx -> float offset of its element inside an [N, C] block: row idx / CV, column V * (idx % CV); CV = ceil(C / V)
+template <int V>
+__device__ __forceinline__ int task_offset(int idx, int CV, int C, int& r, int& c, bool& full) {
+  r = idx / CV;
+  c = (idx - r * CV) * V;
+  full = (V < 4) || (c + 2 < C);
+  return r * C + c;
+}
 
 // LDS carve-up (bytes): two [N*C] float blocks, then the two operators
 struct SlabLds {
@@ -103,6 +136,32 @@ __device__ __forceinline__ T gather_row(const int* __restrict__ rp, const int2* 
   for (; q < e; ++q) {
     const int2 s1 = cv[q];
     acc = fma2(as_float(s1.y), *reinterpret_cast<const T*>(buf + s1.x * C + c), acc);
+  }
+  return acc;
+}
+
+// the same row sum for the two-pair element (`full`: the lane's second pair exists)
+template <typename T>
+__device__ __forceinline__ T gather_row_p2(const int* __restrict__ rp, const int2* __restrict__ cv,
+                                        const float* __restrict__ buf, int r, int c, int C, bool full) {
+  T acc = zero2(T());
+  int q = rp[r];
+  const int e = rp[r + 1];
+  for (; q + 4 <= e; q += 4) {
+    int2 s4[4];
+    T x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] = cv[q + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ldT(buf + s4[u].x * C + c, full, x[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fma2(as_float(s4[u].y), x[u], acc);
+  }
+  for (; q < e; ++q) {
+    const int2 s1 = cv[q];
+    T x1;
+    ldT(buf + s1.x * C + c, full, x1);
+    acc = fma2(as_float(s1.y), x1, acc);
   }
   return acc;
 }
@@ -288,10 +347,207 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_kernel(SlabArgs a
   }
 }
 
+// forward, two column pairs per lane (V = 4): same schedule as dconv_slab_fwd_kernel, element access by float offset
+template <int V, int LDS_BYTES, int MAXT>
+__global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_p2_kernel(SlabArgs a) {
+  typedef typename VecT<V>::type T;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const SlabLds s = carve(smem, a);
+  const int tid = threadIdx.x;
+  const int CV = (a.C + V - 1) / V;
+  const int ntask = a.N * CV;
+  stage_csr(a, s, tid);
+
+  // this thread's tasks: float offset inside a block and whether the second pair exists.  Kept in registers only for
+  // the two-pair element (a division per task); the narrower elements recompute them (offset = V * idx).
+  int off_[V == 4 ? MAXT : 1];
+  bool full_[V == 4 ? MAXT : 1];
+  if constexpr (V == 4) {
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int idx = tid + j * SLAB_THREADS;
+      int r, c;
+      off_[j] = task_offset<V>(idx < ntask ? idx : ntask - 1, CV, a.C, r, c, full_[j]);
+    }
+  }
+  auto LIVE = [&](int j) { return tid + j * SLAB_THREADS < ntask; };
+  auto OFF = [&](int j) {
+    if constexpr (V == 4) return off_[j];
+    else { const int idx = tid + j * SLAB_THREADS; return (idx < ntask ? idx : ntask - 1) * V; }
+  };
+  auto FULL = [&](int j) { if constexpr (V == 4) return full_[j]; else return true; };
+
+  // Software pipeline over samples: the T0 block of the NEXT sample is fetched into registers while this sample's
+  // hops run out of LDS, so no sample waits on its own HBM read.
+  T t0n[MAXT];
+  if ((int)blockIdx.x < a.n_samples) {
+    const float* nb = a.TS + (int64_t)blockIdx.x * a.N * a.C;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) ldT(nb + OFF(j), FULL(j), t0n[j]);
+  }
+  for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
+    float* base = a.TS + (int64_t)b * a.N * a.C;
+    T t0[MAXT], i1[MAXT];
+    __syncthreads();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous sample
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      t0[j] = t0n[j];
+      if (LIVE(j)) stT(s.bufA + OFF(j), FULL(j), t0[j]);
+    }
+    __syncthreads();
+    if (b + (int)gridDim.x < a.n_samples) {
+      const float* nb = a.TS + (int64_t)(b + (int)gridDim.x) * a.N * a.C;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) ldT(nb + OFF(j), FULL(j), t0n[j]);
+    }
+    // hop 1: T1o = P_o T0 (straight into bufB, which nobody reads during this hop), T1i = P_i T0 (registers: bufA
+    // is still being read)
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (LIVE(j)) {
+        const int idx = tid + j * SLAB_THREADS;
+        const int r = idx / CV, c = (idx - r * CV) * V;
+        const T o1 = gather_row_p2<T>(s.rp_o, s.cv_o, s.bufA, r, c, a.C, FULL(j));
+        i1[j] = gather_row_p2<T>(s.rp_i, s.cv_i, s.bufA, r, c, a.C, FULL(j));
+        stT(base + 1 * a.seg_stride + OFF(j), FULL(j), o1);
+        stT(base + 2 * a.seg_stride + OFF(j), FULL(j), i1[j]);
+        if (a.K >= 3) stT(s.bufB + OFF(j), FULL(j), o1);
+      }
+    }
+    if (a.K < 3) continue;  // (uniform) K == 2: no second hop
+    __syncthreads();        // everyone has finished reading T0 out of bufA
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+      if (LIVE(j)) stT(s.bufA + OFF(j), FULL(j), i1[j]);
+    __syncthreads();
+    // hop 2: T2 = 2 P T1 - T0   (Tx_0 is never advanced in the reference, dcrnn.py:106)
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (LIVE(j)) {
+        const int idx = tid + j * SLAB_THREADS;
+        const int r = idx / CV, c = (idx - r * CV) * V;
+        const T o2 = gather_row_p2<T>(s.rp_o, s.cv_o, s.bufB, r, c, a.C, FULL(j));
+        const T i2 = gather_row_p2<T>(s.rp_i, s.cv_i, s.bufA, r, c, a.C, FULL(j));
+        stT(base + 3 * a.seg_stride + OFF(j), FULL(j), axpby(2.0f, o2, -1.0f, t0[j]));
+        stT(base + 4 * a.seg_stride + OFF(j), FULL(j), axpby(2.0f, i2, -1.0f, t0[j]));
+      }
+    }
+  }
+}
+
+// backward, two column pairs per lane (V = 4); see dconv_slab_bwd_kernel.  On the TRANSPOSED operators (a.rp_o = bwd_o ...): segments [G0 | G1o G1i | G2o G2i] -> G0 (in place)
+//   K == 3:  G1d += 2 P_d^T G2d ;  G0 += P_o^T G1o + P_i^T G1i  [ - G2o - G2i unless folded ]
+//   K == 2:  G0 += P_o^T G1o + P_i^T G1i
+template <int V, int LDS_BYTES, int MAXT>
+__global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_p2_kernel(SlabArgs a) {
+  typedef typename VecT<V>::type T;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const SlabLds s = carve(smem, a);
+  const int tid = threadIdx.x;
+  const int CV = (a.C + V - 1) / V;
+  const int ntask = a.N * CV;
+  stage_csr(a, s, tid);
+  // this thread's tasks: float offset inside a block and whether the second pair exists.  Kept in registers only for
+  // the two-pair element (a division per task); the narrower elements recompute them (offset = V * idx).
+  int off_[V == 4 ? MAXT : 1];
+  bool full_[V == 4 ? MAXT : 1];
+  if constexpr (V == 4) {
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int idx = tid + j * SLAB_THREADS;
+      int r, c;
+      off_[j] = task_offset<V>(idx < ntask ? idx : ntask - 1, CV, a.C, r, c, full_[j]);
+    }
+  }
+  auto LIVE = [&](int j) { return tid + j * SLAB_THREADS < ntask; };
+  auto OFF = [&](int j) {
+    if constexpr (V == 4) return off_[j];
+    else { const int idx = tid + j * SLAB_THREADS; return (idx < ntask ? idx : ntask - 1) * V; }
+  };
+  auto FULL = [&](int j) { if constexpr (V == 4) return full_[j]; else return true; };
+  // the pair of blocks that opens a sample's first gather phase: (G2o, G2i) for K == 3, (G1o, G1i) for K == 2;
+  // the next sample's pair is prefetched into registers while this sample is processed
+  const int64_t lead = (a.K >= 3 ? 3 : 1) * a.seg_stride;
+  T pa[MAXT], pb[MAXT];
+  auto prefetch = [&](int bb) {
+    const float* nb = a.TS + (int64_t)bb * a.N * a.C + lead;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      ldT(nb + OFF(j), FULL(j), pa[j]);
+      ldT(nb + a.seg_stride + OFF(j), FULL(j), pb[j]);
+    }
+  };
+  if ((int)blockIdx.x < a.n_samples) prefetch((int)blockIdx.x);
+
+  for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
+    float* base = a.TS + (int64_t)b * a.N * a.C;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (LIVE(j)) {
+        stT(s.bufA + OFF(j), FULL(j), pa[j]);
+        stT(s.bufB + OFF(j), FULL(j), pb[j]);
+      }
+    }
+    __syncthreads();
+    if (b + (int)gridDim.x < a.n_samples) prefetch(b + (int)gridDim.x);
+    if (a.K >= 3) {
+      T g1o[MAXT], g1i[MAXT];
+      // G1d' = G1d + 2 P_d^T G2d   (the elementwise operands are requested before the LDS gathers)
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        ldT(base + 1 * a.seg_stride + OFF(j), FULL(j), g1o[j]);
+        ldT(base + 2 * a.seg_stride + OFF(j), FULL(j), g1i[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (LIVE(j)) {
+          const int idx = tid + j * SLAB_THREADS;
+          const int r = idx / CV, c = (idx - r * CV) * V;
+          g1o[j] = axpby(2.0f, gather_row_p2<T>(s.rp_o, s.cv_o, s.bufA, r, c, a.C, FULL(j)), 1.0f, g1o[j]);
+          g1i[j] = axpby(2.0f, gather_row_p2<T>(s.rp_i, s.cv_i, s.bufB, r, c, a.C, FULL(j)), 1.0f, g1i[j]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (LIVE(j)) {
+          stT(s.bufA + OFF(j), FULL(j), g1o[j]);
+          stT(s.bufB + OFF(j), FULL(j), g1i[j]);
+        }
+      }
+      __syncthreads();
+    }
+    // G0 += P_o^T G1o' + P_i^T G1i'   [ - G2o - G2i unless folded ]
+    T g0[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) ldT(base + OFF(j), FULL(j), g0[j]);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (LIVE(j)) {
+        const int idx = tid + j * SLAB_THREADS;
+        const int r = idx / CV, c = (idx - r * CV) * V;
+        const T po = gather_row_p2<T>(s.rp_o, s.cv_o, s.bufA, r, c, a.C, FULL(j));
+        const T pi = gather_row_p2<T>(s.rp_i, s.cv_i, s.bufB, r, c, a.C, FULL(j));
+        T g = g0[j];
+        if (a.K >= 3 && !a.folded) {  // G0 -= G2o + G2i (re-read: the unfolded form is the rare one)
+          T g2o, g2i;
+          ldT(base + 3 * a.seg_stride + OFF(j), FULL(j), g2o);
+          ldT(base + 4 * a.seg_stride + OFF(j), FULL(j), g2i);
+          g = add3(g, axpby(-1.0f, g2o, 0.0f, g2o), axpby(-1.0f, g2i, 0.0f, g2i));
+        }
+        stT(base + OFF(j), FULL(j), add3(g, po, pi));
+      }
+    }
+  }
+}
+
+int g_slab_pairs = 2;   // pgt_tune("slab_pairs"): column pairs per lane of the LDS-resident stack kernels (1 | 2)
+
 int slab_supported(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i, size_t* bytes) {
   if (N <= 0 || C <= 0 || K < 2 || K > 3) return 0;
   const int V = (C % 2 == 0) ? 2 : 1;
-  if (N * (C / V) > (int64_t)MAXT_CAP * SLAB_THREADS) return 0;
+  if (N * (C / V) > (int64_t)MAXT_CAP * SLAB_THREADS) return 0;   // (the narrowest element the launch may pick)
   if (nnz_o < 0 || nnz_i < 0 || nnz_o > (1 << 24) || nnz_i > (1 << 24)) return 0;
   const size_t need = slab_lds_bytes(N, C, nnz_o, nnz_i);
   if (bytes) *bytes = need;
@@ -300,8 +556,10 @@ int slab_supported(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i
 
 template <bool BWD>
 int launch_slab(const SlabArgs& a, size_t need, pgt_stream_t stream) {
-  const int V = (a.C % 2 == 0 && pgt_aligned(a.TS, 8) && a.seg_stride % 2 == 0) ? 2 : 1;
-  const int64_t ntask = (int64_t)a.N * (a.C / V);
+  int V = (a.C % 2 == 0 && pgt_aligned(a.TS, 8) && a.seg_stride % 2 == 0) ? 2 : 1;
+  // two column pairs per lane (half the slot reads) while its register arrays fit: at most 4 tasks per thread
+  if (V == 2 && g_slab_pairs >= 2 && a.C >= 8 && (int64_t)a.N * pgt_cdiv(a.C, 4) <= 4 * SLAB_THREADS) V = 4;
+  const int64_t ntask = (int64_t)a.N * pgt_cdiv(a.C, V);
   if (ntask > (int64_t)MAXT_CAP * SLAB_THREADS) {
     pgt_set_error("pgt_dconv_stack_slab: block too large for the scalar path");
     return PGT_ERR_INVALID;
@@ -314,6 +572,11 @@ int launch_slab(const SlabArgs& a, size_t need, pgt_stream_t stream) {
     if (BWD) PGT_LAUNCH((dconv_slab_bwd_kernel<V_, L_, T_>), grid, block, stream, a);                 \
     else PGT_LAUNCH((dconv_slab_fwd_kernel<V_, L_, T_>), grid, block, stream, a);                     \
   } while (0)
+#define PGT_SLAB_P2(L_, T_)                                                                           \
+  do {                                                                                                \
+    if (BWD) PGT_LAUNCH((dconv_slab_bwd_p2_kernel<4, L_, T_>), grid, block, stream, a);               \
+    else PGT_LAUNCH((dconv_slab_fwd_p2_kernel<4, L_, T_>), grid, block, stream, a);                   \
+  } while (0)
 #define PGT_SLAB_T(V_, L_)                                                                            \
   do {                                                                                                \
     if (tpt <= 2) PGT_SLAB_K(V_, L_, 2);                                                              \
@@ -321,9 +584,16 @@ int launch_slab(const SlabArgs& a, size_t need, pgt_stream_t stream) {
     else if (tpt <= 7) PGT_SLAB_K(V_, L_, 7);                                                         \
     else PGT_SLAB_K(V_, L_, 8);                                                                       \
   } while (0)
-  if (need <= 64 * 1024) { if (V == 2) PGT_SLAB_T(2, 64 * 1024); else PGT_SLAB_T(1, 64 * 1024); }
-  else { if (V == 2) PGT_SLAB_T(2, 160 * 1024); else PGT_SLAB_T(1, 160 * 1024); }
+  if (V == 4) {                                        // at most 4 tasks per thread (checked above)
+    if (need <= 64 * 1024) { if (tpt <= 2) PGT_SLAB_P2(64 * 1024, 2); else PGT_SLAB_P2(64 * 1024, 4); }
+    else { if (tpt <= 2) PGT_SLAB_P2(160 * 1024, 2); else PGT_SLAB_P2(160 * 1024, 4); }
+  } else if (need <= 64 * 1024) {
+    if (V == 2) PGT_SLAB_T(2, 64 * 1024); else PGT_SLAB_T(1, 64 * 1024);
+  } else {
+    if (V == 2) PGT_SLAB_T(2, 160 * 1024); else PGT_SLAB_T(1, 160 * 1024);
+  }
 #undef PGT_SLAB_T
+#undef PGT_SLAB_P2
 #undef PGT_SLAB_K
   return pgt_check_launch(BWD ? "pgt_dconv_stack_slab_bwd_f32" : "pgt_dconv_stack_slab_f32");
 }
@@ -348,6 +618,8 @@ int slab_entry(bool bwd, const pgt_csr* o, const pgt_csr* i, int64_t nnz_o, int6
 }
 
 }  // namespace
+
+void pgt_slab_set_pairs(int v) { g_slab_pairs = v; }
 
 extern "C" int pgt_dconv_stack_slab_fits(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i) {
   return slab_supported(N, C, K, nnz_o, nnz_i, nullptr);

@@ -489,10 +489,15 @@ def test_locality_hint_is_measured_per_operator(backend):
 
 # ------------------------------------------------------------------------------------------------ LDS-resident diffusion stack
 
-@pytest.mark.parametrize("n,C,K,B", [(20, 36, 2, 3), (40, 6, 3, 5), (33, 7, 3, 2), (207, 66, 3, 2)])
-def test_slab_stack_equals_per_hop_launches(backend, n, C, K, B):
+@pytest.mark.parametrize("n,C,K,B", [(20, 36, 2, 3), (40, 6, 3, 5), (33, 7, 3, 2), (207, 66, 3, 2), (25, 10, 3, 4)])
+@pytest.mark.parametrize("pairs", [2, 1])
+def test_slab_stack_equals_per_hop_launches(backend, n, C, K, B, pairs, request):
     """pgt_dconv_stack_slab(_bwd)_f32 (batch-major rows, one launch) against the per-hop pgt_spmm_csr_f32 path
-    (node-major rows), forward and adjoint, folded and unfolded."""
+    (node-major rows), forward and adjoint, folded and unfolded; with one and with two column pairs per lane (the
+    two-pair kernels take even C >= 8: C = 66 and C = 10 end a row on a half-filled lane)."""
+    lib = _lib.get_lib()
+    lib.tune("slab_pairs", pairs)
+    request.addfinalizer(lambda: lib.tune("slab_pairs", 2))
     if backend.name == "emu" and n > 100:
         B = 1
     ei, ew = syn.sensor_graph(n, 6 * n, seed=n, symmetric=False)

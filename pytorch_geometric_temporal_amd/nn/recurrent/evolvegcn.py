@@ -27,14 +27,15 @@ class GCNConv_Fixed_W(torch.nn.Module):
         self.cached = cached
         self.add_self_loops = add_self_loops
         self.normalize = normalize
-        if not normalize:
-            raise NotImplementedError("GCNConv_Fixed_W(normalize=False): un-normalised propagation is not built yet")
 
     def reset_parameters(self):
         pass
 
     def forward(self, W, x, edge_index, edge_weight=None):
-        g = ops.gcn_graph(edge_index, edge_weight, x.size(-2), self.improved, self.add_self_loops)
+        if self.normalize:
+            g = ops.gcn_graph(edge_index, edge_weight, x.size(-2), self.improved, self.add_self_loops)
+        else:                                      # the edge list as it is: no gcn_norm, no self-loops (:83-90 skipped)
+            g = ops.raw_graph(edge_index, edge_weight, x.size(-2))
         h = ops.linear(x, W, None)                 # x @ W  (evolvegcno.py:92)
         return ops.propagate(g, h)
 

@@ -196,6 +196,36 @@ def gcn_graph(edge_index, edge_weight, num_nodes, improved=False, add_self_loops
                                             add_self_loops=add_self_loops))
 
 
+class RawGraph:
+    """The edge list as it is (no normalisation, no added self-loops): out[i] = sum_{e: col_e = i} w_e x[row_e], the
+    propagate of `GCNConv_Fixed_W(normalize=False)` (evolvegcno.py:92-101), and its transpose for the gradient.
+    Built with device sorts (stable by destination / by source: slots keep the edge order inside a row, like the
+    prep kernels); `.fwd` / `.bwd` are what `propagate` takes."""
+
+    def __init__(self, edge_index, edge_weight, num_nodes):
+        lib = _lib.get_lib()
+        ei, ew = _edge_inputs(lib, edge_index, edge_weight)
+        dev, E, N = ei.device, ei.size(1), int(num_nodes)
+        if E and (int(ei.min()) < 0 or int(ei.max()) >= N):
+            raise IndexError(f"edge_index has endpoint(s) outside [0, {N})")
+        w = ew if ew is not None else torch.ones(E, dtype=F32, device=dev)
+        self.N, self.E, self.device = N, E, dev
+        self.fwd, self.bwd = Csr(N, E, dev), Csr(N, E, dev)
+        for csr, row, col in ((self.fwd, ei[1], ei[0]), (self.bwd, ei[0], ei[1])):
+            order = torch.argsort(row, stable=True)
+            counts = torch.bincount(row, minlength=N)
+            csr.rowptr[1:] = torch.cumsum(counts, 0).to(I32)
+            if E:
+                csr.col[:E] = col[order].to(I32)
+                csr.val[:E] = w[order]
+        measure_locality((self.fwd, self.bwd))
+
+
+def raw_graph(edge_index, edge_weight, num_nodes):
+    return GRAPH_CACHE.get("raw", edge_index, edge_weight, (int(num_nodes),),
+                           lambda: RawGraph(edge_index, edge_weight, num_nodes))
+
+
 def cheb_graph(edge_index, edge_weight, num_nodes, normalization="sym", lambda_max=None, variant=0):
     lam = None if lambda_max is None else float(lambda_max)
     return GRAPH_CACHE.get("cheb", edge_index, edge_weight, (int(num_nodes), normalization, lam, int(variant)),

@@ -273,6 +273,41 @@ def test_evolvegcn_backward_through_the_weight_recurrence(backend):
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
 
 
+def test_evolvegcn_without_normalisation_propagates_the_raw_edge_list(backend):
+    """normalize=False (evolvegcno.py:83-101 with the gcn_norm branch skipped): out = A_raw (X W), A_raw[i, j] = sum of
+    the weights of edges j -> i, duplicates summed, no self-loops added; forward and gradients against a dense fp64
+    evaluation, and against the reference's own GCNConv_Fixed_W when /root/reference is present."""
+    from pytorch_geometric_temporal_amd.nn.recurrent.evolvegcn import GCNConv_Fixed_W
+    torch.manual_seed(3)
+    n, Fdim = 23, 6
+    ei_np, ew_np = syn.sensor_graph(n, 90, seed=2, symmetric=False)
+    ei = torch.from_numpy(ei_np)
+    ei = torch.cat([ei, ei[:, :7]], dim=1)                   # duplicate edges
+    for ew in (torch.cat([torch.from_numpy(ew_np), torch.rand(7)]), None):
+        X, W = torch.randn(n, Fdim), torch.randn(Fdim, Fdim)
+        Xd, Wd = backend.t(X).requires_grad_(), backend.t(W).requires_grad_()
+        conv = GCNConv_Fixed_W(Fdim, Fdim, normalize=False)
+        out = conv(Wd, Xd, backend.t(ei), None if ew is None else backend.t(ew))
+        w64 = torch.ones(ei.size(1), dtype=torch.float64) if ew is None else ew.double()
+        A = torch.zeros(n, n, dtype=torch.float64).index_put_((ei[1], ei[0]), w64, accumulate=True)
+        X64, W64 = X.double().requires_grad_(), W.double().requires_grad_()
+        ref = A @ (X64 @ W64)
+        assert_close_with_nonfinite(out, ref, 2e-5, 2e-5, "raw propagate")
+        g = torch.randn(n, Fdim)
+        (out * backend.t(g)).sum().backward()
+        (ref * g.double()).sum().backward()
+        assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 5e-5, "dX")
+        assert_close_with_nonfinite(Wd.grad, W64.grad, 5e-5, 5e-5, "dW")
+        from oracle import ref_import
+        if ref_import.reference_available():
+            rconv = ref_import.load("nn.recurrent.evolvegcno").GCNConv_Fixed_W(Fdim, Fdim, normalize=False)
+            with torch.no_grad():
+                assert_close_with_nonfinite(out, rconv(W, X, ei, ew), 2e-5, 2e-5, "reference module")
+    m = EvolveGCNO(Fdim, normalize=False).to(backend.device)
+    y = m(backend.t(torch.randn(n, Fdim)), backend.t(ei))
+    assert y.shape == (n, Fdim) and torch.isfinite(y).all()
+
+
 # ------------------------------------------------------------------------------------------------ ChebConvAttention
 
 def test_chebconvattention_forward_matches_reference_fixture(backend):

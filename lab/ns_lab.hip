@@ -126,9 +126,15 @@ int main(int argc, char** argv) {
     timeit(rows == 64 ? "plain tile TR=64" : "plain tile TR=32", [&](int p) { pgt_spmm_csr_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);
   }
   pgt_tune("spmm_tile_rows", 64);
-  for (int cu : {1, 2}) {
+  for (int tpw : {1, 0, 2, 10}) {
+    pgt_tune("spmm_band_cu", 4); pgt_tune("spmm_wtile_tpw", tpw);
+    char nm[64]; snprintf(nm, 64, "window tile TR=32 tiles/wg=%d", tpw);
+    timeit(nm, [&](int p) { pgt_spmm_csr_band_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, 32, st); }, alg);
+  }
+  pgt_tune("spmm_wtile_tpw", 0);
+  for (int cu : {3, 1}) {
     pgt_tune("spmm_band_cu", cu);
-    char nm[64]; snprintf(nm, 64, "band per-CU workgroup x%d", cu);
+    char nm[64]; snprintf(nm, 64, cu >= 3 ? "window tile (band_cu=%d)" : "band per-CU workgroup x%d", cu);
     timeit(nm, [&](int p) { pgt_spmm_csr_band_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, 32, st); }, alg);
   }
   pgt_tune("spmm_band_cu", 0);

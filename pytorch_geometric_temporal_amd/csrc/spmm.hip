@@ -34,7 +34,11 @@ int g_quad = 0;        // F = 64: 1 = barrier-free persistent quad kernel instea
 int g_quad_blocks = 7; // quad kernel: resident workgroups per CU (70 VGPRs -> 7 wavefronts per SIMD)
 int g_band_blocks = 3;  // band kernel: resident workgroups per CU the chunking aims at (<= 3: 160-VGPR kernel)
 int g_band_xcd = 1;     // band kernel: contiguous chunk ranges per XCD
-int g_band_cu = 1;      // band kernel: 1 = one 1024-thread workgroup per CU (spmm_band64_cu_kernel), 0 = small workgroups
+int g_band_cu = 4;      // locality-ordered F = 64 schedule: 4 = 32-row tiles with the X window in LDS (spmm_wtile64_kernel,
+                        // measured best), 3 = 64-row tiles, 1 / 2 = one / two 1024-thread workgroups per CU, 0 = small ring workgroups
+int g_wtile_wgs = 0;     // window-tile kernel: persistent workgroups per CU (0 = 5)
+int g_wtile_tpw = 1;     // window-tile kernel: tiles per workgroup (1 = independent workgroups, measured best: 31.5 us;
+                         // 0 = persistent, g_wtile_wgs per CU with the next tile prefetched: 36.4 us)
 int g_band_nblk = 0;    // test hook: number of workgroups of the per-CU band kernel (0 = one or two per CU)
 
 template <int VEC>
@@ -171,6 +175,134 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
     stv<VEC>(Y + (int64_t)(r0 + r) * ldy + f, out);
   }
   PGT_TRACE_MARK(3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// spmm_wtile64_kernel<TR, H> — F = 64, locality-ordered operator: the row-tile schedule with the tile's X WINDOW in
+// LDS.  The degree sweep shows the row-tile kernel paying ~1.5 us per neighbour at the vector L1's
+// 64 B/clk/CU (the gather re-reads every neighbour row through L1) on top of a 24 us streaming base, while the
+// LDS-window kernels gather for free but carry a 34 us base of steps and barriers.  Here a 256-thread workgroup owns
+// TR rows and first loads rows [r0 - H, r0 + TR + H) of X into LDS with fully coalesced float4 reads, all in flight
+// at once (a window is read (TR + 2H) / TR times through L1 instead of `degree` times), together with the rowptr
+// slice; the (col, val) slots follow (they need rowptr), and the whole gather is then LDS reads (ds_read_b128, one
+// 256-byte row per 16-lane group).  Neighbours outside the window are read from global memory, so any operator is
+// handled.  No steps, no ring, two barriers: independent workgroups overlap each other's round trips.
+template <int TR, int H>
+__global__ __launch_bounds__(256) void spmm_wtile64_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    int n_rows, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt,
+    float alpha, float beta, int tiles_per_wg, int n_tiles, int xcd_remap) {
+  constexpr int WR = TR + 2 * H;             // window rows
+  constexpr int CAP = 16 * TR;               // staged slots per tile; fuller tiles read their slots from global
+  constexpr int XPT = WR * 16 / 256;         // float4 window loads per thread
+  constexpr int SPT = CAP / 256;             // staged slots per thread
+  __shared__ pgt_f4 s_x[WR * 16];
+  __shared__ int s_rp[TR + 1];
+  __shared__ int s_col[CAP];
+  __shared__ float s_val[CAP];
+
+  const int tid = threadIdx.x;
+  const int wg = xcd_remap ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int t_first = wg * tiles_per_wg;
+  const int t_last = (t_first + tiles_per_wg < n_tiles) ? t_first + tiles_per_wg : n_tiles;
+  if (t_first >= t_last) return;
+  const int l16 = tid & 15, rg = tid >> 4;   // 16 row-groups of 16 lanes
+  const float* Xl = X + l16 * 4;
+
+  // One memory phase per tile, requested while the PREVIOUS tile is gathered out of LDS: the tile's slot range comes
+  // from two wave-uniform (scalar) reads of rowptr, so the (col, val) requests go out right behind the X window and
+  // the rowptr slice instead of after a barrier and a second round trip.
+  int p_e0 = 0, p_nnz = 0, p_rp = 0;
+  pgt_f4 xw[XPT];
+  int cq[SPT];
+  float vq[SPT];
+  auto fetch = [&](int tile) {
+    const int r0 = tile * TR;
+    const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
+    p_e0 = rowptr[r0];
+    p_nnz = rowptr[r0 + nr] - p_e0;
+    p_rp = rowptr[r0 + (tid <= nr ? tid : nr)];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      int r = r0 - H + rg + 16 * i;
+      r = r < 0 ? 0 : (r < n_rows ? r : n_rows - 1);
+      xw[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(r * ldx));
+    }
+    const bool st = p_nnz <= CAP;
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+      const int q = tid + 256 * i;
+      const int qc = p_nnz > 0 ? ((st && q < p_nnz) ? p_e0 + q : p_e0) : 0;   // clamped: always a valid slot
+      cq[i] = col[qc];
+      vq[i] = val[qc];
+    }
+  };
+
+  fetch(t_first);
+  for (int tile = t_first; tile < t_last; ++tile) {
+    const int r0 = tile * TR;
+    const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
+    const int w0 = r0 - H;                   // first window row (may be negative: clamped loads, never matched)
+    const int e0 = p_e0, nnz = p_nnz;
+    const bool staged = nnz <= CAP;
+    __syncthreads();                         // the previous tile's gather no longer reads LDS
+    if (tid <= nr) s_rp[tid] = p_rp;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) s_x[(rg + 16 * i) * 16 + l16] = xw[i];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+      const int q = tid + 256 * i;
+      if (staged && q < nnz) { s_col[q] = cq[i]; s_val[q] = vq[i]; }
+    }
+    __syncthreads();
+    if (tile + 1 < t_last) fetch(tile + 1);  // in flight while this tile is gathered and stored
+    // gather out of the window, sequential fma chain in slot order (bit-identical to the row-tile kernel)
+    const int w_lo = w0 < 0 ? 0 : w0;
+    const int w_hi = (w0 + WR < n_rows) ? w0 + WR : n_rows;
+    for (int r = rg; r < nr; r += 16) {
+      const int a = s_rp[r] - e0, b = s_rp[r + 1] - e0;
+      pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+      int q = a;
+      for (; q + 4 <= b; q += 4) {
+        int c[4];
+        float v[4];
+        pgt_f4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          c[u] = staged ? s_col[q + u] : col[e0 + q + u];
+          v[u] = staged ? s_val[q + u] : val[e0 + q + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (c[u] >= w_lo && c[u] < w_hi) x[u] = s_x[(c[u] - w0) * 16 + l16];
+          else x[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c[u] * ldx));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc.x = fmaf(v[u], x[u].x, acc.x); acc.y = fmaf(v[u], x[u].y, acc.y);
+          acc.z = fmaf(v[u], x[u].z, acc.z); acc.w = fmaf(v[u], x[u].w, acc.w);
+        }
+      }
+      for (; q < b; ++q) {
+        const int c0 = staged ? s_col[q] : col[e0 + q];
+        const float v0 = staged ? s_val[q] : val[e0 + q];
+        pgt_f4 x0;
+        if (c0 >= w_lo && c0 < w_hi) x0 = s_x[(c0 - w0) * 16 + l16];
+        else x0 = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c0 * ldx));
+        acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y);
+        acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
+      }
+      pgt_f4 out;
+      if (T != nullptr) {
+        const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + r) * ldt) + l16 * 4);
+        out = pgt_mk4(alpha * acc.x + beta * t.x, alpha * acc.y + beta * t.y, alpha * acc.z + beta * t.z,
+                      alpha * acc.w + beta * t.w);
+      } else {
+        out = pgt_mk4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+      }
+      *reinterpret_cast<pgt_f4*>(Y + (unsigned)((r0 + r) * ldy) + l16 * 4) = out;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -825,6 +957,8 @@ int pgt_spmm_tune(const char* key, int value) {
   if (strcmp(key, "spmm_band_blocks") == 0) { g_band_blocks = value > 0 ? value : 1; return 1; }
   if (strcmp(key, "spmm_band_xcd") == 0) { g_band_xcd = value; return 1; }
   if (strcmp(key, "spmm_band_cu") == 0) { g_band_cu = value; return 1; }
+  if (strcmp(key, "spmm_wtile_wgs") == 0) { g_wtile_wgs = value; return 1; }
+  if (strcmp(key, "spmm_wtile_tpw") == 0) { g_wtile_tpw = value; return 1; }
   if (strcmp(key, "spmm_band_nblk") == 0) { g_band_nblk = value > 0 ? value : 0; return 1; }
   return 0;
 }
@@ -872,6 +1006,23 @@ extern "C" int pgt_spmm_csr_band_f32(const int32_t* rowptr, const int32_t* col, 
   if (halo <= 0 || halo > 96 || F != 64 || vp.v != 4 || n_rows * max_ld >= ((int64_t)1 << 31))
     return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   const int ring = halo <= 32 ? 128 : 256;
+  if (g_band_cu == 4 && halo > 32)           // a +-96 window is 224 rows of LDS per 32-row tile: the plain tiles win
+    return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
+  if (g_band_cu == 3 || g_band_cu == 4) {    // row tiles with the X window in LDS (3: 64-row tiles, 4: 32-row tiles)
+    const int tr = g_band_cu == 3 ? 64 : 32;
+    const int64_t n_tiles = pgt_cdiv(n_rows, tr);
+    // persistent workgroups, a contiguous run of tiles each (the next tile's memory phase overlaps this tile's gather)
+    const int64_t resident = 256 * (int64_t)(g_wtile_wgs > 0 ? g_wtile_wgs : 5);
+    const int64_t tpw = g_wtile_tpw > 0 ? g_wtile_tpw : pgt_cdiv(n_tiles, resident);
+    dim3 grid((unsigned)pgt_cdiv(n_tiles, tpw)), block(256);
+#define PGT_WTILE_GO(TR_, H_)                                                                                      \
+  PGT_LAUNCH((spmm_wtile64_kernel<TR_, H_>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y,   \
+             (int)ldy, T, (int)ldt, alpha, beta, (int)tpw, (int)n_tiles, g_band_xcd)
+    if (halo <= 32) { if (tr == 64) PGT_WTILE_GO(64, 32); else PGT_WTILE_GO(32, 32); }
+    else { if (tr == 64) PGT_WTILE_GO(64, 96); else PGT_WTILE_GO(32, 96); }
+#undef PGT_WTILE_GO
+    return pgt_check_launch("pgt_spmm_csr_band_f32");
+  }
   if (g_band_cu && pgt_cdiv(n_rows, g_band_nblk > 0 ? g_band_nblk : 256 * (int64_t)(g_band_cu >= 2 ? 2 : 1)) + 4 <= 2048) {
     // one 1024-thread workgroup per CU (g_band_cu == 2: two): each owns a contiguous 1/256 (1/512) of the rows
     int64_t nblk = g_band_nblk > 0 ? g_band_nblk : 256 * (int64_t)(g_band_cu >= 2 ? 2 : 1);

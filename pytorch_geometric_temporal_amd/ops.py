@@ -36,10 +36,13 @@ class Csr:
 
 
 BAND_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; keep the plain schedule
-# The LDS-window ("band") schedule is correct for every operator and selected per call through `halo`.  Measured on
-# MI355X at N = 200 000, F = 64 it ties the row-tile schedule (33-37 us vs 32-35 us at in-degree 8), so
-# the measured locality hint is only APPLIED when this switch is on; spmm(..., halo=...) always overrides.
-USE_BAND_SCHEDULE = False
+# The LDS-window schedules are correct for every operator and selected per call through `halo` (the operator's
+# measured locality: 3/4 of the slots within +-32 / +-96 rows).  The best of them, 32-row tiles with the X window in
+# LDS (spmm_wtile64_kernel), measures 31.7 us against 34.2 us for the plain row tiles in the C++ lab harness
+# (N = 200 000, F = 64, in-degree 8) but 34.4 us against 32.9 us inside bench.py (rocprofv3 kernel durations of the
+# same kernels on the same graph).  The hint is therefore only APPLIED on request: PGT_BAND=1 or
+# spmm(..., halo=...), which always overrides.
+USE_BAND_SCHEDULE = os.environ.get("PGT_BAND", "0") == "1"
 # Weight-gradient GEMMs of step t on a side stream while the main stream runs the BPTT chain of step t-1 (same
 # arithmetic, fp32 atomics into dW either way).  Measured on MI355X at METR-LA shape, B = 1024: 23.81 ms per step with
 # the overlap vs 23.79 ms with one whole-sequence weight-gradient GEMM at the end -> off by default.

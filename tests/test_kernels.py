@@ -422,14 +422,21 @@ def banded_csr(n, deg_lo, deg_hi, window, seed, device, far_frac=0.0, heavy_row=
     return csr
 
 
-@pytest.mark.parametrize("halo,window,n", [(32, 32, 333), (32, 40, 1000), (96, 96, 700), (96, 20, 64), (32, 5, 17)])
-def test_spmm_band_window_matches_plain_and_reference(backend, halo, window, n):
+@pytest.mark.parametrize("halo,window,n,sched", [(32, 32, 333, 4), (32, 40, 1000, 4), (96, 96, 700, 4), (32, 5, 17, 4),
+                                                 (32, 40, 1000, 41), (96, 96, 700, 3), (96, 20, 64, 3), (32, 32, 333, 3),
+                                                 (32, 40, 1000, 1), (96, 96, 700, 1), (32, 5, 17, 1),
+                                                 (32, 32, 333, 0), (96, 96, 700, 0)])
+def test_spmm_band_window_matches_plain_and_reference(backend, halo, window, n, sched):
+    """Every locality schedule of pgt_spmm_csr_band_f32 (sched = pgt_tune spmm_band_cu: 4 window tiles of 32 rows
+    [41: persistent, three tiles per workgroup], 3 window tiles of 64 rows, 1 one workgroup per CU, 0 ring workgroups)
+    against the plain schedule (bit-identical) and the fp64 reference, with neighbours outside the window."""
     lib = _lib.get_lib()
+    lib.tune("spmm_band_cu", sched % 10)
+    lib.tune("spmm_wtile_tpw", 3 if sched == 41 else 1)
     if backend.name == "hip":
         n *= 37
-    elif n > 17:
-        # the per-CU kernel launches 256 workgroups of 1024 lanes whatever n is: 15-25 s per launch on the fibre-based
-        # test double.  A 7-workgroup grid runs the same code (the smallest case keeps the full grid).
+    elif n > 17 and sched == 1:
+        # the per-CU kernel launches 256 workgroups of 1024 lanes whatever n is; a 7-workgroup grid runs the same code
         lib.tune("spmm_band_nblk", 7)
     try:
         csr = banded_csr(n, 0, 20, window, seed=n, device=backend.device, far_frac=0.05, heavy_row=min(n - 1, 70))
@@ -450,6 +457,8 @@ def test_spmm_band_window_matches_plain_and_reference(backend, halo, window, n):
         assert_close_with_nonfinite(Tc, spmm_reference(csr, X, T, 2.0, 1.0), 5e-5, 1e-5, "band aliased")
     finally:
         lib.tune("spmm_band_nblk", 0)
+        lib.tune("spmm_band_cu", 4)
+        lib.tune("spmm_wtile_tpw", 1)
 
 
 def test_spmm_band_strided_nonfinite_and_fallback_shapes(backend):
@@ -694,10 +703,12 @@ def test_spmm_band_per_cu_kernel_multi_step_chunks(backend, nblk, n, window):
     Yp, Yb = torch.empty_like(X), torch.full_like(X, float("nan"))
     ops.spmm(csr, X, Yp, T=T, alpha=2.0, beta=-1.0, halo=0)
     lib.tune("spmm_band_nblk", nblk)
+    lib.tune("spmm_band_cu", 1)
     try:
         ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0, halo=32)
     finally:
         lib.tune("spmm_band_nblk", 0)
+        lib.tune("spmm_band_cu", 4)
     assert torch.equal(Yp, Yb)
 
 

@@ -21,10 +21,21 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-for f in glob.glob(os.path.join(src, "stats*", "*", "*kernel_stats.csv")):
-    name = os.path.basename(os.path.dirname(os.path.dirname(f)))
-    shutil.copy(f, os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
-    print("copied", f)
+
+
+def newest(pattern):
+    """rocprofv3 names its files <pid>_*.csv and gpurun MERGES gpurun_out/ across calls, so a pass directory can hold
+    the files of several runs: only the most recent one belongs to this round's numbers."""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+for d in sorted(glob.glob(os.path.join(src, "stats*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in newest(os.path.join(d, "*", "*kernel_stats.csv")):
+        shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(d)}_kernel_stats.csv"))
+        print("copied", f)
 
 rows = []
 
@@ -37,7 +48,7 @@ def short(name):
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*counter_collection.csv")):
         acc = defaultdict(lambda: [0.0, 0.0, 0])
         with open(f) as fh:
             for r in csv.DictReader(fh):

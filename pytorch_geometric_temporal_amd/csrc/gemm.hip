@@ -973,6 +973,207 @@ __global__ __launch_bounds__(512, (16 * NH * NI + 48 <= 128) ? 4 : 2) void gemm_
   }
 }
 
+// ---- skinny shapes: the read-out layer of the examples (hidden -> 1..4 targets per node; `Linear(64, 2)` after the
+// recurrent layer at the benchmark configuration) and its two gradients.  One extent is <= 4, so there is nothing for
+// the matrix pipe to do: three streaming kernels bound by HBM (each reads or writes the [M, hidden] operand once).
+struct SkinnyArgs {
+  const float* A; int64_t lda; const float* Bw; int64_t sbk; int64_t sbn;
+  float* C; int64_t ldc; const float* bias; int M; int N; int K; int accumulate;
+  const float* G; int64_t ldg; float* db;       // weight gradient only: C = dW [K, N] (row stride ldc), db [N] or null
+  int rows_per_wg;
+};
+constexpr int SK_U = 4;   // row groups in flight per wavefront pass (4 rows each)
+
+// C[m, 0:N] (+)= A[m, 0:K] B + bias, N <= 4, K % 4 == 0, K <= 64 NC.  16 lanes x float4 cover 64 columns of a row; a
+// wavefront handles 4 rows per group, SK_U groups in flight; the weights live in registers for the whole kernel.
+template <int NC>
+__global__ __launch_bounds__(256) void gemm_skinny_n_kernel(SkinnyArgs g) {
+  const int lane = threadIdx.x & 63, q = lane & 15, rg = lane >> 4;
+  const int wave_id = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), n_waves = (int)gridDim.x * 4;
+  float4 w[NC][4];
+  bool kv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int k = 64 * c + 4 * q;
+    kv[c] = k < g.K;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const float* b = g.Bw + (int64_t)k * g.sbk + (int64_t)n * g.sbn;
+      const bool ok = kv[c] && n < g.N;
+      w[c][n] = ok ? make_float4(b[0], b[g.sbk], b[2 * g.sbk], b[3 * g.sbk]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float bq = (g.bias && q < g.N) ? g.bias[q] : 0.f;
+  for (int base = wave_id * (4 * SK_U); base < g.M; base += n_waves * (4 * SK_U)) {
+    float4 a[SK_U][NC];
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+      int row = base + 4 * u + rg;
+      row = row < g.M ? row : g.M - 1;
+      const float* ar = g.A + (int64_t)row * g.lda + 4 * q;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        a[u][c] = kv[c] ? *reinterpret_cast<const float4*>(ar + 64 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+      float s[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          t = fmaf(a[u][c].x, w[c][n].x, t);
+          t = fmaf(a[u][c].y, w[c][n].y, t);
+          t = fmaf(a[u][c].z, w[c][n].z, t);
+          t = fmaf(a[u][c].w, w[c][n].w, t);
+        }
+        s[n] = t;
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (n < g.N) {                                   // uniform
+          s[n] += __shfl_xor(s[n], 8, 16);
+          s[n] += __shfl_xor(s[n], 4, 16);
+          s[n] += __shfl_xor(s[n], 2, 16);
+          s[n] += __shfl_xor(s[n], 1, 16);
+        }
+      }
+      const int row = base + 4 * u + rg;
+      if (row < g.M && q < g.N) {
+        float v = (q == 0 ? s[0] : q == 1 ? s[1] : q == 2 ? s[2] : s[3]) + bq;
+        float* p = g.C + (int64_t)row * g.ldc + q;
+        if (g.accumulate) v += *p;
+        *p = v;
+      }
+    }
+  }
+}
+
+// C[m, 0:N] (+)= A[m, 0:K] B + bias, K <= 4, N % 4 == 0, N <= 1024: a write stream.  A thread owns one column quad
+// (its K x 4 weights and bias stay in registers) and walks down the rows: K broadcast loads and one float4 store per
+// row, consecutive lanes on consecutive quads of a row.
+__global__ __launch_bounds__(256) void gemm_skinny_k_kernel(SkinnyArgs g) {
+  const int Q = g.N >> 2, rpb = 256 / Q;              // column quads per row, rows per workgroup pass
+  const int tq = (int)threadIdx.x % Q, tr = (int)threadIdx.x / Q;
+  if (tr >= rpb) return;                              // idle lanes when Q does not divide 256
+  const int n = tq << 2;
+  float4 w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float* b = g.Bw + (int64_t)k * g.sbk + (int64_t)n * g.sbn;
+    w[k] = k < g.K ? make_float4(b[0], b[g.sbn], b[2 * g.sbn], b[3 * g.sbn]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float4 bv = g.bias ? make_float4(g.bias[n], g.bias[n + 1], g.bias[n + 2], g.bias[n + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t step = (int64_t)gridDim.x * rpb;
+#pragma unroll 4
+  for (int64_t m = (int64_t)blockIdx.x * rpb + tr; m < g.M; m += step) {
+    const float* ar = g.A + m * g.lda;
+    float4 v = bv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = k < g.K ? ar[k] : 0.f;
+      v.x = fmaf(a, w[k].x, v.x);
+      v.y = fmaf(a, w[k].y, v.y);
+      v.z = fmaf(a, w[k].z, v.z);
+      v.w = fmaf(a, w[k].w, v.w);
+    }
+    float4* p = reinterpret_cast<float4*>(g.C + m * g.ldc + n);
+    if (g.accumulate) { const float4 o = *p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    *p = v;
+  }
+}
+
+// dW[0:K, 0:N] += A[rows, 0:K]^T G[rows, 0:N], db[n] += sum_rows G[., n], N <= 4, K % 4 == 0, K <= 64 NC.  Same lane
+// map as gemm_skinny_n_kernel; every lane keeps its 4 NC x N partial sums over the rows of the workgroup's slab,
+// the four row groups of a wavefront and the four wavefronts are folded through shuffles / LDS, one atomic per
+// (k, n) and workgroup.
+template <int NC>
+__global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(SkinnyArgs g) {
+  __shared__ float red[4][16][NC][4][4];
+  const int wave = (int)threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane & 15, rg = lane >> 4;
+  const int ms = (int)blockIdx.x * g.rows_per_wg;
+  const int me = (ms + g.rows_per_wg < g.M) ? ms + g.rows_per_wg : g.M;
+  float4 acc[NC][4];
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  bool kv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    kv[c] = 64 * c + 4 * q < g.K;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[c][n] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int base = ms + wave * (4 * SK_U); base < me; base += 4 * (4 * SK_U)) {
+    float4 a[SK_U][NC];
+    float gv[SK_U][4];
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+      const int row = base + 4 * u + rg;
+      const bool rv = row < me;
+      const int rc = rv ? row : me - 1;
+      const float* ar = g.A + (int64_t)rc * g.lda + 4 * q;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        a[u][c] = kv[c] ? *reinterpret_cast<const float4*>(ar + 64 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) gv[u][n] = (rv && n < g.N) ? g.G[(int64_t)rc * g.ldg + n] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        bs[n] += gv[u][n];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          acc[c][n].x = fmaf(a[u][c].x, gv[u][n], acc[c][n].x);
+          acc[c][n].y = fmaf(a[u][c].y, gv[u][n], acc[c][n].y);
+          acc[c][n].z = fmaf(a[u][c].z, gv[u][n], acc[c][n].z);
+          acc[c][n].w = fmaf(a[u][c].w, gv[u][n], acc[c][n].w);
+        }
+      }
+  }
+  // fold the four row groups of the wavefront (lanes q, q + 16, q + 32, q + 48)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    bs[n] += __shfl_xor(bs[n], 16);
+    bs[n] += __shfl_xor(bs[n], 32);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      acc[c][n].x += __shfl_xor(acc[c][n].x, 16); acc[c][n].x += __shfl_xor(acc[c][n].x, 32);
+      acc[c][n].y += __shfl_xor(acc[c][n].y, 16); acc[c][n].y += __shfl_xor(acc[c][n].y, 32);
+      acc[c][n].z += __shfl_xor(acc[c][n].z, 16); acc[c][n].z += __shfl_xor(acc[c][n].z, 32);
+      acc[c][n].w += __shfl_xor(acc[c][n].w, 16); acc[c][n].w += __shfl_xor(acc[c][n].w, 32);
+    }
+  }
+  if (rg == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        red[wave][q][c][n][0] = acc[c][n].x; red[wave][q][c][n][1] = acc[c][n].y;
+        red[wave][q][c][n][2] = acc[c][n].z; red[wave][q][c][n][3] = acc[c][n].w;
+      }
+  }
+  __shared__ float bred[4][4];
+  if (lane == 0)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bred[wave][n] = bs[n];
+  __syncthreads();
+  // element e = ((q * NC + c) * 4 + n) * 4 + i  ->  k = 64 c + 4 q + i
+  for (int e = threadIdx.x; e < 16 * NC * 16; e += 256) {
+    const int i = e & 3, n = (e >> 2) & 3, c = (e >> 4) % NC, qq = (e >> 4) / NC;
+    const int k = 64 * c + 4 * qq + i;
+    if (n < g.N && k < g.K) {
+      const float v = red[0][qq][c][n][i] + red[1][qq][c][n][i] + red[2][qq][c][n][i] + red[3][qq][c][n][i];
+      atomicAdd(g.C + (int64_t)k * g.ldc + n, v);
+    }
+  }
+  if (g.db && threadIdx.x < (unsigned)g.N)
+    atomicAdd(g.db + threadIdx.x, bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x]);
+}
+
+int g_skinny = 1;  // pgt_tune("gemm_skinny"): streaming kernels for extents <= 4: 1 = from 1024 rows, 2 = at any size (tests), 0 = never
+
 int g_tn_pipe = 1;   // pgt_tune("gemm_tn_pipe"): 1 = pipelined whole-K kernel where it applies, 2 = at any M (tests), 0 = never
 
 int g_tn_fullk = 1;  // pgt_tune("gemm_tn_fullk"): 0 = always the k-tiled kernel, 2 = whole-K kernel at any size (tests)
@@ -990,6 +1191,7 @@ void pgt_gemm_set_tn_fullk(int v) { g_tn_fullk = v; }
 void pgt_gemm_set_db(int v) { g_db = v; }
 void pgt_gemm_set_db64(int v) { g_db64 = v; }
 void pgt_gemm_set_tn_pipe(int v) { g_tn_pipe = v; }
+void pgt_gemm_set_skinny(int v) { g_skinny = v; }
 
 static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                       const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int64_t c_seg_stride,
@@ -1009,6 +1211,28 @@ static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t
     g.epi = epi->epi; g.eO = epi->eO; g.efin = epi->efin; g.evec = epi->evec;
     g.eH = epi->eH; g.eldh = epi->eldh; g.eX = epi->eX; g.eldx = epi->eldx;
     g.eZ = epi->eZ; g.eO0 = epi->eO0; g.eld0 = epi->eld0; g.eO1 = epi->eO1; g.eld1 = epi->eld1;
+  }
+  // skinny shapes (see gemm_skinny_*_kernel): one segment in, one segment out, no fused epilogue
+  if (g_skinny && !epi && n_seg == 1 && c_seg_n >= N && (M >= 1024 || g_skinny == 2)) {
+    const int64_t K1 = seg_k;
+    SkinnyArgs sk{A, lda, Bw, sbk, sbn, C, ldc, bias, (int)M, (int)N, (int)K1, accumulate, nullptr, 0, nullptr, 0};
+    if (N <= 4 && K1 >= 16 && K1 <= 256 && K1 % 4 == 0 && lda % 4 == 0 && pgt_aligned(A, 16)) {
+      int64_t wgs = pgt_cdiv(M, 4 * 4 * SK_U);
+      if (wgs > 256 * 8) wgs = 256 * 8;
+      const int NC = (int)pgt_cdiv(K1, 64);
+      dim3 grid((unsigned)wgs), blk(256);
+      if (NC == 1) PGT_LAUNCH((gemm_skinny_n_kernel<1>), grid, blk, stream, sk);
+      else if (NC == 2) PGT_LAUNCH((gemm_skinny_n_kernel<2>), grid, blk, stream, sk);
+      else if (NC == 3) PGT_LAUNCH((gemm_skinny_n_kernel<3>), grid, blk, stream, sk);
+      else PGT_LAUNCH((gemm_skinny_n_kernel<4>), grid, blk, stream, sk);
+      return pgt_check_launch("pgt_gemm_f32");
+    }
+    if (K1 >= 1 && K1 <= 4 && N % 4 == 0 && N <= 1024 && ldc % 4 == 0 && pgt_aligned(C, 16)) {
+      int64_t wgs = pgt_cdiv(M, 256 / (N / 4));
+      if (wgs > 256 * 16) wgs = 256 * 16;
+      PGT_LAUNCH(gemm_skinny_k_kernel, dim3((unsigned)wgs), dim3(256), stream, sk);
+      return pgt_check_launch("pgt_gemm_f32");
+    }
   }
   // float2 loads of A need every (row, even k) address 8-byte aligned and no pair straddling a segment
   const bool av2 = (seg_k % 2 == 0) && (lda % 2 == 0) && (a_seg_stride % 2 == 0) && pgt_aligned(A, 8);
@@ -1118,6 +1342,20 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
   PGT_REQUIRE(Ktot == 0 || (A && dW), "pgt_gemm_tn_acc_f32: null operand");
   PGT_REQUIRE(M < ((int64_t)1 << 31) - 4096 && N < ((int64_t)1 << 31) - 128 && Ktot < ((int64_t)1 << 31) - 128,
               "pgt_gemm_tn_acc_f32: size exceeds int32 indexing");
+  if (g_skinny && N <= 4 && n_seg == 1 && seg_k >= 16 && seg_k <= 256 && seg_k % 4 == 0 && lda % 4 == 0 &&
+      pgt_aligned(A, 16) && (M >= 1024 || g_skinny == 2)) {
+    // <= 1024 workgroups (K N atomics each); slabs are multiples of the 64 rows the four wavefronts take per pass
+    int64_t rows = pgt_cdiv(pgt_cdiv(M, 1024), 16 * SK_U) * (16 * SK_U);
+    const int64_t wgs = pgt_cdiv(M, rows);
+    SkinnyArgs sk{A, lda, nullptr, 0, 0, dW, lddw, nullptr, (int)M, (int)N, (int)seg_k, 1, G, ldg, db, (int)rows};
+    const int NC = (int)pgt_cdiv(seg_k, 64);
+    dim3 grid((unsigned)wgs), blk(256);
+    if (NC == 1) PGT_LAUNCH((gemm_tn_skinny_kernel<1>), grid, blk, stream, sk);
+    else if (NC == 2) PGT_LAUNCH((gemm_tn_skinny_kernel<2>), grid, blk, stream, sk);
+    else if (NC == 3) PGT_LAUNCH((gemm_tn_skinny_kernel<3>), grid, blk, stream, sk);
+    else PGT_LAUNCH((gemm_tn_skinny_kernel<4>), grid, blk, stream, sk);
+    return pgt_check_launch("pgt_gemm_tn_acc_f32");
+  }
   // whole-K schedule: tall slabs, K up to 384; every operand element is read once per 128-wide column block
   // (measured at K = 330 inside the DCRNN training step, M = 2.5 M rows: 4.27 ms per step with this schedule for both
   //  N = 128 and N = 64, 4.68 ms when N = 64 falls back to the k-tiled kernel, 4.85 ms k-tiled only)

@@ -801,3 +801,61 @@ def test_gemm_schedules_agree_at_benchmark_size():
     zr1, xhr1 = torch.empty(M, 2 * O, device=dev), torch.zeros(M, C, device=dev)
     ops.gemm_gru_zr(A, C, M * C, S, C, W, 2 * O, 1, b, zr1, H, xhr1, 2)
     assert torch.equal(zr0, zr1) and torch.equal(xhr0, xhr1)
+
+
+@pytest.mark.parametrize("M,K,N", [(333, 64, 2), (130, 128, 1), (77, 36, 3), (260, 256, 4), (65, 100, 2), (64, 16, 4)])
+def test_gemm_streaming_kernels_for_skinny_shapes(backend, M, K, N):
+    """The read-out layer `Linear(hidden, 1..4)` and its two gradients (gemm_skinny_n / gemm_skinny_k /
+    gemm_tn_skinny kernels: an extent <= 4 leaves nothing for the matrix pipe).  Forced onto small sizes for the CPU
+    test double: ragged row groups, K not a multiple of 64, NN and NT weight layouts, bias, accumulate, padded rows."""
+    lib = _lib.get_lib()
+    if backend.name == "hip":
+        M = M * 301
+    lib.tune("gemm_skinny", 2)
+    try:
+        g = torch.Generator().manual_seed(M + K + N)
+        lda = K + 4                                                    # padded rows
+        A = torch.randn(M, lda, generator=g)
+        W = torch.randn(N, K, generator=g)                             # nn.Linear layout [out, in]
+        b = torch.randn(N, generator=g)
+        Ad, Wd, bd = A.to(backend.device), W.to(backend.device), b.to(backend.device)
+        ref = A[:, :K].double() @ W.double().t() + b.double()
+        # forward, NT weights (sbk = 1, sbn = K)
+        Y = torch.full((M, N), float("nan"), device=backend.device)
+        ops.gemm(Ad, lda, 0, 1, K, Wd, 1, K, Y, N, 0, N, bd, M, N)
+        assert_close_with_nonfinite(Y, ref, 2e-4, 1e-5, "skinny forward (NT)")
+        ops.gemm(Ad, lda, 0, 1, K, Wd, 1, K, Y, N, 0, N, None, M, N, accumulate=True)
+        assert_close_with_nonfinite(Y, 2 * ref - b.double(), 4e-4, 1e-5, "skinny forward accumulate")
+        # forward, NN weights ([K, N] row-major)
+        Wt = W.t().contiguous().to(backend.device)
+        Y2 = torch.full((M, N), float("nan"), device=backend.device)
+        ops.gemm(Ad, lda, 0, 1, K, Wt, N, 1, Y2, N, 0, N, bd, M, N)
+        assert_close_with_nonfinite(Y2, ref, 2e-4, 1e-5, "skinny forward (NN)")
+        # input gradient dX = dY W  (K of this product = N <= 4), into padded rows; untouched padding stays NaN
+        dY = torch.randn(M, N, generator=g)
+        dYd = dY.to(backend.device)
+        dX = torch.full((M, lda), float("nan"), device=backend.device)
+        if K % 4 == 0:
+            ops.gemm(dYd, N, 0, 1, N, Wd, K, 1, dX, lda, 0, K, None, M, K)
+            assert_close_with_nonfinite(dX[:, :K], dY.double() @ W.double(), 1e-4, 1e-5, "skinny input gradient")
+            assert torch.isnan(dX[:, K:]).all()
+            ops.gemm(dYd, N, 0, 1, N, Wd, K, 1, dX, lda, 0, K, None, M, K, accumulate=True)
+            assert_close_with_nonfinite(dX[:, :K], 2 * (dY.double() @ W.double()), 2e-4, 1e-5, "skinny input gradient +=")
+        # weight / bias gradient (accumulating), dW stored [K, N]
+        dW0 = torch.randn(K, N, generator=g)
+        db0 = torch.randn(N, generator=g)
+        dW, db = dW0.clone().to(backend.device), db0.clone().to(backend.device)
+        ops.gemm_tn_acc(Ad, lda, 0, 1, K, dYd, N, dW, N, db, M, N)
+        tol = 2e-4 if backend.name == "emu" else 3e-3
+        assert_close_with_nonfinite(dW, dW0.double() + A[:, :K].double().t() @ dY.double(), tol, 1e-5, "skinny dW")
+        assert_close_with_nonfinite(db, db0.double() + dY.double().sum(0), tol, 1e-5, "skinny db")
+        dW2 = dW0.clone().to(backend.device)
+        ops.gemm_tn_acc(Ad, lda, 0, 1, K, dYd, N, dW2, N, None, M, N)
+        assert_close_with_nonfinite(dW2, dW0.double() + A[:, :K].double().t() @ dY.double(), tol, 1e-5, "skinny dW, no bias")
+        # the same calls through the tile kernels agree (the dispatch is a schedule, not a different result)
+        lib.tune("gemm_skinny", 0)
+        Y3 = torch.empty(M, N, device=backend.device)
+        ops.gemm(Ad, lda, 0, 1, K, Wd, 1, K, Y3, N, 0, N, bd, M, N)
+        assert_close_with_nonfinite(Y3, ref, 2e-4, 1e-5, "tile kernel forward")
+    finally:
+        lib.tune("gemm_skinny", 1)

@@ -726,19 +726,20 @@ class DCRNNSeqFunction(torch.autograd.Function):
         dH = torch.zeros(M, O, dtype=F32, device=dev)      # running d/dH_t
         dPzr = torch.empty(T, M, 2 * O, dtype=F32, device=dev)
         dPh = torch.empty(T, M, O, dtype=F32, device=dev)
-        G = torch.empty(S, M, C, dtype=F32, device=dev)      # (zero-filled below when its input columns stay unwritten)
         Wh_b, folded = fold_backward_weight(Wh_c, K, C)
         Wzr_b, _ = fold_backward_weight(Wzr_c, K, C)
         # When the input needs no gradient (the usual case: X is data), only the hidden-state columns of the stack
-        # gradient are ever read.  The feature-gradient GEMMs then run on the weight rows of those columns only
-        # (S*O = 320 output columns instead of S*C = 330, i.e. 2.5 instead of 3 128-wide column tiles) and write into
-        # the stack gradient at column offset Fin; the input columns of G stay unwritten and feed nothing.
-        skip_x = (SKIP_INPUT_COLUMNS_WHEN_UNUSED and not need_x and Fin > 0 and Fin % 2 == 0 and O % 4 == 0 and S > 1)
+        # gradient are ever read, and the adjoint of the stack acts on every column independently.  The whole backward
+        # stack then runs on those O columns alone: the feature-gradient GEMMs use the weight rows of the hidden
+        # columns (S*O = 320 output columns instead of S*C = 330, i.e. 2.5 instead of 3 128-wide column tiles) and
+        # write [S][M][O] segments -- 256-byte rows, float4 stores, no 8-byte holes where the input columns would be
+        # -- and the stack adjoint reads and writes 64- instead of 66-wide rows.
+        skip_x = (SKIP_INPUT_COLUMNS_WHEN_UNUSED and not need_x and Fin > 0 and O % 4 == 0 and S > 1)
+        Cb, Fb = (O, 0) if skip_x else (C, Fin)                      # width of the stack gradient, its first H column
+        G = torch.empty(S, M, Cb, dtype=F32, device=dev)
         if skip_x:
             WhH = Wh_b.view(S, C, O)[:, Fin:, :].reshape(S * O, O).contiguous()
             WzrH = Wzr_b.view(S, C, 2 * O)[:, Fin:, :].reshape(S * O, 2 * O).contiguous()
-            G.zero_()                                                # the unwritten input columns must stay finite
-            Gh = G.view(-1)[Fin:]                                    # same buffer, rows shifted by Fin floats
             NH = S * O
             n1 = (NH // 128) * 128 if (NH % 128 != 0 and NH > 128 and ((NH // 128) * 128) % O == 0) else NH
 
@@ -747,9 +748,9 @@ class DCRNNSeqFunction(torch.autograd.Function):
             if not skip_x:
                 gemm(dP, Kd, 0, 1, Kd, Wfull, 1, Kd, G, C, M * C, C, None, M, S * C)
                 return
-            gemm(dP, Kd, 0, 1, Kd, WH, 1, Kd, Gh, C, M * C, O, None, M, n1)
+            gemm(dP, Kd, 0, 1, Kd, WH, 1, Kd, G, O, M * O, O, None, M, n1)
             if n1 < NH:                                              # the narrow remainder: 64-wide tiles, no padding
-                gemm(dP, Kd, 0, 1, Kd, WH[n1:], 1, Kd, Gh[(n1 // O) * M * C:], C, M * C, O, None, M, NH - n1)
+                gemm(dP, Kd, 0, 1, Kd, WH[n1:], 1, Kd, G[n1 // O], O, M * O, O, None, M, NH - n1)
         B = ctx.B
         seg = T * M * C
         need_wzr = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
@@ -775,7 +776,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             if K < 2:
                 return
             if ctx.slab:
-                _slab_bwd(g, G[0], M * C, B, C, K, folded)
+                _slab_bwd(g, G[0], M * Cb, B, Cb, K, folded)
             else:
                 _stack_bwd(g, G, K, Nn, folded)
 
@@ -786,7 +787,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             # candidate conv: dT = dPh Wh^T ; adjoint of the stack
             feature_grad(dPh[t], Wh_b, WhH if skip_x else None, O)
             stack_bwd()
-            _gru_zr_bwd(G[0], Fin, ZR[t], Hp, dPzr[t], dH)
+            _gru_zr_bwd(G[0], Fb, ZR[t], Hp, dPzr[t], dH)
             if overlap:                     # dPh[t], dPzr[t] are final: their weight gradients go to the side stream
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -798,7 +799,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             # gate convs
             feature_grad(dPzr[t], Wzr_b, WzrH if skip_x else None, 2 * O)
             stack_bwd()
-            add2d(dH, G[0][:, Fin:])
+            add2d(dH, G[0][:, Fb:])
             if need_x:
                 add2d(dX[t], G[0][:, :Fin])
         if overlap:

@@ -129,7 +129,7 @@ def test_spmm_propagates_inf_and_nan_like_index_add(backend):
 # ------------------------------------------------------------------------------------------------ GEMM
 
 @pytest.mark.parametrize("M,segs,segk,N", [(70, 1, 5, 3), (64, 1, 32, 64), (129, 5, 66, 128), (200, 3, 7, 65),
-                                           (33, 2, 1, 2), (257, 1, 100, 40)])
+                                           (33, 2, 1, 2), (257, 1, 100, 40), (131, 5, 64, 64)])
 def test_gemm_segmented(backend, M, segs, segk, N):
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(segs, M, segk, generator=g)
@@ -338,7 +338,7 @@ def test_spmm_wide_rows_xcd_chunk_mapping(backend, F_):
     assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), ATOL, RTOL, f"wide F={F_}")
 
 
-@pytest.mark.parametrize("M,segs,segk,N", [(200, 5, 66, 128), (300, 5, 66, 64), (150, 1, 128, 330), (260, 3, 7, 65),
+@pytest.mark.parametrize("M,segs,segk,N", [(200, 5, 66, 128), (300, 5, 66, 64), (150, 1, 128, 330), (260, 3, 7, 65), (210, 5, 64, 128),
                                            (129, 2, 33, 40), (260, 1, 64, 48), (140, 2, 18, 72), (70, 1, 2, 4)])
 @pytest.mark.parametrize("pipelined", [1, 2, 0])
 def test_gemm_large_tile_variants(backend, M, segs, segk, N, pipelined):

@@ -77,28 +77,28 @@ int main(int argc, char** argv) {
     float *ZR, *H, *XHR;
     CK(hipMalloc(&ZR, (size_t)M * 128 * 4)); CK(hipMalloc(&H, (size_t)M * 64 * 4)); CK(hipMalloc(&XHR, (size_t)M * C * 4));
     CK(hipMemset(H, 0, (size_t)M * 64 * 4));
-    for (int stg : {0, 16, 32, 48}) {
-      pgt_tune("gemm_db_stagger", stg);
+    for (int stg : {0, 1, 0, 1}) {
+      pgt_tune("gemm_dbp", stg);
       char nm[80];
-      snprintf(nm, 80, "stagger %2d  NT [M,64]->256 cols (66-seg)", stg);
+      snprintf(nm, 80, "dbp %d  NT [M,64]->256 cols (66-seg)", stg);
       timeit(nm, [&]() { pgt_gemm_f32(Cout, 64, 0, 1, 64, W, 1, 64, G + 2, C, (int64_t)M * C, 64, nullptr, M, 256, 0, st); }, 2.0 * M * 64 * 256);
-      snprintf(nm, 80, "stagger %2d  NT [M,128]->256 cols (66-seg)", stg);
+      snprintf(nm, 80, "dbp %d  NT [M,128]->256 cols (66-seg)", stg);
       timeit(nm, [&]() { pgt_gemm_f32(Cout, 128, 0, 1, 128, W, 1, 128, G + 2, C, (int64_t)M * C, 64, nullptr, M, 256, 0, st); }, 2.0 * M * 128 * 256);
-      snprintf(nm, 80, "stagger %2d  NT [M,64]->256 cols (64-seg, aligned)", stg);
+      snprintf(nm, 80, "dbp %d  NT [M,64]->256 cols (64-seg, aligned)", stg);
       timeit(nm, [&]() { pgt_gemm_f32(Cout, 64, 0, 1, 64, W, 1, 64, G, 64, (int64_t)M * 64, 64, nullptr, M, 256, 0, st); }, 2.0 * M * 64 * 256);
-      snprintf(nm, 80, "stagger %2d  NT [M,128]->256 cols (64-seg, aligned)", stg);
+      snprintf(nm, 80, "dbp %d  NT [M,128]->256 cols (64-seg, aligned)", stg);
       timeit(nm, [&]() { pgt_gemm_f32(Cout, 128, 0, 1, 128, W, 1, 128, G, 64, (int64_t)M * 64, 64, nullptr, M, 256, 0, st); }, 2.0 * M * 128 * 256);
-      snprintf(nm, 80, "stagger %2d  NT [M,64]->320 cols (64-seg, aligned)", stg);
+      snprintf(nm, 80, "dbp %d  NT [M,64]->320 cols (64-seg, aligned)", stg);
       timeit(nm, [&]() { pgt_gemm_f32(Cout, 64, 0, 1, 64, W, 1, 64, G, 64, (int64_t)M * 64, 64, nullptr, M, 320, 0, st); }, 2.0 * M * 64 * 320);
-      snprintf(nm, 80, "stagger %2d  NT [M,64]->256 cols (plain 256-wide rows)", stg);
+      snprintf(nm, 80, "dbp %d  NT [M,64]->256 cols (plain 256-wide rows)", stg);
       timeit(nm, [&]() { pgt_gemm_f32(Cout, 64, 0, 1, 64, W, 1, 64, G, 256, 0, 256, nullptr, M, 256, 0, st); }, 2.0 * M * 64 * 256);
-      snprintf(nm, 80, "stagger %2d  NT [M,128]->64 cols", stg);
+      snprintf(nm, 80, "dbp %d  NT [M,128]->64 cols", stg);
       timeit(nm, [&]() { pgt_gemm_f32(Cout, 128, 0, 1, 128, W, 1, 128, G + 2, C, (int64_t)M * C, 64, nullptr, M, 64, 0, st); }, 2.0 * M * 128 * 64);
-      snprintf(nm, 80, "stagger %2d  NN [M,330]->128", stg);
+      snprintf(nm, 80, "dbp %d  NN [M,330]->128", stg);
       timeit(nm, [&]() { pgt_gemm_f32(A, C, (int64_t)M * C, S, C, W, 128, 1, Cout, 128, 0, 128, bias, M, 128, 0, st); }, 2.0 * M * K * 128);
-      snprintf(nm, 80, "stagger %2d  NN+zr [M,330]->128 fused", stg);
+      snprintf(nm, 80, "dbp %d  NN+zr [M,330]->128 fused", stg);
       timeit(nm, [&]() { pgt_gemm_gru_zr_f32(A, C, (int64_t)M * C, S, C, W, 128, 1, bias, ZR, H, 64, XHR, C, 2, M, 64, st); }, 2.0 * M * K * 128);
-      snprintf(nm, 80, "stagger %2d  NN+h [M,330]->64 fused", stg);
+      snprintf(nm, 80, "dbp %d  NN+h [M,330]->64 fused", stg);
       timeit(nm, [&]() { pgt_gemm_gru_h_f32(A, C, (int64_t)M * C, S, C, W, 64, 1, bias, Cout, ZR, H, 64, XHR, 64, nullptr, 0, M, 64, st); }, 2.0 * M * K * 64);
     }
     return 0;

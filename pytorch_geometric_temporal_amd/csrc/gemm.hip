@@ -16,6 +16,8 @@
 // conflict-free for both the "lanes along k" (coalesced 128-byte row pieces of A) and "lanes along n" mappings and
 // for the MFMA operand maps lane -> A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31].
 // Small tile (M < 2048): 64 x 64, one accumulator per wavefront, so launch-bound batches still fill 256 CUs.
+#include <type_traits>
+
 #include "pgt_common.h"
 
 namespace {
@@ -578,6 +580,288 @@ __global__ __launch_bounds__(128 * WAVES_N, WNB == 1 ? 5 : WAVES_N == 2 ? 4 : 3)
   gemm_store_tile<2, WNB, (int)sizeof(st)>(g, acc, reinterpret_cast<float*>(&st[0]), m0 + wm * 64, n0 + wn * 32 * WNB, wave,
                                            lane);
   PGT_TRACE_MARK(1);
+}
+
+// Persistent form of gemm_db_kernel<2, 2, .> (128 x 128 tiles, 256 threads) with DEFERRED stores.  The one-tile kernel
+// pays its epilogue on top of its main loop (the phases add, four resident workgroups do not overlap
+// them).  Here a workgroup walks over tiles w, w + G, w + 2G, ...; when the main loop of tile i ends its accumulators
+// move to a second register set and the main loop of tile i+1 carries tile i's epilogue in its MFMA shadow, one
+// 16-row group (of the wavefront's four) per k-tile iteration: the LDS transpose of the group in k-steps 4-5 (each
+// wavefront has a private staging strip next to the operand stages), its row-contiguous stores in k-steps 6-7.  Needs
+// at least four k-tiles per tile (K >= 49) to hide a whole epilogue; whatever is left is flushed after the loop.
+// The in-loop stores must be STRAIGHT-LINE code: the memory counter is in order, and a store inside a lane-conditional
+// region makes the compiler wait for `vmcnt(0)` -- i.e. for the stores -- wherever it waits for the operand loads
+// (measured: 5x slower).  Hence: N a multiple of 128 (no column guard), rows past M redirected to row M - 1 (their
+// accumulators hold exactly that row: the A loads clamp the same way), store width a template parameter, bias and
+// the output-segment arithmetic hoisted to the tile switch, no fused epilogue.
+constexpr int DBP_EPW = 68;                       // floats per staged row of a wavefront (64 columns + 4)
+
+template <bool BKMAJ, bool EV4>
+__global__ __launch_bounds__(256, 2) void gemm_dbp_kernel(GemmArgs g, int gx, int ntiles) {
+  constexpr int WNB = 2, NTHR = 256, BM = 128, BN = 128;
+  constexpr int AS = BM + DPAD, BS = BN + DPAD;
+  struct Stage { float As[DBK][AS]; float Bs[DBK][BS]; };
+  __shared__ __attribute__((aligned(16))) Stage st[2];
+  __shared__ __attribute__((aligned(16))) float strip[4][16 * DBP_EPW];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int Ktot = g.n_seg * g.seg_k;
+  const int KT = (Ktot + DBK - 1) / DBK;
+  float* const stage = &strip[wave][0];
+  // store lane map: EV4: 16 lanes x float4 per row, 4 rows per pass; else 32 lanes x float2, 2 rows per pass
+  const int s_row = EV4 ? (lane >> 4) : (lane >> 5), s_col = EV4 ? (lane & 15) * 4 : (lane & 31) * 2;
+
+  pgt_f32x16 acc[2][2], sacc[2][2];
+  int pm0 = 0;                                             // first row of the wavefront's sub-tile held in sacc
+  float pbv[2] = {0.f, 0.f};                               // its bias (columns 32 j + lo)
+  float* pcol = g.C;                                       // C + segment / column offset of this lane's store column
+  bool have_prev = false;
+
+  // ---- deferred epilogue of the tile in sacc: group q = 2 i + h (rows 32 i + 16 h .. + 15 of the sub-tile)
+  //      piece 0 / 1: transpose columns 32 j .. (j = piece) into the strip;  piece 2 / 3: first / second half of the stores
+  auto epi_piece = [&](auto QC, auto PC) __attribute__((always_inline)) {
+    constexpr int q = decltype(QC)::value, pc = decltype(PC)::value;
+    constexpr int i = q >> 1, h = q & 1;
+    if constexpr (pc < 2) {
+      constexpr int j = pc;
+      if (pc == 0) PGT_WAVE_SYNC();                        // the previous group's reads of the strip are done
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8)
+        stage[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * DBP_EPW + j * 32 + lo] = sacc[i][j][8 * h + r8] + pbv[j];
+    } else {
+      if (pc == 2) PGT_WAVE_SYNC();
+      const int mrow0 = pm0 + i * 32 + 16 * h;
+      constexpr int RPP_S = EV4 ? 4 : 2;
+#pragma unroll
+      for (int rr = 8 * (pc - 2); rr < 8 * (pc - 2) + 8; rr += RPP_S) {
+        const int row = rr + s_row;
+        int gm = mrow0 + row;
+        gm = gm < g.M ? gm : g.M - 1;                      // duplicate of row M - 1 (identical value)
+        float* p = pcol + (int64_t)gm * g.ldc;
+        if constexpr (EV4) *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(stage + row * DBP_EPW + s_col);
+        else *reinterpret_cast<float2*>(p) = *reinterpret_cast<const float2*>(stage + row * DBP_EPW + s_col);
+      }
+    }
+  };
+  auto epi_group = [&](auto QC) __attribute__((always_inline)) {
+    epi_piece(QC, std::integral_constant<int, 0>{});
+    epi_piece(QC, std::integral_constant<int, 1>{});
+    epi_piece(QC, std::integral_constant<int, 2>{});
+    epi_piece(QC, std::integral_constant<int, 3>{});
+  };
+  auto flush_from = [&](int q0) __attribute__((always_inline)) {                          // groups q0 .. 3, not overlapped (short K / last tile)
+    if (q0 <= 0) epi_group(std::integral_constant<int, 0>{});
+    if (q0 <= 1) epi_group(std::integral_constant<int, 1>{});
+    if (q0 <= 2) epi_group(std::integral_constant<int, 2>{});
+    if (q0 <= 3) epi_group(std::integral_constant<int, 3>{});
+  };
+
+  constexpr int RPP = NTHR / 8, A_PASS = BM / RPP;
+  const int a_k = (tid & 7) * 2, a_m = tid >> 3;
+  auto a_col = [&](int p) __attribute__((always_inline)) { return 64 * (p / (64 / RPP)) + 2 * (a_m + RPP * (p % (32 / RPP))) + ((p / (32 / RPP)) & 1); };
+  constexpr int BQ = BN / 8;
+  const int bn_k = tid / BQ, bn_q = tid % BQ;
+  constexpr int NTP = 4 * BN / NTHR;
+  const int bt_n = tid % BN, bt_kq = tid / BN;
+  const char* const Bb = reinterpret_cast<const char*>(g.Bw);
+  const uint32_t sbk4 = (uint32_t)g.sbk << 2;
+  const uint32_t seg_jump = ((uint32_t)g.a_seg_stride - (uint32_t)g.seg_k) << 2;
+
+  for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+    const int tn = tile / gx, tm = tile - tn * gx;
+    const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint32_t a_row[A_PASS];
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) {
+      int gm = m0 + a_m + RPP * p;
+      gm = gm < g.M ? gm : g.M - 1;
+      a_row[p] = ((uint32_t)(gm - m0) * (uint32_t)g.lda) << 2;
+    }
+    uint32_t b_off[2];
+    if constexpr (BKMAJ) {
+      int gn = n0 + bt_n;
+      gn = gn < g.N ? gn : g.N - 1;
+      b_off[0] = ((uint32_t)gn * (uint32_t)g.sbn) << 2;
+      b_off[1] = 0;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int gn = n0 + 64 * (bn_q >> 3) + 32 * j + 4 * (bn_q & 7);
+        gn = gn < g.N ? gn : 0;
+        b_off[j] = (uint32_t)gn << 2;
+      }
+    }
+    const char* const Ab = reinterpret_cast<const char*>(g.A + (int64_t)m0 * g.lda);
+
+    int ld_k0 = 0;
+    int a_rem = a_k;
+    uint32_t a_ko = (uint32_t)a_k << 2;
+    auto advance = [&]() __attribute__((always_inline)) {
+      const int step = (ld_k0 + DBK < Ktot) ? DBK : 0;
+      ld_k0 += step;
+      a_rem += step;
+      a_ko += (uint32_t)step << 2;
+      const bool wrap = a_rem >= g.seg_k && g.n_seg > 1;
+      a_rem -= wrap ? g.seg_k : 0;
+      a_ko += wrap ? seg_jump : 0u;
+    };
+    float2 ra[A_PASS];
+    pgt_f4 rb4[2];
+    auto load_a = [&]() __attribute__((always_inline)) {
+      const uint32_t ko = (ld_k0 + a_k < Ktot) ? a_ko : 0u;
+#pragma unroll
+      for (int p = 0; p < A_PASS; ++p) ra[p] = *reinterpret_cast<const float2*>(Ab + (ko + a_row[p]));
+    };
+    auto load_b = [&]() __attribute__((always_inline)) {
+      if constexpr (BKMAJ) {
+#pragma unroll
+        for (int p = 0; p < NTP; ++p) {
+          int kg = ld_k0 + 4 * (bt_kq + (NTHR / BN) * p);
+          kg = kg < Ktot ? kg : 0;
+          rb4[p] = *reinterpret_cast<const pgt_f4*>(Bb + (((uint32_t)kg << 2) + b_off[0]));
+        }
+      } else {
+        int kg = ld_k0 + bn_k;
+        kg = kg < Ktot ? kg : 0;
+        const uint32_t ko = (uint32_t)kg * sbk4;
+#pragma unroll
+        for (int j = 0; j < WNB; ++j) rb4[j] = *reinterpret_cast<const pgt_f4*>(Bb + (ko + b_off[j]));
+      }
+    };
+    auto store_a = [&](Stage& s_, int st_k0) __attribute__((always_inline)) {
+      const bool av = st_k0 + a_k < Ktot;
+#pragma unroll
+      for (int p = 0; p < A_PASS; ++p) {
+        const int c = a_col(p);
+        s_.As[a_k][c] = av ? ra[p].x : 0.f;
+        s_.As[a_k + 1][c] = av ? ra[p].y : 0.f;
+      }
+    };
+    auto store_b = [&](Stage& s_, int st_k0) __attribute__((always_inline)) {
+      if constexpr (BKMAJ) {
+        const int c = (bt_n & ~63) + 2 * (bt_n & 31) + ((bt_n >> 5) & 1);
+#pragma unroll
+        for (int p = 0; p < NTP; ++p) {
+          const int k = 4 * (bt_kq + (NTHR / BN) * p);
+          const bool kv = st_k0 + k < Ktot;
+          s_.Bs[k][c] = kv ? rb4[p].x : 0.f;
+          s_.Bs[k + 1][c] = kv ? rb4[p].y : 0.f;
+          s_.Bs[k + 2][c] = kv ? rb4[p].z : 0.f;
+          s_.Bs[k + 3][c] = kv ? rb4[p].w : 0.f;
+        }
+      } else {
+        const bool kv = st_k0 + bn_k < Ktot;
+        const pgt_f4 z = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+        float* dst = &s_.Bs[bn_k][64 * (bn_q >> 3) + 8 * (bn_q & 7)];
+        const pgt_f4 v0 = pgt_mk4(rb4[0].x, rb4[1].x, rb4[0].y, rb4[1].y);
+        const pgt_f4 v1 = pgt_mk4(rb4[0].z, rb4[1].z, rb4[0].w, rb4[1].w);
+        *reinterpret_cast<pgt_f4*>(dst) = kv ? v0 : z;
+        *reinterpret_cast<pgt_f4*>(dst + 4) = kv ? v1 : z;
+      }
+    };
+    auto read_ops = [&](const Stage& s_, int kk, float2& a, float2& b) __attribute__((always_inline)) {
+      a = *reinterpret_cast<const float2*>(&s_.As[kk + hi][wm * 64 + 2 * lo]);
+      b = *reinterpret_cast<const float2*>(&s_.Bs[kk + hi][wn * 64 + 2 * lo]);
+    };
+    auto mma = [&](const float2& a, const float2& b) __attribute__((always_inline)) {
+      acc[0][0] = PGT_MFMA_32x32x2(a.x, b.x, acc[0][0]);
+      acc[0][1] = PGT_MFMA_32x32x2(a.x, b.y, acc[0][1]);
+      acc[1][0] = PGT_MFMA_32x32x2(a.y, b.x, acc[1][0]);
+      acc[1][1] = PGT_MFMA_32x32x2(a.y, b.y, acc[1][1]);
+    };
+
+    float2 a0, b0, a1, b1;
+    load_a();
+    load_b();
+    store_a(st[0], 0);
+    store_b(st[0], 0);
+    advance();
+    int st_k0 = ld_k0;
+    load_a();
+    load_b();
+    __syncthreads();
+    read_ops(st[0], 0, a0, b0);
+    read_ops(st[0], 2, a1, b1);
+    // one k-tile iteration; QC::value in 0..3: carries that group of the previous tile's epilogue, 4: none
+    auto iteration = [&](int t, auto QC) __attribute__((always_inline)) {
+      constexpr int q = decltype(QC)::value;
+      const Stage& cur = st[t & 1];
+      Stage& nxt = st[(t + 1) & 1];
+      // The epilogue pieces sit in k-steps 0-3: the memory counter is shared and unordered between loads and stores,
+      // so the wait for the LAST operand load of an iteration (k-step 1 of the next one) is a wait for every store
+      // issued before it -- the stores go out as early in the iteration as possible to have the longest time to land.
+      PGT_SCHED_FENCE();
+      mma(a0, b0);                                         // k-step 0
+      read_ops(cur, 4, a0, b0);
+      store_a(nxt, st_k0);
+      if constexpr (q < 4) epi_piece(QC, std::integral_constant<int, 0>{});
+      PGT_SCHED_FENCE();
+      mma(a1, b1);                                         // 1
+      read_ops(cur, 6, a1, b1);
+      store_b(nxt, st_k0);
+      if constexpr (q < 4) epi_piece(QC, std::integral_constant<int, 1>{});
+      PGT_SCHED_FENCE();
+      mma(a0, b0);                                         // 2
+      read_ops(cur, 8, a0, b0);
+      if constexpr (q < 4) epi_piece(QC, std::integral_constant<int, 2>{});
+      advance();
+      st_k0 = ld_k0;
+      load_a();
+      PGT_SCHED_FENCE();
+      mma(a1, b1);                                         // 3
+      read_ops(cur, 10, a1, b1);
+      if constexpr (q < 4) epi_piece(QC, std::integral_constant<int, 3>{});
+      load_b();
+      PGT_SCHED_FENCE();
+      mma(a0, b0);                                         // 4
+      read_ops(cur, 12, a0, b0);
+      PGT_SCHED_FENCE();
+      mma(a1, b1);                                         // 5
+      read_ops(cur, 14, a1, b1);
+      PGT_SCHED_FENCE();
+      __syncthreads();
+      PGT_SCHED_FENCE();
+      mma(a0, b0);                                         // 6
+      read_ops(nxt, 0, a0, b0);
+      PGT_SCHED_FENCE();
+      mma(a1, b1);                                         // 7
+      read_ops(nxt, 2, a1, b1);
+    };
+    int t = 0;
+    if (have_prev) {
+      if (t < KT) { iteration(t, std::integral_constant<int, 0>{}); ++t; }
+      if (t < KT) { iteration(t, std::integral_constant<int, 1>{}); ++t; }
+      if (t < KT) { iteration(t, std::integral_constant<int, 2>{}); ++t; }
+      if (t < KT) { iteration(t, std::integral_constant<int, 3>{}); ++t; }
+      if (t < 4) flush_from(t);
+    }
+    for (; t < KT; ++t) iteration(t, std::integral_constant<int, 4>{});
+    __syncthreads();                                       // the next tile's prologue rewrites stage 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sacc[i][j] = acc[i][j];
+    pm0 = m0 + wm * 64;
+    {
+      const int pn0 = n0 + wn * 64;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pbv[j] = g.bias ? g.bias[pn0 + 32 * j + lo] : 0.f;   // N % 128 == 0: in range
+      const int gn = pn0 + s_col, js = gn / g.c_seg_n;
+      pcol = g.C + (int64_t)js * g.c_seg_stride + (gn - js * g.c_seg_n);
+    }
+    have_prev = true;
+  }
+  if (have_prev) flush_from(0);
 }
 
 struct TnArgs {
@@ -1218,6 +1502,8 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(SkinnyArgs g) {
 
 int g_db_stagger = 0;  // pgt_tune("gemm_db_stagger"): delay units (s_sleep 127) per resident slot; +8: slot from HW_ID
 
+int g_dbp = 0;  // pgt_tune("gemm_dbp"): 1 = persistent deferred-store kernel for N > 64 where it applies (K >= 64)
+
 int g_skinny = 1;  // pgt_tune("gemm_skinny"): streaming kernels for extents <= 4: 1 = from 1024 rows, 2 = at any size (tests), 0 = never
 
 int g_tn_pipe = 1;   // pgt_tune("gemm_tn_pipe"): 1 = pipelined whole-K kernel where it applies, 2 = at any M (tests), 0 = never
@@ -1239,6 +1525,7 @@ void pgt_gemm_set_db64(int v) { g_db64 = v; }
 void pgt_gemm_set_tn_pipe(int v) { g_tn_pipe = v; }
 void pgt_gemm_set_skinny(int v) { g_skinny = v; }
 void pgt_gemm_set_db_stagger(int v) { g_db_stagger = v; }
+void pgt_gemm_set_dbp(int v) { g_dbp = v; }
 
 static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                       const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int64_t c_seg_stride,
@@ -1320,6 +1607,24 @@ static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t
   if (db_ok && (N > 64 || !tail64 || g_db == 2 || g_db64 == 1)) {
     const int bn = N > 64 ? 128 : 64;
     g.stagger = g_db_stagger;
+    {
+      auto storable = [&](int v) {
+        return ldc % v == 0 && c_seg_n % v == 0 && c_seg_stride % v == 0 && pgt_aligned(C, 4 * v);
+      };
+      const bool ev4 = storable(4);
+      const bool ev_ok = !accumulate && !epi && N % 128 == 0 && (ev4 || storable(2));
+      const int64_t tgx = pgt_cdiv(M, 128), tiles = tgx * (N / 128);
+      if (g_dbp && bn == 128 && ev_ok && (Ktot >= 64 || g_dbp == 2) && tiles < ((int64_t)1 << 30) && (tiles >= 1024 || g_dbp == 2)) {
+        int64_t wgs = g_dbp == 2 ? 3 : 512;                 // two resident workgroups per CU (tests: 3, several tiles each)
+        if (wgs > tiles) wgs = tiles;
+        dim3 pgrid((unsigned)wgs), pblk(256);
+        if (b_nn && ev4) PGT_LAUNCH((gemm_dbp_kernel<false, true>), pgrid, pblk, stream, g, (int)tgx, (int)tiles);
+        else if (b_nn) PGT_LAUNCH((gemm_dbp_kernel<false, false>), pgrid, pblk, stream, g, (int)tgx, (int)tiles);
+        else if (ev4) PGT_LAUNCH((gemm_dbp_kernel<true, true>), pgrid, pblk, stream, g, (int)tgx, (int)tiles);
+        else PGT_LAUNCH((gemm_dbp_kernel<true, false>), pgrid, pblk, stream, g, (int)tgx, (int)tiles);
+        return pgt_check_launch("pgt_gemm_f32");
+      }
+    }
     const int64_t gx = pgt_cdiv(M, 128), gy = pgt_cdiv(N, bn);
     PGT_REQUIRE(gy <= 65535, "pgt_gemm_f32: N too large");
     dim3 grid((unsigned)gx, (unsigned)gy);

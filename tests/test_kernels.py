@@ -859,3 +859,49 @@ def test_gemm_streaming_kernels_for_skinny_shapes(backend, M, K, N):
         assert_close_with_nonfinite(Y3, ref, 2e-4, 1e-5, "tile kernel forward")
     finally:
         lib.tune("gemm_skinny", 1)
+
+
+@pytest.mark.parametrize("M,segs,segk,N", [(700, 5, 66, 128), (520, 1, 64, 256), (390, 2, 32, 192), (1000, 1, 128, 136),
+                                           (300, 1, 48, 128)])
+def test_gemm_persistent_deferred_store_schedule(backend, M, segs, segk, N):
+    """gemm_dbp_kernel (persistent workgroups; the epilogue of tile i rides in the main loop of tile i+1) forced onto
+    three workgroups so each walks several tiles: NN with bias, NT with a segmented float2 / float4 output, the fused
+    GRU-gate epilogue (bitwise against the one-tile kernel), K with fewer than four k-tiles (flush path), ragged edges."""
+    lib = _lib.get_lib()
+    lib.tune("gemm_small_tiles", 2)
+    lib.tune("gemm_db", 2)
+    try:
+        g = torch.Generator().manual_seed(M * 3 + N)
+        dev = backend.device
+        K = segs * segk
+        A = torch.randn(segs, M, segk, generator=g)
+        W = torch.randn(K, N, generator=g)
+        b = torch.randn(N, generator=g)
+        Ad, Wd, bd = A.to(dev), W.to(dev), b.to(dev)
+        dC = torch.randn(M, N, generator=g).to(dev)
+        outs = {}
+        for dbp in (0, 2):
+            lib.tune("gemm_dbp", dbp)
+            C = torch.full((M, N), float("nan"), device=dev)
+            ops.gemm(Ad, segk, M * segk, segs, segk, Wd, N, 1, C, N, 0, N, bd, M, N)
+            Gs = torch.full((segs, M, segk), float("nan"), device=dev)
+            ops.gemm(dC, N, 0, 1, N, Wd, 1, N, Gs, segk, M * segk, segk, None, M, K)
+            O = N // 2
+            if O % 4 == 0:
+                H = torch.randn(M, O, generator=torch.Generator().manual_seed(5)).to(dev)
+                zr = torch.full((M, N), float("nan"), device=dev)
+                xhr = torch.zeros(M, O + 2, device=dev)
+                ops.gemm_gru_zr(Ad, segk, M * segk, segs, segk, Wd, N, 1, bd, zr, H, xhr, 2)
+            else:
+                zr = xhr = torch.zeros(1, device=dev)
+            outs[dbp] = (C, Gs, zr, xhr)
+        ref = torch.cat([A[j] for j in range(segs)], dim=1).double() @ W.double() + b.double()
+        assert_close_with_nonfinite(outs[2][0], ref, 1e-4, 1e-5, "persistent NN")
+        refG = (dC.cpu().double() @ W.double().t()).view(M, segs, segk).permute(1, 0, 2)
+        assert_close_with_nonfinite(outs[2][1], refG, 1e-4, 1e-5, "persistent NT, segmented output")
+        for a, c in zip(outs[0], outs[2]):                    # same sums in the same order: bitwise
+            assert torch.equal(a, c)
+    finally:
+        lib.tune("gemm_dbp", 0)
+        lib.tune("gemm_small_tiles", 0)
+        lib.tune("gemm_db", 1)

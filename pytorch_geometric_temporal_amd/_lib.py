@@ -172,6 +172,10 @@ def get_lib():
         _LIB = PgtLib(LIB_PATH)
         if _LIB.target != "gfx950":
             raise PgtError(f"{LIB_PATH} reports target {_LIB.target!r}, expected 'gfx950'")
+        # A/B switches for benchmarking without code changes: PGT_TUNE="gemm_dbp=1,slab_pairs=1" (keys of pgt_tune)
+        for item in filter(None, os.environ.get("PGT_TUNE", "").split(",")):
+            key, _, val = item.partition("=")
+            _LIB.tune(key.strip(), int(val))
     return _LIB
 
 

@@ -11,6 +11,7 @@ echo "probe rc=$?"
 (timeout 500 python bench.py ${BENCH_ARGS:-}) > $O/bench.json 2> $O/bench.err
 (timeout 300 python examples/dcrnn_chickenpox.py 20) > $O/example_chickenpox.log 2>&1
 echo "bench rc=$?"
+if [ -n "${AB_TUNE:-}" ]; then (PGT_TUNE="$AB_TUNE" timeout 200 python bench.py --no-cpu-baseline --no-ns --profile-steps 0 ${BENCH_ARGS:-}) > $O/bench_ab.json 2> $O/bench_ab.err; tail -c 300 $O/bench_ab.json; fi
 tail -c 400 $O/bench.json
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof/stats -- \

@@ -56,3 +56,49 @@ def test_only_emu_library_can_be_injected():
         target = "gfx950"
     with pytest.raises(_lib.PgtError):
         _lib._set_library_for_testing(Fake())
+
+
+def test_product_code_never_touches_the_oracle_or_the_test_double():
+    """The oracle (and the CPU test double of the kernels) are test infrastructure: nothing in the package may import,
+    load or shell out to them; bench.py only does so inside its cpu_baseline leg, __graft_entry__ only in smoke()."""
+    pkg = os.path.join(ROOT, "pytorch_geometric_temporal_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            if re.search(r"^\s*(from|import)\s+(oracle|tests|conftest)\b", src, flags=re.M) \
+                    or ("libpgt_emu" in src and f != "_lib.py"):      # _lib.py names it in the test hook's docstring
+                offenders.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    assert offenders == []
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"\boracle\b", bench)]
+    start = bench.index("def cpu_baseline")
+    end = bench.index("\ndef ", start + 1)
+    outside = [u for u in uses if not (start <= u < end)]
+    # mentions outside the function are allowed only in comments / docstrings / help strings, never as an import
+    for u in outside:
+        line = bench[bench.rfind("\n", 0, u) + 1:bench.find("\n", u)]
+        assert not re.match(r"\s*(from|import)\s", line), line
+
+
+def test_tune_switches_from_the_environment_are_parsed(monkeypatch):
+    calls = []
+
+    class Dummy:
+        target = "gfx950"
+
+        def tune(self, k, v):
+            calls.append((k, v))
+
+    monkeypatch.setenv("PGT_TUNE", "gemm_dbp=1, slab_pairs=2")
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "_preload_hip_runtime", lambda: None)
+    monkeypatch.setattr(_lib, "_check_not_stale", lambda: None)
+    monkeypatch.setattr(_lib, "PgtLib", lambda path: Dummy())
+    try:
+        _lib.get_lib()
+        assert calls == [("gemm_dbp", 1), ("slab_pairs", 2)]
+    finally:
+        _lib._LIB = None

@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(SkinnyArgs g) {
 
 int g_db_stagger = 0;  // pgt_tune("gemm_db_stagger"): delay units (s_sleep 127) per resident slot; +8: slot from HW_ID
 
-int g_dbp = 0;  // pgt_tune("gemm_dbp"): 1 = persistent deferred-store kernel for N > 64 where it applies (K >= 64)
+int g_dbp = 1;  // pgt_tune("gemm_dbp"): 1 = persistent deferred-store kernel where it applies (N % 128 == 0, K >= 64, >= 1024 tiles, plain epilogue), 2 = at any size on three workgroups (tests), 0 = never
 
 int g_skinny = 1;  // pgt_tune("gemm_skinny"): streaming kernels for extents <= 4: 1 = from 1024 rows, 2 = at any size (tests), 0 = never
 

@@ -786,9 +786,25 @@ def test_gemm_schedules_agree_at_benchmark_size():
             db_ = torch.zeros(2 * O, device=dev)
             ops.gemm_tn_acc(A, C, M * C, S, C, C1, 2 * O, dW, 2 * O, db_, M, 2 * O)
             out[db] = (C1, C2, G, dW, db_)
+        # the persistent deferred-store schedule at its natural grid (512 workgroups, 3 312 tiles): same sums in the same
+        # order as the one-tile kernel -> bitwise, on the feature-gradient shape of the training step (hidden columns
+        # only: four 64-wide output segments) and on a plain NN product
+        dP = torch.randn(M, O, generator=g).to(dev)
+        WH = (torch.randn(4 * O, O, generator=g) / 8).to(dev)
+        res = {}
+        for dbp in (1, 0):
+            lib.tune("gemm_dbp", dbp)
+            Gh = torch.full((4, M, O), float("nan"), device=dev)
+            ops.gemm(dP, O, 0, 1, O, WH, 1, O, Gh, O, M * O, O, None, M, 4 * O)
+            Cn = torch.full((M, 2 * O), float("nan"), device=dev)
+            ops.gemm(A, C, M * C, S, C, W, 2 * O, 1, Cn, 2 * O, 0, 2 * O, b, M, 2 * O)
+            res[dbp] = (Gh, Cn)
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert_close_with_nonfinite(res[1][0][3], dP.cpu().double() @ WH[3 * O:].cpu().double().t(), 1e-4, 1e-5, "persistent NT")
     finally:
         lib.tune("gemm_db", 1)
         lib.tune("gemm_tn_pipe", 1)
+        lib.tune("gemm_dbp", 1)
     names = ("NN 330->128", "NN 330->64", "NT 128->330", "dW", "db")
     for name, x, y in zip(names, out[1], out[0]):
         scale = float(y.abs().max())
@@ -902,6 +918,6 @@ def test_gemm_persistent_deferred_store_schedule(backend, M, segs, segk, N):
         for a, c in zip(outs[0], outs[2]):                    # same sums in the same order: bitwise
             assert torch.equal(a, c)
     finally:
-        lib.tune("gemm_dbp", 0)
+        lib.tune("gemm_dbp", 1)
         lib.tune("gemm_small_tiles", 0)
         lib.tune("gemm_db", 1)

@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
   if (argc > 5) pgt_tune("gemm_db", atoi(argv[5]));
   const int dbg = argc > 3 ? atoi(argv[3]) : 0;
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lab_dbg), &dbg, sizeof(int)));
-  if (only == 9) {   // start-up stagger sweep on the shapes of the training step
+  if (only == 9) {   // one-tile vs persistent deferred-store schedule on the shapes of the training step
     float *ZR, *H, *XHR;
     CK(hipMalloc(&ZR, (size_t)M * 128 * 4)); CK(hipMalloc(&H, (size_t)M * 64 * 4)); CK(hipMalloc(&XHR, (size_t)M * C * 4));
     CK(hipMemset(H, 0, (size_t)M * 64 * 4));

@@ -24,7 +24,6 @@ void pgt_gemm_set_db64(int) {}
 void pgt_slab_set_pairs(int) {}
 void pgt_gemm_set_tn_pipe(int) {}
 void pgt_gemm_set_skinny(int) {}
-void pgt_gemm_set_db_stagger(int) {}
 void pgt_gemm_set_dbp(int) {}
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/spmm.hip"

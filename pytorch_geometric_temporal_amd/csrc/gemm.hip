@@ -35,7 +35,6 @@ struct GemmArgs {
   int epi; int eO; int efin; int evec;   // evec bit 0: eH float4-loadable, 1: eX float2-storable, 2: eO0 float4, 3: eO1 float2
   const float* eH; int64_t eldh; float* eX; int64_t eldx;
   const float* eZ; float* eO0; int64_t eld0; float* eO1; int64_t eld1;
-  int stagger;   // gemm_db_kernel: start-up delay units per resident slot (see there); 0 = none
 };
 
 // ---- fused GRU epilogues: one output element / one aligned group of four (row gm, columns gn .. gn+3, all < N)
@@ -89,23 +88,6 @@ __device__ __forceinline__ float4 gemm_epi4(const GemmArgs& g, int gm, int gn, f
   return v;
 }
 
-// streaming stores for the epilogue (flag 32 of GemmArgs::stagger): the output tile is not re-read by this kernel
-#if defined(PGT_EMU)
-__device__ __forceinline__ void gemm_st4_stream(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ void gemm_st2_stream(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
-#else
-__device__ __forceinline__ void gemm_st4_stream(float* p, float4 v) {
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
-}
-__device__ __forceinline__ void gemm_st2_stream(float* p, float2 v) {
-  typedef float v2 __attribute__((ext_vector_type(2)));
-  v2 t = {v.x, v.y};
-  __builtin_nontemporal_store(t, reinterpret_cast<v2*>(p));
-}
-#endif
-
 // Epilogue shared by the tile kernels.  D map (cdna_hip_programming.md §3): col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): stored straight from the accumulators a lane writes 4 bytes per row
 // (16 rows x 128-byte pieces per instruction).  Instead each wavefront transposes its 32-row blocks through LDS (the
@@ -157,7 +139,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, pgt_f32x16 (&
               if (g.epi) v = gemm_epi4(g, gm, gn, v);    // N % 4 == 0 and one output segment with a fused epilogue (host)
               const int js = gn / g.c_seg_n;             // c_seg_n % 4 == 0: a quad never straddles segments
               float* p = g.C + (int64_t)js * g.c_seg_stride + (int64_t)gm * g.ldc + (gn - js * g.c_seg_n);
-              if (gn + 3 < g.N) { if (g.stagger & 32) gemm_st4_stream(p, v); else *reinterpret_cast<float4*>(p) = v; }
+              if (gn + 3 < g.N) *reinterpret_cast<float4*>(p) = v;
               else { p[0] = v.x; if (gn + 1 < g.N) p[1] = v.y; if (gn + 2 < g.N) p[2] = v.z; }
             }
           }
@@ -172,7 +154,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, pgt_f32x16 (&
               const float2 v = *reinterpret_cast<const float2*>(stage + row * EPW + c);
               const int js = gn / g.c_seg_n;
               float* p = g.C + (int64_t)js * g.c_seg_stride + (int64_t)gm * g.ldc + (gn - js * g.c_seg_n);
-              if (gn + 1 < g.N) { if (g.stagger & 32) gemm_st2_stream(p, v); else *reinterpret_cast<float2*>(p) = v; }   // c_seg_n even: a pair never straddles segments
+              if (gn + 1 < g.N) *reinterpret_cast<float2*>(p) = v;     // c_seg_n even: a pair never straddles segments
               else p[0] = v.x;
             }
           }
@@ -344,28 +326,6 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
 //     0-1, global loads of tile t+2 in steps 2-3.
 constexpr int DBK = 16;
 constexpr int DPAD = 4;
-// Start-up stagger.  The workgroups resident on a CU start together and, sharing its matrix pipe, stay in phase: all
-// of them load, then all multiply, then all store -- the store phase of a short-K product (the feature-gradient GEMMs:
-// K = 64 / 128, 256 output columns) is as long as its MFMA phase and nothing overlaps it.  Delaying the workgroups of
-// the FIRST resident set by their slot number (later ones inherit the offset from the workgroup they replace) lets one
-// slot store while the others multiply.
-#if defined(PGT_EMU)
-#define PGT_STAGGER(units) do { } while (0)
-#define PGT_SETPRIO_IF(c, p) do { } while (0)
-#else
-#define PGT_SETPRIO_IF(c, p) do { if (c) __builtin_amdgcn_s_setprio(p); } while (0)
-#define PGT_STAGGER(units)                                                                         \
-  do {                                                                                             \
-    const int u_ = (units);                                                                        \
-    if (u_ != 0) {                                                                                 \
-      const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x;                                   \
-      if (lin_ < 1280u) {                                                                          \
-        const int slot_ = (u_ & 8) ? (int)(__builtin_amdgcn_s_getreg(6148) & 3) : (int)((lin_ >> 8) & 3); \
-        for (int i_ = 0; i_ < slot_ * (u_ & 7); ++i_) __builtin_amdgcn_s_sleep(127);               \
-      }                                                                                            \
-    }                                                                                              \
-  } while (0)
-#endif
 #ifndef PGT_LAB_KT
 #define PGT_LAB_KT(kt) (kt)          // lab harness hooks (lab/gemm_lab.hip): truncate the k loop / skip the epilogue
 #define PGT_LAB_SKIP_EPI() false
@@ -387,7 +347,6 @@ __global__ __launch_bounds__(128 * WAVES_N, WNB == 1 ? 5 : WAVES_N == 2 ? 4 : 3)
   const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
   const int Ktot = g.n_seg * g.seg_k;
   const int KT = PGT_LAB_KT((Ktot + DBK - 1) / DBK);
-  PGT_STAGGER(g.stagger);
   PGT_TRACE_MARK(0);
 
   pgt_f32x16 acc[2][WNB];
@@ -537,7 +496,6 @@ __global__ __launch_bounds__(128 * WAVES_N, WNB == 1 ? 5 : WAVES_N == 2 ? 4 : 3)
   __syncthreads();
   read_ops(st[0], 0, a0, b0);
   read_ops(st[0], 2, a1, b1);
-  PGT_SETPRIO_IF(g.stagger & 16, 3);
   for (int t = 0; t < KT; ++t) {
     const Stage& cur = st[t & 1];
     Stage& nxt = st[(t + 1) & 1];
@@ -574,7 +532,6 @@ __global__ __launch_bounds__(128 * WAVES_N, WNB == 1 ? 5 : WAVES_N == 2 ? 4 : 3)
     mma(a1, b1);                                         // 7
     read_ops(nxt, 2, a1, b1);
   }
-  PGT_SETPRIO_IF(g.stagger & 16, 0);
   __syncthreads();                                       // the epilogue reuses the stages
   if (PGT_LAB_SKIP_EPI()) { if (acc[0][0][0] == 1.2345f) g.C[0] = 1.f; return; }
   gemm_store_tile<2, WNB, (int)sizeof(st)>(g, acc, reinterpret_cast<float*>(&st[0]), m0 + wm * 64, n0 + wn * 32 * WNB, wave,
@@ -1500,8 +1457,6 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(SkinnyArgs g) {
     atomicAdd(g.db + threadIdx.x, bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x]);
 }
 
-int g_db_stagger = 0;  // pgt_tune("gemm_db_stagger"): delay units (s_sleep 127) per resident slot; +8: slot from HW_ID
-
 int g_dbp = 1;  // pgt_tune("gemm_dbp"): 1 = persistent deferred-store kernel where it applies (N % 128 == 0, K >= 64, >= 1024 tiles, plain epilogue), 2 = at any size on three workgroups (tests), 0 = never
 
 int g_skinny = 1;  // pgt_tune("gemm_skinny"): streaming kernels for extents <= 4: 1 = from 1024 rows, 2 = at any size (tests), 0 = never
@@ -1524,7 +1479,6 @@ void pgt_gemm_set_db(int v) { g_db = v; }
 void pgt_gemm_set_db64(int v) { g_db64 = v; }
 void pgt_gemm_set_tn_pipe(int v) { g_tn_pipe = v; }
 void pgt_gemm_set_skinny(int v) { g_skinny = v; }
-void pgt_gemm_set_db_stagger(int v) { g_db_stagger = v; }
 void pgt_gemm_set_dbp(int v) { g_dbp = v; }
 
 static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
@@ -1606,7 +1560,6 @@ static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t
   const bool tail64 = tiles64 > resident64 && (tiles64 % resident64) * 2 < resident64;
   if (db_ok && (N > 64 || !tail64 || g_db == 2 || g_db64 == 1)) {
     const int bn = N > 64 ? 128 : 64;
-    g.stagger = g_db_stagger;
     {
       auto storable = [&](int v) {
         return ldc % v == 0 && c_seg_n % v == 0 && c_seg_stride % v == 0 && pgt_aligned(C, 4 * v);

@@ -71,7 +71,6 @@ void pgt_gemm_set_db64(int v);
 void pgt_slab_set_pairs(int v);
 void pgt_gemm_set_tn_pipe(int v);
 void pgt_gemm_set_skinny(int v);
-void pgt_gemm_set_db_stagger(int v);
 void pgt_gemm_set_dbp(int v);
 int pgt_spmm_tune(const char* key, int value);  // returns 1 when the key is known
 

@@ -40,10 +40,6 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_gemm_set_dbp(value);
     return PGT_OK;
   }
-  if (strcmp(key, "gemm_db_stagger") == 0) {
-    pgt_gemm_set_db_stagger(value);
-    return PGT_OK;
-  }
   if (strcmp(key, "gemm_skinny") == 0) {
     pgt_gemm_set_skinny(value);
     return PGT_OK;

@@ -127,8 +127,14 @@ int main(int argc, char** argv) {
     pgt_tune("spmm_tile_rows", rows);
     timeit(rows == 64 ? "plain tile TR=64" : "plain tile TR=32", [&](int p) { pgt_spmm_csr_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);
   }
+  pgt_tune("spmm_tile_rows", 32);
+  for (int nt : {0, 1, 0, 1}) {
+    pgt_tune("spmm_tile_nt", nt);
+    timeit(nt ? "plain tile TR=32, streaming Y stores" : "plain tile TR=32, plain Y stores", [&](int p) { pgt_spmm_csr_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);
+  }
+  pgt_tune("spmm_tile_nt", 0);
   pgt_tune("spmm_tile_rows", 64);
-  for (int tpw : {1, 0, 2, 10}) {
+  for (int tpw : {1}) {
     pgt_tune("spmm_band_cu", 4); pgt_tune("spmm_wtile_tpw", tpw);
     char nm[64]; snprintf(nm, 64, "window tile TR=32 tiles/wg=%d", tpw);
     timeit(nm, [&](int p) { pgt_spmm_csr_band_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, 32, st); }, alg);

@@ -27,6 +27,8 @@ constexpr int CAP_PER_ROW = 24;  // LDS-staged slots per tile = 24 * TR (12 KiB 
 
 // A/B knobs (pgt_tune); the defaults are the shipped configuration
 int g_tile_xcd = 1;    // hand tiles to XCDs in contiguous ranges
+int g_tile_nt = 1;     // pgt_tune("spmm_tile_nt"): non-temporal stores of the aggregated rows: 1 = when Y exceeds the L2s
+                       // (>= 32 MiB: 33.5 vs 34.4 us at N = 200 k, F = 64), 2 = always, 0 = never
 int g_tile_rows = 32;  // rows per tile for the F = 64 fast path (32 | 64 | 128); 32: finer tail, measured best
 int g_unroll = 8;      // neighbour loads in flight per lane group (4 | 8)
 int g_wide_xcd = 1;    // XCD-slab block mapping of the wide kernel
@@ -65,6 +67,27 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const float (&v)[VEC]
   }
 }
 
+// streaming (non-temporal) form of stv: the aggregated rows are not re-read by the launch that writes them, so they
+// need not displace the X rows that neighbouring tiles still gather from L2
+template <int VEC>
+__device__ __forceinline__ void stv_stream(float* __restrict__ p, const float (&v)[VEC]) {
+#if defined(PGT_EMU)
+  stv<VEC>(p, v);
+#else
+  if constexpr (VEC == 4) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
+  } else if constexpr (VEC == 2) {
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 t = {v[0], v[1]};
+    __builtin_nontemporal_store(t, reinterpret_cast<v2*>(p));
+  } else {
+    __builtin_nontemporal_store(v[0], p);
+  }
+#endif
+}
+
 // blockIdx -> tile so that each XCD (block b runs on XCD b % 8) owns a contiguous range of tiles.
 __device__ __forceinline__ int xcd_contiguous_tile(int b, int nb) {
   const int q = nb >> 3, r = nb & 7, x = b & 7;
@@ -82,7 +105,8 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
   __shared__ float s_val[CAP];
 
   const int tid = threadIdx.x;
-  const int tile = xcd_remap ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tile = (xcd_remap & 1) ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const bool stream_y = (xcd_remap & 2) != 0;
   const int r0 = tile * TR;
   const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
 
@@ -172,7 +196,8 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
 #pragma unroll
       for (int i = 0; i < VEC; ++i) out[i] = alpha * acc[i];
     }
-    stv<VEC>(Y + (int64_t)(r0 + r) * ldy + f, out);
+    if (stream_y) stv_stream<VEC>(Y + (int64_t)(r0 + r) * ldy + f, out);
+    else stv<VEC>(Y + (int64_t)(r0 + r) * ldy + f, out);
   }
   PGT_TRACE_MARK(3);
 }
@@ -896,7 +921,7 @@ int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, int
   if (Fv <= 64) {
 #define PGT_SPMM_CASE(L, TR_, U_)                                                                             \
   PGT_LAUNCH((spmm_tile_kernel<VEC, L, TR_, U_>), dim3((unsigned)pgt_cdiv(n_rows, TR_)), block, stream, rowptr, \
-             col, val, n, X, ldx, Y, ldy, T, ldt, alpha, beta, Fi, g_tile_xcd)
+             col, val, n, X, ldx, Y, ldy, T, ldt, alpha, beta, Fi, (g_tile_xcd ? 1 : 0) | ((g_tile_nt == 2 || (g_tile_nt == 1 && (int64_t)n * Fi * 4 >= ((int64_t)32 << 20))) ? 2 : 0))
     if (Fv <= 4) { PGT_SPMM_CASE(4, 64, 4); }
     else if (Fv <= 8) { PGT_SPMM_CASE(8, 64, 4); }
     else if (Fv <= 16) {
@@ -949,6 +974,7 @@ int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, int
 
 int pgt_spmm_tune(const char* key, int value) {
   if (strcmp(key, "spmm_tile_xcd") == 0) { g_tile_xcd = value; return 1; }
+  if (strcmp(key, "spmm_tile_nt") == 0) { g_tile_nt = value; return 1; }
   if (strcmp(key, "spmm_tile_rows") == 0) { g_tile_rows = value; return 1; }
   if (strcmp(key, "spmm_unroll") == 0) { g_unroll = value; return 1; }
   if (strcmp(key, "spmm_wide_xcd") == 0) { g_wide_xcd = value; return 1; }

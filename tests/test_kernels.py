@@ -921,3 +921,50 @@ def test_gemm_persistent_deferred_store_schedule(backend, M, segs, segk, N):
         lib.tune("gemm_dbp", 1)
         lib.tune("gemm_small_tiles", 0)
         lib.tune("gemm_db", 1)
+
+
+@pytest.mark.gpu
+def test_aggregation_at_north_star_size():
+    """BASELINE.json's north-star shape (N = 200 000 nodes, F = 64, in-degree 8; 1.6 M edges) on the product library:
+    the shipped row-tile schedule against an fp64 gather / index_add of the same CSR (1e-5), linearity, the Chebyshev
+    epilogue, and the alternative schedules (streaming vs plain stores, LDS-window tiles) bit for bit -- every one of
+    them sums a row's slots in slot order."""
+    lib = _lib.get_lib()
+    if lib.target != "gfx950":
+        pytest.skip("product library only")
+    dev = torch.device("cuda:0")
+    n, F_ = 200_000, 64
+    ei, ew = syn.local_graph(n, 8, seed=0)
+    G = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
+    csr = G.fwd_o
+    nnz = int(csr.rowptr[-1])
+    assert nnz == ei.shape[1]
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (csr.rowptr[1:] - csr.rowptr[:-1]).long())
+    cols, vals = csr.col[:nnz].long(), csr.val[:nnz].double()
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    X1, X2 = torch.randn(n, F_, generator=gen).to(dev), torch.randn(n, F_, generator=gen).to(dev)
+
+    def reference(X):
+        return torch.zeros(n, F_, dtype=torch.float64, device=dev).index_add_(0, rows, X.double()[cols] * vals[:, None])
+
+    Y1, Y2, Y3 = (torch.full((n, F_), float("nan"), device=dev) for _ in range(3))
+    ops.spmm(csr, X1, Y1)
+    ops.spmm(csr, X2, Y2)
+    ref1 = reference(X1)
+    assert_close_with_nonfinite(Y1, ref1.cpu(), 1e-5, 1e-5, "aggregation vs fp64")
+    ops.spmm(csr, 0.5 * X1 - 2.0 * X2, Y3)
+    assert torch.allclose(Y3, 0.5 * Y1 - 2.0 * Y2, atol=2e-5, rtol=1e-5)                   # linearity
+    ops.spmm(csr, X1, Y3, T=X2, alpha=2.0, beta=-1.0)                                      # 2 P X1 - X2
+    assert_close_with_nonfinite(Y3, (2.0 * ref1 - X2.double()).cpu(), 2e-5, 1e-5, "Chebyshev epilogue")
+    try:
+        for key, value in (("spmm_tile_nt", 0), ("spmm_tile_nt", 2), ("spmm_tile_rows", 64)):
+            lib.tune(key, value)
+            Ys = torch.full((n, F_), float("nan"), device=dev)
+            ops.spmm(csr, X1, Ys)
+            assert torch.equal(Ys, Y1), (key, value)
+        Yb = torch.full((n, F_), float("nan"), device=dev)
+        ops.spmm(csr, X1, Yb, halo=32)                                                     # LDS-window tiles
+        assert torch.equal(Yb, Y1)
+    finally:
+        lib.tune("spmm_tile_nt", 1)
+        lib.tune("spmm_tile_rows", 32)

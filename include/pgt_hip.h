@@ -84,8 +84,14 @@ const char* pgt_last_error(void);
 /* "gfx950" for the product library; "emu" for the CPU test double built under tests/. */
 const char* pgt_build_target(void);
 
-/* Benchmark A/B knobs ("gemm_small_tiles", "spmm_xcd_map", "spmm_tile_xcd", ...); defaults are the shipped
- * configuration.  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe. */
+/* Schedule switches for A/B measurements and for forcing a kernel onto small test problems; every key selects
+ * between kernels that compute the same sums (results differ at most in fp32 summation order), the defaults are the
+ * measured-best configuration.  GEMM: "gemm_db" (pipelined tile kernel: 1 where it applies, 2 always, 0 never),
+ * "gemm_db64", "gemm_dbp" (persistent deferred-store tiles: 1 / 2 = on three workgroups / 0), "gemm_skinny"
+ * (streaming kernels for an extent <= 4: 1 from 1024 rows / 2 always / 0), "gemm_small_tiles", "gemm_tn_pipe",
+ * "gemm_tn_fullk".  Diffusion stack: "slab_pairs".  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
+ * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_band_cu", "spmm_wtile_tpw",
+ * "spmm_quad", ...  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
 int pgt_tune(const char* key, int value);
 
 /* ---------------------------------------------------------------- graph preparation */

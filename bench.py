@@ -249,7 +249,7 @@ def main():
         k = kernels[dom]
         names = {"spmm": "spmm_wide_kernel<4> (pgt_spmm_csr_f32)",
                  "stack": "dconv_slab_fwd/bwd_kernel (pgt_dconv_stack_slab(_bwd)_f32)",
-                 "gemm": "gemm_db_kernel (pgt_gemm_f32 and, with the GRU gate chain in the epilogue, pgt_gemm_gru_zr/h_f32)",
+                 "gemm": "gemm_db_kernel / gemm_dbp_kernel (pgt_gemm_f32 and, with the GRU gate chain in the epilogue, pgt_gemm_gru_zr/h_f32; all launches of the entry points, read-out layer included)",
                  "gemm_tn": "gemm_tn_pipe_kernel (pgt_gemm_tn_acc_f32)"}
         if dom in ("spmm", "stack"):
             ach = k["work_per_launch"] / (k["avg_us"] * 1e-6) / 1e9

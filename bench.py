@@ -227,7 +227,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # ---- live roofline of the path's kernels: extra instrumented steps, HIP events on the launch stream
     roof, kernels = None, None

@@ -104,7 +104,8 @@ size_t pgt_prep_workspace_bytes(int64_t E, int64_t N);
 int pgt_dconv_prep(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N,
                    const pgt_dconv_graph* out, void* ws, size_t ws_bytes, pgt_stream_t stream);
 
-/* gcn_norm: add_remaining_self_loops(fill = improved ? 2 : 1) when add_self_loops != 0, deg = scatter_add(w, col),
+/* gcn_norm: add_remaining_self_loops(fill = improved && edge_weight ? 2 : 1: with NULL weights PyG adds the loops before it
+ * creates the unit weights, so they get 1) when add_self_loops != 0, deg = scatter_add(w, col),
  * w' = deg^-1/2[row] * w * deg^-1/2[col] (inf -> 0).  Live slots: (#non-loop edges) + N when add_self_loops, else E. */
 int pgt_gcn_prep(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N,
                  int improved, int add_self_loops, const pgt_sym_graph* out, void* ws, size_t ws_bytes,

@@ -456,6 +456,9 @@ extern "C" int pgt_dconv_prep(const int64_t* ei, const float* ew, int64_t E, int
 extern "C" int pgt_gcn_prep(const int64_t* ei, const float* ew, int64_t E, int64_t N, int improved,
                             int add_self_loops, const pgt_sym_graph* out, void* ws, size_t ws_bytes,
                             pgt_stream_t stream) {
+  // PyG >= 2.3 runs add_remaining_self_loops BEFORE `edge_weight = ones` (gcn_norm): without edge weights the new
+  // loops carry no attribute and end up with weight 1 like every other edge, i.e. `improved` only acts on weighted input
+  const float fill = (improved && ew != nullptr) ? 2.0f : 1.0f;
   Ws w;
   if (int e = common_checks("pgt_gcn_prep", ei, E, N, ws, ws_bytes, &w)) return e;
   PGT_REQUIRE(out && csr_ok(out->fwd) && csr_ok(out->bwd) && out->deg && out->info,
@@ -468,7 +471,7 @@ extern "C" int pgt_gcn_prep(const int64_t* ei, const float* ew, int64_t E, int64
   if (add_self_loops) {
     PGT_LAUNCH(k_fill_i32, g1(N), block, stream, w.node_i, N, (int32_t)-1);
     PGT_LAUNCH(k_gcn_loop_eid, g1(E), block, stream, ei, E, N, w.node_i);
-    PGT_LAUNCH(k_gcn_stage_loops, g1(N), block, stream, ew, w.node_i, E, N, improved ? 2.0f : 1.0f, w.l_dst,
+    PGT_LAUNCH(k_gcn_stage_loops, g1(N), block, stream, ew, w.node_i, E, N, fill, w.l_dst,
                w.l_src, w.l_val);
     L = E + N;
   }

@@ -73,6 +73,18 @@ def backend(request, emu_lib):
     ops.GRAPH_CACHE.clear()
 
 
+@pytest.fixture
+def emu_backend(emu_lib):
+    """The CPU test double only (property / fuzz tests: many small cases, no GPU leg)."""
+    ops.GRAPH_CACHE.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _lib._set_library_for_testing(emu_lib)
+    yield Backend("emu", "cpu")
+    _lib._set_library_for_testing(None)
+    ops.GRAPH_CACHE.clear()
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     out = {"in": {}, "param": {}, "out": {}, "meta": {}}

@@ -178,3 +178,72 @@ def test_no_cpu_fallback():
     ei_np, ew_np = syn.sensor_graph(10, 40, seed=3)
     with pytest.raises(_lib.PgtError):
         m(torch.zeros(10, 2), torch.from_numpy(ei_np), torch.from_numpy(ew_np))
+
+
+try:
+    from hypothesis import HealthCheck, given, settings, strategies as hst
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(data=hst.data(), K=hst.integers(1, 3), weighted=hst.booleans(), with_h=hst.booleans())
+    def test_fuzz_dcrnn_cell_on_arbitrary_graphs(emu_backend, data, K, weighted, with_h):
+        """DCRNN cell on random small digraphs in arbitrary edge order (self-loops, sinks, sources, isolated nodes):
+        values AND the placement of inf / nan (sources without in-edges: `1/deg_in = inf`) equal
+        the oracle's restatement of `dcrnn.py:42-111,172-219`."""
+        n = data.draw(hst.integers(1, 8))
+        pairs = hst.tuples(hst.integers(0, n - 1), hst.integers(0, n - 1))
+        edges = data.draw(hst.lists(pairs, min_size=1, max_size=20, unique=True))
+        ei = torch.tensor(edges, dtype=torch.long).t().reshape(2, -1)
+        ew = torch.tensor(data.draw(hst.lists(hst.sampled_from([0.5, 1.0, 2.0]), min_size=len(edges),
+                                              max_size=len(edges))), dtype=torch.float32) if weighted else None
+        n_x = int(ei.max()) + 1 if data.draw(hst.booleans()) else n      # X may have trailing nodes without edges
+        if n_x < int(ei.max()) + 1:
+            n_x = int(ei.max()) + 1
+        fin, O = 2, 3
+        torch.manual_seed(len(edges) * 7 + K)
+        m = DCRNN(fin, O, K)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.uniform_(-0.5, 0.5)
+        params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        X = torch.randn(n_x, fin)
+        H = torch.randn(n_x, O) if with_h else None
+        with torch.no_grad():
+            out = m.to(emu_backend.device)(emu_backend.t(X), emu_backend.t(ei),
+                                            None if ew is None else emu_backend.t(ew),
+                                            None if H is None else emu_backend.t(H))
+            ref = F.dcrnn_cell(X, ei, ew, H, params)
+        assert_close_with_nonfinite(out, ref, 2e-5, 1e-5, "fuzz dcrnn")
+
+    @settings(max_examples=50, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(data=hst.data(), K=hst.integers(1, 3), B=hst.integers(1, 3), T=hst.integers(1, 3))
+    def test_fuzz_batched_dcrnn_on_multigraphs(emu_backend, data, K, B, T):
+        """BatchedDConv / BatchedDCRNN keep duplicate edges as separate messages and every weight as given (the
+        scatter form, `dcrnn.py:277-290`) -- unlike DConv's dense path.  Random multigraphs in
+        arbitrary edge order against the oracle, inf / nan placement included."""
+        n = data.draw(hst.integers(1, 7))
+        pairs = hst.tuples(hst.integers(0, n - 1), hst.integers(0, n - 1))
+        edges = data.draw(hst.lists(pairs, min_size=1, max_size=18))
+        ei = torch.tensor(edges, dtype=torch.long).t().reshape(2, -1)
+        ew = torch.tensor(data.draw(hst.lists(hst.sampled_from([0.5, 1.0, 2.0]), min_size=len(edges),
+                                              max_size=len(edges))), dtype=torch.float32)
+        fin, O = 2, 3
+        torch.manual_seed(len(edges) * 5 + K + B)
+        m = BatchedDCRNN(fin, O, K)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.uniform_(-0.5, 0.5)
+        params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        X = torch.randn(B, T, n, fin)
+        with torch.no_grad():
+            out = m.to(emu_backend.device)(emu_backend.t(X), emu_backend.t(ei), emu_backend.t(ew))
+            ref = F.batched_dcrnn(X, ei, ew, params)
+        assert_close_with_nonfinite(out, ref, 2e-5, 1e-5, "fuzz batched dcrnn")
+        conv = BatchedDConv(fin + O, O, K)
+        conv.load_state_dict({"weight": params["conv_x_z.weight"], "bias": params["conv_x_z.bias"]})
+        XH = torch.randn(n, fin + O)
+        with torch.no_grad():
+            a = conv.to(emu_backend.device)(emu_backend.t(XH), emu_backend.t(ei), emu_backend.t(ew))
+            b = F.batched_dconv(XH, ei, ew, params["conv_x_z.weight"], params["conv_x_z.bias"])
+        assert_close_with_nonfinite(a, b, 2e-5, 1e-5, "fuzz batched dconv")
+except ImportError:      # hypothesis is optional
+    pass

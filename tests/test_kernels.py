@@ -968,3 +968,64 @@ def test_aggregation_at_north_star_size():
     finally:
         lib.tune("spmm_tile_nt", 1)
         lib.tune("spmm_tile_rows", 32)
+
+
+# ------------------------------------------------------------------------------------------------ fuzzing the graph prep
+
+def _fuzz_graph(draw, unique):
+    from hypothesis import strategies as st
+    n = draw(st.integers(1, 9))
+    pairs = st.tuples(st.integers(0, n - 1), st.integers(0, n - 1))
+    edges = draw(st.lists(pairs, min_size=0, max_size=24, unique=unique))
+    weights = draw(st.lists(st.sampled_from([0.25, 0.5, 1.0, 1.5, 3.0]), min_size=len(edges), max_size=len(edges)))
+    ei = torch.tensor(edges, dtype=torch.long).t().reshape(2, -1)
+    return n, ei, torch.tensor(weights, dtype=torch.float32)
+
+
+try:
+    from hypothesis import HealthCheck, given, settings, strategies as hst
+
+    _FUZZ = settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+
+    @_FUZZ
+    @given(data=hst.data())
+    def test_fuzz_dconv_prep_on_arbitrary_edge_order(emu_backend, data):
+        """Any order of unique, positively weighted edges (self-loops, isolated nodes, sinks, sources): the four
+        operators equal the reference's scatter form (`dcrnn.py:277-290`), slots keep edge order, degrees bit-exact."""
+        n, ei, ew = _fuzz_graph(data.draw, unique=True)
+        g = ops.DConvGraph(emu_backend.t(ei), emu_backend.t(ew), n)
+        norm_out, norm_in, rev = F.dconv_norms_scatter(ei, ew, n)
+        Po, Pi = dense_from_edges(ei, norm_out, n), dense_from_edges(rev, norm_in, n)
+        for name, csr, ref in (("fwd_o", g.fwd_o, Po), ("fwd_i", g.fwd_i, Pi), ("bwd_o", g.bwd_o, Po.t()),
+                               ("bwd_i", g.bwd_i, Pi.t())):
+            assert_close_with_nonfinite(csr_to_dense(csr, n), ref, 1e-6, 1e-6, name)
+        assert torch.equal(g.deg_out.cpu()[:n], torch.zeros(n).scatter_add_(0, ei[0], ew))
+        assert torch.equal(g.deg_in.cpu()[:n], torch.zeros(n).scatter_add_(0, ei[1], ew))
+        rp, col = g.fwd_o.rowptr.cpu().numpy(), g.fwd_o.col.cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(col[rp[i]:rp[i + 1]], ei[0][ei[1] == i].numpy())
+
+    @_FUZZ
+    @given(data=hst.data(), improved=hst.booleans(), loops=hst.booleans())
+    def test_fuzz_gcn_prep_with_duplicates_and_self_loops(emu_backend, data, improved, loops):
+        """gcn_norm on multigraphs: duplicate edges stay separate messages, existing self-loops keep their weight and
+        move to the end, missing ones get the fill value."""
+        n, ei, ew = _fuzz_graph(data.draw, unique=False)
+        g = ops.SymGraph("gcn", emu_backend.t(ei), emu_backend.t(ew), n, improved=improved, add_self_loops=loops)
+        ei2, w2 = P.gcn_norm(ei, ew, n, improved, loops)
+        A = dense_from_edges(ei2, w2, n)
+        assert_close_with_nonfinite(csr_to_dense(g.fwd, n), A, 1e-6, 1e-5, "gcn fwd")
+        assert_close_with_nonfinite(csr_to_dense(g.bwd, n), A.t(), 1e-6, 1e-5, "gcn bwd")
+
+    @_FUZZ
+    @given(data=hst.data(), norm=hst.sampled_from(["sym", "rw", None]))
+    def test_fuzz_cheb_prep_with_duplicates_and_self_loops(emu_backend, data, norm):
+        """ChebConv.__norm__ (lambda_max = None -> PyG's default) on multigraphs with self-loops and isolated nodes."""
+        n, ei, ew = _fuzz_graph(data.draw, unique=False)
+        g = ops.SymGraph("cheb", emu_backend.t(ei), emu_backend.t(ew), n, normalization=norm, lambda_max=None, variant=0)
+        ei2, w2 = F.cheb_norm(ei, ew, n, norm, None, torch.float32)
+        L = dense_from_edges(ei2, w2, n)
+        assert_close_with_nonfinite(csr_to_dense(g.fwd, n), L, 1e-6, 1e-5, "cheb fwd")
+        assert_close_with_nonfinite(csr_to_dense(g.bwd, n), L.t(), 1e-6, 1e-5, "cheb bwd")
+except ImportError:      # hypothesis is optional
+    pass

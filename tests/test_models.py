@@ -423,3 +423,83 @@ def test_mstgcn_matches_reference_fixture(backend):
     Xg = X.clone().requires_grad_()
     m(Xg, ei).square().sum().backward()
     assert all(p.grad is not None for p in m.parameters())
+
+
+# ------------------------------------------------------------------------------------------------ fuzzing
+
+try:
+    from hypothesis import HealthCheck, given, settings, strategies as hst
+
+    def _draw_multigraph(data, min_edges=0):
+        n = data.draw(hst.integers(1, 8))
+        pairs = hst.tuples(hst.integers(0, n - 1), hst.integers(0, n - 1))
+        edges = data.draw(hst.lists(pairs, min_size=min_edges, max_size=20))          # duplicates and self-loops allowed
+        ei = torch.tensor(edges, dtype=torch.long).t().reshape(2, -1)
+        ws = data.draw(hst.lists(hst.sampled_from([0.25, 1.0, 2.0, 5.0]), min_size=len(edges), max_size=len(edges)))
+        return n, ei, torch.tensor(ws, dtype=torch.float32)
+
+    _FUZZ = settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+
+    @_FUZZ
+    @given(data=hst.data(), improved=hst.booleans(), loops=hst.booleans(), weighted=hst.booleans())
+    def test_fuzz_tgcn_cell_on_multigraphs(emu_backend, data, improved, loops, weighted):
+        """TGCN cell on random multigraphs (duplicate edges, self-loops, isolated nodes, empty edge lists): equals the
+        oracle's restatement of `temporalgcn.py:82-130` + PyG gcn_norm for every `improved` / `add_self_loops` form."""
+        n, ei, ew = _draw_multigraph(data)
+        fin, O = 2, 3
+        m = TGCN(fin, O, improved=improved, add_self_loops=loops)
+        params = {k: v.double() for k, v in _rand_params(m, n + ei.size(1)).items()}
+        X, H = torch.randn(n, fin), torch.randn(n, O)
+        with torch.no_grad():
+            out = m.to(emu_backend.device)(emu_backend.t(X), emu_backend.t(ei),
+                                            emu_backend.t(ew) if weighted else None, emu_backend.t(H))
+            ref = F.tgcn_cell(X.double(), ei, ew.double() if weighted else None, H.double(), params,
+                              improved=improved, add_self_loops=loops)
+        assert_close_with_nonfinite(out, ref, 2e-5, 1e-5, "fuzz tgcn")
+
+    @_FUZZ
+    @given(data=hst.data(), K=hst.integers(1, 4), norm=hst.sampled_from(["sym", "rw", None]), weighted=hst.booleans(),
+           lam=hst.sampled_from([None, 1.7, 3.0]))
+    def test_fuzz_chebconv_on_multigraphs(emu_backend, data, K, norm, weighted, lam):
+        """PyG ChebConv (the graph conv of STConv, `stgcn.py:115-121`) on random multigraphs: duplicate edges, self-loops
+        (removed by get_laplacian), isolated nodes, with and without weights / lambda_max, forward and input gradient."""
+        n, ei, ew = _draw_multigraph(data)
+        fin, fout = 2, 3
+        m = ChebConv(fin, fout, K, normalization=norm)
+        params64 = _rand_params(m, K + n)
+        X = torch.randn(n, fin)
+        Xd = emu_backend.t(X).requires_grad_()
+        out = m.to(emu_backend.device)(Xd, emu_backend.t(ei), emu_backend.t(ew) if weighted else None, lambda_max=lam)
+        out.sum().backward()
+        X64 = X.double().requires_grad_()
+        ref = F.cheb_conv(X64, ei, ew.double() if weighted else None, [params64[f"lins.{k}.weight"] for k in range(K)],
+                          params64["bias"], normalization=norm, lambda_max=lam)
+        ref.sum().backward()
+        assert_close_with_nonfinite(out, ref, 2e-5, 2e-5, "fuzz chebconv")
+        assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "fuzz chebconv dX")
+
+    @_FUZZ
+    @given(data=hst.data(), K=hst.integers(1, 3), norm=hst.sampled_from(["sym", "rw", None]), weighted=hst.booleans())
+    def test_fuzz_chebconvattention_on_multigraphs(emu_backend, data, K, norm, weighted):
+        """ChebConvAttention (`astgcn.py:82-190`) on random multigraphs: in-tree `__norm__` (self-loops removed, -1
+        diagonal added), attention-weighted first hop, plain later hops; forward and both gradients."""
+        from pytorch_geometric_temporal_amd.nn.attention import ChebConvAttention
+        n, ei, ew = _draw_multigraph(data, min_edges=1)
+        n = max(n, int(ei.max()) + 1)
+        fin, fout, B = 2, 3, 2
+        lam = None if norm == "sym" else 2.5
+        m = ChebConvAttention(fin, fout, K, normalization=norm)
+        params64 = _rand_params(m, K + n)
+        X, S = torch.randn(B, n, fin), torch.softmax(torch.randn(B, n, n), dim=1)
+        Xd, Sd = emu_backend.t(X).requires_grad_(), emu_backend.t(S).requires_grad_()
+        out = m.to(emu_backend.device)(Xd, emu_backend.t(ei), Sd, emu_backend.t(ew) if weighted else None, lambda_max=lam)
+        out.sum().backward()
+        X64, S64 = X.double().requires_grad_(), S.double().requires_grad_()
+        ref = F.cheb_conv_attention(X64, ei, S64, ew.double() if weighted else None, params64["_weight"],
+                                    params64["_bias"], norm, lam)
+        ref.sum().backward()
+        assert_close_with_nonfinite(out, ref, 2e-5, 2e-5, "fuzz attention conv")
+        assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "fuzz attention conv dX")
+        assert_close_with_nonfinite(Sd.grad, S64.grad, 5e-5, 1e-4, "fuzz attention conv dS")
+except ImportError:      # hypothesis is optional
+    pass

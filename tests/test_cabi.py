@@ -102,3 +102,39 @@ def test_tune_switches_from_the_environment_are_parsed(monkeypatch):
         assert calls == [("gemm_dbp", 1), ("slab_pairs", 2)]
     finally:
         _lib._LIB = None
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    """The C ABI validates before it launches: null pointers, negative sizes, undersized scratch and unknown switches
+    come back as PGT_ERR_* with a message in pgt_last_error(); zero-sized problems are PGT_OK no-ops (no launch)."""
+    import ctypes
+    import torch
+    lib = _lib.PgtLib(build_emu_library())                  # same host-side entry code as the product library
+    null = ctypes.c_void_p(0)
+    x = torch.zeros(64)
+    p = ctypes.c_void_p(x.data_ptr())
+    bad = [
+        ("pgt_gemm_f32", (p, 4, 0, 1, 4, p, 4, 1, null, 4, 0, 4, null, 4, 4, 0, null)),          # null output
+        ("pgt_gemm_f32", (p, 4, 0, 1, 4, p, 4, 1, p, 4, 0, 4, null, -1, 4, 0, null)),            # negative M
+        ("pgt_gemm_f32", (p, 4, 0, 1, 4, p, 4, 1, p, 4, 0, 0, null, 4, 4, 0, null)),             # c_seg_n = 0
+        ("pgt_gemm_tn_acc_f32", (p, 4, 0, 1, 4, null, 4, p, 4, null, 4, 4, null)),               # null gradient
+        ("pgt_spmm_csr_f32", (null, p, p, 4, p, 4, p, 4, null, 0, 1.0, 0.0, 4, null)),           # null rowptr
+        ("pgt_spmm_csr_f32", (p, p, p, -2, p, 4, p, 4, null, 0, 1.0, 0.0, 4, null)),             # negative rows
+        ("pgt_copy2d_f32", (null, 4, p, 4, 4, 4, null)),                                         # null destination
+    ]
+    for name, args in bad:
+        rc = getattr(lib, "_" + name)(*args)
+        assert rc < 0, (name, rc)
+        assert lib.last_error(), name
+        with pytest.raises(_lib.PgtError, match=name):
+            lib.call(name, *args)
+    with pytest.raises(_lib.PgtError, match="unknown key"):
+        lib.tune("no_such_switch", 1)
+    assert lib.prep_workspace_bytes(2, 2) > 8
+    ok = [
+        ("pgt_gemm_f32", (p, 4, 0, 1, 4, p, 4, 1, p, 4, 0, 4, null, 0, 4, 0, null)),             # M = 0
+        ("pgt_gemm_tn_acc_f32", (p, 4, 0, 1, 4, p, 4, p, 4, null, 0, 4, null)),                  # M = 0
+        ("pgt_copy2d_f32", (p, 4, p, 4, 0, 4, null)),
+    ]
+    for name, args in ok:
+        assert getattr(lib, "_" + name)(*args) == 0, name

@@ -12,7 +12,7 @@ hyp = pytest.importorskip("hypothesis")
 from hypothesis import HealthCheck, given, settings, strategies as hst     # noqa: E402
 
 pytestmark = pytest.mark.skipif(not R.reference_available(), reason="reference checkout not mounted")
-FUZZ = settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+FUZZ = settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 TOL = dict(atol=3e-5, rtol=3e-5)
 
 
@@ -114,17 +114,20 @@ def test_stconv(emu_backend, data, K, weighted):
 
 
 @FUZZ
-@given(data=hst.data(), which=hst.sampled_from(["H", "O"]), weighted=hst.booleans(), steps=hst.integers(1, 3))
-def test_evolvegcn_over_a_changing_graph(emu_backend, data, which, weighted, steps):
+@given(data=hst.data(), which=hst.sampled_from(["H", "O"]), weighted=hst.booleans(), steps=hst.integers(1, 3),
+       improved=hst.booleans(), normalize=hst.booleans(), loops=hst.booleans())
+def test_evolvegcn_over_a_changing_graph(emu_backend, data, which, weighted, steps, improved, normalize, loops):
     """EvolveGCN-H / -O (`evolvegcnh.py:78-102`, `evolvegcno.py:170-191`): the evolving weight is carried across
     snapshots whose edge lists change."""
     from pytorch_geometric_temporal_amd.nn import recurrent as ours
     n = data.draw(hst.integers(4, 8))
     F_ = 3
     if which == "H":
-        ref, our = twin(R.load("nn.recurrent.evolvegcnh").EvolveGCNH, ours.EvolveGCNH, n, F_, seed=n)
+        ref, our = twin(R.load("nn.recurrent.evolvegcnh").EvolveGCNH, ours.EvolveGCNH, n, F_, improved=improved,
+                        normalize=normalize, add_self_loops=loops, seed=n)
     else:
-        ref, our = twin(R.load("nn.recurrent.evolvegcno").EvolveGCNO, ours.EvolveGCNO, F_, seed=n)
+        ref, our = twin(R.load("nn.recurrent.evolvegcno").EvolveGCNO, ours.EvolveGCNO, F_, improved=improved,
+                        normalize=normalize, add_self_loops=loops, seed=n)
     our = our.to(emu_backend.device)
     t = emu_backend.t
     for s in range(steps):

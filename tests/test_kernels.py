@@ -1029,3 +1029,166 @@ try:
         assert_close_with_nonfinite(csr_to_dense(g.bwd, n), L.t(), 1e-6, 1e-5, "cheb bwd")
 except ImportError:      # hypothesis is optional
     pass
+
+
+try:
+    from hypothesis import HealthCheck, given, settings, strategies as hst
+
+    @settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(M=hst.integers(1, 280), segs=hst.integers(1, 4), segk=hst.integers(1, 40), N=hst.integers(1, 140),
+           pad_a=hst.sampled_from([0, 1, 2, 4]), nt=hst.booleans(), bias=hst.booleans(), acc=hst.booleans(),
+           mode=hst.sampled_from(["default", "big", "big_db", "persistent", "skinny"]),
+           seg_out=hst.booleans())
+    def test_fuzz_gemm_entry_point(emu_backend, M, segs, segk, N, pad_a, nt, bias, acc, mode, seg_out):
+        """pgt_gemm_f32 over random shapes and layouts -- K-segmented A with padded rows, NN / NT weights, bias,
+        accumulate, column-segmented output -- with every kernel family forced in turn (64 x 64 tiles, 128-wide tiles,
+        the pipelined kernel, the persistent deferred-store kernel, the streaming kernels): whatever the dispatch
+        picks must produce the same product."""
+        lib = _lib.get_lib()
+        knobs = {"default": {}, "big": {"gemm_small_tiles": 2, "gemm_db": 0}, "big_db": {"gemm_small_tiles": 2, "gemm_db": 2},
+                 "persistent": {"gemm_small_tiles": 2, "gemm_db": 2, "gemm_dbp": 2}, "skinny": {"gemm_skinny": 2}}[mode]
+        defaults = {"gemm_small_tiles": 0, "gemm_db": 1, "gemm_dbp": 1, "gemm_skinny": 1}
+        for k, v in knobs.items():
+            lib.tune(k, v)
+        try:
+            g = torch.Generator().manual_seed(M * 131 + N * 7 + segk)
+            K = segs * segk
+            lda = segk + pad_a
+            A = torch.randn(segs, M, lda, generator=g)
+            W = torch.randn(K, N, generator=g)
+            b = torch.randn(N, generator=g) if bias else None
+            dev = emu_backend.device
+            Wd = (W.t().contiguous() if nt else W).to(dev)
+            sbk, sbn = (1, K) if nt else (N, 1)
+            ref = torch.cat([A[j, :, :segk] for j in range(segs)], dim=1).double() @ W.double()
+            if bias:
+                ref = ref + b.double()
+            # output: plain [M, N], or column segments of width cs at stride M * cs (the diffusion-stack gradient layout)
+            cs = 1
+            if seg_out:
+                divs = [d for d in range(1, N + 1) if N % d == 0]
+                cs = divs[(M + segk) % len(divs)]
+            if seg_out and cs != N:
+                C0 = torch.randn(N // cs, M, cs, generator=g)
+                C = C0.clone().to(dev)
+                ops.gemm(A.to(dev), lda, M * lda, segs, segk, Wd, sbk, sbn, C, cs, M * cs, cs, None if b is None else b.to(dev),
+                         M, N, accumulate=acc)
+                got = C.cpu().permute(1, 0, 2).reshape(M, N)
+                base = C0.permute(1, 0, 2).reshape(M, N)
+            else:
+                C0 = torch.randn(M, N, generator=g)
+                C = C0.clone().to(dev)
+                ops.gemm(A.to(dev), lda, M * lda, segs, segk, Wd, sbk, sbn, C, N, 0, N, None if b is None else b.to(dev),
+                         M, N, accumulate=acc)
+                got, base = C.cpu(), C0
+            want = ref + base.double() if acc else ref
+            assert_close_with_nonfinite(got, want, 2e-4, 2e-5, f"gemm {mode}")
+        finally:
+            for k in knobs:
+                lib.tune(k, defaults[k])
+
+    @settings(max_examples=100, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(M=hst.integers(1, 260), segs=hst.integers(1, 4), segk=hst.integers(1, 70), N=hst.integers(1, 140),
+           pad_a=hst.sampled_from([0, 2, 4]), bias=hst.booleans(),
+           mode=hst.sampled_from(["default", "big", "whole_k", "pipelined", "skinny"]))
+    def test_fuzz_weight_gradient_entry_point(emu_backend, M, segs, segk, N, pad_a, bias, mode):
+        """pgt_gemm_tn_acc_f32 (dW += A^T G, db += column sums) over random shapes with every schedule forced in turn."""
+        lib = _lib.get_lib()
+        knobs = {"default": {}, "big": {"gemm_small_tiles": 2, "gemm_tn_fullk": 0, "gemm_tn_pipe": 0},
+                 "whole_k": {"gemm_tn_fullk": 2, "gemm_tn_pipe": 0}, "pipelined": {"gemm_tn_pipe": 2},
+                 "skinny": {"gemm_skinny": 2}}[mode]
+        defaults = {"gemm_small_tiles": 0, "gemm_tn_fullk": 1, "gemm_tn_pipe": 1, "gemm_skinny": 1}
+        for k, v in knobs.items():
+            lib.tune(k, v)
+        try:
+            g = torch.Generator().manual_seed(M * 17 + N * 3 + segk)
+            lda = segk + pad_a
+            A = torch.randn(segs, M, lda, generator=g)
+            G = torch.randn(M, N, generator=g)
+            dW0, db0 = torch.randn(segs * segk, N, generator=g), torch.randn(N, generator=g)
+            dev = emu_backend.device
+            dW, db = dW0.clone().to(dev), (db0.clone().to(dev) if bias else None)
+            ops.gemm_tn_acc(A.to(dev), lda, M * lda, segs, segk, G.to(dev), N, dW, N, db, M, N)
+            Acat = torch.cat([A[j, :, :segk] for j in range(segs)], dim=1).double()
+            assert_close_with_nonfinite(dW, dW0.double() + Acat.t() @ G.double(), 3e-4, 2e-5, f"dW {mode}")
+            if bias:
+                assert_close_with_nonfinite(db, db0.double() + G.double().sum(0), 3e-4, 2e-5, f"db {mode}")
+        finally:
+            for k in knobs:
+                lib.tune(k, defaults[k])
+
+    @settings(max_examples=100, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(data=hst.data(), F_=hst.integers(1, 300), use_t=hst.booleans(), rows=hst.sampled_from([32, 64]),
+           unroll=hst.sampled_from([4, 8]), halo=hst.sampled_from([0, 0, 32]), nt=hst.sampled_from([0, 2]))
+    def test_fuzz_aggregation_entry_point(emu_backend, data, F_, use_t, rows, unroll, halo, nt):
+        """pgt_spmm_csr_band_f32 on random CSR operators (empty rows, heavy rows, duplicates) for every feature width
+        up to 300, with and without the `alpha A X + beta T` epilogue, across tile shapes, store flavours and the
+        LDS-window schedule (F = 64 only)."""
+        lib = _lib.get_lib()
+        n = data.draw(hst.integers(1, 90))
+        deg = data.draw(hst.lists(hst.integers(0, 9), min_size=n, max_size=n))
+        if data.draw(hst.booleans()):
+            deg[data.draw(hst.integers(0, n - 1))] = 70                    # one heavy row
+        rp = torch.tensor([0] + list(np.cumsum(deg)), dtype=torch.int32)
+        nnz = int(rp[-1])
+        gen = torch.Generator().manual_seed(n * 31 + F_)
+        col = torch.randint(0, n, (nnz,), generator=gen, dtype=torch.int32)
+        val = torch.randn(nnz, generator=gen)
+        dev = emu_backend.device
+        csr = ops.Csr(n, max(nnz, 1), dev)
+        csr.rowptr.copy_(rp)
+        csr.col[:nnz].copy_(col)
+        csr.val[:nnz].copy_(val)
+        X, T = torch.randn(n, F_, generator=gen), torch.randn(n, F_, generator=gen)
+        alpha, beta = (2.0, -1.0) if use_t else (0.5, 0.0)
+        lib.tune("spmm_tile_rows", rows); lib.tune("spmm_unroll", unroll); lib.tune("spmm_tile_nt", nt)
+        try:
+            Y = torch.full((n, F_), float("nan")).to(dev)
+            ops.spmm(csr, X.to(dev), Y, T=T.to(dev) if use_t else None, alpha=alpha, beta=beta,
+                     halo=halo if F_ == 64 else 0)
+        finally:
+            lib.tune("spmm_tile_rows", 32); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_nt", 1)
+        rows_i = torch.repeat_interleave(torch.arange(n), torch.tensor(deg))
+        ref = torch.zeros(n, F_, dtype=torch.float64).index_add_(0, rows_i, X.double()[col.long()] * val.double()[:, None])
+        ref = alpha * ref + (beta * T.double() if use_t else 0.0)
+        assert_close_with_nonfinite(Y, ref, 2e-5, 2e-5, "aggregation")
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(data=hst.data(), C=hst.integers(1, 70), K=hst.integers(2, 3), B=hst.integers(1, 3), pairs=hst.sampled_from([1, 2]),
+           folded=hst.booleans())
+    def test_fuzz_lds_resident_stack(emu_backend, data, C, K, B, pairs, folded):
+        """pgt_dconv_stack_slab(_bwd)_f32 on random small digraphs (any column count incl. odd ones, one or two column
+        pairs per lane) against the one-launch-per-hop path, forward and adjoint."""
+        lib = _lib.get_lib()
+        n = data.draw(hst.integers(1, 24))
+        pairs_ = hst.tuples(hst.integers(0, n - 1), hst.integers(0, n - 1))
+        edges = data.draw(hst.lists(pairs_, min_size=1, max_size=4 * n, unique=True))
+        ei = torch.tensor(edges, dtype=torch.long).t().reshape(2, -1)
+        ew = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(n + C)) + 0.2
+        g = ops.DConvGraph(emu_backend.t(ei), emu_backend.t(ew), n)
+        if not ops.slab_fits(g, C, K):
+            return
+        lib.tune("slab_pairs", pairs)
+        try:
+            S = 2 * K - 1
+            gen = torch.Generator().manual_seed(C * 7 + n)
+            X = torch.randn(B, n, C, generator=gen)
+            TSn = torch.zeros(S, 1, n * B, C)
+            TSn[0, 0] = X.permute(1, 0, 2).reshape(n * B, C)
+            ops._stack_fwd(g, TSn, 0, K, n)
+            TSb = torch.zeros(S, 1, B * n, C)
+            TSb[0, 0] = X.reshape(B * n, C)
+            ops._slab_fwd(g, TSb[0, 0], B * n * C, B, C, K)
+            ref = TSn.view(S, n, B, C).permute(0, 2, 1, 3).reshape(S, B * n, C)
+            assert_close_with_nonfinite(TSb.view(S, B * n, C), ref, 2e-6, 2e-6, "forward stack")
+            Gsrc = torch.randn(S, B, n, C, generator=gen)
+            Gn = Gsrc.permute(0, 2, 1, 3).reshape(S, n * B, C).contiguous()
+            ops._stack_bwd(g, Gn, K, n, folded)
+            Gb = Gsrc.reshape(S, B * n, C).contiguous()
+            ops._slab_bwd(g, Gb[0], B * n * C, B, C, K, folded)
+            refg = Gn[0].view(n, B, C).permute(1, 0, 2).reshape(B * n, C)
+            assert_close_with_nonfinite(Gb[0], refg, 4e-6, 4e-6, "adjoint")
+        finally:
+            lib.tune("slab_pairs", 2)
+except ImportError:      # hypothesis is optional
+    pass

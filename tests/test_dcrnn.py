@@ -245,5 +245,53 @@ try:
             a = conv.to(emu_backend.device)(emu_backend.t(XH), emu_backend.t(ei), emu_backend.t(ew))
             b = F.batched_dconv(XH, ei, ew, params["conv_x_z.weight"], params["conv_x_z.bias"])
         assert_close_with_nonfinite(a, b, 2e-5, 1e-5, "fuzz batched dconv")
+
+    @settings(max_examples=20, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(data=hst.data(), K=hst.integers(1, 3), B=hst.integers(1, 3), T=hst.integers(1, 3), O=hst.sampled_from([4, 8, 6]),
+           need_x=hst.booleans())
+    def test_fuzz_batched_dcrnn_host_paths_agree(emu_backend, data, K, B, T, O, need_x, monkeypatch):
+        """The schedules behind BatchedDCRNN are interchangeable: batch-major rows with the LDS-resident stack vs
+        node-major rows with one launch per hop, fused vs separate gate epilogues, hidden-columns-only vs full
+        stack gradient, zero-copy vs transposed output -- same outputs, same parameter and input gradients."""
+        from pytorch_geometric_temporal_amd import ops
+        n = data.draw(hst.integers(2, 7))
+        pairs = hst.tuples(hst.integers(0, n - 1), hst.integers(0, n - 1))
+        edges = data.draw(hst.lists(pairs, min_size=1, max_size=3 * n, unique=True))
+        ei = torch.tensor(edges, dtype=torch.long).t().reshape(2, -1)
+        keep = ei[0] != ei[1]
+        ei = torch.cat([ei[:, keep], torch.arange(n).repeat(2, 1)], dim=1)          # unit diagonal: finite 1/deg_in
+        ew = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(n)) + 0.3
+        torch.manual_seed(n * 3 + K)
+        m = BatchedDCRNN(2, O, K).to(emu_backend.device)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.uniform_(-0.5, 0.5)
+        X = torch.randn(B, T, n, 2)
+        W = torch.randn(B, T, n, O)
+        results = []
+        real_fits = ops.slab_fits
+        for slab in (True, False):
+            for fuse in (True, False):
+                for skip in (True, False):
+                    for lazy in (False, True):
+                        monkeypatch.setattr(ops, "slab_fits", real_fits if slab else (lambda *a, **k: False))
+                        monkeypatch.setattr(ops, "FUSE_GATE_EPILOGUES", fuse)
+                        monkeypatch.setattr(ops, "SKIP_INPUT_COLUMNS_WHEN_UNUSED", skip)
+                        m.lazy_output = lazy
+                        m.zero_grad()
+                        Xd = emu_backend.t(X).requires_grad_(need_x)
+                        out = m(Xd, emu_backend.t(ei), emu_backend.t(ew))
+                        (out * emu_backend.t(W)).sum().backward()
+                        results.append((out.detach().clone().contiguous(), Xd.grad.clone() if need_x else None,
+                                        [p.grad.clone() for p in m.parameters()]))
+        base = results[0]
+        for r in results[1:]:
+            assert_close_with_nonfinite(r[0], base[0], 2e-5, 2e-5, "output")
+            if need_x:
+                assert_close_with_nonfinite(r[1], base[1], 1e-4, 1e-4, "dX")
+            for a, b in zip(r[2], base[2]):
+                assert_close_with_nonfinite(a, b, 2e-4, 2e-4, "parameter gradient")
+        ref = F.batched_dcrnn(X, ei, ew, {k: v.detach().clone() for k, v in m.state_dict().items()})
+        assert_close_with_nonfinite(base[0], ref, 2e-5, 2e-5, "oracle")
 except ImportError:      # hypothesis is optional
     pass

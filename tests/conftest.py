@@ -26,6 +26,8 @@ def pytest_configure(config):
 
 def build_emu_library():
     """The CPU test double: the SAME kernel sources compiled with g++ against tests/hipemu (fibers instead of lanes)."""
+    if os.environ.get("PGT_EMU_LIB"):        # e.g. an AddressSanitizer build of the same sources (scripts/asan_audit.sh)
+        return os.environ["PGT_EMU_LIB"]
     csrc = os.path.join(ROOT, "pytorch_geometric_temporal_amd", "csrc")
     srcs = sorted(glob.glob(os.path.join(csrc, "*.hip")))
     deps = srcs + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(ROOT, "include", "pgt_hip.h"),

@@ -30,8 +30,13 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+#ifdef PGT_EMU_STRICT_ALIGN   // UBSan audit (scripts/asan_audit.sh ubsan): vector accesses must be naturally aligned
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+#else
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+#endif
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }

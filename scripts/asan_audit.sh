@@ -1,17 +1,26 @@
 #!/bin/bash
 # Memory-safety audit of the kernels: the SAME .hip sources compiled for the CPU test double (tests/hipemu) with a
 # sanitizer, then the kernel / model parity tests (fuzz tests included) run against that build.
-#   scripts/asan_audit.sh [asan|ubsan] [pytest args]     default: asan; kernel, DCRNN, model and edge-case suites
+#   scripts/asan_audit.sh [asan|ubsan|order] [pytest args]     default: asan; kernel, DCRNN, model and edge-case suites
 # asan : every tensor the tests hand to a kernel is a separate heap allocation with red zones, so a clamped-load bug
 #        (a lane reading past the end of an operand, a tile writing past M or N) that a GPU would silently tolerate --
 #        or fault on, once in a while -- stops the run.
 # ubsan: float2 / float4 are declared naturally aligned (PGT_EMU_STRICT_ALIGN), so a vector access the host-side
 #        dispatch should not have allowed (8- / 16-byte alignment of operands, strides and segment offsets) is
 #        reported, together with signed overflow in the index arithmetic, invalid shifts and bounds of fixed arrays.
+# order: no sanitizer; the test double hands out turns to the wavefronts of a workgroup in reverse and in rotating order
+#        (PGT_EMU_ORDER): a result that changes with the order is a missing __syncthreads() between wavefronts.
 set -e
 cd "$(dirname "$0")/.."
 MODE=${1:-asan}
-case "$MODE" in asan|ubsan) shift || true ;; *) MODE=asan ;; esac
+case "$MODE" in asan|ubsan|order) shift || true ;; *) MODE=asan ;; esac
+if [ "$MODE" = order ]; then
+  for o in reverse rotate; do
+    echo "== wavefront order: $o"
+    PGT_EMU_ORDER=$o python -m pytest ${@:-tests/test_kernels.py tests/test_dcrnn.py tests/test_models.py tests/test_edge_cases.py} -x -q -m "not gpu"
+  done
+  exit 0
+fi
 OUT=${TMPDIR:-/tmp}/pgt_${MODE}_emu
 mkdir -p "$OUT"
 if [ "$MODE" = asan ]; then

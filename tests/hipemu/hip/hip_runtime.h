@@ -159,8 +159,17 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
         // barrier, so an intra-wave rendezvous (wave_barrier, shuffles, MFMA) costs one pass over 64 fibres instead
         // of one over the whole block.  A wave that makes no such progress for a few passes (it polls something another
         // wave produces) gives way to the next one.
+        // PGT_EMU_ORDER=reverse|rotate perturbs the ORDER in which wavefronts get their turns (scripts/asan_audit.sh
+        // order): a result that depends on it is a missing __syncthreads() between wavefronts.
+        static const int order_mode = [] {
+          const char* e = getenv("PGT_EMU_ORDER");
+          return !e ? 0 : (strcmp(e, "reverse") == 0 ? 1 : (strcmp(e, "rotate") == 0 ? 2 : 0));
+        }();
+        unsigned turn = 0;
         while (s.live_block) {
-          for (unsigned w = 0; w < nw; ++w) {
+          ++turn;
+          for (unsigned wi = 0; wi < nw; ++wi) {
+            const unsigned w = order_mode == 1 ? nw - 1 - wi : order_mode == 2 ? (wi + turn * 3 + bx) % nw : wi;
             const unsigned lo = w * 64, hi = std::min(lo + 64, s.nthreads);
             for (int pass = 0; pass < 8 && s.live_wave[w]; ++pass) {
               bool ran = false;

@@ -435,7 +435,9 @@ def test_spmm_band_window_matches_plain_and_reference(backend, halo, window, n, 
     lib.tune("spmm_wtile_tpw", 3 if sched == 41 else 1)
     if backend.name == "hip":
         n *= 37
-    elif n > 17 and sched == 1:
+    elif n > 600:
+        n = 600                     # the CPU test double is a fiber emulator: keep its share of the suite to seconds
+    if backend.name != "hip" and n > 17 and sched == 1:
         # the per-CU kernel launches 256 workgroups of 1024 lanes whatever n is; a 7-workgroup grid runs the same code
         lib.tune("spmm_band_nblk", 7)
     try:

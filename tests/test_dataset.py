@@ -234,3 +234,42 @@ def test_sensor_network_loaders(tmp_path, cls, prefix, zipname, mod):
         assert np.array_equal(a.edge_index, b.edge_index) and np.array_equal(a.edge_weight, b.edge_weight)
         for fa, fb, ta, tb in zip(a.features, b.features, a.targets, b.targets):
             assert np.array_equal(fa, fb) and np.array_equal(ta, tb)
+
+
+def test_fuzz_cache_round_trip(tmp_path):
+    """.pgtc files: any mix of dtypes and shapes (zero-sized arrays, scalars-as-1-element, odd byte counts between the
+    64-byte aligned blocks) comes back bit for bit, memory-mapped read-only, with the metadata intact."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import HealthCheck, given, settings, strategies as hst
+    from pytorch_geometric_temporal_amd.dataset.cache import load_cache, save_cache
+
+    dtypes = [np.float32, np.float64, np.int64, np.int32, np.int16, np.uint8, np.bool_]
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(spec=hst.lists(hst.tuples(hst.sampled_from(range(len(dtypes))),
+                                     hst.lists(hst.integers(0, 5), min_size=1, max_size=3)), min_size=1, max_size=6),
+           seed=hst.integers(0, 1000))
+    def run(spec, seed):
+        rng = np.random.default_rng(seed)
+        arrays = {}
+        for i, (dt, shape) in enumerate(spec):
+            a = (rng.random(shape) * 100).astype(dtypes[dt])
+            arrays[f"a{i}"] = a if i % 2 == 0 else np.asfortranarray(a)          # non-contiguous inputs are normalised
+        path = str(tmp_path / f"f{seed}.pgtc")
+        meta = {"seed": seed, "names": sorted(arrays), "nested": {"x": [1, 2.5, "s"]}}
+        save_cache(path, "fuzz", arrays, meta)
+        c = load_cache(path)
+        assert c.name == "fuzz" and c.meta == meta and sorted(c.arrays) == sorted(arrays)
+        for k, a in arrays.items():
+            b = c.arrays[k]
+            assert b.dtype == a.dtype and b.shape == a.shape and np.array_equal(np.asarray(b), a)
+            if a.size:
+                assert not b.flags.writeable
+                assert (b.ctypes.data - np.asarray(b).ctypes.data) == 0
+                assert b.offset % 64 == 0                                        # 64-byte aligned blocks
+
+    run()
+    with pytest.raises(ValueError, match="not a PGTCACHE"):
+        p = tmp_path / "junk.pgtc"
+        p.write_bytes(b"0123456789abcdef0123")
+        load_cache(str(p))

@@ -296,7 +296,7 @@ def astgcn_sensor():
     ei, _ = syn.sensor_graph(24, 150, seed=90, symmetric=False)
     X = _rand((3, 24, 2, 8), 91)
     outs, layer = {}, None
-    for norm in ("sym", None):
+    for norm in ("sym", None, "rw"):   # "rw": lambda_max still comes from the UNNORMALISED Laplacian (astgcn.py:438)
         layer_n = m.ASTGCN(2, 2, 3, 6, 5, 2, 4, 8, 24, normalization=norm)
         if layer is None:
             layer = layer_n
@@ -406,6 +406,88 @@ def evolvegcno_dynamic():
             outs[f"out{s}"] = layer(X, _t(eis[s]), _t(ews[s]))
     return _pack(inputs, layer, outs, {"steps": steps, "num_nodes": n})
 
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE.json shapes
+# Inputs are rebuilt from seeds on both sides (oracle/baseline_cases.py); the fixture stores the parameters, a sample of
+# the reference output and fp64 checksums per slice.
+
+@case
+def baseline_c2_batched_dcrnn64():
+    """config 2 at the BENCHMARKED model: BatchedDCRNN(2, 64, K=3), 207 nodes, B = 64, 12 steps, on the 1 515-edge graph
+    of BASELINE.json and the 1 722-edge variant (the reference's data)."""
+    from . import baseline_cases as BC
+    m = R.load("nn.recurrent.dcrnn")
+    layer = m.BatchedDCRNN(2, 64, 3)
+    BC.randomise(layer, 210)
+    outs = {}
+    for E in (1515, 1722):
+        ei, ew, X = BC.metrla(E)
+        with torch.no_grad():
+            out = layer(X, ei, ew)                                   # [64, 12, 207, 64]
+        outs[f"sample_E{E}"] = out[list(BC.METRLA_SAMPLE_B)][:, list(BC.METRLA_SAMPLE_T)].contiguous()
+        outs[f"sums_bt_E{E}"] = BC.slice_sums(out, (0, 1))
+        outs[f"abs_sums_bt_E{E}"] = BC.slice_sums(out.abs(), (0, 1))
+    return _pack({}, layer, outs, {"K": 3})
+
+
+@case
+def baseline_c3_a3tgcn2_pemsbay():
+    """config 3: A3TGCN2(2, 32, periods=12, batch_size=64) on the PeMS-BAY-shaped graph (325 nodes / 2 694 edges)."""
+    from . import baseline_cases as BC
+    m = R.load("nn.recurrent.attentiontemporalgcn")
+    ei, ew, X, H0 = BC.pemsbay()
+    layer = m.A3TGCN2(2, 32, periods=12, batch_size=64)
+    _fix_attention(layer, 310)
+    with torch.no_grad():
+        o1 = layer(X, ei, ew)
+        o2 = layer(X, ei, ew, H0)
+    sel = list(BC.PEMSBAY_SAMPLE_B)
+    return _pack({}, layer, {"sample_weight": o1[sel].contiguous(), "sample_weight_hidden": o2[sel].contiguous(),
+                             "sums_weight": BC.slice_sums(o1, (0, 1)), "sums_weight_hidden": BC.slice_sums(o2, (0, 1))},
+                 {"periods": 12})
+
+
+@case
+def baseline_c4_tgcn2_50k():
+    """config 4: TGCN2(2, 32, batch_size=8) on 50 000 nodes / 400 000 edges (locality-ordered and uniform-random)."""
+    from . import baseline_cases as BC
+    m = R.load("nn.recurrent.temporalgcn")
+    layer = m.TGCN2(2, 32, batch_size=8)
+    BC.randomise(layer, 410)
+    nodes = BC.sample_nodes_50k()
+    outs = {}
+    for kind in ("local", "uniform"):
+        ei, ew, X, H0 = BC.graph50k(kind)
+        with torch.no_grad():
+            out = layer(X, ei, ew, H0)                               # [8, 50 000, 32]
+        outs[f"sample_{kind}"] = out[:, nodes].contiguous()
+        # one checksum per batch entry and block of 500 consecutive nodes
+        outs[f"sums_{kind}"] = out.double().view(8, 100, 500 * 32).sum(-1)
+    return _pack({"sample_nodes": nodes}, layer, outs)
+
+
+@case
+def baseline_c5_evolvegcnh_covid():
+    """config 5: the vendored dataset/england_covid.json (129 regions, a new directed graph with weights up to 9.6e5
+    every day) through EvolveGCNH(129, 8), every snapshot the reference loader yields (lags = 8: 53 snapshots)."""
+    from . import baseline_cases as BC
+    m = R.load("nn.recurrent.evolvegcnh")
+    ds = R.load_dataset("encovid").EnglandCovidDatasetLoader
+    # the reference loader downloads its JSON; feed it the vendored copy instead
+    with open(os.path.join(R.REFERENCE_ROOT, "dataset", "england_covid.json")) as f:
+        raw = json.load(f)
+    loader = ds.__new__(ds)
+    loader._dataset = raw
+    signal = loader.get_dataset(lags=8)
+    layer = m.EvolveGCNH(129, 8)
+    BC.randomise(layer, 510)
+    outs, wmax = [], 0.0
+    with torch.no_grad():
+        for snap in signal:
+            outs.append(layer(snap.x, snap.edge_index, snap.edge_attr))
+            wmax = max(wmax, float(snap.edge_attr.max()))
+    return _pack({}, layer, {"out": torch.stack(outs)}, {"snapshots": len(outs), "max_weight": wmax})
 
 # ------------------------------------------------------------------------------------------------ signal iterator
 

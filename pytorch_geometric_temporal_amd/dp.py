@@ -129,5 +129,10 @@ def reduce_scalars(values, dst=0):
     """Per-epoch metric reduction (pems_ddp.py:160-161): SUM of a small float vector onto rank `dst`."""
     t = values if isinstance(values, torch.Tensor) else torch.tensor(values, dtype=torch.float64)
     if dist.is_initialized() and dist.get_world_size() > 1:
+        # RCCL ("nccl") only moves device tensors: stage the vector on this rank's GPU and hand back a host tensor
+        if dist.get_backend() == "nccl" and not t.is_cuda:
+            d = t.to(torch.device("cuda", torch.cuda.current_device()))
+            dist.reduce(d, dst=dst, op=dist.ReduceOp.SUM)
+            return d.cpu()
         dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
     return t

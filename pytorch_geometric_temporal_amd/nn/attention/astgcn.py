@@ -138,7 +138,9 @@ class ASTGCNBlock(torch.nn.Module):
         if self._normalization == "sym":
             return None
         from ..conv import laplacian_lambda_max
-        return laplacian_lambda_max(edge_index, n, self._normalization)
+        # LaplacianLambdaMax() with its default normalization=None (astgcn.py:438, :460): the largest eigenvalue of the
+        # UNNORMALISED Laplacian, whatever the block's normalization is
+        return laplacian_lambda_max(edge_index, n, None)
 
     def forward(self, X, edge_index):
         B, N, Fin, T = X.shape

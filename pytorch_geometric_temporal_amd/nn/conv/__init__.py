@@ -214,8 +214,8 @@ def laplacian_lambda_max(edge_index, num_nodes, normalization=None, edge_weight=
     """Largest eigenvalue of the graph Laplacian — what torch_geometric.transforms.LaplacianLambdaMax computes for
     ASTGCN / MSTGCN every forward (astgcn.py:437-440, mstgcn.py:74-76).  Host-side (scipy ARPACK, as in PyG), once
     per edge list: the result is cached by tensor identity."""
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), str(edge_index.device), normalization,
-           None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version), int(num_nodes))
+    key = (edge_index.data_ptr(), ops.tensor_version(edge_index), tuple(edge_index.shape), str(edge_index.device), normalization,
+           None if edge_weight is None else (edge_weight.data_ptr(), ops.tensor_version(edge_weight)), int(num_nodes))
     hit = _LAMBDA_CACHE.get(key)
     if hit is not None:
         return hit[0]

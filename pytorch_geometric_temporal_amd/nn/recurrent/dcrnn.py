@@ -43,8 +43,10 @@ class DConv(torch.nn.Module):
     def forward(self, X, edge_index, edge_weight=None):
         """X [num_nodes, in_channels], edge_index [2,E] int64, edge_weight [E] or None -> [num_nodes, out_channels]
         (reference: dcrnn.py:42-111)."""
-        g = ops.dconv_graph(edge_index, edge_weight, X.size(0), strict_dense=self._strict_dense)
         K = self.weight.size(1)
+        # K = 1 never touches the reversed edge list in the reference (dcrnn.py:85 onwards is skipped), so duplicate
+        # edges / zero weights are accepted there
+        g = ops.dconv_graph(edge_index, edge_weight, X.size(0), strict_dense=self._strict_dense and K > 1)
         return ops.DConvFunction.apply(X.contiguous(), ops.stack_weight(self.weight), self.bias, g, K, 1)
 
 
@@ -97,7 +99,7 @@ class DCRNN(torch.nn.Module):
     def forward(self, X, edge_index, edge_weight=None, H=None):
         """X [N, in], edge_index [2,E], edge_weight [E]|None, H [N, out]|None -> H' [N, out] (dcrnn.py:194-219)."""
         H = self._set_hidden_state(X, H)
-        g = ops.dconv_graph(edge_index, edge_weight, X.size(0), strict_dense=True)
+        g = ops.dconv_graph(edge_index, edge_weight, X.size(0), strict_dense=self.K > 1)
         Wzr, bzr, Wh, bh = _cell_weights(self.conv_x_z, self.conv_x_r, self.conv_x_h)
         out = ops.DCRNNSeqFunction.apply(X.contiguous().unsqueeze(0), H, Wzr, bzr, Wh, bh, g, self.K, 1)
         return out[0]

@@ -7,6 +7,7 @@ import math
 from collections import OrderedDict
 
 import os
+import warnings
 
 import torch
 
@@ -79,6 +80,11 @@ def _edge_inputs(lib, edge_index, edge_weight):
     ew = None
     if edge_weight is not None:
         ew = edge_weight
+        if ew.requires_grad and torch.is_grad_enabled():
+            # graph preparation runs outside autograd: the reference's GCNConv / ChebConv would propagate a gradient
+            # to learnable edge weights, this path does not — say so instead of dropping it silently
+            warnings.warn("pytorch_geometric_temporal_amd: edge_weight requires grad, but graph preparation is not "
+                          "differentiable here — no gradient will reach edge_weight", stacklevel=3)
         if ew.dtype != F32:
             ew = ew.to(F32)
         check_tensor(lib, ew, "edge_weight", F32)
@@ -154,6 +160,12 @@ class SymGraph:
                 raise IndexError(f"edge_index has {oob} endpoint(s) outside [0, {N})")
 
 
+def tensor_version(t):
+    """In-place version counter of `t`; inference tensors (created under torch.inference_mode()) do not track one and
+    cannot be mutated in place outside inference mode, so a constant stands in for it."""
+    return 0 if t.is_inference() else t._version
+
+
 class _GraphCache:
     """Identity-keyed cache (data_ptr + in-place version counter), never torch.equal (no host sync per forward;
     the reference compares with torch.equal twice per BatchedDCRNN forward, dcrnn.py:446-447)."""
@@ -166,7 +178,7 @@ class _GraphCache:
     def _tkey(t):
         if t is None:
             return None
-        return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), str(t.device), t.dtype)
+        return (t.data_ptr(), tensor_version(t), tuple(t.shape), tuple(t.stride()), str(t.device), t.dtype)
 
     def get(self, tag, edge_index, edge_weight, extra, builder):
         key = (tag, self._tkey(edge_index), self._tkey(edge_weight), extra)

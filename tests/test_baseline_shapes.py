@@ -1,0 +1,202 @@
+"""Parity at BASELINE.json's OWN shapes (configs 2-5), against fixtures produced by the reference's actual module files
+(tests/golden/baseline_*.npz, oracle/make_golden.py) and — for the gradients — against the fp64 oracle.
+
+The multi-megabyte inputs are rebuilt from seeds (oracle/baseline_cases.py); a fixture holds the parameters, a sample
+of the reference output and fp64 checksums of every slice of it.  The GPU legs go through libpgt_hip.so on cuda:0; the
+CPU legs pin the oracle itself to the same fixtures.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import assert_close_with_nonfinite, load_golden
+from oracle import baseline_cases as BC
+from oracle import functional as F
+from pytorch_geometric_temporal_amd.nn.recurrent import A3TGCN2, TGCN2, BatchedDCRNN, EvolveGCNH
+
+ATOL, RTOL = 1e-5, 1e-5   # north_star: forward within 1e-5 of the reference CPU forward (fp32)
+
+
+def _check_sums(out, ref_sums, keep_dims, what):
+    """Checksum of every slice: |sum - ref| <= 1e-5 * (sum |x| + sqrt(n)) — catches a wrong element anywhere in the
+    tensor (the sampled slices carry the element-wise 1e-5 check)."""
+    got = BC.slice_sums(out, keep_dims)
+    mag = BC.slice_sums(out.abs(), keep_dims)
+    n = out.numel() / got.numel()
+    ref = ref_sums.double().reshape(got.shape)
+    bad = (got - ref).abs() > 1e-5 * (mag + math.sqrt(n))
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} slice checksum(s) off, worst {float((got - ref).abs().max()):.3e}"
+
+
+def _grad_check(model, params64, atol, rtol):
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        assert_close_with_nonfinite(p.grad, params64[name].grad, atol * float(params64[name].grad.abs().max() + 1), rtol, name)
+
+
+def _params64(g):
+    return {k: v.double().requires_grad_() for k, v in g["param"].items()}
+
+
+# ------------------------------------------------------------------------------------------------ config 2
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E", [1515, 1722])
+@pytest.mark.parametrize("lazy", [False, True])
+def test_config2_benchmarked_dcrnn_forward_matches_reference_fixture(E, lazy):
+    """BatchedDCRNN(2, 64, K=3), 207 nodes, B = 64 x 12 steps: the model bench.py times, through the slab kernels at
+    C = 66 and the gate-fused GEMMs, against the reference module's output."""
+    dev = torch.device("cuda:0")
+    g = load_golden("baseline_c2_batched_dcrnn64")
+    ei, ew, X = BC.metrla(E)
+    m = BatchedDCRNN(2, 64, 3)
+    m.load_state_dict(g["param"], strict=True)
+    m = m.to(dev)
+    m.lazy_output = lazy
+    with torch.no_grad():
+        out = m(X.to(dev), ei.to(dev), ew.to(dev))
+    assert tuple(out.shape) == (64, 12, 207, 64)
+    sample = out[list(BC.METRLA_SAMPLE_B)][:, list(BC.METRLA_SAMPLE_T)]
+    assert_close_with_nonfinite(sample, g["out"][f"sample_E{E}"], ATOL, RTOL, f"E={E} sampled (b, t) slices")
+    _check_sums(out, g["out"][f"sums_bt_E{E}"], (0, 1), f"E={E}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E", [1515, 1722])
+def test_config2_benchmarked_dcrnn_gradients_match_fp64_oracle(E):
+    """Every parameter gradient of the benchmarked model (hidden 64, B = 64) against autograd through the fp64 oracle
+    (op for op the reference).  dW comes from fp32 atomics: tolerance 2e-4 of the gradient's scale."""
+    dev = torch.device("cuda:0")
+    g = load_golden("baseline_c2_batched_dcrnn64")
+    ei, ew, X = BC.metrla(E)
+    w = BC.rand((64, 12, 207, 64), 220)
+    m = BatchedDCRNN(2, 64, 3)
+    m.load_state_dict(g["param"], strict=True)
+    m = m.to(dev)
+    out = m(X.to(dev), ei.to(dev), ew.to(dev))
+    (out * w.to(dev)).sum().backward()
+    p64 = _params64(g)
+    ref = F.batched_dcrnn(X.double(), ei, ew.double(), p64)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward vs fp64 oracle")
+    _grad_check(m, p64, 2e-4, 2e-4)
+
+
+def test_config2_oracle_reproduces_the_reference_fixture():
+    """The fp32 oracle (oracle/functional.py) against the reference module's output at the benchmarked shape
+    (a quarter of the batch: the samples are independent)."""
+    g = load_golden("baseline_c2_batched_dcrnn64")
+    ei, ew, X = BC.metrla(1515)
+    with torch.no_grad():
+        out = F.batched_dcrnn(X[:1], ei, ew, g["param"])
+    assert_close_with_nonfinite(out[0, list(BC.METRLA_SAMPLE_T)], g["out"]["sample_E1515"][0], 2e-6, 2e-6, "b = 0")
+
+
+# ------------------------------------------------------------------------------------------------ config 3
+
+@pytest.mark.gpu
+def test_config3_a3tgcn2_pemsbay_forward_and_gradients():
+    """A3TGCN2(2, 32, periods=12), 325 nodes / 2 694 edges, B = 64 (attentiontemporalgcn.py:130-157)."""
+    dev = torch.device("cuda:0")
+    g = load_golden("baseline_c3_a3tgcn2_pemsbay")
+    ei, ew, X, H0 = BC.pemsbay()
+    m = A3TGCN2(2, 32, periods=12, batch_size=64)
+    m.load_state_dict(g["param"], strict=True)
+    m = m.to(dev)
+    sel = list(BC.PEMSBAY_SAMPLE_B)
+    with torch.no_grad():
+        o1 = m(X.to(dev), ei.to(dev), ew.to(dev))
+        o2 = m(X.to(dev), ei.to(dev), ew.to(dev), H0.to(dev))
+    assert tuple(o1.shape) == (64, 325, 32)
+    assert_close_with_nonfinite(o1[sel], g["out"]["sample_weight"], ATOL, RTOL, "weight")
+    assert_close_with_nonfinite(o2[sel], g["out"]["sample_weight_hidden"], ATOL, RTOL, "weight+hidden")
+    _check_sums(o1, g["out"]["sums_weight"], (0, 1), "weight")
+    _check_sums(o2, g["out"]["sums_weight_hidden"], (0, 1), "weight+hidden")
+    # gradients against the fp64 oracle
+    w = BC.rand((64, 325, 32), 320)
+    Xd, Hd = X.to(dev).requires_grad_(), H0.to(dev).requires_grad_()
+    out = m(Xd, ei.to(dev), ew.to(dev), Hd)
+    (out * w.to(dev)).sum().backward()
+    p64 = _params64(g)
+    X64, H64 = X.double().requires_grad_(), H0.double().requires_grad_()
+    ref = F.a3tgcn(X64, ei, ew.double(), H64, p64)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward vs fp64 oracle")
+    assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+    assert_close_with_nonfinite(Hd.grad, H64.grad, 5e-5, 1e-4, "dH")
+    _grad_check(m, p64, 1e-4, 1e-4)
+
+
+def test_config3_oracle_reproduces_the_reference_fixture():
+    g = load_golden("baseline_c3_a3tgcn2_pemsbay")
+    ei, ew, X, H0 = BC.pemsbay()
+    sel = list(BC.PEMSBAY_SAMPLE_B)
+    with torch.no_grad():
+        o2 = F.a3tgcn(X[sel], ei, ew, H0[sel], g["param"])
+    assert_close_with_nonfinite(o2, g["out"]["sample_weight_hidden"], 2e-6, 2e-6, "weight+hidden")
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["local", "uniform"])
+def test_config4_tgcn2_50k_nodes_forward_and_gradients(kind):
+    """TGCN2(2, 32), 50 000 nodes / 400 000 edges, B = 8 (temporalgcn.py:187-233): the wide aggregation kernel with
+    its XCD column-slab mapping at real size, locality-ordered and uniform-random neighbours."""
+    dev = torch.device("cuda:0")
+    g = load_golden("baseline_c4_tgcn2_50k")
+    ei, ew, X, H0 = BC.graph50k(kind)
+    nodes = BC.sample_nodes_50k()
+    assert torch.equal(nodes, g["in"]["sample_nodes"])
+    m = TGCN2(2, 32, batch_size=8)
+    m.load_state_dict(g["param"], strict=True)
+    m = m.to(dev)
+    Xd, Hd = X.to(dev).requires_grad_(), H0.to(dev).requires_grad_()
+    out = m(Xd, ei.to(dev), ew.to(dev), Hd)
+    assert tuple(out.shape) == (8, 50_000, 32)
+    assert_close_with_nonfinite(out[:, nodes.to(dev)], g["out"][f"sample_{kind}"], ATOL, RTOL, f"{kind}: sampled nodes")
+    got = out.detach().double().cpu().view(8, 100, 500 * 32)
+    bad = (got.sum(-1) - g["out"][f"sums_{kind}"]).abs() > 1e-5 * (got.abs().sum(-1) + math.sqrt(16000))
+    assert not bool(bad.any()), f"{kind}: {int(bad.sum())} block checksum(s) off"
+    w = BC.rand((8, 50_000, 32), 420)
+    (out * w.to(dev)).sum().backward()
+    p64 = _params64(g)
+    X64, H64 = X.double().requires_grad_(), H0.double().requires_grad_()
+    ref = F.tgcn_cell(X64, ei, ew.double(), H64, p64)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward vs fp64 oracle")
+    assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+    assert_close_with_nonfinite(Hd.grad, H64.grad, 5e-5, 1e-4, "dH")
+    _grad_check(m, p64, 2e-4, 2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+
+def _covid_signal():
+    from pytorch_geometric_temporal_amd.dataset import EnglandCovidDatasetLoader
+    return EnglandCovidDatasetLoader().get_dataset(lags=8)
+
+
+def _run_covid(backend):
+    g = load_golden("baseline_c5_evolvegcnh_covid")
+    signal = _covid_signal()
+    m = EvolveGCNH(129, 8)
+    m.load_state_dict(g["param"], strict=True)
+    m = m.to(backend.device)
+    outs, wmax = [], 0.0
+    with torch.no_grad():
+        for snap in signal:        # the evolved weight is carried from snapshot to snapshot (evolvegcnh.py:97-100)
+            outs.append(m(backend.t(snap.x), backend.t(snap.edge_index), backend.t(snap.edge_attr)))
+            wmax = max(wmax, float(snap.edge_attr.max()))
+    assert len(outs) == int(g["meta"]["snapshots"]) == 53
+    assert wmax == float(g["meta"]["max_weight"]) > 9e5
+    ref = g["out"]["out"]
+    for s, o in enumerate(outs):
+        assert_close_with_nonfinite(o, ref[s], 2e-5, 2e-5, f"snapshot {s}")
+
+
+def test_config5_evolvegcnh_on_the_vendored_covid_graphs(backend):
+    """Every snapshot of dataset/england_covid.json (a new directed graph with weights up to 9.6e5 each day) through
+    EvolveGCNH(129, 8), against the reference module fed by the reference loader (evolvegcnh.py:78-102)."""
+    _run_covid(backend)

@@ -812,6 +812,23 @@ def test_gemm_schedules_agree_at_benchmark_size():
         scale = float(y.abs().max())
         tol = 2e-3 if name in ("dW", "db") else 2e-5           # dW / db: 212 k-term sums, atomics in two orders
         assert float((x - y).abs().max()) <= tol * max(scale, 1.0), name
+    # ... and every shape against an fp64 product: 512 sampled rows of the tall outputs, the whole dW / db
+    rows = torch.from_numpy(np.random.default_rng(8).choice(M, size=512, replace=False)).sort().values
+    A64 = A.cpu().double()                                                     # [S, M, C]
+    As = A64[:, rows].permute(1, 0, 2).reshape(512, S * C)                     # sampled rows of the K-segmented operand
+    W64, b64 = W.cpu().double(), b.cpu().double()
+    for db in (1, 0):
+        C1, C2, G, dW, db_ = out[db]
+        assert_close_with_nonfinite(C1[rows.to(dev)], As @ W64 + b64, 2e-5, 2e-5, f"db={db} NN 330->128 vs fp64")
+        assert_close_with_nonfinite(C2[rows.to(dev)], As @ W64[:, :O], 2e-5, 2e-5, f"db={db} NN 330->64 vs fp64")
+        G64 = (C1[rows.to(dev)].cpu().double() @ W64.t()).view(512, S, C).permute(1, 0, 2)
+        assert_close_with_nonfinite(G[:, rows.to(dev)], G64, 2e-5, 2e-5, f"db={db} NT 128->330 vs fp64")
+        C164 = C1.cpu().double()
+        dW64 = A64.permute(1, 0, 2).reshape(M, S * C).t() @ C164
+        scale = float(dW64.abs().max())
+        assert float((dW.cpu().double() - dW64).abs().max()) <= 2e-4 * scale, f"db={db} dW vs fp64"
+        assert float((db_.cpu().double() - C164.sum(0)).abs().max()) <= 2e-4 * float(C164.sum(0).abs().max()), f"db={db} db"
+    del A64, C164
     # fused epilogues at full size
     H = torch.randn(M, O, generator=g).to(dev)
     zr0, xhr0 = out[1][0].clone(), torch.zeros(M, C, device=dev)

@@ -392,7 +392,7 @@ def test_astgcn_matches_reference_fixture_and_backpropagates(backend):
     g = load_golden("astgcn_sensor")
     X, ei = backend.t(g["in"]["X"]), backend.t(g["in"]["edge_index"])
     args = [int(a) for a in g["meta"]["args"]]
-    for norm in ("sym", None):
+    for norm in ("sym", None, "rw"):
         m = _load(ASTGCN(*args, normalization=norm), g["param"], backend.device)
         with torch.no_grad():
             out = m(X, ei)

@@ -147,13 +147,13 @@ def cpu_spmm_ns(cores, seconds=2.0):
 
 
 def spmm_roofline_ns(device, pairs=6, launches=60):
-    """North-star micro-benchmark: one diffusion-conv aggregation Y = P_o X at N = 200 000, F = 64, in-degree 8.
+    """North-star micro-benchmark: one diffusion-conv aggregation Y = P_o X at N = 200 000, F = 64, in-degree 8 (and 16).
     The launches rotate through `pairs` distinct (X, Y) buffer pairs (6 x 102 MB) so the 256 MiB Infinity Cache
     cannot keep X resident between launches: X really comes from HBM every time."""
     res = {}
     n = 200_000
-    for name, gen in (("local", syn.local_graph), ("uniform", syn.uniform_graph)):
-        ei_np, ew_np = gen(n, 8, seed=0)
+    for name, gen, deg in (("local", syn.local_graph, 8), ("uniform", syn.uniform_graph, 8), ("local_deg16", syn.local_graph, 16)):
+        ei_np, ew_np = gen(n, deg, seed=0)
         g = ops.DConvGraph(torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device), n)
         Xs = [torch.randn(n, 64, device=device) for _ in range(pairs)]
         Ys = [torch.empty(n, 64, device=device) for _ in range(pairs)]
@@ -171,17 +171,27 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
         torch.cuda.current_stream(device).wait_stream(side)
         graph.replay()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        graph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        us = 1e3 * e0.elapsed_time(e1) / launches
+        times = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(1e3 * e0.elapsed_time(e1) / launches)
+        us = sum(times) / len(times)                       # the MEAN of three replays of 60 launches (not the best)
         nbytes = ops.spmm_algorithmic_bytes(n, g.E, 64, False)
-        res[name] = {"us_per_launch": us, "algorithmic_MB": nbytes / 1e6, "achieved_GBs": nbytes / us / 1e3,
-                     "frac": nbytes / us / 1e3 / HBM_PEAK_GBS, "edges": int(g.E),
-                     "buffers": f"{pairs} rotating (X,Y) pairs", "launch": f"{launches} launches replayed as one hipGraph"}
-        del g, Xs, Ys
+        e = g.fwd_o.ellw
+        res[name] = {"us_per_launch": us, "us_per_launch_replays": times, "algorithmic_MB": nbytes / 1e6,
+                     "achieved_GBs": nbytes / us / 1e3, "frac": nbytes / us / 1e3 / HBM_PEAK_GBS, "edges": int(g.E),
+                     "in_degree": deg,
+                     "kernel": ("spmm_tile_kernel<4,16,32,8> (CSR row tiles, pgt_spmm_csr_f32)" if e is None else
+                                f"spmm_ellw64_kernel<{0 if e.scale is not None else 1}> (pgt_spmm_ellw_f32: "
+                                f"{e.n_tiles} tiles of {e.tile_rows} rows x {e.width} slots, halo {e.halo}, "
+                                f"{'per-source scale table' if e.scale is not None else 'per-slot coefficients'}, "
+                                f"{e.far} out-of-window slots)"),
+                     "buffers": f"{pairs} rotating (X,Y) pairs", "launch": f"{launches} launches replayed as one hipGraph, mean of 3 replays"}
+        del g, Xs, Ys, graph
     return res
 
 

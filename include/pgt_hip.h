@@ -22,7 +22,7 @@
  *   pgt_spmm_csr_f32      MessagePassing.propagate(aggr="add") + message():
  *                         dcrnn.py:39-40,86-87,95-100,300-313; astgcn.py:169-175,185-190; evolvegcno.py:95-101
  *                         (index_select -> norm*x_j -> scatter_add, fused, with the 2*P*T - T0 epilogue of dcrnn.py:96,100)
- *   pgt_spmm_csr_band_f32 the same propagate call sites on a locality-ordered graph (LDS-window schedule)
+ *   pgt_spmm_ellw_f32     the same propagate call sites on a locality-ordered graph (ELLW layout, LDS window)
  *   pgt_dconv_stack_slab* the K-hop recursion dcrnn.py:85-106 (all propagate calls of one DConv) for small graphs
  *   pgt_gemm_f32          the dense feature transforms: dcrnn.py:81-83,88-92,101-105 (torch.matmul on weight[d][k]);
  *                         PyG Linear in GCNConv/ChebConv; temporalgcn.py:84,90,96 (linear_{z,r,h})
@@ -45,7 +45,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 6
+#define PGT_ABI_VERSION 7
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -90,8 +90,8 @@ const char* pgt_build_target(void);
  * "gemm_db64", "gemm_dbp" (persistent deferred-store tiles: 1 / 2 = on three workgroups / 0), "gemm_skinny"
  * (streaming kernels for an extent <= 4: 1 from 1024 rows / 2 always / 0), "gemm_small_tiles", "gemm_tn_pipe",
  * "gemm_tn_fullk".  Diffusion stack: "slab_pairs".  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
- * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_band_cu", "spmm_wtile_tpw",
- * "spmm_quad", ...  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
+ * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_ellw" (0: pgt_spmm_ellw_f32 runs
+ * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" (test hooks of pgt_ellw_plan).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
 int pgt_tune(const char* key, int value);
 
 /* ---------------------------------------------------------------- graph preparation */
@@ -131,19 +131,50 @@ int pgt_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val
                      const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt,
                      float alpha, float beta, int64_t F, pgt_stream_t stream);
 
-/* Same contract as pgt_spmm_csr_f32 plus a locality hint: `halo` > 0 promises that MOST slots satisfy
- * |col[q] - row| <= halo (a bandwidth-reduced / locality-ordered node numbering, as road-sensor graphs have).
- * For F == 64 (16-byte aligned operands) and halo <= 96 the launch then slides a window of X rows through LDS and
- * serves the neighbour gather from LDS instead of the vector L1; slots outside the window are still read from
- * global memory, so the result is correct for ANY operator — the hint only selects the faster schedule.
- * Other shapes, or halo == 0, run pgt_spmm_csr_f32. */
-int pgt_spmm_csr_band_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
-                          const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt,
-                          float alpha, float beta, int64_t F, int32_t halo, pgt_stream_t stream);
+/* ELLW: the layout of a locality-ordered operator for F = 64 (spmm_ellw64_kernel, csrc/spmm.hip) — what replaces
+ * `propagate` on a bandwidth-reduced node numbering (road-sensor graphs; the north-star shape N = 200 000, in-degree 8:
+ * 21 us = 0.69 of 8 TB/s against 33 us for the CSR row tiles).  Rows are cut into tiles of `tile_rows` rows; every row
+ * has `width` slots (the longest row rounded up to a multiple of 8; padding slots point at a zero row); slot j of row
+ * i is CSR slot rowptr[i] + j, stored as the 16-bit offset of its source row inside the tile's window
+ * [t * tile_rows - halo, (t + 1) * tile_rows + halo), or 0xFFFF when the source lies outside it (then read through
+ * the CSR arrays: any operator is represented exactly).  Coefficients: `vals` (one per slot), or — when
+ * val[q] == scale[col[q]] for every slot, as for DConv's P_o = A D_out^-1 (dcrnn.py:70-73) — the per-source table
+ * `scale` alone (the coefficient stream is dropped and the products are rounded once, as norm * x_j is). */
+typedef struct pgt_ellw {
+  const uint16_t* slots;  /* [n_tiles * tile_rows * width] */
+  const float* vals;      /* [n_tiles * tile_rows * width], or NULL in source-scale mode */
+  const float* scale;     /* [n_rows] coefficient per SOURCE row, or NULL; exactly one of vals / scale is set */
+  int32_t tile_rows, halo, width, reserved;
+  int64_t n_tiles;
+} pgt_ellw;
 
-/* out2[0] = #slots with |col - row| <= 32, out2[1] = #slots with |col - row| <= 96 (device int32[2]); the host
- * derives the `halo` hint above from these two counts once per prepared graph. */
-int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out2,
+/* Host-only: tile height / slot width / tile count for an operator with `n_rows` rows whose longest row has
+ * `max_row_len` slots and whose sources lie (mostly) within `halo` rows of their destination; the tile height fills
+ * whole rounds of one workgroup per CU of the current device.  PGT_ERR_INVALID when the layout does not apply
+ * (rows longer than 32 slots, halo > 224). */
+int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t* tile_rows, int32_t* width,
+                  int64_t* n_tiles);
+
+/* Fill `slots` / `vals` (each n_tiles * tile_rows * width entries; `vals` may be NULL) from the CSR operator, with the
+ * geometry in `op` (its pointers are ignored).  `scale` (float [n_rows], may be NULL) receives the candidate
+ * per-source table scale[col[q]] = val[q].  info (int32 [4], device): [0] = slots outside their window (served
+ * through the CSR at run time: correct, slower), [1] = slots whose val differs bitwise from scale[col] (0 = the
+ * source-scale mode applies), [2] = rows longer than `width` (must be 0: their tail is not represented). */
+int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t nnz,
+                   const pgt_ellw* op, uint16_t* slots, float* vals, float* scale, int32_t* info,
+                   pgt_stream_t stream);
+
+/* pgt_spmm_csr_f32's contract on the ELLW layout of the same operator (the CSR arrays it was built from are passed
+ * along: they serve out-of-window slots, and shapes the window kernel does not cover — F != 64, operands that are
+ * not 16-byte aligned — run the CSR kernels).  Source-scale mode accumulates rounded products with rounded adds in
+ * slot order (the reference's `norm * x_j` then scatter-add); per-slot mode is the CSR kernels' fmaf chain, bit for bit. */
+int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                      const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha,
+                      float beta, int64_t F, pgt_stream_t stream);
+
+/* out3[0] = #slots with |col - row| <= 32, out3[1] = #slots with |col - row| <= 96, out3[2] = slots of the longest
+ * row (device int32[3]); the host decides from these whether the ELLW layout applies, once per prepared graph. */
+int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out3,
                      pgt_stream_t stream);
 
 /* Same with a per-batch dense attention multiplier (ChebConvAttention hop 1, astgcn.py:157,169-171):

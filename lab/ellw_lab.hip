@@ -17,6 +17,17 @@
 #include <algorithm>
 #include <vector>
 
+void pgt_gemm_set_force_small(int) {}
+void pgt_gemm_set_tn_fullk(int) {}
+void pgt_gemm_set_db(int) {}
+void pgt_gemm_set_db64(int) {}
+void pgt_slab_set_pairs(int) {}
+void pgt_gemm_set_tn_pipe(int) {}
+void pgt_gemm_set_skinny(int) {}
+void pgt_gemm_set_dbp(int) {}
+#include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
+#include "../pytorch_geometric_temporal_amd/csrc/spmm.hip"
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(THREADS) void ellw_kernel(
     wr = wr < WR ? wr : WR - 1;
     int r = w0 + wr;
     r = r < 0 ? 0 : (r < n ? r : n - 1);
-    xw[i] = ld4<NTL>(Xl + (size_t)r * 64);
+    xw[i] = ld4<NTL>(Xl + (unsigned)(r * 64));
     if constexpr (MODE == 0) sc[i] = scale[r];
   }
   u4 sv[RPG];
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(THREADS) void ellw_kernel(
   for (int k = 0; k < RPG; ++k) {
     int r = rg + G * k;
     r = r < nr ? r : nr - 1;
-    sv[k] = *reinterpret_cast<const u4*>(slots + ((size_t)(r0 + r)) * W);
+    sv[k] = *reinterpret_cast<const u4*>(slots + (unsigned)((r0 + r) * W));
   }
   // ---- window -> LDS (pre-scaled in MODE 0: the product is rounded once, like norm * x_j in the reference)
 #pragma unroll
@@ -101,8 +112,8 @@ __global__ __launch_bounds__(THREADS) void ellw_kernel(
       f4 x[8];
       float vv[8];
       if constexpr (MODE == 1) {
-        const f4 va = *reinterpret_cast<const f4*>(vals + ((size_t)(r0 + r)) * W);
-        const f4 vb = *reinterpret_cast<const f4*>(vals + ((size_t)(r0 + r)) * W + 4);
+        const f4 va = *reinterpret_cast<const f4*>(vals + (unsigned)((r0 + r) * W));
+        const f4 vb = *reinterpret_cast<const f4*>(vals + (unsigned)((r0 + r) * W) + 4);
         vv[0] = va.x; vv[1] = va.y; vv[2] = va.z; vv[3] = va.w; vv[4] = vb.x; vv[5] = vb.y; vv[6] = vb.z; vv[7] = vb.w;
       }
       bool far = false;
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(THREADS) void ellw_kernel(
         for (int j = 0; j < 8; ++j)
           if (d[j] == 0xffffu) {
             const int c = col[q0 + j];
-            f4 xx = *reinterpret_cast<const f4*>(Xl + (size_t)c * 64);
+            f4 xx = *reinterpret_cast<const f4*>(Xl + (unsigned)(c * 64));
             if constexpr (MODE == 0) {
               const float s = scale[c];
               xx.x = __fmul_rn(xx.x, s); xx.y = __fmul_rn(xx.y, s); xx.z = __fmul_rn(xx.z, s); xx.w = __fmul_rn(xx.w, s);
@@ -138,10 +149,119 @@ __global__ __launch_bounds__(THREADS) void ellw_kernel(
           acc.z = fmaf(vv[j], x[j].z, acc.z); acc.w = fmaf(vv[j], x[j].w, acc.w);
         }
       }
-      st4<NTS>(Y + (size_t)(r0 + r) * 64 + l16 * 4, acc);
+      st4<NTS>(Y + (unsigned)((r0 + r) * 64 + l16 * 4), acc);
     }
   }
   MARK(3);
+}
+
+
+// persistent variant: one workgroup per CU walks `tpw` tiles; the next tile's window / scales / slots are requested
+// right after the barrier that publishes the current window, so they are in flight while the current tile is gathered
+// and stored.  Slot vectors of the current tile live in LDS (the registers hold the next tile's).
+template <int THREADS, int WRMAX, int TRMAX, int NTS, int GSTEP>
+__global__ __launch_bounds__(THREADS) void ellw_persist_kernel(
+    const uint16_t* __restrict__ slots, const float* __restrict__ scale,
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    int n, int TR, int H, const float* __restrict__ X, float* __restrict__ Y, int n_tiles, int tpw) {
+  constexpr int W = 8;
+  constexpr int G = THREADS / 16;
+  constexpr int XPT = (WRMAX + G - 1) / G;
+  constexpr int RPG = (TRMAX + G - 1) / G;
+  __shared__ f4 s_x[(WRMAX + 1) * 16];
+  __shared__ u4 s_sv[TRMAX];
+  const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+  const int WR = TR + 2 * H;
+  const float* Xl = X + l16 * 4;
+  // XCD x = blockIdx % 8 owns a contiguous range of tiles; its workgroups take them round-robin
+  const int nwx = (int)(gridDim.x >> 3), x = (int)(blockIdx.x & 7u), l = (int)(blockIdx.x >> 3);
+  const int q = n_tiles >> 3, rem = n_tiles & 7;
+  const int t_lo = x * q + (x < rem ? x : rem), t_hi = t_lo + q + (x < rem ? 1 : 0);
+  f4 xw[XPT];
+  float sc[XPT];
+  u4 sv[RPG];
+  auto fetch = [&](int tile) {
+    const int r0 = tile * TR, w0 = r0 - H;
+    const int nr = (n - r0 < TR) ? (n - r0) : TR;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      int wr = rg + G * i;
+      wr = wr < WR ? wr : WR - 1;
+      int r = w0 + wr;
+      r = r < 0 ? 0 : (r < n ? r : n - 1);
+      xw[i] = *reinterpret_cast<const f4*>(Xl + (unsigned)(r * 64));
+      sc[i] = scale[r];
+    }
+#pragma unroll
+    for (int k = 0; k < RPG; ++k) {
+      int r = rg + G * k;
+      r = r < nr ? r : nr - 1;
+      sv[k] = *reinterpret_cast<const u4*>(slots + (unsigned)((r0 + r) * W));
+    }
+  };
+  int tile = t_lo + l;
+  if (tile >= t_hi) return;
+  fetch(tile);
+  if (tid < 16) s_x[WR * 16 + tid] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < tpw; ++it) {
+    const int r0 = tile * TR;
+    const int nr = (n - r0 < TR) ? (n - r0) : TR;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int wr = rg + G * i;
+      if (wr < WR) s_x[wr * 16 + l16] = xw[i] * sc[i];
+    }
+#pragma unroll
+    for (int k = 0; k < RPG; ++k) {
+      const int r = rg + G * k;
+      if (r < TR) s_sv[r] = sv[k];
+    }
+    __syncthreads();
+    const int next = tile + nwx;
+    const bool more = (it + 1 < tpw) && next < t_hi;
+    if (more) fetch(next);
+#pragma unroll 1
+    for (int k = 0; k < RPG; ++k) {
+      const int r = rg + G * k;
+      if (r < nr) {
+        const u4 s4 = s_sv[r];
+        const unsigned d[8] = {s4.x & 0xffffu, s4.x >> 16, s4.y & 0xffffu, s4.y >> 16,
+                               s4.z & 0xffffu, s4.z >> 16, s4.w & 0xffffu, s4.w >> 16};
+        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j0 = 0; j0 < 8; j0 += GSTEP) {
+          f4 xx[GSTEP];
+          bool far = false;
+#pragma unroll
+          for (int j = 0; j < GSTEP; ++j) {
+            far |= d[j0 + j] == 0xffffu;
+            xx[j] = s_x[(d[j0 + j] == 0xffffu ? (unsigned)WR : d[j0 + j]) * 16 + l16];
+          }
+          if (far) {
+            const int q0 = rowptr[r0 + r];
+#pragma unroll
+            for (int j = 0; j < GSTEP; ++j)
+              if (d[j0 + j] == 0xffffu) {
+                const int c = col[q0 + j0 + j];
+                f4 v = *reinterpret_cast<const f4*>(Xl + (unsigned)(c * 64));
+                const float s = scale[c];
+                v.x = __fmul_rn(v.x, s); v.y = __fmul_rn(v.y, s); v.z = __fmul_rn(v.z, s); v.w = __fmul_rn(v.w, s);
+                xx[j] = v;
+              }
+          }
+#pragma unroll
+          for (int j = 0; j < GSTEP; ++j) {
+            acc.x = __fadd_rn(acc.x, xx[j].x); acc.y = __fadd_rn(acc.y, xx[j].y);
+            acc.z = __fadd_rn(acc.z, xx[j].z); acc.w = __fadd_rn(acc.w, xx[j].w);
+          }
+        }
+        st4<NTS>(Y + (unsigned)((r0 + r) * 64 + l16 * 4), acc);
+      }
+    }
+    if (!more) break;
+    __syncthreads();
+    tile = next;
+  }
 }
 
 __global__ __launch_bounds__(256) void copy_kernel(const f4* __restrict__ a, f4* __restrict__ b, size_t n) {
@@ -309,49 +429,29 @@ int main(int argc, char** argv) {
     }                                                                                                                     \
   } while (0)
 
-  // tile-height sweep (TR chosen so that the tile count fills whole rounds of resident workgroups, and around it)
-  for (int TR : {32, 48, 64}) { RUN(256, 128, 64, 0, 0, 1, TR, 1); }
-  for (int TR : {64, 96, 104, 112, 128, 132, 136}) { RUN(256, 200, 136, 0, 0, 1, TR, 1); RUN(512, 200, 136, 0, 0, 1, TR, 1); }
-  for (int TR : {160, 176, 196, 200}) { RUN(512, 264, 200, 0, 0, 1, TR, 1); RUN(1024, 264, 200, 0, 0, 1, TR, 1); }
-  for (int TR : {264, 392}) { RUN(1024, 456, 392, 0, 0, 1, TR, 1); }
-  // policies at two promising shapes
-  for (int TR : {104, 132}) {
-    RUN(512, 200, 136, 0, 0, 0, TR, 1);
-    RUN(512, 200, 136, 0, 1, 1, TR, 1);
-    RUN(512, 200, 136, 0, 1, 0, TR, 1);
-    RUN(512, 200, 136, 0, 0, 1, TR, 0);
-    RUN(512, 200, 136, 1, 0, 1, TR, 1);
-    RUN(256, 200, 136, 1, 0, 1, TR, 1);
+  // third lab round: lab kernel vs PRODUCT kernel (C ABI) on the same box, same buffers
+  pgt_ellw op; memset(&op, 0, sizeof(op));
+  op.halo = 32;
+  if (pgt_ellw_plan(n, 32, deg, &op.tile_rows, &op.width, &op.n_tiles)) { printf("plan: %s\n", pgt_last_error()); return 1; }
+  const size_t total = (size_t)op.n_tiles * op.tile_rows * op.width;
+  uint16_t* pslots; float *pvals, *pscale; int32_t* pinfo;
+  CK(hipMalloc(&pslots, total * 2)); CK(hipMalloc(&pvals, total * 4)); CK(hipMalloc(&pscale, n * 4)); CK(hipMalloc(&pinfo, 16));
+  if (pgt_ellw_build(rp, col, val, n, (int64_t)g.col.size(), &op, pslots, pvals, pscale, pinfo, st)) { printf("build: %s\n", pgt_last_error()); return 1; }
+  int32_t hinfo[4]; CK(hipMemcpyAsync(hinfo, pinfo, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+  printf("product plan: %lld tiles of %d rows x %d slots; far %d, scale mismatches %d\n", (long long)op.n_tiles, op.tile_rows, op.width, hinfo[0], hinfo[1]);
+  op.slots = pslots;
+  for (int round = 0; round < 2; ++round) {
+    RUN(1024, 456, 392, 0, 0, 1, 392, 1);
+    op.scale = pscale; op.vals = nullptr;
+    CK(hipMemsetAsync(Y[0], 0xff, (size_t)n * F * 4, st));
+    pgt_spmm_ellw_f32(&op, rp, col, val, n, X[0], F, Y[0], F, nullptr, 0, 1.f, 0.f, F, st);
+    { auto ck = check(Y[0], 0); printf("product mode 0 check: err %.1e, %zu mismatching\n", ck.first, ck.second); }
+    timeit("PRODUCT pgt_spmm_ellw_f32 mode 0 (scale table)", [&](int p) { pgt_spmm_ellw_f32(&op, rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);
+    RUN(1024, 456, 392, 1, 0, 1, 392, 1);
+    op.scale = nullptr; op.vals = pvals;
+    timeit("PRODUCT pgt_spmm_ellw_f32 mode 1 (per-slot vals)", [&](int p) { pgt_spmm_ellw_f32(&op, rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);
+    timeit("PRODUCT pgt_spmm_csr_f32 (CSR row tiles)", [&](int p) { pgt_spmm_csr_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st); }, alg);
   }
 
-  // ---- in-kernel timeline of one launch
-  {
-    const int TR = 132, H = 32, nt = (n + TR - 1) / TR;
-    build(TR, H);
-    long long* tr; CK(hipMalloc(&tr, (size_t)nt * 8 * 8)); CK(hipMemset(tr, 0, (size_t)nt * 8 * 8));
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &tr, sizeof(tr)));
-    CK(hipDeviceSynchronize());
-    hipLaunchKernelGGL((ellw_kernel<512, 200, 136, 0, 0, 1, 1>), dim3(nt), dim3(512), 0, st, d_slots, d_vals, scale, rp, col, val, n, TR, H, X[2], Y[2], 1);
-    CK(hipDeviceSynchronize());
-    std::vector<long long> h((size_t)nt * 8);
-    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
-    long long t0 = h[0], t1 = 0;
-    for (int b = 0; b < nt; ++b) { t0 = std::min(t0, h[(size_t)b * 8]); t1 = std::max(t1, h[(size_t)b * 8 + 3]); }
-    printf("timeline TR=132 thr=512: %d workgroups, span %.2f us\n", nt, (t1 - t0) / 100.0);
-    const char* names[4] = {"start", "loads landed + LDS written", "barrier passed", "gather + stores issued"};
-    for (int s = 0; s < 4; ++s) {
-      double sum = 0, mn = 1e18, mx = 0;
-      for (int b = 0; b < nt; ++b) { double v = (h[(size_t)b * 8 + s] - t0) / 100.0; sum += v; mn = std::min(mn, v); mx = std::max(mx, v); }
-      printf("   mark %d (%s): mean %6.2f us  min %6.2f  max %6.2f\n", s, names[s], sum / nt, mn, mx);
-    }
-    double d01 = 0, d12 = 0, d23 = 0;
-    for (int b = 0; b < nt; ++b) { d01 += (h[(size_t)b * 8 + 1] - h[(size_t)b * 8]) / 100.0; d12 += (h[(size_t)b * 8 + 2] - h[(size_t)b * 8 + 1]) / 100.0; d23 += (h[(size_t)b * 8 + 3] - h[(size_t)b * 8 + 2]) / 100.0; }
-    printf("   mean phase lengths: load %.2f us, barrier %.2f us, gather %.2f us\n", d01 / nt, d12 / nt, d23 / nt);
-    int hist[16] = {0};
-    for (int b = 0; b < nt; ++b) { int k = (int)((h[(size_t)b * 8] - t0) / 100.0 / 2.0); hist[std::min(k, 15)]++; }
-    printf("   workgroup starts per 2 us bin:");
-    for (int k = 0; k < 16; ++k) printf(" %d", hist[k]);
-    printf("\n");
-  }
   return 0;
 }

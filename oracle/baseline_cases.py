@@ -22,12 +22,16 @@ def rand(shape, seed, lo=-1.0, hi=1.0):
     return torch.rand(shape, generator=g) * (hi - lo) + lo
 
 
-def randomise(module, seed):
-    """Re-draw every parameter (including the zero-initialised biases) so that no term is trivially zero."""
+def randomise(module, seed, gain=1.0):
+    """Re-draw every parameter (including the zero-initialised biases) so that no term is trivially zero.  `gain`
+    scales the matrices: a 12-step GRU at hidden 64 with weights at gain 1 is a chaotic map — the reference's OWN fp32
+    forward then sits 1e-4 away from an fp64 evaluation of itself at the last step, so no reordering of the sums can
+    agree with it to 1e-5; at gain 0.25 (still 3x the reference's xavier initialisation, dcrnn.py:35-37) fp32 and
+    fp64 agree to 3e-7 and the 1e-5 comparison measures the implementation, not the conditioning."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for _, p in module.named_parameters():
-            bound = (6.0 / (p.size(-2) + p.size(-1))) ** 0.5 if p.dim() >= 2 else 0.5
+            bound = gain * (6.0 / (p.size(-2) + p.size(-1))) ** 0.5 if p.dim() >= 2 else 0.5
             p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
 
 

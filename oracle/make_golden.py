@@ -419,7 +419,7 @@ def baseline_c2_batched_dcrnn64():
     from . import baseline_cases as BC
     m = R.load("nn.recurrent.dcrnn")
     layer = m.BatchedDCRNN(2, 64, 3)
-    BC.randomise(layer, 210)
+    BC.randomise(layer, 210, gain=0.25)
     outs = {}
     for E in (1515, 1722):
         ei, ew, X = BC.metrla(E)

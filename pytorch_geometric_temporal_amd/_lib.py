@@ -33,6 +33,11 @@ class CsrStruct(ctypes.Structure):
     _fields_ = [("rowptr", c_ptr), ("col", c_ptr), ("val", c_ptr)]
 
 
+class EllwStruct(ctypes.Structure):
+    _fields_ = [("slots", c_ptr), ("vals", c_ptr), ("scale", c_ptr), ("tile_rows", ctypes.c_int32),
+                ("halo", ctypes.c_int32), ("width", ctypes.c_int32), ("reserved", ctypes.c_int32), ("n_tiles", c_i64)]
+
+
 class DConvGraphStruct(ctypes.Structure):
     _fields_ = [("fwd_o", CsrStruct), ("fwd_i", CsrStruct), ("bwd_o", CsrStruct), ("bwd_i", CsrStruct),
                 ("deg_out", c_ptr), ("deg_in", c_ptr), ("info", c_ptr)]
@@ -56,8 +61,12 @@ PROTOTYPES = {
                               c_ptr, c_size, c_ptr]),
     "pgt_spmm_csr_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32,
                                  c_f32, c_i64, c_ptr]),
-    "pgt_spmm_csr_band_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32,
-                                      c_f32, c_i64, ctypes.c_int32, c_ptr]),
+    "pgt_ellw_plan": (c_int, [c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_i64)]),
+    "pgt_ellw_build": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.POINTER(EllwStruct), c_ptr, c_ptr, c_ptr, c_ptr,
+                               c_ptr]),
+    "pgt_spmm_ellw_f32": (c_int, [ctypes.POINTER(EllwStruct), c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
+                                  c_ptr, c_i64, c_f32, c_f32, c_i64, c_ptr]),
     "pgt_csr_locality": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "pgt_spmm_csr_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
     "pgt_sddmm_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -89,7 +98,7 @@ PROTOTYPES = {
     "pgt_swap01_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 6
+EXPECTED_ABI = 7
 
 
 class PgtLib:

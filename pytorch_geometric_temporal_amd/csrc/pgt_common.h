@@ -50,6 +50,20 @@ typedef float4 pgt_f4;
 #else
 typedef float pgt_f4 __attribute__((ext_vector_type(4)));
 #endif
+// 4 x uint32 register vector (slot vectors of the ELLW layout)
+#ifdef PGT_EMU
+struct pgt_u4 { unsigned x, y, z, w; };
+#else
+typedef unsigned int pgt_u4 __attribute__((ext_vector_type(4)));
+#endif
+// a product / a sum that must stay two roundings (hipcc contracts a * b + c into an fma by default)
+#ifdef PGT_EMU
+static inline float pgt_mul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float pgt_add_rn(float a, float b) { volatile float r = a + b; return r; }
+#else
+static __device__ __forceinline__ float pgt_mul_rn(float a, float b) { return __fmul_rn(a, b); }
+static __device__ __forceinline__ float pgt_add_rn(float a, float b) { return __fadd_rn(a, b); }
+#endif
 // the one sigmoid of the library (gate kernels and fused GEMM epilogues must agree bit for bit)
 static __device__ __forceinline__ float pgt_sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 

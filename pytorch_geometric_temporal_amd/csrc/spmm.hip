@@ -32,17 +32,6 @@ int g_tile_nt = 1;     // pgt_tune("spmm_tile_nt"): non-temporal stores of the a
 int g_tile_rows = 32;  // rows per tile for the F = 64 fast path (32 | 64 | 128); 32: finer tail, measured best
 int g_unroll = 8;      // neighbour loads in flight per lane group (4 | 8)
 int g_wide_xcd = 1;    // XCD-slab block mapping of the wide kernel
-int g_quad = 0;        // F = 64: 1 = barrier-free persistent quad kernel instead of the row-tile kernel (measured tie)
-int g_quad_blocks = 7; // quad kernel: resident workgroups per CU (70 VGPRs -> 7 wavefronts per SIMD)
-int g_band_blocks = 3;  // band kernel: resident workgroups per CU the chunking aims at (<= 3: 160-VGPR kernel)
-int g_band_xcd = 1;     // band kernel: contiguous chunk ranges per XCD
-int g_band_cu = 4;      // locality-ordered F = 64 schedule: 4 = 32-row tiles with the X window in LDS (spmm_wtile64_kernel,
-                        // measured best), 3 = 64-row tiles, 1 / 2 = one / two 1024-thread workgroups per CU, 0 = small ring workgroups
-int g_wtile_wgs = 0;     // window-tile kernel: persistent workgroups per CU (0 = 5)
-int g_wtile_tpw = 1;     // window-tile kernel: tiles per workgroup (1 = independent workgroups, measured best: 31.5 us;
-                         // 0 = persistent, g_wtile_wgs per CU with the next tile prefetched: 36.4 us)
-int g_band_nblk = 0;    // test hook: number of workgroups of the per-CU band kernel (0 = one or two per CU)
-
 template <int VEC>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[VEC]) {
   if constexpr (VEC == 4) {
@@ -203,582 +192,203 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// spmm_wtile64_kernel<TR, H> — F = 64, locality-ordered operator: the row-tile schedule with the tile's X WINDOW in
-// LDS.  The degree sweep shows the row-tile kernel paying ~1.5 us per neighbour at the vector L1's
-// 64 B/clk/CU (the gather re-reads every neighbour row through L1) on top of a 24 us streaming base, while the
-// LDS-window kernels gather for free but carry a 34 us base of steps and barriers.  Here a 256-thread workgroup owns
-// TR rows and first loads rows [r0 - H, r0 + TR + H) of X into LDS with fully coalesced float4 reads, all in flight
-// at once (a window is read (TR + 2H) / TR times through L1 instead of `degree` times), together with the rowptr
-// slice; the (col, val) slots follow (they need rowptr), and the whole gather is then LDS reads (ds_read_b128, one
-// 256-byte row per 16-lane group).  Neighbours outside the window are read from global memory, so any operator is
-// handled.  No steps, no ring, two barriers: independent workgroups overlap each other's round trips.
-template <int TR, int H>
-__global__ __launch_bounds__(256) void spmm_wtile64_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    int n_rows, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt,
-    float alpha, float beta, int tiles_per_wg, int n_tiles, int xcd_remap) {
-  constexpr int WR = TR + 2 * H;             // window rows
-  constexpr int CAP = 16 * TR;               // staged slots per tile; fuller tiles read their slots from global
-  constexpr int XPT = WR * 16 / 256;         // float4 window loads per thread
-  constexpr int SPT = CAP / 256;             // staged slots per thread
-  __shared__ pgt_f4 s_x[WR * 16];
-  __shared__ int s_rp[TR + 1];
-  __shared__ int s_col[CAP];
-  __shared__ float s_val[CAP];
-
-  const int tid = threadIdx.x;
-  const int wg = xcd_remap ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int t_first = wg * tiles_per_wg;
-  const int t_last = (t_first + tiles_per_wg < n_tiles) ? t_first + tiles_per_wg : n_tiles;
-  if (t_first >= t_last) return;
-  const int l16 = tid & 15, rg = tid >> 4;   // 16 row-groups of 16 lanes
-  const float* Xl = X + l16 * 4;
-
-  // One memory phase per tile, requested while the PREVIOUS tile is gathered out of LDS: the tile's slot range comes
-  // from two wave-uniform (scalar) reads of rowptr, so the (col, val) requests go out right behind the X window and
-  // the rowptr slice instead of after a barrier and a second round trip.
-  int p_e0 = 0, p_nnz = 0, p_rp = 0;
-  pgt_f4 xw[XPT];
-  int cq[SPT];
-  float vq[SPT];
-  auto fetch = [&](int tile) {
-    const int r0 = tile * TR;
-    const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
-    p_e0 = rowptr[r0];
-    p_nnz = rowptr[r0 + nr] - p_e0;
-    p_rp = rowptr[r0 + (tid <= nr ? tid : nr)];
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      int r = r0 - H + rg + 16 * i;
-      r = r < 0 ? 0 : (r < n_rows ? r : n_rows - 1);
-      xw[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(r * ldx));
-    }
-    const bool st = p_nnz <= CAP;
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) {
-      const int q = tid + 256 * i;
-      const int qc = p_nnz > 0 ? ((st && q < p_nnz) ? p_e0 + q : p_e0) : 0;   // clamped: always a valid slot
-      cq[i] = col[qc];
-      vq[i] = val[qc];
-    }
-  };
-
-  fetch(t_first);
-  for (int tile = t_first; tile < t_last; ++tile) {
-    const int r0 = tile * TR;
-    const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
-    const int w0 = r0 - H;                   // first window row (may be negative: clamped loads, never matched)
-    const int e0 = p_e0, nnz = p_nnz;
-    const bool staged = nnz <= CAP;
-    __syncthreads();                         // the previous tile's gather no longer reads LDS
-    if (tid <= nr) s_rp[tid] = p_rp;
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) s_x[(rg + 16 * i) * 16 + l16] = xw[i];
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) {
-      const int q = tid + 256 * i;
-      if (staged && q < nnz) { s_col[q] = cq[i]; s_val[q] = vq[i]; }
-    }
-    __syncthreads();
-    if (tile + 1 < t_last) fetch(tile + 1);  // in flight while this tile is gathered and stored
-    // gather out of the window, sequential fma chain in slot order (bit-identical to the row-tile kernel)
-    const int w_lo = w0 < 0 ? 0 : w0;
-    const int w_hi = (w0 + WR < n_rows) ? w0 + WR : n_rows;
-    for (int r = rg; r < nr; r += 16) {
-      const int a = s_rp[r] - e0, b = s_rp[r + 1] - e0;
-      pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-      int q = a;
-      for (; q + 4 <= b; q += 4) {
-        int c[4];
-        float v[4];
-        pgt_f4 x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          c[u] = staged ? s_col[q + u] : col[e0 + q + u];
-          v[u] = staged ? s_val[q + u] : val[e0 + q + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (c[u] >= w_lo && c[u] < w_hi) x[u] = s_x[(c[u] - w0) * 16 + l16];
-          else x[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c[u] * ldx));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          acc.x = fmaf(v[u], x[u].x, acc.x); acc.y = fmaf(v[u], x[u].y, acc.y);
-          acc.z = fmaf(v[u], x[u].z, acc.z); acc.w = fmaf(v[u], x[u].w, acc.w);
-        }
-      }
-      for (; q < b; ++q) {
-        const int c0 = staged ? s_col[q] : col[e0 + q];
-        const float v0 = staged ? s_val[q] : val[e0 + q];
-        pgt_f4 x0;
-        if (c0 >= w_lo && c0 < w_hi) x0 = s_x[(c0 - w0) * 16 + l16];
-        else x0 = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c0 * ldx));
-        acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y);
-        acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
-      }
-      pgt_f4 out;
-      if (T != nullptr) {
-        const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + r) * ldt) + l16 * 4);
-        out = pgt_mk4(alpha * acc.x + beta * t.x, alpha * acc.y + beta * t.y, alpha * acc.z + beta * t.z,
-                      alpha * acc.w + beta * t.w);
-      } else {
-        out = pgt_mk4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
-      }
-      *reinterpret_cast<pgt_f4*>(Y + (unsigned)((r0 + r) * ldy) + l16 * 4) = out;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// spmm_band64_kernel<RING> — F = 64 floats per row on a locality-ordered (banded) operator.
+// spmm_ellw64_kernel<MODE> — F = 64 on a locality-ordered operator in the ELLW layout (pgt_ellw, include/pgt_hip.h).
 //
-// Why: the per-row gather of the tile kernel moves deg x 256 B through the CU's vector L1 for every 256 B it
-// writes; on MI355X a CU sustains only ~64 cache lines in flight, so at in-degree 8 the launch is bound by that
-// queue (measured: HBM traffic == algorithmic bytes, 3.2 TB/s) and not by HBM.  Here a workgroup owns a contiguous
-// chunk of rows and slides a RING-row window of X through LDS (RING x 256 B, rows [s0 - H, s0 + 64 + H) resident
-// while rows [s0, s0 + 64) are produced, H = (RING - 64) / 2).  Every X row goes through the vector memory path
-// once per chunk (plus 2H halo rows per chunk, L2 hits) with fully coalesced 256-B reads, and the deg-fold gather
-// is served by ds_read_b128 (one 256-B row per 16-lane group: conflict-free, 256 B/clk/CU).  Neighbours outside
-// the resident window (the wrap-around rows, or a graph that is not banded) fall back to a global read, so the
-// kernel is correct for any operator; the host only selects it when most slots are within the halo.
-// (col, val) never touch LDS: each 16-lane group loads up to 16 slots of its row with one coalesced read and
-// broadcasts them with ds_bpermute (__shfl, width 16).  Accumulation is sequential in slot order: deterministic.
-// Work distribution: static.  The rows are cut into gridDim.x contiguous chunks (rows_per_chunk each, a multiple of 4)
-// and chunk ranges are contiguous per XCD; every chunk is swept in `steps` equal steps of `srows` <= 64 rows.
-// (A dynamic per-XCD ticket counter was measured and rejected: at N = 200 000 a workgroup only owns ~3 steps, so the
-// per-chunk prologue it adds costs far more than the finish-time spread it removes: 57 us vs 33 us.)
-template <int RING>
-__global__ __launch_bounds__(256, (RING == 128 ? 3 : 2)) void spmm_band64_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    int n_rows, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt,
-    float alpha, float beta, int rows_per_chunk, int srows, int xcd_remap) {
-  constexpr int S = 64, H = (RING - S) / 2;  // S: ring capacity per step; the step actually advances `srows` rows
-  __shared__ pgt_f4 s_x[RING * 16];
+// Why: the CSR row tiles pay a dependent chain per tile — rowptr -> (col, val) -> neighbour rows -> store, two
+// barriers — and re-read every neighbour row through the vector L1 (N = 200 000, in-degree 8: 32.4 - 34 us, 0.43 of
+// 8 TB/s, although FETCH + WRITE equal the algorithmic bytes).  Here everything a workgroup needs is addressable from
+// blockIdx alone, so window rows, slot block and (MODE 0) source scales are requested in ONE memory phase:
+//   * rows are cut into tiles of TR rows; a tile's sources lie in the window [r0 - H, r0 + TR + H) of X, which is
+//     loaded once with coalesced 16-byte reads and parked in LDS (1 + 2H/TR reads of X through L2, 1x from HBM);
+//   * every row has W slots (W = longest row rounded up to 8; padding slots point at a zero row behind the window); a
+//     slot is the 16-bit offset of its source row inside the window, or 0xFFFF for a source outside it (wrap-around,
+//     long-range edge), which is fetched through the CSR the operator was built from — any operator is handled;
+//   * MODE 0 (val[q] == scale[col[q]] for every slot: P_o of DConv, dcrnn.py:70-73): the per-slot coefficient stream
+//     is dropped; a window row is multiplied by its scale once when it enters LDS and the gather is a chain of rounded
+//     adds in slot order — the same roundings as the reference's `norm * x_j` followed by scatter-add;
+//     MODE 1: per-slot coefficients, fmaf chain in slot order (bit-identical to the CSR kernels);
+//   * one 1024-thread workgroup per CU holds up to 456 window rows (114 KB of LDS): the host picks TR so that the
+//     tiles fill whole rounds of the 256 CUs (N = 200 000, H = 32: 511 tiles of 392 rows, halo re-reads 16 %).
+// Measured (lab/ellw_lab, N = 200 000, in-degree 8, rotating buffers): 21.2 us = 0.685 of 8 TB/s (MODE 0), 22.6 us
+// (MODE 1); a float4 copy of the same X -> Y on the same box: 18.8 us.  Streaming (non-temporal) stores of Y matter:
+// 27.6 us without them.
+constexpr int ELLW_THREADS = 1024;
+constexpr int ELLW_WRMAX = 456;          // window rows held in LDS (+ one zero row)
+constexpr int ELLW_SLOTS = 392 * 16;     // tile_rows * width <= ELLW_SLOTS (slot block staged in LDS)
+constexpr int ELLW_WMAX = 32;
 
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, l16 = lane & 15;
-  const int chunk = xcd_remap ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int c0 = chunk * rows_per_chunk;
-  if (c0 >= n_rows) return;  // whole workgroup
-  const int c1 = (c0 + rows_per_chunk < n_rows) ? c0 + rows_per_chunk : n_rows;
-  PGT_TRACE_MARK(0);
-  {
-  const int rg = tid >> 4;  // 16 row-groups of 16 lanes: one 256-B row each per staging pass
-  const float* Xl = X + l16 * 4;
+int g_ellw = 1;        // pgt_tune("spmm_ellw"): 0 = pgt_spmm_ellw_f32 runs the CSR kernels instead (A/B)
+int g_ellw_rows = 0;   // pgt_tune("spmm_ellw_rows"): test hook, caps the planned tile height (0 = no cap)
+int g_ellw_cus = 0;    // pgt_tune("spmm_ellw_cus"): test hook, CU count the plan balances for (0 = the device's)
 
-  // Software pipeline, one step (64 rows) deep: while step s is computed out of LDS, the X rows of step s+1
-  // (registers t), the (col, val) slots of step s+1 (registers mc/mv) and rowptr of step s+2 are already in
-  // flight, so no step waits on a global-memory round trip it issued itself.
-  auto clampr = [&](int r) { return r < 0 ? 0 : (r < n_rows ? r : n_rows - 1); };
-  auto load_rp = [&](int s0, int& r0, int& r1) {  // rowptr[s0 + lane], rowptr[s0 + lane + 1] (clamped at n_rows)
-    const int i0 = s0 + lane < n_rows ? s0 + lane : n_rows;
-    const int i1 = s0 + lane + 1 < n_rows ? s0 + lane + 1 : n_rows;
-    r0 = rowptr[i0];
-    r1 = rowptr[i1];
-  };
-  // first 16 slots of the wave's four row-quads of the step starting at s0
-  auto load_cv = [&](int s0, int r0, int r1, int (&qa)[4], int (&qn)[4], int (&qc)[4], float (&qv)[4]) {
-    const int send = s0 + srows < c1 ? s0 + srows : c1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rl = (wave + 4 * j) * 4 + g;
-      const int a = __shfl(r0, rl), b = __shfl(r1, rl);
-      qa[j] = a;
-      qn[j] = (s0 + rl < send) ? b - a : 0;
-      // unconditional loads from a clamped slot (keeps the number of loads in flight static, so the compiler can
-      // count them instead of draining the queue); dead lanes are masked by `qn` at use
-      const int q = (l16 < qn[j]) ? a + l16 : (b > 0 ? b - 1 : 0);
-      qc[j] = col[q];
-      qv[j] = val[q];
-    }
-  };
-
-  pgt_f4 t[4], pre[4];
-  int rpA0, rpA1, rpB0 = 0, rpB1 = 0;
-  int qa[4], qn[4], qc[4];
-  float qv[4];
-  // (rowptr loads are always issued FIRST in a phase: vmcnt retires in order, so whatever is issued behind a load
-  //  — including the Y stores — has to drain before that load's result can be used)
-  load_rp(c0, rpA0, rpA1);
-  if (c0 + srows < c1) load_rp(c0 + srows, rpB0, rpB1);
-  {
-    // leading half-window rows [c0 - H, c0 + H) and the first step's rows [c0 + H, c0 + S + H)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = c0 - H + rg + 16 * i;
-      pre[i] = (i * 16 < 2 * H) ? *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(r) * ldx)) : pgt_mk4(0, 0, 0, 0);
-    }
-    pgt_f4 pre2[(2 * H > 64) ? (2 * H - 64) / 16 : 1];
-    if constexpr (2 * H > 64) {
-#pragma unroll
-      for (int i = 4; i < 2 * H / 16; ++i)
-        pre2[i - 4] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(c0 - H + rg + 16 * i) * ldx));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      t[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(c0 + H + rg + 16 * i) * ldx));
-    load_cv(c0, rpA0, rpA1, qa, qn, qc, qv);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = c0 - H + rg + 16 * i;
-      if (i * 16 < 2 * H && r >= 0 && r < n_rows) s_x[(r & (RING - 1)) * 16 + l16] = pre[i];
-    }
-    if constexpr (2 * H > 64) {
-#pragma unroll
-      for (int i = 4; i < 2 * H / 16; ++i) {
-        const int r = c0 - H + rg + 16 * i;
-        if (r >= 0 && r < n_rows) s_x[(r & (RING - 1)) * 16 + l16] = pre2[i - 4];
-      }
-    }
-  }
-
-  PGT_TRACE_MARK(1);
-  // One step.  (ca, cn, cc, cv) hold this step's slots (loaded a step ago); the next step's go to (na, nn, nc, nv).
-  // The two register sets ping-pong between calls: copying a set would make the compiler wait for its loads.
-  auto step = [&](const int s0, int (&ca)[4], int (&cn)[4], int (&cc)[4], float (&cv)[4], int (&na)[4], int (&nn)[4],
-                  int (&nc)[4], float (&nv)[4], int& rc0, int& rc1, int& rn0, int& rn1) {
-    // rows [s0 + H, s0 + srows + H) of this step, fetched one step ago
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = s0 + H + rg + 16 * i;
-      if (r < n_rows && rg + 16 * i < srows) s_x[(r & (RING - 1)) * 16 + l16] = t[i];
-    }
-    __syncthreads();
-    PGT_TRACE_MARK(2 + 2 * ((s0 - c0) / srows));
-    const bool more = s0 + srows < c1;
-    // the next step's loads are issued before any of this step's LDS work
-    if (more) {
-      if (s0 + 2 * srows < c1) load_rp(s0 + 2 * srows, rn0, rn1);   // rowptr of step s+2
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        t[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(s0 + srows + H + rg + 16 * i) * ldx));
-      load_cv(s0 + srows, rc0, rc1, na, nn, nc, nv);                 // slots of step s+1 (rowptr came a step ago)
-    }
-    const int send = more ? s0 + srows : c1;
-    const int w_lo = (s0 - H > 0) ? s0 - H : 0;
-    const int w_hi = (s0 + srows + H < n_rows) ? s0 + srows + H : n_rows;
-
-    // (a lambda invoked with literal quad indices: the slot registers must never be indexed dynamically)
-    auto quad = [&](const int j, const int a, const int n, int mc, float mv) {
-      const int row = s0 + (wave + 4 * j) * 4 + g;
-      pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-      for (int q0 = 0; __ballot(q0 < n) != 0ull; q0 += 16) {
-        const bool mine = q0 + l16 < n;
-        if (q0 > 0) {  // rows longer than the 16 prefetched slots
-          mc = mine ? col[a + q0 + l16] : 0;
-          mv = mine ? val[a + q0 + l16] : 0.f;
-        }
-        // wave-uniform: does any live slot of this 16-slot chunk point outside the resident window?
-        const bool any_far = __ballot(mine && (mc < w_lo || mc >= w_hi)) != 0ull;
-        for (int u0 = 0; u0 < 16 && __ballot(q0 + u0 < n) != 0ull; u0 += 4) {
-          int c[4];
-          float v[4];
-          pgt_f4 x[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { c[u] = __shfl(mc, u0 + u, 16); v[u] = __shfl(mv, u0 + u, 16); }
-          // every ring slot is mapped LDS, so the read is unconditional (a dead slot's value is discarded below)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = s_x[(c[u] & (RING - 1)) * 16 + l16];
-          if (any_far) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (q0 + u0 + u < n && (c[u] < w_lo || c[u] >= w_hi))
-                x[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c[u] * ldx));
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const bool live = q0 + u0 + u < n;  // select, not multiply-by-zero: a dead slot must not inject NaN
-            acc.x = live ? fmaf(v[u], x[u].x, acc.x) : acc.x;
-            acc.y = live ? fmaf(v[u], x[u].y, acc.y) : acc.y;
-            acc.z = live ? fmaf(v[u], x[u].z, acc.z) : acc.z;
-            acc.w = live ? fmaf(v[u], x[u].w, acc.w) : acc.w;
-          }
-        }
-      }
-      if (row < send) {
-        pgt_f4 o;
-        if (T != nullptr) {
-          const pgt_f4 tt = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(row * ldt + l16 * 4));
-          o = pgt_mk4(alpha * acc.x + beta * tt.x, alpha * acc.y + beta * tt.y, alpha * acc.z + beta * tt.z,
-                          alpha * acc.w + beta * tt.w);
-        } else {
-          o = pgt_mk4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
-        }
-        *reinterpret_cast<pgt_f4*>(Y + (unsigned)(row * ldy + l16 * 4)) = o;
-      }
-    };
-    quad(0, ca[0], cn[0], cc[0], cv[0]);
-    quad(1, ca[1], cn[1], cc[1], cv[1]);
-    quad(2, ca[2], cn[2], cc[2], cv[2]);
-    quad(3, ca[3], cn[3], cc[3], cv[3]);
-    __syncthreads();
-    PGT_TRACE_MARK(3 + 2 * ((s0 - c0) / srows));
-  };
-  int ra[4], rn[4], rc[4];
-  float rv[4];
-#pragma unroll 1
-  for (int s0 = c0; s0 < c1; s0 += 2 * srows) {
-    step(s0, qa, qn, qc, qv, ra, rn, rc, rv, rpB0, rpB1, rpA0, rpA1);
-    if (s0 + srows < c1) step(s0 + srows, ra, rn, rc, rv, qa, qn, qc, qv, rpA0, rpA1, rpB0, rpB1);
-  }
-  }
-  PGT_TRACE_MARK(15);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// spmm_band64_cu_kernel<RING> — the LDS-window schedule with ONE 1024-thread workgroup per CU.
-// PMC analysis of the other schedules (profiles/r01e_pmc_ns.csv): a CU's vector L1 keeps ~64 read misses in flight;
-// the neighbour gather of the tile / quad schedules produces 3x more L1 misses than the rows a CU needs (L1 hit rate
-// 50 %), and although they hit in L2 (~500 cycles) they occupy the same miss slots as the HBM fetches (~1 500 cycles),
-// which caps the HBM stream at ~60 % of what a copy achieves.  Serving the gather from LDS leaves the miss slots to the
-// one-time HBM fetch of X, Y and the CSR arrays.  Compared with spmm_band64_kernel (3-4 small workgroups per CU, 3-5
-// steps each) one workgroup owns all ~n_rows/256 rows of its CU: one prologue and 2H halo rows per CU instead of per
-// chunk, 12+ pipelined steps, every wavefront gathers exactly one row-quad per step, and all CUs finish together.
-template <int RING>
-__global__ __launch_bounds__(1024) void spmm_band64_cu_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    int n_rows, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt,
-    float alpha, float beta, int rows_per_chunk, int srows, int xcd_remap) {
-  constexpr int S = 64, H = (RING - S) / 2;
-  constexpr int PRE = 2 * H / 64;            // 64-row passes of the leading half-window
-  constexpr int MAXCHUNK = 2048;             // rows per workgroup (rowptr slice staged in LDS)
-  __shared__ pgt_f4 s_x[RING * 16];
-  __shared__ int s_rp[MAXCHUNK + 1];
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, l16 = lane & 15;
-  const int rg = tid >> 4;                   // 64 row-groups of 16 lanes: one 256-B row each per staging pass
-  const int chunk = xcd_remap ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int c0 = chunk * rows_per_chunk;
-  if (c0 >= n_rows) return;  // whole workgroup
-  const int c1 = (c0 + rows_per_chunk < n_rows) ? c0 + rows_per_chunk : n_rows;
-  const float* Xl = X + l16 * 4;
-  PGT_TRACE_MARK(0);
-
-  auto clampr = [&](int r) { return r < 0 ? 0 : (r < n_rows ? r : n_rows - 1); };
-  // this thread's float4 of row s0 + H + rg (the rows step s0 adds to the window).  Always issued — past the end of
-  // the chunk every lane re-reads the chunk's last window row (an L1 hit) — so that the number of requests in flight
-  // is the same on every path and the compiler can count them (s_waitcnt vmcnt(N)) instead of draining the queue.
-  const int last_row = clampr(c1 + H - 1);
-  auto load_x = [&](int s0) {
-    const int r = s0 + H + rg;
-    return *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)((r < c1 + H ? clampr(r) : last_row) * ldx));
-  };
-  // first 16 slots of this wavefront's row-quad of the step starting at s0 (wave w owns rows 4w .. 4w+3 of the step);
-  // rowptr comes out of LDS, so the request depends on nothing that is still in flight
-  auto load_cv = [&](int s0, int& qa, int& qn, int& qc, float& qv) {
-    const int send = s0 + srows < c1 ? s0 + srows : c1;
-    const int row = s0 + wave * 4 + g;
-    const int rl = row < c1 ? row - c0 : c1 - c0;
-    const int a = s_rp[rl], b = s_rp[rl < c1 - c0 ? rl + 1 : rl];
-    qa = a;
-    qn = (row < send) ? b - a : 0;
-    const int q = (l16 < qn) ? a + l16 : (b > 0 ? b - 1 : 0);
-    qc = col[q];
-    qv = val[q];
-  };
-
-  // ---- prologue: rowptr slice -> LDS, leading half-window -> LDS, X rows of steps 0..2 -> registers
-  for (int i = tid; i <= c1 - c0; i += 1024) s_rp[i] = rowptr[c0 + i];
-  pgt_f4 pre[PRE];
-#pragma unroll
-  for (int i = 0; i < PRE; ++i) pre[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(clampr(c0 - H + rg + 64 * i) * ldx));
-  pgt_f4 tA = load_x(c0), tB = load_x(c0 + srows), tC = load_x(c0 + 2 * srows);
-#pragma unroll
-  for (int i = 0; i < PRE; ++i) {
-    const int r = c0 - H + rg + 64 * i;
-    if (r >= 0 && r < n_rows) s_x[(r & (RING - 1)) * 16 + l16] = pre[i];
-  }
-  __syncthreads();   // s_rp visible
-  int aA, nA, cA, aB = 0, nB = 0, cB = 0, aC = 0, nC = 0, cC = 0;
-  float vA, vB = 0.f, vC = 0.f;
-  load_cv(c0, aA, nA, cA, vA);
-  load_cv(c0 + srows, aB, nB, cB, vB);
-  PGT_TRACE_MARK(1);
-
-  // One step.  tt: this step's X rows (requested three steps ago), refilled with the rows of step s0 + 3*srows.
-  // (ca, cn, cc, cv): this step's slots; the slots of step s0 + 2*srows go to (na, nn, nc, nv).  The three register sets
-  // rotate through the three calls of the unrolled loop: nothing that is in flight is ever copied.
-  auto step = [&](const int s0, pgt_f4& tt, int ca, int cn, int cc, float cv, int& na, int& nn, int& nc, float& nv) {
-    {
-      const int r = s0 + H + rg;
-      if (r < n_rows && rg < srows && s0 < c1) s_x[(r & (RING - 1)) * 16 + l16] = tt;
-    }
-    __syncthreads();
-    tt = load_x(s0 + 3 * srows);
-    load_cv(s0 + 2 * srows, na, nn, nc, nv);
-    const int send = s0 + srows < c1 ? s0 + srows : c1;
-    const int w_lo = (s0 - H > 0) ? s0 - H : 0;
-    const int w_hi = (send + H < n_rows) ? send + H : n_rows;   // rows past send + H were not fetched (load_x clamps)
-    const int row = s0 + wave * 4 + g;
-    const int a = ca, n = cn;
-    int mc = cc;
-    float mv = cv;
-    pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-    for (int q0 = 0; __ballot(q0 < n) != 0ull; q0 += 16) {
-      const bool mine = q0 + l16 < n;
-      if (q0 > 0) {  // rows longer than the 16 prefetched slots
-        mc = mine ? col[a + q0 + l16] : 0;
-        mv = mine ? val[a + q0 + l16] : 0.f;
-      }
-      const bool any_far = __ballot(mine && (mc < w_lo || mc >= w_hi)) != 0ull;
-      for (int u0 = 0; u0 < 16 && __ballot(q0 + u0 < n) != 0ull; u0 += 8) {
-        int c[8];
-        float v[8];
-        pgt_f4 x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { c[u] = __shfl(mc, u0 + u, 16); v[u] = __shfl(mv, u0 + u, 16); }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = s_x[(c[u] & (RING - 1)) * 16 + l16];
-        if (any_far) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (q0 + u0 + u < n && (c[u] < w_lo || c[u] >= w_hi))
-              x[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c[u] * ldx));
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const bool live = q0 + u0 + u < n;
-          acc.x = live ? fmaf(v[u], x[u].x, acc.x) : acc.x;
-          acc.y = live ? fmaf(v[u], x[u].y, acc.y) : acc.y;
-          acc.z = live ? fmaf(v[u], x[u].z, acc.z) : acc.z;
-          acc.w = live ? fmaf(v[u], x[u].w, acc.w) : acc.w;
-        }
-      }
-    }
-    if (row < send) {
-      pgt_f4 o;
-      if (T != nullptr) {
-        const pgt_f4 t4 = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(row * ldt + l16 * 4));
-        o = pgt_mk4(alpha * acc.x + beta * t4.x, alpha * acc.y + beta * t4.y, alpha * acc.z + beta * t4.z,
-                    alpha * acc.w + beta * t4.w);
-      } else {
-        o = pgt_mk4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
-      }
-      *reinterpret_cast<pgt_f4*>(Y + (unsigned)(row * ldy + l16 * 4)) = o;
-    }
-    __syncthreads();
-  };
-#pragma unroll 1
-  for (int s0 = c0; s0 < c1; s0 += 3 * srows) {
-    // (steps past the end of the chunk are empty: no LDS write, no slots, no store — but the same barriers and requests)
-    step(s0, tA, aA, nA, cA, vA, aC, nC, cC, vC);
-    step(s0 + srows, tB, aB, nB, cB, vB, aA, nA, cA, vA);
-    step(s0 + 2 * srows, tC, aC, nC, cC, vC, aB, nB, cB, vB);
-  }
-  PGT_TRACE_MARK(15);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// spmm_quad64_kernel — F = 64, barrier-free and persistent: every wavefront walks its own sequence of row-quads
-// (4 rows x 16 lanes x float4).  No LDS, no workgroup barrier: a quad's (col, val) slots are fetched with one
-// coalesced 16-slot read per row and broadcast with ds_bpermute; rowptr of quad i+2 and the slots of quad i+1 are in
-// flight while the neighbour rows of quad i are gathered (two register sets ping-pong, nothing in flight is copied).
-// Work split: XCD x (blockIdx % 8) owns a contiguous eighth of the quads, its wavefronts take them round-robin, so at
-// any time one XCD works on a narrow band of rows (L2 locality) and the tail is one quad per wavefront, not one tile
-// per workgroup (the tile kernel's second, ragged wave of workgroups cost 9 - 33 us of a 33 us launch).
-__global__ __launch_bounds__(256) void spmm_quad64_kernel(
+template <int MODE>
+__global__ __launch_bounds__(ELLW_THREADS) void spmm_ellw64_kernel(
+    const uint16_t* __restrict__ slots, const float* __restrict__ vals, const float* __restrict__ scale,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
-    const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt, float alpha, float beta) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l16 = lane & 15;
-  const int x = (int)(blockIdx.x & 7u);
-  const int nwx = (int)(gridDim.x >> 3) * 4;              // wavefronts per XCD
-  const int wi = (int)(blockIdx.x >> 3) * 4 + wave;
-  const int nq = (n_rows + 3) >> 2;
-  const int qx = (nq + 7) >> 3;
-  const int qend = (x + 1) * qx < nq ? (x + 1) * qx : nq;
-  int q = x * qx + wi;
-  if (q >= qend) return;
+    int TR, int H, int W, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt, float alpha,
+    float beta, int flags) {
+  constexpr int G = ELLW_THREADS / 16;                 // 64 row groups of 16 lanes: one 256-byte row each
+  constexpr int XPT = (ELLW_WRMAX + G - 1) / G;        // window rows per group
+  __shared__ pgt_f4 s_x[(ELLW_WRMAX + 1) * 16];
+  __shared__ pgt_u4 s_slots[ELLW_SLOTS / 8];
+  __shared__ pgt_f4 s_vals[MODE == 1 ? ELLW_SLOTS / 4 : 1];
+  const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+  const int tile = (flags & 1) ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const bool stream_y = (flags & 2) != 0;
+  const int r0 = tile * TR, w0 = r0 - H, WR = TR + 2 * H;
+  const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
+  const int W8 = W >> 3;                               // slot vectors (8 x u16) per row
   const float* Xl = X + l16 * 4;
-
-  auto load_rp = [&](int qq, int& a, int& b) {
-    const int row = 4 * qq + g;
-    a = rowptr[row < n_rows ? row : n_rows];
-    b = rowptr[row + 1 < n_rows ? row + 1 : n_rows];
-  };
-  auto load_cv = [&](int a, int b, int& n, int& mc, float& mv) {   // first 16 slots of the row, one per lane
-    n = b - a;
-    const int idx = l16 < n ? a + l16 : (b > 0 ? b - 1 : 0);
-    mc = col[idx];
-    mv = val[idx];
-  };
-  auto gather_store = [&](int qq, int a, int n, int mc, float mv) {
-    const int row = 4 * qq + g;
+  // ---- one memory phase: window rows, their source scales, the tile's slot block (and coefficient block)
+  pgt_f4 xw[XPT];
+  float sc[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    int wr = rg + G * i;
+    wr = wr < WR ? wr : WR - 1;                        // unconditional clamped loads: a static number in flight
+    int r = w0 + wr;
+    r = r < 0 ? 0 : (r < n_rows ? r : n_rows - 1);
+    xw[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(r * ldx));
+    sc[i] = MODE == 0 ? scale[r] : 1.f;
+  }
+  const int nvec = TR * W8;                            // <= ELLW_SLOTS / 8 <= ELLW_THREADS
+  const pgt_u4 sv = reinterpret_cast<const pgt_u4*>(slots + (size_t)tile * TR * W)[tid < nvec ? tid : nvec - 1];
+  pgt_f4 va = pgt_mk4(0.f, 0.f, 0.f, 0.f), vb = va;
+  if constexpr (MODE == 1) {
+    const pgt_f4* vp = reinterpret_cast<const pgt_f4*>(vals + (size_t)tile * TR * W);
+    const int nv4 = 2 * nvec;
+    va = vp[tid < nv4 ? tid : nv4 - 1];
+    vb = vp[tid + ELLW_THREADS < nv4 ? tid + ELLW_THREADS : nv4 - 1];
+  }
+  pgt_f4 tcur = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+  if (T != nullptr && rg < nr) tcur = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + rg) * ldt) + l16 * 4);
+  // ---- window -> LDS.  MODE 0: scaled on the way in (the product is rounded once, like norm * x_j in the reference)
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int wr = rg + G * i;
+    if (wr < WR) {
+      pgt_f4 v = xw[i];
+      if constexpr (MODE == 0) v = pgt_mk4(pgt_mul_rn(v.x, sc[i]), pgt_mul_rn(v.y, sc[i]), pgt_mul_rn(v.z, sc[i]), pgt_mul_rn(v.w, sc[i]));
+      s_x[wr * 16 + l16] = v;
+    }
+  }
+  if (tid < 16) s_x[WR * 16 + tid] = pgt_mk4(0.f, 0.f, 0.f, 0.f);     // the row padding slots point at
+  if (tid < nvec) s_slots[tid] = sv;
+  if constexpr (MODE == 1) {
+    if (tid < 2 * nvec) s_vals[tid] = va;
+    if (tid + ELLW_THREADS < 2 * nvec) s_vals[tid + ELLW_THREADS] = vb;
+  }
+  __syncthreads();
+  // ---- gather out of the window: rows rg, rg + 64, ... ; sequential chain in slot order
+  for (int r = rg; r < nr; r += G) {
+    pgt_f4 tnext = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+    if (T != nullptr && r + G < nr) tnext = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + r + G) * ldt) + l16 * 4);
     pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-    for (int q0 = 0; __ballot(q0 < n) != 0ull; q0 += 16) {
-      if (q0 > 0) {                                          // rows longer than the 16 prefetched slots
-        const int idx = q0 + l16 < n ? a + q0 + l16 : a;
-        mc = col[idx];
-        mv = val[idx];
+    for (int c8 = 0; c8 < W8; ++c8) {
+      const pgt_u4 s4 = s_slots[r * W8 + c8];
+      const unsigned d[8] = {s4.x & 0xffffu, s4.x >> 16, s4.y & 0xffffu, s4.y >> 16,
+                             s4.z & 0xffffu, s4.z >> 16, s4.w & 0xffffu, s4.w >> 16};
+      float vv[8];
+      if constexpr (MODE == 1) {
+        const pgt_f4 v0 = s_vals[(r * W8 + c8) * 2], v1 = s_vals[(r * W8 + c8) * 2 + 1];
+        vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
       }
-      for (int u0 = 0; u0 < 16 && __ballot(q0 + u0 < n) != 0ull; u0 += 8) {
-        int c[8];
-        float v[8];
-        pgt_f4 xx[8];
+      pgt_f4 x[8];
+      bool far = false;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { c[u] = __shfl(mc, u0 + u, 16); v[u] = __shfl(mv, u0 + u, 16); }
+      for (int j = 0; j < 8; ++j) {
+        far |= d[j] == 0xffffu;
+        x[j] = s_x[(d[j] == 0xffffu ? (unsigned)WR : d[j]) * 16 + l16];
+      }
+      if (far) {   // rare: a source row outside the window comes through the CSR (slot j of the row = CSR slot j)
+        const int q0 = rowptr[r0 + r] + c8 * 8;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)   // dead slots re-read the last live source row (harmless, discarded below)
-          xx[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(c[u] * ldx));
+        for (int j = 0; j < 8; ++j)
+          if (d[j] == 0xffffu) {
+            const int cj = col[q0 + j];
+            pgt_f4 xx = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(cj * ldx));
+            if constexpr (MODE == 0) {
+              const float s = scale[cj];
+              xx = pgt_mk4(pgt_mul_rn(xx.x, s), pgt_mul_rn(xx.y, s), pgt_mul_rn(xx.z, s), pgt_mul_rn(xx.w, s));
+            }
+            x[j] = xx;
+          }
+      }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const bool live = q0 + u0 + u < n;
-          acc.x = live ? fmaf(v[u], xx[u].x, acc.x) : acc.x;
-          acc.y = live ? fmaf(v[u], xx[u].y, acc.y) : acc.y;
-          acc.z = live ? fmaf(v[u], xx[u].z, acc.z) : acc.z;
-          acc.w = live ? fmaf(v[u], xx[u].w, acc.w) : acc.w;
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (MODE == 0) {
+          acc = pgt_mk4(pgt_add_rn(acc.x, x[j].x), pgt_add_rn(acc.y, x[j].y), pgt_add_rn(acc.z, x[j].z), pgt_add_rn(acc.w, x[j].w));
+        } else {
+          acc = pgt_mk4(fmaf(vv[j], x[j].x, acc.x), fmaf(vv[j], x[j].y, acc.y), fmaf(vv[j], x[j].z, acc.z), fmaf(vv[j], x[j].w, acc.w));
         }
       }
     }
-    if (row < n_rows) {
-      pgt_f4 o;
-      if (T != nullptr) {
-        const pgt_f4 tt = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(row * ldt + l16 * 4));
-        o = pgt_mk4(alpha * acc.x + beta * tt.x, alpha * acc.y + beta * tt.y, alpha * acc.z + beta * tt.z,
-                    alpha * acc.w + beta * tt.w);
-      } else {
-        o = pgt_mk4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
-      }
-      *reinterpret_cast<pgt_f4*>(Y + (unsigned)(row * ldy + l16 * 4)) = o;
+    float out[4];
+    if (T != nullptr) {
+      out[0] = alpha * acc.x + beta * tcur.x; out[1] = alpha * acc.y + beta * tcur.y;
+      out[2] = alpha * acc.z + beta * tcur.z; out[3] = alpha * acc.w + beta * tcur.w;
+    } else {
+      out[0] = alpha * acc.x; out[1] = alpha * acc.y; out[2] = alpha * acc.z; out[3] = alpha * acc.w;
     }
-  };
-
-  int a0, b0, a1 = 0, b1 = 0;
-  load_rp(q, a0, b0);
-  if (q + nwx < qend) load_rp(q + nwx, a1, b1);
-  int n0, c0;
-  float v0;
-  load_cv(a0, b0, n0, c0, v0);
-  int s0 = a0;
-#pragma unroll 1
-  for (;;) {
-    // --- even half: gather quad q from set 0; slots of q + nwx -> set 1; rowptr of q + 2 nwx -> (a0, b0)
-    int n1 = 0, c1 = 0, s1 = 0;
-    float v1 = 0.f;
-    const bool has1 = q + nwx < qend;
-    if (q + 2 * nwx < qend) load_rp(q + 2 * nwx, a0, b0);
-    if (has1) { load_cv(a1, b1, n1, c1, v1); s1 = a1; }
-    gather_store(q, s0, n0, c0, v0);
-    if (!has1) break;
-    q += nwx;
-    // --- odd half: gather quad q from set 1; slots of q + nwx -> set 0; rowptr of q + 2 nwx -> (a1, b1)
-    const bool has0 = q + nwx < qend;
-    if (q + 2 * nwx < qend) load_rp(q + 2 * nwx, a1, b1);
-    if (has0) { load_cv(a0, b0, n0, c0, v0); s0 = a0; }
-    gather_store(q, s1, n1, c1, v1);
-    if (!has0) break;
-    q += nwx;
+    float* yp = Y + (unsigned)((r0 + r) * ldy) + l16 * 4;
+    if (stream_y) stv_stream<4>(yp, out);
+    else stv<4>(yp, out);
+    tcur = tnext;
   }
 }
 
-// slots of a CSR operator whose source lies within +-32 / +-96 rows of the destination (selects the band kernel)
+// scale[col[q]] = val[q]: the candidate per-source coefficient table of MODE 0 (every writer of one entry stores the
+// same bits when the operator is source-scaled; ellw_build_kernel verifies it)
+__global__ __launch_bounds__(256) void ellw_scale_scatter_kernel(const int32_t* __restrict__ col,
+                                                                 const float* __restrict__ val, int nnz, float* scale) {
+  const int q = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (q < nnz) scale[col[q]] = val[q];
+}
+
+// one thread per (row, slot): slot block + coefficient block of the ELLW layout from the CSR operator.
+// info[0] += slots outside their tile's window, info[1] += slots whose val differs from scale[col] (bitwise),
+// info[2] += rows longer than W (their tail is NOT represented: the caller must not use the operator)
+__global__ __launch_bounds__(256) void ellw_build_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const float* __restrict__ val, int n_rows, int TR, int H, int W,
+                                                         int n_tiles, const float* __restrict__ scale, uint16_t* slots,
+                                                         float* vals, int32_t* info) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)n_tiles * TR * W;
+  if (idx >= total) return;
+  const int row = (int)(idx / W), j = (int)(idx % W);
+  const int tile = row / TR, w0 = tile * TR - H, WR = TR + 2 * H;
+  unsigned d = (unsigned)WR;   // padding: the zero row
+  float v = 0.f;
+  if (row < n_rows) {
+    const int a = rowptr[row], len = rowptr[row + 1] - a;
+    if (j == 0 && len > W) atomicAdd(&info[2], 1);
+    if (j < len) {
+      const int c = col[a + j];
+      v = val[a + j];
+      if (c >= w0 && c < w0 + WR && c >= 0 && c < n_rows) d = (unsigned)(c - w0);
+      else { d = 0xffffu; atomicAdd(&info[0], 1); }
+      if (scale != nullptr) {
+        unsigned bv, bs;
+        const float s = scale[c];
+        memcpy(&bv, &v, 4); memcpy(&bs, &s, 4);
+        if (bv != bs) atomicAdd(&info[1], 1);
+      }
+    }
+  }
+  slots[idx] = (uint16_t)d;
+  if (vals != nullptr) vals[idx] = v;
+}
+
+
+// slots of a CSR operator whose source lies within +-32 / +-96 rows of the destination, and the longest row (selects
+// the ELLW layout)
 __global__ __launch_bounds__(256) void csr_locality_kernel(const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, int n_rows,
                                                            int32_t* out) {
   const int row = (int)(blockIdx.x * 256 + threadIdx.x);
   int n32 = 0, n96 = 0;
   if (row < n_rows) {
+    atomicMax(&out[2], rowptr[row + 1] - rowptr[row]);
     for (int q = rowptr[row]; q < rowptr[row + 1]; ++q) {
       const int d = col[q] - row;
       n32 += (d >= -32 && d <= 32) ? 1 : 0;
@@ -925,18 +535,6 @@ int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, int
     if (Fv <= 4) { PGT_SPMM_CASE(4, 64, 4); }
     else if (Fv <= 8) { PGT_SPMM_CASE(8, 64, 4); }
     else if (Fv <= 16) {
-      if (VEC == 4 && Fi == 64 && g_quad && n_rows >= 1024) {
-        const int64_t max_ld = ldx > ldy ? (ldx > ldt ? ldx : ldt) : (ldy > ldt ? ldy : ldt);
-        if (n_rows * max_ld < ((int64_t)1 << 31)) {
-          int64_t nblk = 256 * (int64_t)g_quad_blocks;              // persistent: g_quad_blocks workgroups per CU
-          const int64_t need = pgt_cdiv(pgt_cdiv(n_rows, 4), 4);    // one quad per wavefront at least
-          if (nblk > need) nblk = need;
-          nblk = pgt_cdiv(nblk, 8) * 8;                             // every XCD gets the same number of workgroups
-          PGT_LAUNCH(spmm_quad64_kernel, dim3((unsigned)nblk), block, stream, rowptr, col, val, n, X, (int)ldx, Y,
-                     (int)ldy, T, (int)ldt, alpha, beta);
-          return pgt_check_launch("pgt_spmm_csr_f32");
-        }
-      }
       if (VEC == 4) {  // the F = 64 fast path carries the A/B variants
         const int key = g_tile_rows * 10 + g_unroll;
         if (key == 324) { PGT_SPMM_CASE(16, 32, 4); }
@@ -978,14 +576,9 @@ int pgt_spmm_tune(const char* key, int value) {
   if (strcmp(key, "spmm_tile_rows") == 0) { g_tile_rows = value; return 1; }
   if (strcmp(key, "spmm_unroll") == 0) { g_unroll = value; return 1; }
   if (strcmp(key, "spmm_wide_xcd") == 0) { g_wide_xcd = value; return 1; }
-  if (strcmp(key, "spmm_quad") == 0) { g_quad = value; return 1; }
-  if (strcmp(key, "spmm_quad_blocks") == 0) { g_quad_blocks = value > 0 ? value : 1; return 1; }
-  if (strcmp(key, "spmm_band_blocks") == 0) { g_band_blocks = value > 0 ? value : 1; return 1; }
-  if (strcmp(key, "spmm_band_xcd") == 0) { g_band_xcd = value; return 1; }
-  if (strcmp(key, "spmm_band_cu") == 0) { g_band_cu = value; return 1; }
-  if (strcmp(key, "spmm_wtile_wgs") == 0) { g_wtile_wgs = value; return 1; }
-  if (strcmp(key, "spmm_wtile_tpw") == 0) { g_wtile_tpw = value; return 1; }
-  if (strcmp(key, "spmm_band_nblk") == 0) { g_band_nblk = value > 0 ? value : 0; return 1; }
+  if (strcmp(key, "spmm_ellw") == 0) { g_ellw = value; return 1; }
+  if (strcmp(key, "spmm_ellw_rows") == 0) { g_ellw_rows = value > 0 ? value : 0; return 1; }
+  if (strcmp(key, "spmm_ellw_cus") == 0) { g_ellw_cus = value > 0 ? value : 0; return 1; }
   return 0;
 }
 
@@ -1019,88 +612,133 @@ static int spmm_validate(const char* who, const int32_t* rowptr, int64_t n_rows,
   return PGT_OK;
 }
 
-extern "C" int pgt_spmm_csr_band_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
-                                     const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T,
-                                     int64_t ldt, float alpha, float beta, int64_t F, int32_t halo,
-                                     pgt_stream_t stream) {
-  PGT_REQUIRE(n_rows >= 0 && F >= 0, "pgt_spmm_csr_f32: negative size");
+static int ellw_device_cus() {
+  if (g_ellw_cus > 0) return g_ellw_cus;
+#ifdef PGT_EMU
+  return 4;
+#else
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else cus = 256;
+  }
+  return cus;
+#endif
+}
+
+extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t* tile_rows, int32_t* width,
+                             int64_t* n_tiles) {
+  PGT_REQUIRE(tile_rows && width && n_tiles, "pgt_ellw_plan: null pointer");
+  *tile_rows = 0; *width = 0; *n_tiles = 0;
+  PGT_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 31) - 1024, "pgt_ellw_plan: n_rows out of range");
+  PGT_REQUIRE(halo >= 1 && 2 * halo <= ELLW_WRMAX - 8, "pgt_ellw_plan: halo %d outside [1, %d]", (int)halo, (ELLW_WRMAX - 8) / 2);
+  PGT_REQUIRE(max_row_len >= 0 && max_row_len <= ELLW_WMAX, "pgt_ellw_plan: rows of up to %d slots exceed the layout's %d",
+              (int)max_row_len, ELLW_WMAX);
+  const int W = max_row_len <= 8 ? 8 : (int)pgt_cdiv(max_row_len, 8) * 8;
+  int cap = ELLW_WRMAX - 2 * halo;
+  if (cap > ELLW_SLOTS / W) cap = ELLW_SLOTS / W;
+  if (g_ellw_rows > 0 && cap > g_ellw_rows) cap = g_ellw_rows;
+  cap &= ~3;
+  PGT_REQUIRE(cap >= 4, "pgt_ellw_plan: no room for a tile");
+  // whole rounds of one workgroup per CU: the smallest number of rounds whose tiles fit, then the tile height that
+  // spreads the rows evenly over rounds * CUs tiles (a last, nearly empty round would cost a full tile time)
+  const int64_t cus = ellw_device_cus();
+  const int64_t rounds = pgt_cdiv(n_rows, cus * cap);
+  int64_t tr = pgt_cdiv(pgt_cdiv(n_rows, cus * rounds), 4) * 4;
+  if (tr > cap) tr = cap;
+  if (tr < 4) tr = 4;
+  *tile_rows = (int32_t)tr;
+  *width = W;
+  *n_tiles = pgt_cdiv(n_rows, tr);
+  return PGT_OK;
+}
+
+static int ellw_check(const char* who, const pgt_ellw* op, int64_t n_rows) {
+  PGT_REQUIRE(op != nullptr && op->slots != nullptr, "%s: null operator", who);
+  PGT_REQUIRE(op->width >= 8 && op->width % 8 == 0 && op->width <= ELLW_WMAX, "%s: width %d", who, (int)op->width);
+  PGT_REQUIRE(op->halo >= 1 && op->tile_rows >= 1 && op->tile_rows + 2 * op->halo <= ELLW_WRMAX &&
+                  (int64_t)op->tile_rows * op->width <= ELLW_SLOTS,
+              "%s: tile of %d rows x %d slots with halo %d does not fit the kernel (see pgt_ellw_plan)", who,
+              (int)op->tile_rows, (int)op->width, (int)op->halo);
+  PGT_REQUIRE(op->n_tiles == pgt_cdiv(n_rows, op->tile_rows), "%s: n_tiles %lld does not cover %lld rows", who,
+              (long long)op->n_tiles, (long long)n_rows);
+  PGT_REQUIRE(op->n_tiles < ((int64_t)1 << 31) && op->n_tiles * op->tile_rows * op->width < ((int64_t)1 << 40),
+              "%s: operator too large", who);
+  return PGT_OK;
+}
+
+extern "C" int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t nnz,
+                              const pgt_ellw* op, uint16_t* slots, float* vals, float* scale, int32_t* info,
+                              pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 1 && nnz >= 0, "pgt_ellw_build: bad size");
+  PGT_REQUIRE(rowptr && col && val && slots && info, "pgt_ellw_build: null pointer");
+  pgt_ellw tmp = *op;
+  tmp.slots = slots;
+  if (int rc = ellw_check("pgt_ellw_build", &tmp, n_rows)) return rc;
+  PGT_REQUIRE(nnz < ((int64_t)1 << 31), "pgt_ellw_build: nnz exceeds int32 indexing");
+  if (hipMemsetAsync(info, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+    pgt_set_error("pgt_ellw_build: memset failed");
+    return PGT_ERR_LAUNCH;
+  }
+  if (scale != nullptr) {
+    if (hipMemsetAsync(scale, 0, (size_t)n_rows * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+      pgt_set_error("pgt_ellw_build: memset failed");
+      return PGT_ERR_LAUNCH;
+    }
+    if (nnz > 0)
+      PGT_LAUNCH(ellw_scale_scatter_kernel, dim3((unsigned)pgt_cdiv(nnz, 256)), dim3(256), stream, col, val, (int)nnz, scale);
+  }
+  const int64_t total = op->n_tiles * op->tile_rows * op->width;
+  PGT_REQUIRE(pgt_cdiv(total, 256) < ((int64_t)1 << 31), "pgt_ellw_build: grid too large");
+  PGT_LAUNCH(ellw_build_kernel, dim3((unsigned)pgt_cdiv(total, 256)), dim3(256), stream, rowptr, col, val, (int)n_rows,
+             (int)op->tile_rows, (int)op->halo, (int)op->width, (int)op->n_tiles, (const float*)scale, slots, vals, info);
+  return pgt_check_launch("pgt_ellw_build");
+}
+
+extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, const int32_t* col, const float* val,
+                                 int64_t n_rows, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T,
+                                 int64_t ldt, float alpha, float beta, int64_t F, pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0 && F >= 0, "pgt_spmm_ellw_f32: negative size");
   if (n_rows == 0 || F == 0) return PGT_OK;
-  if (int rc = spmm_validate("pgt_spmm_csr_band_f32", rowptr, n_rows, X, ldx, Y, ldy, T, ldt, F)) return rc;
+  if (int rc = spmm_validate("pgt_spmm_ellw_f32", rowptr, n_rows, X, ldx, Y, ldy, T, ldt, F)) return rc;
+  PGT_REQUIRE(col && val, "pgt_spmm_ellw_f32: the CSR operator the layout was built from is required");
+  if (int rc = ellw_check("pgt_spmm_ellw_f32", op, n_rows)) return rc;
+  PGT_REQUIRE((op->vals != nullptr) != (op->scale != nullptr), "pgt_spmm_ellw_f32: exactly one of vals / scale must be set");
   PgtVecPick vp;
   vp.width(F); vp.operand(X, ldx); vp.operand(Y, ldy); vp.operand(T, ldt);
   const int64_t max_ld = ldx > ldy ? (ldx > ldt ? ldx : ldt) : (ldy > ldt ? ldy : ldt);
-  if (halo <= 0 || halo > 96 || F != 64 || vp.v != 4 || n_rows * max_ld >= ((int64_t)1 << 31))
+  // shapes the window kernel does not cover run the CSR row tiles (same sums, fmaf chain)
+  if (!g_ellw || F != 64 || vp.v != 4 || (n_rows + ELLW_WRMAX) * max_ld >= ((int64_t)1 << 31))
     return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
-  const int ring = halo <= 32 ? 128 : 256;
-  if (g_band_cu == 4 && halo > 32)           // a +-96 window is 224 rows of LDS per 32-row tile: the plain tiles win
-    return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
-  if (g_band_cu == 3 || g_band_cu == 4) {    // row tiles with the X window in LDS (3: 64-row tiles, 4: 32-row tiles)
-    const int tr = g_band_cu == 3 ? 64 : 32;
-    const int64_t n_tiles = pgt_cdiv(n_rows, tr);
-    // persistent workgroups, a contiguous run of tiles each (the next tile's memory phase overlaps this tile's gather)
-    const int64_t resident = 256 * (int64_t)(g_wtile_wgs > 0 ? g_wtile_wgs : 5);
-    const int64_t tpw = g_wtile_tpw > 0 ? g_wtile_tpw : pgt_cdiv(n_tiles, resident);
-    dim3 grid((unsigned)pgt_cdiv(n_tiles, tpw)), block(256);
-#define PGT_WTILE_GO(TR_, H_)                                                                                      \
-  PGT_LAUNCH((spmm_wtile64_kernel<TR_, H_>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y,   \
-             (int)ldy, T, (int)ldt, alpha, beta, (int)tpw, (int)n_tiles, g_band_xcd)
-    if (halo <= 32) { if (tr == 64) PGT_WTILE_GO(64, 32); else PGT_WTILE_GO(32, 32); }
-    else { if (tr == 64) PGT_WTILE_GO(64, 96); else PGT_WTILE_GO(32, 96); }
-#undef PGT_WTILE_GO
-    return pgt_check_launch("pgt_spmm_csr_band_f32");
-  }
-  if (g_band_cu && pgt_cdiv(n_rows, g_band_nblk > 0 ? g_band_nblk : 256 * (int64_t)(g_band_cu >= 2 ? 2 : 1)) + 4 <= 2048) {
-    // one 1024-thread workgroup per CU (g_band_cu == 2: two): each owns a contiguous 1/256 (1/512) of the rows
-    int64_t nblk = g_band_nblk > 0 ? g_band_nblk : 256 * (int64_t)(g_band_cu >= 2 ? 2 : 1);
-    int64_t rpc = pgt_cdiv(pgt_cdiv(n_rows, nblk), 4) * 4;
-    if (rpc < 64) rpc = 64;
-    const int64_t steps = pgt_cdiv(rpc, 64);
-    const int64_t srows = pgt_cdiv(pgt_cdiv(rpc, steps), 4) * 4;
-    nblk = pgt_cdiv(n_rows, rpc);
-    dim3 grid((unsigned)nblk), block(1024);
-    if (ring == 128) {
-      PGT_LAUNCH((spmm_band64_cu_kernel<128>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y,
-                 (int)ldy, T, (int)ldt, alpha, beta, (int)rpc, (int)srows, g_band_xcd);
-    } else {
-      PGT_LAUNCH((spmm_band64_cu_kernel<256>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y,
-                 (int)ldy, T, (int)ldt, alpha, beta, (int)rpc, (int)srows, g_band_xcd);
-    }
-    return pgt_check_launch("pgt_spmm_csr_band_f32");
-  }
-  // chunking: g_band_blocks resident workgroups per CU (registers admit 3 at RING = 128, LDS 2 at RING = 256); each chunk is
-  // swept in equal steps of at most 64 rows
-  const int per_cu = ring == 128 ? (g_band_blocks < 3 ? g_band_blocks : 3) : (g_band_blocks < 2 ? g_band_blocks : 2);
-  int64_t nblk = 256 * (int64_t)per_cu;
-  int64_t rpc = pgt_cdiv(n_rows, nblk);
-  if (rpc < 64) rpc = 64;
-  const int64_t steps = pgt_cdiv(rpc, 64);
-  const int64_t srows = pgt_cdiv(pgt_cdiv(rpc, steps), 4) * 4;
-  rpc = srows * steps;
-  nblk = pgt_cdiv(n_rows, rpc);
-  dim3 grid((unsigned)nblk), block(256);
-  if (ring == 128) {
-    PGT_LAUNCH((spmm_band64_kernel<128>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y, (int)ldy, T,
-               (int)ldt, alpha, beta, (int)rpc, (int)srows, g_band_xcd);
+  const int flags = (g_tile_xcd ? 1 : 0) | (g_tile_nt ? 2 : 0);
+  dim3 grid((unsigned)op->n_tiles), block(ELLW_THREADS);
+  if (op->scale != nullptr) {
+    PGT_LAUNCH((spmm_ellw64_kernel<0>), grid, block, stream, op->slots, (const float*)nullptr, op->scale, rowptr, col, val,
+               (int)n_rows, (int)op->tile_rows, (int)op->halo, (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha,
+               beta, flags);
   } else {
-    PGT_LAUNCH((spmm_band64_kernel<256>), grid, block, stream, rowptr, col, val, (int)n_rows, X, (int)ldx, Y, (int)ldy, T,
-               (int)ldt, alpha, beta, (int)rpc, (int)srows, g_band_xcd);
+    PGT_LAUNCH((spmm_ellw64_kernel<1>), grid, block, stream, op->slots, op->vals, (const float*)nullptr, rowptr, col, val,
+               (int)n_rows, (int)op->tile_rows, (int)op->halo, (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha,
+               beta, flags);
   }
-  return pgt_check_launch("pgt_spmm_csr_band_f32");
+  return pgt_check_launch("pgt_spmm_ellw_f32");
 }
 
-extern "C" int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out2,
+extern "C" int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out3,
                                 pgt_stream_t stream) {
   PGT_REQUIRE(n_rows >= 0, "pgt_csr_locality: negative size");
-  PGT_REQUIRE(out2 != nullptr, "pgt_csr_locality: null pointer");
+  PGT_REQUIRE(out3 != nullptr, "pgt_csr_locality: null pointer");
   PGT_REQUIRE(n_rows < ((int64_t)1 << 31) - 256, "pgt_csr_locality: size exceeds int32 indexing");
-  if (hipMemsetAsync(out2, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+  if (hipMemsetAsync(out3, 0, 3 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
     pgt_set_error("pgt_csr_locality: memset failed");
     return PGT_ERR_LAUNCH;
   }
   if (n_rows == 0) return PGT_OK;
   PGT_REQUIRE(rowptr && col, "pgt_csr_locality: null pointer");
   PGT_LAUNCH(csr_locality_kernel, dim3((unsigned)pgt_cdiv(n_rows, 256)), dim3(256), stream, rowptr, col, (int)n_rows,
-             out2);
+             out3);
   return pgt_check_launch("pgt_csr_locality");
 }
 

@@ -12,7 +12,7 @@ import warnings
 import torch
 
 from . import _lib
-from ._lib import CsrStruct, DConvGraphStruct, SymGraphStruct, PgtError, check_tensor, ptr, stream_of
+from ._lib import CsrStruct, DConvGraphStruct, EllwStruct, SymGraphStruct, PgtError, check_tensor, ptr, stream_of
 
 F32 = torch.float32
 I32 = torch.int32
@@ -21,13 +21,17 @@ I32 = torch.int32
 # --------------------------------------------------------------------------------------------- graph handles
 
 class Csr:
-    """CSR operator by destination row.  `halo` is the locality hint handed to pgt_spmm_csr_band_f32: 32 / 96 when at
-    least 3/4 of the slots have |col - row| within that distance (locality-ordered node numbering), else 0."""
-    __slots__ = ("rowptr", "col", "val", "n_rows", "halo")
+    """CSR operator by destination row.  `halo` is the operator's measured locality: 32 / 96 when at least 95 % of the
+    slots have |col - row| within that distance (locality-ordered node numbering), else 0; `max_len` the longest row.
+    `ellw` caches the ELLW layout (pgt_ellw) built for the F = 64 LDS-window kernel on first use."""
+    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw")
 
     def __init__(self, n_rows, cap, device):
         self.n_rows = n_rows
         self.halo = 0
+        self.max_len = -1
+        self.nnz = -1
+        self.ellw = None
         self.rowptr = torch.zeros(n_rows + 1, dtype=I32, device=device)
         self.col = torch.zeros(max(cap, 1), dtype=I32, device=device)
         self.val = torch.zeros(max(cap, 1), dtype=F32, device=device)
@@ -36,14 +40,11 @@ class Csr:
         return CsrStruct(ptr(self.rowptr), ptr(self.col), ptr(self.val))
 
 
-BAND_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; keep the plain schedule
-# The LDS-window schedules are correct for every operator and selected per call through `halo` (the operator's
-# measured locality: 3/4 of the slots within +-32 / +-96 rows).  The best of them, 32-row tiles with the X window in
-# LDS (spmm_wtile64_kernel), measures 31.7 us against 34.2 us for the plain row tiles in the C++ lab harness
-# (N = 200 000, F = 64, in-degree 8) but 34.4 us against 32.9 us inside bench.py (rocprofv3 kernel durations of the
-# same kernels on the same graph).  The hint is therefore only APPLIED on request: PGT_BAND=1 or
-# spmm(..., halo=...), which always overrides.
-USE_BAND_SCHEDULE = os.environ.get("PGT_BAND", "0") == "1"
+ELLW_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; keep the CSR row tiles
+# Locality-ordered operators (>= 95 % of the slots within +-32 / +-96 rows, rows of at most 32 slots) take the ELLW
+# layout at F = 64: 21 us against 33 us for the CSR row tiles at N = 200 000, in-degree 8.
+# PGT_ELLW=0 keeps every operator on the CSR kernels (A/B).
+USE_ELLW = os.environ.get("PGT_ELLW", "1") != "0"
 # Weight-gradient GEMMs of step t on a side stream while the main stream runs the BPTT chain of step t-1 (same
 # arithmetic, fp32 atomics into dW either way).  Measured on MI355X at METR-LA shape, B = 1024: 23.81 ms per step with
 # the overlap vs 23.79 ms with one whole-sequence weight-gradient GEMM at the end -> off by default.
@@ -59,17 +60,57 @@ def _side_stream(device):
 
 
 def measure_locality(csrs):
-    """Set `halo` on each operator from pgt_csr_locality (one small launch per operator, ONE host read for all)."""
+    """Set `halo`, `max_len`, `nnz` on each operator from pgt_csr_locality (one small launch per operator, ONE host
+    read for all)."""
     lib = _lib.get_lib()
-    todo = [c for c in csrs if c.n_rows >= BAND_MIN_ROWS]
+    todo = [c for c in csrs if c.n_rows >= ELLW_MIN_ROWS]
     if not todo:
         return
-    out = torch.zeros(len(todo), 3, dtype=I32, device=todo[0].rowptr.device)
+    out = torch.zeros(len(todo), 4, dtype=I32, device=todo[0].rowptr.device)
     for i, c in enumerate(todo):
         lib.call("pgt_csr_locality", ptr(c.rowptr), ptr(c.col), c.n_rows, ptr(out[i]), stream_of(lib, c.rowptr))
-        out[i, 2:3].copy_(c.rowptr[c.n_rows:c.n_rows + 1])
-    for c, (n32, n96, nnz) in zip(todo, out.tolist()):
-        c.halo = 32 if 4 * n32 >= 3 * nnz > 0 else (96 if 4 * n96 >= 3 * nnz > 0 else 0)
+        out[i, 3:4].copy_(c.rowptr[c.n_rows:c.n_rows + 1])
+    for c, (n32, n96, max_len, nnz) in zip(todo, out.tolist()):
+        c.halo = 32 if 20 * n32 >= 19 * nnz > 0 else (96 if 20 * n96 >= 19 * nnz > 0 else 0)
+        c.max_len, c.nnz = max_len, nnz
+
+
+class Ellw:
+    """The ELLW layout of one Csr (include/pgt_hip.h: pgt_ellw) — slot block, coefficient block or per-source scale
+    table, geometry — built on the device by pgt_ellw_build."""
+
+    def __init__(self, csr, halo):
+        lib = _lib.get_lib()
+        dev = csr.rowptr.device
+        tr, w, nt = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0)
+        lib.call("pgt_ellw_plan", csr.n_rows, int(halo), int(csr.max_len), ctypes.byref(tr), ctypes.byref(w),
+                 ctypes.byref(nt))
+        self.tile_rows, self.width, self.n_tiles, self.halo = tr.value, w.value, nt.value, int(halo)
+        total = self.n_tiles * self.tile_rows * self.width
+        self.slots = torch.empty(total, dtype=torch.int16, device=dev)      # uint16 bit patterns
+        vals = torch.empty(total, dtype=F32, device=dev)
+        scale = torch.empty(csr.n_rows, dtype=F32, device=dev)
+        info = torch.zeros(4, dtype=I32, device=dev)
+        geo = EllwStruct(None, None, None, self.tile_rows, self.halo, self.width, 0, self.n_tiles)
+        lib.call("pgt_ellw_build", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, int(csr.nnz),
+                 ctypes.byref(geo), ptr(self.slots), ptr(vals), ptr(scale), ptr(info), stream_of(lib, csr.rowptr))
+        self.far, mismatch, overflow, _ = info.tolist()        # one host sync per new operator
+        if overflow:
+            raise PgtError(f"ELLW: {overflow} row(s) longer than the planned width {self.width}")
+        # source-scaled operator (val[q] == scale[col[q]] everywhere): the coefficient stream is dropped
+        self.scale, self.vals = (scale, None) if mismatch == 0 else (None, vals)
+
+    def struct(self):
+        return EllwStruct(ptr(self.slots), ptr(self.vals), ptr(self.scale), self.tile_rows, self.halo, self.width, 0,
+                          self.n_tiles)
+
+
+def ellw_of(csr):
+    """The cached ELLW layout of `csr`, built on first use; None when the layout does not apply."""
+    e = getattr(csr, "ellw", None)
+    if e is None and getattr(csr, "halo", 0) > 0 and 0 <= getattr(csr, "max_len", -1) <= 32 and csr.nnz > 0:
+        e = csr.ellw = Ellw(csr, csr.halo)
+    return e
 
 
 def _edge_inputs(lib, edge_index, edge_weight):
@@ -313,9 +354,10 @@ def _rows(t, name):
     return ptr(t), (t.stride(0) if t.size(0) > 1 else max(t.size(1), t.stride(0)))
 
 
-def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, halo=None):
-    """Y = alpha * A @ X + beta * T on [n_rows, F] views (pgt_spmm_csr_band_f32; `halo` overrides the operator's
-    measured locality hint)."""
+def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
+    """Y = alpha * A @ X + beta * T on [n_rows, F] views.  F = 64 on a locality-ordered operator runs the ELLW
+    LDS-window kernel (pgt_spmm_ellw_f32), everything else the CSR kernels (pgt_spmm_csr_f32); `ellw` = False / True
+    overrides the choice (True: build the layout with the operator's measured halo, or +-32 when it has none)."""
     lib = _lib.get_lib()
     for t, n in ((X, "X"), (Y, "Y")) + (((T, "T"),) if T is not None else ()):
         check_tensor(lib, t, n)
@@ -325,14 +367,35 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, halo=None):
     yp, ldy = _rows(Y, "Y")
     tp, ldt = _rows(T, "T") if T is not None else (ptr(None), 0)
     st = stream_of(lib, X)
-    if halo is None:
-        halo = getattr(csr, "halo", 0) if USE_BAND_SCHEDULE else 0
-    halo = int(halo)
+    op = None
+    if X.size(1) == 64 and (ellw if ellw is not None else USE_ELLW):
+        if ellw and getattr(csr, "ellw", None) is None:
+            _force_ellw(csr)
+        op = ellw_of(csr)
     work = spmm_algorithmic_bytes(csr.n_rows, csr.col.numel(), X.size(1), T is not None) if KERNEL_TIMER else 0
+    if op is not None:
+        es = op.struct()
+        _timed("spmm", work, lambda: lib.call(
+            "pgt_spmm_ellw_f32", ctypes.byref(es), ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx,
+            yp, ldy, tp, ldt, float(alpha), float(beta), X.size(1), st))
+        return Y
     _timed("spmm", work, lambda: lib.call(
-        "pgt_spmm_csr_band_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,
-        float(alpha), float(beta), X.size(1), halo, st))
+        "pgt_spmm_csr_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,
+        float(alpha), float(beta), X.size(1), st))
     return Y
+
+
+def _force_ellw(csr, halo=None):
+    """Build the ELLW layout of `csr` regardless of its size / measured locality (tests, A/B runs): correct for any
+    operator with rows of at most 32 slots — out-of-window slots are served through the CSR arrays."""
+    if getattr(csr, "max_len", -1) < 0 or getattr(csr, "nnz", -1) < 0:
+        rp = csr.rowptr[:csr.n_rows + 1]
+        csr.nnz = int(rp[csr.n_rows])
+        csr.max_len = int((rp[1:] - rp[:-1]).max()) if csr.n_rows else 0
+    if csr.max_len > 32 or csr.nnz <= 0:
+        return None
+    csr.ellw = Ellw(csr, halo or csr.halo or 32)
+    return csr.ellw
 
 
 def gemm(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, C, ldc, c_seg_stride, c_seg_n, bias, M, N,

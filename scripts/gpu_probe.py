@@ -60,16 +60,20 @@ def identity_graph(n):
 
 
 def probe_spmm_ns():
-    """North-star aggregation (N = 200 000, F = 64): LDS-window (band) schedule vs the plain row-tile schedule."""
+    """North-star aggregation (N = 200 000, F = 64): the ELLW LDS-window kernel vs the CSR row tiles, in-degree 1 / 8 / 16,
+    locality-ordered and uniform-random graphs."""
     from pytorch_geometric_temporal_amd import _lib
     lib = _lib.get_lib()
     n = 200_000
     gid = identity_graph(n)
     nb = ops.spmm_algorithmic_bytes(n, n, 64, False)
-    for halo in (0, 32):
-        gid.fwd_o.halo = halo
+    for ellw in (False, True):
+        if ellw:
+            ops._force_ellw(gid.fwd_o, 32)
+        else:
+            gid.fwd_o.ellw, gid.fwd_o.halo = None, 0
         us = _rot_time(gid.fwd_o, n, 64, 6)
-        emit(probe="spmm_ns_identity_rotating", halo=halo, us=us, GBs=nb / us / 1e3,
+        emit(probe="spmm_ns_identity_rotating", ellw=ellw, us=us, GBs=nb / us / 1e3,
              note="pure streaming through the kernel (in-degree 1)")
     del gid
     for name, gen in (("local", syn.local_graph), ("uniform", syn.uniform_graph)):
@@ -79,21 +83,27 @@ def probe_spmm_ns():
             nb = ops.spmm_algorithmic_bytes(n, g.E, 64, False)
             X = torch.randn(n, 64, device=dev)
             Y = torch.empty_like(X)
-            measured = g.fwd_o.halo
-            variants = [dict(halo=0, rows=64, unroll=8), dict(halo=0, rows=32, unroll=8)]
+            variants = [dict(ellw=False, rows=64), dict(ellw=False, rows=32)]
             if name == "local":
-                variants += [dict(halo=32, k=3, xcd=1), dict(halo=32, k=2, xcd=1)]
+                variants += [dict(ellw=True, mode="scale"), dict(ellw=True, mode="vals")]
             for v in variants:
-                g.fwd_o.halo = v["halo"]
-                lib.tune("spmm_tile_rows", v.get("rows", 64)); lib.tune("spmm_unroll", v.get("unroll", 8))
-                lib.tune("spmm_band_blocks", v.get("k", 3)); lib.tune("spmm_band_xcd", v.get("xcd", 1))
-                us_res = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
-                us_rot = _rot_time(g.fwd_o, n, 64, 6)
-                emit(probe="spmm_ns", graph=name, deg=deg, F=64, measured_halo=measured, E=int(g.E), alg_MB=nb / 1e6,
+                csr = g.fwd_o
+                lib.tune("spmm_tile_rows", v.get("rows", 32))
+                lib.tune("spmm_ellw", 1 if v["ellw"] else 0)
+                if v.get("mode") == "vals" and csr.ellw is not None and csr.ellw.vals is None:
+                    csr.val[0] = csr.val[0] * (1 + 2 ** -20)     # not a function of the source any more: per-slot mode
+                    csr.ellw = None
+                    ops._force_ellw(csr, 32)
+                us_res = timeit(lambda: ops.spmm(csr, X, Y))
+                us_rot = _rot_time(csr, n, 64, 6)
+                e = csr.ellw
+                emit(probe="spmm_ns", graph=name, deg=deg, F=64, measured_halo=csr.halo, E=int(g.E), alg_MB=nb / 1e6,
                      us_resident=us_res, frac_resident=nb / us_res / 1e3 / 8000, us_rotating=us_rot,
-                     GBs_rotating=nb / us_rot / 1e3, frac_rotating=nb / us_rot / 1e3 / 8000, **v)
-            lib.tune("spmm_tile_rows", 32); lib.tune("spmm_unroll", 8)
-            lib.tune("spmm_band_blocks", 3); lib.tune("spmm_band_xcd", 1)
+                     GBs_rotating=nb / us_rot / 1e3, frac_rotating=nb / us_rot / 1e3 / 8000,
+                     layout=None if e is None or not v["ellw"] else dict(tile_rows=e.tile_rows, width=e.width,
+                                                                         tiles=e.n_tiles, far=e.far), **v)
+            lib.tune("spmm_tile_rows", 32)
+            lib.tune("spmm_ellw", 1)
             del g, X, Y
 
 

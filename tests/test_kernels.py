@@ -399,11 +399,11 @@ def test_spmm_tuning_variants_agree(backend):
         lib.tune("spmm_tile_rows", 32); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_xcd", 1)
 
 
-# ------------------------------------------------------------------------------------------------ band (LDS-window) SpMM
+# ------------------------------------------------------------------------------------------------ ELLW (LDS-window) SpMM
 
-def banded_csr(n, deg_lo, deg_hi, window, seed, device, far_frac=0.0, heavy_row=None):
+def banded_csr(n, deg_lo, deg_hi, window, seed, device, far_frac=0.0, heavy_row=None, source_scaled=False):
     """rows with sources inside +-window (wrapping modulo n at both ends, like synthetic.local_graph) plus a fraction
-    of far-away sources; optionally one row with hundreds of slots."""
+    of far-away sources; optionally one row with hundreds of slots; `source_scaled`: val[q] = scale[col[q]] (DConv's P_o)."""
     rng = np.random.default_rng(seed)
     degs = rng.integers(deg_lo, deg_hi + 1, size=n)
     if heavy_row is not None:
@@ -414,73 +414,153 @@ def banded_csr(n, deg_lo, deg_hi, window, seed, device, far_frac=0.0, heavy_row=
     col = (rows + rng.integers(-window, window + 1, size=rows.size)) % n
     far = rng.random(rows.size) < far_frac
     col[far] = rng.integers(0, n, size=int(far.sum()))
+    val = rng.standard_normal(rows.size).astype(np.float32)
+    if source_scaled:
+        val = (0.25 + rng.random(n)).astype(np.float32)[col]
     csr = ops.Csr.__new__(ops.Csr)
-    csr.n_rows, csr.halo = n, 0
+    csr.n_rows, csr.halo, csr.max_len, csr.nnz, csr.ellw = n, 0, -1, -1, None
     csr.rowptr = torch.from_numpy(rowptr).to(device)
     csr.col = torch.from_numpy(col.astype(np.int32)).to(device)
-    csr.val = torch.from_numpy(rng.standard_normal(rows.size).astype(np.float32)).to(device)
+    csr.val = torch.from_numpy(val).to(device)
     return csr
 
 
-@pytest.mark.parametrize("halo,window,n,sched", [(32, 32, 333, 4), (32, 40, 1000, 4), (96, 96, 700, 4), (32, 5, 17, 4),
-                                                 (32, 40, 1000, 41), (96, 96, 700, 3), (96, 20, 64, 3), (32, 32, 333, 3),
-                                                 (32, 40, 1000, 1), (96, 96, 700, 1), (32, 5, 17, 1),
-                                                 (32, 32, 333, 0), (96, 96, 700, 0)])
-def test_spmm_band_window_matches_plain_and_reference(backend, halo, window, n, sched):
-    """Every locality schedule of pgt_spmm_csr_band_f32 (sched = pgt_tune spmm_band_cu: 4 window tiles of 32 rows
-    [41: persistent, three tiles per workgroup], 3 window tiles of 64 rows, 1 one workgroup per CU, 0 ring workgroups)
-    against the plain schedule (bit-identical) and the fp64 reference, with neighbours outside the window."""
+def source_scaled_reference(csr, X):
+    """fp32, the roundings of the reference's propagate: message = norm * x_j (rounded), then a sequential add per
+    destination in slot order (scatter-add on the CPU) — what the source-scale mode of the ELLW kernel reproduces."""
+    rp = csr.rowptr.cpu().long()
+    n = csr.n_rows
+    lens = rp[1:] - rp[:-1]
+    col, val, Xc = csr.col.cpu().long(), csr.val.cpu(), X.cpu()
+    acc = torch.zeros(n, X.size(1))
+    for j in range(int(lens.max()) if n else 0):
+        live = torch.nonzero(lens > j).flatten()
+        q = rp[live] + j
+        acc[live] = acc[live] + val[q, None] * Xc[col[q]]
+    return acc
+
+
+@pytest.mark.parametrize("halo,window,n,cap,cus", [(32, 32, 333, 0, 0), (32, 40, 1000, 48, 3), (96, 96, 700, 0, 0),
+                                                   (32, 5, 17, 0, 0), (32, 30, 900, 100, 2), (96, 20, 64, 16, 0)])
+def test_spmm_ellw_matches_csr_kernels_and_reference(backend, halo, window, n, cap, cus):
+    """pgt_spmm_ellw_f32 (ELLW layout, X window in LDS) with per-slot coefficients: the same fmaf chain in slot order as
+    the CSR row tiles, bit for bit, with sources outside the window (wrap-around, 5 % long-range edges), empty rows,
+    tile heights forced small (`spmm_ellw_rows`) so that several ragged tiles occur, the epilogue, an aliased T."""
     lib = _lib.get_lib()
-    lib.tune("spmm_band_cu", sched % 10)
-    lib.tune("spmm_wtile_tpw", 3 if sched == 41 else 1)
     if backend.name == "hip":
         n *= 37
     elif n > 600:
         n = 600                     # the CPU test double is a fiber emulator: keep its share of the suite to seconds
-    if backend.name != "hip" and n > 17 and sched == 1:
-        # the per-CU kernel launches 256 workgroups of 1024 lanes whatever n is; a 7-workgroup grid runs the same code
-        lib.tune("spmm_band_nblk", 7)
+    lib.tune("spmm_ellw_rows", cap)
+    lib.tune("spmm_ellw_cus", cus)
     try:
-        csr = banded_csr(n, 0, 20, window, seed=n, device=backend.device, far_frac=0.05, heavy_row=min(n - 1, 70))
+        csr = banded_csr(n, 0, 20, window, seed=n, device=backend.device, far_frac=0.05)
         g = torch.Generator().manual_seed(n)
         X = torch.randn(n, 64, generator=g).to(backend.device)
         T = torch.randn(n, 64, generator=g).to(backend.device)
+        e = ops._force_ellw(csr, halo)
+        assert e is not None and e.vals is not None and e.scale is None and e.width == 24
+        assert e.n_tiles * e.tile_rows >= n and (cap == 0 or e.tile_rows <= cap)
+        assert e.far > 0 or n < 200     # wrap-around / long-range sources outside the window
         ref = spmm_reference(csr, X, None, 1.0, 0.0)
         Yb = torch.full((n, 64), float("nan"), device=backend.device)
-        ops.spmm(csr, X, Yb, halo=halo)
-        assert_close_with_nonfinite(Yb, ref, 5e-5, 1e-5, "band")
+        ops.spmm(csr, X, Yb)
+        assert_close_with_nonfinite(Yb, ref, 5e-5, 1e-5, "ellw")
         Yp = torch.empty_like(Yb)
-        ops.spmm(csr, X, Yp, halo=0)
-        assert torch.equal(Yb, Yp)          # same slot-order fma chain in both schedules: bit-identical
-        ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0, halo=halo)
-        assert_close_with_nonfinite(Yb, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "band epilogue")
+        ops.spmm(csr, X, Yp, ellw=False)
+        assert torch.equal(Yb, Yp)          # same slot-order fma chain in both kernels: bit-identical
+        ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0)
+        ops.spmm(csr, X, Yp, T=T, alpha=2.0, beta=-1.0, ellw=False)
+        assert torch.equal(Yb, Yp)
+        assert_close_with_nonfinite(Yb, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "ellw epilogue")
         Tc = T.clone()
-        ops.spmm(csr, X, Tc, T=Tc, alpha=2.0, beta=1.0, halo=halo)
-        assert_close_with_nonfinite(Tc, spmm_reference(csr, X, T, 2.0, 1.0), 5e-5, 1e-5, "band aliased")
+        ops.spmm(csr, X, Tc, T=Tc, alpha=2.0, beta=1.0)
+        assert_close_with_nonfinite(Tc, spmm_reference(csr, X, T, 2.0, 1.0), 5e-5, 1e-5, "ellw aliased")
     finally:
-        lib.tune("spmm_band_nblk", 0)
-        lib.tune("spmm_band_cu", 4)
-        lib.tune("spmm_wtile_tpw", 1)
+        lib.tune("spmm_ellw_rows", 0)
+        lib.tune("spmm_ellw_cus", 0)
 
 
-def test_spmm_band_strided_nonfinite_and_fallback_shapes(backend):
+@pytest.mark.parametrize("n,cap,deg_hi", [(400, 40, 8), (523, 0, 30), (90, 12, 5)])
+def test_spmm_ellw_source_scaled_operator_drops_the_coefficient_stream(backend, n, cap, deg_hi):
+    """val[q] == scale[col[q]] for every slot (DConv's P_o, dcrnn.py:70-73): the layout keeps the per-source table only and
+    the kernel reproduces the reference's roundings exactly (rounded product, sequential rounded adds)."""
+    lib = _lib.get_lib()
+    if backend.name == "hip":
+        n *= 53
+    lib.tune("spmm_ellw_rows", cap)
+    try:
+        csr = banded_csr(n, 0, deg_hi, 30, seed=n + 1, device=backend.device, far_frac=0.03, source_scaled=True)
+        e = ops._force_ellw(csr, 32)
+        assert e is not None and e.scale is not None and e.vals is None
+        X = torch.randn(n, 64, generator=torch.Generator().manual_seed(n)).to(backend.device)
+        Y = torch.full((n, 64), float("nan"), device=backend.device)
+        ops.spmm(csr, X, Y)
+        assert torch.equal(Y.cpu(), source_scaled_reference(csr, X))
+        assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "vs fp64")
+        T = torch.randn(n, 64).to(backend.device)
+        ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0)
+        assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "epilogue")
+    finally:
+        lib.tune("spmm_ellw_rows", 0)
+
+
+def test_spmm_ellw_strided_nonfinite_and_fallback_shapes(backend):
     n = 300 if backend.name == "emu" else 9000
     csr = banded_csr(n, 1, 9, 30, seed=5, device=backend.device)
+    assert ops._force_ellw(csr, 32) is not None
     big = torch.randn(n, 80).to(backend.device)
     big[7, 10] = float("inf")
     big[n - 1, 12] = float("nan")
     X = big[:, 8:72]
     out = torch.zeros(n, 100, device=backend.device)
     Y = out[:, 4:68]
-    ops.spmm(csr, X, Y, halo=32)
-    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "band strided")
+    ops.spmm(csr, X, Y)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "ellw strided")
     assert float(out[:, :4].abs().max()) == 0.0 and float(out[:, 68:].abs().max()) == 0.0
-    # shapes the window schedule does not cover run the plain kernels under the same entry point
+    # shapes the window kernel does not cover run the CSR kernels: other widths, operands that are not 16-byte aligned
     for F_ in (32, 66, 128):
         Xf = torch.randn(n, F_).to(backend.device)
         Yf = torch.empty_like(Xf)
-        ops.spmm(csr, Xf, Yf, halo=32)
+        ops.spmm(csr, Xf, Yf)
         assert_close_with_nonfinite(Yf, spmm_reference(csr, Xf, None, 1.0, 0.0), 5e-5, 1e-5, f"fallback F={F_}")
+    Xo = torch.randn(n, 65).to(backend.device)[:, 1:]
+    Yo = torch.empty(n, 64, device=backend.device)
+    ops.spmm(csr, Xo, Yo)
+    assert_close_with_nonfinite(Yo, spmm_reference(csr, Xo, None, 1.0, 0.0), 5e-5, 1e-5, "unaligned X")
+    # rows longer than 32 slots: the layout does not apply, the operator stays on the CSR kernels
+    heavy = banded_csr(n, 0, 6, 30, seed=6, device=backend.device, heavy_row=40)
+    assert ops._force_ellw(heavy, 32) is None and heavy.ellw is None
+    Xh, Yh = torch.randn(n, 64).to(backend.device), torch.empty(n, 64, device=backend.device)
+    ops.spmm(heavy, Xh, Yh, ellw=True)
+    assert_close_with_nonfinite(Yh, spmm_reference(heavy, Xh, None, 1.0, 0.0), 5e-5, 1e-5, "heavy row")
+
+
+def test_ellw_plan_fills_whole_rounds_of_the_cus(backend):
+    """pgt_ellw_plan: N = 200 000, halo 32 on 256 CUs -> 511 tiles of 392 rows (two rounds); the caps are honoured."""
+    import ctypes
+    lib = _lib.get_lib()
+
+    def plan(n, halo, max_len):
+        tr, w, nt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        lib.call("pgt_ellw_plan", n, halo, max_len, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(nt))
+        return tr.value, w.value, nt.value
+
+    lib.tune("spmm_ellw_cus", 256)
+    try:
+        assert plan(200_000, 32, 8) == (392, 8, 511)
+        assert plan(200_000, 96, 8) == (264, 8, 758)          # window of 456 rows: 264 + 2 * 96
+        assert plan(200_000, 32, 17) == (196, 24, 1021)       # 392 * 16 staged slots: at most 260 rows of 24 -> four rounds
+        tr, w, nt = plan(50_000, 32, 8)
+        assert (tr, w, nt) == (196, 8, 256)                   # one round
+        tr, w, nt = plan(1_000_000, 32, 3)
+        assert w == 8 and tr <= 392 and nt == -(-1_000_000 // tr) and nt <= 11 * 256
+        with pytest.raises(_lib.PgtError, match="exceed"):
+            plan(1000, 32, 33)
+        with pytest.raises(_lib.PgtError, match="halo"):
+            plan(1000, 300, 8)
+    finally:
+        lib.tune("spmm_ellw_cus", 0)
 
 
 def test_locality_hint_is_measured_per_operator(backend):
@@ -631,28 +711,6 @@ def test_gemm_tn_pipelined_whole_k_schedule(backend, M, segs, segk, N):
         lib.tune("gemm_tn_pipe", 1)
 
 
-def test_spmm_quad_persistent_schedule_matches_tile_schedule(backend):
-    """The barrier-free persistent F = 64 schedule (pgt_tune spmm_quad) is bit-identical to the row-tile schedule."""
-    lib = _lib.get_lib()
-    n = 1100 if backend.name == "emu" else 150_000
-    csr = banded_csr(n, 0, 20, 40, seed=9, device=backend.device, far_frac=0.1, heavy_row=77)
-    X = torch.randn(n, 64).to(backend.device)
-    T = torch.randn(n, 64).to(backend.device)
-    Ya, Yb = torch.empty_like(X), torch.empty_like(X)
-    ops.spmm(csr, X, Ya, T=T, alpha=2.0, beta=-1.0, halo=0)
-    lib.tune("spmm_quad", 1)
-    try:
-        for blocks in (7, 2):
-            lib.tune("spmm_quad_blocks", blocks)
-            Yb.fill_(float("nan"))
-            ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0, halo=0)
-            assert torch.equal(Ya, Yb)
-    finally:
-        lib.tune("spmm_quad", 0)
-        lib.tune("spmm_quad_blocks", 7)
-    assert_close_with_nonfinite(Ya, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "quad")
-
-
 @pytest.mark.parametrize("O,peep", [(8, True), (6, True), (5, False), (64, True)])
 def test_lstm_gate_kernels_against_autograd(backend, O, peep):
     """pgt_lstm_gates(_bwd)_f32 against the gate equations of gconv_lstm.py:138-172 written with torch autograd."""
@@ -691,27 +749,6 @@ def test_lstm_gate_kernels_against_autograd(backend, O, peep):
         tol = 1e-4 if backend.name == "emu" else 5e-3       # column sums over M rows (fp32 atomics on the GPU leg)
         for a, b_, nm in zip(wd, w64, ("w_ci", "w_cf", "w_co")):
             assert_close_with_nonfinite(a.grad, b_.grad, tol, 1e-4, nm)
-
-
-@pytest.mark.parametrize("nblk,n,window", [(3, 700, 40), (2, 333, 32), (4, 900, 50)])
-def test_spmm_band_per_cu_kernel_multi_step_chunks(backend, nblk, n, window):
-    """The per-CU LDS-window kernel with several pipelined steps per workgroup and partial last steps (on the GPU these
-    only occur beyond 16 384 rows; the `spmm_band_nblk` hook forces few workgroups so the CPU test double sees them),
-    with sources just outside the halo at chunk ends."""
-    lib = _lib.get_lib()
-    csr = banded_csr(n, 0, 18, window, seed=n, device=backend.device, far_frac=0.03, heavy_row=min(n - 1, 200))
-    X = torch.randn(n, 64).to(backend.device)
-    T = torch.randn(n, 64).to(backend.device)
-    Yp, Yb = torch.empty_like(X), torch.full_like(X, float("nan"))
-    ops.spmm(csr, X, Yp, T=T, alpha=2.0, beta=-1.0, halo=0)
-    lib.tune("spmm_band_nblk", nblk)
-    lib.tune("spmm_band_cu", 1)
-    try:
-        ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0, halo=32)
-    finally:
-        lib.tune("spmm_band_nblk", 0)
-        lib.tune("spmm_band_cu", 4)
-    assert torch.equal(Yp, Yb)
 
 
 @pytest.mark.parametrize("M,segs,segk,O,fin", [(150, 5, 66, 64, 2), (70, 3, 10, 8, 2), (260, 1, 128, 32, 0),
@@ -945,48 +982,71 @@ def test_gemm_persistent_deferred_store_schedule(backend, M, segs, segk, N):
 @pytest.mark.gpu
 def test_aggregation_at_north_star_size():
     """BASELINE.json's north-star shape (N = 200 000 nodes, F = 64, in-degree 8; 1.6 M edges) on the product library:
-    the shipped row-tile schedule against an fp64 gather / index_add of the same CSR (1e-5), linearity, the Chebyshev
-    epilogue, and the alternative schedules (streaming vs plain stores, LDS-window tiles) bit for bit -- every one of
-    them sums a row's slots in slot order."""
+    the shipped kernel (ELLW layout, source-scale mode: P_o = A D_out^-1) against an fp64 gather / index_add of the same
+    CSR (1e-5) and, bit for bit, against the reference's fp32 roundings (rounded `norm * x_j`, sequential adds);
+    linearity, the Chebyshev epilogue; the per-slot-coefficient mode and the CSR row tiles (streaming vs plain stores,
+    tile heights) agree with each other bit for bit and with the shipped kernel to 1e-5.  The uniform-random graph of the
+    bench line (no locality: CSR row tiles) against fp64 as well."""
     lib = _lib.get_lib()
     if lib.target != "gfx950":
         pytest.skip("product library only")
     dev = torch.device("cuda:0")
     n, F_ = 200_000, 64
-    ei, ew = syn.local_graph(n, 8, seed=0)
-    G = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
-    csr = G.fwd_o
-    nnz = int(csr.rowptr[-1])
-    assert nnz == ei.shape[1]
-    rows = torch.repeat_interleave(torch.arange(n, device=dev), (csr.rowptr[1:] - csr.rowptr[:-1]).long())
-    cols, vals = csr.col[:nnz].long(), csr.val[:nnz].double()
     gen = torch.Generator(device="cpu").manual_seed(11)
     X1, X2 = torch.randn(n, F_, generator=gen).to(dev), torch.randn(n, F_, generator=gen).to(dev)
+    for kind, graph in (("local", syn.local_graph), ("uniform", syn.uniform_graph)):
+        ei, ew = graph(n, 8, seed=0)
+        G = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
+        csr = G.fwd_o
+        nnz = int(csr.rowptr[-1])
+        assert nnz == ei.shape[1]
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), (csr.rowptr[1:] - csr.rowptr[:-1]).long())
+        cols, vals = csr.col[:nnz].long(), csr.val[:nnz].double()
 
-    def reference(X):
-        return torch.zeros(n, F_, dtype=torch.float64, device=dev).index_add_(0, rows, X.double()[cols] * vals[:, None])
+        def reference(X):
+            return torch.zeros(n, F_, dtype=torch.float64, device=dev).index_add_(0, rows, X.double()[cols] * vals[:, None])
 
-    Y1, Y2, Y3 = (torch.full((n, F_), float("nan"), device=dev) for _ in range(3))
-    ops.spmm(csr, X1, Y1)
-    ops.spmm(csr, X2, Y2)
-    ref1 = reference(X1)
-    assert_close_with_nonfinite(Y1, ref1.cpu(), 1e-5, 1e-5, "aggregation vs fp64")
-    ops.spmm(csr, 0.5 * X1 - 2.0 * X2, Y3)
-    assert torch.allclose(Y3, 0.5 * Y1 - 2.0 * Y2, atol=2e-5, rtol=1e-5)                   # linearity
-    ops.spmm(csr, X1, Y3, T=X2, alpha=2.0, beta=-1.0)                                      # 2 P X1 - X2
-    assert_close_with_nonfinite(Y3, (2.0 * ref1 - X2.double()).cpu(), 2e-5, 1e-5, "Chebyshev epilogue")
-    try:
-        for key, value in (("spmm_tile_nt", 0), ("spmm_tile_nt", 2), ("spmm_tile_rows", 64)):
-            lib.tune(key, value)
-            Ys = torch.full((n, F_), float("nan"), device=dev)
-            ops.spmm(csr, X1, Ys)
-            assert torch.equal(Ys, Y1), (key, value)
-        Yb = torch.full((n, F_), float("nan"), device=dev)
-        ops.spmm(csr, X1, Yb, halo=32)                                                     # LDS-window tiles
-        assert torch.equal(Yb, Y1)
-    finally:
-        lib.tune("spmm_tile_nt", 1)
-        lib.tune("spmm_tile_rows", 32)
+        Y1, Y2, Y3 = (torch.full((n, F_), float("nan"), device=dev) for _ in range(3))
+        ops.spmm(csr, X1, Y1)
+        e = csr.ellw
+        if kind == "local":
+            assert e is not None and e.scale is not None and e.vals is None and (e.tile_rows, e.width) == (392, 8)
+            assert 0 < e.far < 1000                                                        # the wrap-around rows
+        else:
+            assert e is None and csr.halo == 0
+        ops.spmm(csr, X2, Y2)
+        ref1 = reference(X1)
+        assert_close_with_nonfinite(Y1, ref1.cpu(), 1e-5, 1e-5, f"{kind}: aggregation vs fp64")
+        ops.spmm(csr, 0.5 * X1 - 2.0 * X2, Y3)
+        assert torch.allclose(Y3, 0.5 * Y1 - 2.0 * Y2, atol=2e-5, rtol=1e-5)               # linearity
+        ops.spmm(csr, X1, Y3, T=X2, alpha=2.0, beta=-1.0)                                  # 2 P X1 - X2
+        assert_close_with_nonfinite(Y3, (2.0 * ref1 - X2.double()).cpu(), 2e-5, 1e-5, f"{kind}: Chebyshev epilogue")
+        Yc = torch.full((n, F_), float("nan"), device=dev)
+        ops.spmm(csr, X1, Yc, ellw=False)                                                  # CSR row tiles
+        try:
+            for key, value in (("spmm_tile_nt", 0), ("spmm_tile_nt", 2), ("spmm_tile_rows", 64)):
+                lib.tune(key, value)
+                Ys = torch.full((n, F_), float("nan"), device=dev)
+                ops.spmm(csr, X1, Ys, ellw=False)
+                assert torch.equal(Ys, Yc), (key, value)
+        finally:
+            lib.tune("spmm_tile_nt", 1)
+            lib.tune("spmm_tile_rows", 32)
+        if kind == "local":
+            assert torch.equal(Y1.cpu(), source_scaled_reference(csr, X1))                 # the reference's roundings
+            assert_close_with_nonfinite(Yc, Y1.cpu(), 1e-5, 1e-5, "CSR tiles vs ELLW")
+            # per-slot coefficient mode of the same layout: the CSR kernels' fmaf chain, bit for bit
+            e.vals, e.scale = csr.val.new_zeros(e.n_tiles * e.tile_rows * e.width), None
+            perslot = ops.Ellw.__new__(ops.Ellw)
+            csr.val[0] = csr.val[0] * (1 + 2 ** -20)          # no longer a function of the source: forces per-slot mode
+            csr.ellw = None
+            ops._force_ellw(csr, 32)
+            assert csr.ellw.vals is not None and csr.ellw.scale is None
+            Yv, Yc2 = torch.full((n, F_), float("nan"), device=dev), torch.empty(n, F_, device=dev)
+            ops.spmm(csr, X1, Yv)
+            ops.spmm(csr, X1, Yc2, ellw=False)
+            assert torch.equal(Yv, Yc2)
+        del G, csr
 
 
 # ------------------------------------------------------------------------------------------------ fuzzing the graph prep
@@ -1138,11 +1198,13 @@ try:
 
     @settings(max_examples=100, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
     @given(data=hst.data(), F_=hst.integers(1, 300), use_t=hst.booleans(), rows=hst.sampled_from([32, 64]),
-           unroll=hst.sampled_from([4, 8]), halo=hst.sampled_from([0, 0, 32]), nt=hst.sampled_from([0, 2]))
-    def test_fuzz_aggregation_entry_point(emu_backend, data, F_, use_t, rows, unroll, halo, nt):
-        """pgt_spmm_csr_band_f32 on random CSR operators (empty rows, heavy rows, duplicates) for every feature width
-        up to 300, with and without the `alpha A X + beta T` epilogue, across tile shapes, store flavours and the
-        LDS-window schedule (F = 64 only)."""
+           unroll=hst.sampled_from([4, 8]), halo=hst.sampled_from([0, 0, 32]), nt=hst.sampled_from([0, 2]),
+           cap=hst.sampled_from([0, 8, 20]), scaled=hst.booleans())
+    def test_fuzz_aggregation_entry_point(emu_backend, data, F_, use_t, rows, unroll, halo, nt, cap, scaled):
+        """pgt_spmm_csr_f32 / pgt_spmm_ellw_f32 on random CSR operators (empty rows, heavy rows, duplicates) for every
+        feature width up to 300, with and without the `alpha A X + beta T` epilogue, across tile shapes, store flavours
+        and the ELLW layout (F = 64 only; per-slot and source-scaled coefficients, sources anywhere: most slots then take
+        the out-of-window path)."""
         lib = _lib.get_lib()
         n = data.draw(hst.integers(1, 90))
         deg = data.draw(hst.lists(hst.integers(0, 9), min_size=n, max_size=n))
@@ -1153,6 +1215,8 @@ try:
         gen = torch.Generator().manual_seed(n * 31 + F_)
         col = torch.randint(0, n, (nnz,), generator=gen, dtype=torch.int32)
         val = torch.randn(nnz, generator=gen)
+        if scaled:
+            val = torch.randn(n, generator=gen)[col.long()]
         dev = emu_backend.device
         csr = ops.Csr(n, max(nnz, 1), dev)
         csr.rowptr.copy_(rp)
@@ -1161,12 +1225,18 @@ try:
         X, T = torch.randn(n, F_, generator=gen), torch.randn(n, F_, generator=gen)
         alpha, beta = (2.0, -1.0) if use_t else (0.5, 0.0)
         lib.tune("spmm_tile_rows", rows); lib.tune("spmm_unroll", unroll); lib.tune("spmm_tile_nt", nt)
+        lib.tune("spmm_ellw_rows", cap)
         try:
             Y = torch.full((n, F_), float("nan")).to(dev)
-            ops.spmm(csr, X.to(dev), Y, T=T.to(dev) if use_t else None, alpha=alpha, beta=beta,
-                     halo=halo if F_ == 64 else 0)
+            use_ellw = halo > 0 and F_ == 64 and nnz > 0
+            if use_ellw:
+                e = ops._force_ellw(csr, halo)
+                assert (e is None) == (max(deg) > 32)
+                assert e is None or (e.scale is not None) == scaled
+            ops.spmm(csr, X.to(dev), Y, T=T.to(dev) if use_t else None, alpha=alpha, beta=beta, ellw=use_ellw)
         finally:
             lib.tune("spmm_tile_rows", 32); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_nt", 1)
+            lib.tune("spmm_ellw_rows", 0)
         rows_i = torch.repeat_interleave(torch.arange(n), torch.tensor(deg))
         ref = torch.zeros(n, F_, dtype=torch.float64).index_add_(0, rows_i, X.double()[col.long()] * val.double()[:, None])
         ref = alpha * ref + (beta * T.double() if use_t else 0.0)

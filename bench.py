@@ -169,7 +169,8 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
                 for i in range(launches):
                     ops.spmm(g.fwd_o, Xs[i % pairs], Ys[i % pairs])
         torch.cuda.current_stream(device).wait_stream(side)
-        graph.replay()
+        for _ in range(5):                                 # ~7 ms of launches: clocks out of the idle state
+            graph.replay()
         torch.cuda.synchronize()
         times = []
         for _ in range(3):
@@ -234,6 +235,12 @@ def main():
         flat.all_reduce_mean(world)
         opt.step()
         return loss
+
+    # north-star micro-benchmark before the training loop (PGT_NS_FIRST=0: after it — an A/B of the GPU's thermal /
+    # power state: the training step is MFMA-heavy and leaves the part hot)
+    ns, ns_first = None, os.environ.get("PGT_NS_FIRST", "1") != "0"
+    if rank == 0 and world == 1 and not args.no_ns and ns_first:
+        ns = spmm_roofline_ns(device)
 
     # one initialisation pass (not a warmup step): first-use work that does not belong to any step - graph preparation
     # (cached by tensor identity afterwards), code-object load of every kernel, growth of torch's caching allocator to the
@@ -312,8 +319,7 @@ def main():
                                   "TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12}
                                  for r in shapes if r["tag"][0] == kk]
 
-    ns = None
-    if rank == 0 and world == 1 and not args.no_ns:
+    if rank == 0 and world == 1 and not args.no_ns and not ns_first:
         ns = spmm_roofline_ns(device)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -91,7 +91,7 @@ const char* pgt_build_target(void);
  * (streaming kernels for an extent <= 4: 1 from 1024 rows / 2 always / 0), "gemm_small_tiles", "gemm_tn_pipe",
  * "gemm_tn_fullk".  Diffusion stack: "slab_pairs".  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
  * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_ellw" (0: pgt_spmm_ellw_f32 runs
- * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" (test hooks of pgt_ellw_plan).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
+ * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
 int pgt_tune(const char* key, int value);
 
 /* ---------------------------------------------------------------- graph preparation */
@@ -144,16 +144,18 @@ typedef struct pgt_ellw {
   const uint16_t* slots;  /* [n_tiles * tile_rows * width] */
   const float* vals;      /* [n_tiles * tile_rows * width], or NULL in source-scale mode */
   const float* scale;     /* [n_rows] coefficient per SOURCE row, or NULL; exactly one of vals / scale is set */
-  int32_t tile_rows, halo, width, reserved;
+  int32_t tile_rows, halo, width;
+  int32_t config;         /* launch shape, from pgt_ellw_plan: 1 = one 1024-thread workgroup per CU (456 window rows),
+                             2 = two 512-thread workgroups per CU (240 window rows) */
   int64_t n_tiles;
 } pgt_ellw;
 
 /* Host-only: tile height / slot width / tile count for an operator with `n_rows` rows whose longest row has
  * `max_row_len` slots and whose sources lie (mostly) within `halo` rows of their destination; the tile height fills
- * whole rounds of one workgroup per CU of the current device.  PGT_ERR_INVALID when the layout does not apply
- * (rows longer than 32 slots, halo > 224). */
+ * whole rounds of the resident workgroups (config 1: rows of <= 8 slots; config 2: wider rows) of the current device.
+ * PGT_ERR_INVALID when the layout does not apply (rows longer than 32 slots, halo > 116). */
 int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t* tile_rows, int32_t* width,
-                  int64_t* n_tiles);
+                  int32_t* config, int64_t* n_tiles);
 
 /* Fill `slots` / `vals` (each n_tiles * tile_rows * width entries; `vals` may be NULL) from the CSR operator, with the
  * geometry in `op` (its pointers are ignored).  `scale` (float [n_rows], may be NULL) receives the candidate

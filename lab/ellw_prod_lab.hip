@@ -64,18 +64,6 @@ int main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double alg = 4.0 * (n + 1) + 8.0 * nnz + 8.0 * n * F;
-  // build the layout through the C ABI
-  pgt_ellw op; memset(&op, 0, sizeof(op));
-  op.halo = 32;
-  PK(pgt_ellw_plan(n, 32, deg, &op.tile_rows, &op.width, &op.n_tiles));
-  const size_t total = (size_t)op.n_tiles * op.tile_rows * op.width;
-  uint16_t* slots; float *vals, *scale; int32_t* info;
-  CK(hipMalloc(&slots, total * 2)); CK(hipMalloc(&vals, total * 4)); CK(hipMalloc(&scale, n * 4)); CK(hipMalloc(&info, 16));
-  PK(pgt_ellw_build(rp, col, val, n, nnz, &op, slots, vals, scale, info, st));
-  int32_t hinfo[4]; CK(hipMemcpyAsync(hinfo, info, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-  printf("deg %d: plan: %lld tiles of %d rows x %d slots; far %d, scale mismatches %d, overflow rows %d; algorithmic %.1f MB\n",
-         deg, (long long)op.n_tiles, op.tile_rows, op.width, hinfo[0], hinfo[1], hinfo[2], alg / 1e6);
-  op.slots = slots;
   auto timeit = [&](const char* name, auto fn) {
     for (int i = 0; i < 2 * PAIRS; ++i) fn(i % PAIRS);
     double best = 1e9, sum = 0;
@@ -91,11 +79,25 @@ int main(int argc, char** argv) {
     printf("%-64s %7.2f us (mean %6.2f)  %.3f of 8 TB/s\n", name, best, sum / 3, alg / best / 1e3 / 8000);
     fflush(stdout);
   };
+  // build the layout through the C ABI
+  for (int cfg : {1, 2}) {
+  pgt_tune("spmm_ellw_cfg", cfg);
+  pgt_ellw op; memset(&op, 0, sizeof(op));
+  op.halo = 32;
+  PK(pgt_ellw_plan(n, 32, deg, &op.tile_rows, &op.width, &op.config, &op.n_tiles));
+  const size_t total = (size_t)op.n_tiles * op.tile_rows * op.width;
+  uint16_t* slots; float *vals, *scale; int32_t* info;
+  CK(hipMalloc(&slots, total * 2)); CK(hipMalloc(&vals, total * 4)); CK(hipMalloc(&scale, n * 4)); CK(hipMalloc(&info, 16));
+  PK(pgt_ellw_build(rp, col, val, n, nnz, &op, slots, vals, scale, info, st));
+  int32_t hinfo[4]; CK(hipMemcpyAsync(hinfo, info, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+  printf("cfg %d deg %d: plan: %lld tiles of %d rows x %d slots; far %d, scale mismatches %d, overflow rows %d; algorithmic %.1f MB\n",
+         cfg, deg, (long long)op.n_tiles, op.tile_rows, op.width, hinfo[0], hinfo[1], hinfo[2], alg / 1e6);
+  op.slots = slots;
   for (int mode = 0; mode < 2; ++mode) {
     op.scale = mode == 0 ? scale : nullptr;
     op.vals = mode == 0 ? nullptr : vals;
     char nm[96];
-    snprintf(nm, 96, "product kernel, mode %d (%s), stream launches", mode, mode == 0 ? "scale table" : "per-slot vals");
+    snprintf(nm, 96, "cfg %d product kernel, mode %d (%s), stream launches", cfg, mode, mode == 0 ? "scale table" : "per-slot vals");
     timeit(nm, [&](int p) { PK(pgt_spmm_ellw_f32(&op, rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st)); });
     // the same 60 launches as one hipGraph (what bench.py replays)
     hipGraph_t graph; hipGraphExec_t exec;
@@ -110,14 +112,16 @@ int main(int argc, char** argv) {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       best = std::min(best, ms * 1e3 / 60); sum += ms * 1e3 / 60;
     }
-    snprintf(nm, 96, "product kernel, mode %d, 60 launches as one hipGraph", mode);
+    snprintf(nm, 96, "cfg %d product kernel, mode %d, 60 launches as one hipGraph", cfg, mode);
     printf("%-64s %7.2f us (mean %6.2f)  %.3f of 8 TB/s\n", nm, best, sum / 3, alg / best / 1e3 / 8000);
     CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
   }
+  op.scale = scale; op.vals = nullptr;
+  timeit("  same, mode 0, epilogue 2*P*X - T", [&](int p) { PK(pgt_spmm_ellw_f32(&op, rp, col, val, n, X[p], F, Y[p], F, X[(p + 1) % PAIRS], F, 2.f, -1.f, F, st)); });
+  CK(hipFree(slots)); CK(hipFree(vals)); CK(hipFree(scale)); CK(hipFree(info));
+  }
+  pgt_tune("spmm_ellw_cfg", 0);
   // CSR row tiles for reference
   timeit("CSR row tiles (pgt_spmm_csr_f32)", [&](int p) { PK(pgt_spmm_csr_f32(rp, col, val, n, X[p], F, Y[p], F, nullptr, 0, 1.f, 0.f, F, st)); });
-  // Chebyshev epilogue form
-  op.scale = scale; op.vals = nullptr;
-  timeit("product kernel, mode 0, epilogue 2*P*X - T", [&](int p) { PK(pgt_spmm_ellw_f32(&op, rp, col, val, n, X[p], F, Y[p], F, X[(p + 1) % PAIRS], F, 2.f, -1.f, F, st)); });
   return 0;
 }

@@ -35,7 +35,7 @@ class CsrStruct(ctypes.Structure):
 
 class EllwStruct(ctypes.Structure):
     _fields_ = [("slots", c_ptr), ("vals", c_ptr), ("scale", c_ptr), ("tile_rows", ctypes.c_int32),
-                ("halo", ctypes.c_int32), ("width", ctypes.c_int32), ("reserved", ctypes.c_int32), ("n_tiles", c_i64)]
+                ("halo", ctypes.c_int32), ("width", ctypes.c_int32), ("config", ctypes.c_int32), ("n_tiles", c_i64)]
 
 
 class DConvGraphStruct(ctypes.Structure):
@@ -62,7 +62,7 @@ PROTOTYPES = {
     "pgt_spmm_csr_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32,
                                  c_f32, c_i64, c_ptr]),
     "pgt_ellw_plan": (c_int, [c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
-                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_i64)]),
+                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_i64)]),
     "pgt_ellw_build": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.POINTER(EllwStruct), c_ptr, c_ptr, c_ptr, c_ptr,
                                c_ptr]),
     "pgt_spmm_ellw_f32": (c_int, [ctypes.POINTER(EllwStruct), c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,

@@ -212,32 +212,41 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
 // Measured (lab/ellw_lab, N = 200 000, in-degree 8, rotating buffers): 21.2 us = 0.685 of 8 TB/s (MODE 0), 22.6 us
 // (MODE 1); a float4 copy of the same X -> Y on the same box: 18.8 us.  Streaming (non-temporal) stores of Y matter:
 // 27.6 us without them.
-constexpr int ELLW_THREADS = 1024;
-constexpr int ELLW_WRMAX = 456;          // window rows held in LDS (+ one zero row)
-constexpr int ELLW_SLOTS = 392 * 16;     // tile_rows * width <= ELLW_SLOTS (slot block staged in LDS)
+// Two launch shapes (ELLW_CFG):
+//   A: 1024 threads, 456 window rows (130 - 155 KB of LDS): one workgroup per CU, the smallest halo overhead; load phase
+//      and gather phase of a CU do not overlap.  Best at in-degree <= 8 (W = 8).
+//   B:  512 threads, 240 window rows (67 - 79 KB): two workgroups per CU, one gathers out of LDS while the other's
+//      memory phase is in flight.  For wider rows (W >= 16), where the LDS gather is as long as the memory phase.
+struct EllwCfgA { static constexpr int THREADS = 1024, WRMAX = 456, SLOTS = 392 * 16; };
+struct EllwCfgB { static constexpr int THREADS = 512, WRMAX = 240, SLOTS = 176 * 16; };
 constexpr int ELLW_WMAX = 32;
 
 int g_ellw = 1;        // pgt_tune("spmm_ellw"): 0 = pgt_spmm_ellw_f32 runs the CSR kernels instead (A/B)
 int g_ellw_rows = 0;   // pgt_tune("spmm_ellw_rows"): test hook, caps the planned tile height (0 = no cap)
 int g_ellw_cus = 0;    // pgt_tune("spmm_ellw_cus"): test hook, CU count the plan balances for (0 = the device's)
+int g_ellw_cfg = 0;    // pgt_tune("spmm_ellw_cfg"): launch shape pgt_ellw_plan picks: 0 = by row width, 1 = A, 2 = B
 
-template <int MODE>
-__global__ __launch_bounds__(ELLW_THREADS) void spmm_ellw64_kernel(
+// W8C: slot vectors (8 slots) per row when known at compile time (1, 2), 0 = runtime
+template <int MODE, class CFG, int W8C>
+__global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     const uint16_t* __restrict__ slots, const float* __restrict__ vals, const float* __restrict__ scale,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
     int TR, int H, int W, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt, float alpha,
     float beta, int flags) {
-  constexpr int G = ELLW_THREADS / 16;                 // 64 row groups of 16 lanes: one 256-byte row each
-  constexpr int XPT = (ELLW_WRMAX + G - 1) / G;        // window rows per group
-  __shared__ pgt_f4 s_x[(ELLW_WRMAX + 1) * 16];
-  __shared__ pgt_u4 s_slots[ELLW_SLOTS / 8];
-  __shared__ pgt_f4 s_vals[MODE == 1 ? ELLW_SLOTS / 4 : 1];
+  constexpr int THREADS = CFG::THREADS, WRMAX = CFG::WRMAX, SLOTS = CFG::SLOTS;
+  constexpr int G = THREADS / 16;                      // row groups of 16 lanes: one 256-byte row each
+  constexpr int XPT = (WRMAX + G - 1) / G;             // window rows per group
+  constexpr int RPG = (WRMAX - 2 + G - 1) / G;         // output rows per group (TR <= WRMAX - 2 H, H >= 1)
+  constexpr int NSV = (SLOTS / 8 + THREADS - 1) / THREADS;   // slot vectors per thread
+  __shared__ pgt_f4 s_x[(WRMAX + 1) * 16];
+  __shared__ pgt_u4 s_slots[SLOTS / 8];
+  __shared__ pgt_f4 s_vals[MODE == 1 ? SLOTS / 4 : 1];
   const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
   const int tile = (flags & 1) ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const bool stream_y = (flags & 2) != 0;
   const int r0 = tile * TR, w0 = r0 - H, WR = TR + 2 * H;
   const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
-  const int W8 = W >> 3;                               // slot vectors (8 x u16) per row
+  const int W8 = W8C > 0 ? W8C : (W >> 3);             // slot vectors (8 x u16) per row
   const float* Xl = X + l16 * 4;
   // ---- one memory phase: window rows, their source scales, the tile's slot block (and coefficient block)
   pgt_f4 xw[XPT];
@@ -251,14 +260,18 @@ __global__ __launch_bounds__(ELLW_THREADS) void spmm_ellw64_kernel(
     xw[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(r * ldx));
     sc[i] = MODE == 0 ? scale[r] : 1.f;
   }
-  const int nvec = TR * W8;                            // <= ELLW_SLOTS / 8 <= ELLW_THREADS
-  const pgt_u4 sv = reinterpret_cast<const pgt_u4*>(slots + (size_t)tile * TR * W)[tid < nvec ? tid : nvec - 1];
-  pgt_f4 va = pgt_mk4(0.f, 0.f, 0.f, 0.f), vb = va;
-  if constexpr (MODE == 1) {
-    const pgt_f4* vp = reinterpret_cast<const pgt_f4*>(vals + (size_t)tile * TR * W);
-    const int nv4 = 2 * nvec;
-    va = vp[tid < nv4 ? tid : nv4 - 1];
-    vb = vp[tid + ELLW_THREADS < nv4 ? tid + ELLW_THREADS : nv4 - 1];
+  const int nvec = TR * W8;                            // <= SLOTS / 8
+  pgt_u4 sv[NSV];
+  pgt_f4 va[MODE == 1 ? 2 * NSV : 1];
+  {
+    const pgt_u4* sp = reinterpret_cast<const pgt_u4*>(slots + (size_t)tile * TR * W8 * 8);
+#pragma unroll
+    for (int i = 0; i < NSV; ++i) { const int v = tid + THREADS * i; sv[i] = sp[v < nvec ? v : nvec - 1]; }
+    if constexpr (MODE == 1) {
+      const pgt_f4* vp = reinterpret_cast<const pgt_f4*>(vals + (size_t)tile * TR * W8 * 8);
+#pragma unroll
+      for (int i = 0; i < 2 * NSV; ++i) { const int v = tid + THREADS * i; va[i] = vp[v < 2 * nvec ? v : 2 * nvec - 1]; }
+    }
   }
   pgt_f4 tcur = pgt_mk4(0.f, 0.f, 0.f, 0.f);
   if (T != nullptr && rg < nr) tcur = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + rg) * ldt) + l16 * 4);
@@ -273,18 +286,19 @@ __global__ __launch_bounds__(ELLW_THREADS) void spmm_ellw64_kernel(
     }
   }
   if (tid < 16) s_x[WR * 16 + tid] = pgt_mk4(0.f, 0.f, 0.f, 0.f);     // the row padding slots point at
-  if (tid < nvec) s_slots[tid] = sv;
+#pragma unroll
+  for (int i = 0; i < NSV; ++i) { const int v = tid + THREADS * i; if (v < nvec) s_slots[v] = sv[i]; }
   if constexpr (MODE == 1) {
-    if (tid < 2 * nvec) s_vals[tid] = va;
-    if (tid + ELLW_THREADS < 2 * nvec) s_vals[tid + ELLW_THREADS] = vb;
+#pragma unroll
+    for (int i = 0; i < 2 * NSV; ++i) { const int v = tid + THREADS * i; if (v < 2 * nvec) s_vals[v] = va[i]; }
   }
   __syncthreads();
-  // ---- gather out of the window: rows rg, rg + 64, ... ; sequential chain in slot order
-  for (int r = rg; r < nr; r += G) {
+  // ---- gather out of the window: rows rg, rg + G, ... ; sequential chain in slot order
+  auto do_row = [&](const int r, pgt_f4& tc) {
     pgt_f4 tnext = pgt_mk4(0.f, 0.f, 0.f, 0.f);
     if (T != nullptr && r + G < nr) tnext = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + r + G) * ldt) + l16 * 4);
     pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-    for (int c8 = 0; c8 < W8; ++c8) {
+    auto chunk = [&](const int c8) {
       const pgt_u4 s4 = s_slots[r * W8 + c8];
       const unsigned d[8] = {s4.x & 0xffffu, s4.x >> 16, s4.y & 0xffffu, s4.y >> 16,
                              s4.z & 0xffffu, s4.z >> 16, s4.w & 0xffffu, s4.w >> 16};
@@ -322,18 +336,34 @@ __global__ __launch_bounds__(ELLW_THREADS) void spmm_ellw64_kernel(
           acc = pgt_mk4(fmaf(vv[j], x[j].x, acc.x), fmaf(vv[j], x[j].y, acc.y), fmaf(vv[j], x[j].z, acc.z), fmaf(vv[j], x[j].w, acc.w));
         }
       }
+    };
+    if constexpr (W8C > 0) {
+#pragma unroll
+      for (int c8 = 0; c8 < W8C; ++c8) chunk(c8);
+    } else {
+      for (int c8 = 0; c8 < W8; ++c8) chunk(c8);
     }
     float out[4];
     if (T != nullptr) {
-      out[0] = alpha * acc.x + beta * tcur.x; out[1] = alpha * acc.y + beta * tcur.y;
-      out[2] = alpha * acc.z + beta * tcur.z; out[3] = alpha * acc.w + beta * tcur.w;
+      out[0] = alpha * acc.x + beta * tc.x; out[1] = alpha * acc.y + beta * tc.y;
+      out[2] = alpha * acc.z + beta * tc.z; out[3] = alpha * acc.w + beta * tc.w;
     } else {
       out[0] = alpha * acc.x; out[1] = alpha * acc.y; out[2] = alpha * acc.z; out[3] = alpha * acc.w;
     }
     float* yp = Y + (unsigned)((r0 + r) * ldy) + l16 * 4;
     if (stream_y) stv_stream<4>(yp, out);
     else stv<4>(yp, out);
-    tcur = tnext;
+    tc = tnext;
+  };
+  if constexpr (W8C == 1) {
+    // narrow rows: the row loop is unrolled so the LDS reads of several rows are in flight together
+#pragma unroll
+    for (int k = 0; k < RPG; ++k) {
+      const int r = rg + G * k;
+      if (r < nr) do_row(r, tcur);
+    }
+  } else {
+    for (int r = rg; r < nr; r += G) do_row(r, tcur);
   }
 }
 
@@ -579,6 +609,7 @@ int pgt_spmm_tune(const char* key, int value) {
   if (strcmp(key, "spmm_ellw") == 0) { g_ellw = value; return 1; }
   if (strcmp(key, "spmm_ellw_rows") == 0) { g_ellw_rows = value > 0 ? value : 0; return 1; }
   if (strcmp(key, "spmm_ellw_cus") == 0) { g_ellw_cus = value > 0 ? value : 0; return 1; }
+  if (strcmp(key, "spmm_ellw_cfg") == 0) { g_ellw_cfg = value; return 1; }
   return 0;
 }
 
@@ -629,22 +660,28 @@ static int ellw_device_cus() {
 }
 
 extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t* tile_rows, int32_t* width,
-                             int64_t* n_tiles) {
-  PGT_REQUIRE(tile_rows && width && n_tiles, "pgt_ellw_plan: null pointer");
-  *tile_rows = 0; *width = 0; *n_tiles = 0;
+                             int32_t* config, int64_t* n_tiles) {
+  PGT_REQUIRE(tile_rows && width && config && n_tiles, "pgt_ellw_plan: null pointer");
+  *tile_rows = 0; *width = 0; *config = 0; *n_tiles = 0;
   PGT_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 31) - 1024, "pgt_ellw_plan: n_rows out of range");
-  PGT_REQUIRE(halo >= 1 && 2 * halo <= ELLW_WRMAX - 8, "pgt_ellw_plan: halo %d outside [1, %d]", (int)halo, (ELLW_WRMAX - 8) / 2);
+  PGT_REQUIRE(halo >= 1 && 2 * halo <= EllwCfgB::WRMAX - 8, "pgt_ellw_plan: halo %d outside [1, %d]", (int)halo,
+              (EllwCfgB::WRMAX - 8) / 2);
   PGT_REQUIRE(max_row_len >= 0 && max_row_len <= ELLW_WMAX, "pgt_ellw_plan: rows of up to %d slots exceed the layout's %d",
               (int)max_row_len, ELLW_WMAX);
   const int W = max_row_len <= 8 ? 8 : (int)pgt_cdiv(max_row_len, 8) * 8;
-  int cap = ELLW_WRMAX - 2 * halo;
-  if (cap > ELLW_SLOTS / W) cap = ELLW_SLOTS / W;
+  const int cfg = g_ellw_cfg == 1 || g_ellw_cfg == 2 ? g_ellw_cfg : ((W <= 8 || halo > 40) ? 1 : 2);
+  *config = cfg;
+  const int wrmax = cfg == 1 ? EllwCfgA::WRMAX : EllwCfgB::WRMAX, slots_cap = cfg == 1 ? EllwCfgA::SLOTS : EllwCfgB::SLOTS;
+  const int per_cu = cfg == 1 ? 1 : 2;
+  int cap = wrmax - 2 * halo;
+  if (cap > slots_cap / W) cap = slots_cap / W;
   if (g_ellw_rows > 0 && cap > g_ellw_rows) cap = g_ellw_rows;
   cap &= ~3;
   PGT_REQUIRE(cap >= 4, "pgt_ellw_plan: no room for a tile");
-  // whole rounds of one workgroup per CU: the smallest number of rounds whose tiles fit, then the tile height that
-  // spreads the rows evenly over rounds * CUs tiles (a last, nearly empty round would cost a full tile time)
-  const int64_t cus = ellw_device_cus();
+  // whole rounds of the resident workgroups (one or two per CU): the smallest number of rounds whose tiles fit, then
+  // the tile height that spreads the rows evenly over rounds * slots tiles (a last, nearly empty round would cost a
+  // full tile time)
+  const int64_t cus = (int64_t)ellw_device_cus() * per_cu;
   const int64_t rounds = pgt_cdiv(n_rows, cus * cap);
   int64_t tr = pgt_cdiv(pgt_cdiv(n_rows, cus * rounds), 4) * 4;
   if (tr > cap) tr = cap;
@@ -658,8 +695,11 @@ extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, 
 static int ellw_check(const char* who, const pgt_ellw* op, int64_t n_rows) {
   PGT_REQUIRE(op != nullptr && op->slots != nullptr, "%s: null operator", who);
   PGT_REQUIRE(op->width >= 8 && op->width % 8 == 0 && op->width <= ELLW_WMAX, "%s: width %d", who, (int)op->width);
-  PGT_REQUIRE(op->halo >= 1 && op->tile_rows >= 1 && op->tile_rows + 2 * op->halo <= ELLW_WRMAX &&
-                  (int64_t)op->tile_rows * op->width <= ELLW_SLOTS,
+  PGT_REQUIRE(op->config == 1 || op->config == 2, "%s: config %d (1 = one workgroup per CU, 2 = two)", who, (int)op->config);
+  const int wrmax = op->config == 1 ? EllwCfgA::WRMAX : EllwCfgB::WRMAX;
+  const int slots_cap = op->config == 1 ? EllwCfgA::SLOTS : EllwCfgB::SLOTS;
+  PGT_REQUIRE(op->halo >= 1 && op->tile_rows >= 1 && op->tile_rows + 2 * op->halo <= wrmax &&
+                  (int64_t)op->tile_rows * op->width <= slots_cap,
               "%s: tile of %d rows x %d slots with halo %d does not fit the kernel (see pgt_ellw_plan)", who,
               (int)op->tile_rows, (int)op->width, (int)op->halo);
   PGT_REQUIRE(op->n_tiles == pgt_cdiv(n_rows, op->tile_rows), "%s: n_tiles %lld does not cover %lld rows", who,
@@ -710,19 +750,27 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
   vp.width(F); vp.operand(X, ldx); vp.operand(Y, ldy); vp.operand(T, ldt);
   const int64_t max_ld = ldx > ldy ? (ldx > ldt ? ldx : ldt) : (ldy > ldt ? ldy : ldt);
   // shapes the window kernel does not cover run the CSR row tiles (same sums, fmaf chain)
-  if (!g_ellw || F != 64 || vp.v != 4 || (n_rows + ELLW_WRMAX) * max_ld >= ((int64_t)1 << 31))
+  if (!g_ellw || F != 64 || vp.v != 4 || (n_rows + EllwCfgA::WRMAX) * max_ld >= ((int64_t)1 << 31))
     return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   const int flags = (g_tile_xcd ? 1 : 0) | (g_tile_nt ? 2 : 0);
-  dim3 grid((unsigned)op->n_tiles), block(ELLW_THREADS);
+  dim3 grid((unsigned)op->n_tiles);
+#define PGT_ELLW_GO(MODE_, CFG_, W8C_)                                                                                \
+  PGT_LAUNCH((spmm_ellw64_kernel<MODE_, CFG_, W8C_>), grid, dim3(CFG_::THREADS), stream, op->slots, op->vals, op->scale, \
+             rowptr, col, val, (int)n_rows, (int)op->tile_rows, (int)op->halo, (int)op->width, X, (int)ldx, Y, (int)ldy,  \
+             T, (int)ldt, alpha, beta, flags)
+#define PGT_ELLW_W(MODE_, CFG_)                                  \
+  do {                                                           \
+    if (op->width == 8) PGT_ELLW_GO(MODE_, CFG_, 1);             \
+    else if (op->width == 16) PGT_ELLW_GO(MODE_, CFG_, 2);       \
+    else PGT_ELLW_GO(MODE_, CFG_, 0);                            \
+  } while (0)
   if (op->scale != nullptr) {
-    PGT_LAUNCH((spmm_ellw64_kernel<0>), grid, block, stream, op->slots, (const float*)nullptr, op->scale, rowptr, col, val,
-               (int)n_rows, (int)op->tile_rows, (int)op->halo, (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha,
-               beta, flags);
+    if (op->config == 1) PGT_ELLW_W(0, EllwCfgA); else PGT_ELLW_W(0, EllwCfgB);
   } else {
-    PGT_LAUNCH((spmm_ellw64_kernel<1>), grid, block, stream, op->slots, op->vals, (const float*)nullptr, rowptr, col, val,
-               (int)n_rows, (int)op->tile_rows, (int)op->halo, (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha,
-               beta, flags);
+    if (op->config == 1) PGT_ELLW_W(1, EllwCfgA); else PGT_ELLW_W(1, EllwCfgB);
   }
+#undef PGT_ELLW_W
+#undef PGT_ELLW_GO
   return pgt_check_launch("pgt_spmm_ellw_f32");
 }
 

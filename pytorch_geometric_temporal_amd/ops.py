@@ -82,16 +82,16 @@ class Ellw:
     def __init__(self, csr, halo):
         lib = _lib.get_lib()
         dev = csr.rowptr.device
-        tr, w, nt = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0)
+        tr, w, cfg, nt = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0)
         lib.call("pgt_ellw_plan", csr.n_rows, int(halo), int(csr.max_len), ctypes.byref(tr), ctypes.byref(w),
-                 ctypes.byref(nt))
-        self.tile_rows, self.width, self.n_tiles, self.halo = tr.value, w.value, nt.value, int(halo)
+                 ctypes.byref(cfg), ctypes.byref(nt))
+        self.tile_rows, self.width, self.n_tiles, self.halo, self.config = tr.value, w.value, nt.value, int(halo), cfg.value
         total = self.n_tiles * self.tile_rows * self.width
         self.slots = torch.empty(total, dtype=torch.int16, device=dev)      # uint16 bit patterns
         vals = torch.empty(total, dtype=F32, device=dev)
         scale = torch.empty(csr.n_rows, dtype=F32, device=dev)
         info = torch.zeros(4, dtype=I32, device=dev)
-        geo = EllwStruct(None, None, None, self.tile_rows, self.halo, self.width, 0, self.n_tiles)
+        geo = EllwStruct(None, None, None, self.tile_rows, self.halo, self.width, self.config, self.n_tiles)
         lib.call("pgt_ellw_build", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, int(csr.nnz),
                  ctypes.byref(geo), ptr(self.slots), ptr(vals), ptr(scale), ptr(info), stream_of(lib, csr.rowptr))
         self.far, mismatch, overflow, _ = info.tolist()        # one host sync per new operator
@@ -101,8 +101,8 @@ class Ellw:
         self.scale, self.vals = (scale, None) if mismatch == 0 else (None, vals)
 
     def struct(self):
-        return EllwStruct(ptr(self.slots), ptr(self.vals), ptr(self.scale), self.tile_rows, self.halo, self.width, 0,
-                          self.n_tiles)
+        return EllwStruct(ptr(self.slots), ptr(self.vals), ptr(self.scale), self.tile_rows, self.halo, self.width,
+                          self.config, self.n_tiles)
 
 
 def ellw_of(csr):

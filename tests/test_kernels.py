@@ -542,15 +542,18 @@ def test_ellw_plan_fills_whole_rounds_of_the_cus(backend):
     lib = _lib.get_lib()
 
     def plan(n, halo, max_len):
-        tr, w, nt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
-        lib.call("pgt_ellw_plan", n, halo, max_len, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(nt))
+        tr, w, cfg, nt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        lib.call("pgt_ellw_plan", n, halo, max_len, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(cfg), ctypes.byref(nt))
+        assert cfg.value == (1 if (w.value == 8 or halo > 40) else 2)
         return tr.value, w.value, nt.value
 
     lib.tune("spmm_ellw_cus", 256)
     try:
         assert plan(200_000, 32, 8) == (392, 8, 511)
         assert plan(200_000, 96, 8) == (264, 8, 758)          # window of 456 rows: 264 + 2 * 96
-        assert plan(200_000, 32, 17) == (196, 24, 1021)       # 392 * 16 staged slots: at most 260 rows of 24 -> four rounds
+        assert plan(200_000, 32, 17) == (100, 24, 2000)       # two workgroups per CU, 176 * 16 staged slots: <= 116 rows of 24
+        assert plan(200_000, 32, 16) == (132, 16, 1516)       # 176 window-limited rows -> three rounds of 512
+        assert plan(200_000, 96, 16) == (264, 16, 758)        # wide halo: one workgroup per CU
         tr, w, nt = plan(50_000, 32, 8)
         assert (tr, w, nt) == (196, 8, 256)                   # one round
         tr, w, nt = plan(1_000_000, 32, 3)
@@ -1199,8 +1202,8 @@ try:
     @settings(max_examples=100, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
     @given(data=hst.data(), F_=hst.integers(1, 300), use_t=hst.booleans(), rows=hst.sampled_from([32, 64]),
            unroll=hst.sampled_from([4, 8]), halo=hst.sampled_from([0, 0, 32]), nt=hst.sampled_from([0, 2]),
-           cap=hst.sampled_from([0, 8, 20]), scaled=hst.booleans())
-    def test_fuzz_aggregation_entry_point(emu_backend, data, F_, use_t, rows, unroll, halo, nt, cap, scaled):
+           cap=hst.sampled_from([0, 8, 20]), scaled=hst.booleans(), cfg=hst.sampled_from([0, 1, 2]))
+    def test_fuzz_aggregation_entry_point(emu_backend, data, F_, use_t, rows, unroll, halo, nt, cap, scaled, cfg):
         """pgt_spmm_csr_f32 / pgt_spmm_ellw_f32 on random CSR operators (empty rows, heavy rows, duplicates) for every
         feature width up to 300, with and without the `alpha A X + beta T` epilogue, across tile shapes, store flavours
         and the ELLW layout (F = 64 only; per-slot and source-scaled coefficients, sources anywhere: most slots then take
@@ -1226,6 +1229,7 @@ try:
         alpha, beta = (2.0, -1.0) if use_t else (0.5, 0.0)
         lib.tune("spmm_tile_rows", rows); lib.tune("spmm_unroll", unroll); lib.tune("spmm_tile_nt", nt)
         lib.tune("spmm_ellw_rows", cap)
+        lib.tune("spmm_ellw_cfg", cfg)
         try:
             Y = torch.full((n, F_), float("nan")).to(dev)
             use_ellw = halo > 0 and F_ == 64 and nnz > 0
@@ -1237,6 +1241,7 @@ try:
         finally:
             lib.tune("spmm_tile_rows", 32); lib.tune("spmm_unroll", 8); lib.tune("spmm_tile_nt", 1)
             lib.tune("spmm_ellw_rows", 0)
+            lib.tune("spmm_ellw_cfg", 0)
         rows_i = torch.repeat_interleave(torch.arange(n), torch.tensor(deg))
         ref = torch.zeros(n, F_, dtype=torch.float64).index_add_(0, rows_i, X.double()[col.long()] * val.double()[:, None])
         ref = alpha * ref + (beta * T.double() if use_t else 0.0)

@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline figures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ns", action="store_true", help="skip the N=200k F=64 aggregation micro-benchmark")
+    ap.add_argument("--no-extra", action="store_true", help="skip the small-batch / other-config lines (bench_configs.py)")
     args = ap.parse_args()
 
     rank, local_rank, world = dp.init_from_env("nccl")   # "nccl" is RCCL on ROCm; no-op for a single process
@@ -329,6 +330,25 @@ def main():
         except Exception as e:                                 # an auxiliary line must never cost the bench line
             cpu["optimised_spmm"] = {"error": repr(e)}
 
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        import bench_configs as BCfg
+        cores = min(os.cpu_count() or 1, 32)
+        extra = {}
+        blocks = {
+            "small_batch": lambda: BCfg.small_batch(device, Model, masked_mae_loss, series, ei, ew, N_EDGES, SEQ, MEAN, STD, cores),
+            "config1_chickenpox": lambda: BCfg.chickenpox_epoch(device, cores),
+            "config3_pemsbay_a3tgcn2": lambda: BCfg.config3_pemsbay(device, cores),
+            "config4_50k_tgcn2": lambda: BCfg.config4_50k(device, cores),
+            "config5_covid_evolvegcnh": lambda: BCfg.covid_epoch(device, cores),
+        }
+        for name, fn in blocks.items():
+            try:
+                extra[name] = fn()
+            except Exception as e:                             # an auxiliary line must never cost the bench line
+                extra[name] = {"error": repr(e)}
+            torch.cuda.synchronize()
+
     if rank == 0:
         edges_per_step = world * args.batch * SEQ * N_EDGES
         line = {
@@ -346,6 +366,7 @@ def main():
             "epoch_time_s_23974_windows": 23974.0 / (world * args.batch) * dt / args.steps,
             "final_loss": final_loss,
             "roofline": roof, "kernels": kernels, "roofline_ns_spmm_N200k_F64": ns, "cpu_baseline": cpu,
+            "other_configs": extra,
         }
         print(json.dumps(line))
     if world > 1:

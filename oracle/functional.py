@@ -162,6 +162,39 @@ def a3tgcn(X, edge_index, edge_weight, H, p, improved=False, add_self_loops=True
     return acc
 
 
+# ------------------------------------------------------------------------------------------------ EvolveGCN-H
+
+def gru_step(x, h, p, prefix="recurrent_layer."):
+    """torch.nn.GRU(num_layers=1) on a length-1 sequence: one cell step with nn.GRU's gate order (r, z, n)."""
+    wi, wh = p[prefix + "weight_ih_l0"], p[prefix + "weight_hh_l0"]
+    bi, bh = p[prefix + "bias_ih_l0"], p[prefix + "bias_hh_l0"]
+    gi, gh = x @ wi.t() + bi, h @ wh.t() + bh
+    i_r, i_z, i_n = gi.chunk(3, dim=-1)
+    h_r, h_z, h_n = gh.chunk(3, dim=-1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return (1 - z) * n + z * h
+
+
+def evolvegcnh_step(X, edge_index, edge_weight, W, p, improved=False, add_self_loops=True):
+    """One snapshot of EvolveGCNH.forward (evolvegcnh.py:78-102): the node summary from TopKPooling(ratio =
+    in_channels / num_nodes) (:63, PyG: score = tanh(x.p / |p|), top-k rows scaled by their score) drives one GRU step
+    on the [F, F] weight matrix (:95-100), which then transforms X before the normalised propagate of GCNConv_Fixed_W
+    (evolvegcno.py:81-98).  W: the carried weight [F, F] (p["initial_weight"][0] at the first snapshot).
+    Returns (out [N, F], new W [F, F])."""
+    n, Fdim = X.shape
+    w = p["pooling_layer.select.weight"]
+    score = torch.tanh((X * w).sum(dim=-1) / w.norm(p=2, dim=-1))
+    k = int((float(Fdim / n) * torch.tensor(n).to(score.dtype)).ceil().to(torch.long))
+    perm = torch.sort(score.view(-1), descending=True).indices[:k]
+    x_tilde = X[perm] * score[perm].view(-1, 1)                       # [F, F]: batch of F "sequences", input size F
+    W_new = gru_step(x_tilde, W, p)
+    ei, nw = P.gcn_norm(edge_index, edge_weight, n, improved, add_self_loops, dtype=X.dtype)
+    out = propagate_add(ei, X @ W_new, nw.to(X.dtype))
+    return out, W_new
+
+
 # ------------------------------------------------------------------------------------------------ Chebyshev family
 
 def cheb_norm(edge_index, edge_weight, num_nodes, normalization, lambda_max, dtype):

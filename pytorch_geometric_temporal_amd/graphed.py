@@ -29,7 +29,8 @@ class GraphedStep:
         self.static_inputs = [t.clone() if isinstance(t, torch.Tensor) else t for t in example_inputs]
         dev = device
         if dev is None:
-            dev = next(t.device for t in self.static_inputs if isinstance(t, torch.Tensor))
+            dev = next((t.device for t in self.static_inputs if isinstance(t, torch.Tensor)),
+                       torch.device("cuda", torch.cuda.current_device()))
         self.device = dev
         if ops.KERNEL_TIMER is not None:
             raise RuntimeError("GraphedStep: per-launch timing (ops.KERNEL_TIMER) cannot be captured")

@@ -211,7 +211,7 @@ class _GraphCache:
     """Identity-keyed cache (data_ptr + in-place version counter), never torch.equal (no host sync per forward;
     the reference compares with torch.equal twice per BatchedDCRNN forward, dcrnn.py:446-447)."""
 
-    def __init__(self, capacity=16):
+    def __init__(self, capacity=128):      # a dynamic-graph signal holds one edge list per snapshot (England-Covid: 53)
         self.capacity = capacity
         self._d = OrderedDict()
 

@@ -200,3 +200,15 @@ def test_config5_evolvegcnh_on_the_vendored_covid_graphs(backend):
     """Every snapshot of dataset/england_covid.json (a new directed graph with weights up to 9.6e5 each day) through
     EvolveGCNH(129, 8), against the reference module fed by the reference loader (evolvegcnh.py:78-102)."""
     _run_covid(backend)
+
+
+def test_config5_oracle_reproduces_the_reference_fixture():
+    """oracle/functional.evolvegcnh_step (TopK summary -> GRU step on the weight -> GCN propagate) over the 53 vendored
+    covid snapshots against the reference module's outputs (the bench's CPU baseline for config 5 times this oracle)."""
+    g = load_golden("baseline_c5_evolvegcnh_covid")
+    p = g["param"]
+    W = p["initial_weight"][0]
+    with torch.no_grad():
+        for s, snap in enumerate(_covid_signal()):
+            out, W = F.evolvegcnh_step(snap.x, snap.edge_index, snap.edge_attr, W, p)
+            assert_close_with_nonfinite(out, g["out"]["out"][s], 2e-5, 2e-5, f"snapshot {s}")

@@ -35,6 +35,23 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measur
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, exact fp32
 
 N_NODES, N_EDGES, SEQ = 207, 1515, 12
+PROPAGATES_PER_CELL = 12     # the reference's op count per DCRNN cell step: 6 (K - 1) propagate calls at K = 3
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+
+def pmc_traffic(kind):
+    """HBM bytes per launch of the dominant kernel class from the rocprofv3 --pmc passes of THIS bench command
+    (scripts/pmc_bench.sh: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, averaged over the kernel's dispatches),
+    committed as profiles/r02_pmc_traffic.json — counters cannot be read from inside the process."""
+    try:
+        with open(PMC_FILE) as fh:
+            d = json.load(fh)
+        e = d["kernels"][kind]
+        return {"traffic": e["bytes_per_launch"], "traffic_source": f"profiles/r02_pmc_traffic.json ({d.get('command', '')}): "
+                f"FETCH_SIZE x2 {e['fetch_bytes_per_launch']:.3e} + WRITE_SIZE {e['write_bytes_per_launch']:.3e} B per launch "
+                f"over {e['dispatches']} dispatches"}
+    except Exception:
+        return {"traffic": None}
 MEAN, STD = 54.0, 19.5       # METR-LA-like speed statistics used to de-normalise inside the loss
 
 
@@ -48,11 +65,11 @@ def masked_mae_loss(y_pred, y_true):
 
 
 class Model(torch.nn.Module):
-    def __init__(self, hidden):
+    def __init__(self, hidden, dropin=False):
         super().__init__()
         self.rnn = BatchedDCRNN(2, hidden, K=3)
-        self.rnn.lazy_output = True     # [B, T, N, O] as a zero-copy view of the time-major states (same values)
-        self.head = None if hidden == 2 else Linear(hidden, 2)
+        self.rnn.lazy_output = not dropin   # [B, T, N, O] as a zero-copy view of the time-major states (same values)
+        self.head = None if hidden == 2 else (torch.nn.Linear(hidden, 2) if dropin else Linear(hidden, 2))
 
     def forward(self, X, ei, ew):
         h = self.rnn(X, ei, ew)
@@ -196,35 +213,19 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step (weak scaling)")
-    ap.add_argument("--hidden", type=int, default=64, help="DCRNN hidden width (2 = the reference example's model)")
-    ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline figures")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ns", action="store_true", help="skip the N=200k F=64 aggregation micro-benchmark")
-    ap.add_argument("--no-extra", action="store_true", help="skip the small-batch / other-config lines (bench_configs.py)")
-    args = ap.parse_args()
-
-    rank, local_rank, world = dp.init_from_env("nccl")   # "nccl" is RCCL on ROCm; no-op for a single process
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    lib = _lib.get_lib()
-    assert lib.target == "gfx950"
-
-    ei_np, ew_np = syn.sensor_graph(N_NODES, N_EDGES, seed=0, symmetric=False)
+def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup, profile_steps=0, dropin=False):
+    """Build the model on the `n_edges`-edge METR-LA-shaped graph, run one initialisation pass, `warmup` untimed steps,
+    then EXACTLY `steps` timed steps bracketed by barrier + synchronize; MAX over ranks.  `dropin`: the configuration a
+    user gets by swapping the import only (contiguous [B, T, N, O] output, torch.nn.Linear read-out) instead of the
+    tuned one (zero-copy output view consumed by this package's Linear).  Returns (seconds, final loss, step function)."""
+    ei_np, ew_np = syn.sensor_graph(N_NODES, n_edges, seed=0, symmetric=False)
     ei, ew = torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device)
-    series = torch.from_numpy(syn.traffic_series(34272, N_NODES, seed=1)).to(device)   # resident [T, N, 2]
     torch.manual_seed(0)
-    model = Model(args.hidden).to(device)
+    model = Model(hidden, dropin=dropin).to(device)
     flat = dp.FlatParameters(model.parameters())   # one gradient buffer, one parameter buffer
     opt = flat.optimizer(torch.optim.Adam, lr=1e-3)  # Adam over the flat parameter: one (fused) update per step
-    n_total = args.warmup + args.steps + args.profile_steps
-    batches = make_batches(series, args.batch, n_total, seed=1000 + rank, device=device)
+    n_total = warmup + steps + profile_steps
+    batches = make_batches(series, batch, n_total, seed=1000 + rank, device=device)
 
     def step(i):
         xi, yi = batches[i]
@@ -233,15 +234,10 @@ def main():
         loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
         flat.zero()
         loss.backward()
-        flat.all_reduce_mean(world)
+        work = flat.all_reduce_mean(world, async_op=True)   # RCCL over xGMI; the wait sits right before the update
+        flat.finish(work, world)
         opt.step()
         return loss
-
-    # north-star micro-benchmark before the training loop (PGT_NS_FIRST=0: after it — an A/B of the GPU's thermal /
-    # power state: the training step is MFMA-heavy and leaves the part hot)
-    ns, ns_first = None, os.environ.get("PGT_NS_FIRST", "1") != "0"
-    if rank == 0 and world == 1 and not args.no_ns and ns_first:
-        ns = spmm_roofline_ns(device)
 
     # one initialisation pass (not a warmup step): first-use work that does not belong to any step - graph preparation
     # (cached by tensor identity afterwards), code-object load of every kernel, growth of torch's caching allocator to the
@@ -252,7 +248,7 @@ def main():
     opt = flat.optimizer(torch.optim.Adam, lr=1e-3)
     del snapshot
     trace = os.environ.get("PGT_BENCH_STEP_TIMES") == "1"     # diagnostic: synchronised wall time of every warmup step
-    for i in range(args.warmup):
+    for i in range(warmup):
         if trace:
             torch.cuda.synchronize()
             ts = time.perf_counter()
@@ -260,21 +256,64 @@ def main():
         if trace:
             torch.cuda.synchronize()
             print(f"[bench] warmup step {i}: {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        loss = step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    final_loss = float(loss.detach())
+    dt, loss = dp.timed_steps(step, warmup, steps, device)   # barrier + synchronize on both sides, MAX over ranks
+    return dt, float(loss.detach()), step, (ei, ew)
+
+
+def pin_host_threads(local_rank, world):
+    """8 ranks x ~250 ctypes launches per step share one host: give every rank its own slice of the cores and keep
+    the intra-op pools small (the step is launch-issue bound on the host side, not compute bound)."""
+    ncpu = os.cpu_count() or 1
+    per = max(1, ncpu // max(world, 1))
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(per, 8)))
+    torch.set_num_threads(min(per, 8))
+    if world > 1 and hasattr(os, "sched_setaffinity"):
+        try:
+            avail = sorted(os.sched_getaffinity(0))
+            per = max(1, len(avail) // world)
+            os.sched_setaffinity(0, set(avail[local_rank * per:(local_rank + 1) * per]) or set(avail))
+        except OSError:
+            pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: total windows per step, split evenly over the ranks (overrides --batch)")
+    ap.add_argument("--edges", type=int, default=N_EDGES, help="edges of the METR-LA-shaped graph (1722 = the reference's data)")
+    ap.add_argument("--hidden", type=int, default=64, help="DCRNN hidden width (2 = the reference example's model)")
+    ap.add_argument("--profile-steps", type=int, default=2, help="extra instrumented steps for the roofline figures")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ns", action="store_true", help="skip the N=200k F=64 aggregation micro-benchmark")
+    ap.add_argument("--no-extra", action="store_true", help="skip the drop-in / E=1722 / small-batch / other-config lines")
+    args = ap.parse_args()
+
+    rank, local_rank, world = dp.init_from_env("nccl")   # "nccl" is RCCL on ROCm; no-op for a single process
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    pin_host_threads(local_rank, world)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    lib = _lib.get_lib()
+    assert lib.target == "gfx950"
+    scaling = "weak"
+    if args.global_batch > 0:
+        assert args.global_batch % world == 0, "--global-batch must be a multiple of the number of ranks"
+        args.batch, scaling = args.global_batch // world, "strong"
+
+    series = torch.from_numpy(syn.traffic_series(34272, N_NODES, seed=1)).to(device)   # resident [T, N, 2]
+
+    # north-star micro-benchmark (rank 0 of a single-GPU run only)
+    ns = None
+    if rank == 0 and world == 1 and not args.no_ns:
+        ns = spmm_roofline_ns(device)
+
+    dt, final_loss, step, (ei, ew) = train_run(device, rank, world, series, args.edges, args.batch, args.hidden,
+                                               args.steps, args.warmup, args.profile_steps)
+    n_total = args.warmup + args.steps + args.profile_steps
 
     # ---- live roofline of the path's kernels: extra instrumented steps, HIP events on the launch stream
     roof, kernels = None, None
@@ -308,6 +347,7 @@ def main():
                     "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None}
         roof["avg_us_per_launch"] = k["avg_us"]
         roof["launches_per_step"] = k["launches"] / args.profile_steps
+        roof.update(pmc_traffic(dom))
         for kk, v in kernels.items():
             if kk in ("spmm", "stack"):
                 v["achieved_GBs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
@@ -319,9 +359,8 @@ def main():
                 v["by_shape"] = [{"shape": r["tag"][1:], "launches": r["launches"], "avg_us": r["avg_us"],
                                   "TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12}
                                  for r in shapes if r["tag"][0] == kk]
+    del step
 
-    if rank == 0 and world == 1 and not args.no_ns and not ns_first:
-        ns = spmm_roofline_ns(device)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.hidden)
@@ -330,13 +369,31 @@ def main():
         except Exception as e:                                 # an auxiliary line must never cost the bench line
             cpu["optimised_spmm"] = {"error": repr(e)}
 
-    extra = None
+    def throughput(d, edges, batch, steps):
+        return {"value": world * batch * SEQ * edges * steps / d, "ms_per_step": 1e3 * d / steps,
+                "edge_messages_per_s": world * batch * SEQ * edges * steps / d * PROPAGATES_PER_CELL}
+
+    variants, extra = None, None
+    if world == 1 and not args.no_extra:
+        # the same step (a) as a user gets it by swapping the import only, (b) on the 1 722-edge graph of the reference's
+        # data; short runs, same bracketing
+        variants = {}
+        torch.cuda.empty_cache()
+        d2, _, s2, _ = train_run(device, rank, world, series, args.edges, args.batch, args.hidden, 5, 2, dropin=True)
+        del s2
+        variants["dropin_default"] = dict(throughput(d2, args.edges, args.batch, 5),
+                                          what="lazy_output=False (contiguous [B,T,N,O] output) + torch.nn.Linear read-out")
+        torch.cuda.empty_cache()
+        d3, _, s3, _ = train_run(device, rank, world, series, 1722, args.batch, args.hidden, 5, 2)
+        del s3
+        variants["edges_1722"] = dict(throughput(d3, 1722, args.batch, 5), what="1 722-edge graph (the reference's METR-LA data)")
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extra:
         import bench_configs as BCfg
         cores = min(os.cpu_count() or 1, 32)
         extra = {}
         blocks = {
-            "small_batch": lambda: BCfg.small_batch(device, Model, masked_mae_loss, series, ei, ew, N_EDGES, SEQ, MEAN, STD, cores),
+            "small_batch": lambda: BCfg.small_batch(device, Model, masked_mae_loss, series, ei, ew, args.edges, SEQ, MEAN, STD, cores),
             "config1_chickenpox": lambda: BCfg.chickenpox_epoch(device, cores),
             "config3_pemsbay_a3tgcn2": lambda: BCfg.config3_pemsbay(device, cores),
             "config4_50k_tgcn2": lambda: BCfg.config4_50k(device, cores),
@@ -350,23 +407,25 @@ def main():
             torch.cuda.synchronize()
 
     if rank == 0:
-        edges_per_step = world * args.batch * SEQ * N_EDGES
+        head = throughput(dt, args.edges, args.batch, args.steps)
         line = {
             "metric": "snapshot-edges aggregated/sec",
-            "value": edges_per_step * args.steps / dt,
+            "value": head["value"],
             "unit": "snapshot-edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"METR-LA-shaped synthetic (207 nodes, 1515 edges, 12-step) BatchedDCRNN(2,{args.hidden},K=3)"
+            "config": {"workload": f"METR-LA-shaped synthetic (207 nodes, {args.edges} edges, 12-step) BatchedDCRNN(2,{args.hidden},K=3)"
                                    + ("" if args.hidden == 2 else "+Linear") + " training step (fwd+bwd+allreduce+Adam)",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "seq_len": SEQ,
-                       "parallelism": f"dp{world}", "hidden": args.hidden, "K": 3, "init_passes": 1},
+                       "parallelism": f"dp{world}", "hidden": args.hidden, "K": 3, "init_passes": 1,
+                       "output_layout": "lazy_output=True (zero-copy [B,T,N,O] view) + package Linear; the drop-in default is in variants.dropin_default"},
+            "edge_messages_per_s": head["edge_messages_per_s"],
             "epoch_time_s_23974_windows": 23974.0 / (world * args.batch) * dt / args.steps,
             "final_loss": final_loss,
             "roofline": roof, "kernels": kernels, "roofline_ns_spmm_N200k_F64": ns, "cpu_baseline": cpu,
-            "other_configs": extra,
+            "variants": variants, "other_configs": extra,
         }
         print(json.dumps(line))
     if world > 1:

@@ -136,3 +136,33 @@ def reduce_scalars(values, dst=0):
             return d.cpu()
         dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
     return t
+
+
+def _sync(device):
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def timed_steps(step, first, count, device=None):
+    """The timing protocol of bench.py: barrier + device synchronize, EXACTLY `count` calls step(first), ...,
+    step(first + count - 1), barrier + synchronize; returns (the MAX over ranks of the elapsed seconds, the last step's
+    return value).  Every rank gets the same number — the job is as slow as its slowest rank."""
+    import time
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1:
+        dist.barrier()
+    _sync(device)
+    t0 = time.perf_counter()
+    out = None
+    for i in range(first, first + count):
+        out = step(i)
+    if world > 1:
+        dist.barrier()
+    _sync(device)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        on_gpu = device is not None and torch.device(device).type == "cuda"
+        t = torch.tensor([dt], dtype=torch.float64, device=device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out

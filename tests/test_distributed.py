@@ -43,6 +43,32 @@ def test_two_rank_step_equals_single_process_step(tmp_path, model):
     assert one["losses"] == pytest.approx(two["losses"], rel=1e-5, abs=1e-6)
 
 
+@pytest.mark.parametrize("world,total", [(2, 10), (4, 10), (8, 21)])
+def test_bench_protocol_under_gloo_with_uneven_shards(tmp_path, world, total):
+    """bench.py's multi-rank protocol (dp.timed_steps + async flat all-reduce + DistributedSampler-style padding) with
+    world sizes 2 / 4 / 8 and sample counts the ranks do not divide: every rank runs exactly the same steps, reports the
+    same (MAX-reduced) time — which contains the slow rank's sleeps — and ends with identical parameters."""
+    port = _free_port()
+    out = str(tmp_path / "proto")
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_protocol_worker.py"), out, str(total)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    per = -(-total // world)
+    for r in res:
+        assert r["world"] == world and r["calls"] == [2, 3, 4, 5, 6]
+        assert r["shard"] == per                                   # padded by wrap-around to equal shard sizes
+        assert r["dt"] == res[0]["dt"] and r["dt"] >= 3 * 0.02     # one number for the job: the slowest rank's
+        assert torch.equal(r["params"], res[0]["params"])
+    assert res[0]["sums"][1] == float(world)                       # reduce_scalars: SUM onto rank 0
+
+
 def test_shard_indices_follow_distributed_sampler():
     from torch.utils.data.distributed import DistributedSampler
     ds = list(range(23))

@@ -27,6 +27,7 @@
  *   pgt_gemm_f32          the dense feature transforms: dcrnn.py:81-83,88-92,101-105 (torch.matmul on weight[d][k]);
  *                         PyG Linear in GCNConv/ChebConv; temporalgcn.py:84,90,96 (linear_{z,r,h})
  *   pgt_gemm_tn_acc_f32   autograd of the above w.r.t. the weights (torch autograd in the reference)
+ *   pgt_window_gather_f32 signal/index_dataset.py:32-57 (the index-batch windows of a resident series)
  *   pgt_gru_*             the GRU gate chains: dcrnn.py:172-192,406-427; temporalgcn.py:82-102
  *   pgt_lstm_gates*       the LSTM gate chains: gconv_lstm.py:138-172 (peepholes), gc_lstm.py:138-169
  */
@@ -302,6 +303,14 @@ int pgt_axpby2d_f32(float* dst, int64_t ldd, const float* x, int64_t ldx, float 
                     float b, int64_t M, int64_t W, pgt_stream_t stream);
 /* [D0][D1][W] -> [D1][D0][W] blocked transpose of W-float records (batch-major <-> node-major). */
 int pgt_swap01_f32(float* dst, const float* src, int64_t D0, int64_t D1, int64_t W, pgt_stream_t stream);
+
+/* Index-batch window gather (signal/index_dataset.py:32-57; examples/indexBatching: "GPU-index-batching"): for every
+ * sample b, X[b] = data[idx[b] : idx[b] + h], Y[b] = data[idx[b] + h : idx[b] + 2 h] from the resident series
+ * data [T_total, W] (W = nodes * features), both windows of all B samples in one launch.  time_major != 0 writes
+ * [h][B][W] instead of [B][h][W].  idx: int64 [B] on the device; the caller guarantees 0 <= idx[b] <= T_total - 2 h
+ * (out-of-range rows are clamped, never read outside the series). */
+int pgt_window_gather_f32(const float* data, int64_t T_total, int64_t W, const int64_t* idx, int64_t B, int64_t h,
+                          float* X, float* Y, int time_major, pgt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -272,6 +272,30 @@ __global__ __launch_bounds__(256) void swap01_kernel(float* __restrict__ dst, co
   pgt_stv<V>(dst + (d1 * D0 + d0) * W + w, v);
 }
 
+
+// Index-batch window gather (signal/index_dataset.py:32-57: x = data[idx : idx + h], y = data[idx + h : idx + 2 h] for
+// every sample of the batch) from the HBM-resident series in ONE launch: both windows of all B samples, optionally
+// written time-major ([h][B][W] instead of [B][h][W]) — the row order the recurrent layers consume, which saves the
+// [B, T] -> [T, B] transposition that would follow.
+template <int V>
+__global__ __launch_bounds__(256) void window_gather_kernel(const float* __restrict__ data, const int64_t* __restrict__ idx,
+                                                             int64_t B, int64_t h, int64_t W, int64_t T_total,
+                                                             float* __restrict__ X, float* __restrict__ Y, int time_major) {
+  const int64_t WV = W / V;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * B * h * WV) return;
+  const int64_t w = (e % WV) * V;
+  const int64_t t = (e / WV) % h;
+  const int64_t b = (e / (WV * h)) % B;
+  const int which = (int)(e / (WV * h * B));         // 0: the input window, 1: the target window
+  int64_t row = idx[b] + t + (which ? h : 0);
+  row = row < 0 ? 0 : (row < T_total ? row : T_total - 1);   // the host validates the indices; never read outside
+  float v[V];
+  pgt_ldv<V>(data + row * W + w, v);
+  float* out = which ? Y : X;
+  pgt_stv<V>(out + (time_major ? (t * B + b) : (b * h + t)) * W + w, v);
+}
+
 inline int grid_for(int64_t total, const char* what, dim3* grid) {
   const int64_t nb = pgt_cdiv(total, 256);
   if (nb >= ((int64_t)1 << 31)) {
@@ -440,4 +464,20 @@ extern "C" int pgt_swap01_f32(float* dst, const float* src, int64_t D0, int64_t 
   if (int e = grid_for(D0 * D1 * (W / pick.v), "pgt_swap01_f32", &grid)) return e;
   PGT_VDISPATCH(pick.v, swap01_kernel, grid, block, stream, dst, src, D0, D1, W);
   return pgt_check_launch("pgt_swap01_f32");
+}
+
+extern "C" int pgt_window_gather_f32(const float* data, int64_t T_total, int64_t W, const int64_t* idx, int64_t B,
+                                     int64_t h, float* X, float* Y, int time_major, pgt_stream_t stream) {
+  PGT_REQUIRE(T_total >= 0 && W >= 0 && B >= 0 && h >= 0, "pgt_window_gather_f32: negative size");
+  if (B == 0 || h == 0 || W == 0) return PGT_OK;
+  PGT_REQUIRE(data && idx && X && Y, "pgt_window_gather_f32: null pointer");
+  PGT_REQUIRE(T_total >= 2 * h, "pgt_window_gather_f32: the series (%lld steps) is shorter than two windows of %lld",
+              (long long)T_total, (long long)h);
+  PgtVecPick pick;
+  pick.width(W);
+  pick.operand(data, W); pick.operand(X, W); pick.operand(Y, W);
+  dim3 grid, block(256);
+  if (int e = grid_for(2 * B * h * (W / pick.v), "pgt_window_gather_f32", &grid)) return e;
+  PGT_VDISPATCH(pick.v, window_gather_kernel, grid, block, stream, data, idx, B, h, W, T_total, X, Y, time_major ? 1 : 0);
+  return pgt_check_launch("pgt_window_gather_f32");
 }

@@ -30,7 +30,7 @@ from ..signal import DynamicGraphTemporalSignal, IndexDataset, StaticGraphTempor
 from .cache import TemporalGraphCache, csr_by_destination, load_cache, save_cache
 
 __all__ = ["ChickenpoxDatasetLoader", "EnglandCovidDatasetLoader", "PedalMeDatasetLoader", "MontevideoBusDatasetLoader",
-           "METRLADatasetLoader", "PemsBayDatasetLoader",
+           "METRLADatasetLoader", "PemsBayDatasetLoader", "PemsDatasetLoader",
            "TemporalGraphCache", "load_cache", "save_cache", "csr_by_destination", "dense_to_sparse_numpy"]
 
 _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -377,3 +377,75 @@ class PemsBayDatasetLoader(_SensorNetworkLoader):
     `pems_adj_mat.npy`, `pems_node_values.npy` (or `pems_bay.pgtc`) in `raw_data_dir`."""
     _ADJ, _VALUES, _CACHE, _NAME = "pems_adj_mat.npy", "pems_node_values.npy", "pems_bay.pgtc", "PEMS-BAY"
     _TARGET_FEATURE_0_ONLY = False
+
+
+class PemsDatasetLoader(object):
+    """The California-wide PeMS speed dataset of the DCRNN-partitioning paper (reference: dataset/pems.py:14-179):
+    11 160 sensors; `pems_cali_adj_mat.pkl` (a pickled (ids, id->index, dense adjacency) triple) and
+    `pems_cali_speed.h5` (a pandas frame [T, N] with a DatetimeIndex) in `raw_data_dir`.  Index batching only, as in
+    the reference.  Channel 0 = speed, channel 1 = time of day; z-scored over (time, node) per channel.
+
+    Never downloads.  The first construction from the raw files needs pandas + PyTables for the .h5 (as the reference
+    does); `write_cache()` then persists `pems_cali.pgtc` (time-major series, edge list, CSR by destination,
+    statistics), which later constructions memory-map without either dependency."""
+
+    _ADJ, _VALUES, _CACHE, _NAME = "pems_cali_adj_mat.pkl", "pems_cali_speed.h5", "pems_cali.pgtc", "PEMS-CALI"
+
+    def __init__(self, raw_data_dir=os.path.join(os.getcwd(), "data"), index=False):
+        self.index = index
+        self.raw_data_dir = raw_data_dir
+        self.IndexDataset = IndexDataset
+        self._cache = None
+        self._load()
+
+    def _load(self):
+        cpath = os.path.join(self.raw_data_dir, self._CACHE)
+        if os.path.isfile(cpath):
+            self._cache = load_cache(cpath)
+            return
+        apath, vpath = os.path.join(self.raw_data_dir, self._ADJ), os.path.join(self.raw_data_dir, self._VALUES)
+        if not (os.path.isfile(apath) and os.path.isfile(vpath)):
+            raise FileNotFoundError(
+                f"{self._NAME}: neither {cpath} nor {apath} + {vpath} exist.  This package never downloads: put the "
+                f"reference's two files into raw_data_dir ({self.raw_data_dir}) yourself.")
+        import pickle
+        import pandas as pd
+        with open(apath, "rb") as f:
+            _, _, adj_mx = pickle.load(f)                                       # pems.py:103-104
+        df = pd.read_hdf(vpath, "df")                                           # pems.py:108
+        values = df.values
+        num_nodes = values.shape[1]
+        time_ind = (df.index.values - df.index.values.astype("datetime64[D]")) / np.timedelta64(1, "D")
+        time_in_day = np.tile(time_ind, [1, num_nodes, 1]).transpose((2, 1, 0))
+        data = np.concatenate([np.expand_dims(values, axis=-1), time_in_day], axis=-1)     # [T, N, 2], pems.py:119-139
+        means = np.mean(data, axis=(0, 1))
+        stds = np.std(data, axis=(0, 1))
+        data = (data - means) / stds
+        ei, ew = dense_to_sparse_numpy(np.asarray(adj_mx))
+        rp, col, val = csr_by_destination(ei, ew, np.asarray(adj_mx).shape[0])
+        arrays = {"series": np.ascontiguousarray(data), "edge_index": ei, "edge_weight": ew, "csr_rowptr": rp,
+                  "csr_col": col, "csr_val": val, "means": means, "stds": stds}
+        self._cache = TemporalGraphCache(self._NAME, {"nodes": int(num_nodes), "steps": int(data.shape[0])}, arrays, None)
+
+    def write_cache(self, path=None):
+        path = path or os.path.join(self.raw_data_dir, self._CACHE)
+        return save_cache(path, self._cache.name, {k: np.asarray(v) for k, v in self._cache.arrays.items()},
+                          self._cache.meta)
+
+    def get_index_dataset(self, lags: int = 12, batch_size: int = 64, shuffle: bool = False, allGPU: int = -1,
+                          ratio: Tuple[float, float, float] = (0.7, 0.1, 0.2), world_size: int = -1,
+                          ddp_rank: int = -1, dask_batching: bool = False):
+        """(train, val, test DataLoaders, edges [2, E], edge_weights [E], means, stds) exactly as pems.py:71-179
+        returns them: float64 windows on the CPU path, float32 device-resident windows when `allGPU` names a GPU."""
+        edges = torch.from_numpy(np.array(self._cache.edge_index, dtype=np.int64))
+        edge_weights = torch.from_numpy(np.array(self._cache.edge_weight))
+        data = np.array(self._cache.series)
+        means = torch.tensor(np.asarray(self._cache.means), dtype=torch.float)
+        stds = torch.tensor(np.asarray(self._cache.stds), dtype=torch.float)
+        if allGPU != -1:
+            data = torch.from_numpy(data).to(f"cuda:{allGPU}", dtype=torch.float)
+            means, stds = means.to(data.device).view(1, 1, -1), stds.to(data.device).view(1, 1, -1)
+        parts = _split_indices(data.shape[0], lags, ratio)
+        tr, va, te = _loaders(parts, data, lags, batch_size, shuffle, gpu=allGPU != -1, lazy=dask_batching,
+                              world_size=world_size, ddp_rank=ddp_rank)
+        return tr, va, te, edges, edge_weights, means, stds

@@ -506,6 +506,25 @@ def swap01(src, D0, D1, W):
     return dst
 
 
+def window_gather(data, starts, horizon, time_major=False):
+    """(X, Y) index-batch windows of a resident series `data` [T, ...] at the int64 start indices `starts` [B]
+    (pgt_window_gather_f32): X[b] = data[s_b : s_b + h], Y[b] = data[s_b + h : s_b + 2 h]; shapes [B, h, ...] or, with
+    time_major, [h, B, ...]."""
+    lib = _lib.get_lib()
+    check_tensor(lib, data, "data")
+    check_tensor(lib, starts, "starts", torch.int64)
+    data = data.contiguous()
+    starts = starts.contiguous()
+    T_total, B, h = data.size(0), starts.numel(), int(horizon)
+    W = data[0].numel() if T_total else 0
+    lead = (h, B) if time_major else (B, h)
+    X = torch.empty(*lead, *data.shape[1:], dtype=F32, device=data.device)
+    Y = torch.empty_like(X)
+    lib.call("pgt_window_gather_f32", ptr(data), T_total, W, ptr(starts), B, h, ptr(X), ptr(Y), int(bool(time_major)),
+             stream_of(lib, data))
+    return X, Y
+
+
 class Swap01(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, D0, D1, W):

@@ -260,6 +260,13 @@ class IndexDataset(torch.utils.data.Dataset):
         data = self.data if isinstance(self.data, torch.Tensor) else torch.from_numpy(np.asarray(self.data))
         if device is not None:
             data = data.to(device)
-        idx = torch.as_tensor(np.asarray(self.indices)[np.asarray(batch_indices)], device=data.device).long()
+        if isinstance(batch_indices, torch.Tensor) and isinstance(self.indices, torch.Tensor):
+            idx = self.indices.to(data.device)[batch_indices.to(data.device)].long()       # no host round trip
+        else:
+            idx = torch.as_tensor(np.asarray(self.indices)[np.asarray(batch_indices)], device=data.device).long()
+        if data.is_cuda and data.dtype == torch.float32:
+            # resident series: both windows of the whole batch in ONE launch (pgt_window_gather_f32)
+            from .. import ops
+            return ops.window_gather(data, idx, self.horizon)
         ar = torch.arange(self.horizon, device=data.device)
         return data[idx[:, None] + ar[None, :]], data[idx[:, None] + self.horizon + ar[None, :]]

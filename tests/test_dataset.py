@@ -273,3 +273,62 @@ def test_fuzz_cache_round_trip(tmp_path):
         p = tmp_path / "junk.pgtc"
         p.write_bytes(b"0123456789abcdef0123")
         load_cache(str(p))
+
+
+def test_pems_california_loader_pkl_h5_and_cache(tmp_path, monkeypatch):
+    """PemsDatasetLoader (dataset/pems.py:14-179): pickled adjacency + pandas .h5 frame -> z-scored [T, N, 2] series
+    (speed, time of day), index-batch loaders; value for value against the reference loader on the same files when the
+    reference is mounted.  PyTables is not installed here, so `pandas.read_hdf` is served from a pickled frame of the
+    same content (the loaders call nothing else on the .h5)."""
+    import pickle
+    import pandas as pd
+    from pytorch_geometric_temporal_amd.dataset import PemsDatasetLoader
+    d = str(tmp_path)
+    with pytest.raises(FileNotFoundError, match="never downloads"):
+        PemsDatasetLoader(raw_data_dir=d, index=True)
+    rng = np.random.default_rng(0)
+    n, steps = 7, 80
+    A = rng.random((n, n)).astype(np.float32)
+    A[A < 0.55] = 0.0
+    np.fill_diagonal(A, 1.0)
+    with open(os.path.join(d, "pems_cali_adj_mat.pkl"), "wb") as f:
+        pickle.dump(([str(i) for i in range(n)], {str(i): i for i in range(n)}, A), f)
+    frame = pd.DataFrame(55 + 9 * rng.standard_normal((steps, n)),
+                         index=pd.date_range("2018-01-01 00:00", periods=steps, freq="5min"))
+    frame.to_pickle(os.path.join(d, "pems_cali_speed.h5"))
+    monkeypatch.setattr(pd, "read_hdf", lambda path, key=None, **kw: pd.read_pickle(path))
+    L = PemsDatasetLoader(raw_data_dir=d, index=True)
+    tr, va, te, edges, w, means, stds = L.get_index_dataset(lags=4, batch_size=6, shuffle=False)
+    ei, ew = dense_to_sparse_numpy(A)
+    assert torch.equal(edges, torch.from_numpy(ei)) and torch.equal(w, torch.from_numpy(ew))
+    nwin = steps - 7
+    assert (len(tr.dataset), len(va.dataset), len(te.dataset)) == (round(nwin * 0.7), nwin - round(nwin * 0.7) - round(nwin * 0.2),
+                                                                  round(nwin * 0.2))
+    x, y = next(iter(tr))
+    assert x.shape == (6, 4, n, 2) and y.shape == (6, 4, n, 2) and x.dtype == torch.float64
+    tod = (np.arange(steps) * 5 / 1440.0) % 1.0
+    raw = np.stack([frame.values, np.tile(tod[:, None], (1, n))], axis=-1)
+    assert np.allclose(means.numpy(), raw.mean(axis=(0, 1)), rtol=1e-6)
+    assert np.allclose(x[2].numpy(), ((raw - raw.mean(axis=(0, 1))) / raw.std(axis=(0, 1)))[2:6], rtol=1e-12, atol=1e-12)
+    if ref_import.reference_available():
+        import sys
+        import types
+        if "dask" not in sys.modules:       # the reference's index_dataset.py imports dask.array at module level (unused here)
+            monkeypatch.setitem(sys.modules, "dask", types.ModuleType("dask"))
+            monkeypatch.setitem(sys.modules, "dask.array", types.ModuleType("dask.array"))
+        ref = ref_import.load_dataset("pems").PemsDatasetLoader(raw_data_dir=d, index=True)   # files exist: no download
+        rtr, rva, rte, redges, rw, rmeans, rstds = ref.get_index_dataset(lags=4, batch_size=6, shuffle=False)
+        assert torch.equal(redges, edges) and torch.equal(rw, w)
+        assert torch.equal(rmeans, means) and torch.equal(rstds, stds)
+        for a, b in ((rtr, tr), (rva, va), (rte, te)):
+            assert len(a.dataset) == len(b.dataset)
+            for (xa, ya), (xb, yb) in zip(a, b):
+                assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    # persisted cache: the raw files (and pandas / PyTables) are no longer needed
+    L.write_cache()
+    os.remove(os.path.join(d, "pems_cali_adj_mat.pkl"))
+    os.remove(os.path.join(d, "pems_cali_speed.h5"))
+    monkeypatch.setattr(pd, "read_hdf", lambda *a, **k: (_ for _ in ()).throw(AssertionError("cache must not read the .h5")))
+    L2 = PemsDatasetLoader(raw_data_dir=d, index=True)
+    x2, y2 = next(iter(L2.get_index_dataset(lags=4, batch_size=6)[0]))
+    assert torch.equal(x2, x) and torch.equal(y2, y)

@@ -2,6 +2,7 @@
 StaticGraphTemporalSignal on the vendored Chickenpox file; behaviour pinned by the reference's iterator contract
 (test/dataset_test.py:304-312, test/index_test.py:93-115)."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden
@@ -100,3 +101,57 @@ def test_index_dataset_equals_snapshot_windows():
     loader = torch.utils.data.DataLoader(ds, batch_size=8, shuffle=False)
     xb, yb = next(iter(loader))
     assert xb.shape == (8, 4, 5, 2) and torch.equal(xb[3], x)
+
+
+@pytest.mark.parametrize("time_major", [False, True])
+@pytest.mark.parametrize("shape", [(40, 5, 2), (33, 7, 1), (64, 207, 2)])
+def test_window_gather_kernel_equals_the_reference_windows(backend, shape, time_major):
+    """pgt_window_gather_f32: both windows of a whole index batch in one launch == IndexDataset.__getitem__ per sample
+    (signal/index_dataset.py:32-57), batch-major and time-major."""
+    from pytorch_geometric_temporal_amd import ops
+    T, h = shape[0], 4
+    data = torch.randn(*shape, generator=torch.Generator().manual_seed(T))
+    starts = torch.tensor([0, 3, T - 2 * h, 5, 3], dtype=torch.int64)
+    X, Y = ops.window_gather(backend.t(data), backend.t(starts), h, time_major=time_major)
+    ds = IndexDataset(starts.numpy(), data.numpy(), horizon=h)
+    for b in range(starts.numel()):
+        x, y = ds[b]
+        xs, ys = (X[:, b], Y[:, b]) if time_major else (X[b], Y[b])
+        assert torch.equal(xs.cpu(), x) and torch.equal(ys.cpu(), y)
+
+
+@pytest.mark.gpu
+def test_resident_signal_and_index_batches_on_the_gpu():
+    """§8 f2 on the device: `.to(cuda)` uploads the series once and every snapshot is a view of that upload with
+    memoised edge tensors (the graph cache then hits by identity); IndexDataset.gather on the resident series runs
+    the one-launch window gather and equals the CPU dataset sample for sample."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4)
+    ei = rng.integers(0, 30, size=(2, 120))
+    feats = [rng.random((30, 3)).astype(np.float32) for _ in range(20)]
+    targs = [rng.random(30).astype(np.float32) for _ in range(20)]
+    s = StaticGraphTemporalSignal(ei, np.ones(120), feats, targs).to(dev)
+    a, b = s[1], s[7]
+    assert a.x.is_cuda and a.x.untyped_storage().data_ptr() == b.x.untyped_storage().data_ptr()
+    assert a.edge_index is b.edge_index and a.edge_attr is b.edge_attr
+    assert torch.equal(b.x.cpu(), torch.from_numpy(feats[7])) and torch.equal(b.y.cpu(), torch.from_numpy(targs[7]))
+    from pytorch_geometric_temporal_amd.nn.recurrent import DCRNN
+    from pytorch_geometric_temporal_amd import ops
+    m = DCRNN(3, 4, 2).to(dev)
+    ops.GRAPH_CACHE.clear()
+    with torch.no_grad():
+        for snap in s:
+            m(snap.x, snap.edge_index, snap.edge_attr)
+    assert len(ops.GRAPH_CACHE._d) == 1                      # one prepared graph for the whole signal
+    data = torch.randn(500, 207, 2)
+    idx = np.arange(0, 500 - 24)
+    cpu_ds = IndexDataset(idx, data.numpy(), horizon=12)
+    gpu_ds = IndexDataset(idx, data.to(dev), horizon=12, gpu=True)
+    batch = [0, 17, 475, 230, 17]
+    X, Y = gpu_ds.gather(batch)
+    assert X.is_cuda and X.shape == (5, 12, 207, 2)
+    for j, i in enumerate(batch):
+        x, y = cpu_ds[i]
+        assert torch.equal(X[j].cpu(), x) and torch.equal(Y[j].cpu(), y)
+    xg, yg = gpu_ds[230]
+    assert torch.equal(xg.cpu(), cpu_ds[230][0])

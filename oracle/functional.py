@@ -226,6 +226,20 @@ def cheb_conv(x, edge_index, edge_weight, lin_weights, bias, normalization="sym"
     return out
 
 
+def gconv_gru_cell(X, edge_index, edge_weight, H, p, K, normalization="sym", lambda_max=None):
+    """GConvGRU.forward (gconv_gru.py:119-170): Z = s(cheb_xz(X) + cheb_hz(H)), R likewise (:121-133),
+    H~ = tanh(cheb_xh(X) + cheb_hh(H * R)) (:135-139), H' = Z * H + (1 - Z) * H~ (:141-143)."""
+    def conv(name, x):
+        lins = [p[f"{name}.lins.{k}.weight"] for k in range(K)]
+        return cheb_conv(x, edge_index, edge_weight, lins, p.get(f"{name}.bias"), normalization, lambda_max)
+    if H is None:
+        H = torch.zeros(X.size(0), p["conv_h_z.lins.0.weight"].size(0), dtype=X.dtype)
+    Z = torch.sigmoid(conv("conv_x_z", X) + conv("conv_h_z", H))
+    R = torch.sigmoid(conv("conv_x_r", X) + conv("conv_h_r", H))
+    Ht = torch.tanh(conv("conv_x_h", X) + conv("conv_h_h", H * R))
+    return Z * H + (1 - Z) * Ht
+
+
 def cheb_conv_attention(x, edge_index, spatial_attention, edge_weight, weight, bias, normalization, lambda_max=None):
     """ChebConvAttention.forward (astgcn.py:112-183) with its in-tree __norm__ (:82-110): x [B,N,Fin],
     spatial_attention [B,N,N], weight [K,Fin,Fout]."""

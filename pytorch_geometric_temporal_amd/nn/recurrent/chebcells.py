@@ -6,7 +6,8 @@ signatures and outputs.  Every gate of a cell convolves the SAME inputs, so inst
 calls (each with its own Laplacian normalisation and K-1 propagates) a cell runs ONE Chebyshev stack of [X, H] (one
 aggregation launch per hop at width in+out) and ONE MFMA GEMM that produces all gate pre-activations; GConvGRU's
 candidate needs a second stack of [X, H*R].  The LSTM gate chain (peepholes included) is one fused kernel
-(pgt_lstm_gates_f32) with a hand-written backward; GConvGRU's three gate expressions are elementwise torch ops.
+(pgt_lstm_gates_f32) with a hand-written backward; GConvGRU's gate chain runs in the epilogues of its two GEMMs
+(pgt_gemm_gru_zr/h_f32, the entry points DCRNN uses) inside one autograd node (ops.ChebGRUCellFunction).
 """
 from typing import Tuple
 
@@ -73,11 +74,10 @@ class GConvGRU(torch.nn.Module):
         O = self.out_channels
         g = _graph(self.conv_x_z, edge_index, edge_weight, X.size(0), lambda_max)
         Wzr, bzr = _gate_weights([self.conv_x_z, self.conv_x_r], [self.conv_h_z, self.conv_h_r])
-        ZR = torch.sigmoid(ops.ChebConvFunction.apply(torch.cat([X, H], dim=1), Wzr, bzr, g, self.K, 1))
-        Z, R = ZR[:, :O], ZR[:, O:]
         Wh, bh = _gate_weights([self.conv_x_h], [self.conv_h_h])
-        H_tilde = torch.tanh(ops.ChebConvFunction.apply(torch.cat([X, H * R], dim=1), Wh, bh, g, self.K, 1))
-        return Z * H + (1 - Z) * H_tilde
+        # both Chebyshev stacks, both gate GEMMs (sigmoid / H*R and tanh / blend in their epilogues) and the
+        # hand-written backward in one autograd node
+        return ops.ChebGRUCellFunction.apply(X, H, Wzr, bzr, Wh, bh, g, self.K)
 
 
 class GConvLSTM(torch.nn.Module):

@@ -385,6 +385,43 @@ def test_cheb_cells_match_reference_fixture_and_backpropagate(backend, name, cls
             assert p.grad is not None, n_
 
 
+@pytest.mark.parametrize("O,K,norm,lam", [(8, 3, "sym", None), (7, 2, "rw", 2.4), (12, 1, "sym", None), (64, 3, "sym", None)])
+def test_gconvgru_fused_cell_matches_oracle_forward_and_backward(backend, O, K, norm, lam):
+    """GConvGRU as one autograd node (ops.ChebGRUCellFunction: both Chebyshev stacks, the two gate GEMMs with the
+    sigmoid / H*R and tanh / blend epilogues — O % 4 == 0 — or the stand-alone gate kernels, hand-written backward)
+    against the fp64 oracle of gconv_gru.py:119-170 (itself pinned to the reference's fixture below)."""
+    from pytorch_geometric_temporal_amd.nn.recurrent import GConvGRU
+    torch.manual_seed(O + K)
+    n, fin = 30, 3
+    ei_np, ew_np = syn.sensor_graph(n, 190, seed=O, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    m = GConvGRU(fin, O, K, normalization=norm)
+    params64 = _rand_params(m, 21)
+    m = m.to(backend.device)
+    X, H, w = torch.randn(n, fin), torch.randn(n, O), torch.randn(n, O)
+    kw = {} if lam is None else {"lambda_max": torch.tensor(lam)}
+    Xd, Hd = backend.t(X).requires_grad_(), backend.t(H).requires_grad_()
+    out = m(Xd, backend.t(ei), backend.t(ew), Hd, **kw)
+    (out * backend.t(w)).sum().backward()
+    X64, H64 = X.double().requires_grad_(), H.double().requires_grad_()
+    ref = F.gconv_gru_cell(X64, ei, ew.double(), H64, params64, K, norm, lam)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward")
+    assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
+    assert_close_with_nonfinite(Hd.grad, H64.grad, 5e-5, 1e-4, "dH")
+    _check_param_grads(m, params64)
+
+
+def test_gconvgru_oracle_reproduces_the_reference_fixture():
+    g = load_golden("gconvgru_sensor")
+    X, H0, ei, ew = (g["in"][k] for k in ("X", "H0", "edge_index", "edge_weight"))
+    with torch.no_grad():
+        a = F.gconv_gru_cell(X, ei, ew, H0, g["param"], int(g["meta"]["K"]), "sym", None)
+        b = F.gconv_gru_cell(X, ei, ew, H0, g["param"], int(g["meta"]["K"]), "rw", float(g["meta"]["lambda_rw"]))
+    assert_close_with_nonfinite(a, g["out"]["H_state_sym"], 2e-6, 2e-6, "sym")
+    assert_close_with_nonfinite(b, g["out"]["H_state_rw"], 2e-6, 2e-6, "rw")
+
+
 # ------------------------------------------------------------------------------------------------ ASTGCN / MSTGCN (§8f)
 
 def test_astgcn_matches_reference_fixture_and_backpropagates(backend):

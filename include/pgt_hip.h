@@ -27,6 +27,7 @@
  *   pgt_gemm_f32          the dense feature transforms: dcrnn.py:81-83,88-92,101-105 (torch.matmul on weight[d][k]);
  *                         PyG Linear in GCNConv/ChebConv; temporalgcn.py:84,90,96 (linear_{z,r,h})
  *   pgt_gemm_tn_acc_f32   autograd of the above w.r.t. the weights (torch autograd in the reference)
+ *   pgt_att_*             SpatialAttention / TemporalAttention of ASTGCN: nn/attention/astgcn.py:226-262, :291-328
  *   pgt_window_gather_f32 signal/index_dataset.py:32-57 (the index-batch windows of a resident series)
  *   pgt_gru_*             the GRU gate chains: dcrnn.py:172-192,406-427; temporalgcn.py:82-102
  *   pgt_lstm_gates*       the LSTM gate chains: gconv_lstm.py:138-172 (peepholes), gc_lstm.py:138-169
@@ -303,6 +304,22 @@ int pgt_axpby2d_f32(float* dst, int64_t ldd, const float* x, int64_t ldx, float 
                     float b, int64_t M, int64_t W, pgt_stream_t stream);
 /* [D0][D1][W] -> [D1][D0][W] blocked transpose of W-float records (batch-major <-> node-major). */
 int pgt_swap01_f32(float* dst, const float* src, int64_t D0, int64_t D1, int64_t W, pgt_stream_t stream);
+
+/* ---------------------------------------------------------------- dense attention scores (ASTGCN)
+ * S[b] = softmax_dim1( V . sigmoid( L[b] R[b] + bias ) )  (SpatialAttention astgcn.py:226-262 with n = nodes, m = time steps;
+ * TemporalAttention :291-328 with n = time steps, m = nodes).  The intermediate layout is [i][b][j] (score-matrix row
+ * outermost) so that V . sigma_b for the whole batch is ONE pgt_gemm_f32 call [n, n] x [n, B n] and every stage is
+ * coalesced along j.  L [B, n, m], R [B, m, n], bias [n, n], row-major.
+ *   pgt_att_sigmoid_scores_f32   sig[i][b][j] = sigmoid(sum_t L[b,i,t] R[b,t,j] + bias[i,j])    (L R is never stored)
+ *   pgt_att_softmax_rows_f32     S[b][i][j] = softmax over i of C[i][b][j]                        (F.softmax(., dim=1))
+ *   pgt_att_softmax_rows_bwd_f32 dC[i][b][j] = S (dS - sum_i dS S)
+ *   pgt_att_sigmoid_bwd_f32      dP[b][i][j] = dsig[i][b][j] sig (1 - sig); dbias[i][j] = sum_b dP   (dbias may be NULL) */
+int pgt_att_sigmoid_scores_f32(const float* L, const float* R, const float* bias, int64_t B, int64_t n, int64_t m,
+                               float* sig, pgt_stream_t stream);
+int pgt_att_softmax_rows_f32(const float* C, int64_t B, int64_t n, float* S, pgt_stream_t stream);
+int pgt_att_softmax_rows_bwd_f32(const float* S, const float* dS, int64_t B, int64_t n, float* dC, pgt_stream_t stream);
+int pgt_att_sigmoid_bwd_f32(const float* sig, const float* dsig, int64_t B, int64_t n, float* dP, float* dbias,
+                            pgt_stream_t stream);
 
 /* Index-batch window gather (signal/index_dataset.py:32-57; examples/indexBatching: "GPU-index-batching"): for every
  * sample b, X[b] = data[idx[b] : idx[b] + h], Y[b] = data[idx[b] + h : idx[b] + 2 h] from the resident series

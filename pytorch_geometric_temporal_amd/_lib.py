@@ -96,6 +96,10 @@ PROTOTYPES = {
     "pgt_add2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_axpby2d_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_i64, c_f32, c_i64, c_i64, c_ptr]),
     "pgt_swap01_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_att_sigmoid_scores_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    "pgt_att_softmax_rows_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "pgt_att_softmax_rows_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "pgt_att_sigmoid_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "pgt_window_gather_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
 }
 

@@ -77,7 +77,8 @@ def _init_like_reference(module):
 
 class SpatialAttention(torch.nn.Module):
     r"""Spatial attention of ASTGCN (reference: astgcn.py:201-262): X [B, N, F, T] -> S [B, N, N],
-    S = softmax_dim1( Vs . sigmoid( (X W1 W2) (W3 X)^T + bs ) ).  Dense [B,N,N] work: torch matmuls."""
+    S = softmax_dim1( Vs . sigmoid( (X W1 W2) (W3 X)^T + bs ) ).  The two embeddings are small torch products; the
+    [B, N, N] part (product, bias, sigmoid, Vs product, softmax) is ops.AttentionScoresFunction (csrc/attention.hip)."""
 
     def __init__(self, in_channels: int, num_of_vertices: int, num_of_timesteps: int):
         super().__init__()
@@ -91,8 +92,8 @@ class SpatialAttention(torch.nn.Module):
     def forward(self, X):
         lhs = torch.matmul(torch.matmul(X, self._W1), self._W2)          # [B, N, T]
         rhs = torch.matmul(self._W3, X).transpose(-1, -2)                # [B, T, N]
-        S = torch.matmul(self._Vs, torch.sigmoid(torch.matmul(lhs, rhs) + self._bs))
-        return torch.softmax(S, dim=1)
+        # V . sigmoid(lhs rhs + b) and the softmax over dim 1: fused score kernel, one MFMA GEMM for the batch, softmax
+        return ops.AttentionScoresFunction.apply(lhs, rhs, self._bs, self._Vs)
 
 
 class TemporalAttention(torch.nn.Module):
@@ -110,8 +111,7 @@ class TemporalAttention(torch.nn.Module):
     def forward(self, X):
         lhs = torch.matmul(torch.matmul(X.permute(0, 3, 2, 1), self._U1), self._U2)   # [B, T, N]
         rhs = torch.matmul(self._U3, X)                                                # [B, N, T]
-        E = torch.matmul(self._Ve, torch.sigmoid(torch.matmul(lhs, rhs) + self._be))
-        return torch.softmax(E, dim=1)
+        return ops.AttentionScoresFunction.apply(lhs, rhs, self._be, self._Ve)
 
 
 class ASTGCNBlock(torch.nn.Module):

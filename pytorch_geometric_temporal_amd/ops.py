@@ -1211,6 +1211,67 @@ class ChebConvFunction(torch.autograd.Function):
         return dX, dW, db, None, None, None
 
 
+# --------------------------------------------------------------------------------------------- dense attention scores
+
+class AttentionScoresFunction(torch.autograd.Function):
+    """S = softmax_dim1( V . sigmoid( L R + bias ) ) for a batch of score matrices (ASTGCN's SpatialAttention,
+    astgcn.py:226-262, and TemporalAttention, :291-328): L [B, n, m], R [B, m, n], bias [1, n, n] or [n, n], V [n, n]
+    -> S [B, n, n].  Three launches forward (fused L R + bias + sigmoid; ONE MFMA GEMM for the whole batch on the
+    [i][b][j] layout; softmax over dim 1) instead of five torch ops with [B, n, n] temporaries; hand-written backward
+    (softmax and sigmoid adjoints, two GEMMs); the two small products with L and R that close the chain are batched
+    library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, L, R, bias, V):
+        lib = _lib.get_lib()
+        for t, nm in ((L, "L"), (R, "R"), (bias, "bias"), (V, "V")):
+            check_tensor(lib, t, nm)
+        Lc, Rc, Vc = L.contiguous(), R.contiguous(), V.contiguous()
+        bc = bias.contiguous()
+        B, n, m = Lc.shape
+        if Rc.shape != (B, m, n) or Vc.shape != (n, n) or bc.numel() != n * n:
+            raise ValueError("AttentionScoresFunction: inconsistent operand shapes")
+        dev, st = Lc.device, stream_of(lib, Lc)
+        sig = torch.empty(n, B, n, dtype=F32, device=dev)
+        lib.call("pgt_att_sigmoid_scores_f32", ptr(Lc), ptr(Rc), ptr(bc), B, n, m, ptr(sig), st)
+        C = torch.empty(n, B * n, dtype=F32, device=dev)
+        gemm(Vc, n, 0, 1, n, sig, B * n, 1, C, B * n, 0, B * n, None, n, B * n)
+        S = torch.empty(B, n, n, dtype=F32, device=dev)
+        lib.call("pgt_att_softmax_rows_f32", ptr(C), B, n, ptr(S), st)
+        ctx.save_for_backward(Lc, Rc, Vc, sig, S)
+        ctx.bias_shape = bias.shape
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        lib = _lib.get_lib()
+        Lc, Rc, Vc, sig, S = ctx.saved_tensors
+        B, n, m = Lc.shape
+        dev, st = dS.device, stream_of(lib, dS)
+        dS = dS.contiguous()
+        dC = torch.empty(n, B * n, dtype=F32, device=dev)
+        lib.call("pgt_att_softmax_rows_bwd_f32", ptr(S), ptr(dS), B, n, ptr(dC), st)
+        dV = None
+        if ctx.needs_input_grad[3]:
+            dV = torch.empty(n, n, dtype=F32, device=dev)
+            gemm(dC, B * n, 0, 1, B * n, sig, 1, B * n, dV, n, 0, n, None, n, n)          # dV = dC sig^T
+        dL = dR = dbias = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            Vt = Vc.t().contiguous()
+            dsig = torch.empty(n, B * n, dtype=F32, device=dev)
+            gemm(Vt, n, 0, 1, n, dC, B * n, 1, dsig, B * n, 0, B * n, None, n, B * n)    # dsig = V^T dC
+            dP = torch.empty(B, n, n, dtype=F32, device=dev)
+            db = torch.empty(n, n, dtype=F32, device=dev)
+            lib.call("pgt_att_sigmoid_bwd_f32", ptr(sig), ptr(dsig), B, n, ptr(dP), ptr(db), st)
+            if ctx.needs_input_grad[2]:
+                dbias = db.view(ctx.bias_shape)
+            if ctx.needs_input_grad[0]:
+                dL = torch.bmm(dP, Rc.transpose(1, 2))                                    # [B, n, m]
+            if ctx.needs_input_grad[1]:
+                dR = torch.bmm(Lc.transpose(1, 2), dP)                                    # [B, m, n]
+        return dL, dR, dbias, dV
+
+
 # --------------------------------------------------------------------------------------------- attention Chebyshev conv
 
 def spmm_att(csr, S, X3, transpose_s=False):

@@ -540,3 +540,23 @@ try:
         assert_close_with_nonfinite(Sd.grad, S64.grad, 5e-5, 1e-4, "fuzz attention conv dS")
 except ImportError:      # hypothesis is optional
     pass
+
+
+@pytest.mark.parametrize("B,n,m", [(3, 24, 5), (2, 70, 12), (4, 7, 33), (1, 1, 1)])
+def test_attention_scores_function_matches_torch_forward_and_backward(backend, B, n, m):
+    """ops.AttentionScoresFunction (csrc/attention.hip + one pgt_gemm_f32 for the batch) against the reference's
+    formula S = softmax(V @ sigmoid(L @ R + b), dim=1) (astgcn.py:258-261 / :324-327) in fp64 autograd."""
+    from pytorch_geometric_temporal_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + n)
+    L, R = torch.randn(B, n, m, generator=g), torch.randn(B, m, n, generator=g)
+    bias, V = torch.randn(1, n, n, generator=g), torch.randn(n, n, generator=g) / max(n, 1) ** 0.5
+    w = torch.randn(B, n, n, generator=g)
+    args = [backend.t(t).requires_grad_() for t in (L, R, bias, V)]
+    out = ops.AttentionScoresFunction.apply(*args)
+    (out * backend.t(w)).sum().backward()
+    ref_args = [t.double().requires_grad_() for t in (L, R, bias, V)]
+    ref = torch.softmax(torch.matmul(ref_args[3], torch.sigmoid(torch.matmul(ref_args[0], ref_args[1]) + ref_args[2])), dim=1)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "S")
+    for a, r, nm in zip(args, ref_args, ("dL", "dR", "dbias", "dV")):
+        assert_close_with_nonfinite(a.grad, r.grad, 2e-5, 1e-4, nm)

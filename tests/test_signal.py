@@ -127,10 +127,11 @@ def test_resident_signal_and_index_batches_on_the_gpu():
     the one-launch window gather and equals the CPU dataset sample for sample."""
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(4)
-    ei = rng.integers(0, 30, size=(2, 120))
+    from pytorch_geometric_temporal_amd.dataset import synthetic as syn
+    ei, ew = syn.sensor_graph(30, 120, seed=4)                  # unique edges (DConv's dense path rejects duplicates)
     feats = [rng.random((30, 3)).astype(np.float32) for _ in range(20)]
     targs = [rng.random(30).astype(np.float32) for _ in range(20)]
-    s = StaticGraphTemporalSignal(ei, np.ones(120), feats, targs).to(dev)
+    s = StaticGraphTemporalSignal(ei, ew, feats, targs).to(dev)
     a, b = s[1], s[7]
     assert a.x.is_cuda and a.x.untyped_storage().data_ptr() == b.x.untyped_storage().data_ptr()
     assert a.edge_index is b.edge_index and a.edge_attr is b.edge_attr

@@ -18,6 +18,7 @@
 #include <vector>
 
 void pgt_gemm_set_force_small(int) {}
+void pgt_gemm_set_small_fill(int) {}
 void pgt_gemm_set_tn_fullk(int) {}
 void pgt_gemm_set_db(int) {}
 void pgt_gemm_set_db64(int) {}

@@ -18,6 +18,7 @@ __device__ long long* g_trace_buf = nullptr;
   } while (0)
 
 void pgt_gemm_set_force_small(int) {}
+void pgt_gemm_set_small_fill(int) {}
 void pgt_gemm_set_tn_fullk(int) {}
 void pgt_gemm_set_db(int) {}
 void pgt_gemm_set_db64(int) {}

@@ -1469,11 +1469,13 @@ int g_db = 1;  // pgt_tune("gemm_db"): 1 = pipelined two-stage kernel where it a
 
 int g_db64 = 1;  // pgt_tune("gemm_db64"): N <= 64 tile of the pipelined kernel: 1 = four wavefronts of 64 x 32, 0 = two of 64 x 64
 
+int g_small_fill = 256;  // pgt_tune("gemm_small_fill"): fewest 128-row tiles for which the 128-row kernels are used
 int g_force_small_tiles = 0;  // pgt_tune("gemm_small_tiles"): 0 = by size, 1 = always 64x64, 2 = always 128-wide
 
 }  // namespace
 
 void pgt_gemm_set_force_small(int v) { g_force_small_tiles = v; }
+void pgt_gemm_set_small_fill(int v) { g_small_fill = v; }
 void pgt_gemm_set_tn_fullk(int v) { g_tn_fullk = v; }
 void pgt_gemm_set_db(int v) { g_db = v; }
 void pgt_gemm_set_db64(int v) { g_db64 = v; }
@@ -1525,7 +1527,11 @@ static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t
   // float2 loads of A need every (row, even k) address 8-byte aligned and no pair straddling a segment
   const bool av2 = (seg_k % 2 == 0) && (lda % 2 == 0) && (a_seg_stride % 2 == 0) && pgt_aligned(A, 8);
   const bool kmaj = (sbk == 1 && sbn != 1);
-  const bool big = g_force_small_tiles == 2 || ((M >= 2048) && g_force_small_tiles == 0);
+  // 128-row tiles only when they fill the chip: a tile's K loop is one latency-bound chain (~40 us at K = 330), so a
+  // product whose 128-row tiling yields fewer workgroups than there are CUs runs faster on four times as many 64 x 64
+  // tiles (DCRNN training step at B = 64, M = 13 248: 3.67 -> 3.12 ms per step); pgt_tune("gemm_small_tiles") overrides
+  const int64_t fill128 = pgt_cdiv(M, 128) * pgt_cdiv(N, N > 64 ? 128 : 64);
+  const bool big = g_force_small_tiles == 2 || ((M >= 2048) && fill128 >= g_small_fill && g_force_small_tiles == 0);
   dim3 block(256);
   // tile depth with the least K padding (30 divides the 330-wide diffusion stack; 32 the power-of-two widths)
   const int64_t Ktot = n_seg * seg_k;

@@ -79,6 +79,7 @@ static __device__ __forceinline__ pgt_f4 pgt_mk4(float a, float b, float c, floa
 void pgt_set_error(const char* fmt, ...);
 // tuning knobs (pgt_tune): each translation unit owns its own
 void pgt_gemm_set_force_small(int v);
+void pgt_gemm_set_small_fill(int v);
 void pgt_gemm_set_tn_fullk(int v);
 void pgt_gemm_set_db(int v);
 void pgt_gemm_set_db64(int v);

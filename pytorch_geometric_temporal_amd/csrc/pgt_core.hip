@@ -28,6 +28,10 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_gemm_set_force_small(value);
     return PGT_OK;
   }
+  if (strcmp(key, "gemm_small_fill") == 0) {
+    pgt_gemm_set_small_fill(value);
+    return PGT_OK;
+  }
   if (strcmp(key, "gemm_tn_fullk") == 0) {
     pgt_gemm_set_tn_fullk(value);
     return PGT_OK;

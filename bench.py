@@ -379,14 +379,14 @@ def main():
         # data; short runs, same bracketing
         variants = {}
         torch.cuda.empty_cache()
-        d2, _, s2, _ = train_run(device, rank, world, series, args.edges, args.batch, args.hidden, 5, 2, dropin=True)
+        d2, _, s2, _ = train_run(device, rank, world, series, args.edges, args.batch, args.hidden, 8, 3, dropin=True)
         del s2
-        variants["dropin_default"] = dict(throughput(d2, args.edges, args.batch, 5),
+        variants["dropin_default"] = dict(throughput(d2, args.edges, args.batch, 8),
                                           what="lazy_output=False (contiguous [B,T,N,O] output) + torch.nn.Linear read-out")
         torch.cuda.empty_cache()
-        d3, _, s3, _ = train_run(device, rank, world, series, 1722, args.batch, args.hidden, 5, 2)
+        d3, _, s3, _ = train_run(device, rank, world, series, 1722, args.batch, args.hidden, 8, 3)
         del s3
-        variants["edges_1722"] = dict(throughput(d3, 1722, args.batch, 5), what="1 722-edge graph (the reference's METR-LA data)")
+        variants["edges_1722"] = dict(throughput(d3, 1722, args.batch, 8), what="1 722-edge graph (the reference's METR-LA data)")
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extra:
         import bench_configs as BCfg

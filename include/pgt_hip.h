@@ -234,6 +234,15 @@ int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64
                         const float* G, int64_t ldg, float* dW, int64_t lddw, float* db, int64_t M, int64_t N,
                         pgt_stream_t stream);
 
+/* The same sums without float atomics: every workgroup STORES its partial dW / db into `ws` and a second pass adds the
+ * row slabs in index order, so the result is bitwise reproducible run to run (pgt_gemm_tn_acc_f32's fp32 atomics make
+ * dW depend on the order in which workgroups retire).  ws: device scratch of pgt_gemm_tn_det_ws_bytes(...) bytes,
+ * 16-byte aligned, owned by the caller.  Costs one extra pass over <= 1024 partial [K, N] blocks. */
+size_t pgt_gemm_tn_det_ws_bytes(int64_t n_seg, int64_t seg_k, int64_t N, int64_t lddw);
+int pgt_gemm_tn_det_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                        const float* G, int64_t ldg, float* dW, int64_t lddw, float* db, int64_t M, int64_t N,
+                        void* ws, size_t ws_bytes, pgt_stream_t stream);
+
 /* The DCRNN gate GEMMs with the gate chain fused into the epilogue (operands A / Bw / bias as pgt_gemm_f32):
  *   pgt_gemm_gru_zr_f32:  zr [M,2O] = sigmoid(A Bw + bias);  xhr[m, f_in + o] = H[m,o] * zr[m, O + o]
  *                         == pgt_gemm_f32 into zr followed by pgt_gru_zr_f32 (dcrnn.py:172-185), bit for bit,

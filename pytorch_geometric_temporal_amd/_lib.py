@@ -83,6 +83,9 @@ PROTOTYPES = {
                                    c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_gemm_tn_acc_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                     c_i64, c_ptr]),
+    "pgt_gemm_tn_det_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64]),
+    "pgt_gemm_tn_det_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
+                                    c_i64, c_ptr, c_size, c_ptr]),
     "pgt_gru_zr_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_gru_h_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_gru_h_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,

@@ -824,7 +824,38 @@ __global__ __launch_bounds__(256, 2) void gemm_dbp_kernel(GemmArgs g, int gx, in
 struct TnArgs {
   const float* A; int64_t lda; int64_t a_seg_stride; int n_seg; int seg_k;
   const float* G; int64_t ldg; float* dW; int64_t lddw; float* db; int M; int N; int rows_per_slab;
+  // deterministic mode (pgt_gemm_tn_det_f32): every (slab, k, n) partial sum is STORED at part + slab * part_stride +
+  // k * lddw + n (bias partials at dbpart + slab * N + n) and tn_reduce_kernel adds the slabs in index order; null =
+  // fp32 atomics straight into dW / db
+  float* part; int64_t part_stride; float* dbpart;
 };
+
+__device__ __forceinline__ void tn_out(const TnArgs& g, int slab, int gk, int gn, float v) {
+  if (g.part != nullptr) g.part[(int64_t)slab * g.part_stride + (int64_t)gk * g.lddw + gn] = v;
+  else atomicAdd(g.dW + (int64_t)gk * g.lddw + gn, v);
+}
+__device__ __forceinline__ void tn_out_bias(const TnArgs& g, int slab, int gn, float v) {
+  if (g.dbpart != nullptr) g.dbpart[(int64_t)slab * g.N + gn] = v;
+  else atomicAdd(g.db + gn, v);
+}
+
+// dW[k, n] += sum over the slabs, in slab order (the deterministic second pass); one thread per element
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int64_t part_stride, int nslab,
+                                                        int K, int N, int64_t lddw, float* dW,
+                                                        const float* __restrict__ dbpart, float* db) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < (int64_t)K * N) {
+    const int k = (int)(e / N), n = (int)(e % N);
+    float acc = 0.f;
+    for (int s = 0; s < nslab; ++s) acc += part[(int64_t)s * part_stride + (int64_t)k * lddw + n];
+    dW[(int64_t)k * lddw + n] += acc;
+  } else if (db != nullptr && e < (int64_t)K * N + N) {
+    const int n = (int)(e - (int64_t)K * N);
+    float acc = 0.f;
+    for (int s = 0; s < nslab; ++s) acc += dbpart[(int64_t)s * N + n];
+    db[n] += acc;
+  }
+}
 
 // dW tile [BKC kc x BN n] += A[slab, kc]^T G[slab, n].  Both operands are staged in their natural [m][col] layout
 // (lanes along the contiguous column): the MFMA "A" operand A'[i = kc][k = m] is As[m][kc].
@@ -914,11 +945,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gk = k0 + wk * (BKC / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (gk < Ktot) atomicAdd(g.dW + (int64_t)gk * g.lddw + gn, acc[i][jj][r]);
+        if (gk < Ktot) tn_out(g, (int)blockIdx.z, gk, gn, acc[i][jj][r]);
       }
     }
   }
-  if (do_bias && (n0 + tid) < g.N) atomicAdd(g.db + n0 + tid, bsum);
+  if (do_bias && (n0 + tid) < g.N) tn_out_bias(g, (int)blockIdx.z, n0 + tid, bsum);
 }
 
 // dW[0:Ktot, n0:n0+BN] += A[slab, 0:Ktot]^T G[slab, n0:n0+BN] with the WHOLE K extent (Ktot <= 384) in one workgroup:
@@ -1044,11 +1075,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fullk_kernel(TnArgs g, int KT,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (gk < Ktot) atomicAdd(g.dW + (int64_t)gk * g.lddw + gn, acc[i][j][r]);
+        if (gk < Ktot) tn_out(g, (int)blockIdx.x, gk, gn, acc[i][j][r]);
       }
     }
   }
-  if (do_bias && (n0 + tid) < g.N) atomicAdd(g.db + n0 + tid, bsum);
+  if (do_bias && (n0 + tid) < g.N) tn_out_bias(g, (int)blockIdx.x, n0 + tid, bsum);
 }
 
 // Whole-K weight gradient, pipelined like gemm_db_kernel: dW[0:Ktot, n0:n0+BN] += A[slab, :]^T G[slab, n0:n0+BN] with
@@ -1240,7 +1271,7 @@ __global__ __launch_bounds__(512, (16 * NH * NI + 48 <= 128) ? 4 : 2) void gemm_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (gk < Ktot) atomicAdd(g.dW + (int64_t)gk * g.lddw + gn, acc[i][j][r]);
+        if (gk < Ktot) tn_out(g, (int)blockIdx.x, gk, gn, acc[i][j][r]);
       }
     }
   }
@@ -1253,7 +1284,7 @@ __global__ __launch_bounds__(512, (16 * NH * NI + 48 <= 128) ? 4 : 2) void gemm_
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < TNP_ROWS; ++r) t += red[r * BN + tid];
-      atomicAdd(g.db + n0 + tid, t);
+      tn_out_bias(g, (int)blockIdx.x, n0 + tid, t);
     }
   }
 }
@@ -1266,6 +1297,7 @@ struct SkinnyArgs {
   float* C; int64_t ldc; const float* bias; int M; int N; int K; int accumulate;
   const float* G; int64_t ldg; float* db;       // weight gradient only: C = dW [K, N] (row stride ldc), db [N] or null
   int rows_per_wg;
+  float* part; int64_t part_stride; float* dbpart;   // deterministic mode: per-workgroup partials (see TnArgs)
 };
 constexpr int SK_U = 4;   // row groups in flight per wavefront pass (4 rows each)
 
@@ -1450,11 +1482,15 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(SkinnyArgs g) {
     const int k = 64 * c + 4 * qq + i;
     if (n < g.N && k < g.K) {
       const float v = red[0][qq][c][n][i] + red[1][qq][c][n][i] + red[2][qq][c][n][i] + red[3][qq][c][n][i];
-      atomicAdd(g.C + (int64_t)k * g.ldc + n, v);
+      if (g.part != nullptr) g.part[(int64_t)blockIdx.x * g.part_stride + (int64_t)k * g.ldc + n] = v;
+      else atomicAdd(g.C + (int64_t)k * g.ldc + n, v);
     }
   }
-  if (g.db && threadIdx.x < (unsigned)g.N)
-    atomicAdd(g.db + threadIdx.x, bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x]);
+  if (g.db && threadIdx.x < (unsigned)g.N) {
+    const float bv = bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x];
+    if (g.dbpart != nullptr) g.dbpart[(int64_t)blockIdx.x * g.N + threadIdx.x] = bv;
+    else atomicAdd(g.db + threadIdx.x, bv);
+  }
 }
 
 int g_dbp = 1;  // pgt_tune("gemm_dbp"): 1 = persistent deferred-store kernel where it applies (N % 128 == 0, K >= 64, >= 1024 tiles, plain epilogue), 2 = at any size on three workgroups (tests), 0 = never
@@ -1505,7 +1541,8 @@ static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t
   // skinny shapes (see gemm_skinny_*_kernel): one segment in, one segment out, no fused epilogue
   if (g_skinny && !epi && n_seg == 1 && c_seg_n >= N && (M >= 1024 || g_skinny == 2)) {
     const int64_t K1 = seg_k;
-    SkinnyArgs sk{A, lda, Bw, sbk, sbn, C, ldc, bias, (int)M, (int)N, (int)K1, accumulate, nullptr, 0, nullptr, 0};
+    SkinnyArgs sk{A, lda, Bw, sbk, sbn, C, ldc, bias, (int)M, (int)N, (int)K1, accumulate, nullptr, 0, nullptr, 0,
+                  nullptr, 0, nullptr};
     if (N <= 4 && K1 >= 16 && K1 <= 256 && K1 % 4 == 0 && lda % 4 == 0 && pgt_aligned(A, 16)) {
       int64_t wgs = pgt_cdiv(M, 4 * 4 * SK_U);
       if (wgs > 256 * 8) wgs = 256 * 8;
@@ -1644,9 +1681,30 @@ extern "C" int pgt_gemm_gru_h_f32(const float* A, int64_t lda, int64_t a_seg_str
   return gemm_entry(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, ht, O, 0, O, bias, M, O, 0, &e, stream);
 }
 
-extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg,
-                                   int64_t seg_k, const float* G, int64_t ldg, float* dW, int64_t lddw,
-                                   float* db, int64_t M, int64_t N, pgt_stream_t stream) {
+constexpr int64_t TN_DET_SLABS = 1024;   // most row slabs any weight-gradient schedule launches
+
+// deterministic mode: point the kernel at the partial buffers inside `ws` ...
+static int tn_det_setup(float* ws, size_t ws_bytes, int64_t nslab, int64_t Ktot, int64_t N, int64_t lddw, float** part,
+                        int64_t* part_stride, float** dbpart) {
+  const int64_t stride = Ktot * lddw;
+  PGT_REQUIRE(nslab <= TN_DET_SLABS, "pgt_gemm_tn_det_f32: %lld row slabs", (long long)nslab);
+  PGT_REQUIRE((size_t)(nslab * (stride + N)) * sizeof(float) <= ws_bytes, "pgt_gemm_tn_det_f32: workspace too small");
+  *part = ws; *part_stride = stride; *dbpart = ws + nslab * stride;
+  return PGT_OK;
+}
+// ... and add the slabs to dW / db in slab order afterwards
+static int tn_det_finish(const float* part, int64_t part_stride, int64_t nslab, int64_t Ktot, int64_t N, int64_t lddw,
+                         float* dW, const float* dbpart, float* db, pgt_stream_t stream) {
+  const int64_t total = Ktot * N + (db ? N : 0);
+  if (total == 0) return PGT_OK;
+  PGT_LAUNCH(tn_reduce_kernel, dim3((unsigned)pgt_cdiv(total, 256)), dim3(256), stream, part, part_stride, (int)nslab,
+             (int)Ktot, (int)N, lddw, dW, dbpart, db);
+  return pgt_check_launch("pgt_gemm_tn_det_f32");
+}
+
+static int tn_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k, const float* G,
+                    int64_t ldg, float* dW, int64_t lddw, float* db, int64_t M, int64_t N, float* ws, size_t ws_bytes,
+                    pgt_stream_t stream) {
   PGT_REQUIRE(M >= 0 && N >= 0 && n_seg >= 0 && seg_k >= 0, "pgt_gemm_tn_acc_f32: negative size");
   const int64_t Ktot = n_seg * seg_k;
   if (M == 0 || N == 0) return PGT_OK;
@@ -1659,14 +1717,17 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
     // <= 1024 workgroups (K N atomics each); slabs are multiples of the 64 rows the four wavefronts take per pass
     int64_t rows = pgt_cdiv(pgt_cdiv(M, 1024), 16 * SK_U) * (16 * SK_U);
     const int64_t wgs = pgt_cdiv(M, rows);
-    SkinnyArgs sk{A, lda, nullptr, 0, 0, dW, lddw, nullptr, (int)M, (int)N, (int)seg_k, 1, G, ldg, db, (int)rows};
+    SkinnyArgs sk{A, lda, nullptr, 0, 0, dW, lddw, nullptr, (int)M, (int)N, (int)seg_k, 1, G, ldg, db, (int)rows,
+                  nullptr, 0, nullptr};
+    if (ws) { if (int rc = tn_det_setup(ws, ws_bytes, wgs, Ktot, N, lddw, &sk.part, &sk.part_stride, &sk.dbpart)) return rc; }
     const int NC = (int)pgt_cdiv(seg_k, 64);
     dim3 grid((unsigned)wgs), blk(256);
     if (NC == 1) PGT_LAUNCH((gemm_tn_skinny_kernel<1>), grid, blk, stream, sk);
     else if (NC == 2) PGT_LAUNCH((gemm_tn_skinny_kernel<2>), grid, blk, stream, sk);
     else if (NC == 3) PGT_LAUNCH((gemm_tn_skinny_kernel<3>), grid, blk, stream, sk);
     else PGT_LAUNCH((gemm_tn_skinny_kernel<4>), grid, blk, stream, sk);
-    return pgt_check_launch("pgt_gemm_tn_acc_f32");
+    if (int rc = pgt_check_launch("pgt_gemm_tn_acc_f32")) return rc;
+    return ws ? tn_det_finish(sk.part, sk.part_stride, wgs, Ktot, N, lddw, dW, sk.dbpart, db, stream) : PGT_OK;
   }
   // whole-K schedule: tall slabs, K up to 384; every operand element is read once per 128-wide column block
   // (measured at K = 330 inside the DCRNN training step, M = 2.5 M rows: 4.27 ms per step with this schedule for both
@@ -1690,13 +1751,15 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
       nslab = pgt_cdiv(M, rows);
       if (n_seg * a_seg_stride + rows * lda < ((int64_t)1 << 30) && rows * ldg + N < ((int64_t)1 << 30)) {
         TnArgs t{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), G, ldg, dW, lddw, db, (int)M, (int)N,
-                 (int)rows};
+                 (int)rows, nullptr, 0, nullptr};
+        if (ws) { if (int rc = tn_det_setup(ws, ws_bytes, nslab, Ktot, N, lddw, &t.part, &t.part_stride, &t.dbpart)) return rc; }
         dim3 grid((unsigned)nslab, (unsigned)gy), block(512);
 #define PGT_TNP_GO(NH_, NI_) PGT_LAUNCH((gemm_tn_pipe_kernel<NH_, NI_>), grid, block, stream, t)
         if (BNp == 128) { if (NI == 1) PGT_TNP_GO(2, 1); else if (NI == 2) PGT_TNP_GO(2, 2); else PGT_TNP_GO(2, 3); }
         else { if (NI == 1) PGT_TNP_GO(1, 1); else if (NI == 2) PGT_TNP_GO(1, 2); else PGT_TNP_GO(1, 3); }
 #undef PGT_TNP_GO
-        return pgt_check_launch("pgt_gemm_tn_acc_f32");
+        if (int rc = pgt_check_launch("pgt_gemm_tn_acc_f32")) return rc;
+        return ws ? tn_det_finish(t.part, t.part_stride, nslab, Ktot, N, lddw, dW, t.dbpart, db, stream) : PGT_OK;
       }
     }
   }
@@ -1711,12 +1774,14 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
     int64_t rows = pgt_cdiv(pgt_cdiv(M, nslab), TNF_ROWS) * TNF_ROWS;
     nslab = pgt_cdiv(M, rows);
     TnArgs t{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), G, ldg, dW, lddw, db, (int)M, (int)N,
-             (int)rows};
+             (int)rows, nullptr, 0, nullptr};
+    if (ws) { if (int rc = tn_det_setup(ws, ws_bytes, nslab, Ktot, N, lddw, &t.part, &t.part_stride, &t.dbpart)) return rc; }
     dim3 grid((unsigned)nslab, (unsigned)gy), block(512);
     const int g_vec4 = (ldg % 4 == 0) && pgt_aligned(G, 16);
     if (BNf == 128) PGT_LAUNCH((gemm_tn_fullk_kernel<4>), grid, block, stream, t, KT, g_vec4);
     else PGT_LAUNCH((gemm_tn_fullk_kernel<2>), grid, block, stream, t, KT, g_vec4);
-    return pgt_check_launch("pgt_gemm_tn_acc_f32");
+    if (int rc = pgt_check_launch("pgt_gemm_tn_acc_f32")) return rc;
+    return ws ? tn_det_finish(t.part, t.part_stride, nslab, Ktot, N, lddw, dW, t.dbpart, db, stream) : PGT_OK;
   }
   const bool big = g_force_small_tiles == 2 || ((M >= 16384) && (Ktot > 64) && (N > 64) && g_force_small_tiles == 0);
   const int BKC = big ? 128 : 64, BN = big ? 128 : 64;
@@ -1732,9 +1797,29 @@ extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_st
   const int64_t rows = pgt_cdiv(pgt_cdiv(M, nslab), BK) * BK;
   nslab = pgt_cdiv(M, rows);
   TnArgs t{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), G, ldg, dW, lddw, db, (int)M, (int)N,
-           (int)rows};
+           (int)rows, nullptr, 0, nullptr};
+  if (ws) { if (int rc = tn_det_setup(ws, ws_bytes, nslab, Ktot, N, lddw, &t.part, &t.part_stride, &t.dbpart)) return rc; }
   dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)nslab), block(256);
   if (big) PGT_LAUNCH((gemm_tn_kernel<128, 128>), grid, block, stream, t);
   else PGT_LAUNCH((gemm_tn_kernel<64, 64>), grid, block, stream, t);
-  return pgt_check_launch("pgt_gemm_tn_acc_f32");
+  if (int rc = pgt_check_launch("pgt_gemm_tn_acc_f32")) return rc;
+  return ws ? tn_det_finish(t.part, t.part_stride, nslab, Ktot, N, lddw, dW, t.dbpart, db, stream) : PGT_OK;
+}
+
+extern "C" int pgt_gemm_tn_acc_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg,
+                                   int64_t seg_k, const float* G, int64_t ldg, float* dW, int64_t lddw,
+                                   float* db, int64_t M, int64_t N, pgt_stream_t stream) {
+  return tn_entry(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N, nullptr, 0, stream);
+}
+
+extern "C" size_t pgt_gemm_tn_det_ws_bytes(int64_t n_seg, int64_t seg_k, int64_t N, int64_t lddw) {
+  if (n_seg < 0 || seg_k < 0 || N < 0 || lddw < 0) return 0;
+  return (size_t)(TN_DET_SLABS * (n_seg * seg_k * lddw + N)) * sizeof(float);
+}
+
+extern "C" int pgt_gemm_tn_det_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
+                                   const float* G, int64_t ldg, float* dW, int64_t lddw, float* db, int64_t M, int64_t N,
+                                   void* ws, size_t ws_bytes, pgt_stream_t stream) {
+  PGT_REQUIRE(ws != nullptr && pgt_aligned(ws, 16), "pgt_gemm_tn_det_f32: null or misaligned workspace");
+  return tn_entry(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N, static_cast<float*>(ws), ws_bytes, stream);
 }

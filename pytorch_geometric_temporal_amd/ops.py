@@ -418,6 +418,13 @@ def gemm(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, C, ldc, c_seg_stride,
 SKIP_INPUT_COLUMNS_WHEN_UNUSED = os.environ.get("PGT_SKIP_X", "1") != "0"
 # DCRNN cell forward: sigmoid / H*R and tanh / blend inside the gate GEMMs' epilogues (A/B: PGT_FUSE_GATES=0)
 FUSE_GATE_EPILOGUES = os.environ.get("PGT_FUSE_GATES", "1") != "0"
+# feature-gradient GEMM of the hidden columns (S*O = 320 output columns): 1 = a 256-column product on the persistent
+# deferred-store kernel + a 64-column remainder, 0 = one 320-column product (three 128-wide column tiles, the last masked)
+SPLIT_FEATURE_GRADIENT = os.environ.get("PGT_SPLIT_FG", "1") != "0"
+# weight / bias gradients without float atomics (pgt_gemm_tn_det_f32): bitwise reproducible run to run, one extra pass
+# over the per-slab partial sums.  Off by default (the atomics are ~2 % faster at the benchmark shape); PGT_DETERMINISTIC=1
+# or ops.DETERMINISTIC_WEIGHT_GRADIENTS = True turns it on.
+DETERMINISTIC_WEIGHT_GRADIENTS = os.environ.get("PGT_DETERMINISTIC", "0") == "1"
 
 
 def gemm_gru_zr(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, bias, zr, H, xhr, f_in):
@@ -454,6 +461,14 @@ def gemm_tn_acc(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N):
     if db is not None:
         check_tensor(lib, db, "db")
     st = stream_of(lib, G)
+    if DETERMINISTIC_WEIGHT_GRADIENTS:
+        # no float atomics: per-slab partial sums in a scratch buffer, added in slab order (bitwise reproducible)
+        nbytes = int(lib._pgt_gemm_tn_det_ws_bytes(n_seg, seg_k, N, lddw))
+        ws = torch.empty(max(nbytes // 4, 1), dtype=F32, device=G.device)
+        _timed("gemm_tn", 2.0 * M * N * n_seg * seg_k, lambda: lib.call(
+            "pgt_gemm_tn_det_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(G), ldg, ptr(dW), lddw, ptr(db), M, N,
+            ptr(ws), nbytes, st), tag=(M, N, n_seg, seg_k))
+        return dW
     _timed("gemm_tn", 2.0 * M * N * n_seg * seg_k, lambda: lib.call(
         "pgt_gemm_tn_acc_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(G), ldg, ptr(dW), lddw, ptr(db), M, N, st),
         tag=(M, N, n_seg, seg_k))
@@ -835,7 +850,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             WhH = Wh_b.view(S, C, O)[:, Fin:, :].reshape(S * O, O).contiguous()
             WzrH = Wzr_b.view(S, C, 2 * O)[:, Fin:, :].reshape(S * O, 2 * O).contiguous()
             NH = S * O
-            n1 = (NH // 128) * 128 if (NH % 128 != 0 and NH > 128 and ((NH // 128) * 128) % O == 0) else NH
+            n1 = (NH // 128) * 128 if (SPLIT_FEATURE_GRADIENT and NH % 128 != 0 and NH > 128 and ((NH // 128) * 128) % O == 0) else NH
 
         def feature_grad(dP, Wfull, WH, Kd):
             """G[s] = dP W_s^T for every stack segment (the stack adjoint consumes G in place)."""

@@ -1286,3 +1286,45 @@ try:
             lib.tune("slab_pairs", 2)
 except ImportError:      # hypothesis is optional
     pass
+
+
+@pytest.mark.parametrize("M,segs,segk,N,mode", [(300, 5, 66, 128, "default"), (2500, 2, 10, 7, "default"),
+                                                (700, 1, 64, 2, "skinny"), (4100, 3, 40, 64, "pipelined"),
+                                                (900, 5, 66, 64, "whole_k"), (130, 1, 33, 70, "default")])
+def test_deterministic_weight_gradient_matches_and_is_reproducible(backend, M, segs, segk, N, mode):
+    """pgt_gemm_tn_det_f32 (per-slab partial sums stored, then added in slab order) against the fp64 product and the
+    atomic entry point, for every weight-gradient schedule; two runs give bit-identical results."""
+    from pytorch_geometric_temporal_amd import ops
+    lib = _lib.get_lib()
+    knobs = {"default": {}, "whole_k": {"gemm_tn_fullk": 2, "gemm_tn_pipe": 0}, "pipelined": {"gemm_tn_pipe": 2},
+             "skinny": {"gemm_skinny": 2}}[mode]
+    defaults = {"gemm_tn_fullk": 1, "gemm_tn_pipe": 1, "gemm_skinny": 1}
+    if backend.name == "hip":
+        M *= 40
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(segs, M, segk, generator=g).to(backend.device)
+    G = torch.randn(M, N, generator=g).to(backend.device)
+    dW0 = torch.randn(segs * segk, N, generator=g)
+    db0 = torch.randn(N, generator=g)
+    for k, v in knobs.items():
+        lib.tune(k, v)
+    try:
+        outs = []
+        ops.DETERMINISTIC_WEIGHT_GRADIENTS = True
+        for _ in range(2):
+            dW, db = dW0.clone().to(backend.device), db0.clone().to(backend.device)
+            ops.gemm_tn_acc(A, segk, M * segk, segs, segk, G, N, dW, N, db, M, N)
+            outs.append((dW.cpu(), db.cpu()))
+        ops.DETERMINISTIC_WEIGHT_GRADIENTS = False
+        dWa, dba = dW0.clone().to(backend.device), db0.clone().to(backend.device)
+        ops.gemm_tn_acc(A, segk, M * segk, segs, segk, G, N, dWa, N, dba, M, N)
+    finally:
+        ops.DETERMINISTIC_WEIGHT_GRADIENTS = False
+        for k in knobs:
+            lib.tune(k, defaults[k])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # reproducible
+    Acat = torch.cat([A[j].cpu() for j in range(segs)], dim=1).double()
+    tol = 3e-4 if backend.name == "emu" else 3e-3
+    assert_close_with_nonfinite(outs[0][0], dW0.double() + Acat.t() @ G.cpu().double(), tol, 2e-5, "dW deterministic")
+    assert_close_with_nonfinite(outs[0][1], db0.double() + G.cpu().double().sum(0), tol, 2e-5, "db deterministic")
+    assert_close_with_nonfinite(dWa, outs[0][0], tol, 2e-5, "atomic vs deterministic")

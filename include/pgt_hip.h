@@ -23,7 +23,6 @@
  *                         dcrnn.py:39-40,86-87,95-100,300-313; astgcn.py:169-175,185-190; evolvegcno.py:95-101
  *                         (index_select -> norm*x_j -> scatter_add, fused, with the 2*P*T - T0 epilogue of dcrnn.py:96,100)
  *   pgt_spmm_ellw_f32     the same propagate call sites on a locality-ordered graph (ELLW layout, LDS window)
- *   pgt_dconv_fused_*     a whole gate convolution of the DCRNN cell: dcrnn.py:79-111 with the gate chains :172-192
  *   pgt_dconv_stack_slab* the K-hop recursion dcrnn.py:85-106 (all propagate calls of one DConv) for small graphs
  *   pgt_gemm_f32          the dense feature transforms: dcrnn.py:81-83,88-92,101-105 (torch.matmul on weight[d][k]);
  *                         PyG Linear in GCNConv/ChebConv; temporalgcn.py:84,90,96 (linear_{z,r,h})
@@ -314,24 +313,6 @@ int pgt_axpby2d_f32(float* dst, int64_t ldd, const float* x, int64_t ldx, float 
                     float b, int64_t M, int64_t W, pgt_stream_t stream);
 /* [D0][D1][W] -> [D1][D0][W] blocked transpose of W-float records (batch-major <-> node-major). */
 int pgt_swap01_f32(float* dst, const float* src, int64_t D0, int64_t D1, int64_t W, pgt_stream_t stream);
-
-/* ---------------------------------------------------------------- fused diffusion convolution + gate (small graphs)
- * One launch per gate convolution of the DCRNN cell (dcrnn.py:79-111 + :172-192) for a batch of samples sharing one small
- * graph, K = 3, hidden width 64: a 512-thread workgroup per sample keeps T_0 and the term being produced in LDS next to
- * both operators and multiplies every term by its weight block out of LDS (v_mfma_f32_32x32x2_f32) — the stack is still
- * stored (segments 1..4 of TS, for the weight gradient) but never re-read by a separate GEMM.  Stack layout as for
- * pgt_dconv_stack_slab_f32 (batch-major rows, segment 0 = T_0 = [X_t, H] given).  W: [5 C, NOUT] row-major.
- *   _zr: NOUT = 2 O; ZR[m, :] = sigmoid(.);  XHR[m, Fin + o] = H[m, o] * R[m, o]  (XHR: segment 0 of the candidate's stack)
- *   _h : NOUT = O;   HT = tanh(.);  Hout = Z * Hp + (1 - Z) * HT;  Hnext (nullable) gets a second copy.
- * Sums run in a different order than pgt_gemm_f32's (k interleaved by pairs): equal to 1e-6, not bit for bit. */
-int pgt_dconv_fused_fits(int64_t N, int64_t C, int64_t O, int64_t K, int64_t nnz_o, int64_t nnz_i);
-int pgt_dconv_fused_zr_f32(const pgt_csr* fwd_o, const pgt_csr* fwd_i, int64_t nnz_o, int64_t nnz_i, int64_t N,
-                           int64_t n_samples, int64_t C, int64_t Fin, int64_t O, float* TS, int64_t seg_stride,
-                           const float* W, const float* bias, float* ZR, float* XHR, int64_t ldxhr, pgt_stream_t stream);
-int pgt_dconv_fused_h_f32(const pgt_csr* fwd_o, const pgt_csr* fwd_i, int64_t nnz_o, int64_t nnz_i, int64_t N,
-                          int64_t n_samples, int64_t C, int64_t Fin, int64_t O, float* TS, int64_t seg_stride,
-                          const float* W, const float* bias, float* HT, const float* ZR, const float* Hp, int64_t ldhp,
-                          float* Hout, int64_t ldo, float* Hnext, int64_t ldn, pgt_stream_t stream);
 
 /* ---------------------------------------------------------------- dense attention scores (ASTGCN)
  * S[b] = softmax_dim1( V . sigmoid( L[b] R[b] + bias ) )  (SpatialAttention astgcn.py:226-262 with n = nodes, m = time steps;

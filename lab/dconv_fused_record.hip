@@ -1,3 +1,19 @@
+// LAB RECORD (not built into the library): the per-sample fused diffusion convolution + gate kernel of DESIGN.md section 9
+// ("stack in LDS -> MFMA"), built, parity-green on the CPU test double and on the GPU (commit "Fused diffusion
+// convolution + gate kernel", tests/test_dcrnn.py at that commit) and MEASURED at the benchmark shape (B = 1024,
+// N = 207, C = 66, hidden 64; scripts at that commit: scripts/fused_probe.py):
+//
+//     two-launch path (stack kernel + gate-fused GEMM)     zr: 82 + 253 = 335 us      h: 82 + 154 = 236 us
+//     this kernel                                          zr: 492 us                 h: 410 us
+//     ... with the MFMAs removed 306 us, with the gathers removed 375 us, with the stack stores removed 435 us,
+//     with all three removed 160 us (T_0 loads, nine barriers, epilogue)
+//
+// The parts ADD: one resident workgroup per CU (two [N, C + 4] blocks + both operators = 142 KB of LDS leave no room for
+// a second one) runs load -> MFMA -> gather -> MFMA -> ... strictly in sequence, so MFMA (46 us per sample, 31 us ideal),
+// LDS gathers (29 us), stack stores (14 us) and the skeleton (40 us) never overlap, while the two-launch path keeps four
+// GEMM workgroups per CU in different phases.  Even with ideal MFMA issue and the stack kernel's gather speed the sum
+// is ~80 us per sample = 320 us per launch: parity at best.  The step stays on the two-launch path.
+//
 // Fused diffusion convolution + gate for small graphs (K = 3): the five diffusion terms of one DConv never leave the CU
 // between the aggregation and the feature transform.
 //
@@ -40,6 +56,7 @@ struct FusedArgs {
   const float* Hp; int64_t ldhp;     // h: previous hidden state
   float* Hout; int64_t ldo;          // h: new hidden state
   float* Hnext; int64_t ldn;         // h: second copy (next step's stack slot) or null
+  int dbg;                           // lab switches (pgt_tune("dconv_fused_dbg")): 1 = no MFMA, 2 = no gathers, 4 = no stack stores
 };
 
 constexpr int FUSED_THREADS = 512;   // 8 wavefronts, two per SIMD: 256 registers per lane (four accumulator tiles + the held second hop)
@@ -96,43 +113,57 @@ __global__ __launch_bounds__(FUSED_THREADS) void dconv_fused_kernel(FusedArgs a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // acc += buf[N, Kp] @ W[seg * C : (seg + 1) * C, tile columns]
-    auto mma_term = [&](const float* buf, int seg) {
+    // Weight rows of one chunk (four groups of four k = 16 rows of the term) for this lane's output column: rows
+    // 4g + 2 hi and 4g + 2 hi + 1 of every group.  L2-resident: every workgroup reads the same [5 C, NOUT] block.
+    // A term's first chunk is requested BEFORE the gather phase that precedes its MFMAs, the following chunks one
+    // chunk (>= 32 MFMAs per wavefront) ahead of their use.
+    const int n_groups = Kp >> 2;
+    auto load_w = [&](int seg, int g0, float (&bb)[8]) {
       const float* Wb = a.W + (int64_t)seg * C * NOUT + col;
-      int rowA[TPW];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kb = 4 * (g0 + u) + 2 * hi;
+        bb[2 * u] = kb < C ? Wb[kb * NOUT] : 0.f;
+        bb[2 * u + 1] = kb + 1 < C ? Wb[(kb + 1) * NOUT] : 0.f;
+      }
+    };
+    // acc += buf[N, Kp] @ W[seg]; bn holds the term's first chunk on entry
+    auto mma_term = [&](const float* buf, int seg, float (&bn)[8]) {
+      const int my_tiles = rs < n_rt ? (n_rt - rs + RSLOTS - 1) / RSLOTS : 0;     // wave-uniform
+      if (my_tiles == 0 || (a.dbg & 1)) return;
+      const float* pa[TPW];
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
-        int row = (rs + j * RSLOTS) * 32 + lo;
-        rowA[j] = (row < N ? row : N - 1) * CP + 2 * hi;
-      }
-      const int my_tiles = rs < n_rt ? (n_rt - rs + RSLOTS - 1) / RSLOTS : 0;     // wave-uniform
-      if (my_tiles == 0) return;
-      float b0 = 0.f, b1 = 0.f;
-      {
-        const int kb = 2 * hi;
-        b0 = kb < C ? Wb[(int64_t)kb * NOUT] : 0.f;
-        b1 = kb + 1 < C ? Wb[(int64_t)(kb + 1) * NOUT] : 0.f;
+        const int row = (rs + j * RSLOTS) * 32 + lo;
+        pa[j] = buf + (row < N ? row : N - 1) * CP + 2 * hi;
       }
 #pragma unroll 1
-      for (int g = 0; g < Kp; g += 4) {
-        float n0 = 0.f, n1 = 0.f;
-        const int kb = g + 4 + 2 * hi;                  // next group's weight rows, in flight during this group's MFMAs
-        if (kb < C) n0 = Wb[(int64_t)kb * NOUT];
-        if (kb + 1 < C) n1 = Wb[(int64_t)(kb + 1) * NOUT];
+      for (int g0 = 0; g0 < n_groups; g0 += 4) {
+        float bc[8];
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-          if (j < my_tiles) {
-            const float2 aj = *reinterpret_cast<const float2*>(buf + rowA[j] + g);
-            acc[j] = PGT_MFMA_32x32x2(aj.x, b0, acc[j]);
-            acc[j] = PGT_MFMA_32x32x2(aj.y, b1, acc[j]);
+        for (int u = 0; u < 8; ++u) bc[u] = bn[u];
+        if (g0 + 4 < n_groups) load_w(seg, g0 + 4, bn);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (g0 + u < n_groups) {
+            float2 ac[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) ac[j] = *reinterpret_cast<const float2*>(pa[j] + 4 * (g0 + u));
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+              if (j < my_tiles) {
+                acc[j] = PGT_MFMA_32x32x2(ac[j].x, bc[2 * u], acc[j]);
+                acc[j] = PGT_MFMA_32x32x2(ac[j].y, bc[2 * u + 1], acc[j]);
+              }
+            }
           }
         }
-        b0 = n0; b1 = n1;
       }
     };
     // sum over the slots of row r of (val * src[col, pair p]); four slots' LDS reads in flight
     auto gather = [&](const int* rp, const int2* cv, const float* src, int r, int p) {
       float2 s = make_float2(0.f, 0.f);
+      if (a.dbg & 2) return s;
       int q = rp[r];
       const int e = rp[r + 1];
       for (; q + 4 <= e; q += 4) {
@@ -153,7 +184,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void dconv_fused_kernel(FusedArgs a)
       }
       return s;
     };
-    mma_term(sA, 0);
+    float bw[8];
+    load_w(0, 0, bw);
+    mma_term(sA, 0, bw);
 #pragma unroll 1
     for (int d = 0; d < 2; ++d) {
       const int* rp = d ? rp_i : rp_o;
@@ -167,16 +200,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void dconv_fused_kernel(FusedArgs a)
         }
         __syncthreads();
       }
+      load_w(seg1, 0, bw);                            // in flight during the first hop
       // first hop: T_1 = P T_0 -> sB (and the stack)
       float* g1 = a.TS + (int64_t)seg1 * a.seg_stride + (int64_t)b * blk;
       for (int t = tid; t < n_tasks; t += FUSED_THREADS) {
         const int r = t / NP, p = t - r * NP;
         const float2 v = gather(rp, cv, sA, r, p);
         *reinterpret_cast<float2*>(sB + r * CP + 2 * p) = v;
-        *reinterpret_cast<float2*>(g1 + 2 * t) = v;
+        if (!(a.dbg & 4)) *reinterpret_cast<float2*>(g1 + 2 * t) = v;
       }
       __syncthreads();
-      mma_term(sB, seg1);
+      mma_term(sB, seg1, bw);
+      load_w(seg2, 0, bw);                            // in flight during the second hop
       // second hop: T_2 = 2 P T_1 - T_0 written IN PLACE over T_0 (each element of sA is read and rewritten by its own
       // task only; every other access of this phase — the gathers and the MFMAs of T_1 — reads sB)
       float* g2 = a.TS + (int64_t)seg2 * a.seg_stride + (int64_t)b * blk;
@@ -187,10 +222,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void dconv_fused_kernel(FusedArgs a)
         const float2 x0 = *own;
         const float2 v = make_float2(2.f * s2.x + -1.f * x0.x, 2.f * s2.y + -1.f * x0.y);
         *own = v;
-        *reinterpret_cast<float2*>(g2 + 2 * t) = v;
+        if (!(a.dbg & 4)) *reinterpret_cast<float2*>(g2 + 2 * t) = v;
       }
       __syncthreads();
-      mma_term(sA, seg2);
+      mma_term(sA, seg2, bw);
       __syncthreads();                                 // sA / sB are free again
     }
 
@@ -240,13 +275,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void dconv_fused_kernel(FusedArgs a)
   }
 }
 
+int g_fused_dbg = 0;     // see FusedArgs::dbg
+
 static size_t fused_lds_bytes(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i) {
   const int64_t CP = ((C + 3) & ~(int64_t)3) + 2;
   return (size_t)(2 * N * CP * 4 + (nnz_o + nnz_i) * 8 + 2 * (N + 1) * 4);
 }
 
 static bool fused_fits(int64_t N, int64_t C, int64_t O, int64_t nnz_o, int64_t nnz_i, int nout) {
-  if (N < 1 || N > 256 || C < 2 || C % 2 != 0 || O < 32 || O % 32 != 0) return false;
+  if (N < 1 || N > 256 || C < 2 || C % 2 != 0 || C > 128 || O < 32 || O % 32 != 0) return false;
   if (nout != 64 && nout != 128) return false;
   return fused_lds_bytes(N, C, nnz_o, nnz_i) <= (size_t)FUSED_LDS;
 }
@@ -260,7 +297,7 @@ static int fused_common(const char* who, const pgt_csr* fo, const pgt_csr* fi, i
   PGT_REQUIRE(seg_stride >= n_samples * N * C && seg_stride % 2 == 0 && pgt_aligned(TS, 8), "%s: bad stack layout", who);
   *g = FusedArgs{fo->rowptr, fo->col, fo->val, fi->rowptr, fi->col, fi->val, (int)N, (int)C, (int)Fin, (int)O, (int)nnz_o,
                  (int)nnz_i, (int)n_samples, TS, seg_stride, W, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr,
-                 0, nullptr, 0};
+                 0, nullptr, 0, g_fused_dbg};
   return PGT_OK;
 }
 
@@ -270,6 +307,7 @@ int g_fused_wgs = 256;   // workgroups launched (one per CU); pgt_tune("dconv_fu
 
 int pgt_fused_tune(const char* key, int value) {
   if (strcmp(key, "dconv_fused_wgs") == 0) { g_fused_wgs = value > 0 ? value : 256; return 1; }
+  if (strcmp(key, "dconv_fused_dbg") == 0) { g_fused_dbg = value; return 1; }
   return 0;
 }
 

@@ -8,7 +8,6 @@
 #include <algorithm>
 #include <vector>
 
-int pgt_fused_tune(const char*, int) { return 0; }
 void pgt_gemm_set_force_small(int) {}
 void pgt_gemm_set_small_fill(int) {}
 void pgt_gemm_set_tn_fullk(int) {}

@@ -17,7 +17,6 @@ __device__ long long* g_trace_buf = nullptr;
       g_trace_buf[(size_t)blockIdx.x * 16 + (slot)] = (long long)wall_clock64();          \
   } while (0)
 
-int pgt_fused_tune(const char*, int) { return 0; }
 void pgt_gemm_set_force_small(int) {}
 void pgt_gemm_set_small_fill(int) {}
 void pgt_gemm_set_tn_fullk(int) {}

@@ -75,12 +75,6 @@ PROTOTYPES = {
                                          c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
     "pgt_dconv_stack_slab_bwd_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64,
                                              c_i64, c_i64, c_i64, c_ptr, c_i64, c_int, c_ptr]),
-    "pgt_dconv_fused_fits": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, c_i64]),
-    "pgt_dconv_fused_zr_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64, c_i64, c_i64,
-                                       c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
-    "pgt_dconv_fused_h_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64, c_i64, c_i64,
-                                      c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
-                                      c_i64, c_ptr]),
     "pgt_gemm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64,
                              c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "pgt_gemm_gru_zr_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64,

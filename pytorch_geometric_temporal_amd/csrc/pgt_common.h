@@ -88,7 +88,6 @@ void pgt_gemm_set_tn_pipe(int v);
 void pgt_gemm_set_skinny(int v);
 void pgt_gemm_set_dbp(int v);
 int pgt_spmm_tune(const char* key, int value);  // returns 1 when the key is known
-int pgt_fused_tune(const char* key, int value);
 
 #define PGT_REQUIRE(cond, ...)            \
   do {                                    \

@@ -61,7 +61,6 @@ extern "C" int pgt_tune(const char* key, int value) {
     return PGT_OK;
   }
   if (pgt_spmm_tune(key, value)) return PGT_OK;
-  if (pgt_fused_tune(key, value)) return PGT_OK;
   pgt_set_error("pgt_tune: unknown key '%s'", key);
   return PGT_ERR_INVALID;
 }

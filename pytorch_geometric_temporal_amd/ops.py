@@ -425,9 +425,6 @@ SPLIT_FEATURE_GRADIENT = os.environ.get("PGT_SPLIT_FG", "1") != "0"
 # over the per-slab partial sums.  Off by default (the atomics are ~2 % faster at the benchmark shape); PGT_DETERMINISTIC=1
 # or ops.DETERMINISTIC_WEIGHT_GRADIENTS = True turns it on.
 DETERMINISTIC_WEIGHT_GRADIENTS = os.environ.get("PGT_DETERMINISTIC", "0") == "1"
-# forward gate convolutions of the DCRNN cell as one launch each (pgt_dconv_fused_zr/h_f32: diffusion terms multiplied by
-# their weight blocks straight out of LDS) instead of stack kernel + GEMM; K = 3, hidden 64, graphs that fit a CU's LDS
-FUSED_DCONV = os.environ.get("PGT_FUSED_DCONV", "0") == "1"
 
 
 def gemm_gru_zr(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, bias, zr, H, xhr, f_in):
@@ -629,34 +626,6 @@ def _slab_bwd(g, G0, seg_stride, n_samples, C, K, folded):
         seg_stride, int(bool(folded)), stream_of(lib, G0)))
 
 
-def fused_dconv_fits(g, C, O, K):
-    """True when the fused diffusion-convolution + gate kernels (pgt_dconv_fused_zr/h_f32) cover this shape."""
-    lib = _lib.get_lib()
-    return bool(lib._pgt_dconv_fused_fits(g.N, int(C), int(O), int(K), g.E, g.E))
-
-
-def _fused_zr(g, TS0, seg_stride, n_samples, C, Fin, O, W, bias, ZR, XHR):
-    lib = _lib.get_lib()
-    so, si = g.fwd_o.struct(), g.fwd_i.struct()
-    M = n_samples * g.N
-    _timed("fused", 2.0 * M * 5 * C * 2 * O, lambda: lib.call(
-        "pgt_dconv_fused_zr_f32", ctypes.byref(so), ctypes.byref(si), g.E, g.E, g.N, n_samples, C, Fin, O, ptr(TS0),
-        seg_stride, ptr(W), ptr(bias), ptr(ZR), ptr(XHR), XHR.stride(0), stream_of(lib, TS0)), tag=("zr", M, 2 * O, 5, C))
-
-
-def _fused_h(g, TS0, seg_stride, n_samples, C, Fin, O, W, bias, HT, ZR, Hp, Hout, Hnext):
-    lib = _lib.get_lib()
-    so, si = g.fwd_o.struct(), g.fwd_i.struct()
-    M = n_samples * g.N
-    hp, ldh = _rows(Hp, "Hp")
-    op, ldo = _rows(Hout, "Hout")
-    np_, ldn = _rows(Hnext, "Hnext") if Hnext is not None else (ptr(None), 0)
-    _timed("fused", 2.0 * M * 5 * C * O, lambda: lib.call(
-        "pgt_dconv_fused_h_f32", ctypes.byref(so), ctypes.byref(si), g.E, g.E, g.N, n_samples, C, Fin, O, ptr(TS0),
-        seg_stride, ptr(W), ptr(bias), ptr(HT), ptr(ZR), hp, ldh, op, ldo, np_, ldn, stream_of(lib, TS0)),
-        tag=("h", M, O, 5, C))
-
-
 class _StackWeight(torch.autograd.Function):
     """DConv weight [2,K,C,O] -> [(2K-1)*C, O] with three copies forward and three backward (torch's slice / cat graph
     of the same rearrangement costs ~30 tiny launches per weight and backward pass)."""
@@ -831,17 +800,11 @@ class DCRNNSeqFunction(torch.autograd.Function):
         copy2d(TSzr[0].view(T * M, C)[:, :Fin], X.view(T * M, Fin))
         copy2d(TSh[0].view(T * M, C)[:, :Fin], X.view(T * M, Fin))
         fuse = FUSE_GATE_EPILOGUES and O % 4 == 0
-        fused_conv = FUSED_DCONV and slab and fused_dconv_fits(g, C, O, K)
         for t in range(T):
             Hp = H0c if t == 0 else Hout[t - 1]
             if t == 0:
                 copy2d(TSzr[0, t][:, Fin:], Hp)     # later steps: written by the previous step's blend
             Hnext = TSzr[0, t + 1][:, Fin:] if t + 1 < T else None
-            if fused_conv:
-                # stack + feature transform + gate chain of a convolution in ONE launch (terms multiplied out of LDS)
-                _fused_zr(g, TSzr[0, t], seg, B, C, Fin, O, Wzr_c, bzr, ZR[t], TSh[0, t])
-                _fused_h(g, TSh[0, t], seg, B, C, Fin, O, Wh_c, bh, HT[t], ZR[t], Hp, Hout[t], Hnext)
-                continue
             stack(TSzr, t)
             if fuse:
                 gemm_gru_zr(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, bzr, ZR[t], Hp, TSh[0, t], Fin)

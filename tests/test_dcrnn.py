@@ -295,45 +295,3 @@ try:
         assert_close_with_nonfinite(base[0], ref, 2e-5, 2e-5, "oracle")
 except ImportError:      # hypothesis is optional
     pass
-
-
-@pytest.mark.parametrize("n_nodes,B,T", [(37, 3, 2), (207, 2, 2), (64, 5, 1)])
-def test_fused_diffusion_convolution_equals_the_two_launch_path(backend, n_nodes, B, T):
-    """pgt_dconv_fused_zr/h_f32 (diffusion terms multiplied by their weight blocks out of LDS, gate chain in the
-    epilogue) against stack kernel + gate-fused GEMM: hidden states, saved stacks (through the gradients) — equal to
-    1e-6 (the fused kernel sums k in interleaved pairs), and both against the fp64 oracle."""
-    from pytorch_geometric_temporal_amd import ops, _lib
-    torch.manual_seed(n_nodes)
-    fin, O, K = 2, 64, 3
-    ei_np, ew_np = syn.sensor_graph(n_nodes, 6 * n_nodes, seed=3, symmetric=False)
-    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
-    m = BatchedDCRNN(fin, O, K)
-    with torch.no_grad():
-        for p in m.parameters():
-            p.uniform_(-0.12, 0.12)
-    params64 = {k: v.detach().double().requires_grad_() for k, v in m.state_dict().items()}
-    m = m.to(backend.device)
-    X = torch.randn(B, T, n_nodes, fin)
-    w = torch.randn(B, T, n_nodes, O)
-    lib = _lib.get_lib()
-    if backend.name == "emu":
-        lib.tune("dconv_fused_wgs", 2)              # several samples per workgroup on the CPU test double
-    outs, grads = {}, {}
-    try:
-        for fused in (False, True):
-            ops.FUSED_DCONV = fused
-            m.zero_grad(set_to_none=True)
-            out = m(backend.t(X), backend.t(ei), backend.t(ew))
-            (out * backend.t(w)).sum().backward()
-            outs[fused] = out.detach().cpu()
-            grads[fused] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
-    finally:
-        ops.FUSED_DCONV = False
-        lib.tune("dconv_fused_wgs", 256)
-    g = ops.dconv_graph(backend.t(ei), backend.t(ew), n_nodes)
-    assert ops.fused_dconv_fits(g, fin + O, O, K)
-    assert_close_with_nonfinite(outs[True], outs[False], 2e-6, 2e-6, "fused vs two-launch")
-    for n in grads[True]:
-        assert_close_with_nonfinite(grads[True][n], grads[False][n], 2e-4, 1e-4, n)
-    ref = F.batched_dcrnn(X.double(), ei, ew.double(), params64)
-    assert_close_with_nonfinite(outs[True], ref, ATOL, RTOL, "fused vs fp64 oracle")

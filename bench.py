@@ -292,11 +292,14 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the drop-in / E=1722 / small-batch / other-config lines")
     args = ap.parse_args()
 
-    rank, local_rank, world = dp.init_from_env("nccl")   # "nccl" is RCCL on ROCm; no-op for a single process
+    # "nccl" is RCCL on ROCm; no-op for a single process.  PGT_BENCH_BACKEND=gloo is a self-test hook: it lets two ranks share
+    # the one GPU of a test box so that the multi-rank code path (barrier, all-reduce, MAX-reduce, rank-0 printing) runs there.
+    rank, local_rank, world = dp.init_from_env(os.environ.get("PGT_BENCH_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     pin_host_threads(local_rank, world)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     lib = _lib.get_lib()
     assert lib.target == "gfx950"
     scaling = "weak"

@@ -18,7 +18,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available() and backend != "gloo":
+    if torch.cuda.is_available():
         torch.cuda.set_device(local_rank % torch.cuda.device_count())   # bind BEFORE the communicator is created
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

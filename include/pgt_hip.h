@@ -169,8 +169,8 @@ int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const float* val, 
                    pgt_stream_t stream);
 
 /* pgt_spmm_csr_f32's contract on the ELLW layout of the same operator (the CSR arrays it was built from are passed
- * along: they serve out-of-window slots, and shapes the window kernel does not cover — F != 64, operands that are
- * not 16-byte aligned — run the CSR kernels).  Source-scale mode accumulates rounded products with rounded adds in
+ * along: they serve out-of-window slots, and shapes the window kernel does not cover — F not a multiple of 64, operands
+ * that are not 16-byte aligned — run the CSR kernels; F = 64 k (node-major batches) runs k column chunks per tile).  Source-scale mode accumulates rounded products with rounded adds in
  * slot order (the reference's `norm * x_j` then scatter-add); per-slot mode is the CSR kernels' fmaf chain, bit for bit. */
 int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                       const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha,

@@ -247,6 +247,11 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   const int r0 = tile * TR, w0 = r0 - H, WR = TR + 2 * H;
   const int nr = (n_rows - r0 < TR) ? (n_rows - r0) : TR;
   const int W8 = W8C > 0 ? W8C : (W >> 3);             // slot vectors (8 x u16) per row
+  // rows wider than 64 floats (node-major batches, F = B * C): blockIdx.y picks a 64-float column chunk; the window of
+  // a chunk is the 256-byte segment of each window row, the slot block is shared by all chunks of the tile
+  const int chunk0 = (int)blockIdx.y * 64;
+  X += chunk0; Y += chunk0;
+  if (T != nullptr) T += chunk0;
   const float* Xl = X + l16 * 4;
   // ---- one memory phase: window rows, their source scales, the tile's slot block (and coefficient block)
   pgt_f4 xw[XPT];
@@ -337,11 +342,17 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
         }
       }
     };
+    // padding sits at the end of a row: a slot vector whose FIRST slot is padding (the zero row) is all padding, and so
+    // are the vectors behind it — rows shorter than the layout's width stop early (out-degree spread of P_i: longest
+    // row 20 slots -> width 24, mean 8)
     if constexpr (W8C > 0) {
+      chunk(0);
 #pragma unroll
-      for (int c8 = 0; c8 < W8C; ++c8) chunk(c8);
+      for (int c8 = 1; c8 < W8C; ++c8)
+        if ((s_slots[r * W8 + c8].x & 0xffffu) != (unsigned)WR) chunk(c8);
     } else {
-      for (int c8 = 0; c8 < W8; ++c8) chunk(c8);
+      chunk(0);
+      for (int c8 = 1; c8 < W8 && (s_slots[r * W8 + c8].x & 0xffffu) != (unsigned)WR; ++c8) chunk(c8);
     }
     float out[4];
     if (T != nullptr) {
@@ -750,10 +761,10 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
   vp.width(F); vp.operand(X, ldx); vp.operand(Y, ldy); vp.operand(T, ldt);
   const int64_t max_ld = ldx > ldy ? (ldx > ldt ? ldx : ldt) : (ldy > ldt ? ldy : ldt);
   // shapes the window kernel does not cover run the CSR row tiles (same sums, fmaf chain)
-  if (!g_ellw || F != 64 || vp.v != 4 || (n_rows + EllwCfgA::WRMAX) * max_ld >= ((int64_t)1 << 31))
+  if (!g_ellw || F % 64 != 0 || F / 64 > 65535 || vp.v != 4 || (n_rows + EllwCfgA::WRMAX) * max_ld >= ((int64_t)1 << 31))
     return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   const int flags = (g_tile_xcd ? 1 : 0) | (g_tile_nt ? 2 : 0);
-  dim3 grid((unsigned)op->n_tiles);
+  dim3 grid((unsigned)op->n_tiles, (unsigned)(F / 64));   // y: 64-float column chunks (1 for the F = 64 north-star shape)
 #define PGT_ELLW_GO(MODE_, CFG_, W8C_)                                                                                \
   PGT_LAUNCH((spmm_ellw64_kernel<MODE_, CFG_, W8C_>), grid, dim3(CFG_::THREADS), stream, op->slots, op->vals, op->scale, \
              rowptr, col, val, (int)n_rows, (int)op->tile_rows, (int)op->halo, (int)op->width, X, (int)ldx, Y, (int)ldy,  \

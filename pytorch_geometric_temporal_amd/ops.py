@@ -368,7 +368,7 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
     tp, ldt = _rows(T, "T") if T is not None else (ptr(None), 0)
     st = stream_of(lib, X)
     op = None
-    if X.size(1) == 64 and (ellw if ellw is not None else USE_ELLW):
+    if X.size(1) % 64 == 0 and X.size(1) > 0 and (ellw if ellw is not None else USE_ELLW):
         if ellw and getattr(csr, "ellw", None) is None:
             _force_ellw(csr)
         op = ellw_of(csr)

@@ -518,8 +518,9 @@ def test_spmm_ellw_strided_nonfinite_and_fallback_shapes(backend):
     ops.spmm(csr, X, Y)
     assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "ellw strided")
     assert float(out[:, :4].abs().max()) == 0.0 and float(out[:, 68:].abs().max()) == 0.0
-    # shapes the window kernel does not cover run the CSR kernels: other widths, operands that are not 16-byte aligned
-    for F_ in (32, 66, 128):
+    # multiples of 64 run one column chunk per 64 floats; other widths and operands that are not 16-byte aligned run
+    # the CSR kernels under the same entry point
+    for F_ in (32, 66, 128, 320):
         Xf = torch.randn(n, F_).to(backend.device)
         Yf = torch.empty_like(Xf)
         ops.spmm(csr, Xf, Yf)
@@ -534,6 +535,21 @@ def test_spmm_ellw_strided_nonfinite_and_fallback_shapes(backend):
     Xh, Yh = torch.randn(n, 64).to(backend.device), torch.empty(n, 64, device=backend.device)
     ops.spmm(heavy, Xh, Yh, ellw=True)
     assert_close_with_nonfinite(Yh, spmm_reference(heavy, Xh, None, 1.0, 0.0), 5e-5, 1e-5, "heavy row")
+
+
+def test_spmm_ellw_wide_rows_run_column_chunks(backend):
+    """F = 64 k (node-major batches [N][B C]): k column chunks per tile, bit-identical to the CSR kernels in per-slot mode,
+    with the epilogue and strided operands."""
+    n = 260 if backend.name == "emu" else 30_000
+    csr = banded_csr(n, 0, 12, 28, seed=3, device=backend.device, far_frac=0.02)
+    assert ops._force_ellw(csr, 32) is not None
+    big = torch.randn(n, 200).to(backend.device)
+    X, T = big[:, 4:196], torch.randn(n, 192).to(backend.device)
+    Ya, Yb = torch.full((n, 192), float("nan"), device=backend.device), torch.empty(n, 192, device=backend.device)
+    ops.spmm(csr, X, Ya, T=T, alpha=2.0, beta=-1.0)
+    ops.spmm(csr, X, Yb, T=T, alpha=2.0, beta=-1.0, ellw=False)
+    assert torch.equal(Ya, Yb)
+    assert_close_with_nonfinite(Ya, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "wide rows")
 
 
 def test_ellw_plan_fills_whole_rounds_of_the_cus(backend):
@@ -1232,7 +1248,7 @@ try:
         lib.tune("spmm_ellw_cfg", cfg)
         try:
             Y = torch.full((n, F_), float("nan")).to(dev)
-            use_ellw = halo > 0 and F_ == 64 and nnz > 0
+            use_ellw = halo > 0 and F_ % 64 == 0 and nnz > 0
             if use_ellw:
                 e = ops._force_ellw(csr, halo)
                 assert (e is None) == (max(deg) > 32)

@@ -1,5 +1,8 @@
 #!/bin/bash
-# builds lab/ns_lab (kernel lab harness; cross-compiles without a GPU)
+# builds the kernel lab harnesses under lab/ (cross-compiles without a GPU; the binaries are git-ignored and travel to the
+# GPU box with gpurun)
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include -I pytorch_geometric_temporal_amd/csrc lab/ns_lab.hip -o lab/ns_lab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include -I pytorch_geometric_temporal_amd/csrc lab/gemm_lab.hip -o lab/gemm_lab
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include -I pytorch_geometric_temporal_amd/csrc"
+for h in ellw_lab ellw_prod_lab gemm_lab; do
+  /opt/rocm/bin/hipcc $FLAGS lab/$h.hip -o lab/$h || exit 1
+done

@@ -489,6 +489,49 @@ def baseline_c5_evolvegcnh_covid():
             wmax = max(wmax, float(snap.edge_attr.max()))
     return _pack({}, layer, {"out": torch.stack(outs)}, {"snapshots": len(outs), "max_weight": wmax})
 
+
+@case
+def baseline_c1_chickenpox_epoch():
+    """config 1: the reference example's loop (examples/recurrent/dcrnn_example.py:19-46) with the reference's own modules:
+    ChickenpoxDatasetLoader (fed from the vendored JSON) -> temporal_signal_split(0.2) -> DCRNN(4, 32, 1) + Linear(32, 1),
+    cost = mean over the 103 train snapshots of the MSE, one backward.  Stored: the cost, the first predictions, every
+    parameter gradient."""
+    from . import baseline_cases as BC
+    m = R.load("nn.recurrent.dcrnn")
+    ds_mod = R.load_dataset("chickenpox")
+    loader = ds_mod.ChickenpoxDatasetLoader.__new__(ds_mod.ChickenpoxDatasetLoader)
+    with open(os.path.join(R.REFERENCE_ROOT, "dataset", "chickenpox.json")) as f:
+        loader._dataset = json.load(f)
+    dataset = loader.get_dataset()
+    # temporal_signal_split(dataset, train_ratio=0.2) (signal/train_test_split.py: int(ratio * snapshot_count) leading
+    # snapshots; the module itself imports the batch iterators, which need torch_geometric.data.Batch)
+    train = dataset[0:int(0.2 * dataset.snapshot_count)]
+
+    class RecurrentGCN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.recurrent = m.DCRNN(4, 32, 1)
+            self.linear = torch.nn.Linear(32, 1)
+
+        def forward(self, x, edge_index, edge_weight):
+            return self.linear(torch.relu(self.recurrent(x, edge_index, edge_weight)))
+
+    model = RecurrentGCN()
+    BC.randomise(model, 610, gain=0.5)
+    cost, preds, n = 0, [], 0
+    for snap in train:
+        y_hat = model(snap.x, snap.edge_index, snap.edge_attr)
+        if n < 3:
+            preds.append(y_hat.detach())
+        cost = cost + torch.mean((y_hat - snap.y) ** 2)
+        n += 1
+    cost = cost / n
+    cost.backward()
+    outs = {"cost": cost.detach(), "pred_head": torch.stack(preds)}
+    for k, p in model.named_parameters():
+        outs["grad/" + k] = p.grad.detach()
+    return _pack({}, model, outs, {"snapshots": n})
+
 # ------------------------------------------------------------------------------------------------ signal iterator
 
 @case

@@ -212,3 +212,46 @@ def test_config5_oracle_reproduces_the_reference_fixture():
         for s, snap in enumerate(_covid_signal()):
             out, W = F.evolvegcnh_step(snap.x, snap.edge_index, snap.edge_attr, W, p)
             assert_close_with_nonfinite(out, g["out"]["out"][s], 2e-5, 2e-5, f"snapshot {s}")
+
+
+# ------------------------------------------------------------------------------------------------ config 1
+
+def test_config1_chickenpox_epoch_cost_and_gradients(backend):
+    """BASELINE.json configs[0]: the reference example's epoch (examples/recurrent/dcrnn_example.py:19-46) — our
+    ChickenpoxDatasetLoader + temporal_signal_split + DCRNN(4, 32, 1) + torch Linear, 103 train snapshots, cost = mean
+    MSE, one backward — against the cost, the first predictions and EVERY parameter gradient of the reference's own
+    loader / iterator / module running the same loop."""
+    from pytorch_geometric_temporal_amd.dataset import ChickenpoxDatasetLoader
+    from pytorch_geometric_temporal_amd.nn.recurrent import DCRNN
+    from pytorch_geometric_temporal_amd.signal import temporal_signal_split
+    g = load_golden("baseline_c1_chickenpox_epoch")
+
+    class RecurrentGCN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.recurrent = DCRNN(4, 32, 1)
+            self.linear = torch.nn.Linear(32, 1)
+
+        def forward(self, x, edge_index, edge_weight):
+            return self.linear(torch.relu(self.recurrent(x, edge_index, edge_weight)))
+
+    model = RecurrentGCN()
+    model.load_state_dict(g["param"], strict=True)
+    model = model.to(backend.device)
+    train, _ = temporal_signal_split(ChickenpoxDatasetLoader().get_dataset(), train_ratio=0.2)
+    train = train.to(backend.device)
+    cost, preds, n = 0, [], 0
+    for snap in train:
+        y_hat = model(snap.x, snap.edge_index, snap.edge_attr)
+        if n < 3:
+            preds.append(y_hat.detach())
+        cost = cost + torch.mean((y_hat - snap.y) ** 2)
+        n += 1
+    assert n == int(g["meta"]["snapshots"]) == 103
+    cost = cost / n
+    cost.backward()
+    assert_close_with_nonfinite(torch.stack(preds), g["out"]["pred_head"], ATOL, RTOL, "first predictions")
+    assert_close_with_nonfinite(cost.detach(), g["out"]["cost"], 1e-6, 1e-5, "epoch cost")
+    for name, p in model.named_parameters():
+        ref = g["out"]["grad/" + name]
+        assert_close_with_nonfinite(p.grad, ref, 1e-6 + 1e-4 * float(ref.abs().max()), 1e-4, "grad " + name)

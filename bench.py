@@ -169,7 +169,8 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
     cannot keep X resident between launches: X really comes from HBM every time."""
     res = {}
     n = 200_000
-    for name, gen, deg in (("local", syn.local_graph, 8), ("uniform", syn.uniform_graph, 8), ("local_deg16", syn.local_graph, 16)):
+    for name, gen, deg in (("local", syn.local_graph, 8), ("uniform", syn.uniform_graph, 8), ("local_deg16", syn.local_graph, 16),
+                           ("local_hubs_20x2000", syn.hub_graph, 8)):
         ei_np, ew_np = gen(n, deg, seed=0)
         g = ops.DConvGraph(torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device), n)
         Xs = [torch.randn(n, 64, device=device) for _ in range(pairs)]
@@ -203,7 +204,9 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
         res[name] = {"us_per_launch": us, "us_per_launch_replays": times, "algorithmic_MB": nbytes / 1e6,
                      "achieved_GBs": nbytes / us / 1e3, "frac": nbytes / us / 1e3 / HBM_PEAK_GBS, "edges": int(g.E),
                      "in_degree": deg,
-                     "kernel": ("spmm_tile_kernel<4,16,32,8> (CSR row tiles, pgt_spmm_csr_f32)" if e is None else
+                     "kernel": (("spmm_tile_kernel<4,16,32,8> (CSR row tiles, pgt_spmm_csr_f32)" if g.fwd_o.long_rows is None else
+                                 f"spmm_tile_kernel + spmm_long_rows_kernel (pgt_spmm_csr_long_f32: {g.fwd_o.long_rows.numel()} rows "
+                                 f"longer than {ops.LONG_ROW} slots, one workgroup each; longest {g.fwd_o.max_len})") if e is None else
                                 f"spmm_ellw64_kernel<{0 if e.scale is not None else 1}> (pgt_spmm_ellw_f32: "
                                 f"{e.n_tiles} tiles of {e.tile_rows} rows x {e.width} slots, halo {e.halo}, "
                                 f"{'per-source scale table' if e.scale is not None else 'per-slot coefficients'}, "

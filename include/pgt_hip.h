@@ -176,10 +176,22 @@ int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, const int32_t* 
                       const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha,
                       float beta, int64_t F, pgt_stream_t stream);
 
-/* out3[0] = #slots with |col - row| <= 32, out3[1] = #slots with |col - row| <= 96, out3[2] = slots of the longest
- * row (device int32[3]); the host decides from these whether the ELLW layout applies, once per prepared graph. */
-int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out3,
-                     pgt_stream_t stream);
+/* out4[0] = #slots with |col - row| <= 32, out4[1] = #slots with |col - row| <= 96, out4[2] = slots of the longest row,
+ * out4[3] = #rows longer than long_len (device int32[4]); the first min(out4[3], long_cap) of those rows are listed in
+ * long_rows (int32 [long_cap], any order; NULL / long_cap 0: no list).  The host decides from these, once per prepared
+ * graph, whether the ELLW layout applies and which rows go to the long-row kernel. */
+int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out4, int32_t* long_rows,
+                     int64_t long_cap, int32_t long_len, pgt_stream_t stream);
+
+/* pgt_spmm_csr_f32 for operators with hubs: rows longer than long_len (the n_long rows listed in long_rows, from
+ * pgt_csr_locality) are skipped by the row tiles and produced by one 1024-thread workgroup each, the lane groups taking
+ * the row's slots round-robin and meeting in LDS (a fixed order: deterministic; the sums of those rows run in a
+ * different order than the sequential chain).  Without it a 2 000-slot row costs 660 us and a 20 000-slot row 6.4 ms at
+ * N = 200 000 (one lane group walks the row).  F beyond the tile kernels' 256 floats runs pgt_spmm_csr_f32 unchanged. */
+int pgt_spmm_csr_long_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                          const int32_t* long_rows, int64_t n_long, int32_t long_len, const float* X, int64_t ldx,
+                          float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha, float beta, int64_t F,
+                          pgt_stream_t stream);
 
 /* Same with a per-batch dense attention multiplier (ChebConvAttention hop 1, astgcn.py:157,169-171):
  * rows are node-major [N][B][C]; the coefficient of slot q of row i for batch b is val[q] * S[b, i, col[q]]

@@ -87,7 +87,7 @@ template <int VEC, int LPR, int TR, int U>
 __global__ __launch_bounds__(256) void spmm_tile_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     int n_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy, const float* T,
-    int64_t ldt, float alpha, float beta, int F, int xcd_remap) {
+    int64_t ldt, float alpha, float beta, int F, int xcd_remap, int skip_len) {
   constexpr int CAP = CAP_PER_ROW * TR;
   __shared__ int s_rp[TR + 1];
   __shared__ int s_col[CAP];
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
 
   for (int r = g; r < nr; r += GROUPS) {
     const int a = s_rp[r] - e0, b = s_rp[r + 1] - e0;
+    if (skip_len > 0 && b - a > skip_len) continue;   // a long row: spmm_long_rows_kernel produces it (pgt_spmm_csr_long_f32)
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -421,15 +422,86 @@ __global__ __launch_bounds__(256) void ellw_build_kernel(const int32_t* __restri
 }
 
 
-// slots of a CSR operator whose source lies within +-32 / +-96 rows of the destination, and the longest row (selects
-// the ELLW layout)
+// Rows far longer than their neighbours (hubs): in the tile kernel one lane group walks a row's slots one dependent
+// chain after the other, so a 2 000-slot row costs 660 us and a 20 000-slot row 6.4 ms at N = 200 000 (the whole launch
+// otherwise takes 20 - 30 us).  Here one 1024-thread workgroup owns ONE long row: its lane groups (lpr lanes x VEC floats
+// = one feature row each) take the slots round-robin, eight neighbour rows in flight per group, and the partial sums
+// meet in LDS where group 0 adds them in group order — deterministic, and a pairwise-style sum that is closer to the
+// exact result than the sequential chain.
+template <int VEC>
+__global__ __launch_bounds__(1024) void spmm_long_rows_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const int32_t* __restrict__ long_rows, const float* __restrict__ X, int64_t ldx, float* Y, int64_t ldy,
+    const float* T, int64_t ldt, float alpha, float beta, int F, int lpr) {
+  __shared__ float s_part[1024 * VEC];
+  const int tid = threadIdx.x;
+  const int groups = 1024 / lpr, g = tid / lpr, l = tid - g * lpr;
+  const int f = l * VEC;
+  const bool active = f < F;
+  const int row = long_rows[blockIdx.x];
+  const int a = rowptr[row], b = rowptr[row + 1];
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  const float* Xf = X + (active ? f : 0);
+  constexpr int U = 8;
+  for (int q0 = a + g; q0 < b; q0 += groups * U) {
+    int c[U];
+    float v[U];
+    float x[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + groups * u;
+      const bool live = q < b;
+      c[u] = live ? col[q] : col[a];
+      v[u] = live ? val[q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) ldv<VEC>(Xf + (int64_t)c[u] * ldx, x[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = q0 + groups * u < b;              // select, not multiply-by-zero: a dead slot must not inject NaN
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = live ? fmaf(v[u], x[u][i], acc[i]) : acc[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s_part[tid * VEC + i] = acc[i];
+  __syncthreads();
+  if (g == 0 && active) {
+    float out[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[i] = 0.f;
+    for (int gg = 0; gg < groups; ++gg)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) out[i] += s_part[(gg * lpr + l) * VEC + i];
+    if (T != nullptr) {
+      float t[VEC];
+      ldv<VEC>(T + (int64_t)row * ldt + f, t);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) out[i] = alpha * out[i] + beta * t[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) out[i] = alpha * out[i];
+    }
+    stv<VEC>(Y + (int64_t)row * ldy + f, out);
+  }
+}
+
+// slots of a CSR operator whose source lies within +-32 / +-96 rows of the destination, the longest row (selects the ELLW
+// layout) and the list of rows longer than long_len (handled by spmm_long_rows_kernel)
 __global__ __launch_bounds__(256) void csr_locality_kernel(const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col, int n_rows,
-                                                           int32_t* out) {
+                                                           int32_t* out, int32_t* long_rows, int long_cap, int long_len) {
   const int row = (int)(blockIdx.x * 256 + threadIdx.x);
   int n32 = 0, n96 = 0;
   if (row < n_rows) {
-    atomicMax(&out[2], rowptr[row + 1] - rowptr[row]);
+    const int len = rowptr[row + 1] - rowptr[row];
+    atomicMax(&out[2], len);
+    if (long_rows != nullptr && len > long_len) {
+      const int slot = atomicAdd(&out[3], 1);            // out[3]: number of long rows (may exceed long_cap: list truncated)
+      if (slot < long_cap) long_rows[slot] = row;
+    }
     for (int q = rowptr[row]; q < rowptr[row + 1]; ++q) {
       const int d = col[q] - row;
       n32 += (d >= -32 && d <= 32) ? 1 : 0;
@@ -565,14 +637,14 @@ __global__ __launch_bounds__(256) void sddmm_att_kernel(
 template <int VEC>
 int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const float* X,
                 int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha, float beta,
-                int64_t F, pgt_stream_t stream) {
+                int64_t F, pgt_stream_t stream, int skip_len = 0) {
   const int64_t Fv = F / VEC;
   const int n = (int)n_rows, Fi = (int)F;
   dim3 block(256);
   if (Fv <= 64) {
 #define PGT_SPMM_CASE(L, TR_, U_)                                                                             \
   PGT_LAUNCH((spmm_tile_kernel<VEC, L, TR_, U_>), dim3((unsigned)pgt_cdiv(n_rows, TR_)), block, stream, rowptr, \
-             col, val, n, X, ldx, Y, ldy, T, ldt, alpha, beta, Fi, (g_tile_xcd ? 1 : 0) | ((g_tile_nt == 2 || (g_tile_nt == 1 && (int64_t)n * Fi * 4 >= ((int64_t)32 << 20))) ? 2 : 0))
+             col, val, n, X, ldx, Y, ldy, T, ldt, alpha, beta, Fi, (g_tile_xcd ? 1 : 0) | ((g_tile_nt == 2 || (g_tile_nt == 1 && (int64_t)n * Fi * 4 >= ((int64_t)32 << 20))) ? 2 : 0), skip_len)
     if (Fv <= 4) { PGT_SPMM_CASE(4, 64, 4); }
     else if (Fv <= 8) { PGT_SPMM_CASE(8, 64, 4); }
     else if (Fv <= 16) {
@@ -785,20 +857,48 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
   return pgt_check_launch("pgt_spmm_ellw_f32");
 }
 
-extern "C" int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out3,
-                                pgt_stream_t stream) {
-  PGT_REQUIRE(n_rows >= 0, "pgt_csr_locality: negative size");
-  PGT_REQUIRE(out3 != nullptr, "pgt_csr_locality: null pointer");
-  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) - 256, "pgt_csr_locality: size exceeds int32 indexing");
-  if (hipMemsetAsync(out3, 0, 3 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+extern "C" int pgt_csr_locality(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t* out4,
+                                int32_t* long_rows, int64_t long_cap, int32_t long_len, pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0 && long_cap >= 0, "pgt_csr_locality: negative size");
+  PGT_REQUIRE(out4 != nullptr, "pgt_csr_locality: null pointer");
+  PGT_REQUIRE(n_rows < ((int64_t)1 << 31) - 256 && long_cap < ((int64_t)1 << 31), "pgt_csr_locality: size exceeds int32 indexing");
+  if (hipMemsetAsync(out4, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
     pgt_set_error("pgt_csr_locality: memset failed");
     return PGT_ERR_LAUNCH;
   }
   if (n_rows == 0) return PGT_OK;
   PGT_REQUIRE(rowptr && col, "pgt_csr_locality: null pointer");
   PGT_LAUNCH(csr_locality_kernel, dim3((unsigned)pgt_cdiv(n_rows, 256)), dim3(256), stream, rowptr, col, (int)n_rows,
-             out3);
+             out4, long_cap > 0 ? long_rows : (int32_t*)nullptr, (int)long_cap, (int)long_len);
   return pgt_check_launch("pgt_csr_locality");
+}
+
+extern "C" int pgt_spmm_csr_long_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                     const int32_t* long_rows, int64_t n_long, int32_t long_len, const float* X,
+                                     int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha,
+                                     float beta, int64_t F, pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0 && F >= 0 && n_long >= 0, "pgt_spmm_csr_long_f32: negative size");
+  if (n_rows == 0 || F == 0) return PGT_OK;
+  if (int rc = spmm_validate("pgt_spmm_csr_long_f32", rowptr, n_rows, X, ldx, Y, ldy, T, ldt, F)) return rc;
+  PGT_REQUIRE(n_long == 0 || (long_rows != nullptr && long_len > 0), "pgt_spmm_csr_long_f32: long-row list missing");
+  PGT_REQUIRE(n_long < ((int64_t)1 << 31), "pgt_spmm_csr_long_f32: too many long rows");
+  PgtVecPick vp;
+  vp.width(F); vp.operand(X, ldx); vp.operand(Y, ldy); vp.operand(T, ldt);
+  const int64_t Fv = F / vp.v;
+  // rows wider than the tile kernels cover (node-major batches) already spread a row over many wavefronts
+  if (n_long == 0 || Fv > 64) return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
+  int rc;
+  if (vp.v == 4) rc = launch_spmm<4>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream, long_len);
+  else if (vp.v == 2) rc = launch_spmm<2>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream, long_len);
+  else rc = launch_spmm<1>(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream, long_len);
+  if (rc) return rc;
+  int lpr = 4;
+  while (lpr < Fv) lpr <<= 1;
+  dim3 grid((unsigned)n_long), block(1024);
+  if (vp.v == 4) PGT_LAUNCH((spmm_long_rows_kernel<4>), grid, block, stream, rowptr, col, val, long_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, (int)F, lpr);
+  else if (vp.v == 2) PGT_LAUNCH((spmm_long_rows_kernel<2>), grid, block, stream, rowptr, col, val, long_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, (int)F, lpr);
+  else PGT_LAUNCH((spmm_long_rows_kernel<1>), grid, block, stream, rowptr, col, val, long_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, (int)F, lpr);
+  return pgt_check_launch("pgt_spmm_csr_long_f32");
 }
 
 extern "C" int pgt_spmm_csr_att_f32(const int32_t* rowptr, const int32_t* col, const float* val,

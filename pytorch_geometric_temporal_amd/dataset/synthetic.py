@@ -73,6 +73,21 @@ def local_graph(num_nodes=200_000, degree=8, window=64, seed=0):
     return _row_major(src, dst, w)
 
 
+def hub_graph(num_nodes=200_000, degree=8, hubs=20, hub_degree=2000, seed=0):
+    """local_graph plus `hubs` nodes that also receive `hub_degree` uniformly drawn in-edges (a skewed in-degree
+    distribution: the long rows a row-per-lane-group aggregation kernel chokes on)."""
+    rng = np.random.default_rng(seed + 1)
+    n = int(num_nodes)
+    ei, ew = local_graph(n, degree, seed=seed)
+    rows = rng.choice(n, hubs, replace=False)
+    src = np.concatenate([rng.choice(n, hub_degree, replace=False) for _ in rows])
+    dst = np.repeat(rows, hub_degree)
+    e2 = np.concatenate([ei, np.stack([src, dst])], axis=1)
+    w2 = np.concatenate([ew, (0.5 + rng.random(src.size)).astype(np.float32)])
+    keep = np.unique(e2[0].astype(np.int64) * n + e2[1], return_index=True)[1]
+    return _row_major(e2[0][keep], e2[1][keep], w2[keep])
+
+
 def uniform_graph(num_nodes=200_000, degree=8, seed=0):
     """Uniform-random in-neighbours (no locality; worst case for the L2): `degree` random permutations, duplicates
     removed, so E is within a few edges of num_nodes * degree."""

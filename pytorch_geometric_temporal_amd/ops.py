@@ -24,7 +24,7 @@ class Csr:
     """CSR operator by destination row.  `halo` is the operator's measured locality: 32 / 96 when at least 95 % of the
     slots have |col - row| within that distance (locality-ordered node numbering), else 0; `max_len` the longest row.
     `ellw` caches the ELLW layout (pgt_ellw) built for the F = 64 LDS-window kernel on first use."""
-    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw")
+    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows")
 
     def __init__(self, n_rows, cap, device):
         self.n_rows = n_rows
@@ -32,6 +32,7 @@ class Csr:
         self.max_len = -1
         self.nnz = -1
         self.ellw = None
+        self.long_rows = None      # int32 device list of the rows longer than LONG_ROW slots (hubs), or None
         self.rowptr = torch.zeros(n_rows + 1, dtype=I32, device=device)
         self.col = torch.zeros(max(cap, 1), dtype=I32, device=device)
         self.val = torch.zeros(max(cap, 1), dtype=F32, device=device)
@@ -40,6 +41,8 @@ class Csr:
         return CsrStruct(ptr(self.rowptr), ptr(self.col), ptr(self.val))
 
 
+LONG_ROW = 128         # rows with more slots go to the long-row kernel (one workgroup per row: pgt_spmm_csr_long_f32)
+LONG_ROW_CAP = 4096    # at most this many long rows are listed; an operator with more keeps the plain row tiles
 ELLW_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; keep the CSR row tiles
 # Locality-ordered operators (>= 95 % of the slots within +-32 / +-96 rows, rows of at most 32 slots) take the ELLW
 # layout at F = 64: 21 us against 33 us for the CSR row tiles at N = 200 000, in-degree 8.
@@ -66,13 +69,17 @@ def measure_locality(csrs):
     todo = [c for c in csrs if c.n_rows >= ELLW_MIN_ROWS]
     if not todo:
         return
-    out = torch.zeros(len(todo), 4, dtype=I32, device=todo[0].rowptr.device)
+    dev = todo[0].rowptr.device
+    out = torch.zeros(len(todo), 5, dtype=I32, device=dev)
+    lists = [torch.empty(LONG_ROW_CAP, dtype=I32, device=dev) for _ in todo]
     for i, c in enumerate(todo):
-        lib.call("pgt_csr_locality", ptr(c.rowptr), ptr(c.col), c.n_rows, ptr(out[i]), stream_of(lib, c.rowptr))
-        out[i, 3:4].copy_(c.rowptr[c.n_rows:c.n_rows + 1])
-    for c, (n32, n96, max_len, nnz) in zip(todo, out.tolist()):
+        lib.call("pgt_csr_locality", ptr(c.rowptr), ptr(c.col), c.n_rows, ptr(out[i]), ptr(lists[i]), LONG_ROW_CAP,
+                 LONG_ROW, stream_of(lib, c.rowptr))
+        out[i, 4:5].copy_(c.rowptr[c.n_rows:c.n_rows + 1])
+    for c, lst, (n32, n96, max_len, n_long, nnz) in zip(todo, lists, out.tolist()):
         c.halo = 32 if 20 * n32 >= 19 * nnz > 0 else (96 if 20 * n96 >= 19 * nnz > 0 else 0)
         c.max_len, c.nnz = max_len, nnz
+        c.long_rows = lst[:n_long] if 0 < n_long <= LONG_ROW_CAP else None
 
 
 class Ellw:
@@ -378,6 +385,12 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
         _timed("spmm", work, lambda: lib.call(
             "pgt_spmm_ellw_f32", ctypes.byref(es), ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx,
             yp, ldy, tp, ldt, float(alpha), float(beta), X.size(1), st))
+        return Y
+    lr = getattr(csr, "long_rows", None)
+    if lr is not None:       # hubs: the row tiles skip them, one workgroup per long row produces them
+        _timed("spmm", work, lambda: lib.call(
+            "pgt_spmm_csr_long_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, ptr(lr), lr.numel(),
+            LONG_ROW, xp, ldx, yp, ldy, tp, ldt, float(alpha), float(beta), X.size(1), st))
         return Y
     _timed("spmm", work, lambda: lib.call(
         "pgt_spmm_csr_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx, yp, ldy, tp, ldt,

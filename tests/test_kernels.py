@@ -418,7 +418,7 @@ def banded_csr(n, deg_lo, deg_hi, window, seed, device, far_frac=0.0, heavy_row=
     if source_scaled:
         val = (0.25 + rng.random(n)).astype(np.float32)[col]
     csr = ops.Csr.__new__(ops.Csr)
-    csr.n_rows, csr.halo, csr.max_len, csr.nnz, csr.ellw = n, 0, -1, -1, None
+    csr.n_rows, csr.halo, csr.max_len, csr.nnz, csr.ellw, csr.long_rows = n, 0, -1, -1, None, None
     csr.rowptr = torch.from_numpy(rowptr).to(device)
     csr.col = torch.from_numpy(col.astype(np.int32)).to(device)
     csr.val = torch.from_numpy(val).to(device)
@@ -1344,3 +1344,49 @@ def test_deterministic_weight_gradient_matches_and_is_reproducible(backend, M, s
     assert_close_with_nonfinite(outs[0][0], dW0.double() + Acat.t() @ G.cpu().double(), tol, 2e-5, "dW deterministic")
     assert_close_with_nonfinite(outs[0][1], db0.double() + G.cpu().double().sum(0), tol, 2e-5, "db deterministic")
     assert_close_with_nonfinite(dWa, outs[0][0], tol, 2e-5, "atomic vs deterministic")
+
+
+@pytest.mark.parametrize("F_", [64, 32, 6, 200])
+def test_spmm_long_rows_are_split_across_the_workgroup(backend, F_):
+    """pgt_spmm_csr_long_f32: rows longer than ops.LONG_ROW slots (hubs) are skipped by the row tiles and produced by one
+    workgroup each (lane groups round-robin over the slots, LDS reduction in group order) — against the fp64 reference
+    and the plain entry point, with the epilogue, empty rows next to hubs, and a width the tile kernels do not cover."""
+    n = 500 if backend.name == "emu" else 20_000
+    csr = banded_csr(n, 0, 9, 25, seed=11, device=backend.device, far_frac=0.1, heavy_row=min(n - 1, 123))
+    rp = csr.rowptr.cpu()
+    lens = rp[1:] - rp[:-1]
+    long_rows = torch.nonzero(lens > ops.LONG_ROW).flatten().to(torch.int32)
+    assert long_rows.numel() == 1 and int(lens.max()) == 300
+    csr.long_rows = long_rows.to(backend.device)
+    g = torch.Generator().manual_seed(F_)
+    X, T = torch.randn(n, F_, generator=g).to(backend.device), torch.randn(n, F_, generator=g).to(backend.device)
+    Y = torch.full((n, F_), float("nan"), device=backend.device)
+    ops.spmm(csr, X, Y, ellw=False)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "long rows")
+    ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0, ellw=False)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "long rows + epilogue")
+    csr.long_rows = None
+    Yp = torch.empty_like(Y)
+    ops.spmm(csr, X, Yp, T=T, alpha=2.0, beta=-1.0, ellw=False)
+    short = torch.ones(n, dtype=torch.bool)
+    short[long_rows.long()] = False
+    assert torch.equal(Y[short.to(Y.device)], Yp[short.to(Y.device)])        # every other row: the same kernel, bit for bit
+
+
+def test_long_rows_are_listed_at_graph_preparation(backend):
+    n = 5000
+    ei, ew = syn.local_graph(n, 4, window=64, seed=0)
+    rng = np.random.default_rng(1)
+    hubs = np.array([17, 4000])
+    src = np.concatenate([rng.choice(n, 400, replace=False) for _ in hubs])
+    e2 = np.concatenate([ei, np.stack([src, np.repeat(hubs, 400)])], axis=1)
+    key = np.unique(e2[0].astype(np.int64) * n + e2[1], return_index=True)[1]
+    e2 = e2[:, key]
+    g = ops.DConvGraph(backend.t(e2), None, n)
+    assert g.fwd_o.long_rows is not None and sorted(g.fwd_o.long_rows.tolist()) == [17, 4000]
+    assert g.fwd_o.max_len >= 400 and g.fwd_o.ellw is None
+    assert g.bwd_o.long_rows is None                                       # the transposed operator has no hub ROWS
+    X = torch.randn(n, 64).to(backend.device)
+    Y = torch.empty_like(X)
+    ops.spmm(g.fwd_o, X, Y)
+    assert_close_with_nonfinite(Y, spmm_reference(g.fwd_o, X, None, 1.0, 0.0), 5e-5, 1e-5, "hub graph")

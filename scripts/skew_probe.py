@@ -40,3 +40,20 @@ for hubs, hub_deg in ((0, 0), (20, 2000), (20, 20000), (200, 2000)):
     err = float((Y.double() - ref).abs().max())
     print(f"hubs={hubs} x {hub_deg}: E={g.E} longest row {csr.max_len} ellw={'yes' if csr.ellw is not None else 'no'}: {t:.1f} us "
           f"({nb / t / 1e3 / 8000:.3f} of 8 TB/s), max err {err:.2e}")
+
+# locality-ordered graph with a fraction of long-range edges (served through the CSR by the ELLW kernel's far path)
+for frac in (0.0, 0.01, 0.03, 0.05):
+    e2, w2 = ei.copy(), ew.copy()
+    k = int(frac * e2.shape[1])
+    if k:
+        pick = rng.choice(e2.shape[1], k, replace=False)
+        e2[0, pick] = rng.integers(0, n, k)
+        key = np.unique(e2[0].astype(np.int64) * n + e2[1], return_index=True)[1]
+        e2, w2 = e2[:, key], w2[key]
+    g = ops.DConvGraph(torch.from_numpy(e2).to(dev), torch.from_numpy(w2).to(dev), n)
+    X, Y = torch.randn(n, 64, device=dev), torch.empty(n, 64, device=dev)
+    nb = ops.spmm_algorithmic_bytes(n, g.E, 64, False)
+    t_e = timeit(lambda: ops.spmm(g.fwd_o, X, Y))
+    far = g.fwd_o.ellw.far if g.fwd_o.ellw is not None else -1
+    t_c = timeit(lambda: ops.spmm(g.fwd_o, X, Y, ellw=False))
+    print(f"long-range fraction {frac}: halo {g.fwd_o.halo}, ELLW far slots {far}: auto {t_e:.1f} us, CSR tiles {t_c:.1f} us")

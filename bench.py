@@ -341,7 +341,9 @@ def main():
         k = kernels[dom]
         names = {"spmm": "spmm_wide_kernel<4> (pgt_spmm_csr_f32)",
                  "stack": "dconv_slab_fwd/bwd_kernel (pgt_dconv_stack_slab(_bwd)_f32)",
-                 "gemm": "gemm_db_kernel / gemm_dbp_kernel (pgt_gemm_f32 and, with the GRU gate chain in the epilogue, pgt_gemm_gru_zr/h_f32; all launches of the entry points, read-out layer included)",
+                 "gemm": "gemm_bx_kernel (split-bf16 on the bf16 matrix pipe: 330->128 with the z|r gate chain, 128->256) + gemm_db_kernel / "
+                         "gemm_dbp_kernel (exact-fp32 MFMA: the other shapes) behind pgt_gemm_f32 / pgt_gemm_gru_zr/h_f32; all launches "
+                         "of the entry points, read-out layer included; flops = 2 M N K of the fp32 product, priced against the fp32 MFMA peak",
                  "gemm_tn": "gemm_tn_pipe_kernel (pgt_gemm_tn_acc_f32)"}
         if dom in ("spmm", "stack"):
             ach = k["work_per_launch"] / (k["avg_us"] * 1e-6) / 1e9

@@ -47,7 +47,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 7
+#define PGT_ABI_VERSION 8
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -150,23 +150,33 @@ typedef struct pgt_ellw {
   int32_t config;         /* launch shape, from pgt_ellw_plan: 1 = one 1024-thread workgroup per CU (456 window rows),
                              2 = two 512-thread workgroups per CU (240 window rows) */
   int64_t n_tiles;
+  const int32_t* far_col; /* [n_tiles * far_rows] sources outside a tile's window that get an LDS row of their own (their
+                             slots hold window_rows + 1 + k; -1 = unused entry), or NULL: every out-of-window slot is
+                             0xFFFF and comes through the CSR */
+  int32_t far_rows;       /* from pgt_ellw_plan (depends on config and mode) */
 } pgt_ellw;
 
 /* Host-only: tile height / slot width / tile count for an operator with `n_rows` rows whose longest row has
  * `max_row_len` slots and whose sources lie (mostly) within `halo` rows of their destination; the tile height fills
  * whole rounds of the resident workgroups (config 1: rows of <= 8 slots; config 2: wider rows) of the current device.
+ * `far_rows` = entries per tile of the out-of-window table (what the LDS budget of the launch shape leaves: more in
+ * source-scale mode, which has no coefficient block).
  * PGT_ERR_INVALID when the layout does not apply (rows longer than 32 slots, halo > 116). */
-int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t* tile_rows, int32_t* width,
-                  int32_t* config, int64_t* n_tiles);
+int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t source_scaled, int32_t* tile_rows,
+                  int32_t* width, int32_t* config, int64_t* n_tiles, int32_t* far_rows);
 
 /* Fill `slots` / `vals` (each n_tiles * tile_rows * width entries; `vals` may be NULL) from the CSR operator, with the
  * geometry in `op` (its pointers are ignored).  `scale` (float [n_rows], may be NULL) receives the candidate
- * per-source table scale[col[q]] = val[q].  info (int32 [4], device): [0] = slots outside their window (served
- * through the CSR at run time: correct, slower), [1] = slots whose val differs bitwise from scale[col] (0 = the
- * source-scale mode applies), [2] = rows longer than `width` (must be 0: their tail is not represented). */
+ * per-source table scale[col[q]] = val[q]; it also states the mode the layout is built for (NULL: per-slot mode,
+ * op->far_rows must be the per-slot plan's).  `far_col` (int32 [n_tiles * op->far_rows]) / `far_cnt` (int32 [n_tiles],
+ * scratch) receive the out-of-window table; both NULL: no table.  info (int32 [4], device): [0] = slots outside their
+ * window, [1] = slots whose val differs bitwise from scale[col] (0 = the source-scale mode applies; otherwise rebuild
+ * with scale = NULL and the per-slot plan), [2] = rows longer than `width` (must be 0: their tail is not represented),
+ * [3] = out-of-window slots that did not fit their tile's table (0xFFFF: served through the CSR at run time — correct,
+ * slower). */
 int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t nnz,
-                   const pgt_ellw* op, uint16_t* slots, float* vals, float* scale, int32_t* info,
-                   pgt_stream_t stream);
+                   const pgt_ellw* op, uint16_t* slots, float* vals, float* scale, int32_t* far_col, int32_t* far_cnt,
+                   int32_t* info, pgt_stream_t stream);
 
 /* pgt_spmm_csr_f32's contract on the ELLW layout of the same operator (the CSR arrays it was built from are passed
  * along: they serve out-of-window slots, and shapes the window kernel does not cover — F not a multiple of 64, operands

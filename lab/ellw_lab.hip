@@ -433,11 +433,11 @@ int main(int argc, char** argv) {
   // third lab round: lab kernel vs PRODUCT kernel (C ABI) on the same box, same buffers
   pgt_ellw op; memset(&op, 0, sizeof(op));
   op.halo = 32;
-  if (pgt_ellw_plan(n, 32, deg, &op.tile_rows, &op.width, &op.config, &op.n_tiles)) { printf("plan: %s\n", pgt_last_error()); return 1; }
+  if (pgt_ellw_plan(n, 32, deg, 1, &op.tile_rows, &op.width, &op.config, &op.n_tiles, &op.far_rows)) { printf("plan: %s\n", pgt_last_error()); return 1; }
   const size_t total = (size_t)op.n_tiles * op.tile_rows * op.width;
   uint16_t* pslots; float *pvals, *pscale; int32_t* pinfo;
   CK(hipMalloc(&pslots, total * 2)); CK(hipMalloc(&pvals, total * 4)); CK(hipMalloc(&pscale, n * 4)); CK(hipMalloc(&pinfo, 16));
-  if (pgt_ellw_build(rp, col, val, n, (int64_t)g.col.size(), &op, pslots, pvals, pscale, pinfo, st)) { printf("build: %s\n", pgt_last_error()); return 1; }
+  if (pgt_ellw_build(rp, col, val, n, (int64_t)g.col.size(), &op, pslots, pvals, pscale, nullptr, nullptr, pinfo, st)) { printf("build: %s\n", pgt_last_error()); return 1; }
   int32_t hinfo[4]; CK(hipMemcpyAsync(hinfo, pinfo, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
   printf("product plan: %lld tiles of %d rows x %d slots; far %d, scale mismatches %d\n", (long long)op.n_tiles, op.tile_rows, op.width, hinfo[0], hinfo[1]);
   op.slots = pslots;

@@ -85,11 +85,11 @@ int main(int argc, char** argv) {
   pgt_tune("spmm_ellw_cfg", cfg);
   pgt_ellw op; memset(&op, 0, sizeof(op));
   op.halo = 32;
-  PK(pgt_ellw_plan(n, 32, deg, &op.tile_rows, &op.width, &op.config, &op.n_tiles));
+  PK(pgt_ellw_plan(n, 32, deg, 1, &op.tile_rows, &op.width, &op.config, &op.n_tiles, &op.far_rows));
   const size_t total = (size_t)op.n_tiles * op.tile_rows * op.width;
   uint16_t* slots; float *vals, *scale; int32_t* info;
   CK(hipMalloc(&slots, total * 2)); CK(hipMalloc(&vals, total * 4)); CK(hipMalloc(&scale, n * 4)); CK(hipMalloc(&info, 16));
-  PK(pgt_ellw_build(rp, col, val, n, nnz, &op, slots, vals, scale, info, st));
+  PK(pgt_ellw_build(rp, col, val, n, nnz, &op, slots, vals, scale, nullptr, nullptr, info, st));
   int32_t hinfo[4]; CK(hipMemcpyAsync(hinfo, info, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
   printf("cfg %d deg %d: plan: %lld tiles of %d rows x %d slots; far %d, scale mismatches %d, overflow rows %d; algorithmic %.1f MB\n",
          cfg, deg, (long long)op.n_tiles, op.tile_rows, op.width, hinfo[0], hinfo[1], hinfo[2], alg / 1e6);

@@ -12,8 +12,8 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpgt_hip.so")
 INCLUDE = os.path.join(ROOT, "include")
 
-SOURCES = ["pgt_core.hip", "spmm.hip", "dconv_slab.hip", "gemm.hip", "elementwise.hip", "graph_prep.hip",
-           "attention.hip"]
+SOURCES = ["pgt_core.hip", "spmm.hip", "dconv_slab.hip", "gemm.hip", "gemm_bx.hip", "elementwise.hip",
+           "graph_prep.hip", "attention.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function"]
 
@@ -55,7 +55,7 @@ def build_hip_library(force=False, verbose=False):
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, "pgt_common.h"), os.path.join(INCLUDE, "pgt_hip.h")]
-    objs, relink = [], force
+    objs, relink, jobs = [], force, []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, src.replace(".hip", ".o"))
@@ -63,9 +63,14 @@ def build_hip_library(force=False, verbose=False):
             cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
+            jobs.append(cmd)
             relink = True
         objs.append(o)
+    if jobs:
+        # one hipcc per translation unit, side by side (the unrolled GEMM kernels take minutes each)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(lambda c: subprocess.run(c, check=True), jobs))
     if relink or not os.path.exists(LIB_PATH):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
         if verbose:

@@ -35,7 +35,8 @@ class CsrStruct(ctypes.Structure):
 
 class EllwStruct(ctypes.Structure):
     _fields_ = [("slots", c_ptr), ("vals", c_ptr), ("scale", c_ptr), ("tile_rows", ctypes.c_int32),
-                ("halo", ctypes.c_int32), ("width", ctypes.c_int32), ("config", ctypes.c_int32), ("n_tiles", c_i64)]
+                ("halo", ctypes.c_int32), ("width", ctypes.c_int32), ("config", ctypes.c_int32), ("n_tiles", c_i64),
+                ("far_col", c_ptr), ("far_rows", ctypes.c_int32)]
 
 
 class DConvGraphStruct(ctypes.Structure):
@@ -61,10 +62,11 @@ PROTOTYPES = {
                               c_ptr, c_size, c_ptr]),
     "pgt_spmm_csr_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32,
                                  c_f32, c_i64, c_ptr]),
-    "pgt_ellw_plan": (c_int, [c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
-                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_i64)]),
+    "pgt_ellw_plan": (c_int, [c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_i64),
+                              ctypes.POINTER(ctypes.c_int32)]),
     "pgt_ellw_build": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.POINTER(EllwStruct), c_ptr, c_ptr, c_ptr, c_ptr,
-                               c_ptr]),
+                               c_ptr, c_ptr, c_ptr]),
     "pgt_spmm_ellw_f32": (c_int, [ctypes.POINTER(EllwStruct), c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                   c_ptr, c_i64, c_f32, c_f32, c_i64, c_ptr]),
     "pgt_csr_locality": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, ctypes.c_int32, c_ptr]),
@@ -108,7 +110,7 @@ PROTOTYPES = {
     "pgt_window_gather_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
 }
 
-EXPECTED_ABI = 7
+EXPECTED_ABI = 8
 
 
 class PgtLib:

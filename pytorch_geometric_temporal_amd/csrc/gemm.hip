@@ -24,18 +24,7 @@ namespace {
 
 constexpr int BK = 32;
 
-struct GemmArgs {
-  const float* A; int64_t lda; int64_t a_seg_stride; int n_seg; int seg_k;
-  const float* Bw; int64_t sbk; int64_t sbn;
-  float* C; int64_t ldc; int64_t c_seg_stride; int c_seg_n;
-  const float* bias; int M; int N; int accumulate;
-  // fused GRU epilogues (pgt_gemm_gru_zr_f32 / pgt_gemm_gru_h_f32); epi = 0: plain GEMM
-  //   1: C = sigmoid(acc + bias) [M, 2O];  eX[m, efin + o] = eH[m, o] * C[m, O + o]
-  //   2: C = tanh(acc + bias) [M, O];  Hnew = Z * H + (1 - Z) * C with Z = eZ[m * 2O + o]  -> eO0 (and eO1 when non-null)
-  int epi; int eO; int efin; int evec;   // evec bit 0: eH float4-loadable, 1: eX float2-storable, 2: eO0 float4, 3: eO1 float2
-  const float* eH; int64_t eldh; float* eX; int64_t eldx;
-  const float* eZ; float* eO0; int64_t eld0; float* eO1; int64_t eld1;
-};
+using GemmArgs = PgtGemmArgs;   // pgt_common.h (shared with gemm_bx.hip)
 
 // ---- fused GRU epilogues: one output element / one aligned group of four (row gm, columns gn .. gn+3, all < N)
 __device__ __forceinline__ float gemm_epi1(const GemmArgs& g, int gm, int gn, float v) {
@@ -1561,6 +1550,8 @@ static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t
       return pgt_check_launch("pgt_gemm_f32");
     }
   }
+  // large products whose K fits the register-resident B slice: split-bf16 kernel on the bf16 matrix pipe (gemm_bx.hip)
+  if (const int rc = pgt_gemm_bx_launch(g, stream)) return rc < 0 ? rc : PGT_OK;
   // float2 loads of A need every (row, even k) address 8-byte aligned and no pair straddling a segment
   const bool av2 = (seg_k % 2 == 0) && (lda % 2 == 0) && (a_seg_stride % 2 == 0) && pgt_aligned(A, 8);
   const bool kmaj = (sbk == 1 && sbn != 1);

@@ -1,0 +1,434 @@
+// Dense feature transform through the bf16 matrix pipe with fp32 accuracy ("split-bf16").
+//
+// Why: gfx950 has no TF32, and v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate (157 vs 2 500 TFLOP/s), so the fp32
+// tile kernels of gemm.hip are matrix-pipe bound at the DCRNN shapes (M = N_nodes * B rows, K = 330, 128 / 64 columns:
+// 0.34 - 0.59 of the fp32 peak) although the operands would stream from HBM in a third of the time.  Here every fp32
+// operand is split into three bf16 pieces, x = x1 + x2 + x3 (8 significant bits each = the 24 bits of an fp32
+// significand), and a product is accumulated from the six largest piece products
+//     x1 y1  +  (x1 y2 + x2 y1 + x2 y2 + x1 y3 + x3 y1)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the big term and the corrections in separate accumulators, added
+// once at the end).  Each bf16 x bf16 product is exact in fp32; the dropped terms (x2 y3, x3 y2, x3 y3) are below
+// 2^-24 |x y|.  Measured against an fp64 product (K = 330, lab/gemm_bx_lab.hip): mean error 3.7e-8, max 3.9e-7 — the
+// fp32 MFMA kernel of gemm.hip on the same inputs: 1.4e-7 / 1.6e-6.  Six bf16 MFMAs are 2.67x the fp32 MFMA peak.
+// Non-finite operands: an infinite x gives x - x1 = nan, so its output row is nan where the fp32 product has +-inf or
+// nan (nan operands propagate as usual).
+//
+// Schedule: one persistent 512-thread workgroup per CU = two wavefronts per SIMD.
+//   * wavefronts 0 .. 3 ("consumers") own 32 * WN output columns each and the first KA k-steps (16 deep) of K, and run
+//     the epilogue (bias, GRU gate chain of pgt_gemm_gru_zr/h_f32, stores straight from the accumulator layout: one
+//     register = one 128-byte row piece per half-wavefront);
+//   * wavefronts 4 .. 7 ("producers") own the same columns for the remaining k-steps and bring the next 32-row block of A
+//     in: global fp32 (8-byte loads through a buffer descriptor that ends at the last valid row: ragged and
+//     out-of-range blocks read zeros, no branch) -> three bf16 planes in the other LDS buffer;
+//   * the B slice of a wavefront (its columns x its part of K, three planes) stays in registers for the whole launch;
+//   * the two K parts meet in LDS: the producer leaves its partial sums there and moves on to the next block, the
+//     consumer adds them and stores.  One workgroup barrier per block (LDS counters only: loads and stores stay in
+//     flight across it) plus an LDS flag that orders the reuse of the partial-sum buffer.
+// The producers' loads are issued with inline asm and waited for by hand (s_waitcnt vmcnt(EPT - 1)): the compiler's
+// counter insertion drains vmcnt at every loop back-edge, which serialises a load with the k-steps it should hide
+// behind (measured: 157 -> 128 us).  For the same reason nothing in the steady state uses FLAT or scratch accesses.
+#include "pgt_common.h"
+
+#ifdef PGT_EMU
+// The CPU test double does not model the bf16 matrix instruction or buffer descriptors: the entry reports "not covered"
+// and the callers run the fp32 tile kernels (tests/ -m gpu cover this file on the device).
+int pgt_gemm_bx_launch(const PgtGemmArgs&, pgt_stream_t) { return 0; }
+void pgt_gemm_bx_set(int) {}
+#else
+
+namespace {
+
+int g_bx = 1;   // pgt_tune("gemm_bx"): 1 = where it applies (>= 8192 rows), 2 = at any size (tests), 0 = never
+
+typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float bx_f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t bx_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t bx_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t bx_pack(float x, float y) {     // v_cvt_pk_bf16_f32: round to nearest even
+  bx_f32x2 v = {x, y};
+  bx_bf16x2 r = __builtin_convertvector(v, bx_bf16x2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+// (x, y) -> three packed bf16 pairs (low half = x's piece), every piece rounded to nearest: the resident operand
+__device__ __forceinline__ void bx_split2(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = bx_pack(x, y);
+  float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
+  rx = (fabsf(rx) <= 3.0e38f) ? rx : 0.f;      // inf / nan: the first piece carries it, the others are zero
+  ry = (fabsf(ry) <= 3.0e38f) ? ry : 0.f;
+  p2 = bx_pack(rx, ry);
+  rx -= __uint_as_float(p2 << 16);
+  ry -= __uint_as_float(p2 & 0xffff0000u);
+  p3 = bx_pack(rx, ry);
+}
+// the streaming operand: first piece rounded to nearest, the other two cut off (x - x1 has at most 16 significant bits,
+// the second cut leaves at most 9): 9 instructions per pair
+__device__ __forceinline__ void bx_split2_fast(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = bx_pack(x, y);
+  float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
+  p2 = __builtin_amdgcn_perm(__float_as_uint(ry), __float_as_uint(rx), 0x07060302u);
+  rx -= __uint_as_float(p2 << 16);
+  ry -= __uint_as_float(p2 & 0xffff0000u);
+  p3 = __builtin_amdgcn_perm(__float_as_uint(ry), __float_as_uint(rx), 0x07060302u);
+}
+
+__device__ __forceinline__ pgt_f32x16 bx_mfma(bx_u32x4 a, bx_u32x4 b, pgt_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bx_bf16x8, a), __builtin_bit_cast(bx_bf16x8, b), c, 0, 0, 0);
+}
+
+// sigmoid on the hardware exp / reciprocal (1 ulp each): the gate chain runs on the four consumer wavefronts only, sixteen
+// elements per lane and block, and the library expf + IEEE division (~50 instructions per element) was a third of the
+// fused kernel's time (182 -> 14x us at M = 211 968)
+__device__ __forceinline__ float bx_sigmoidf(float x) { return __frcp_rn(1.f + __expf(-x)); }
+
+// LDS-only workgroup barrier: planes and partial sums travel through LDS (lgkmcnt); the loads of the blocks ahead and the
+// epilogue's stores stay in flight across it (__syncthreads would drain vmcnt as well)
+__device__ __forceinline__ void bx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// KSTEPS: 16-deep k-steps covering K (zero padded); WN: 32-column blocks per wavefront; EPI: 0 bias, 1 / 2 the GRU
+// epilogues of PgtGemmArgs.  A: n_seg segments of seg_k (even) columns, consumed as one [M, n_seg * seg_k] operand.
+template <int KSTEPS, int WN, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_blocks) {
+  constexpr int BM = 32, KP = KSTEPS * 16, SROW = KP * 2 + 16, PLANE = BM * SROW, BUF = 3 * PLANE;
+  constexpr int EPT = (KP / 2) / 8;                       // float pairs per producer thread and block (8 threads per row)
+  constexpr int PART = 64 * 16 * WN * 4;                  // a column's partial sums, accumulator layout
+  constexpr int KA = KSTEPS / 2, KB = KSTEPS - KA, KMAX = KB;
+  static_assert((KP / 2) % 8 == 0 && KA >= 1, "shape");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 4 * PART + 16];
+  unsigned char* const stage_part = lds + 2 * BUF;
+  typedef __attribute__((address_space(3))) volatile int bx_lds_vint;   // an LDS access (a generic pointer would be a FLAT
+  bx_lds_vint* const part_seen = (bx_lds_vint*)(lds + 2 * BUF + 4 * PART);   // load, and FLAT waits drain vmcnt)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 3;
+  const bool producer = wave >= 4;
+  const int nwg = gridDim.x;
+  const int Ktot = g.n_seg * g.seg_k;
+  // ---- B slice -> registers (consumer: k-steps [0, KA), producer: [KA, KSTEPS)); every piece rounded to nearest
+  bx_u32x4 bf[KMAX][WN][3];
+  {
+    const int kbase = producer ? KA : 0, ksteps = producer ? KB : KA;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = (wc * WN + j) * 32 + (lane & 31), k0 = (kbase + i) * 16 + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int k = k0 + t;
+          v[t] = (k < Ktot && col < g.N && i < ksteps) ? g.Bw[(int64_t)k * g.sbk + (int64_t)col * g.sbn] : 0.f;
+        }
+        uint32_t p[3][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bx_split2(v[2 * t], v[2 * t + 1], p[0][t], p[1][t], p[2][t]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { bx_u32x4 f = {p[q][0], p[q][1], p[q][2], p[q][3]}; bf[i][j][q] = f; }
+      }
+  }
+  // ---- zero both A buffers once (the K padding columns are never written again)
+  for (int i = tid; i < 2 * BUF / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 4) part_seen[tid] = 0;
+  int rb = blockIdx.x;
+  if (rb >= n_blocks) return;
+  __syncthreads();
+  const int arow = (lane & 31) * SROW + 16 * (lane >> 5);
+  int n_iter = 0;
+  if (producer) {
+    // ---- element map of a 32-row block over the 256 producer threads: row = ptid / 8, pairs (ptid % 8) + 8 t
+    const int ptid = tid - 256, erow = ptid >> 3, el = ptid & 7;
+    const int half = g.seg_k >> 1, rpairs = g.n_seg * half;
+    uint32_t goff[EPT];   // byte offset from the block base; past the row's last pair: outside the descriptor (reads 0)
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+      const int pi = el + 8 * t, seg = pi / half, pp = pi - seg * half;
+      goff[t] = pi < rpairs ? (uint32_t)((seg * g.a_seg_stride + erow * g.lda + 2 * pp) * 4) : 0xfffffff0u;
+    }
+    const uint32_t lbase = (uint32_t)(erow * SROW + el * 4);
+    // a block's rows are read through a buffer descriptor that ends with the last valid row of the last segment: rows
+    // past M (ragged last block) and whole blocks past the end read as zero, without a branch
+    const int64_t span_last = (int64_t)(g.n_seg - 1) * g.a_seg_stride * 4;
+    auto block_rsrc = [&](int b) {
+      const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
+      const int64_t rows = rows_left < BM ? rows_left : BM;
+      const int64_t bytes = rows_left > 0 ? span_last + (rows - 1) * g.lda * 4 + (int64_t)g.seg_k * 4 : 0;
+      const uint64_t base = reinterpret_cast<uint64_t>(g.A + (int64_t)(rows_left > 0 ? b : 0) * BM * g.lda);
+      bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes), 0x00020000u};
+      return r;
+    };
+    // Loads return in order and every conversion is followed by the reload of its register pair, so exactly EPT - 1
+    // younger loads are in flight when element t of the previous round is due.
+    bx_u32x2 raw[EPT];
+    auto issue_load = [&](int t, const bx_u32x4& r) {
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(raw[t]) : "v"(goff[t]), "s"(r) : "memory");
+    };
+    auto convert_one = [&](int t, unsigned char* buf) {
+      uint32_t p1, p2, p3;
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1));
+      bx_split2_fast(__uint_as_float(raw[t].x), __uint_as_float(raw[t].y), p1, p2, p3);
+      unsigned char* d = buf + lbase + 32 * t;
+      *reinterpret_cast<uint32_t*>(d) = p1;
+      *reinterpret_cast<uint32_t*>(d + PLANE) = p2;
+      *reinterpret_cast<uint32_t*>(d + 2 * PLANE) = p3;
+    };
+    {
+      const bx_u32x4 r0 = block_rsrc(rb), r1 = block_rsrc(rb + nwg);
+#pragma unroll
+      for (int t = 0; t < EPT; ++t) issue_load(t, r0);
+#pragma unroll
+      for (int t = 0; t < EPT; ++t) {
+        convert_one(t, lds);
+        issue_load(t, r1);
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);        // the younger half of the workgroup loses the VALU arbitration otherwise
+    bx_barrier();
+    int cur = 0;
+    for (; rb < n_blocks; rb += nwg, ++n_iter) {
+      unsigned char* bcur = lds + cur * BUF;
+      unsigned char* bnxt = lds + (cur ^ 1) * BUF;
+      const bx_u32x4 r2 = block_rsrc(rb + 2 * nwg);
+      pgt_f32x16 am[WN], ac[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac[j][r] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        bx_u32x4 fa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (KA + i) * 32);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          am[j] = bx_mfma(fa[0], bf[i][j][0], am[j]);
+          ac[j] = bx_mfma(fa[0], bf[i][j][1], ac[j]);
+          ac[j] = bx_mfma(fa[1], bf[i][j][0], ac[j]);
+          ac[j] = bx_mfma(fa[1], bf[i][j][1], ac[j]);
+          ac[j] = bx_mfma(fa[0], bf[i][j][2], ac[j]);
+          ac[j] = bx_mfma(fa[2], bf[i][j][0], ac[j]);
+        }
+        // this k-step's share of the next block: fp32 (in registers since the previous iteration) -> bf16 planes in the
+        // other buffer, and the load of the block after it into the freed registers
+#pragma unroll
+        for (int t = i * EPT / KB; t < (i + 1) * EPT / KB; ++t) {
+          convert_one(t, bnxt);
+          issue_load(t, r2);
+        }
+      }
+      while (part_seen[wc] != n_iter) { }     // the consumer has picked up the previous block's partial sums (long ago)
+      {
+        float4* d = reinterpret_cast<float4*>(stage_part + wc * PART);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4)
+            d[(j * 4 + r4) * 64 + lane] = make_float4(am[j][4 * r4] + ac[j][4 * r4], am[j][4 * r4 + 1] + ac[j][4 * r4 + 1],
+                                                      am[j][4 * r4 + 2] + ac[j][4 * r4 + 2], am[j][4 * r4 + 3] + ac[j][4 * r4 + 3]);
+      }
+      bx_barrier();      // partial sums visible; everyone is done with this block's planes and the next block's are complete
+      cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    const int lo = lane & 31, hi = lane >> 5;
+    float bias_r[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int gn = (wc * WN + j) * 32 + lo;
+      bias_r[j] = (g.bias && gn < g.N) ? g.bias[gn] : 0.f;
+    }
+    const bool cols_live = wc * WN * 32 < g.N;           // N <= 96: the last column wavefronts only keep the barriers company
+    // ---- operands of the fused GRU epilogues (H, and Z for the candidate gate), accumulator layout: register r of lane
+    // (lo, hi) is row (r & 3) + 8 (r >> 2) + 4 hi, column lo.  They are fetched one block ahead with hand-issued buffer
+    // loads (rows past M read zero) placed BEFORE the previous block's stores: loads and stores share vmcnt and return in
+    // order, so a load issued behind a block's stores would wait for their write acknowledgements (measured: + 4 us per
+    // block).  At the use, at least 16 younger instructions (the previous block's C stores) are in flight: vmcnt(16).
+    const int egn = wc * 32 + lo;                                        // EPI != 0 implies WN == 1
+    const bool e_live = EPI != 0 && cols_live && (EPI == 2 || wc * 32 >= g.eO);
+    const int eo = EPI == 1 ? egn - g.eO : egn;
+    float eh[EPI != 0 ? 16 : 1], ez[EPI == 2 ? 16 : 1];
+    const uint32_t evoff_h = (uint32_t)((4 * hi * g.eldh + eo) * 4), evoff_z = (uint32_t)((4 * hi * 2 * g.eO + egn) * 4);
+    auto e_rsrc = [&](const float* p, int64_t ld, int cols, int b) {
+      const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
+      const int64_t rows = rows_left < BM ? rows_left : BM;
+      const int64_t bytes = rows_left > 0 ? ((rows - 1) * ld + cols) * 4 : 0;
+      const uint64_t base = reinterpret_cast<uint64_t>(p + (int64_t)(rows_left > 0 ? b : 0) * BM * ld);
+      bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes), 0x00020000u};
+      return r;
+    };
+    auto e_issue = [&](int b) {
+      if constexpr (EPI != 0) {
+        const bx_u32x4 rh = e_rsrc(g.eH, g.eldh, g.eO, b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int soff = __builtin_amdgcn_readfirstlane(((r & 3) + 8 * (r >> 2)) * (int)g.eldh * 4);
+          asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(eh[r]) : "v"(evoff_h), "s"(rh), "s"(soff) : "memory");
+        }
+        if constexpr (EPI == 2) {
+          const bx_u32x4 rz = e_rsrc(g.eZ, 2 * g.eO, 2 * g.eO, b);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int soff = __builtin_amdgcn_readfirstlane(((r & 3) + 8 * (r >> 2)) * 2 * g.eO * 4);
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(ez[r]) : "v"(evoff_z), "s"(rz), "s"(soff) : "memory");
+          }
+        }
+      }
+    };
+    if (e_live) e_issue(rb);
+    bx_barrier();
+    int cur = 0;
+    for (; rb < n_blocks; rb += nwg, ++n_iter) {
+      unsigned char* bcur = lds + cur * BUF;
+      pgt_f32x16 am[WN], ac[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac[j][r] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < KA; ++i) {
+        bx_u32x4 fa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + i * 32);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          am[j] = bx_mfma(fa[0], bf[i][j][0], am[j]);
+          ac[j] = bx_mfma(fa[0], bf[i][j][1], ac[j]);
+          ac[j] = bx_mfma(fa[1], bf[i][j][0], ac[j]);
+          ac[j] = bx_mfma(fa[1], bf[i][j][1], ac[j]);
+          ac[j] = bx_mfma(fa[0], bf[i][j][2], ac[j]);
+          ac[j] = bx_mfma(fa[2], bf[i][j][0], ac[j]);
+        }
+      }
+      float acc[WN][16];
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = am[j][r] + ac[j][r] + bias_r[j];
+      bx_barrier();
+      // ---- the producer's partial sums join in registers; the block is stored straight from the accumulator layout: a
+      // register is one 128-byte row piece per half-wavefront
+      {
+        const float4* d = reinterpret_cast<const float4*>(stage_part + wc * PART);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 v = d[(j * 4 + r4) * 64 + lane];
+            acc[j][4 * r4] += v.x; acc[j][4 * r4 + 1] += v.y; acc[j][4 * r4 + 2] += v.z; acc[j][4 * r4 + 3] += v.w;
+          }
+      }
+      if (lane == 0) part_seen[wc] = n_iter + 1;     // after the reads above: a wavefront's LDS operations complete in order
+      if (cols_live) {
+        float side[EPI != 0 ? 16 : 1];                 // eX = H r (zr) / the new hidden state (candidate gate)
+        if constexpr (EPI != 0) {
+          if (e_live) {
+            if (n_iter == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              asm volatile("s_waitcnt vmcnt(16)" : "+v"(eh[r]));
+              if constexpr (EPI == 2) asm volatile("s_waitcnt vmcnt(16)" : "+v"(ez[r]));
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (EPI == 1) {
+              acc[0][r] = bx_sigmoidf(acc[0][r]);
+              side[r] = eh[r] * acc[0][r];
+            } else {
+              acc[0][r] = tanhf(acc[0][r]);
+              side[r] = pgt_gru_blend(ez[r], eh[r], acc[0][r]);
+            }
+          }
+          if (e_live) e_issue(rb + nwg);               // the next block's operands, ahead of this block's stores
+          asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int gn = (wc * WN + j) * 32 + lo;
+          if (gn >= g.N) continue;
+          const int js = gn / g.c_seg_n;
+          float* cp = g.C + (int64_t)js * g.c_seg_stride + (gn - js * g.c_seg_n);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int gm = rb * BM + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (gm >= g.M) continue;
+            cp[(int64_t)gm * g.ldc] = acc[j][r];
+            if constexpr (EPI == 1) {
+              if (gn >= g.eO) g.eX[(int64_t)gm * g.eldx + g.efin + (gn - g.eO)] = side[r];
+            } else if constexpr (EPI == 2) {
+              g.eO0[(int64_t)gm * g.eld0 + gn] = side[r];
+              if (g.eO1) g.eO1[(int64_t)gm * g.eld1 + gn] = side[r];
+            }
+          }
+        }
+      }
+      cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+int bx_device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else cus = 256;
+  }
+  return cus;
+}
+
+}  // namespace
+
+void pgt_gemm_bx_set(int v) { g_bx = v; }
+
+int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
+  if (!g_bx) return 0;
+  const int64_t K = (int64_t)g.n_seg * g.seg_k;
+  // covered: K <= 336 in even segments read with 8-byte loads, N <= 128 (256 for K <= 128), no accumulation into C
+  if (g.accumulate || K < 16 || K > 336 || g.seg_k % 2 || g.lda % 2 || g.a_seg_stride % 2 || !pgt_aligned(g.A, 8)) return 0;
+  if (g.lda < 0 || g.a_seg_stride < 0 || g.c_seg_n <= 0) return 0;
+  if (g.M < 8192 && g_bx != 2) return 0;
+  // 32-bit byte offsets inside a block's buffer descriptor
+  if (((int64_t)g.n_seg * g.a_seg_stride + 33 * g.lda + g.seg_k) * 4 >= (int64_t)0xfff00000) return 0;
+  const int wn = g.N <= 128 ? 1 : 2;
+  if (g.N > 256 || (wn == 2 && K > 128)) return 0;
+  // Where it does not pay (measured inside the training step, M = 211 968; g_bx = 2 runs them anyway for the tests):
+  //  * short K into <= 128 columns: little arithmetic per row block, the fp32 tile kernels are as fast (48 vs 50 us);
+  //  * K <= 64 into 256 columns: 85 vs 85 us;
+  //  * the candidate-gate epilogue (64 columns: half the column wavefronts idle, and the product moves 550 MB with its
+  //    three outputs — the fp32 kernel is already at 3.5 TB/s): 180 vs 158 us.
+  if (g_bx != 2 && ((K <= 128 && wn == 1) || K <= 64 || g.epi == 2)) return 0;
+  if (g.epi) {
+    // the gate epilogues: whole 32-column blocks on either side of the z | r boundary, hidden width = N (h) or N / 2 (zr)
+    if (wn != 1 || K <= 128 || g.c_seg_n != g.N) return 0;
+    if (g.epi == 1 && (g.eO % 32 || g.N != 2 * g.eO)) return 0;
+    if (g.epi == 2 && g.N != g.eO) return 0;
+  }
+  const int n_blocks = (int)pgt_cdiv(g.M, 32);
+  int wgs = bx_device_cus();
+  if (g_bx == 2 && wgs > 3) wgs = 3;                    // tests: several blocks per workgroup at small sizes
+  if (wgs > n_blocks) wgs = n_blocks;
+  dim3 grid((unsigned)wgs), block(512);
+#define PGT_BX_GO(KS_, WN_, EPI_) PGT_LAUNCH((gemm_bx_kernel<KS_, WN_, EPI_>), grid, block, stream, g, n_blocks)
+  if (K > 128) {
+    if (g.epi == 1) PGT_BX_GO(21, 1, 1);
+    else if (g.epi == 2) PGT_BX_GO(21, 1, 2);
+    else PGT_BX_GO(21, 1, 0);
+  } else if (K > 64) {
+    if (wn == 1) PGT_BX_GO(8, 1, 0); else PGT_BX_GO(8, 2, 0);
+  } else {
+    if (wn == 1) PGT_BX_GO(4, 1, 0); else PGT_BX_GO(4, 2, 0);
+  }
+#undef PGT_BX_GO
+  const int rc = pgt_check_launch("pgt_gemm_f32 (split-bf16)");
+  return rc ? rc : 1;
+}
+
+#endif  // PGT_EMU

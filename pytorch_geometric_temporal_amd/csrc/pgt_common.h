@@ -109,6 +109,23 @@ static inline int pgt_check_launch(const char* what) {
 static inline int64_t pgt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline bool pgt_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// Arguments of the GEMM tile kernels (gemm.hip) and of the split-bf16 kernel (gemm_bx.hip).
+struct PgtGemmArgs {
+  const float* A; int64_t lda; int64_t a_seg_stride; int n_seg; int seg_k;
+  const float* Bw; int64_t sbk; int64_t sbn;
+  float* C; int64_t ldc; int64_t c_seg_stride; int c_seg_n;
+  const float* bias; int M; int N; int accumulate;
+  // fused GRU epilogues (pgt_gemm_gru_zr_f32 / pgt_gemm_gru_h_f32); epi = 0: plain GEMM
+  //   1: C = sigmoid(acc + bias) [M, 2O];  eX[m, efin + o] = eH[m, o] * C[m, O + o]
+  //   2: C = tanh(acc + bias) [M, O];  Hnew = Z * H + (1 - Z) * C with Z = eZ[m * 2O + o]  -> eO0 (and eO1 when non-null)
+  int epi; int eO; int efin; int evec;   // evec bit 0: eH float4-loadable, 1: eX float2-storable, 2: eO0 float4, 3: eO1 float2
+  const float* eH; int64_t eldh; float* eX; int64_t eldx;
+  const float* eZ; float* eO0; int64_t eld0; float* eO1; int64_t eld1;
+};
+// gemm_bx.hip: 1 = launched, 0 = shape not covered (the caller runs the fp32 MFMA kernels), < 0 = error
+int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream);
+void pgt_gemm_bx_set(int v);
+
 // V-float (4 / 8 / 16-byte) global accesses; V is chosen by the host from pointer and stride alignment.
 template <int VEC>
 __device__ __forceinline__ void pgt_ldv(const float* __restrict__ p, float (&v)[VEC]) {

@@ -218,8 +218,9 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
 //      and gather phase of a CU do not overlap.  Best at in-degree <= 8 (W = 8).
 //   B:  512 threads, 240 window rows (67 - 79 KB): two workgroups per CU, one gathers out of LDS while the other's
 //      memory phase is in flight.  For wider rows (W >= 16), where the LDS gather is as long as the memory phase.
-struct EllwCfgA { static constexpr int THREADS = 1024, WRMAX = 456, SLOTS = 392 * 16; };
-struct EllwCfgB { static constexpr int THREADS = 512, WRMAX = 240, SLOTS = 176 * 16; };
+// FAR0 / FAR1: LDS rows for out-of-window sources in source-scale / per-slot mode (what the LDS budget leaves)
+struct EllwCfgA { static constexpr int THREADS = 1024, WRMAX = 456, SLOTS = 392 * 16, FAR0 = 128, FAR1 = 32; };
+struct EllwCfgB { static constexpr int THREADS = 512, WRMAX = 240, SLOTS = 176 * 16, FAR0 = 48, FAR1 = 12; };
 constexpr int ELLW_WMAX = 32;
 
 int g_ellw = 1;        // pgt_tune("spmm_ellw"): 0 = pgt_spmm_ellw_f32 runs the CSR kernels instead (A/B)
@@ -233,13 +234,14 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     const uint16_t* __restrict__ slots, const float* __restrict__ vals, const float* __restrict__ scale,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
     int TR, int H, int W, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt, float alpha,
-    float beta, int flags) {
+    float beta, int flags, const int32_t* __restrict__ far_col) {
   constexpr int THREADS = CFG::THREADS, WRMAX = CFG::WRMAX, SLOTS = CFG::SLOTS;
+  constexpr int FARMAX = MODE == 0 ? CFG::FAR0 : CFG::FAR1;   // LDS rows behind the zero row for out-of-window sources
   constexpr int G = THREADS / 16;                      // row groups of 16 lanes: one 256-byte row each
   constexpr int XPT = (WRMAX + G - 1) / G;             // window rows per group
   constexpr int RPG = (WRMAX - 2 + G - 1) / G;         // output rows per group (TR <= WRMAX - 2 H, H >= 1)
   constexpr int NSV = (SLOTS / 8 + THREADS - 1) / THREADS;   // slot vectors per thread
-  __shared__ pgt_f4 s_x[(WRMAX + 1) * 16];
+  __shared__ pgt_f4 s_x[(WRMAX + 1 + FARMAX) * 16];
   __shared__ pgt_u4 s_slots[SLOTS / 8];
   __shared__ pgt_f4 s_vals[MODE == 1 ? SLOTS / 4 : 1];
   const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
@@ -255,6 +257,17 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   if (T != nullptr) T += chunk0;
   const float* Xl = X + l16 * 4;
   // ---- one memory phase: window rows, their source scales, the tile's slot block (and coefficient block)
+  // Out-of-window sources (wrap-around rows, long-range edges): the layout lists up to FARMAX of them per tile
+  // (far_col, -1 = unused entry) and their slots already point at the LDS rows behind the zero row, so the gather below
+  // is uniform.  The list is requested FIRST (loads return in order: its consumer, the far-row loads, then waits for
+  // nothing younger) and the far rows ride in the shadow of the window loads.
+  constexpr int FPT = (FARMAX + G - 1) / G;            // far rows per lane group
+  int fc[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    const int k = rg + G * i;
+    fc[i] = (far_col != nullptr && k < FARMAX) ? far_col[(size_t)tile * FARMAX + k] : -1;
+  }
   pgt_f4 xw[XPT];
   float sc[XPT];
 #pragma unroll
@@ -279,6 +292,17 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
       for (int i = 0; i < 2 * NSV; ++i) { const int v = tid + THREADS * i; va[i] = vp[v < 2 * nvec ? v : 2 * nvec - 1]; }
     }
   }
+  pgt_f4 xfar[FPT];
+  float sfar[FPT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {                      // far rows: second (short) hop behind far_col, in the shadow of the window
+    xfar[i] = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+    sfar[i] = 1.f;
+    if (fc[i] >= 0 && fc[i] < n_rows) {
+      xfar[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(fc[i] * ldx));
+      if constexpr (MODE == 0) sfar[i] = scale[fc[i]];
+    }
+  }
   pgt_f4 tcur = pgt_mk4(0.f, 0.f, 0.f, 0.f);
   if (T != nullptr && rg < nr) tcur = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + rg) * ldt) + l16 * 4);
   // ---- window -> LDS.  MODE 0: scaled on the way in (the product is rounded once, like norm * x_j in the reference)
@@ -292,6 +316,15 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     }
   }
   if (tid < 16) s_x[WR * 16 + tid] = pgt_mk4(0.f, 0.f, 0.f, 0.f);     // the row padding slots point at
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    const int k = rg + G * i;
+    if (fc[i] >= 0) {
+      pgt_f4 v = xfar[i];
+      if constexpr (MODE == 0) v = pgt_mk4(pgt_mul_rn(v.x, sfar[i]), pgt_mul_rn(v.y, sfar[i]), pgt_mul_rn(v.z, sfar[i]), pgt_mul_rn(v.w, sfar[i]));
+      s_x[(WR + 1 + k) * 16 + l16] = v;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NSV; ++i) { const int v = tid + THREADS * i; if (v < nvec) s_slots[v] = sv[i]; }
   if constexpr (MODE == 1) {
@@ -389,11 +422,13 @@ __global__ __launch_bounds__(256) void ellw_scale_scatter_kernel(const int32_t* 
 
 // one thread per (row, slot): slot block + coefficient block of the ELLW layout from the CSR operator.
 // info[0] += slots outside their tile's window, info[1] += slots whose val differs from scale[col] (bitwise),
-// info[2] += rows longer than W (their tail is NOT represented: the caller must not use the operator)
+// info[2] += rows longer than W (their tail is NOT represented: the caller must not use the operator),
+// info[3] += out-of-window slots beyond the tile's far_max LDS rows (kept as 0xFFFF)
 __global__ __launch_bounds__(256) void ellw_build_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                          const float* __restrict__ val, int n_rows, int TR, int H, int W,
                                                          int n_tiles, const float* __restrict__ scale, uint16_t* slots,
-                                                         float* vals, int32_t* info) {
+                                                         float* vals, int32_t* info, int32_t* far_col, int32_t* far_cnt,
+                                                         int far_max) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)n_tiles * TR * W;
   if (idx >= total) return;
@@ -408,7 +443,17 @@ __global__ __launch_bounds__(256) void ellw_build_kernel(const int32_t* __restri
       const int c = col[a + j];
       v = val[a + j];
       if (c >= w0 && c < w0 + WR && c >= 0 && c < n_rows) d = (unsigned)(c - w0);
-      else { d = 0xffffu; atomicAdd(&info[0], 1); }
+      else {
+        // out of the window: one of the tile's far_max LDS rows behind the zero row if one is left (the slot then points
+        // at it and the kernel prefetches X[c] into it), otherwise 0xFFFF = fetched through the CSR inside the gather
+        d = 0xffffu;
+        atomicAdd(&info[0], 1);
+        if (far_cnt != nullptr) {
+          const int k = atomicAdd(&far_cnt[tile], 1);
+          if (k < far_max) { far_col[(int64_t)tile * far_max + k] = c; d = (unsigned)(WR + 1 + k); }
+          else atomicAdd(&info[3], 1);
+        }
+      }
       if (scale != nullptr) {
         unsigned bv, bs;
         const float s = scale[c];
@@ -742,10 +787,14 @@ static int ellw_device_cus() {
 #endif
 }
 
-extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t* tile_rows, int32_t* width,
-                             int32_t* config, int64_t* n_tiles) {
-  PGT_REQUIRE(tile_rows && width && config && n_tiles, "pgt_ellw_plan: null pointer");
-  *tile_rows = 0; *width = 0; *config = 0; *n_tiles = 0;
+static int ellw_far_rows(int config, bool source_scaled) {
+  return config == 1 ? (source_scaled ? EllwCfgA::FAR0 : EllwCfgA::FAR1) : (source_scaled ? EllwCfgB::FAR0 : EllwCfgB::FAR1);
+}
+
+extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t source_scaled, int32_t* tile_rows,
+                             int32_t* width, int32_t* config, int64_t* n_tiles, int32_t* far_rows) {
+  PGT_REQUIRE(tile_rows && width && config && n_tiles && far_rows, "pgt_ellw_plan: null pointer");
+  *tile_rows = 0; *width = 0; *config = 0; *n_tiles = 0; *far_rows = 0;
   PGT_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 31) - 1024, "pgt_ellw_plan: n_rows out of range");
   PGT_REQUIRE(halo >= 1 && 2 * halo <= EllwCfgB::WRMAX - 8, "pgt_ellw_plan: halo %d outside [1, %d]", (int)halo,
               (EllwCfgB::WRMAX - 8) / 2);
@@ -754,6 +803,7 @@ extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, 
   const int W = max_row_len <= 8 ? 8 : (int)pgt_cdiv(max_row_len, 8) * 8;
   const int cfg = g_ellw_cfg == 1 || g_ellw_cfg == 2 ? g_ellw_cfg : ((W <= 8 || halo > 40) ? 1 : 2);
   *config = cfg;
+  *far_rows = ellw_far_rows(cfg, source_scaled != 0);
   const int wrmax = cfg == 1 ? EllwCfgA::WRMAX : EllwCfgB::WRMAX, slots_cap = cfg == 1 ? EllwCfgA::SLOTS : EllwCfgB::SLOTS;
   const int per_cu = cfg == 1 ? 1 : 2;
   int cap = wrmax - 2 * halo;
@@ -789,17 +839,31 @@ static int ellw_check(const char* who, const pgt_ellw* op, int64_t n_rows) {
               (long long)op->n_tiles, (long long)n_rows);
   PGT_REQUIRE(op->n_tiles < ((int64_t)1 << 31) && op->n_tiles * op->tile_rows * op->width < ((int64_t)1 << 40),
               "%s: operator too large", who);
+  PGT_REQUIRE(op->far_col == nullptr || op->far_rows == ellw_far_rows(op->config, op->scale != nullptr),
+              "%s: far_rows %d does not match the kernel's table for this config / mode (see pgt_ellw_plan)", who,
+              (int)op->far_rows);
   return PGT_OK;
 }
 
 extern "C" int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t nnz,
-                              const pgt_ellw* op, uint16_t* slots, float* vals, float* scale, int32_t* info,
-                              pgt_stream_t stream) {
+                              const pgt_ellw* op, uint16_t* slots, float* vals, float* scale, int32_t* far_col,
+                              int32_t* far_cnt, int32_t* info, pgt_stream_t stream) {
   PGT_REQUIRE(n_rows >= 1 && nnz >= 0, "pgt_ellw_build: bad size");
   PGT_REQUIRE(rowptr && col && val && slots && info, "pgt_ellw_build: null pointer");
+  PGT_REQUIRE((far_col == nullptr) == (far_cnt == nullptr), "pgt_ellw_build: far_col and far_cnt go together");
   pgt_ellw tmp = *op;
   tmp.slots = slots;
+  tmp.scale = scale;
+  tmp.far_col = far_col;
   if (int rc = ellw_check("pgt_ellw_build", &tmp, n_rows)) return rc;
+  if (far_col != nullptr) {
+    // -1 = unused entry of the far table; far_cnt counts a tile's out-of-window slots (may exceed far_rows)
+    if (hipMemsetAsync(far_col, 0xff, (size_t)op->n_tiles * op->far_rows * sizeof(int32_t), (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(far_cnt, 0, (size_t)op->n_tiles * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+      pgt_set_error("pgt_ellw_build: memset failed");
+      return PGT_ERR_LAUNCH;
+    }
+  }
   PGT_REQUIRE(nnz < ((int64_t)1 << 31), "pgt_ellw_build: nnz exceeds int32 indexing");
   if (hipMemsetAsync(info, 0, 4 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
     pgt_set_error("pgt_ellw_build: memset failed");
@@ -816,7 +880,8 @@ extern "C" int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const f
   const int64_t total = op->n_tiles * op->tile_rows * op->width;
   PGT_REQUIRE(pgt_cdiv(total, 256) < ((int64_t)1 << 31), "pgt_ellw_build: grid too large");
   PGT_LAUNCH(ellw_build_kernel, dim3((unsigned)pgt_cdiv(total, 256)), dim3(256), stream, rowptr, col, val, (int)n_rows,
-             (int)op->tile_rows, (int)op->halo, (int)op->width, (int)op->n_tiles, (const float*)scale, slots, vals, info);
+             (int)op->tile_rows, (int)op->halo, (int)op->width, (int)op->n_tiles, (const float*)scale, slots, vals, info,
+             far_col, far_cnt, (int)op->far_rows);
   return pgt_check_launch("pgt_ellw_build");
 }
 
@@ -840,7 +905,7 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
 #define PGT_ELLW_GO(MODE_, CFG_, W8C_)                                                                                \
   PGT_LAUNCH((spmm_ellw64_kernel<MODE_, CFG_, W8C_>), grid, dim3(CFG_::THREADS), stream, op->slots, op->vals, op->scale, \
              rowptr, col, val, (int)n_rows, (int)op->tile_rows, (int)op->halo, (int)op->width, X, (int)ldx, Y, (int)ldy,  \
-             T, (int)ldt, alpha, beta, flags)
+             T, (int)ldt, alpha, beta, flags, op->far_col)
 #define PGT_ELLW_W(MODE_, CFG_)                                  \
   do {                                                           \
     if (op->width == 8) PGT_ELLW_GO(MODE_, CFG_, 1);             \

@@ -89,27 +89,42 @@ class Ellw:
     def __init__(self, csr, halo):
         lib = _lib.get_lib()
         dev = csr.rowptr.device
-        tr, w, cfg, nt = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0)
-        lib.call("pgt_ellw_plan", csr.n_rows, int(halo), int(csr.max_len), ctypes.byref(tr), ctypes.byref(w),
-                 ctypes.byref(cfg), ctypes.byref(nt))
-        self.tile_rows, self.width, self.n_tiles, self.halo, self.config = tr.value, w.value, nt.value, int(halo), cfg.value
+        self.halo = int(halo)
+        # first as a source-scaled operator (P_o of DConv); the build verifies that and reports the slots outside
+        # their window — if it is not, lay it out again with per-slot coefficients (whose plan leaves fewer far rows)
+        mismatch = self._build(lib, csr, dev, True)
+        if mismatch:
+            self._build(lib, csr, dev, False)
+
+    def _build(self, lib, csr, dev, source_scaled):
+        tr, w, cfg, nt, fr = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
+        lib.call("pgt_ellw_plan", csr.n_rows, self.halo, int(csr.max_len), 1 if source_scaled else 0, ctypes.byref(tr),
+                 ctypes.byref(w), ctypes.byref(cfg), ctypes.byref(nt), ctypes.byref(fr))
+        self.tile_rows, self.width, self.n_tiles, self.config = tr.value, w.value, nt.value, cfg.value
+        self.far_rows = fr.value
         total = self.n_tiles * self.tile_rows * self.width
         self.slots = torch.empty(total, dtype=torch.int16, device=dev)      # uint16 bit patterns
-        vals = torch.empty(total, dtype=F32, device=dev)
-        scale = torch.empty(csr.n_rows, dtype=F32, device=dev)
+        vals = None if source_scaled else torch.empty(total, dtype=F32, device=dev)
+        scale = torch.empty(csr.n_rows, dtype=F32, device=dev) if source_scaled else None
+        far_col = torch.empty(self.n_tiles * self.far_rows, dtype=I32, device=dev)
+        far_cnt = torch.empty(self.n_tiles, dtype=I32, device=dev)
         info = torch.zeros(4, dtype=I32, device=dev)
-        geo = EllwStruct(None, None, None, self.tile_rows, self.halo, self.width, self.config, self.n_tiles)
+        geo = EllwStruct(None, None, None, self.tile_rows, self.halo, self.width, self.config, self.n_tiles, None,
+                         self.far_rows)
         lib.call("pgt_ellw_build", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, int(csr.nnz),
-                 ctypes.byref(geo), ptr(self.slots), ptr(vals), ptr(scale), ptr(info), stream_of(lib, csr.rowptr))
-        self.far, mismatch, overflow, _ = info.tolist()        # one host sync per new operator
+                 ctypes.byref(geo), ptr(self.slots), ptr(vals), ptr(scale), ptr(far_col), ptr(far_cnt), ptr(info),
+                 stream_of(lib, csr.rowptr))
+        # far = slots outside their window, far_csr = those that did not fit the tile's table (served through the CSR)
+        self.far, mismatch, overflow, self.far_csr = info.tolist()        # one host sync per new operator
         if overflow:
             raise PgtError(f"ELLW: {overflow} row(s) longer than the planned width {self.width}")
-        # source-scaled operator (val[q] == scale[col[q]] everywhere): the coefficient stream is dropped
-        self.scale, self.vals = (scale, None) if mismatch == 0 else (None, vals)
+        self.scale, self.vals = scale, vals
+        self.far_col = far_col if self.far else None                   # no table: the kernel skips its loads
+        return mismatch if source_scaled else 0
 
     def struct(self):
         return EllwStruct(ptr(self.slots), ptr(self.vals), ptr(self.scale), self.tile_rows, self.halo, self.width,
-                          self.config, self.n_tiles)
+                          self.config, self.n_tiles, ptr(self.far_col), self.far_rows)
 
 
 def ellw_of(csr):

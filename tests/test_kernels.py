@@ -505,6 +505,38 @@ def test_spmm_ellw_source_scaled_operator_drops_the_coefficient_stream(backend, 
         lib.tune("spmm_ellw_rows", 0)
 
 
+@pytest.mark.parametrize("source_scaled", [True, False])
+def test_spmm_ellw_out_of_window_sources_get_lds_rows(backend, source_scaled):
+    """Sources outside a tile's window (long-range edges): up to far_rows of them per tile are prefetched into LDS rows
+    behind the zero row (their slots point there), the rest keep 0xFFFF and come through the CSR — same sums either way."""
+    lib = _lib.get_lib()
+    n = 500 if backend.name == "emu" else 40_000
+    lib.tune("spmm_ellw_rows", 64)
+    try:
+        for far_frac, all_fit in ((0.01, True), (0.5, False)):
+            csr = banded_csr(n, 2, 8, 20, seed=17, device=backend.device, far_frac=far_frac, source_scaled=source_scaled)
+            e = ops._force_ellw(csr, 32)
+            assert e is not None and (e.scale is not None) == source_scaled and e.width == 8 and e.config == 1
+            assert e.far_rows == (128 if source_scaled else 32) and e.far > 0 and e.far_col is not None
+            assert (e.far_csr == 0) if all_fit else (0 < e.far_csr < e.far)
+            table = e.far_col.view(e.n_tiles, e.far_rows).cpu()
+            used = (table >= 0).sum().item()
+            assert used == e.far - e.far_csr and int(table.max()) < n
+            X = torch.randn(n, 64, generator=torch.Generator().manual_seed(1)).to(backend.device)
+            T = torch.randn(n, 64, generator=torch.Generator().manual_seed(2)).to(backend.device)
+            Y = torch.full((n, 64), float("nan"), device=backend.device)
+            ops.spmm(csr, X, Y, T=T, alpha=0.5, beta=2.0)
+            if source_scaled:
+                assert torch.equal(Y.cpu(), (0.5 * source_scaled_reference(csr, X) + 2.0 * T.cpu()))
+            else:
+                Yp = torch.empty_like(Y)
+                ops.spmm(csr, X, Yp, T=T, alpha=0.5, beta=2.0, ellw=False)
+                assert torch.equal(Y, Yp)
+            assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 0.5, 2.0), 5e-5, 1e-5, "far rows")
+    finally:
+        lib.tune("spmm_ellw_rows", 0)
+
+
 def test_spmm_ellw_strided_nonfinite_and_fallback_shapes(backend):
     n = 300 if backend.name == "emu" else 9000
     csr = banded_csr(n, 1, 9, 30, seed=5, device=backend.device)
@@ -557,15 +589,19 @@ def test_ellw_plan_fills_whole_rounds_of_the_cus(backend):
     import ctypes
     lib = _lib.get_lib()
 
-    def plan(n, halo, max_len):
-        tr, w, cfg, nt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
-        lib.call("pgt_ellw_plan", n, halo, max_len, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(cfg), ctypes.byref(nt))
+    def plan(n, halo, max_len, source_scaled=1):
+        tr, w, cfg, nt, fr = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int32()
+        lib.call("pgt_ellw_plan", n, halo, max_len, source_scaled, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(cfg),
+                 ctypes.byref(nt), ctypes.byref(fr))
         assert cfg.value == (1 if (w.value == 8 or halo > 40) else 2)
+        # out-of-window table: what the LDS budget of the launch shape leaves next to window, slots (and coefficients)
+        assert fr.value == {(1, 1): 128, (1, 0): 32, (2, 1): 48, (2, 0): 12}[(cfg.value, source_scaled)]
         return tr.value, w.value, nt.value
 
     lib.tune("spmm_ellw_cus", 256)
     try:
         assert plan(200_000, 32, 8) == (392, 8, 511)
+        assert plan(200_000, 32, 8, 0) == (392, 8, 511)
         assert plan(200_000, 96, 8) == (264, 8, 758)          # window of 456 rows: 264 + 2 * 96
         assert plan(200_000, 32, 17) == (100, 24, 2000)       # two workgroups per CU, 176 * 16 staged slots: <= 116 rows of 24
         assert plan(200_000, 32, 16) == (132, 16, 1516)       # 176 window-limited rows -> three rounds of 512
@@ -830,6 +866,7 @@ def test_gemm_schedules_agree_at_benchmark_size():
     W = (torch.randn(S * C, 2 * O, generator=g) / 18).to(dev)
     b = torch.randn(2 * O, generator=g).to(dev)
     out = {}
+    lib.tune("gemm_bx", 0)            # this test is about the fp32 tile kernels (the split-bf16 kernel has its own below)
     try:
         for db in (1, 0):
             lib.tune("gemm_db", db)
@@ -891,7 +928,195 @@ def test_gemm_schedules_agree_at_benchmark_size():
     ops._gru_zr(zr0, H, xhr0, 2)
     zr1, xhr1 = torch.empty(M, 2 * O, device=dev), torch.zeros(M, C, device=dev)
     ops.gemm_gru_zr(A, C, M * C, S, C, W, 2 * O, 1, b, zr1, H, xhr1, 2)
+    lib.tune("gemm_bx", 1)
     assert torch.equal(zr0, zr1) and torch.equal(xhr0, xhr1)
+
+
+def _bx_case(M, segs, segk, N, nt, seed):
+    """Operands of one product C = A . B (+ bias): A in `segs` segments of `segk` columns; B as [K, N] (NN) or, for the
+    feature-gradient form, as W^T with unit k stride and the output cut into 64-column segments."""
+    g = torch.Generator().manual_seed(seed)
+    K = segs * segk
+    A = torch.randn(segs, M, segk, generator=g)
+    B = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = None if nt else torch.randn(N, generator=g)
+    A2 = torch.cat([A[j] for j in range(segs)], dim=1).double()
+    ref = A2 @ B.double() + (0 if bias is None else bias.double())
+    return A, B, bias, ref
+
+
+def _bx_run(A, B, bias, M, segs, segk, N, nt, dev):
+    Ad = A.to(dev)
+    if nt:
+        Bt = B.t().contiguous().to(dev)                          # [N, K]: unit k stride, column stride K
+        nseg_out = N // 64
+        Cs = torch.full((nseg_out, M, 64), float("nan"), device=dev)
+        ops.gemm(Ad, segk, M * segk, segs, segk, Bt, 1, segs * segk, Cs, 64, M * 64, 64, None, M, N)
+        return Cs.permute(1, 0, 2).reshape(M, N)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(Ad, segk, M * segk, segs, segk, B.to(dev), N, 1, C, N, 0, N, None if bias is None else bias.to(dev), M, N)
+    return C
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,segs,segk,N,nt", [(5000, 5, 66, 128, False), (4131, 5, 66, 64, False), (3000, 3, 34, 96, False),
+                                              (7000, 1, 128, 256, True), (2500, 1, 64, 256, True), (3333, 1, 128, 64, True),
+                                              (2000, 1, 64, 64, True), (100, 5, 66, 128, False), (31, 1, 64, 64, True),
+                                              (1025, 2, 24, 40, False), (640, 1, 16, 128, True)])
+def test_gemm_split_bf16_is_at_least_as_accurate_as_the_fp32_kernels(M, segs, segk, N, nt):
+    """gemm_bx.hip: fp32 operands split into three bf16 pieces, six piece products on the bf16 matrix pipe, fp32
+    accumulation.  Against an fp64 product it must be no worse than the exact-fp32 MFMA kernels on the same operands (it
+    is better: big term and corrections are accumulated separately), at ragged sizes, every K bucket (<= 64, <= 128,
+    <= 336 columns, zero padded), one and two 32-column blocks per wavefront, segmented inputs and outputs."""
+    lib = _lib.get_lib()
+    if lib.target != "gfx950":
+        pytest.skip("product library only")
+    dev = torch.device("cuda:0")
+    A, B, bias, ref = _bx_case(M, segs, segk, N, nt, seed=M + N)
+    try:
+        lib.tune("gemm_bx", 2)
+        C_bx = _bx_run(A, B, bias, M, segs, segk, N, nt, dev).cpu().double()
+        lib.tune("gemm_bx", 0)
+        C_32 = _bx_run(A, B, bias, M, segs, segk, N, nt, dev).cpu().double()
+    finally:
+        lib.tune("gemm_bx", 1)
+    assert torch.isfinite(C_bx).all()
+    e_bx, e_32 = (C_bx - ref).abs(), (C_32 - ref).abs()
+    scale = float(ref.abs().max())
+    assert float(e_bx.max()) <= 2e-6 * max(scale, 1.0), (float(e_bx.max()), scale)
+    assert float(e_bx.mean()) <= 1.1 * float(e_32.mean()) + 1e-9, (float(e_bx.mean()), float(e_32.mean()))
+    assert float((C_bx - C_32).abs().max()) <= 1e-5 * max(scale, 1.0)
+
+
+@pytest.mark.gpu
+def test_gemm_split_bf16_exact_cases_and_non_finite_rows():
+    lib = _lib.get_lib()
+    if lib.target != "gfx950":
+        pytest.skip("product library only")
+    dev = torch.device("cuda:0")
+    try:
+        lib.tune("gemm_bx", 2)
+        # integers: every piece product and every partial sum is exact -> the result is exact
+        A = torch.randint(-200, 201, (300, 64)).float()
+        W = torch.randint(-200, 201, (64, 64)).float()
+        C = torch.empty(300, 64, device=dev)
+        ops.gemm(A.to(dev), 64, 0, 1, 64, W.to(dev), 64, 1, C, 64, 0, 64, None, 300, 64)
+        assert torch.equal(C.cpu().double(), A.double() @ W.double())
+        # asymmetric-B identity check (a transposed or permuted store would show)
+        I = torch.eye(64)
+        Bm = (torch.arange(64 * 64, dtype=torch.float32).view(64, 64) * 1.0009765625)   # needs all three pieces
+        ops.gemm(I.to(dev), 64, 0, 1, 64, Bm.to(dev), 64, 1, C[:64], 64, 0, 64, None, 64, 64)
+        assert torch.equal(C[:64].cpu(), Bm)
+        # 24-bit operands: x = x1 + x2 + x3 exactly, one product per output -> only the dropped piece products remain
+        x = torch.rand(64, 64) + 0.5
+        ops.gemm(x.to(dev), 64, 0, 1, 64, (I * 1.2345678).to(dev), 64, 1, C[:64], 64, 0, 64, None, 64, 64)
+        assert float((C[:64].cpu().double() - x.double() * float(torch.tensor(1.2345678))).abs().max()) <= 2.0 ** -23 * 2.5
+        # a nan / inf operand poisons its own row only
+        A, B, bias, ref = _bx_case(200, 5, 66, 128, False, seed=3)
+        A[2, 17, 5] = float("nan")
+        A[0, 40, 65] = float("inf")
+        out = _bx_run(A, B, bias, 200, 5, 66, 128, False, dev).cpu()
+        bad = torch.zeros(200, dtype=torch.bool)
+        bad[17] = bad[40] = True
+        assert not torch.isfinite(out[bad]).any()
+        assert torch.isfinite(out[~bad]).all()
+        assert float((out[~bad].double() - ref[~bad]).abs().max()) <= 2e-6 * float(ref[~bad].abs().max())
+    finally:
+        lib.tune("gemm_bx", 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,O,fin", [(4100, 64, 2), (1000, 32, 2), (33, 64, 0)])
+def test_gemm_split_bf16_fused_gru_epilogues(M, O, fin):
+    """The gate epilogues of pgt_gemm_gru_zr_f32 / pgt_gemm_gru_h_f32 on the split-bf16 kernel against the fp32 kernels
+    (same gate formulas on sums that differ by fp32 rounding) and against an fp64 evaluation."""
+    lib = _lib.get_lib()
+    if lib.target != "gfx950":
+        pytest.skip("product library only")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + O)
+    segs, segk = 5, fin + O
+    K, C = segs * segk, fin + O
+    A = torch.randn(segs, M, segk, generator=g).to(dev)
+    Wzr, bzr = (torch.randn(K, 2 * O, generator=g) / K ** 0.5).to(dev), torch.randn(2 * O, generator=g).to(dev)
+    Wh, bh = (torch.randn(K, O, generator=g) / K ** 0.5).to(dev), torch.randn(O, generator=g).to(dev)
+    H = torch.randn(M, O, generator=g).to(dev)
+    res = {}
+    try:
+        for bx in (2, 0):
+            lib.tune("gemm_bx", bx)
+            zr = torch.full((M, 2 * O), float("nan"), device=dev)
+            xhr = torch.zeros(M, C, device=dev)
+            ops.gemm_gru_zr(A, segk, M * segk, segs, segk, Wzr, 2 * O, 1, bzr, zr, H, xhr, fin)
+            ht = torch.full((M, O), float("nan"), device=dev)
+            out0, out1 = torch.full((M, O), float("nan"), device=dev), torch.zeros(M, C, device=dev)
+            ops.gemm_gru_h(A, segk, M * segk, segs, segk, Wh, O, 1, bh, ht, zr, H, out0, out1[:, fin:])
+            res[bx] = (zr, xhr, ht, out0, out1)
+    finally:
+        lib.tune("gemm_bx", 1)
+    for name, a, b in zip(("zr", "xhr", "ht", "out0", "out1"), res[2], res[0]):
+        assert torch.isfinite(a).all(), name
+        assert float((a - b).abs().max()) <= 3e-6, name
+    A2 = torch.cat([A[j] for j in range(segs)], dim=1).cpu().double()
+    zr64 = torch.sigmoid(A2 @ Wzr.cpu().double() + bzr.cpu().double())
+    assert float((res[2][0].cpu().double() - zr64).abs().max()) <= 1e-6
+    assert float((res[2][1][:, fin:].cpu().double() - H.cpu().double() * zr64[:, O:]).abs().max()) <= 4e-6
+    ht64 = torch.tanh(A2 @ Wh.cpu().double() + bh.cpu().double())
+    z = res[2][0][:, :O].cpu().double()
+    assert float((res[2][3].cpu().double() - (z * H.cpu().double() + (1 - z) * ht64)).abs().max()) <= 4e-6
+
+
+@pytest.mark.gpu
+def test_gemm_split_bf16_at_benchmark_size():
+    """The three products the training step routes to the split-bf16 kernel, at BASELINE.json's full size (M = 1024 x 207
+    rows out of a 3-step diffusion stack, segment stride 3 M C): 512 sampled rows + the last (ragged) row block against
+    fp64, and against the fp32 kernels; the fused z | r epilogue against GEMM-then-gates."""
+    lib = _lib.get_lib()
+    if lib.target != "gfx950":
+        pytest.skip("product library only")
+    dev = torch.device("cuda:0")
+    M, S, C, O, T = 1024 * 207 - 13, 5, 66, 64, 3
+    g = torch.Generator(device="cpu").manual_seed(11)
+    TS = torch.randn(S, T, M, C, generator=g).to(dev)
+    A = TS[:, 1]
+    W = (torch.randn(S * C, 2 * O, generator=g) / 18).to(dev)
+    b = torch.randn(2 * O, generator=g).to(dev)
+    H = torch.randn(M, O, generator=g).to(dev)
+    dG = torch.randn(M, 2 * O, generator=g).to(dev)
+    rows = torch.from_numpy(np.random.default_rng(8).choice(M - 40, size=512, replace=False)).sort().values
+    rows = torch.cat([rows, torch.arange(M - 40, M)])
+    A64 = A[:, rows.to(dev)].cpu().double().permute(1, 0, 2).reshape(len(rows), S * C)
+    W64, b64 = W.cpu().double(), b.cpu().double()
+    res = {}
+    try:
+        for bx in (1, 0):
+            lib.tune("gemm_bx", bx)
+            C1 = torch.full((M, 2 * O), float("nan"), device=dev)
+            ops.gemm(A, C, T * M * C, S, C, W, 2 * O, 1, C1, 2 * O, 0, 2 * O, b, M, 2 * O)
+            zr, xhr = torch.full((M, 2 * O), float("nan"), device=dev), torch.zeros(M, C, device=dev)
+            ops.gemm_gru_zr(A, C, T * M * C, S, C, W, 2 * O, 1, b, zr, H, xhr, 2)
+            G = torch.full((4, M, O), float("nan"), device=dev)
+            ops.gemm(dG, 2 * O, 0, 1, 2 * O, W[:4 * O], 1, 2 * O, G, O, M * O, O, None, M, 4 * O)
+            res[bx] = (C1, zr, xhr, G)
+    finally:
+        lib.tune("gemm_bx", 1)
+    for bx in (1, 0):
+        C1, zr, xhr, G = res[bx]
+        assert torch.isfinite(C1).all() and torch.isfinite(zr).all() and torch.isfinite(G).all()
+        ref = A64 @ W64 + b64
+        tol = 2e-6 if bx else 2e-5
+        assert_close_with_nonfinite(C1[rows.to(dev)], ref, tol, tol, f"bx={bx} NN 330->128 vs fp64")
+        assert_close_with_nonfinite(zr[rows.to(dev)], torch.sigmoid(ref), tol, tol, f"bx={bx} z|r vs fp64")
+        assert_close_with_nonfinite(xhr[rows.to(dev)][:, 2:], H[rows.to(dev)].cpu().double() * torch.sigmoid(ref)[:, O:], 4 * tol, tol,
+                                    f"bx={bx} r*H vs fp64")
+        G64 = (dG[rows.to(dev)].cpu().double() @ W64[:4 * O].t()).view(len(rows), 4, O).permute(1, 0, 2)
+        assert_close_with_nonfinite(G[:, rows.to(dev)], G64, 2 * tol, tol, f"bx={bx} NT 128->256 vs fp64")
+    for a, b_ in zip(res[1], res[0]):
+        assert float((a - b_).abs().max()) <= 2e-5 * max(1.0, float(b_.abs().max()))
+    # fused epilogue vs product then gate kernel: the same sums; the fused chain uses the hardware exp / reciprocal
+    zr0, xhr0 = res[1][0].clone(), torch.zeros(M, C, device=dev)
+    ops._gru_zr(zr0, H, xhr0, 2)
+    assert float((zr0 - res[1][1]).abs().max()) <= 3e-7 and float((xhr0 - res[1][2]).abs().max()) <= 3e-6
 
 
 @pytest.mark.parametrize("M,K,N", [(333, 64, 2), (130, 128, 1), (77, 36, 3), (260, 256, 4), (65, 100, 2), (64, 16, 4)])

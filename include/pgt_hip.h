@@ -91,7 +91,9 @@ const char* pgt_build_target(void);
  * measured-best configuration.  GEMM: "gemm_db" (pipelined tile kernel: 1 where it applies, 2 always, 0 never),
  * "gemm_db64", "gemm_dbp" (persistent deferred-store tiles: 1 / 2 = on three workgroups / 0), "gemm_skinny"
  * (streaming kernels for an extent <= 4: 1 from 1024 rows / 2 always / 0), "gemm_small_tiles", "gemm_tn_pipe",
- * "gemm_tn_fullk".  Diffusion stack: "slab_pairs".  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
+ * "gemm_tn_fullk", "gemm_small_fill", "gemm_bx" (split-bf16 kernel on the bf16 matrix pipe — fp32 operands as three
+ * bf16 pieces, six piece products, fp32 accumulation; at least as close to the exact product as the fp32 kernels:
+ * 1 where it wins / 2 at any size / 0 never).  Diffusion stack: "slab_pairs".  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
  * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_ellw" (0: pgt_spmm_ellw_f32 runs
  * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
 int pgt_tune(const char* key, int value);
@@ -238,13 +240,16 @@ int pgt_dconv_stack_slab_bwd_f32(const pgt_csr* bwd_o, const pgt_csr* bwd_i, int
                                  int64_t n_samples, int64_t C, int64_t K, float* G, int64_t seg_stride, int folded,
                                  pgt_stream_t stream);
 
-/* ---------------------------------------------------------------- dense feature transform (fp32 MFMA) */
+/* ---------------------------------------------------------------- dense feature transform (fp32 sums on the matrix cores) */
 
 /* C(m,n) = sum_j A_j[M, seg_k] * Bw[j*seg_k : (j+1)*seg_k, 0:N]  (+ bias[N])  (+ C if accumulate)
  * A_j = A + j*a_seg_stride, row stride lda.  Bw element (k,n) at Bw[k*sbk + n*sbn]  (sbk=ldb,sbn=1: NN; sbk=1,sbn=ldb: NT).
  * The output may be split into column segments of c_seg_n columns: C(m,n) lives at
  * C[(n / c_seg_n)*c_seg_stride + m*ldc + n % c_seg_n]  (c_seg_n = N, c_seg_stride = 0 for a plain matrix).
- * exact fp32 (v_mfma_f32_32x32x2_f32). */
+ * Arithmetic: fp32 sums on the matrix cores.  Most shapes run v_mfma_f32_32x32x2_f32 (an exact fmaf chain); tall products
+ * (>= 8192 rows) with K <= 336 run the split-bf16 kernel (three bf16 pieces per fp32 operand, six piece products, fp32
+ * accumulation; measured closer to the exact product than the fmaf chain; an INFINITE input element turns its output row
+ * into nan instead of +-inf / nan).  pgt_tune("gemm_bx", 0) keeps every shape on the fmaf-chain kernels. */
 int pgt_gemm_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                  const float* Bw, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int64_t c_seg_stride,
                  int64_t c_seg_n, const float* bias, int64_t M, int64_t N, int accumulate,

@@ -810,14 +810,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dbp_kernel(GemmArgs g, int gx, in
   if (have_prev) flush_from(0);
 }
 
-struct TnArgs {
-  const float* A; int64_t lda; int64_t a_seg_stride; int n_seg; int seg_k;
-  const float* G; int64_t ldg; float* dW; int64_t lddw; float* db; int M; int N; int rows_per_slab;
-  // deterministic mode (pgt_gemm_tn_det_f32): every (slab, k, n) partial sum is STORED at part + slab * part_stride +
-  // k * lddw + n (bias partials at dbpart + slab * N + n) and tn_reduce_kernel adds the slabs in index order; null =
-  // fp32 atomics straight into dW / db
-  float* part; int64_t part_stride; float* dbpart;
-};
+using TnArgs = PgtTnArgs;   // pgt_common.h (shared with gemm_bx.hip)
 
 __device__ __forceinline__ void tn_out(const TnArgs& g, int slab, int gk, int gn, float v) {
   if (g.part != nullptr) g.part[(int64_t)slab * g.part_stride + (int64_t)gk * g.lddw + gn] = v;
@@ -1719,6 +1712,17 @@ static int tn_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n
     else PGT_LAUNCH((gemm_tn_skinny_kernel<4>), grid, blk, stream, sk);
     if (int rc = pgt_check_launch("pgt_gemm_tn_acc_f32")) return rc;
     return ws ? tn_det_finish(sk.part, sk.part_stride, wgs, Ktot, N, lddw, dW, sk.dbpart, db, stream) : PGT_OK;
+  }
+  // tall products with 128 < K <= 351: split-bf16 kernel on the bf16 matrix pipe (gemm_bx.hip)
+  {
+    TnArgs t{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), G, ldg, dW, lddw, db, (int)M, (int)N, 0,
+             nullptr, 0, nullptr};
+    int64_t nslab = 0;
+    if (g_force_small_tiles != 1 && pgt_gemm_bx_tn_plan(t, &nslab)) {
+      if (ws) { if (int rc = tn_det_setup(ws, ws_bytes, nslab, Ktot, N, lddw, &t.part, &t.part_stride, &t.dbpart)) return rc; }
+      if (int rc = pgt_gemm_bx_tn_launch(t, stream)) return rc;
+      return ws ? tn_det_finish(t.part, t.part_stride, nslab, Ktot, N, lddw, dW, t.dbpart, db, stream) : PGT_OK;
+    }
   }
   // whole-K schedule: tall slabs, K up to 384; every operand element is read once per 128-wide column block
   // (measured at K = 330 inside the DCRNN training step, M = 2.5 M rows: 4.27 ms per step with this schedule for both

@@ -33,6 +33,8 @@
 // The CPU test double does not model the bf16 matrix instruction or buffer descriptors: the entry reports "not covered"
 // and the callers run the fp32 tile kernels (tests/ -m gpu cover this file on the device).
 int pgt_gemm_bx_launch(const PgtGemmArgs&, pgt_stream_t) { return 0; }
+int pgt_gemm_bx_tn_plan(const PgtTnArgs&, int64_t*) { return 0; }
+int pgt_gemm_bx_tn_launch(const PgtTnArgs&, pgt_stream_t) { return PGT_ERR_INVALID; }
 void pgt_gemm_bx_set(int) {}
 #else
 
@@ -373,6 +375,183 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient: dW[k, n] += sum_m A[m, k] G[m, n], db[n] += sum_m G[m, n] (K + 1 <= 352 rows of dW: row K is the bias
+// gradient — A^T carries a row of ones there — N <= 32 NCB columns).  BOTH operands stream, 16 rows per stage; both are
+// cut into three bf16 planes and stored TRANSPOSED in LDS ([column][row], 48-byte rows: `ds_read_b128` of eight
+// consecutive rows of one column is conflict-free), which is the MFMA operand layout for a product that contracts over
+// rows.  A lane converts (column, row pair) units: the two floats of a pair are exactly what v_cvt_pk_bf16_f32 packs into
+// the dword LDS wants.  One persistent 512-thread workgroup per CU, all wavefronts alike: wavefront w owns the 32-column
+// block w % NCB of G and every (8 / NCB)-th 32-row block of dW (six 32 x 32 accumulators at NCB = 4); double-buffered
+// stages, one LDS-only barrier per stage, hand-issued loads / hand-counted waits as above (two loads per unit:
+// vmcnt(2 (EPT - 1))).  A launch covers at most ~5 000 rows per workgroup (the host cuts taller operands into several
+// launches): the rounding error of a running sum grows with its length times its size, and that is what the fp32 kernels'
+// slabs hold (measured at M = 2.5 M rows against fp64: 6.5e-3 of a scale of 1 100 in one launch, 2 - 3e-3 in two — the
+// fp32 kernels: 2e-3).  The sums leave through atomics, or as the deterministic mode's partial-sum slabs.  Measured (lab/gemm_bx_tn_lab.hip, M = 2 543 616, K = 330): N = 128: 1.50 ms against 2.27 ms for the
+// fp32 MFMA kernel, N = 64: 1.10 against 1.47 ms.
+template <int NCB, bool DET>
+__global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_stages, int slab_base) {
+  constexpr int RB = 11, ROWB = 48, APL = RB * 32 * ROWB, GPL = NCB * 32 * ROWB, BUF = 3 * (APL + GPL);
+  constexpr int RSTEP = 8 / NCB, MAXB = (RB + RSTEP - 1) / RSTEP;
+  constexpr int EPT_A = 6, EPT_G = NCB * 32 * 8 / 512, EPT = EPT_A + EPT_G;     // (column, row pair) units per thread and stage
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave % NCB, r0 = wave / NCB;
+  const int nwg = gridDim.x;
+  const int K = g.n_seg * g.seg_k;
+  // ---- LDS: zeros, then the row of ones at column K of A^T (first plane; 1.0 = 0x3f80)
+  for (int i = tid; i < 2 * BUF / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (tid < 16) reinterpret_cast<uint32_t*>(lds + (tid >> 3) * BUF + K * ROWB)[tid & 7] = 0x3f803f80u;
+  // ---- unit map: unit = (column, row pair); lanes along the columns
+  uint32_t goff[EPT];   // byte offset of the unit's first row from the stage base (A or G)
+  uint32_t loff[EPT];   // byte offset of the unit's dword inside a buffer, first plane
+#pragma unroll
+  for (int t = 0; t < EPT_A; ++t) {
+    const int u = tid + 512 * t;
+    if (u < K * 8) {
+      const int rp = u / K, c = u - rp * K, seg = c / g.seg_k, cc = c - seg * g.seg_k;
+      goff[t] = (uint32_t)((seg * g.a_seg_stride + 2 * rp * g.lda + cc) * 4);
+      loff[t] = (uint32_t)(c * ROWB + rp * 4);
+    } else {
+      goff[t] = 0xfffffff0u;                              // outside the descriptor: reads zero ...
+      loff[t] = (uint32_t)((RB * 32 - 1) * ROWB + 32);    // ... and lands in the padding of the last row
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < EPT_G; ++t) {
+    const int u = tid + 512 * t, rp = u / (NCB * 32), c = u - rp * (NCB * 32);
+    goff[EPT_A + t] = c < g.N ? (uint32_t)((2 * rp * g.ldg + c) * 4) : 0xfffffff0u;
+    loff[EPT_A + t] = (uint32_t)(3 * APL + c * ROWB + rp * 4);
+  }
+  const uint32_t lda4 = (uint32_t)(g.lda * 4), ldg4 = (uint32_t)(g.ldg * 4);
+  auto rsrc = [&](const float* p, int64_t bytes) {
+    const uint64_t base = reinterpret_cast<uint64_t>(p);
+    bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0 ? bytes : 0)), 0x00020000u};
+    return r;
+  };
+  const int64_t span_last = (int64_t)(g.n_seg - 1) * g.a_seg_stride * 4;
+  auto a_rsrc = [&](int st) {
+    const int64_t rows_left = (int64_t)g.M - (int64_t)st * 16;
+    const int64_t rows = rows_left < 16 ? rows_left : 16;
+    return rsrc(g.A + (int64_t)(rows_left > 0 ? st : 0) * 16 * g.lda,
+                rows_left > 0 ? span_last + (rows - 1) * g.lda * 4 + (int64_t)g.seg_k * 4 : 0);
+  };
+  auto g_rsrc = [&](int st) {
+    const int64_t rows_left = (int64_t)g.M - (int64_t)st * 16;
+    const int64_t rows = rows_left < 16 ? rows_left : 16;
+    return rsrc(g.G + (int64_t)(rows_left > 0 ? st : 0) * 16 * g.ldg, rows_left > 0 ? (rows - 1) * g.ldg * 4 + (int64_t)g.N * 4 : 0);
+  };
+  float raw0[EPT], raw1[EPT];
+  auto issue = [&](int t, const bx_u32x4& ra, const bx_u32x4& rg) {
+    if (t < EPT_A) {
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(raw0[t]) : "v"(goff[t]), "s"(ra) : "memory");
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(raw1[t]) : "v"(goff[t]), "s"(ra), "s"(lda4) : "memory");
+    } else {
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(raw0[t]) : "v"(goff[t]), "s"(rg) : "memory");
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(raw1[t]) : "v"(goff[t]), "s"(rg), "s"(ldg4) : "memory");
+    }
+  };
+  // rows_left: valid rows of the stage being converted.  A rows past M inside the earlier segments are other data, not
+  // zeros (the descriptor only ends the LAST segment): masked here; G rows past M read zero through the descriptor.
+  auto convert = [&](int t, unsigned char* buf, int rows_left) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(raw0[t]), "+v"(raw1[t]) : "n"(2 * (EPT - 1)));
+    float x = raw0[t], y = raw1[t];
+    if (rows_left < 16 && t < EPT_A) {
+      const int m0 = 2 * (int)((loff[t] % ROWB) >> 2);
+      x = m0 < rows_left ? x : 0.f;
+      y = m0 + 1 < rows_left ? y : 0.f;
+    }
+    uint32_t p1, p2, p3;
+    bx_split2_fast(x, y, p1, p2, p3);
+    unsigned char* d = buf + loff[t];
+    const int pl = t < EPT_A ? APL : GPL;
+    *reinterpret_cast<uint32_t*>(d) = p1;
+    *reinterpret_cast<uint32_t*>(d + pl) = p2;
+    *reinterpret_cast<uint32_t*>(d + 2 * pl) = p3;
+  };
+  pgt_f32x16 acc[MAXB];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int n = cb * 32 + lo;
+  auto flush = [&]() {
+    const int slab = slab_base + (int)blockIdx.x;
+    float* const wbase = (DET ? g.part + (int64_t)slab * g.part_stride : g.dW) + n;
+    float* const bbase = g.db == nullptr ? nullptr : (DET ? g.dbpart + (int64_t)slab * g.N : g.db) + n;
+    const uint32_t ld = (uint32_t)g.lddw;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+      const int rb = r0 + RSTEP * b;
+      if (rb >= RB || n >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (k < K) {
+          if constexpr (DET) wbase[(uint32_t)k * ld] = acc[b][r];
+          else atomicAdd(wbase + (uint32_t)k * ld, acc[b][r]);
+        } else if (k == K && bbase != nullptr) {
+          if constexpr (DET) *bbase = acc[b][r];
+          else atomicAdd(bbase, acc[b][r]);
+        }
+      }
+    }
+  };
+  int st = blockIdx.x;
+  __syncthreads();
+  {
+    const bx_u32x4 ra0 = a_rsrc(st), rg0 = g_rsrc(st), ra1 = a_rsrc(st + nwg), rg1 = g_rsrc(st + nwg);
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) issue(t, ra0, rg0);
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+      convert(t, lds, g.M - st * 16);
+      issue(t, ra1, rg1);
+    }
+  }
+  bx_barrier();
+  int cur = 0;
+  const int afrag = (lane & 31) * ROWB + 16 * (lane >> 5);
+  for (; st < n_stages; st += nwg) {
+    unsigned char* bcur = lds + cur * BUF;
+    unsigned char* bnxt = lds + (cur ^ 1) * BUF;
+    const bx_u32x4 ra2 = a_rsrc(st + 2 * nwg), rg2 = g_rsrc(st + 2 * nwg);
+    const int rows_next = g.M - (st + nwg) * 16;
+    bx_u32x4 fb[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bx_u32x4*>(bcur + 3 * APL + q * GPL + cb * 32 * ROWB + afrag);
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+      const int rb = r0 + RSTEP * b;
+      if (rb < RB) {
+        bx_u32x4 fa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * APL + rb * 32 * ROWB + afrag);
+        acc[b] = bx_mfma(fa[2], fb[0], acc[b]);      // small piece products first
+        acc[b] = bx_mfma(fa[0], fb[2], acc[b]);
+        acc[b] = bx_mfma(fa[1], fb[1], acc[b]);
+        acc[b] = bx_mfma(fa[1], fb[0], acc[b]);
+        acc[b] = bx_mfma(fa[0], fb[1], acc[b]);
+        acc[b] = bx_mfma(fa[0], fb[0], acc[b]);
+      }
+#pragma unroll
+      for (int t = b * EPT / MAXB; t < (b + 1) * EPT / MAXB; ++t) {
+        convert(t, bnxt, rows_next);
+        issue(t, ra2, rg2);
+      }
+    }
+    bx_barrier();
+    cur ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  flush();
+}
+
 int bx_device_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -429,6 +608,61 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
 #undef PGT_BX_GO
   const int rc = pgt_check_launch("pgt_gemm_f32 (split-bf16)");
   return rc ? rc : 1;
+}
+
+// A launch = `wgs` workgroups over a chunk of rows, at most ~5 000 rows (320 stages) per workgroup: what the fp32
+// kernels' slabs hold; at most four launches (the deterministic scratch is sized for 1024 slabs)
+static void bx_tn_schedule(const PgtTnArgs& t, int* wgs, int64_t* chunk_rows, int* n_chunks) {
+  const int64_t n_stages = pgt_cdiv(t.M, 16);
+  *wgs = bx_device_cus();
+  if (g_bx == 2 && *wgs > 3) *wgs = 3;
+  if (*wgs > n_stages) *wgs = (int)n_stages;
+  const int64_t per_wg = g_bx == 2 ? 5 : 320;
+  int64_t chunks = pgt_cdiv(n_stages, (int64_t)*wgs * per_wg);
+  if (chunks > 4) chunks = 4;
+  *chunk_rows = pgt_cdiv(pgt_cdiv(n_stages, chunks), *wgs) * *wgs * 16;      // whole rounds of the workgroups
+  *n_chunks = (int)pgt_cdiv(t.M, *chunk_rows);
+}
+
+int pgt_gemm_bx_tn_plan(const PgtTnArgs& t, int64_t* nslab) {
+  if (!g_bx) return 0;
+  const int64_t K = (int64_t)t.n_seg * t.seg_k;
+  // covered: 128 < K <= 351 (below that the fp32 whole-K kernel is HBM-bound already), N <= 128, tall operands
+  if (K <= 128 || K > 351 || t.N > 128 || t.N < 1) return 0;
+  if (t.M < 16384 && g_bx != 2) return 0;
+  if (t.lda < 0 || t.a_seg_stride < 0 || t.ldg < 0 || !pgt_aligned(t.A, 4) || !pgt_aligned(t.G, 4)) return 0;
+  // 32-bit byte offsets inside a stage's buffer descriptors
+  if (((int64_t)t.n_seg * t.a_seg_stride + 17 * t.lda + t.seg_k) * 4 >= (int64_t)0xfff00000 ||
+      (17 * t.ldg + t.N) * 4 >= (int64_t)0xfff00000) return 0;
+  int wgs, n_chunks;
+  int64_t chunk_rows;
+  bx_tn_schedule(t, &wgs, &chunk_rows, &n_chunks);
+  *nslab = (int64_t)wgs * n_chunks;
+  return 1;
+}
+
+int pgt_gemm_bx_tn_launch(const PgtTnArgs& t, pgt_stream_t stream) {
+  int wgs, n_chunks;
+  int64_t chunk_rows;
+  bx_tn_schedule(t, &wgs, &chunk_rows, &n_chunks);
+  for (int c = 0; c < n_chunks; ++c) {
+    PgtTnArgs u = t;
+    const int64_t row0 = (int64_t)c * chunk_rows;
+    u.A = t.A + row0 * t.lda;
+    u.G = t.G + row0 * t.ldg;
+    u.M = (int)((t.M - row0) < chunk_rows ? (t.M - row0) : chunk_rows);
+    const int n_stages = (int)pgt_cdiv(u.M, 16);
+    dim3 grid((unsigned)wgs), block(512);                  // every workgroup writes its slab, also when it has no stage
+    const int slab_base = c * wgs;
+    if (t.part != nullptr) {
+      if (t.N > 64) PGT_LAUNCH((gemm_bx_tn_kernel<4, true>), grid, block, stream, u, n_stages, slab_base);
+      else PGT_LAUNCH((gemm_bx_tn_kernel<2, true>), grid, block, stream, u, n_stages, slab_base);
+    } else {
+      if (t.N > 64) PGT_LAUNCH((gemm_bx_tn_kernel<4, false>), grid, block, stream, u, n_stages, slab_base);
+      else PGT_LAUNCH((gemm_bx_tn_kernel<2, false>), grid, block, stream, u, n_stages, slab_base);
+    }
+  }
+  return pgt_check_launch("pgt_gemm_tn_acc_f32 (split-bf16)");
 }
 
 #endif  // PGT_EMU

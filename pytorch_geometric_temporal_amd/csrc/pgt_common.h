@@ -122,6 +122,19 @@ struct PgtGemmArgs {
   const float* eH; int64_t eldh; float* eX; int64_t eldx;
   const float* eZ; float* eO0; int64_t eld0; float* eO1; int64_t eld1;
 };
+// Arguments of the weight-gradient kernels: dW[k, n] += sum_m A[m, k] G[m, n], db[n] += sum_m G[m, n].
+struct PgtTnArgs {
+  const float* A; int64_t lda; int64_t a_seg_stride; int n_seg; int seg_k;
+  const float* G; int64_t ldg; float* dW; int64_t lddw; float* db; int M; int N; int rows_per_slab;
+  // deterministic mode (pgt_gemm_tn_det_f32): every (slab, k, n) partial sum is STORED at part + slab * part_stride +
+  // k * lddw + n (bias partials at dbpart + slab * N + n) and tn_reduce_kernel adds the slabs in index order; null =
+  // fp32 atomics straight into dW / db
+  float* part; int64_t part_stride; float* dbpart;
+};
+// gemm_bx.hip, weight gradient: plan = 1 when the split-bf16 kernel covers the shape (*nslab = partial-sum slabs it
+// produces: the caller sizes the deterministic scratch with it), launch as below
+int pgt_gemm_bx_tn_plan(const PgtTnArgs& t, int64_t* nslab);
+int pgt_gemm_bx_tn_launch(const PgtTnArgs& t, pgt_stream_t stream);
 // gemm_bx.hip: 1 = launched, 0 = shape not covered (the caller runs the fp32 MFMA kernels), < 0 = error
 int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream);
 void pgt_gemm_bx_set(int v);

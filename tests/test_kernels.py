@@ -1067,6 +1067,58 @@ def test_gemm_split_bf16_fused_gru_epilogues(M, O, fin):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,segs,segk,N,force", [(20000, 5, 66, 128, False), (17001, 5, 66, 64, False), (3000, 3, 60, 100, True),
+                                                 (1000, 5, 66, 128, True), (517, 2, 66, 33, True), (40, 5, 70, 128, True)])
+def test_gemm_tn_split_bf16_weight_and_bias_gradient(M, segs, segk, N, force):
+    """gemm_bx_tn_kernel: dW += A^T G and db += column sums of G through the bf16 matrix pipe (both operands as three
+    bf16 planes, transposed in LDS; the bias gradient from a row of ones) against fp64 and against the fp32 kernels:
+    ragged row counts, several launches per product (forced small chunks), accumulation into non-zero dW / db, db absent,
+    and the deterministic mode (bitwise reproducible)."""
+    lib = _lib.get_lib()
+    if lib.target != "gfx950":
+        pytest.skip("product library only")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(segs, M, segk, generator=g)
+    G = torch.randn(M, N, generator=g)
+    dW0, db0 = torch.randn(segs * segk, N, generator=g), torch.randn(N, generator=g)
+    A2 = torch.cat([A[j] for j in range(segs)], dim=1).double()
+    refW, refb = dW0.double() + A2.t() @ G.double(), db0.double() + G.double().sum(0)
+    Ad, Gd = A.to(dev), G.to(dev)
+    out = {}
+    try:
+        for bx in ((2 if force else 1), 0):
+            lib.tune("gemm_bx", bx)
+            dW, db = dW0.clone().to(dev), db0.clone().to(dev)
+            ops.gemm_tn_acc(Ad, segk, M * segk, segs, segk, Gd, N, dW, N, db, M, N)
+            out[bx] = (dW, db)
+        bx = 2 if force else 1
+        lib.tune("gemm_bx", bx)
+        dWn = dW0.clone().to(dev)
+        ops.gemm_tn_acc(Ad, segk, M * segk, segs, segk, Gd, N, dWn, N, None, M, N)             # no bias gradient
+        det = []
+        old = ops.DETERMINISTIC_WEIGHT_GRADIENTS
+        ops.DETERMINISTIC_WEIGHT_GRADIENTS = True
+        try:
+            for _ in range(2):
+                dW, db = dW0.clone().to(dev), db0.clone().to(dev)
+                ops.gemm_tn_acc(Ad, segk, M * segk, segs, segk, Gd, N, dW, N, db, M, N)
+                det.append((dW, db))
+        finally:
+            ops.DETERMINISTIC_WEIGHT_GRADIENTS = old
+    finally:
+        lib.tune("gemm_bx", 1)
+    sw, sb = float(refW.abs().max()), float(refb.abs().max())
+    for name, (dW, db) in (("split-bf16", out[bx]), ("fp32", out[0]), ("deterministic", det[0])):
+        assert float((dW.cpu().double() - refW).abs().max()) <= 3e-6 * sw, name
+        assert float((db.cpu().double() - refb).abs().max()) <= 3e-6 * sb + 1e-5, name
+    assert float((dWn.cpu().double() - refW).abs().max()) <= 3e-6 * sw
+    assert torch.equal(det[0][0], det[1][0]) and torch.equal(det[0][1], det[1][1])
+    e_bx, e_32 = float((out[bx][0].cpu().double() - refW).abs().mean()), float((out[0][0].cpu().double() - refW).abs().mean())
+    assert e_bx <= 1.5 * e_32 + 1e-9, (e_bx, e_32)
+
+
+@pytest.mark.gpu
 def test_gemm_split_bf16_at_benchmark_size():
     """The three products the training step routes to the split-bf16 kernel, at BASELINE.json's full size (M = 1024 x 207
     rows out of a 3-step diffusion stack, segment stride 3 M C): 512 sampled rows + the last (ragged) row block against
@@ -1113,6 +1165,17 @@ def test_gemm_split_bf16_at_benchmark_size():
         assert_close_with_nonfinite(G[:, rows.to(dev)], G64, 2 * tol, tol, f"bx={bx} NT 128->256 vs fp64")
     for a, b_ in zip(res[1], res[0]):
         assert float((a - b_).abs().max()) <= 2e-5 * max(1.0, float(b_.abs().max()))
+    # the weight gradient of the same product over all M rows (two launches of the split-bf16 kernel), against fp64
+    A64f = A.cpu().double().permute(1, 0, 2).reshape(M, S * C)
+    dW64, db64 = A64f.t() @ dG.cpu().double(), dG.cpu().double().sum(0)
+    del A64f
+    for bx in (1, 0):
+        lib.tune("gemm_bx", bx)
+        dW, db_ = torch.zeros(S * C, 2 * O, device=dev), torch.zeros(2 * O, device=dev)
+        ops.gemm_tn_acc(A, C, T * M * C, S, C, dG, 2 * O, dW, 2 * O, db_, M, 2 * O)
+        assert float((dW.cpu().double() - dW64).abs().max()) <= 2e-5 * float(dW64.abs().max()), f"bx={bx} dW vs fp64"
+        assert float((db_.cpu().double() - db64).abs().max()) <= 2e-5 * float(db64.abs().max()) + 1e-3, f"bx={bx} db vs fp64"
+    lib.tune("gemm_bx", 1)
     # fused epilogue vs product then gate kernel: the same sums; the fused chain uses the hardware exp / reciprocal
     zr0, xhr0 = res[1][0].clone(), torch.zeros(M, C, device=dev)
     ops._gru_zr(zr0, H, xhr0, 2)

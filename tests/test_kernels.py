@@ -1068,7 +1068,8 @@ def test_gemm_split_bf16_fused_gru_epilogues(M, O, fin):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,segs,segk,N,force", [(20000, 5, 66, 128, False), (17001, 5, 66, 64, False), (3000, 3, 60, 100, True),
-                                                 (1000, 5, 66, 128, True), (517, 2, 66, 33, True), (40, 5, 70, 128, True)])
+                                                 (1000, 5, 66, 128, True), (517, 2, 66, 33, True), (40, 5, 70, 128, True),
+                                                 (2048, 3, 61, 50, True)])
 def test_gemm_tn_split_bf16_weight_and_bias_gradient(M, segs, segk, N, force):
     """gemm_bx_tn_kernel: dW += A^T G and db += column sums of G through the bf16 matrix pipe (both operands as three
     bf16 planes, transposed in LDS; the bias gradient from a row of ones) against fp64 and against the fp32 kernels:

@@ -24,7 +24,7 @@ def newest(pattern):
 
 
 def klass(name):
-    if "gemm_tn" in name:
+    if "gemm_tn" in name or "gemm_bx_tn" in name:
         return "gemm_tn"
     if "gemm" in name:
         return "gemm"

@@ -83,6 +83,7 @@ __device__ __forceinline__ pgt_f32x16 bx_mfma(bx_u32x4 a, bx_u32x4 b, pgt_f32x16
 // elements per lane and block, and the library expf + IEEE division (~50 instructions per element) was a third of the
 // fused kernel's time (182 -> 14x us at M = 211 968)
 __device__ __forceinline__ float bx_sigmoidf(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float bx_tanhf(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }   // |error| ~ 1e-7
 
 // LDS-only workgroup barrier: planes and partial sums travel through LDS (lgkmcnt); the loads of the blocks ahead and the
 // epilogue's stores stay in flight across it (__syncthreads would drain vmcnt as well)
@@ -90,32 +91,38 @@ __device__ __forceinline__ void bx_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 // KSTEPS: 16-deep k-steps covering K (zero padded); WN: 32-column blocks per wavefront; EPI: 0 bias, 1 / 2 the GRU
 // epilogues of PgtGemmArgs.  A: n_seg segments of seg_k (even) columns, consumed as one [M, n_seg * seg_k] operand.
-template <int KSTEPS, int WN, int EPI>
+// Q4 (N <= 64): only two column blocks exist, so K is cut four ways instead — consumers 0, 1 (epilogue) and 2, 3, producers
+// 0, 1 and 2, 3 each take a quarter of the k-steps of column block (wavefront & 1) and three partial sums meet in LDS.
+template <int KSTEPS, int WN, int EPI, bool Q4>
 __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_blocks) {
   constexpr int BM = 32, KP = KSTEPS * 16, SROW = KP * 2 + 16, PLANE = BM * SROW, BUF = 3 * PLANE;
   constexpr int EPT = (KP / 2) / 8;                       // float pairs per producer thread and block (8 threads per row)
   constexpr int PART = 64 * 16 * WN * 4;                  // a column's partial sums, accumulator layout
-  constexpr int KA = KSTEPS / 2, KB = KSTEPS - KA, KMAX = KB;
-  static_assert((KP / 2) % 8 == 0 && KA >= 1, "shape");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 4 * PART + 16];
+  constexpr int NPART = Q4 ? 4 : 2, NCOL = Q4 ? 2 : 4;     // parts of K x column blocks = the eight wavefronts
+  constexpr int KQ = KSTEPS / NPART, KMAX = KSTEPS - (NPART - 1) * KQ;   // k-steps of a part / of the last part
+  constexpr int NREG = (NPART - 1) * NCOL;                 // partial-sum regions
+  static_assert((KP / 2) % 8 == 0 && KQ >= 1 && (!Q4 || WN == 1), "shape");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NREG * PART + 16];
   unsigned char* const stage_part = lds + 2 * BUF;
   typedef __attribute__((address_space(3))) volatile int bx_lds_vint;   // an LDS access (a generic pointer would be a FLAT
-  bx_lds_vint* const part_seen = (bx_lds_vint*)(lds + 2 * BUF + 4 * PART);   // load, and FLAT waits drain vmcnt)
+  bx_lds_vint* const part_seen = (bx_lds_vint*)(lds + 2 * BUF + NREG * PART);   // load, and FLAT waits drain vmcnt)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 3;
   const bool producer = wave >= 4;
+  const int cb = Q4 ? (wc & 1) : wc;                                       // column block
+  const int part = (producer ? NPART / 2 : 0) + (Q4 ? (wc >> 1) : 0);      // part of K
+  const int kbase = part * KQ, ksteps = part == NPART - 1 ? KMAX : KQ;
   const int nwg = gridDim.x;
   const int Ktot = g.n_seg * g.seg_k;
-  // ---- B slice -> registers (consumer: k-steps [0, KA), producer: [KA, KSTEPS)); every piece rounded to nearest
+  // ---- B slice -> registers (this wavefront's columns x its part of K); every piece rounded to nearest
   bx_u32x4 bf[KMAX][WN][3];
   {
-    const int kbase = producer ? KA : 0, ksteps = producer ? KB : KA;
 #pragma unroll
     for (int i = 0; i < KMAX; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const int col = (wc * WN + j) * 32 + (lane & 31), k0 = (kbase + i) * 16 + 8 * (lane >> 5);
+        const int col = (cb * WN + j) * 32 + (lane & 31), k0 = (kbase + i) * 16 + 8 * (lane >> 5);
         float v[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -199,30 +206,34 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
 #pragma unroll
         for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac[j][r] = 0.f; }
 #pragma unroll
-      for (int i = 0; i < KB; ++i) {
-        bx_u32x4 fa[3];
+      for (int i = 0; i < KMAX; ++i) {
+        if (i < ksteps) {
+          bx_u32x4 fa[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (KA + i) * 32);
+          for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (kbase + i) * 32);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          am[j] = bx_mfma(fa[0], bf[i][j][0], am[j]);
-          ac[j] = bx_mfma(fa[0], bf[i][j][1], ac[j]);
-          ac[j] = bx_mfma(fa[1], bf[i][j][0], ac[j]);
-          ac[j] = bx_mfma(fa[1], bf[i][j][1], ac[j]);
-          ac[j] = bx_mfma(fa[0], bf[i][j][2], ac[j]);
-          ac[j] = bx_mfma(fa[2], bf[i][j][0], ac[j]);
+          for (int j = 0; j < WN; ++j) {
+            am[j] = bx_mfma(fa[0], bf[i][j][0], am[j]);
+            ac[j] = bx_mfma(fa[0], bf[i][j][1], ac[j]);
+            ac[j] = bx_mfma(fa[1], bf[i][j][0], ac[j]);
+            ac[j] = bx_mfma(fa[1], bf[i][j][1], ac[j]);
+            ac[j] = bx_mfma(fa[0], bf[i][j][2], ac[j]);
+            ac[j] = bx_mfma(fa[2], bf[i][j][0], ac[j]);
+          }
         }
         // this k-step's share of the next block: fp32 (in registers since the previous iteration) -> bf16 planes in the
         // other buffer, and the load of the block after it into the freed registers
+        if (i < KQ) {
 #pragma unroll
-        for (int t = i * EPT / KB; t < (i + 1) * EPT / KB; ++t) {
-          convert_one(t, bnxt);
-          issue_load(t, r2);
+          for (int t = i * EPT / KQ; t < (i + 1) * EPT / KQ; ++t) {
+            convert_one(t, bnxt);
+            issue_load(t, r2);
+          }
         }
       }
-      while (part_seen[wc] != n_iter) { }     // the consumer has picked up the previous block's partial sums (long ago)
+      while (part_seen[cb] != n_iter) { }     // the consumer has picked up the previous block's partial sums (long ago)
       {
-        float4* d = reinterpret_cast<float4*>(stage_part + wc * PART);
+        float4* d = reinterpret_cast<float4*>(stage_part + ((part - 1) * NCOL + cb) * PART);
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -234,22 +245,61 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (Q4 && part != 0) {
+    // ---- compute-only consumers (Q4): their part of K, then the partial sums, like a producer without a block to fetch
+    bx_barrier();
+    int cur = 0;
+    for (; rb < n_blocks; rb += nwg, ++n_iter) {
+      unsigned char* bcur = lds + cur * BUF;
+      pgt_f32x16 am[WN], ac[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac[j][r] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) {
+        bx_u32x4 fa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (kbase + i) * 32);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          am[j] = bx_mfma(fa[0], bf[i][j][0], am[j]);
+          ac[j] = bx_mfma(fa[0], bf[i][j][1], ac[j]);
+          ac[j] = bx_mfma(fa[1], bf[i][j][0], ac[j]);
+          ac[j] = bx_mfma(fa[1], bf[i][j][1], ac[j]);
+          ac[j] = bx_mfma(fa[0], bf[i][j][2], ac[j]);
+          ac[j] = bx_mfma(fa[2], bf[i][j][0], ac[j]);
+        }
+      }
+      while (part_seen[cb] != n_iter) { }
+      {
+        float4* d = reinterpret_cast<float4*>(stage_part + ((part - 1) * NCOL + cb) * PART);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4)
+            d[(j * 4 + r4) * 64 + lane] = make_float4(am[j][4 * r4] + ac[j][4 * r4], am[j][4 * r4 + 1] + ac[j][4 * r4 + 1],
+                                                      am[j][4 * r4 + 2] + ac[j][4 * r4 + 2], am[j][4 * r4 + 3] + ac[j][4 * r4 + 3]);
+      }
+      bx_barrier();
+      cur ^= 1;
+    }
   } else {
     const int lo = lane & 31, hi = lane >> 5;
     float bias_r[WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const int gn = (wc * WN + j) * 32 + lo;
+      const int gn = (cb * WN + j) * 32 + lo;
       bias_r[j] = (g.bias && gn < g.N) ? g.bias[gn] : 0.f;
     }
-    const bool cols_live = wc * WN * 32 < g.N;           // N <= 96: the last column wavefronts only keep the barriers company
+    const bool cols_live = cb * WN * 32 < g.N;           // N <= 96: the last column wavefronts only keep the barriers company
     // ---- operands of the fused GRU epilogues (H, and Z for the candidate gate), accumulator layout: register r of lane
     // (lo, hi) is row (r & 3) + 8 (r >> 2) + 4 hi, column lo.  They are fetched one block ahead with hand-issued buffer
     // loads (rows past M read zero) placed BEFORE the previous block's stores: loads and stores share vmcnt and return in
     // order, so a load issued behind a block's stores would wait for their write acknowledgements (measured: + 4 us per
     // block).  At the use, at least 16 younger instructions (the previous block's C stores) are in flight: vmcnt(16).
-    const int egn = wc * 32 + lo;                                        // EPI != 0 implies WN == 1
-    const bool e_live = EPI != 0 && cols_live && (EPI == 2 || wc * 32 >= g.eO);
+    const int egn = cb * 32 + lo;                                        // EPI != 0 implies WN == 1
+    const bool e_live = EPI != 0 && cols_live && (EPI == 2 || cb * 32 >= g.eO);
     const int eo = EPI == 1 ? egn - g.eO : egn;
     float eh[EPI != 0 ? 16 : 1], ez[EPI == 2 ? 16 : 1];
     const uint32_t evoff_h = (uint32_t)((4 * hi * g.eldh + eo) * 4), evoff_z = (uint32_t)((4 * hi * 2 * g.eO + egn) * 4);
@@ -292,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
 #pragma unroll
         for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac[j][r] = 0.f; }
 #pragma unroll
-      for (int i = 0; i < KA; ++i) {
+      for (int i = 0; i < KQ; ++i) {
         bx_u32x4 fa[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + i * 32);
@@ -314,8 +364,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       bx_barrier();
       // ---- the producer's partial sums join in registers; the block is stored straight from the accumulator layout: a
       // register is one 128-byte row piece per half-wavefront
-      {
-        const float4* d = reinterpret_cast<const float4*>(stage_part + wc * PART);
+#pragma unroll
+      for (int p = 1; p < NPART; ++p) {
+        const float4* d = reinterpret_cast<const float4*>(stage_part + ((p - 1) * NCOL + cb) * PART);
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -324,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
             acc[j][4 * r4] += v.x; acc[j][4 * r4 + 1] += v.y; acc[j][4 * r4 + 2] += v.z; acc[j][4 * r4 + 3] += v.w;
           }
       }
-      if (lane == 0) part_seen[wc] = n_iter + 1;     // after the reads above: a wavefront's LDS operations complete in order
+      if (lane == 0) part_seen[cb] = n_iter + 1;     // after the reads above: a wavefront's LDS operations complete in order
       if (cols_live) {
         float side[EPI != 0 ? 16 : 1];                 // eX = H r (zr) / the new hidden state (candidate gate)
         if constexpr (EPI != 0) {
@@ -342,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
               acc[0][r] = bx_sigmoidf(acc[0][r]);
               side[r] = eh[r] * acc[0][r];
             } else {
-              acc[0][r] = tanhf(acc[0][r]);
+              acc[0][r] = bx_tanhf(acc[0][r]);
               side[r] = pgt_gru_blend(ez[r], eh[r], acc[0][r]);
             }
           }
@@ -351,7 +402,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
         }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          const int gn = (wc * WN + j) * 32 + lo;
+          const int gn = (cb * WN + j) * 32 + lo;
           if (gn >= g.N) continue;
           const int js = gn / g.c_seg_n;
           float* cp = g.C + (int64_t)js * g.c_seg_stride + (gn - js * g.c_seg_n);
@@ -580,30 +631,28 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (g.N > 256 || (wn == 2 && K > 128)) return 0;
   // Where it does not pay (measured inside the training step, M = 211 968; g_bx = 2 runs them anyway for the tests):
   //  * short K into <= 128 columns: little arithmetic per row block, the fp32 tile kernels are as fast (48 vs 50 us);
-  //  * K <= 64 into 256 columns: 85 vs 85 us;
-  //  * the candidate-gate epilogue (64 columns: half the column wavefronts idle, and the product moves 550 MB with its
-  //    three outputs — the fp32 kernel is already at 3.5 TB/s): 180 vs 158 us.
-  if (g_bx != 2 && ((K <= 128 && wn == 1) || K <= 64 || g.epi == 2)) return 0;
-  if (g.epi) {
-    // the gate epilogues: whole 32-column blocks on either side of the z | r boundary, hidden width = N (h) or N / 2 (zr)
-    if (wn != 1 || K <= 128 || g.c_seg_n != g.N) return 0;
-    if (g.epi == 1 && (g.eO % 32 || g.N != 2 * g.eO)) return 0;
-    if (g.epi == 2 && g.N != g.eO) return 0;
-  }
+  //  * K <= 64 into 256 columns: 85 vs 85 us.
+  // The candidate-gate product (64 columns, 550 MB moved with its three outputs) lost with half the column wavefronts idle
+  // (180 vs 158 us) and wins with K cut four ways and the hardware exp / rcp in its tanh (131 - 144 vs 158 - 164 us).
+  if (g_bx != 2 && ((K <= 128 && wn == 1) || K <= 64)) return 0;
   const int n_blocks = (int)pgt_cdiv(g.M, 32);
   int wgs = bx_device_cus();
   if (g_bx == 2 && wgs > 3) wgs = 3;                    // tests: several blocks per workgroup at small sizes
   if (wgs > n_blocks) wgs = n_blocks;
   dim3 grid((unsigned)wgs), block(512);
-#define PGT_BX_GO(KS_, WN_, EPI_) PGT_LAUNCH((gemm_bx_kernel<KS_, WN_, EPI_>), grid, block, stream, g, n_blocks)
-  if (K > 128) {
-    if (g.epi == 1) PGT_BX_GO(21, 1, 1);
-    else if (g.epi == 2) PGT_BX_GO(21, 1, 2);
-    else PGT_BX_GO(21, 1, 0);
+#define PGT_BX_GO(KS_, WN_, EPI_, Q4_) PGT_LAUNCH((gemm_bx_kernel<KS_, WN_, EPI_, Q4_>), grid, block, stream, g, n_blocks)
+  if (K > 128 && g.N <= 64) {                         // two column blocks: K cut four ways
+    if (g.epi == 1) PGT_BX_GO(21, 1, 1, true);
+    else if (g.epi == 2) PGT_BX_GO(21, 1, 2, true);
+    else PGT_BX_GO(21, 1, 0, true);
+  } else if (K > 128) {
+    if (g.epi == 1) PGT_BX_GO(21, 1, 1, false);
+    else if (g.epi == 2) PGT_BX_GO(21, 1, 2, false);
+    else PGT_BX_GO(21, 1, 0, false);
   } else if (K > 64) {
-    if (wn == 1) PGT_BX_GO(8, 1, 0); else PGT_BX_GO(8, 2, 0);
+    if (wn == 1) PGT_BX_GO(8, 1, 0, false); else PGT_BX_GO(8, 2, 0, false);
   } else {
-    if (wn == 1) PGT_BX_GO(4, 1, 0); else PGT_BX_GO(4, 2, 0);
+    if (wn == 1) PGT_BX_GO(4, 1, 0, false); else PGT_BX_GO(4, 2, 0, false);
   }
 #undef PGT_BX_GO
   const int rc = pgt_check_launch("pgt_gemm_f32 (split-bf16)");

@@ -1,4 +1,6 @@
-// LAB HARNESS (not shipped): split-bf16 GEMM prototype.
+// LAB HARNESS (not shipped): split-bf16 GEMM prototype — the experiment log behind csrc/gemm_bx.hip.
+// Compile-time switches select the variants that were measured (BX_KA, BX_PRIO, BX_TL / BX_TL2 timelines, BX_NOEPI,
+// BX_NOCONV, BX_SLOWSPLIT); the shipped kernel is the default configuration plus the fused epilogues.
 //
 // fp32 operands are split into three bf16 pieces each (x = x1 + x2 + x3, 8 significant bits per piece = the 24 bits of an
 // fp32 significand) and the product is accumulated from the six largest piece products on v_mfma_f32_32x32x16_bf16

@@ -36,11 +36,13 @@ int pgt_gemm_bx_launch(const PgtGemmArgs&, pgt_stream_t) { return 0; }
 int pgt_gemm_bx_tn_plan(const PgtTnArgs&, int64_t*) { return 0; }
 int pgt_gemm_bx_tn_launch(const PgtTnArgs&, pgt_stream_t) { return PGT_ERR_INVALID; }
 void pgt_gemm_bx_set(int) {}
+void pgt_gemm_bx_sym_set(int) {}
 #else
 
 namespace {
 
 int g_bx = 1;   // pgt_tune("gemm_bx"): 1 = where it applies (>= 8192 rows), 2 = at any size (tests), 0 = never
+int g_bx_sym = 1;   // pgt_tune("gemm_bx_sym"): 0 = short-K products on the K-split kernel instead of the symmetric one (A/B)
 
 typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bx_bf16x2 __attribute__((ext_vector_type(2)));
@@ -603,6 +605,149 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
   flush();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Short K (<= 128) into up to 256 columns — the feature-gradient products dP W^T of the training step: nothing to split
+// along K, so all eight wavefronts are alike: wavefront w owns the 32-column block w for the whole K (B slice: KSTEPS x 3
+// fragments in registers), every thread converts its share of the next 32-row block of A, no partial sums, no flag,
+// one LDS-only barrier per block.  Loads AND stores are hand-issued buffer instructions (the descriptors end at the
+// last valid row: ragged blocks need no branch), so that the number of younger instructions at every wait is known:
+// EPT - 1 loads + the 16 stores of the previous block.
+template <int KSTEPS>
+__global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int n_blocks) {
+  constexpr int BM = 32, KP = KSTEPS * 16, SROW = KP * 2 + 16, PLANE = BM * SROW, BUF = 3 * PLANE;
+  constexpr int EPT = (KP / 2) / 16;                      // float pairs per thread and block (16 threads per row)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x;
+  const int Ktot = g.n_seg * g.seg_k;
+  const int col = wave * 32 + lo;
+  const bool live = wave * 32 < g.N;
+  bx_u32x4 bf[KSTEPS][3];
+#pragma unroll
+  for (int i = 0; i < KSTEPS; ++i) {
+    const int k0 = i * 16 + 8 * hi;
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = k0 + t;
+      v[t] = (k < Ktot && col < g.N) ? g.Bw[(int64_t)k * g.sbk + (int64_t)col * g.sbn] : 0.f;
+    }
+    uint32_t p[3][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bx_split2(v[2 * t], v[2 * t + 1], p[0][t], p[1][t], p[2][t]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { bx_u32x4 f = {p[q][0], p[q][1], p[q][2], p[q][3]}; bf[i][q] = f; }
+  }
+  for (int i = tid; i < 2 * BUF / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  int rb = blockIdx.x;
+  if (rb >= n_blocks) return;
+  __syncthreads();
+  // ---- element map: row = tid / 16, pairs (tid % 16) + 16 t
+  const int erow = tid >> 4, el = tid & 15;
+  const int half = g.seg_k >> 1, rpairs = g.n_seg * half;
+  uint32_t goff[EPT];
+#pragma unroll
+  for (int t = 0; t < EPT; ++t) {
+    const int pi = el + 16 * t, seg = pi / half, pp = pi - seg * half;
+    goff[t] = pi < rpairs ? (uint32_t)((seg * g.a_seg_stride + erow * g.lda + 2 * pp) * 4) : 0xfffffff0u;
+  }
+  const uint32_t lbase = (uint32_t)(erow * SROW + el * 4);
+  auto rsrc = [&](const float* p, int64_t bytes) {
+    const uint64_t base = reinterpret_cast<uint64_t>(p);
+    bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0 ? bytes : 0)), 0x00020000u};
+    return r;
+  };
+  const int64_t span_last = (int64_t)(g.n_seg - 1) * g.a_seg_stride * 4;
+  auto a_rsrc = [&](int b) {
+    const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
+    const int64_t rows = rows_left < BM ? rows_left : BM;
+    return rsrc(g.A + (int64_t)(rows_left > 0 ? b : 0) * BM * g.lda, rows_left > 0 ? span_last + (rows - 1) * g.lda * 4 + (int64_t)g.seg_k * 4 : 0);
+  };
+  // the wavefront's output block: column segment js of C (c_seg_n is a multiple of 32), rows of block b
+  const int js = (wave * 32) / g.c_seg_n;
+  const float* cbase = g.C + (int64_t)js * g.c_seg_stride + (wave * 32 - js * g.c_seg_n);
+  const uint32_t cvoff = col < g.N ? (uint32_t)((4 * hi * g.ldc + lo) * 4) : 0xfffffff0u;
+  auto c_rsrc = [&](int b) {
+    const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
+    const int64_t rows = rows_left < BM ? rows_left : BM;
+    return rsrc(cbase + (int64_t)b * BM * g.ldc, ((rows - 1) * g.ldc + 32) * 4);
+  };
+  bx_u32x2 raw[EPT];
+  auto issue_load = [&](int t, const bx_u32x4& r) {
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(raw[t]) : "v"(goff[t]), "s"(r) : "memory");
+  };
+  // younger instructions at the wait for element t: the other EPT - 1 loads, and — from the second block on, for a
+  // wavefront that stores — the 16 stores of the previous block
+  auto convert_one = [&](int t, unsigned char* buf, bool with_stores) {
+    if (with_stores) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1 + 16));
+    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1));
+    uint32_t p1, p2, p3;
+    bx_split2_fast(__uint_as_float(raw[t].x), __uint_as_float(raw[t].y), p1, p2, p3);
+    unsigned char* d = buf + lbase + 64 * t;
+    *reinterpret_cast<uint32_t*>(d) = p1;
+    *reinterpret_cast<uint32_t*>(d + PLANE) = p2;
+    *reinterpret_cast<uint32_t*>(d + 2 * PLANE) = p3;
+  };
+  {
+    const bx_u32x4 r0 = a_rsrc(rb), r1 = a_rsrc(rb + nwg);
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) issue_load(t, r0);
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+      convert_one(t, lds, false);
+      issue_load(t, r1);
+    }
+  }
+  const float bias_r = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(EPT) : "memory");      // the B / bias loads above are older than the EPT block loads
+  bx_barrier();
+  int cur = 0;
+  bool stored = false;
+  const int arow = lo * SROW + 16 * hi;
+  const uint32_t ldc4 = (uint32_t)(g.ldc * 4);
+  for (; rb < n_blocks; rb += nwg) {
+    unsigned char* bcur = lds + cur * BUF;
+    unsigned char* bnxt = lds + (cur ^ 1) * BUF;
+    const bx_u32x4 r2 = a_rsrc(rb + 2 * nwg);
+    pgt_f32x16 am, ac;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { am[r] = 0.f; ac[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < KSTEPS; ++i) {
+      bx_u32x4 fa[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + i * 32);
+      am = bx_mfma(fa[0], bf[i][0], am);
+      ac = bx_mfma(fa[0], bf[i][1], ac);
+      ac = bx_mfma(fa[1], bf[i][0], ac);
+      ac = bx_mfma(fa[1], bf[i][1], ac);
+      ac = bx_mfma(fa[0], bf[i][2], ac);
+      ac = bx_mfma(fa[2], bf[i][0], ac);
+#pragma unroll
+      for (int t = i * EPT / KSTEPS; t < (i + 1) * EPT / KSTEPS; ++t) {
+        convert_one(t, bnxt, stored);
+        issue_load(t, r2);
+      }
+    }
+    if (live) {
+      const bx_u32x4 rc = c_rsrc(rb);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = am[r] + ac[r] + bias_r;
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
+        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(cvoff), "s"(rc), "s"(soff) : "memory");
+      }
+      stored = true;
+    }
+    bx_barrier();
+    cur ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 int bx_device_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -617,6 +762,7 @@ int bx_device_cus() {
 }  // namespace
 
 void pgt_gemm_bx_set(int v) { g_bx = v; }
+void pgt_gemm_bx_sym_set(int v) { g_bx_sym = v; }
 
 int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (!g_bx) return 0;
@@ -634,14 +780,20 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   //  * K <= 64 into 256 columns: 85 vs 85 us.
   // The candidate-gate product (64 columns, 550 MB moved with its three outputs) lost with half the column wavefronts idle
   // (180 vs 158 us) and wins with K cut four ways and the hardware exp / rcp in its tanh (131 - 144 vs 158 - 164 us).
-  if (g_bx != 2 && ((K <= 128 && wn == 1) || K <= 64)) return 0;
+  if (g_bx != 2 && ((K <= 128 && wn == 1) || (K <= 64 && !g_bx_sym))) return 0;
   const int n_blocks = (int)pgt_cdiv(g.M, 32);
+  // short K: the symmetric kernel (one column block per wavefront) when the output layout allows its buffer stores
+  const bool sym_ok = K <= 128 && !g.epi && g.c_seg_n % 32 == 0 && g.ldc >= 0 && g.c_seg_stride >= 0 &&
+                      (33 * g.ldc + 32) * 4 < (int64_t)0xfff00000 && g_bx_sym;
   int wgs = bx_device_cus();
   if (g_bx == 2 && wgs > 3) wgs = 3;                    // tests: several blocks per workgroup at small sizes
   if (wgs > n_blocks) wgs = n_blocks;
   dim3 grid((unsigned)wgs), block(512);
 #define PGT_BX_GO(KS_, WN_, EPI_, Q4_) PGT_LAUNCH((gemm_bx_kernel<KS_, WN_, EPI_, Q4_>), grid, block, stream, g, n_blocks)
-  if (K > 128 && g.N <= 64) {                         // two column blocks: K cut four ways
+  if (sym_ok) {
+    if (K > 64) PGT_LAUNCH((gemm_bx_sym_kernel<8>), grid, block, stream, g, n_blocks);
+    else PGT_LAUNCH((gemm_bx_sym_kernel<4>), grid, block, stream, g, n_blocks);
+  } else if (K > 128 && g.N <= 64) {                         // two column blocks: K cut four ways
     if (g.epi == 1) PGT_BX_GO(21, 1, 1, true);
     else if (g.epi == 2) PGT_BX_GO(21, 1, 2, true);
     else PGT_BX_GO(21, 1, 0, true);

@@ -197,14 +197,14 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_kernel(SlabArgs a
   for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
     float* base = a.TS + (int64_t)b * a.N * a.C;
     T t0[MAXT], i1[MAXT];
-    __syncthreads();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous sample
+    PGT_LDS_BARRIER();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous sample
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS;
       t0[j] = t0n[j];
       if (idx < ntask) reinterpret_cast<T*>(s.bufA)[idx] = t0[j];
     }
-    __syncthreads();
+    PGT_LDS_BARRIER();
     if (b + (int)gridDim.x < a.n_samples) {
       const float* nb = a.TS + (int64_t)(b + (int)gridDim.x) * a.N * a.C;
 #pragma unroll
@@ -228,13 +228,13 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_kernel(SlabArgs a
       }
     }
     if (a.K < 3) continue;  // (uniform) K == 2: no second hop
-    __syncthreads();        // everyone has finished reading T0 out of bufA
+    PGT_LDS_BARRIER();        // everyone has finished reading T0 out of bufA
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS;
       if (idx < ntask) reinterpret_cast<T*>(s.bufA)[idx] = i1[j];
     }
-    __syncthreads();
+    PGT_LDS_BARRIER();
     // hop 2: T2 = 2 P T1 - T0   (Tx_0 is never advanced in the reference, dcrnn.py:106)
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_kernel(SlabArgs a
 
   for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
     float* base = a.TS + (int64_t)b * a.N * a.C;
-    __syncthreads();
+    PGT_LDS_BARRIER();
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_kernel(SlabArgs a
         reinterpret_cast<T*>(s.bufB)[idx] = pb[j];
       }
     }
-    __syncthreads();
+    PGT_LDS_BARRIER();
     if (b + (int)gridDim.x < a.n_samples) prefetch(b + (int)gridDim.x);
     if (a.K >= 3) {
       T g1o[MAXT], g1i[MAXT];
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_kernel(SlabArgs a
           g1i[j] = axpby(2.0f, gather_row<T>(s.rp_i, s.cv_i, s.bufB, r, c, a.C), 1.0f, g1i[j]);
         }
       }
-      __syncthreads();
+      PGT_LDS_BARRIER();
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) {
         const int idx = tid + j * SLAB_THREADS;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_kernel(SlabArgs a
           reinterpret_cast<T*>(s.bufB)[idx] = g1i[j];
         }
       }
-      __syncthreads();
+      PGT_LDS_BARRIER();
     }
     // G0 += P_o^T G1o' + P_i^T G1i'   [ - G2o - G2i unless folded ]
     T g0[MAXT];
@@ -388,13 +388,13 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_p2_kernel(SlabArg
   for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
     float* base = a.TS + (int64_t)b * a.N * a.C;
     T t0[MAXT], i1[MAXT];
-    __syncthreads();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous sample
+    PGT_LDS_BARRIER();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous sample
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       t0[j] = t0n[j];
       if (LIVE(j)) stT(s.bufA + OFF(j), FULL(j), t0[j]);
     }
-    __syncthreads();
+    PGT_LDS_BARRIER();
     if (b + (int)gridDim.x < a.n_samples) {
       const float* nb = a.TS + (int64_t)(b + (int)gridDim.x) * a.N * a.C;
 #pragma unroll
@@ -415,11 +415,11 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_p2_kernel(SlabArg
       }
     }
     if (a.K < 3) continue;  // (uniform) K == 2: no second hop
-    __syncthreads();        // everyone has finished reading T0 out of bufA
+    PGT_LDS_BARRIER();        // everyone has finished reading T0 out of bufA
 #pragma unroll
     for (int j = 0; j < MAXT; ++j)
       if (LIVE(j)) stT(s.bufA + OFF(j), FULL(j), i1[j]);
-    __syncthreads();
+    PGT_LDS_BARRIER();
     // hop 2: T2 = 2 P T1 - T0   (Tx_0 is never advanced in the reference, dcrnn.py:106)
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_p2_kernel(SlabArg
 
   for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
     float* base = a.TS + (int64_t)b * a.N * a.C;
-    __syncthreads();
+    PGT_LDS_BARRIER();
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       if (LIVE(j)) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_p2_kernel(SlabArg
         stT(s.bufB + OFF(j), FULL(j), pb[j]);
       }
     }
-    __syncthreads();
+    PGT_LDS_BARRIER();
     if (b + (int)gridDim.x < a.n_samples) prefetch(b + (int)gridDim.x);
     if (a.K >= 3) {
       T g1o[MAXT], g1i[MAXT];
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_p2_kernel(SlabArg
           g1i[j] = axpby(2.0f, gather_row_p2<T>(s.rp_i, s.cv_i, s.bufB, r, c, a.C, FULL(j)), 1.0f, g1i[j]);
         }
       }
-      __syncthreads();
+      PGT_LDS_BARRIER();
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) {
         if (LIVE(j)) {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_p2_kernel(SlabArg
           stT(s.bufB + OFF(j), FULL(j), g1i[j]);
         }
       }
-      __syncthreads();
+      PGT_LDS_BARRIER();
     }
     // G0 += P_o^T G1o' + P_i^T G1i'   [ - G2o - G2i unless folded ]
     T g0[MAXT];

@@ -29,10 +29,15 @@ typedef float pgt_f32x16 __attribute__((ext_vector_type(16)));
 
 // Wavefront-private LDS hand-off (one lane writes, another lane of the SAME wavefront reads): the hardware keeps a
 // wavefront's LDS operations in order; the test double runs lanes as fibers and needs a rendezvous.
+// PGT_LDS_BARRIER(): workgroup barrier for data that travels through LDS only.  __syncthreads() also drains vmcnt (its
+// fence covers global memory), so a kernel that has global stores in flight pays their write acknowledgements at every
+// barrier; here only the LDS counter is waited for, loads and stores stay in flight across the barrier.
 #ifdef PGT_EMU
 #define PGT_WAVE_SYNC() pgt_emu::wave_barrier()
 #define PGT_SCHED_FENCE() ((void)0)
+#define PGT_LDS_BARRIER() __syncthreads()
 #else
+#define PGT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PGT_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // compiler-only fence: no instruction is scheduled across it (pins software-pipelined LDS reads ahead of MFMAs)
 #define PGT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

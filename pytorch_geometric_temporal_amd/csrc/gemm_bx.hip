@@ -606,23 +606,29 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Short K (<= 128) into up to 256 columns — the feature-gradient products dP W^T of the training step: nothing to split
+// Short K (<= 128) into up to 320 columns — the feature-gradient products dP W^T of the training step: nothing to split
 // along K, so all eight wavefronts are alike: wavefront w owns the 32-column block w for the whole K (B slice: KSTEPS x 3
 // fragments in registers), every thread converts its share of the next 32-row block of A, no partial sums, no flag,
 // one LDS-only barrier per block.  Loads AND stores are hand-issued buffer instructions (the descriptors end at the
 // last valid row: ragged blocks need no branch), so that the number of younger instructions at every wait is known:
-// EPT - 1 loads + the 16 stores of the previous block.
+// EPT - 1 loads + the 16 stores of the previous block.  Column blocks 8 and 9 (N = 320 = five 64-wide stack segments:
+// one product reads dP once instead of a 256-column product plus a 64-column remainder) go to wavefronts 0 and 1 as a
+// second block whose B fragments wait in LDS in operand order.
 template <int KSTEPS>
 __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int n_blocks) {
   constexpr int BM = 32, KP = KSTEPS * 16, SROW = KP * 2 + 16, PLANE = BM * SROW, BUF = 3 * PLANE;
   constexpr int EPT = (KP / 2) / 16;                      // float pairs per thread and block (16 threads per row)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  constexpr int B2 = KSTEPS * 3 * 64 * 16;                // one extra column block's B fragments, operand order
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 2 * B2];
   const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = gridDim.x;
   const int Ktot = g.n_seg * g.seg_k;
   const int col = wave * 32 + lo;
   const bool live = wave * 32 < g.N;
+  const bool two = (wave + 8) * 32 < g.N;                  // this wavefront owns a second column block (wave + 8)
+  const int col2 = (wave + 8) * 32 + lo;
+  bx_u32x4* const b2 = reinterpret_cast<bx_u32x4*>(lds + 2 * BUF + (wave & 1) * B2);
   bx_u32x4 bf[KSTEPS][3];
 #pragma unroll
   for (int i = 0; i < KSTEPS; ++i) {
@@ -640,6 +646,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
     for (int q = 0; q < 3; ++q) { bx_u32x4 f = {p[q][0], p[q][1], p[q][2], p[q][3]}; bf[i][q] = f; }
   }
   for (int i = tid; i < 2 * BUF / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  if (two) {
+#pragma unroll
+    for (int i = 0; i < KSTEPS; ++i) {
+      const int k0 = i * 16 + 8 * hi;
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = k0 + t;
+        v[t] = (k < Ktot && col2 < g.N) ? g.Bw[(int64_t)k * g.sbk + (int64_t)col2 * g.sbn] : 0.f;
+      }
+      uint32_t p[3][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bx_split2(v[2 * t], v[2 * t + 1], p[0][t], p[1][t], p[2][t]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { bx_u32x4 f = {p[q][0], p[q][1], p[q][2], p[q][3]}; b2[(i * 3 + q) * 64 + lane] = f; }
+    }
+  }
   int rb = blockIdx.x;
   if (rb >= n_blocks) return;
   __syncthreads();
@@ -670,10 +693,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   const int js = (wave * 32) / g.c_seg_n;
   const float* cbase = g.C + (int64_t)js * g.c_seg_stride + (wave * 32 - js * g.c_seg_n);
   const uint32_t cvoff = col < g.N ? (uint32_t)((4 * hi * g.ldc + lo) * 4) : 0xfffffff0u;
-  auto c_rsrc = [&](int b) {
+  const int js2 = ((wave + 8) * 32) / g.c_seg_n;
+  const float* cbase2 = g.C + (int64_t)js2 * g.c_seg_stride + ((wave + 8) * 32 - js2 * g.c_seg_n);
+  const uint32_t cvoff2 = col2 < g.N ? (uint32_t)((4 * hi * g.ldc + lo) * 4) : 0xfffffff0u;
+  auto c_rsrc = [&](const float* cb_, int b) {
     const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
     const int64_t rows = rows_left < BM ? rows_left : BM;
-    return rsrc(cbase + (int64_t)b * BM * g.ldc, ((rows - 1) * g.ldc + 32) * 4);
+    return rsrc(cb_ + (int64_t)b * BM * g.ldc, ((rows - 1) * g.ldc + 32) * 4);
   };
   bx_u32x2 raw[EPT];
   auto issue_load = [&](int t, const bx_u32x4& r) {
@@ -681,8 +707,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   };
   // younger instructions at the wait for element t: the other EPT - 1 loads, and — from the second block on, for a
   // wavefront that stores — the 16 stores of the previous block
-  auto convert_one = [&](int t, unsigned char* buf, bool with_stores) {
-    if (with_stores) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1 + 16));
+  auto convert_one = [&](int t, unsigned char* buf, int n_stores) {
+    if (n_stores == 32) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1 + 32));
+    else if (n_stores == 16) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1 + 16));
     else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1));
     uint32_t p1, p2, p3;
     bx_split2_fast(__uint_as_float(raw[t].x), __uint_as_float(raw[t].y), p1, p2, p3);
@@ -697,24 +724,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
     for (int t = 0; t < EPT; ++t) issue_load(t, r0);
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
-      convert_one(t, lds, false);
+      convert_one(t, lds, 0);
       issue_load(t, r1);
     }
   }
   const float bias_r = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+  const float bias_r2 = (g.bias && col2 < g.N) ? g.bias[col2] : 0.f;
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(EPT) : "memory");      // the B / bias loads above are older than the EPT block loads
   bx_barrier();
   int cur = 0;
-  bool stored = false;
+  int stored = 0;                                          // store instructions of the previous block: 0 | 16 | 32
   const int arow = lo * SROW + 16 * hi;
   const uint32_t ldc4 = (uint32_t)(g.ldc * 4);
   for (; rb < n_blocks; rb += nwg) {
     unsigned char* bcur = lds + cur * BUF;
     unsigned char* bnxt = lds + (cur ^ 1) * BUF;
     const bx_u32x4 r2 = a_rsrc(rb + 2 * nwg);
-    pgt_f32x16 am, ac;
+    pgt_f32x16 am, ac, am2, ac2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { am[r] = 0.f; ac[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { am[r] = 0.f; ac[r] = 0.f; am2[r] = 0.f; ac2[r] = 0.f; }
 #pragma unroll
     for (int i = 0; i < KSTEPS; ++i) {
       bx_u32x4 fa[3];
@@ -726,6 +754,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
       ac = bx_mfma(fa[1], bf[i][1], ac);
       ac = bx_mfma(fa[0], bf[i][2], ac);
       ac = bx_mfma(fa[2], bf[i][0], ac);
+      if (two) {
+        bx_u32x4 fb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fb[q] = b2[(i * 3 + q) * 64 + lane];
+        am2 = bx_mfma(fa[0], fb[0], am2);
+        ac2 = bx_mfma(fa[0], fb[1], ac2);
+        ac2 = bx_mfma(fa[1], fb[0], ac2);
+        ac2 = bx_mfma(fa[1], fb[1], ac2);
+        ac2 = bx_mfma(fa[0], fb[2], ac2);
+        ac2 = bx_mfma(fa[2], fb[0], ac2);
+      }
 #pragma unroll
       for (int t = i * EPT / KSTEPS; t < (i + 1) * EPT / KSTEPS; ++t) {
         convert_one(t, bnxt, stored);
@@ -733,14 +772,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
       }
     }
     if (live) {
-      const bx_u32x4 rc = c_rsrc(rb);
+      const bx_u32x4 rc = c_rsrc(cbase, rb);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = am[r] + ac[r] + bias_r;
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
         asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(cvoff), "s"(rc), "s"(soff) : "memory");
       }
-      stored = true;
+      stored = 16;
+      if (two) {
+        const bx_u32x4 rc2 = c_rsrc(cbase2, rb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = am2[r] + ac2[r] + bias_r2;
+          const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
+          asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(cvoff2), "s"(rc2), "s"(soff) : "memory");
+        }
+        stored = 32;
+      }
     }
     bx_barrier();
     cur ^= 1;
@@ -774,7 +823,7 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   // 32-bit byte offsets inside a block's buffer descriptor
   if (((int64_t)g.n_seg * g.a_seg_stride + 33 * g.lda + g.seg_k) * 4 >= (int64_t)0xfff00000) return 0;
   const int wn = g.N <= 128 ? 1 : 2;
-  if (g.N > 256 || (wn == 2 && K > 128)) return 0;
+  if (g.N > 320 || (wn == 2 && K > 128)) return 0;
   // Where it does not pay (measured inside the training step, M = 211 968; g_bx = 2 runs them anyway for the tests):
   //  * short K into <= 128 columns: little arithmetic per row block, the fp32 tile kernels are as fast (48 vs 50 us);
   //  * K <= 64 into 256 columns: 85 vs 85 us.
@@ -783,8 +832,9 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (g_bx != 2 && ((K <= 128 && wn == 1) || (K <= 64 && !g_bx_sym))) return 0;
   const int n_blocks = (int)pgt_cdiv(g.M, 32);
   // short K: the symmetric kernel (one column block per wavefront) when the output layout allows its buffer stores
-  const bool sym_ok = K <= 128 && !g.epi && g.c_seg_n % 32 == 0 && g.ldc >= 0 && g.c_seg_stride >= 0 &&
+  const bool sym_ok = K <= 128 && g.N > 128 && !g.epi && g.c_seg_n % 32 == 0 && g.ldc >= 0 && g.c_seg_stride >= 0 &&
                       (33 * g.ldc + 32) * 4 < (int64_t)0xfff00000 && g_bx_sym;
+  if (g.N > 256 && !sym_ok) return 0;                   // only the symmetric kernel reaches past 256 columns
   int wgs = bx_device_cus();
   if (g_bx == 2 && wgs > 3) wgs = 3;                    // tests: several blocks per workgroup at small sizes
   if (wgs > n_blocks) wgs = n_blocks;

@@ -449,6 +449,7 @@ FUSE_GATE_EPILOGUES = os.environ.get("PGT_FUSE_GATES", "1") != "0"
 # feature-gradient GEMM of the hidden columns (S*O = 320 output columns): 1 = a 256-column product on the persistent
 # deferred-store kernel + a 64-column remainder, 0 = one 320-column product (three 128-wide column tiles, the last masked)
 SPLIT_FEATURE_GRADIENT = os.environ.get("PGT_SPLIT_FG", "1") != "0"
+ONE_FEATURE_GRADIENT = os.environ.get("PGT_ONE_FG", "1") != "0"
 # weight / bias gradients without float atomics (pgt_gemm_tn_det_f32): bitwise reproducible run to run, one extra pass
 # over the per-slab partial sums.  Off by default (the atomics are ~2 % faster at the benchmark shape); PGT_DETERMINISTIC=1
 # or ops.DETERMINISTIC_WEIGHT_GRADIENTS = True turns it on.
@@ -879,6 +880,10 @@ class DCRNNSeqFunction(torch.autograd.Function):
             WzrH = Wzr_b.view(S, C, 2 * O)[:, Fin:, :].reshape(S * O, 2 * O).contiguous()
             NH = S * O
             n1 = (NH // 128) * 128 if (SPLIT_FEATURE_GRADIENT and NH % 128 != 0 and NH > 128 and ((NH // 128) * 128) % O == 0) else NH
+            # tall batches: ONE product over all S*O <= 320 columns on the symmetric split-bf16 kernel (dP is read once;
+            # column blocks 8 and 9 ride along as second blocks) instead of 256 columns + a 64-column remainder
+            if ONE_FEATURE_GRADIENT and M >= 8192 and 128 < NH <= 320 and NH % 32 == 0 and 2 * O <= 128 and O % 32 == 0:
+                n1 = NH
 
         def feature_grad(dP, Wfull, WH, Kd):
             """G[s] = dP W_s^T for every stack segment (the stack adjoint consumes G in place)."""

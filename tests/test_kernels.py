@@ -961,6 +961,7 @@ def _bx_run(A, B, bias, M, segs, segk, N, nt, dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,segs,segk,N,nt", [(5000, 5, 66, 128, False), (4131, 5, 66, 64, False), (3000, 3, 34, 96, False),
                                               (7000, 1, 128, 256, True), (2500, 1, 64, 256, True), (3333, 1, 128, 64, True),
+                                              (6100, 1, 128, 320, True), (2049, 1, 64, 320, True), (900, 1, 100, 192, True),
                                               (2000, 1, 64, 64, True), (100, 5, 66, 128, False), (31, 1, 64, 64, True),
                                               (1025, 2, 24, 40, False), (640, 1, 16, 128, True)])
 def test_gemm_split_bf16_is_at_least_as_accurate_as_the_fp32_kernels(M, segs, segk, N, nt):

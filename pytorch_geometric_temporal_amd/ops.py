@@ -882,7 +882,9 @@ class DCRNNSeqFunction(torch.autograd.Function):
             n1 = (NH // 128) * 128 if (SPLIT_FEATURE_GRADIENT and NH % 128 != 0 and NH > 128 and ((NH // 128) * 128) % O == 0) else NH
             # tall batches: ONE product over all S*O <= 320 columns on the symmetric split-bf16 kernel (dP is read once;
             # column blocks 8 and 9 ride along as second blocks) instead of 256 columns + a 64-column remainder
-            if ONE_FEATURE_GRADIENT and M >= 8192 and 128 < NH <= 320 and NH % 32 == 0 and 2 * O <= 128 and O % 32 == 0:
+            # (from 32 768 rows: at B = 64, M = 13 248, the two-block wavefronts leave the second round of row blocks
+            # half empty and the whole step is 15 % slower than with the 256 + 64 split)
+            if ONE_FEATURE_GRADIENT and M >= 32768 and 128 < NH <= 320 and NH % 32 == 0 and 2 * O <= 128 and O % 32 == 0:
                 n1 = NH
 
         def feature_grad(dP, Wfull, WH, Kd):

@@ -830,6 +830,15 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   // The candidate-gate product (64 columns, 550 MB moved with its three outputs) lost with half the column wavefronts idle
   // (180 vs 158 us) and wins with K cut four ways and the hardware exp / rcp in its tanh (131 - 144 vs 158 - 164 us).
   if (g_bx != 2 && ((K <= 128 && wn == 1) || (K <= 64 && !g_bx_sym))) return 0;
+  if (g.epi) {
+    // the gate epilogues: whole 32-column blocks on either side of the z | r boundary, hidden width = N (h) or N / 2 (zr),
+    // one output segment, K in the 21-step bucket (the short-K kernels have no epilogue variants)
+    if (wn != 1 || K <= 128 || g.c_seg_n != g.N) return 0;
+    if (g.epi == 1 && (g.eO % 32 || g.N != 2 * g.eO)) return 0;
+    // candidate gate: N = hidden <= 64 (the 128-wide instantiation would spill registers: scripts/bx_isa_audit.py)
+    if (g.epi == 2 && (g.N != g.eO || g.N > 64)) return 0;
+    if (g.epi != 1 && g.epi != 2) return 0;
+  }
   const int n_blocks = (int)pgt_cdiv(g.M, 32);
   // short K: the symmetric kernel (one column block per wavefront) when the output layout allows its buffer stores
   const bool sym_ok = K <= 128 && g.N > 128 && !g.epi && g.c_seg_n % 32 == 0 && g.ldc >= 0 && g.c_seg_stride >= 0 &&
@@ -849,7 +858,6 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
     else PGT_BX_GO(21, 1, 0, true);
   } else if (K > 128) {
     if (g.epi == 1) PGT_BX_GO(21, 1, 1, false);
-    else if (g.epi == 2) PGT_BX_GO(21, 1, 2, false);
     else PGT_BX_GO(21, 1, 0, false);
   } else if (K > 64) {
     if (wn == 1) PGT_BX_GO(8, 1, 0, false); else PGT_BX_GO(8, 2, 0, false);

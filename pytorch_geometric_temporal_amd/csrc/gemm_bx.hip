@@ -29,67 +29,142 @@
 // behind (measured: 157 -> 128 us).  For the same reason nothing in the steady state uses FLAT or scratch accesses.
 #include "pgt_common.h"
 
-#ifdef PGT_EMU
-// The CPU test double does not model the bf16 matrix instruction or buffer descriptors: the entry reports "not covered"
-// and the callers run the fp32 tile kernels (tests/ -m gpu cover this file on the device).
-int pgt_gemm_bx_launch(const PgtGemmArgs&, pgt_stream_t) { return 0; }
-int pgt_gemm_bx_tn_plan(const PgtTnArgs&, int64_t*) { return 0; }
-int pgt_gemm_bx_tn_launch(const PgtTnArgs&, pgt_stream_t) { return PGT_ERR_INVALID; }
-void pgt_gemm_bx_set(int) {}
-void pgt_gemm_bx_sym_set(int) {}
-#else
-
 namespace {
 
 int g_bx = 1;   // pgt_tune("gemm_bx"): 1 = where it applies (>= 8192 rows), 2 = at any size (tests), 0 = never
 int g_bx_sym = 1;   // pgt_tune("gemm_bx_sym"): 0 = short-K products on the K-split kernel instead of the symmetric one (A/B)
 
+// ---- platform layer: the handful of operations below are hand-written gfx950 instructions on the device and plain C++
+// in the CPU test double (tests/hipemu: fibers, no vmcnt, no descriptors), so that the SAME kernel bodies run under both.
+#ifdef PGT_EMU
+typedef uint32_t bx_u32x4 __attribute__((vector_size(16)));
+typedef uint32_t bx_u32x2 __attribute__((vector_size(8)));
+struct BxRsrc { const unsigned char* base; uint32_t bytes; };
+static inline BxRsrc bx_make_rsrc(const void* p, int64_t bytes) { return BxRsrc{static_cast<const unsigned char*>(p), (uint32_t)bytes}; }
+static inline bool bx_in_range(const BxRsrc& r, uint64_t off, unsigned size) { return off + size <= r.bytes; }   // raw buffer rule
+#define BX_LOAD2(dst, voff, rs) do { uint64_t o_ = (voff); if (bx_in_range(rs, o_, 8)) memcpy(&(dst), (rs).base + o_, 8); else memset(&(dst), 0, 8); } while (0)
+#define BX_LOAD1(dst, voff, rs) do { uint64_t o_ = (voff); if (bx_in_range(rs, o_, 4)) memcpy(&(dst), (rs).base + o_, 4); else memset(&(dst), 0, 4); } while (0)
+#define BX_LOAD1S(dst, voff, rs, soff) do { uint64_t o_ = (uint64_t)(uint32_t)(voff) + (uint32_t)(soff); if (bx_in_range(rs, o_, 4)) memcpy(&(dst), (rs).base + o_, 4); else memset(&(dst), 0, 4); } while (0)
+#define BX_STORE1S(val, voff, rs, soff) do { uint64_t o_ = (uint64_t)(uint32_t)(voff) + (uint32_t)(soff); float v_ = (val); if (bx_in_range(rs, o_, 4)) memcpy(const_cast<unsigned char*>((rs).base) + o_, &v_, 4); } while (0)
+#define BX_WAIT(n, reg) ((void)0)
+#define BX_WAIT2(n, r0, r1) ((void)0)
+#define BX_WAIT_PLAIN(n) ((void)0)
+#define BX_DRAIN() ((void)0)
+#define BX_FENCE() ((void)0)
+#define BX_SGPR(x) (x)
+#define BX_SETPRIO(n) ((void)0)
+#define BX_YIELD() pgt_emu::yield_()
+typedef volatile int bx_lds_vint;
+static inline void bx_barrier() { __syncthreads(); }
+static inline float bx_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t bx_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline uint32_t bx_bf16_rne(float x) {                         // v_cvt_pk_bf16_f32 on one value: bits of the bf16
+  uint32_t u = bx_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // nan stays nan
+  return (uint32_t)(((uint64_t)u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline uint32_t bx_pack(float x, float y) { return (bx_bf16_rne(x) & 0xffffu) | (bx_bf16_rne(y) << 16); }
+static inline uint32_t bx_perm_hi16(uint32_t y, uint32_t x) { return (y & 0xffff0000u) | (x >> 16); }
+static inline float bx_rcp(float x) { return 1.f / x; }
+static inline float bx_exp(float x) { return expf(x); }
+// v_mfma_f32_32x32x16_bf16 on fibers: lane l holds A[i = l % 32][k = 8 (l / 32) .. + 7] and B[k = 8 (l / 32) .. + 7][j = l % 32];
+// D as pgt_emu_mfma_32x32x2
+static uint32_t bx_emu_a[16][64][4], bx_emu_b[16][64][4];
+static inline pgt_f32x16 bx_mfma(bx_u32x4 a, bx_u32x4 b, pgt_f32x16 c) {
+  pgt_emu::State& st = pgt_emu::S();
+  const unsigned w = st.cur / 64, lane = st.cur % 64;
+  for (int q = 0; q < 4; ++q) { bx_emu_a[w][lane][q] = a[q]; bx_emu_b[w][lane][q] = b[q]; }
+  pgt_emu::wave_barrier();
+  const unsigned col = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    const unsigned row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float acc = c[r];
+    for (int kk = 0; kk < 16; ++kk) {
+      const unsigned kh = kk >> 3, t = kk & 7;
+      const uint32_t wa = bx_emu_a[w][row + 32 * kh][t >> 1], wb = bx_emu_b[w][col + 32 * kh][t >> 1];
+      const float av = bx_as_float((t & 1) ? (wa & 0xffff0000u) : (wa << 16)), bv = bx_as_float((t & 1) ? (wb & 0xffff0000u) : (wb << 16));
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  pgt_emu::wave_barrier();
+  return c;
+}
+#else
 typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bx_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float bx_f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t bx_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t bx_u32x2 __attribute__((ext_vector_type(2)));
-
+// buffer descriptor (raw buffer, stride 0): accesses past `bytes` read zero / are dropped
+typedef bx_u32x4 BxRsrc;
+__device__ __forceinline__ BxRsrc bx_make_rsrc(const void* p, int64_t bytes) {
+  const uint64_t base = reinterpret_cast<uint64_t>(p);
+  bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes), 0x00020000u};
+  return r;
+}
+#define BX_LOAD2(dst, voff, rs) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory")
+#define BX_LOAD1(dst, voff, rs) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory")
+#define BX_LOAD1S(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory")
+#define BX_STORE1S(val, voff, rs, soff) asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(val), "v"(voff), "s"(rs), "s"(soff) : "memory")
+// hand-counted waits, tied to the registers they release so that the consumer cannot be scheduled above them
+#define BX_WAIT(n, reg) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n))
+#define BX_WAIT2(n, r0, r1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(n))
+#define BX_WAIT_PLAIN(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+#define BX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define BX_FENCE() asm volatile("" ::: "memory")
+#define BX_SGPR(x) __builtin_amdgcn_readfirstlane(x)
+#define BX_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define BX_YIELD() ((void)0)
+typedef __attribute__((address_space(3))) volatile int bx_lds_vint;   // an LDS access (a generic pointer would be a FLAT load,
+                                                                      // and FLAT waits drain vmcnt)
+// LDS-only workgroup barrier: planes and partial sums travel through LDS (lgkmcnt); the loads of the blocks ahead and the
+// epilogue's stores stay in flight across it (__syncthreads would drain vmcnt as well)
+__device__ __forceinline__ void bx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float bx_as_float(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t bx_as_uint(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ uint32_t bx_pack(float x, float y) {     // v_cvt_pk_bf16_f32: round to nearest even
   bx_f32x2 v = {x, y};
   bx_bf16x2 r = __builtin_convertvector(v, bx_bf16x2);
   return __builtin_bit_cast(uint32_t, r);
 }
+__device__ __forceinline__ uint32_t bx_perm_hi16(uint32_t y, uint32_t x) { return __builtin_amdgcn_perm(y, x, 0x07060302u); }
+__device__ __forceinline__ float bx_rcp(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float bx_exp(float x) { return __expf(x); }
+__device__ __forceinline__ pgt_f32x16 bx_mfma(bx_u32x4 a, bx_u32x4 b, pgt_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bx_bf16x8, a), __builtin_bit_cast(bx_bf16x8, b), c, 0, 0, 0);
+}
+#endif
+
 // (x, y) -> three packed bf16 pairs (low half = x's piece), every piece rounded to nearest: the resident operand
 __device__ __forceinline__ void bx_split2(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
   p1 = bx_pack(x, y);
-  float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
+  float rx = x - bx_as_float(p1 << 16), ry = y - bx_as_float(p1 & 0xffff0000u);
   rx = (fabsf(rx) <= 3.0e38f) ? rx : 0.f;      // inf / nan: the first piece carries it, the others are zero
   ry = (fabsf(ry) <= 3.0e38f) ? ry : 0.f;
   p2 = bx_pack(rx, ry);
-  rx -= __uint_as_float(p2 << 16);
-  ry -= __uint_as_float(p2 & 0xffff0000u);
+  rx -= bx_as_float(p2 << 16);
+  ry -= bx_as_float(p2 & 0xffff0000u);
   p3 = bx_pack(rx, ry);
 }
 // the streaming operand: first piece rounded to nearest, the other two cut off (x - x1 has at most 16 significant bits,
 // the second cut leaves at most 9): 9 instructions per pair
 __device__ __forceinline__ void bx_split2_fast(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
   p1 = bx_pack(x, y);
-  float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
-  p2 = __builtin_amdgcn_perm(__float_as_uint(ry), __float_as_uint(rx), 0x07060302u);
-  rx -= __uint_as_float(p2 << 16);
-  ry -= __uint_as_float(p2 & 0xffff0000u);
-  p3 = __builtin_amdgcn_perm(__float_as_uint(ry), __float_as_uint(rx), 0x07060302u);
+  float rx = x - bx_as_float(p1 << 16), ry = y - bx_as_float(p1 & 0xffff0000u);
+  p2 = bx_perm_hi16(bx_as_uint(ry), bx_as_uint(rx));
+  rx -= bx_as_float(p2 << 16);
+  ry -= bx_as_float(p2 & 0xffff0000u);
+  p3 = bx_perm_hi16(bx_as_uint(ry), bx_as_uint(rx));
 }
 
-__device__ __forceinline__ pgt_f32x16 bx_mfma(bx_u32x4 a, bx_u32x4 b, pgt_f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bx_bf16x8, a), __builtin_bit_cast(bx_bf16x8, b), c, 0, 0, 0);
-}
-
-// sigmoid on the hardware exp / reciprocal (1 ulp each): the gate chain runs on the four consumer wavefronts only, sixteen
-// elements per lane and block, and the library expf + IEEE division (~50 instructions per element) was a third of the
-// fused kernel's time (182 -> 14x us at M = 211 968)
-__device__ __forceinline__ float bx_sigmoidf(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float bx_tanhf(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }   // |error| ~ 1e-7
-
-// LDS-only workgroup barrier: planes and partial sums travel through LDS (lgkmcnt); the loads of the blocks ahead and the
-// epilogue's stores stay in flight across it (__syncthreads would drain vmcnt as well)
-__device__ __forceinline__ void bx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// sigmoid / tanh on the hardware exp / reciprocal (1 ulp each): the gate chain runs on the four consumer wavefronts only,
+// sixteen elements per lane and block, and the library expf + IEEE division (~50 instructions per element) was a third of
+// the fused kernel's time (182 -> 168 us at M = 211 968)
+__device__ __forceinline__ float bx_sigmoidf(float x) { return bx_rcp(1.f + bx_exp(-x)); }
+__device__ __forceinline__ float bx_tanhf(float x) { return 1.f - 2.f * bx_rcp(1.f + bx_exp(2.f * x)); }   // |error| ~ 1e-7
 
 // KSTEPS: 16-deep k-steps covering K (zero padded); WN: 32-column blocks per wavefront; EPI: 0 bias, 1 / 2 the GRU
 // epilogues of PgtGemmArgs.  A: n_seg segments of seg_k (even) columns, consumed as one [M, n_seg * seg_k] operand.
@@ -106,10 +181,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
   static_assert((KP / 2) % 8 == 0 && KQ >= 1 && (!Q4 || WN == 1), "shape");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NREG * PART + 16];
   unsigned char* const stage_part = lds + 2 * BUF;
-  typedef __attribute__((address_space(3))) volatile int bx_lds_vint;   // an LDS access (a generic pointer would be a FLAT
-  bx_lds_vint* const part_seen = (bx_lds_vint*)(lds + 2 * BUF + NREG * PART);   // load, and FLAT waits drain vmcnt)
+  bx_lds_vint* const part_seen = (bx_lds_vint*)(lds + 2 * BUF + NREG * PART);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = BX_SGPR(tid >> 6);
   const int wc = wave & 3;
   const bool producer = wave >= 4;
   const int cb = Q4 ? (wc & 1) : wc;                                       // column block
@@ -164,29 +238,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
       const int64_t rows = rows_left < BM ? rows_left : BM;
       const int64_t bytes = rows_left > 0 ? span_last + (rows - 1) * g.lda * 4 + (int64_t)g.seg_k * 4 : 0;
-      const uint64_t base = reinterpret_cast<uint64_t>(g.A + (int64_t)(rows_left > 0 ? b : 0) * BM * g.lda);
-      bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes), 0x00020000u};
-      return r;
+      return bx_make_rsrc(g.A + (int64_t)(rows_left > 0 ? b : 0) * BM * g.lda, bytes);
     };
     // Loads return in order and every conversion is followed by the reload of its register pair, so exactly EPT - 1
     // younger loads are in flight when element t of the previous round is due.
     bx_u32x2 raw[EPT];
-    auto issue_load = [&](int t, const bx_u32x4& r) {
-      asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(raw[t]) : "v"(goff[t]), "s"(r) : "memory");
+    auto issue_load = [&](int t, const BxRsrc& r) {
+      BX_LOAD2(raw[t], goff[t], r);
     };
     auto convert_one = [&](int t, unsigned char* buf) {
       uint32_t p1, p2, p3;
-      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1));
-      bx_split2_fast(__uint_as_float(raw[t].x), __uint_as_float(raw[t].y), p1, p2, p3);
+      BX_WAIT(EPT - 1, raw[t]);
+      bx_split2_fast(bx_as_float(raw[t][0]), bx_as_float(raw[t][1]), p1, p2, p3);
       unsigned char* d = buf + lbase + 32 * t;
       *reinterpret_cast<uint32_t*>(d) = p1;
       *reinterpret_cast<uint32_t*>(d + PLANE) = p2;
       *reinterpret_cast<uint32_t*>(d + 2 * PLANE) = p3;
     };
     {
-      const bx_u32x4 r0 = block_rsrc(rb), r1 = block_rsrc(rb + nwg);
+      const BxRsrc r0 = block_rsrc(rb), r1 = block_rsrc(rb + nwg);
 #pragma unroll
       for (int t = 0; t < EPT; ++t) issue_load(t, r0);
 #pragma unroll
@@ -195,13 +265,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
         issue_load(t, r1);
       }
     }
-    __builtin_amdgcn_s_setprio(1);        // the younger half of the workgroup loses the VALU arbitration otherwise
+    BX_SETPRIO(1);        // the younger half of the workgroup loses the VALU arbitration otherwise
     bx_barrier();
     int cur = 0;
     for (; rb < n_blocks; rb += nwg, ++n_iter) {
       unsigned char* bcur = lds + cur * BUF;
       unsigned char* bnxt = lds + (cur ^ 1) * BUF;
-      const bx_u32x4 r2 = block_rsrc(rb + 2 * nwg);
+      const BxRsrc r2 = block_rsrc(rb + 2 * nwg);
       pgt_f32x16 am[WN], ac[WN];
 #pragma unroll
       for (int j = 0; j < WN; ++j)
@@ -233,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
           }
         }
       }
-      while (part_seen[cb] != n_iter) { }     // the consumer has picked up the previous block's partial sums (long ago)
+      while (part_seen[cb] != n_iter) { BX_YIELD(); }     // the consumer has picked up the previous block's partial sums (long ago)
       {
         float4* d = reinterpret_cast<float4*>(stage_part + ((part - 1) * NCOL + cb) * PART);
 #pragma unroll
@@ -246,7 +316,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       bx_barrier();      // partial sums visible; everyone is done with this block's planes and the next block's are complete
       cur ^= 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BX_DRAIN();
   } else if (Q4 && part != 0) {
     // ---- compute-only consumers (Q4): their part of K, then the partial sums, like a producer without a block to fetch
     bx_barrier();
@@ -273,7 +343,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
           ac[j] = bx_mfma(fa[2], bf[i][j][0], ac[j]);
         }
       }
-      while (part_seen[cb] != n_iter) { }
+      while (part_seen[cb] != n_iter) { BX_YIELD(); }
       {
         float4* d = reinterpret_cast<float4*>(stage_part + ((part - 1) * NCOL + cb) * PART);
 #pragma unroll
@@ -309,26 +379,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
       const int64_t rows = rows_left < BM ? rows_left : BM;
       const int64_t bytes = rows_left > 0 ? ((rows - 1) * ld + cols) * 4 : 0;
-      const uint64_t base = reinterpret_cast<uint64_t>(p + (int64_t)(rows_left > 0 ? b : 0) * BM * ld);
-      bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes), 0x00020000u};
-      return r;
+      return bx_make_rsrc(p + (int64_t)(rows_left > 0 ? b : 0) * BM * ld, bytes);
     };
     auto e_issue = [&](int b) {
       if constexpr (EPI != 0) {
-        const bx_u32x4 rh = e_rsrc(g.eH, g.eldh, g.eO, b);
+        const BxRsrc rh = e_rsrc(g.eH, g.eldh, g.eO, b);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int soff = __builtin_amdgcn_readfirstlane(((r & 3) + 8 * (r >> 2)) * (int)g.eldh * 4);
-          asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(eh[r]) : "v"(evoff_h), "s"(rh), "s"(soff) : "memory");
+          const int soff = BX_SGPR(((r & 3) + 8 * (r >> 2)) * (int)g.eldh * 4);
+          BX_LOAD1S(eh[r], evoff_h, rh, soff);
         }
         if constexpr (EPI == 2) {
-          const bx_u32x4 rz = e_rsrc(g.eZ, 2 * g.eO, 2 * g.eO, b);
+          const BxRsrc rz = e_rsrc(g.eZ, 2 * g.eO, 2 * g.eO, b);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int soff = __builtin_amdgcn_readfirstlane(((r & 3) + 8 * (r >> 2)) * 2 * g.eO * 4);
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(ez[r]) : "v"(evoff_z), "s"(rz), "s"(soff) : "memory");
+            const int soff = BX_SGPR(((r & 3) + 8 * (r >> 2)) * 2 * g.eO * 4);
+            BX_LOAD1S(ez[r], evoff_z, rz, soff);
           }
         }
       }
@@ -382,11 +448,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
         float side[EPI != 0 ? 16 : 1];                 // eX = H r (zr) / the new hidden state (candidate gate)
         if constexpr (EPI != 0) {
           if (e_live) {
-            if (n_iter == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (n_iter == 0) BX_DRAIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              asm volatile("s_waitcnt vmcnt(16)" : "+v"(eh[r]));
-              if constexpr (EPI == 2) asm volatile("s_waitcnt vmcnt(16)" : "+v"(ez[r]));
+              BX_WAIT(16, eh[r]);
+              if constexpr (EPI == 2) BX_WAIT(16, ez[r]);
             }
           }
 #pragma unroll
@@ -400,7 +466,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
             }
           }
           if (e_live) e_issue(rb + nwg);               // the next block's operands, ahead of this block's stores
-          asm volatile("" ::: "memory");
+          BX_FENCE();
         }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
@@ -424,7 +490,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       }
       cur ^= 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BX_DRAIN();
   }
 }
 
@@ -449,7 +515,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
   constexpr int EPT_A = 6, EPT_G = NCB * 32 * 8 / 512, EPT = EPT_A + EPT_G;     // (column, row pair) units per thread and stage
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = BX_SGPR(tid >> 6);
   const int cb = wave % NCB, r0 = wave / NCB;
   const int nwg = gridDim.x;
   const int K = g.n_seg * g.seg_k;
@@ -480,11 +546,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
   }
   const uint32_t lda4 = (uint32_t)(g.lda * 4), ldg4 = (uint32_t)(g.ldg * 4);
   auto rsrc = [&](const float* p, int64_t bytes) {
-    const uint64_t base = reinterpret_cast<uint64_t>(p);
-    bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0 ? bytes : 0)), 0x00020000u};
-    return r;
+    return bx_make_rsrc(p, bytes > 0 ? bytes : 0);
   };
   const int64_t span_last = (int64_t)(g.n_seg - 1) * g.a_seg_stride * 4;
   auto a_rsrc = [&](int st) {
@@ -499,19 +561,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
     return rsrc(g.G + (int64_t)(rows_left > 0 ? st : 0) * 16 * g.ldg, rows_left > 0 ? (rows - 1) * g.ldg * 4 + (int64_t)g.N * 4 : 0);
   };
   float raw0[EPT], raw1[EPT];
-  auto issue = [&](int t, const bx_u32x4& ra, const bx_u32x4& rg) {
+  auto issue = [&](int t, const BxRsrc& ra, const BxRsrc& rg) {
     if (t < EPT_A) {
-      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(raw0[t]) : "v"(goff[t]), "s"(ra) : "memory");
-      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(raw1[t]) : "v"(goff[t]), "s"(ra), "s"(lda4) : "memory");
+      BX_LOAD1(raw0[t], goff[t], ra);
+      BX_LOAD1S(raw1[t], goff[t], ra, lda4);
     } else {
-      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(raw0[t]) : "v"(goff[t]), "s"(rg) : "memory");
-      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(raw1[t]) : "v"(goff[t]), "s"(rg), "s"(ldg4) : "memory");
+      BX_LOAD1(raw0[t], goff[t], rg);
+      BX_LOAD1S(raw1[t], goff[t], rg, ldg4);
     }
   };
   // rows_left: valid rows of the stage being converted.  A rows past M inside the earlier segments are other data, not
   // zeros (the descriptor only ends the LAST segment): masked here; G rows past M read zero through the descriptor.
   auto convert = [&](int t, unsigned char* buf, int rows_left) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(raw0[t]), "+v"(raw1[t]) : "n"(2 * (EPT - 1)));
+    BX_WAIT2(2 * (EPT - 1), raw0[t], raw1[t]);
     float x = raw0[t], y = raw1[t];
     if (rows_left < 16 && t < EPT_A) {
       const int m0 = 2 * (int)((loff[t] % ROWB) >> 2);
@@ -558,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
   int st = blockIdx.x;
   __syncthreads();
   {
-    const bx_u32x4 ra0 = a_rsrc(st), rg0 = g_rsrc(st), ra1 = a_rsrc(st + nwg), rg1 = g_rsrc(st + nwg);
+    const BxRsrc ra0 = a_rsrc(st), rg0 = g_rsrc(st), ra1 = a_rsrc(st + nwg), rg1 = g_rsrc(st + nwg);
 #pragma unroll
     for (int t = 0; t < EPT; ++t) issue(t, ra0, rg0);
 #pragma unroll
@@ -573,7 +635,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
   for (; st < n_stages; st += nwg) {
     unsigned char* bcur = lds + cur * BUF;
     unsigned char* bnxt = lds + (cur ^ 1) * BUF;
-    const bx_u32x4 ra2 = a_rsrc(st + 2 * nwg), rg2 = g_rsrc(st + 2 * nwg);
+    const BxRsrc ra2 = a_rsrc(st + 2 * nwg), rg2 = g_rsrc(st + 2 * nwg);
     const int rows_next = g.M - (st + nwg) * 16;
     bx_u32x4 fb[3];
 #pragma unroll
@@ -601,7 +663,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
     bx_barrier();
     cur ^= 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BX_DRAIN();
   flush();
 }
 
@@ -621,7 +683,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   constexpr int B2 = KSTEPS * 3 * 64 * 16;                // one extra column block's B fragments, operand order
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 2 * B2];
   const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = BX_SGPR(tid >> 6);
   const int nwg = gridDim.x;
   const int Ktot = g.n_seg * g.seg_k;
   const int col = wave * 32 + lo;
@@ -677,11 +739,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   }
   const uint32_t lbase = (uint32_t)(erow * SROW + el * 4);
   auto rsrc = [&](const float* p, int64_t bytes) {
-    const uint64_t base = reinterpret_cast<uint64_t>(p);
-    bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffffu,
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0 ? bytes : 0)), 0x00020000u};
-    return r;
+    return bx_make_rsrc(p, bytes > 0 ? bytes : 0);
   };
   const int64_t span_last = (int64_t)(g.n_seg - 1) * g.a_seg_stride * 4;
   auto a_rsrc = [&](int b) {
@@ -702,24 +760,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
     return rsrc(cb_ + (int64_t)b * BM * g.ldc, ((rows - 1) * g.ldc + 32) * 4);
   };
   bx_u32x2 raw[EPT];
-  auto issue_load = [&](int t, const bx_u32x4& r) {
-    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(raw[t]) : "v"(goff[t]), "s"(r) : "memory");
+  auto issue_load = [&](int t, const BxRsrc& r) {
+    BX_LOAD2(raw[t], goff[t], r);
   };
   // younger instructions at the wait for element t: the other EPT - 1 loads, and — from the second block on, for a
   // wavefront that stores — the 16 stores of the previous block
   auto convert_one = [&](int t, unsigned char* buf, int n_stores) {
-    if (n_stores == 32) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1 + 32));
-    else if (n_stores == 16) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1 + 16));
-    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[t]) : "n"(EPT - 1));
+    if (n_stores == 32) BX_WAIT(EPT - 1 + 32, raw[t]);
+    else if (n_stores == 16) BX_WAIT(EPT - 1 + 16, raw[t]);
+    else BX_WAIT(EPT - 1, raw[t]);
     uint32_t p1, p2, p3;
-    bx_split2_fast(__uint_as_float(raw[t].x), __uint_as_float(raw[t].y), p1, p2, p3);
+    bx_split2_fast(bx_as_float(raw[t][0]), bx_as_float(raw[t][1]), p1, p2, p3);
     unsigned char* d = buf + lbase + 64 * t;
     *reinterpret_cast<uint32_t*>(d) = p1;
     *reinterpret_cast<uint32_t*>(d + PLANE) = p2;
     *reinterpret_cast<uint32_t*>(d + 2 * PLANE) = p3;
   };
   {
-    const bx_u32x4 r0 = a_rsrc(rb), r1 = a_rsrc(rb + nwg);
+    const BxRsrc r0 = a_rsrc(rb), r1 = a_rsrc(rb + nwg);
 #pragma unroll
     for (int t = 0; t < EPT; ++t) issue_load(t, r0);
 #pragma unroll
@@ -730,7 +788,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   }
   const float bias_r = (g.bias && col < g.N) ? g.bias[col] : 0.f;
   const float bias_r2 = (g.bias && col2 < g.N) ? g.bias[col2] : 0.f;
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(EPT) : "memory");      // the B / bias loads above are older than the EPT block loads
+  BX_WAIT_PLAIN(EPT);      // the B / bias loads above are older than the EPT block loads
   bx_barrier();
   int cur = 0;
   int stored = 0;                                          // store instructions of the previous block: 0 | 16 | 32
@@ -739,7 +797,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   for (; rb < n_blocks; rb += nwg) {
     unsigned char* bcur = lds + cur * BUF;
     unsigned char* bnxt = lds + (cur ^ 1) * BUF;
-    const bx_u32x4 r2 = a_rsrc(rb + 2 * nwg);
+    const BxRsrc r2 = a_rsrc(rb + 2 * nwg);
     pgt_f32x16 am, ac, am2, ac2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { am[r] = 0.f; ac[r] = 0.f; am2[r] = 0.f; ac2[r] = 0.f; }
@@ -772,21 +830,21 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
       }
     }
     if (live) {
-      const bx_u32x4 rc = c_rsrc(cbase, rb);
+      const BxRsrc rc = c_rsrc(cbase, rb);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = am[r] + ac[r] + bias_r;
-        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
-        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(cvoff), "s"(rc), "s"(soff) : "memory");
+        const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
+        BX_STORE1S(v, cvoff, rc, soff);
       }
       stored = 16;
       if (two) {
-        const bx_u32x4 rc2 = c_rsrc(cbase2, rb);
+        const BxRsrc rc2 = c_rsrc(cbase2, rb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float v = am2[r] + ac2[r] + bias_r2;
-          const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
-          asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v), "v"(cvoff2), "s"(rc2), "s"(soff) : "memory");
+          const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
+          BX_STORE1S(v, cvoff2, rc2, soff);
         }
         stored = 32;
       }
@@ -794,10 +852,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
     bx_barrier();
     cur ^= 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BX_DRAIN();
 }
 
 int bx_device_cus() {
+#ifdef PGT_EMU
+  return 4;
+#else
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, v = 0;
@@ -806,6 +867,7 @@ int bx_device_cus() {
     else cus = 256;
   }
   return cus;
+#endif
 }
 
 }  // namespace
@@ -924,4 +986,3 @@ int pgt_gemm_bx_tn_launch(const PgtTnArgs& t, pgt_stream_t stream) {
   return pgt_check_launch("pgt_gemm_tn_acc_f32 (split-bf16)");
 }
 
-#endif  // PGT_EMU

@@ -78,10 +78,21 @@ def test_dcrnn_backward_matches_oracle_autograd(backend, K):
         assert_close_with_nonfinite(p.grad, params64[name].grad, 1e-4, 1e-4, name)
 
 
-@pytest.mark.parametrize("x_grad,O", [(True, 4), (False, 4), (False, 64)])
-def test_batched_dcrnn_backward_matches_oracle_autograd(backend, x_grad, O):
+@pytest.mark.parametrize("x_grad,O,bx", [(True, 4, 1), (False, 4, 1), (False, 64, 1), (False, 64, 2), (True, 64, 2)])
+def test_batched_dcrnn_backward_matches_oracle_autograd(backend, x_grad, O, bx):
     """x_grad=False: the input is data; the backward then computes only the hidden-state columns of the stack gradient
-    (O = 64: 320 columns, split into a 256-wide and a 64-wide feature-gradient GEMM)."""
+    (O = 64: 320 columns, split into a 256-wide and a 64-wide feature-gradient GEMM).  bx = 2: every dense product of the
+    step on the split-bf16 kernels (csrc/gemm_bx.hip: gates with fused epilogues, feature gradients, weight gradients),
+    which otherwise start at 8 192 rows — forward and all gradients against the fp64 oracle autograd."""
+    from pytorch_geometric_temporal_amd import _lib
+    _lib.get_lib().tune("gemm_bx", bx)
+    try:
+        _batched_dcrnn_backward_case(backend, x_grad, O)
+    finally:
+        _lib.get_lib().tune("gemm_bx", 1)
+
+
+def _batched_dcrnn_backward_case(backend, x_grad, O):
     torch.manual_seed(0)
     B, T, n, fin, K = 2, 3, 18, 2, 3
     ei_np, ew_np = syn.sensor_graph(n, 110, seed=9, symmetric=False)

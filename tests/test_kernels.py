@@ -958,21 +958,21 @@ def _bx_run(A, B, bias, M, segs, segk, N, nt, dev):
     return C
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("M,segs,segk,N,nt", [(5000, 5, 66, 128, False), (4131, 5, 66, 64, False), (3000, 3, 34, 96, False),
                                               (7000, 1, 128, 256, True), (2500, 1, 64, 256, True), (3333, 1, 128, 64, True),
                                               (6100, 1, 128, 320, True), (2049, 1, 64, 320, True), (900, 1, 100, 192, True),
                                               (2000, 1, 64, 64, True), (100, 5, 66, 128, False), (31, 1, 64, 64, True),
                                               (1025, 2, 24, 40, False), (640, 1, 16, 128, True)])
-def test_gemm_split_bf16_is_at_least_as_accurate_as_the_fp32_kernels(M, segs, segk, N, nt):
+def test_gemm_split_bf16_is_at_least_as_accurate_as_the_fp32_kernels(backend, M, segs, segk, N, nt):
     """gemm_bx.hip: fp32 operands split into three bf16 pieces, six piece products on the bf16 matrix pipe, fp32
     accumulation.  Against an fp64 product it must be no worse than the exact-fp32 MFMA kernels on the same operands (it
     is better: big term and corrections are accumulated separately), at ragged sizes, every K bucket (<= 64, <= 128,
-    <= 336 columns, zero padded), one and two 32-column blocks per wavefront, segmented inputs and outputs."""
+    <= 336 columns, zero padded), one and two 32-column blocks per wavefront, segmented inputs and outputs.  The same
+    kernel bodies run on the CPU test double (csrc/gemm_bx.hip's platform layer) at a few hundred rows."""
     lib = _lib.get_lib()
-    if lib.target != "gfx950":
-        pytest.skip("product library only")
-    dev = torch.device("cuda:0")
+    dev = backend.device
+    if backend.name == "emu":
+        M = min(M, 70 + M % 97)
     A, B, bias, ref = _bx_case(M, segs, segk, N, nt, seed=M + N)
     try:
         lib.tune("gemm_bx", 2)
@@ -989,12 +989,9 @@ def test_gemm_split_bf16_is_at_least_as_accurate_as_the_fp32_kernels(M, segs, se
     assert float((C_bx - C_32).abs().max()) <= 1e-5 * max(scale, 1.0)
 
 
-@pytest.mark.gpu
-def test_gemm_split_bf16_exact_cases_and_non_finite_rows():
+def test_gemm_split_bf16_exact_cases_and_non_finite_rows(backend):
     lib = _lib.get_lib()
-    if lib.target != "gfx950":
-        pytest.skip("product library only")
-    dev = torch.device("cuda:0")
+    dev = backend.device
     try:
         lib.tune("gemm_bx", 2)
         # integers: every piece product and every partial sum is exact -> the result is exact
@@ -1026,17 +1023,16 @@ def test_gemm_split_bf16_exact_cases_and_non_finite_rows():
         lib.tune("gemm_bx", 1)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("M,segs,O,fin,bx", [(9000, 5, 48, 2, 1), (9000, 2, 32, 2, 2), (8200, 5, 128, 2, 1)])
-def test_gemm_split_bf16_declines_gate_shapes_it_cannot_tile(M, segs, O, fin, bx):
+def test_gemm_split_bf16_declines_gate_shapes_it_cannot_tile(backend, M, segs, O, fin, bx):
     """The fused gate epilogues of the split-bf16 kernel need whole 32-column blocks on either side of the z | r boundary,
     K in the 21-step bucket and (candidate gate) at most 64 columns; every other shape must fall through to the fp32
     kernels — bit for bit the result with the kernel switched off (hidden 48: the boundary cuts a block; K = 68: short-K
     kernels have no epilogue; hidden 128: the instantiation would spill)."""
     lib = _lib.get_lib()
-    if lib.target != "gfx950":
-        pytest.skip("product library only")
-    dev = torch.device("cuda:0")
+    dev = backend.device
+    if backend.name == "emu":
+        M, bx = 150, 2                  # the size gate (>= 8192 rows) is not what this test is about
     g = torch.Generator().manual_seed(M + O)
     segk = fin + O
     K, C = segs * segk, fin + O
@@ -1067,15 +1063,14 @@ def test_gemm_split_bf16_declines_gate_shapes_it_cannot_tile(M, segs, O, fin, bx
             assert float((a - b).abs().max()) <= 3e-6
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("M,O,fin", [(4100, 64, 2), (1000, 32, 2), (33, 64, 0)])
-def test_gemm_split_bf16_fused_gru_epilogues(M, O, fin):
+def test_gemm_split_bf16_fused_gru_epilogues(backend, M, O, fin):
     """The gate epilogues of pgt_gemm_gru_zr_f32 / pgt_gemm_gru_h_f32 on the split-bf16 kernel against the fp32 kernels
     (same gate formulas on sums that differ by fp32 rounding) and against an fp64 evaluation."""
     lib = _lib.get_lib()
-    if lib.target != "gfx950":
-        pytest.skip("product library only")
-    dev = torch.device("cuda:0")
+    dev = backend.device
+    if backend.name == "emu":
+        M = min(M, 101)
     g = torch.Generator().manual_seed(M + O)
     segs, segk = 5, fin + O
     K, C = segs * segk, fin + O
@@ -1108,19 +1103,18 @@ def test_gemm_split_bf16_fused_gru_epilogues(M, O, fin):
     assert float((res[2][3].cpu().double() - (z * H.cpu().double() + (1 - z) * ht64)).abs().max()) <= 4e-6
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("M,segs,segk,N,force", [(20000, 5, 66, 128, False), (17001, 5, 66, 64, False), (3000, 3, 60, 100, True),
                                                  (1000, 5, 66, 128, True), (517, 2, 66, 33, True), (40, 5, 70, 128, True),
                                                  (2048, 3, 61, 50, True)])
-def test_gemm_tn_split_bf16_weight_and_bias_gradient(M, segs, segk, N, force):
+def test_gemm_tn_split_bf16_weight_and_bias_gradient(backend, M, segs, segk, N, force):
     """gemm_bx_tn_kernel: dW += A^T G and db += column sums of G through the bf16 matrix pipe (both operands as three
     bf16 planes, transposed in LDS; the bias gradient from a row of ones) against fp64 and against the fp32 kernels:
     ragged row counts, several launches per product (forced small chunks), accumulation into non-zero dW / db, db absent,
     and the deterministic mode (bitwise reproducible)."""
     lib = _lib.get_lib()
-    if lib.target != "gfx950":
-        pytest.skip("product library only")
-    dev = torch.device("cuda:0")
+    dev = backend.device
+    if backend.name == "emu":
+        M, force = min(M, 150 + M % 61), True
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(segs, M, segk, generator=g)
     G = torch.randn(M, N, generator=g)
@@ -1158,7 +1152,8 @@ def test_gemm_tn_split_bf16_weight_and_bias_gradient(M, segs, segk, N, force):
     assert float((dWn.cpu().double() - refW).abs().max()) <= 3e-6 * sw
     assert torch.equal(det[0][0], det[1][0]) and torch.equal(det[0][1], det[1][1])
     e_bx, e_32 = float((out[bx][0].cpu().double() - refW).abs().mean()), float((out[0][0].cpu().double() - refW).abs().mean())
-    assert e_bx <= 1.5 * e_32 + 1e-9, (e_bx, e_32)
+    if backend.name == "hip":          # at a few hundred rows (test double) both errors are a handful of roundings
+        assert e_bx <= 1.5 * e_32 + 1e-9, (e_bx, e_32)
 
 
 @pytest.mark.gpu

@@ -987,6 +987,8 @@ def test_gemm_split_bf16_is_at_least_as_accurate_as_the_fp32_kernels(backend, M,
     assert float(e_bx.max()) <= 2e-6 * max(scale, 1.0), (float(e_bx.max()), scale)
     assert float(e_bx.mean()) <= 1.1 * float(e_32.mean()) + 1e-9, (float(e_bx.mean()), float(e_32.mean()))
     assert float((C_bx - C_32).abs().max()) <= 1e-5 * max(scale, 1.0)
+    if (segs, segk, N) in ((5, 66, 128), (1, 128, 256), (1, 64, 320)):
+        assert not torch.equal(C_bx, C_32)      # different arithmetic: identical bits would mean the kernel did not run
 
 
 def test_gemm_split_bf16_exact_cases_and_non_finite_rows(backend):
@@ -1154,6 +1156,51 @@ def test_gemm_tn_split_bf16_weight_and_bias_gradient(backend, M, segs, segk, N, 
     e_bx, e_32 = float((out[bx][0].cpu().double() - refW).abs().mean()), float((out[0][0].cpu().double() - refW).abs().mean())
     if backend.name == "hip":          # at a few hundred rows (test double) both errors are a handful of roundings
         assert e_bx <= 1.5 * e_32 + 1e-9, (e_bx, e_32)
+
+
+def test_gemm_split_bf16_fuzz_shapes_on_the_test_double(emu_backend):
+    """Seeded sweep over shapes around every routing boundary of gemm_bx.hip (K buckets 64 / 128 / 336, one / two / three
+    column-block layouts, 256 / 320 columns, odd row counts, segmented inputs and outputs, with and without bias), the
+    kernels forced on at any size: every result against fp64.  Shapes the kernels decline run the fp32 kernels — the
+    point is that NO routing decision produces a wrong result."""
+    lib = _lib.get_lib()
+    rng = np.random.default_rng(2024)
+    lib.tune("gemm_bx", 2)
+    try:
+        for case in range(48):
+            segs = int(rng.integers(1, 6))
+            segk = 2 * int(rng.integers(1, 34))
+            if segs * segk > 336:
+                segk = 2 * (336 // (2 * segs))
+            K = segs * segk
+            nt = bool(rng.integers(0, 2)) and K <= 128
+            N = int(rng.choice([1, 31, 32, 33, 64, 96, 100, 128])) if K > 128 else int(rng.choice([1, 40, 64, 128, 129, 192, 256, 288, 320]))
+            if nt:
+                N = 64 * max(1, N // 64)
+            M = int(rng.integers(1, 130))
+            A, B, bias, ref = _bx_case(M, segs, segk, N, nt, seed=1000 + case)
+            if not nt and rng.integers(0, 2):
+                bias, ref = None, ref - bias.double()
+            C = _bx_run(A, B, bias, M, segs, segk, N, nt, emu_backend.device).double()
+            scale = max(float(ref.abs().max()), 1.0)
+            assert torch.isfinite(C).all(), (case, M, segs, segk, N, nt)
+            assert float((C - ref).abs().max()) <= 3e-6 * scale, (case, M, segs, segk, N, nt, float((C - ref).abs().max()))
+        for case in range(12):                                   # weight gradients: 128 < K <= 351, N <= 128
+            segs = int(rng.integers(2, 6))
+            segk = int(rng.integers(130 // segs + 1, 351 // segs + 1))
+            N = int(rng.choice([1, 17, 32, 64, 65, 100, 128]))
+            M = int(rng.integers(1, 260))
+            g = torch.Generator().manual_seed(2000 + case)
+            A, G = torch.randn(segs, M, segk, generator=g), torch.randn(M, N, generator=g)
+            dW0, db0 = torch.randn(segs * segk, N, generator=g), torch.randn(N, generator=g)
+            A2 = torch.cat([A[j] for j in range(segs)], dim=1).double()
+            refW, refb = dW0.double() + A2.t() @ G.double(), db0.double() + G.double().sum(0)
+            dW, db = dW0.clone(), db0.clone()
+            ops.gemm_tn_acc(A, segk, M * segk, segs, segk, G, N, dW, N, db, M, N)
+            assert float((dW.double() - refW).abs().max()) <= 3e-6 * max(float(refW.abs().max()), 1.0), (case, M, segs, segk, N)
+            assert float((db.double() - refb).abs().max()) <= 3e-6 * max(float(refb.abs().max()), 1.0) + 1e-5, (case, M, segs, segk, N)
+    finally:
+        lib.tune("gemm_bx", 1)
 
 
 @pytest.mark.gpu

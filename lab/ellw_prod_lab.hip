@@ -17,6 +17,8 @@ void pgt_slab_set_pairs(int) {}
 void pgt_gemm_set_tn_pipe(int) {}
 void pgt_gemm_set_skinny(int) {}
 void pgt_gemm_set_dbp(int) {}
+void pgt_gemm_bx_set(int) {}
+void pgt_gemm_bx_sym_set(int) {}
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/spmm.hip"
 

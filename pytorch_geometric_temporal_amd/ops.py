@@ -450,6 +450,7 @@ FUSE_GATE_EPILOGUES = os.environ.get("PGT_FUSE_GATES", "1") != "0"
 # deferred-store kernel + a 64-column remainder, 0 = one 320-column product (three 128-wide column tiles, the last masked)
 SPLIT_FEATURE_GRADIENT = os.environ.get("PGT_SPLIT_FG", "1") != "0"
 ONE_FEATURE_GRADIENT = os.environ.get("PGT_ONE_FG", "1") != "0"
+ONE_FEATURE_GRADIENT_MIN_ROWS = 32768      # tests lower it to drive the 320-column product at small sizes
 # weight / bias gradients without float atomics (pgt_gemm_tn_det_f32): bitwise reproducible run to run, one extra pass
 # over the per-slab partial sums.  Off by default (the atomics are ~2 % faster at the benchmark shape); PGT_DETERMINISTIC=1
 # or ops.DETERMINISTIC_WEIGHT_GRADIENTS = True turns it on.
@@ -884,7 +885,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             # column blocks 8 and 9 ride along as second blocks) instead of 256 columns + a 64-column remainder
             # (from 32 768 rows: at B = 64, M = 13 248, the two-block wavefronts leave the second round of row blocks
             # half empty and the whole step is 15 % slower than with the 256 + 64 split)
-            if ONE_FEATURE_GRADIENT and M >= 32768 and 128 < NH <= 320 and NH % 32 == 0 and 2 * O <= 128 and O % 32 == 0:
+            if ONE_FEATURE_GRADIENT and M >= ONE_FEATURE_GRADIENT_MIN_ROWS and 128 < NH <= 320 and NH % 32 == 0 and 2 * O <= 128 and O % 32 == 0:
                 n1 = NH
 
         def feature_grad(dP, Wfull, WH, Kd):

@@ -84,12 +84,16 @@ def test_batched_dcrnn_backward_matches_oracle_autograd(backend, x_grad, O, bx):
     (O = 64: 320 columns, split into a 256-wide and a 64-wide feature-gradient GEMM).  bx = 2: every dense product of the
     step on the split-bf16 kernels (csrc/gemm_bx.hip: gates with fused epilogues, feature gradients, weight gradients),
     which otherwise start at 8 192 rows — forward and all gradients against the fp64 oracle autograd."""
-    from pytorch_geometric_temporal_amd import _lib
+    from pytorch_geometric_temporal_amd import _lib, ops
     _lib.get_lib().tune("gemm_bx", bx)
+    min_rows = ops.ONE_FEATURE_GRADIENT_MIN_ROWS
+    if bx == 2:
+        ops.ONE_FEATURE_GRADIENT_MIN_ROWS = 0      # ... including the single 320-column feature-gradient product
     try:
         _batched_dcrnn_backward_case(backend, x_grad, O)
     finally:
         _lib.get_lib().tune("gemm_bx", 1)
+        ops.ONE_FEATURE_GRADIENT_MIN_ROWS = min_rows
 
 
 def _batched_dcrnn_backward_case(backend, x_grad, O):

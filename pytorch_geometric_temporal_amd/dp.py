@@ -53,7 +53,11 @@ def shard_indices(num_samples, rank, world, epoch=0, shuffle=True, seed=0, drop_
 
 
 class FlatGradients:
-    """Every parameter's .grad is a view into one contiguous buffer -> one all-reduce per optimisation step."""
+    """Every parameter's .grad is a view into one contiguous buffer -> one all-reduce per optimisation step.
+
+    Clear gradients with `.zero()` (or `optimizer.zero_grad(set_to_none=False)`): `zero_grad(set_to_none=True)` — the
+    torch default — replaces each .grad by None and silently detaches the views, after which the all-reduce would
+    average a buffer no backward pass writes to."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]

@@ -39,6 +39,30 @@ PROPAGATES_PER_CELL = 12     # the reference's op count per DCRNN cell step: 6 (
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
+def _safe(fn):
+    """Auxiliary figures must never cost the bench line."""
+    try:
+        return fn()
+    except Exception:
+        return None
+
+
+def gemm_operand_bytes(shape):
+    """fp32 bytes a product has to move once: A [M, K] + C [M, N] (+ the gate chain's operands and side outputs:
+    "NN+zr": H in, H*r out; "NN+h": z, H in, the new state twice out); weight-gradient shapes [M, N, segs, seg_k]:
+    A and G once."""
+    if isinstance(shape[0], str):
+        op, M, N, n_seg, seg_k = shape[0], shape[1], shape[2], shape[3], shape[4]
+        b = 4.0 * M * (n_seg * seg_k + N)
+        if op == "NN+zr":
+            b += 4.0 * M * N                  # H [M, N/2] in, H*r [M, N/2] out
+        elif op == "NN+h":
+            b += 4.0 * M * N * 4              # z, H in; out0, out1 out
+        return b
+    M, N, n_seg, seg_k = shape[0], shape[1], shape[2], shape[3]
+    return 4.0 * M * (n_seg * seg_k + N)
+
+
 def pmc_traffic(kind):
     """HBM bytes per launch of the dominant kernel class from the rocprofv3 --pmc passes of THIS bench command
     (scripts/pmc_bench.sh: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, averaged over the kernel's dispatches),
@@ -365,7 +389,9 @@ def main():
                 v["mfma_frac"] = v["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS
                 # per shape: [op, M, N, k-segments, segment width, ...]; "NN+zr" / "NN+h" carry the gate chain
                 v["by_shape"] = [{"shape": r["tag"][1:], "launches": r["launches"], "avg_us": r["avg_us"],
-                                  "TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12}
+                                  "TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12,
+                                  # the split-bf16 kernels made these products HBM-bound: operand bytes / time
+                                  "operand_GBs": _safe(lambda r=r: gemm_operand_bytes(r["tag"][1:]) / (r["avg_us"] * 1e-6) / 1e9)}
                                  for r in shapes if r["tag"][0] == kk]
     del step
 

@@ -130,6 +130,16 @@ def test_bad_arguments_return_error_codes_not_crashes():
             lib.call(name, *args)
     with pytest.raises(_lib.PgtError, match="unknown key"):
         lib.tune("no_such_switch", 1)
+    # every switch the header documents is accepted (a key dropped from pgt_tune would silently disable an A/B script)
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pgt_hip.h")).read()
+    doc = header[header.index("Schedule switches for A/B measurements"):header.index("int pgt_tune(")]
+    keys = set(re.findall(r'"([a-z][a-z0-9_]+)"', doc))
+    assert {"gemm_bx", "gemm_bx_sym", "gemm_db", "spmm_ellw", "slab_pairs"} <= keys
+    defaults = {"gemm_small_fill": 256, "gemm_small_tiles": 0, "spmm_tile_rows": 32, "spmm_unroll": 8, "spmm_ellw_rows": 0,
+                "spmm_ellw_cus": 0, "spmm_ellw_cfg": 0, "slab_pairs": 2}       # every other switch defaults to 1
+    for k in sorted(keys):
+        lib.tune(k, defaults.get(k, 1))
     assert lib.prep_workspace_bytes(2, 2) > 8
     ok = [
         ("pgt_gemm_f32", (p, 4, 0, 1, 4, p, 4, 1, p, 4, 0, 4, null, 0, 4, 0, null)),             # M = 0

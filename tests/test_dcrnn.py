@@ -78,7 +78,8 @@ def test_dcrnn_backward_matches_oracle_autograd(backend, K):
         assert_close_with_nonfinite(p.grad, params64[name].grad, 1e-4, 1e-4, name)
 
 
-@pytest.mark.parametrize("x_grad,O,bx", [(True, 4, 1), (False, 4, 1), (False, 64, 1), (False, 64, 2), (True, 64, 2)])
+@pytest.mark.parametrize("x_grad,O,bx", [(True, 4, 1), (False, 4, 1), (False, 64, 1), (False, 64, 2), (True, 64, 2),
+                                              (False, 32, 2)])
 def test_batched_dcrnn_backward_matches_oracle_autograd(backend, x_grad, O, bx):
     """x_grad=False: the input is data; the backward then computes only the hidden-state columns of the stack gradient
     (O = 64: 320 columns, split into a 256-wide and a 64-wide feature-gradient GEMM).  bx = 2: every dense product of the
@@ -119,7 +120,7 @@ def _batched_dcrnn_backward_case(backend, x_grad, O):
     if x_grad:
         assert_close_with_nonfinite(Xd.grad, X64.grad, 5e-5, 1e-4, "dX")
     for name, p in m.named_parameters():
-        assert_close_with_nonfinite(p.grad, params64[name].grad, 2e-4 if O == 64 else 1e-4, 1e-4, name)
+        assert_close_with_nonfinite(p.grad, params64[name].grad, 2e-4 if O >= 32 else 1e-4, 1e-4, name)
 
 
 @pytest.mark.parametrize("n_nodes", [18, 330])

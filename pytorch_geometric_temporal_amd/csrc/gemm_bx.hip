@@ -164,7 +164,57 @@ __device__ __forceinline__ void bx_split2_fast(float x, float y, uint32_t& p1, u
 // sixteen elements per lane and block, and the library expf + IEEE division (~50 instructions per element) was a third of
 // the fused kernel's time (182 -> 168 us at M = 211 968)
 __device__ __forceinline__ float bx_sigmoidf(float x) { return bx_rcp(1.f + bx_exp(-x)); }
-__device__ __forceinline__ float bx_tanhf(float x) { return 1.f - 2.f * bx_rcp(1.f + bx_exp(2.f * x)); }   // |error| ~ 1e-7
+// 1 - 2 / (1 + e^2x) has an ABSOLUTE error of ~1e-7, i.e. a poor relative one near 0: there the odd series takes over
+// (|x| < 0.04: the x^7 term is below 1e-11 |x|)
+__device__ __forceinline__ float bx_tanhf(float x) {
+  const float x2 = x * x;
+  const float small = x * fmaf(x2, fmaf(x2, 0.13333334f, -0.33333334f), 1.f);
+  const float big = 1.f - 2.f * bx_rcp(1.f + bx_exp(2.f * x));
+  return fabsf(x) < 0.04f ? small : big;
+}
+
+// ---- non-finite operands.  An infinite or nan element of the streaming operand turns its whole output ROW into nan
+// (x - x1 = nan reaches every column), a non-finite weight its whole column (0 * inf in the zero-padded k-steps), where
+// the reference's fp32 product (torch.matmul, dcrnn.py:81-105) has +-inf or nan element by element.  Every wavefront that
+// finds a nan among the sums of a 32 x 32 tile recomputes the tile as an fp32 fmaf chain over the ORIGINAL operands — the
+// arithmetic of gemm.hip's kernels — so that inf / nan land exactly where the reference puts them.  Rare path (plain
+// loads, ~0.1 ms per tile); rows past M are clamped (their sums are never stored).
+__device__ __forceinline__ bool bx_tile_has_nan(const float (&acc)[16]) {
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bad |= acc[r] != acc[r];
+  return __ballot(bad) != 0;
+}
+// `ra`: the buffer descriptor of the tile's 32-row block of A (ends with the last valid row of the last segment; rows past
+// M of the other segments read whatever follows — their sums are never stored).  One lane register per load and a
+// uniform row offset: no 64-bit address per row, so the rare path costs the hot loop no registers.
+__device__ __forceinline__ void bx_exact_tile(const PgtGemmArgs& g, const BxRsrc& ra, int col, int hi, float bias, float (&acc)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool col_ok = col < g.N;
+  const float* bcol = g.Bw + (int64_t)(col_ok ? col : 0) * g.sbn;
+  const uint32_t lda4 = (uint32_t)(g.lda * 4);
+  for (int seg = 0; seg < g.n_seg; ++seg) {
+    uint32_t voff = (uint32_t)((seg * g.a_seg_stride + 4 * hi * g.lda) * 4);
+    for (int kk = 0; kk < g.seg_k; ++kk, voff += 4) {
+      const float b = col_ok ? bcol[(int64_t)(seg * g.seg_k + kk) * g.sbk] : 0.f;
+      float a[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int soff = BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * lda4));
+        BX_LOAD1S(a[r], voff, ra, soff);
+      }
+      BX_DRAIN();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        BX_WAIT(0, a[r]);
+        acc[r] = fmaf(a[r], b, acc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += bias;
+}
 
 // KSTEPS: 16-deep k-steps covering K (zero padded); WN: 32-column blocks per wavefront; EPI: 0 bias, 1 / 2 the GRU
 // epilogues of PgtGemmArgs.  A: n_seg segments of seg_k (even) columns, consumed as one [M, n_seg * seg_k] operand.
@@ -445,6 +495,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       }
       if (lane == 0) part_seen[cb] = n_iter + 1;     // after the reads above: a wavefront's LDS operations complete in order
       if (cols_live) {
+        // a non-finite operand shows as nan sums: redo the tile in exact fp32 (bx_exact_tile; rare)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          if (bx_tile_has_nan(acc[j])) {
+            BX_DRAIN();
+            const int64_t rows_left = (int64_t)g.M - (int64_t)rb * BM, rows = rows_left < BM ? rows_left : BM;
+            const BxRsrc ra = bx_make_rsrc(g.A + (int64_t)rb * BM * g.lda, (int64_t)(g.n_seg - 1) * g.a_seg_stride * 4 +
+                                           (rows - 1) * g.lda * 4 + (int64_t)g.seg_k * 4);
+            bx_exact_tile(g, ra, (cb * WN + j) * 32 + lo, hi, bias_r[j], acc[j]);
+          }
+      }
+      if (cols_live) {
         float side[EPI != 0 ? 16 : 1];                 // eX = H r (zr) / the new hidden state (candidate gate)
         if constexpr (EPI != 0) {
           if (e_live) {
@@ -595,25 +657,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
   const int lo = lane & 31, hi = lane >> 5;
   const int n = cb * 32 + lo;
-  auto flush = [&]() {
+  // one 32 x 32 block of dW (rows rb * 32 ..) leaves through atomics or as this workgroup's deterministic slab
+  auto flush_block = [&](int rb, const auto& v) {
     const int slab = slab_base + (int)blockIdx.x;
     float* const wbase = (DET ? g.part + (int64_t)slab * g.part_stride : g.dW) + n;
     float* const bbase = g.db == nullptr ? nullptr : (DET ? g.dbpart + (int64_t)slab * g.N : g.db) + n;
     const uint32_t ld = (uint32_t)g.lddw;
+    if (rb >= RB || n >= g.N) return;
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b) {
-      const int rb = r0 + RSTEP * b;
-      if (rb >= RB || n >= g.N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (k < K) {
-          if constexpr (DET) wbase[(uint32_t)k * ld] = acc[b][r];
-          else atomicAdd(wbase + (uint32_t)k * ld, acc[b][r]);
-        } else if (k == K && bbase != nullptr) {
-          if constexpr (DET) *bbase = acc[b][r];
-          else atomicAdd(bbase, acc[b][r]);
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (k < K) {
+        if constexpr (DET) wbase[(uint32_t)k * ld] = v[r];
+        else atomicAdd(wbase + (uint32_t)k * ld, v[r]);
+      } else if (k == K && bbase != nullptr) {
+        if constexpr (DET) *bbase = v[r];
+        else atomicAdd(bbase, v[r]);
       }
     }
   };
@@ -664,7 +723,48 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
     cur ^= 1;
   }
   BX_DRAIN();
-  flush();
+  // ---- non-finite operands (see bx_exact_tile): a nan among this workgroup's sums -> its whole slab again as an fp32
+  // fmaf chain over the original operands, so that the +-inf / nan of the reference's dW = A^T G land where they belong
+  {
+    bool bad = false;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bad |= acc[b][r] != acc[b][r];
+    if (__ballot(bad) != 0) {
+      // the fast sums are dropped here, so the redo needs no register beyond one block's
+      for (int b = 0; b < MAXB; ++b) {
+        const int rb = r0 + RSTEP * b;
+        if (rb >= RB) continue;
+        int koff[16];                                      // element offset of column k inside a row of A; -1: the ones; -2: none
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int seg = k / g.seg_k;
+          koff[r] = k > K ? -2 : k == K ? -1 : (int)(seg * g.a_seg_stride + (k - seg * g.seg_k));
+          t[r] = 0.f;
+        }
+        for (int s2 = blockIdx.x; s2 < n_stages; s2 += nwg)
+          for (int i = 0; i < 16; ++i) {
+            const int64_t m = (int64_t)s2 * 16 + i;
+            if (m >= g.M) break;
+            const float gv = n < g.N ? g.G[m * g.ldg + n] : 0.f;
+            const float* ar = g.A + m * g.lda;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int o = koff[r];
+              const float a = o >= 0 ? ar[o] : (o == -1 ? 1.f : 0.f);
+              t[r] = fmaf(a, gv, t[r]);
+            }
+          }
+        flush_block(rb, t);
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) flush_block(r0 + RSTEP * b, acc[b]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -831,20 +931,31 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
     }
     if (live) {
       const BxRsrc rc = c_rsrc(cbase, rb);
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = am[r] + ac[r] + bias_r;
+      if (bx_tile_has_nan(v)) {                              // non-finite operand: exact fp32 tile (rare)
+        BX_DRAIN();
+        bx_exact_tile(g, a_rsrc(rb), col, hi, bias_r, v);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = am[r] + ac[r] + bias_r;
         const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
-        BX_STORE1S(v, cvoff, rc, soff);
+        BX_STORE1S(v[r], cvoff, rc, soff);
       }
       stored = 16;
       if (two) {
         const BxRsrc rc2 = c_rsrc(cbase2, rb);
 #pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = am2[r] + ac2[r] + bias_r2;
+        if (bx_tile_has_nan(v)) {
+          BX_DRAIN();
+          bx_exact_tile(g, a_rsrc(rb), col2, hi, bias_r2, v);
+        }
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = am2[r] + ac2[r] + bias_r2;
           const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
-          BX_STORE1S(v, cvoff2, rc2, soff);
+          BX_STORE1S(v[r], cvoff2, rc2, soff);
         }
         stored = 32;
       }

@@ -97,6 +97,51 @@ def test_batched_dcrnn_backward_matches_oracle_autograd(backend, x_grad, O, bx):
         ops.ONE_FEATURE_GRADIENT_MIN_ROWS = min_rows
 
 
+def test_batched_dcrnn_zero_in_degree_graph_through_the_split_bf16_kernels(backend):
+    """The reference's own mock graph (test/recurrent_test.py:16-23: watts_strogatz_graph(100, 10, 0.5).edges(), i.e. one
+    direction per edge) leaves nodes without in-edges, so 1 / deg_in is infinite (dcrnn.py:279-290) and DConv's terms carry
+    inf / nan (dcrnn.py:292-325).  With B >= 82 graphs the products have >= 8 192 rows and run on the split-bf16 kernels,
+    whose piece arithmetic would turn an infinite operand into a nan ROW: the per-tile exact-fp32 redo (bx_exact_tile)
+    must put every inf / nan where the reference's fp32 arithmetic (the oracle) puts it.  Also: forward and every gradient
+    equal, placement included, to the same step on the exact-fp32 kernels."""
+    from pytorch_geometric_temporal_amd import _lib, ops
+    lib = _lib.get_lib()
+    hip = backend.name == "hip"
+    n, B, T, O, K = 100, (82 if hip else 2), (3 if hip else 2), 64, 3
+    ei = torch.from_numpy(syn.watts_strogatz_directed(n, 10, 0.5, seed=0))
+    ew = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(1)) + 0.5
+    torch.manual_seed(3)
+    m = BatchedDCRNN(2, O, K)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.3, 0.3)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(backend.device)
+    X = torch.randn(B, T, n, 2)
+    w = torch.randn(B, T, n, O)
+    ref = F.batched_dcrnn(X, ei, ew, params)
+    assert torch.isinf(ref).any() or torch.isnan(ref).any()
+    assert torch.isfinite(ref).any()
+    res = {}
+    min_rows = ops.ONE_FEATURE_GRADIENT_MIN_ROWS
+    try:
+        for bx in ((1 if hip else 2), 0):
+            lib.tune("gemm_bx", bx)
+            ops.ONE_FEATURE_GRADIENT_MIN_ROWS = 0 if bx else min_rows
+            m.zero_grad()
+            out = m(backend.t(X), backend.t(ei), backend.t(ew))
+            (out * backend.t(w)).sum().backward()
+            res[bx] = (out.detach().clone(), [p.grad.clone() for p in m.parameters()])
+    finally:
+        lib.tune("gemm_bx", 1)
+        ops.ONE_FEATURE_GRADIENT_MIN_ROWS = min_rows
+    fast, exact = res[1 if hip else 2], res[0]
+    assert_close_with_nonfinite(exact[0], ref, ATOL, RTOL, "exact-fp32 kernels vs oracle")
+    assert_close_with_nonfinite(fast[0], ref, ATOL, RTOL, "split-bf16 kernels vs oracle")
+    for a, b, (name, _) in zip(fast[1], exact[1], m.named_parameters()):
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.isinf(a), torch.isinf(b)), name
+
+
 def _batched_dcrnn_backward_case(backend, x_grad, O):
     torch.manual_seed(0)
     B, T, n, fin, K = 2, 3, 18, 2, 3

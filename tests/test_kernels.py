@@ -1011,18 +1011,65 @@ def test_gemm_split_bf16_exact_cases_and_non_finite_rows(backend):
         x = torch.rand(64, 64) + 0.5
         ops.gemm(x.to(dev), 64, 0, 1, 64, (I * 1.2345678).to(dev), 64, 1, C[:64], 64, 0, 64, None, 64, 64)
         assert float((C[:64].cpu().double() - x.double() * float(torch.tensor(1.2345678))).abs().max()) <= 2.0 ** -23 * 2.5
-        # a nan / inf operand poisons its own row only
-        A, B, bias, ref = _bx_case(200, 5, 66, 128, False, seed=3)
-        A[2, 17, 5] = float("nan")
-        A[0, 40, 65] = float("inf")
-        out = _bx_run(A, B, bias, 200, 5, 66, 128, False, dev).cpu()
-        bad = torch.zeros(200, dtype=torch.bool)
-        bad[17] = bad[40] = True
-        assert not torch.isfinite(out[bad]).any()
-        assert torch.isfinite(out[~bad]).all()
-        assert float((out[~bad].double() - ref[~bad]).abs().max()) <= 2e-6 * float(ref[~bad].abs().max())
     finally:
         lib.tune("gemm_bx", 1)
+
+
+@pytest.mark.parametrize("M,segs,segk,N,nt", [(200, 5, 66, 128, False), (170, 5, 66, 64, False), (150, 1, 128, 256, True),
+                                              (130, 1, 64, 320, True), (140, 3, 34, 96, False)])
+def test_gemm_split_bf16_non_finite_operands_land_where_fp32_puts_them(backend, M, segs, segk, N, nt):
+    """inf / nan in the streaming operand or in the weights: a split piece `x - x1` is nan, so the six piece products give
+    a nan ROW (operand) or COLUMN (weight) where the reference's fp32 product (torch.matmul, dcrnn.py:81-105) has +-inf /
+    nan element by element.  The kernels detect the nan sums per 32 x 32 tile and redo the tile as an fp32 fmaf chain
+    (bx_exact_tile): value AND placement must equal the exact-fp32 kernels' and a plain fp32 matmul's, every K bucket,
+    one / two column blocks, the symmetric short-K kernel with its second blocks."""
+    lib = _lib.get_lib()
+    dev = backend.device
+    A, B, bias, _ = _bx_case(M, segs, segk, N, nt, seed=3 + N)
+    inf, nan = float("inf"), float("nan")
+    A[segs - 1, 17, 5] = nan
+    A[0, 40, segk - 1] = inf
+    A[0, 41, 0] = -inf
+    A[segs // 2, 77, 3] = inf
+    A[segs // 2, 77, 4] = -inf                 # +inf and -inf in one row: nan where both weights are non-zero
+    A[0, M - 1, 1] = inf                       # ragged last block
+    K = segs * segk
+    Bm = B.clone()                             # [K, N] (the NT form is transposed inside _bx_run)
+    Bm[7, 5] = 0.0                             # inf * 0 = nan exactly there (rows 77: k = 3, 4 -> not this one; row 41: k = 0)
+    Bm[0, 6] = 0.0                             # row 41 (k = 0): nan in column 6, -+inf elsewhere
+    Aflat = torch.cat([A[s] for s in range(segs)], dim=1)
+    b0 = 0.0 if bias is None else bias
+    ref = Aflat.double() @ Bm.double() + (0.0 if bias is None else bias.double())
+    ref32 = Aflat @ Bm + b0                    # torch's fp32 product: the reference's arithmetic
+    try:
+        lib.tune("gemm_bx", 2)
+        out = _bx_run(A, Bm, bias, M, segs, segk, N, nt, dev).cpu()
+        lib.tune("gemm_bx", 0)
+        out32 = _bx_run(A, Bm, bias, M, segs, segk, N, nt, dev).cpu()
+    finally:
+        lib.tune("gemm_bx", 1)
+    bad_rows = [17, 40, 41, 77, M - 1]
+    assert not torch.isfinite(out32[bad_rows]).all()
+    assert_close_with_nonfinite(out, out32, 2e-5, 2e-5, "split-bf16 vs exact-fp32 kernels")
+    assert_close_with_nonfinite(out, ref32, 2e-5, 2e-5, "split-bf16 vs torch fp32 matmul")
+    good = torch.ones(M, dtype=torch.bool)
+    good[bad_rows] = False
+    assert torch.isfinite(out[good]).all()
+    assert float((out[good].double() - ref[good]).abs().max()) <= 2e-6 * float(ref[good].abs().max())
+    # a non-finite WEIGHT: its column (all rows) must follow the fp32 product too
+    B2 = B.clone()
+    B2[11, 9] = inf
+    A2, _, _, _ = _bx_case(M, segs, segk, N, nt, seed=3 + N)
+    A2[0, 3, 11 if segk > 11 else 1] = 0.0     # 0 * inf = nan in that one row
+    try:
+        lib.tune("gemm_bx", 2)
+        outw = _bx_run(A2, B2, bias, M, segs, segk, N, nt, dev).cpu()
+        lib.tune("gemm_bx", 0)
+        outw32 = _bx_run(A2, B2, bias, M, segs, segk, N, nt, dev).cpu()
+    finally:
+        lib.tune("gemm_bx", 1)
+    assert torch.isinf(outw32[:, 9]).any()
+    assert_close_with_nonfinite(outw, outw32, 2e-5, 2e-5, "non-finite weight")
 
 
 @pytest.mark.parametrize("M,segs,O,fin,bx", [(9000, 5, 48, 2, 1), (9000, 2, 32, 2, 2), (8200, 5, 128, 2, 1)])
@@ -1156,6 +1203,56 @@ def test_gemm_tn_split_bf16_weight_and_bias_gradient(backend, M, segs, segk, N, 
     e_bx, e_32 = float((out[bx][0].cpu().double() - refW).abs().mean()), float((out[0][0].cpu().double() - refW).abs().mean())
     if backend.name == "hip":          # at a few hundred rows (test double) both errors are a handful of roundings
         assert e_bx <= 1.5 * e_32 + 1e-9, (e_bx, e_32)
+
+
+@pytest.mark.parametrize("M,O,fin", [(300, 64, 2), (100, 32, 2)])
+def test_gemm_split_bf16_gate_epilogues_and_weight_gradient_with_non_finite_operands(backend, M, O, fin):
+    """The fused z | r and candidate-gate products (K cut two / four ways, partial sums through LDS) and the weight-gradient
+    kernel with inf / nan operands — what DConv's infinite norm_in on a graph with a zero in-degree node feeds them
+    (dcrnn.py:279-290): every output, side outputs included, must carry its non-finite entries
+    exactly where the exact-fp32 kernels (== the reference's fp32 arithmetic) put them."""
+    lib = _lib.get_lib()
+    dev = backend.device
+    inf, nan = float("inf"), float("nan")
+    g = torch.Generator().manual_seed(M + O)
+    segs, segk = 5, fin + O
+    K, C = segs * segk, fin + O
+    A = torch.randn(segs, M, segk, generator=g)
+    A[2, 5, 3] = inf
+    A[2, 5, 9] = -inf
+    A[4, 33, segk - 1] = -inf
+    A[0, 64, 0] = nan
+    A[1, M - 1, 7] = inf
+    A = A.to(dev)
+    Wzr, bzr = (torch.randn(K, 2 * O, generator=g) / K ** 0.5).to(dev), torch.randn(2 * O, generator=g).to(dev)
+    Wh, bh = (torch.randn(K, O, generator=g) / K ** 0.5), torch.randn(O, generator=g).to(dev)
+    Wh[2 * segk + 3, 4] = 0.0          # inf * 0
+    Wh = Wh.to(dev)
+    H = torch.randn(M, O, generator=g).to(dev)
+    G = torch.randn(M, 2 * O, generator=g)
+    G[5, 1] = 0.0                      # inf * 0 in the weight gradient
+    G[70, 3] = inf                     # a non-finite gradient row
+    G = G.to(dev)
+    res = {}
+    try:
+        for bx in (2, 0):
+            lib.tune("gemm_bx", bx)
+            zr = torch.full((M, 2 * O), 7.0, device=dev)
+            xhr = torch.zeros(M, C, device=dev)
+            ops.gemm_gru_zr(A, segk, M * segk, segs, segk, Wzr, 2 * O, 1, bzr, zr, H, xhr, fin)
+            zr_fin = torch.sigmoid(torch.randn(M, 2 * O, generator=torch.Generator().manual_seed(1))).to(dev)
+            ht = torch.full((M, O), 7.0, device=dev)
+            out0, out1 = torch.full((M, O), 7.0, device=dev), torch.zeros(M, C, device=dev)
+            ops.gemm_gru_h(A, segk, M * segk, segs, segk, Wh, O, 1, bh, ht, zr_fin, H, out0, out1[:, fin:])
+            dW, db = torch.zeros(K, 2 * O, device=dev), torch.zeros(2 * O, device=dev)
+            ops.gemm_tn_acc(A, segk, M * segk, segs, segk, G, 2 * O, dW, 2 * O, db, M, 2 * O)
+            res[bx] = (zr, xhr, ht, out0, out1, dW, db)
+    finally:
+        lib.tune("gemm_bx", 1)
+    assert not torch.isfinite(res[0][5]).all() and not torch.isfinite(res[0][3]).all()
+    for name, a, b in zip(("zr", "xhr", "ht", "out0", "out1", "dW", "db"), res[2], res[0]):
+        tol = 2e-4 if name in ("dW", "db") else 4e-6
+        assert_close_with_nonfinite(a, b, tol, tol, name)
 
 
 def test_gemm_split_bf16_fuzz_shapes_on_the_test_double(emu_backend):

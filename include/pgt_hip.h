@@ -47,7 +47,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 8
+#define PGT_ABI_VERSION 9
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -80,6 +80,17 @@ typedef struct pgt_sym_graph {
   float* deg;       /* [N] */
   int32_t* info;    /* [4] info[2] = #edge endpoints outside [0,N) */
 } pgt_sym_graph;
+
+/* Two-level row layout of an [M, W] operand: row m starts at base + (m / period) * stride_hi + (m % period) * ld floats,
+ * with ld the operand's ordinary row-stride argument (period = 0, or a NULL map: a plain matrix, row m at base + m * ld).
+ * It lets one time step of the DCRNN sequence read and write the reference's [B, T, N, O] tensors in place
+ * (BatchedDCRNN.forward returns torch.stack(outputs, dim=1), dcrnn.py:463-475, and autograd hands the gradient back in
+ * that layout): batch-major rows m = b * N + n -> period = N, stride_hi = T * N * O, ld = O, base = out + t * N * O;
+ * node-major rows m = n * B + b -> period = B, stride_hi = O, ld = T * N * O.  period, M < 2^31. */
+typedef struct pgt_rowmap {
+  int64_t period;
+  int64_t stride_hi;
+} pgt_rowmap;
 
 int pgt_abi_version(void);
 const char* pgt_last_error(void);
@@ -273,19 +284,23 @@ int pgt_gemm_tn_det_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64
 
 /* The DCRNN gate GEMMs with the gate chain fused into the epilogue (operands A / Bw / bias as pgt_gemm_f32):
  *   pgt_gemm_gru_zr_f32:  zr [M,2O] = sigmoid(A Bw + bias);  xhr[m, f_in + o] = H[m,o] * zr[m, O + o]
- *                         == pgt_gemm_f32 into zr followed by pgt_gru_zr_f32 (dcrnn.py:172-185), bit for bit,
- *                         without writing and re-reading the pre-activations.
+ *                         == pgt_gemm_f32 into zr followed by pgt_gru_zr_f32 (dcrnn.py:172-185) (bit for bit on the
+ *                         fmaf-chain kernels), without writing and re-reading the pre-activations.
  *   pgt_gemm_gru_h_f32:   ht [M,O] = tanh(A Bw + bias);  Hnew = Z*H + (1-Z)*ht with Z = zr[m, o] (row stride 2O)
  *                         written to out0 and, when non-NULL, out1 == pgt_gemm_f32 + pgt_gru_h_f32 (dcrnn.py:186-192).
- * O must be a multiple of 4, zr / ht 16-byte aligned. */
+ *                         map0 (NULL = plain rows): out0 in a two-level row layout (pgt_rowmap) — the cell of time step t
+ *                         writes H_t straight into the reference's [B, T, N, O] result (dcrnn.py:463-475).
+ * O must be a multiple of 4, zr / ht 16-byte aligned.  Arithmetic as pgt_gemm_f32; on the split-bf16 kernel the gate chain
+ * uses the hardware exp / reciprocal (sigmoid within 3e-7 of the library one, tanh by its odd series below |x| = 0.04), so
+ * the fused and the unfused path agree to a few 1e-7, not bit for bit, from 8 192 rows. */
 int pgt_gemm_gru_zr_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                         const float* Bw, int64_t sbk, int64_t sbn, const float* bias, float* zr, const float* H,
                         int64_t ldh, float* xhr, int64_t ldxhr, int64_t f_in, int64_t M, int64_t O,
                         pgt_stream_t stream);
 int pgt_gemm_gru_h_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                        const float* Bw, int64_t sbk, int64_t sbn, const float* bias, float* ht, const float* zr,
-                       const float* H, int64_t ldh, float* out0, int64_t ld0, float* out1, int64_t ld1, int64_t M,
-                       int64_t O, pgt_stream_t stream);
+                       const float* H, int64_t ldh, float* out0, int64_t ld0, const pgt_rowmap* map0, float* out1,
+                       int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream);
 
 /* ---------------------------------------------------------------- GRU gate chains */
 
@@ -296,17 +311,20 @@ int pgt_gru_zr_f32(float* pre_zr, const float* H, int64_t ldh, float* xhr, int64
 /*   ht = tanh(pre_h) in place;  Hnew = Z*H + (1-Z)*ht  (dcrnn.py:188-192), written to out0 (row stride ld0)
  *   and, when out1 != NULL, also to out1 (row stride ld1). */
 int pgt_gru_h_f32(float* pre_h, const float* zr, const float* H, int64_t ldh, float* out0, int64_t ld0,
-                  float* out1, int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream);
+                  const pgt_rowmap* map0, float* out1, int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream);
 /* backward of pgt_gru_h_f32: given dHnew (+ dHnew2 when non-NULL: the output gradient and the running state
  *   gradient are summed on the fly), writes d_pre_h [M,O], d_pre_zr[:, 0:O] (update gate), and
- *   dH (=|+=) dHnew * Z  depending on accumulate_dh.  dH may alias dHnew2. */
-int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const float* dHnew2, int64_t lddh2, const float* zr,
-                      const float* H, int64_t ldh, const float* ht, float* d_pre_h, float* d_pre_zr, float* dH,
-                      int64_t lddhp, int accumulate_dh, int64_t M, int64_t O, pgt_stream_t stream);
+ *   dH (=|+=) dHnew * Z  depending on accumulate_dh.  dH may alias dHnew2.  map_dh / map_h (NULL = plain rows): dHnew / H
+ *   in a two-level row layout (pgt_rowmap): the incoming gradient and the previous state are read in place from
+ *   [B, T, N, O] tensors. */
+int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const pgt_rowmap* map_dh, const float* dHnew2, int64_t lddh2,
+                      const float* zr, const float* H, int64_t ldh, const pgt_rowmap* map_h, const float* ht,
+                      float* d_pre_h, float* d_pre_zr, float* dH, int64_t lddhp, int accumulate_dh, int64_t M, int64_t O,
+                      pgt_stream_t stream);
 /* backward of pgt_gru_zr_f32: dxhr[:, f_in:] is d(H*R);  d_pre_zr[:, O:2O] = dHR*H*R*(1-R);  dH += dHR*R */
 int pgt_gru_zr_bwd_f32(const float* dxhr, int64_t lddxhr, int64_t f_in, const float* zr, const float* H,
-                       int64_t ldh, float* d_pre_zr, float* dH, int64_t lddhp, int64_t M, int64_t O,
-                       pgt_stream_t stream);
+                       int64_t ldh, const pgt_rowmap* map_h, float* d_pre_zr, float* dH, int64_t lddhp, int64_t M,
+                       int64_t O, pgt_stream_t stream);
 
 /* TGCN (temporalgcn.py:82-102): pre_zr [M,2*O] = linear_{z,r}([conv(X), H]);
  *   zr = sigmoid(pre_zr) in place; hr[m,o] = H[m,o]*R[m,o] */

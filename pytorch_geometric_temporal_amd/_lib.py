@@ -44,6 +44,11 @@ class DConvGraphStruct(ctypes.Structure):
                 ("deg_out", c_ptr), ("deg_in", c_ptr), ("info", c_ptr)]
 
 
+class RowMapStruct(ctypes.Structure):
+    """pgt_rowmap: row m of an operand at base + (m // period) * stride_hi + (m % period) * ld."""
+    _fields_ = [("period", c_i64), ("stride_hi", c_i64)]
+
+
 class SymGraphStruct(ctypes.Structure):
     _fields_ = [("fwd", CsrStruct), ("bwd", CsrStruct), ("deg", c_ptr), ("info", c_ptr)]
 
@@ -84,17 +89,17 @@ PROTOTYPES = {
     "pgt_gemm_gru_zr_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64,
                                     c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_gemm_gru_h_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
-                                   c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+                                   c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_gemm_tn_acc_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                     c_i64, c_ptr]),
     "pgt_gemm_tn_det_ws_bytes": (c_size, [c_i64, c_i64, c_i64, c_i64]),
     "pgt_gemm_tn_det_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                     c_i64, c_ptr, c_size, c_ptr]),
     "pgt_gru_zr_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
-    "pgt_gru_h_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
-    "pgt_gru_h_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
-                                  c_int, c_i64, c_i64, c_ptr]),
-    "pgt_gru_zr_bwd_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64,
+    "pgt_gru_h_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_gru_h_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                                  c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr]),
+    "pgt_gru_zr_bwd_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
                                    c_ptr]),
     "pgt_lstm_gates_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_lstm_gates_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64,
@@ -110,7 +115,7 @@ PROTOTYPES = {
     "pgt_window_gather_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
 }
 
-EXPECTED_ABI = 8
+EXPECTED_ABI = 9
 
 
 class PgtLib:

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void gru_zr_kernel(float* pre_zr, const float*
 template <int V>
 __global__ __launch_bounds__(256) void gru_h_kernel(float* pre_h, const float* __restrict__ zr,
                                                      const float* __restrict__ H, int64_t ldh, float* out0,
-                                                     int64_t ld0, float* out1, int64_t ld1, int64_t M, int O) {
+                                                     int64_t ld0, pgt_rowmap map0, float* out1, int64_t ld1, int64_t M,
+                                                     int O) {
   const int OV = O / V;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * OV) return;
@@ -50,15 +51,15 @@ __global__ __launch_bounds__(256) void gru_h_kernel(float* pre_h, const float* _
     hn[i] = pgt_gru_blend(z[i], h[i], t[i]);
   }
   pgt_stv<V>(pre_h + m * O + o, t);
-  pgt_stv<V>(out0 + m * ld0 + o, hn);
+  pgt_stv<V>(out0 + pgt_row_off(m, ld0, map0.period, map0.stride_hi) + o, hn);
   if (out1) pgt_stv<V>(out1 + m * ld1 + o, hn);
 }
 
 template <int V>
-__global__ __launch_bounds__(256) void gru_h_bwd_kernel(const float* __restrict__ dHn, int64_t lddh,
+__global__ __launch_bounds__(256) void gru_h_bwd_kernel(const float* __restrict__ dHn, int64_t lddh, pgt_rowmap map_dh,
                                                          const float* dHn2, int64_t lddh2,
                                                          const float* __restrict__ zr,
-                                                         const float* __restrict__ H, int64_t ldh,
+                                                         const float* __restrict__ H, int64_t ldh, pgt_rowmap map_h,
                                                          const float* __restrict__ ht, float* d_pre_h,
                                                          float* d_pre_zr, float* dH, int64_t lddhp, int acc,
                                                          int64_t M, int O) {
@@ -68,14 +69,14 @@ __global__ __launch_bounds__(256) void gru_h_bwd_kernel(const float* __restrict_
   const int64_t m = idx / OV;
   const int o = (int)(idx - m * OV) * V;
   float g[V], g2[V], z[V], h[V], t[V], dph[V], dpz[V], dh[V];
-  pgt_ldv<V>(dHn + m * lddh + o, g);
+  pgt_ldv<V>(dHn + pgt_row_off(m, lddh, map_dh.period, map_dh.stride_hi) + o, g);
   if (dHn2) {
     pgt_ldv<V>(dHn2 + m * lddh2 + o, g2);
 #pragma unroll
     for (int i = 0; i < V; ++i) g[i] += g2[i];
   }
   pgt_ldv<V>(zr + m * 2 * O + o, z);
-  pgt_ldv<V>(H + m * ldh + o, h);
+  pgt_ldv<V>(H + pgt_row_off(m, ldh, map_h.period, map_h.stride_hi) + o, h);
   pgt_ldv<V>(ht + m * O + o, t);
   float* q = dH + m * lddhp + o;
   if (acc) pgt_ldv<V>(q, dh);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void gru_h_bwd_kernel(const float* __restrict_
 template <int V>
 __global__ __launch_bounds__(256) void gru_zr_bwd_kernel(const float* __restrict__ dxhr, int64_t lddxhr, int f_in,
                                                           const float* __restrict__ zr,
-                                                          const float* __restrict__ H, int64_t ldh,
+                                                          const float* __restrict__ H, int64_t ldh, pgt_rowmap map_h,
                                                           float* d_pre_zr, float* dH, int64_t lddhp, int64_t M,
                                                           int O) {
   const int OV = O / V;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void gru_zr_bwd_kernel(const float* __restrict
   float g[V], r[V], h[V], dpr[V], dh[V];
   pgt_ldv<V>(dxhr + m * lddxhr + f_in + o, g);
   pgt_ldv<V>(zr + m * 2 * O + O + o, r);
-  pgt_ldv<V>(H + m * ldh + o, h);
+  pgt_ldv<V>(H + pgt_row_off(m, ldh, map_h.period, map_h.stride_hi) + o, h);
   float* q = dH + m * lddhp + o;
   pgt_ldv<V>(q, dh);
 #pragma unroll
@@ -330,52 +331,58 @@ extern "C" int pgt_gru_zr_f32(float* pre_zr, const float* H, int64_t ldh, float*
 }
 
 extern "C" int pgt_gru_h_f32(float* pre_h, const float* zr, const float* H, int64_t ldh, float* out0,
-                             int64_t ld0, float* out1, int64_t ld1, int64_t M, int64_t O,
+                             int64_t ld0, const pgt_rowmap* map0, float* out1, int64_t ld1, int64_t M, int64_t O,
                              pgt_stream_t stream) {
   PGT_REQUIRE(M >= 0 && O >= 0, "pgt_gru_h_f32: negative size");
   if (M == 0 || O == 0) return PGT_OK;
   PGT_REQUIRE(pre_h && zr && H && out0, "pgt_gru_h_f32: null pointer");
+  pgt_rowmap m0;
+  PGT_REQUIRE(pgt_rowmap_take(map0, M, &m0), "pgt_gru_h_f32: row map out of range");
   PgtVecPick pick;
   pick.width(O);
-  pick.operand(pre_h, O); pick.operand(zr, 2 * O); pick.operand(H, ldh); pick.operand(out0, ld0);
+  pick.operand(pre_h, O); pick.operand(zr, 2 * O); pick.operand(H, ldh); pick.operand(out0, ld0, m0);
   pick.operand(out1, ld1);
   dim3 grid, block(256);
   if (int e = grid_for(M * (O / pick.v), "pgt_gru_h_f32", &grid)) return e;
-  PGT_VDISPATCH(pick.v, gru_h_kernel, grid, block, stream, pre_h, zr, H, ldh, out0, ld0, out1, ld1, M, (int)O);
+  PGT_VDISPATCH(pick.v, gru_h_kernel, grid, block, stream, pre_h, zr, H, ldh, out0, ld0, m0, out1, ld1, M, (int)O);
   return pgt_check_launch("pgt_gru_h_f32");
 }
 
-extern "C" int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const float* dHnew2, int64_t lddh2,
-                                 const float* zr, const float* H, int64_t ldh, const float* ht, float* d_pre_h,
-                                 float* d_pre_zr, float* dH, int64_t lddhp, int accumulate_dh, int64_t M,
-                                 int64_t O, pgt_stream_t stream) {
+extern "C" int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const pgt_rowmap* map_dh, const float* dHnew2,
+                                 int64_t lddh2, const float* zr, const float* H, int64_t ldh, const pgt_rowmap* map_h,
+                                 const float* ht, float* d_pre_h, float* d_pre_zr, float* dH, int64_t lddhp,
+                                 int accumulate_dh, int64_t M, int64_t O, pgt_stream_t stream) {
   PGT_REQUIRE(M >= 0 && O >= 0, "pgt_gru_h_bwd_f32: negative size");
   if (M == 0 || O == 0) return PGT_OK;
   PGT_REQUIRE(dHnew && zr && H && ht && d_pre_h && d_pre_zr && dH, "pgt_gru_h_bwd_f32: null pointer");
+  pgt_rowmap mg, mh;
+  PGT_REQUIRE(pgt_rowmap_take(map_dh, M, &mg) && pgt_rowmap_take(map_h, M, &mh), "pgt_gru_h_bwd_f32: row map out of range");
   PgtVecPick pick;
   pick.width(O);
-  pick.operand(dHnew, lddh); pick.operand(dHnew2, lddh2); pick.operand(zr, 2 * O); pick.operand(H, ldh);
+  pick.operand(dHnew, lddh, mg); pick.operand(dHnew2, lddh2); pick.operand(zr, 2 * O); pick.operand(H, ldh, mh);
   pick.operand(ht, O); pick.operand(d_pre_h, O); pick.operand(d_pre_zr, 2 * O); pick.operand(dH, lddhp);
   dim3 grid, block(256);
   if (int e = grid_for(M * (O / pick.v), "pgt_gru_h_bwd_f32", &grid)) return e;
-  PGT_VDISPATCH(pick.v, gru_h_bwd_kernel, grid, block, stream, dHnew, lddh, dHnew2, lddh2, zr, H, ldh, ht, d_pre_h,
-                d_pre_zr, dH, lddhp, accumulate_dh, M, (int)O);
+  PGT_VDISPATCH(pick.v, gru_h_bwd_kernel, grid, block, stream, dHnew, lddh, mg, dHnew2, lddh2, zr, H, ldh, mh, ht,
+                d_pre_h, d_pre_zr, dH, lddhp, accumulate_dh, M, (int)O);
   return pgt_check_launch("pgt_gru_h_bwd_f32");
 }
 
 extern "C" int pgt_gru_zr_bwd_f32(const float* dxhr, int64_t lddxhr, int64_t f_in, const float* zr,
-                                  const float* H, int64_t ldh, float* d_pre_zr, float* dH, int64_t lddhp,
-                                  int64_t M, int64_t O, pgt_stream_t stream) {
+                                  const float* H, int64_t ldh, const pgt_rowmap* map_h, float* d_pre_zr, float* dH,
+                                  int64_t lddhp, int64_t M, int64_t O, pgt_stream_t stream) {
   PGT_REQUIRE(M >= 0 && O >= 0 && f_in >= 0, "pgt_gru_zr_bwd_f32: negative size");
   if (M == 0 || O == 0) return PGT_OK;
   PGT_REQUIRE(dxhr && zr && H && d_pre_zr && dH, "pgt_gru_zr_bwd_f32: null pointer");
+  pgt_rowmap mh;
+  PGT_REQUIRE(pgt_rowmap_take(map_h, M, &mh), "pgt_gru_zr_bwd_f32: row map out of range");
   PgtVecPick pick;
   pick.width(O);
-  pick.operand(dxhr + f_in, lddxhr); pick.operand(zr + O, 2 * O); pick.operand(H, ldh);
+  pick.operand(dxhr + f_in, lddxhr); pick.operand(zr + O, 2 * O); pick.operand(H, ldh, mh);
   pick.operand(d_pre_zr + O, 2 * O); pick.operand(dH, lddhp);
   dim3 grid, block(256);
   if (int e = grid_for(M * (O / pick.v), "pgt_gru_zr_bwd_f32", &grid)) return e;
-  PGT_VDISPATCH(pick.v, gru_zr_bwd_kernel, grid, block, stream, dxhr, lddxhr, (int)f_in, zr, H, ldh, d_pre_zr, dH,
+  PGT_VDISPATCH(pick.v, gru_zr_bwd_kernel, grid, block, stream, dxhr, lddxhr, (int)f_in, zr, H, ldh, mh, d_pre_zr, dH,
                 lddhp, M, (int)O);
   return pgt_check_launch("pgt_gru_zr_bwd_f32");
 }

@@ -38,7 +38,7 @@ __device__ __forceinline__ float gemm_epi1(const GemmArgs& g, int gm, int gn, fl
     v = tanhf(v);
     const float z = g.eZ[(int64_t)gm * 2 * g.eO + gn], h = g.eH[(int64_t)gm * g.eldh + gn];
     const float hn = pgt_gru_blend(z, h, v);
-    g.eO0[(int64_t)gm * g.eld0 + gn] = hn;
+    g.eO0[pgt_row_off(gm, g.eld0, g.e0_period, g.e0_hi) + gn] = hn;
     if (g.eO1) g.eO1[(int64_t)gm * g.eld1 + gn] = hn;
   }
   return v;
@@ -71,7 +71,7 @@ __device__ __forceinline__ float4 gemm_epi4(const GemmArgs& g, int gm, int gn, f
     const float4 h = gemm_epi_ld4(g.eH + (int64_t)gm * g.eldh + gn, g.evec & 1);
     const float4 hn = make_float4(pgt_gru_blend(z.x, h.x, v.x), pgt_gru_blend(z.y, h.y, v.y),
                                   pgt_gru_blend(z.z, h.z, v.z), pgt_gru_blend(z.w, h.w, v.w));
-    gemm_epi_st4(g.eO0 + (int64_t)gm * g.eld0 + gn, hn, g.evec & 4, false);
+    gemm_epi_st4(g.eO0 + pgt_row_off(gm, g.eld0, g.e0_period, g.e0_hi) + gn, hn, g.evec & 4, false);
     if (g.eO1) gemm_epi_st4(g.eO1 + (int64_t)gm * g.eld1 + gn, hn, false, g.evec & 8);
   }
   return v;
@@ -1514,11 +1514,12 @@ static int gemm_entry(const float* A, int64_t lda, int64_t a_seg_stride, int64_t
               "pgt_gemm_f32: size exceeds int32 indexing");
   GemmArgs g{A, lda, a_seg_stride, (int)n_seg, (int)(seg_k > 0 ? seg_k : 1), Bw, sbk, sbn, C, ldc, c_seg_stride,
              (int)c_seg_n, bias, (int)M, (int)N, accumulate, 0, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0,
-             nullptr, 0};
+             nullptr, 0, 0, 0};
   if (epi) {
     g.epi = epi->epi; g.eO = epi->eO; g.efin = epi->efin; g.evec = epi->evec;
     g.eH = epi->eH; g.eldh = epi->eldh; g.eX = epi->eX; g.eldx = epi->eldx;
     g.eZ = epi->eZ; g.eO0 = epi->eO0; g.eld0 = epi->eld0; g.eO1 = epi->eO1; g.eld1 = epi->eld1;
+    g.e0_period = epi->e0_period; g.e0_hi = epi->e0_hi;
   }
   // skinny shapes (see gemm_skinny_*_kernel): one segment in, one segment out, no fused epilogue
   if (g_skinny && !epi && n_seg == 1 && c_seg_n >= N && (M >= 1024 || g_skinny == 2)) {
@@ -1650,17 +1651,22 @@ extern "C" int pgt_gemm_gru_zr_f32(const float* A, int64_t lda, int64_t a_seg_st
 
 extern "C" int pgt_gemm_gru_h_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_t n_seg, int64_t seg_k,
                                   const float* Bw, int64_t sbk, int64_t sbn, const float* bias, float* ht,
-                                  const float* zr, const float* H, int64_t ldh, float* out0, int64_t ld0, float* out1,
-                                  int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream) {
+                                  const float* zr, const float* H, int64_t ldh, float* out0, int64_t ld0,
+                                  const pgt_rowmap* map0, float* out1, int64_t ld1, int64_t M, int64_t O,
+                                  pgt_stream_t stream) {
   PGT_REQUIRE(M >= 0 && O >= 0, "pgt_gemm_gru_h_f32: negative size");
   if (M == 0 || O == 0) return PGT_OK;
   PGT_REQUIRE(ht && zr && H && out0, "pgt_gemm_gru_h_f32: null pointer");
+  pgt_rowmap m0;
+  PGT_REQUIRE(pgt_rowmap_take(map0, M, &m0), "pgt_gemm_gru_h_f32: row map out of range");
   PGT_REQUIRE(O % 4 == 0 && pgt_aligned(ht, 16) && pgt_aligned(zr, 16),
               "pgt_gemm_gru_h_f32: O must be a multiple of 4 and ht / zr 16-byte aligned");
   GemmArgs e{};
   e.epi = 2; e.eO = (int)O;
   e.eH = H; e.eldh = ldh; e.eZ = zr; e.eO0 = out0; e.eld0 = ld0; e.eO1 = out1; e.eld1 = ld1;
-  e.evec = ((ldh % 4 == 0 && pgt_aligned(H, 16)) ? 1 : 0) | ((ld0 % 4 == 0 && pgt_aligned(out0, 16)) ? 4 : 0) |
+  e.e0_period = m0.period; e.e0_hi = m0.stride_hi;
+  e.evec = ((ldh % 4 == 0 && pgt_aligned(H, 16)) ? 1 : 0) |
+           ((ld0 % 4 == 0 && pgt_aligned(out0, 16) && (m0.period == 0 || m0.stride_hi % 4 == 0)) ? 4 : 0) |
            ((out1 && ld1 % 2 == 0 && pgt_aligned(out1, 8)) ? 8 : 0);
   return gemm_entry(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, ht, O, 0, O, bias, M, O, 0, &e, stream);
 }

@@ -530,6 +530,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
           if (e_live) e_issue(rb + nwg);               // the next block's operands, ahead of this block's stores
           BX_FENCE();
         }
+        // eO0 in a two-level row layout (pgt_rowmap: H_t straight into the [B, T, N, O] result): one uniform division per
+        // block, a compare per row (a block of 32 rows crosses at most one period boundary when period >= 32)
+        int64_t o0_q = 0;
+        int o0_rem = 0;
+        if constexpr (EPI == 2) {
+          if (g.e0_period > 0) {
+            const uint32_t q = (uint32_t)BX_SGPR((int)((uint32_t)(rb * BM) / (uint32_t)g.e0_period));
+            o0_q = (int64_t)q * g.e0_hi;
+            o0_rem = rb * BM - (int)(q * (uint32_t)g.e0_period);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
           const int gn = (cb * WN + j) * 32 + lo;
@@ -544,7 +555,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
             if constexpr (EPI == 1) {
               if (gn >= g.eO) g.eX[(int64_t)gm * g.eldx + g.efin + (gn - g.eO)] = side[r];
             } else if constexpr (EPI == 2) {
-              g.eO0[(int64_t)gm * g.eld0 + gn] = side[r];
+              int64_t o0;
+              if (g.e0_period >= BM) {
+                const int rr = o0_rem + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool wrap = rr >= (int)g.e0_period;
+                o0 = o0_q + (wrap ? g.e0_hi : 0) + (int64_t)(rr - (wrap ? (int)g.e0_period : 0)) * g.eld0;
+              } else {
+                o0 = pgt_row_off(gm, g.eld0, g.e0_period, g.e0_hi);
+              }
+              g.eO0[o0 + gn] = side[r];
               if (g.eO1) g.eO1[(int64_t)gm * g.eld1 + gn] = side[r];
             }
           }

@@ -126,7 +126,16 @@ struct PgtGemmArgs {
   int epi; int eO; int efin; int evec;   // evec bit 0: eH float4-loadable, 1: eX float2-storable, 2: eO0 float4, 3: eO1 float2
   const float* eH; int64_t eldh; float* eX; int64_t eldx;
   const float* eZ; float* eO0; int64_t eld0; float* eO1; int64_t eld1;
+  // two-level row layout of eO0 (pgt_rowmap): row m at eO0 + (m / e0_period) * e0_hi + (m % e0_period) * eld0; 0 = plain
+  int64_t e0_period; int64_t e0_hi;
 };
+
+// pgt_rowmap on the device: float offset of row m of an operand with row stride ld (period <= 0: a plain matrix)
+__device__ __forceinline__ int64_t pgt_row_off(int64_t m, int64_t ld, int64_t period, int64_t stride_hi) {
+  if (period <= 0) return m * ld;
+  const uint32_t q = (uint32_t)m / (uint32_t)period;                   // m < 2^31, period < 2^31 (checked by the host)
+  return (int64_t)q * stride_hi + (int64_t)((uint32_t)m - q * (uint32_t)period) * ld;
+}
 // Arguments of the weight-gradient kernels: dW[k, n] += sum_m A[m, k] G[m, n], db[n] += sum_m G[m, n].
 struct PgtTnArgs {
   const float* A; int64_t lda; int64_t a_seg_stride; int n_seg; int seg_k;
@@ -178,4 +187,17 @@ struct PgtVecPick {
     if (p == nullptr) return;
     while (v > 1 && (ld % v || reinterpret_cast<uintptr_t>(p) % (4u * v))) v >>= 1;
   }
+  void operand(const void* p, int64_t ld, const pgt_rowmap& m) {
+    operand(p, ld);
+    if (m.period > 0) while (v > 1 && m.stride_hi % v) v >>= 1;
+  }
 };
+
+// a caller's pgt_rowmap (NULL = plain rows) by value; false when it cannot be indexed with 32-bit row arithmetic
+static inline bool pgt_rowmap_take(const pgt_rowmap* in, int64_t M, pgt_rowmap* out) {
+  out->period = 0; out->stride_hi = 0;
+  if (in == nullptr || in->period == 0) return true;
+  if (in->period < 0 || in->period >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 31)) return false;
+  *out = *in;
+  return true;
+}

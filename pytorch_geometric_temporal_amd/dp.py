@@ -23,7 +23,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+        # (hosts whose driver only supports dmabuf IPC need HSA_ENABLE_IPC_MODE_LEGACY=0 in the launcher's environment
+        # for RCCL; a library does not edit its user's environment — bench.py, a launcher, sets it for itself)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -74,7 +75,9 @@ class FlatGradients:
         self.flat.zero_()
 
     def all_reduce_mean(self, world=None, async_op=False):
-        """SUM over ranks then 1/world (DDP's gradient averaging).  Returns the work handle when async_op."""
+        """SUM over ranks then 1/world (DDP's gradient averaging).  Returns the work handle when async_op (finish() waits
+        and scales).  The whole gradient is 0.6 - 305 KB and final only when BPTT ends (the weight gradients of all T steps
+        are one product at the end), so there is nothing to overlap it with: bench.py issues it synchronously."""
         if world is None:
             world = dist.get_world_size() if dist.is_initialized() else 1
         if world <= 1:

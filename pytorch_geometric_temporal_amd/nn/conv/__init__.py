@@ -21,8 +21,7 @@ def _rows_in_memory_order(x):
     """(x as [rows, C] without a copy when possible, function restoring the leading shape of a [rows, C'] result).
 
     A product over the last dimension does not care in which order the rows are visited: when `x` is a permuted view
-    of a contiguous tensor (e.g. the zero-copy `[B, T, N, C]` output of BatchedDCRNN(lazy_output=True), stored
-    `[T, B, N, C]`), the rows are taken in MEMORY order and the result is handed back as the same permuted view."""
+    of a contiguous tensor (e.g. a `[B, T, N, C]` view of states stored `[T, B, N, C]`), the rows are taken in MEMORY order and the result is handed back as the same permuted view."""
     lead = x.shape[:-1]
     if x.is_contiguous() or x.dim() < 3 or x.stride(-1) != 1:
         return x.reshape(-1, x.shape[-1]), (lambda y: y.view(*lead, y.shape[-1]))

@@ -121,12 +121,9 @@ class BatchedDCRNN(torch.nn.Module):
         self.conv_x_z = BatchedDConv(c, out_channels, K, bias)
         self.conv_x_r = BatchedDConv(c, out_channels, K, bias)
         self.conv_x_h = BatchedDConv(c, out_channels, K, bias)
-        # The hidden states are produced time-major ([T][B*N][O] or [T][N*B][O]); the reference returns [B, T, N, O]
-        # (dcrnn.py:470-475).  False: the result is transposed into a contiguous [B, T, N, O] tensor (1.3 GB of traffic
-        # at B = 1024, hidden 64, forward and again backward).  True: the SAME values are returned as a zero-copy
-        # permuted view (shape [B, T, N, O], non-contiguous: `.view()` on it needs `.contiguous()` first); this
-        # package's Linear consumes such a view in memory order, so the readout needs no transposition either.
-        self.lazy_output = False
+        # The result is the reference's contiguous [B, T, N, O] tensor (torch.stack(outputs, dim=1), dcrnn.py:463-475): the
+        # candidate-gate epilogue of every step stores its H_t straight into out[:, t] (ops.DCRNNSeqFunction, btno) and the
+        # backward pass reads the incoming gradient in that layout -- no transposition pass in either direction.
 
     def forward(self, X, edge_index, edge_weight):
         B, T, N, Fin = X.shape
@@ -140,15 +137,8 @@ class BatchedDCRNN(torch.nn.Module):
             # [B][T][N*F] -> [T][B][N*F]
             Xbm = ops.Swap01.apply(X.contiguous().view(B, T, N * Fin), B, T, N * Fin).view(T, B * N, Fin)
             H0 = torch.zeros(B * N, O, device=X.device, dtype=X.dtype)
-            Hs = ops.DCRNNSeqFunction.apply(Xbm, H0, Wzr, bzr, Wh, bh, g, self.K, B, True)     # [T, B*N, O]
-            if self.lazy_output:
-                return Hs.view(T, B, N, O).permute(1, 0, 2, 3)
-            return ops.Swap01.apply(Hs.view(T, B, N * O), T, B, N * O).view(B, T, N, O)
+            return ops.DCRNNSeqFunction.apply(Xbm, H0, Wzr, bzr, Wh, bh, g, self.K, B, True, True)       # [B, T, N, O]
         # [B][T*N][F] -> [T*N][B][F]  (node-major rows m = n*B + b per step: one aggregation launch per hop)
         Xnm = ops.Swap01.apply(X.contiguous().view(B, T * N, Fin), B, T * N, Fin).view(T, N * B, Fin)
         H0 = torch.zeros(N * B, O, device=X.device, dtype=X.dtype)
-        Hs = ops.DCRNNSeqFunction.apply(Xnm, H0, Wzr, bzr, Wh, bh, g, self.K, B)   # [T, N*B, O]
-        if self.lazy_output:
-            return Hs.view(T, N, B, O).permute(2, 0, 1, 3)
-        out = ops.Swap01.apply(Hs.view(T * N, B, O), T * N, B, O)
-        return out.view(B, T, N, O)
+        return ops.DCRNNSeqFunction.apply(Xnm, H0, Wzr, bzr, Wh, bh, g, self.K, B, False, True)        # [B, T, N, O]

@@ -12,7 +12,7 @@ import warnings
 import torch
 
 from . import _lib
-from ._lib import CsrStruct, DConvGraphStruct, EllwStruct, SymGraphStruct, PgtError, check_tensor, ptr, stream_of
+from ._lib import CsrStruct, DConvGraphStruct, EllwStruct, RowMapStruct, SymGraphStruct, PgtError, check_tensor, ptr, stream_of
 
 F32 = torch.float32
 I32 = torch.int32
@@ -470,18 +470,40 @@ def gemm_gru_zr(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, bias, zr, H, x
         xp, ldx, f_in, M, O2 // 2, stream_of(lib, zr)), tag=("NN+zr", M, O2, n_seg, seg_k, O2, 0))
 
 
+class RowMap:
+    """A [M, W] operand inside a larger tensor (pgt_rowmap): row m at `base` + (m // period) * stride_hi +
+    (m % period) * ld floats.  `base` is a tensor view whose data_ptr is row 0; `width` the row length."""
+    __slots__ = ("base", "ld", "period", "stride_hi", "width", "_st")
+
+    def __init__(self, base, ld, period, stride_hi, width):
+        self.base, self.ld, self.period, self.stride_hi, self.width = base, int(ld), int(period), int(stride_hi), int(width)
+        self._st = RowMapStruct(self.period, self.stride_hi)
+
+    def ref(self):
+        return ctypes.byref(self._st)
+
+
+def _rows_or_map(t, name):
+    """(pointer, row stride, pgt_rowmap* or NULL) of a plain 2-D view or a RowMap."""
+    if isinstance(t, RowMap):
+        return ptr(t.base), t.ld, t.ref()
+    p, ld = _rows(t, name)
+    return p, ld, None
+
+
 def gemm_gru_h(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, bias, ht, zr, H, out0, out1=None):
-    """pgt_gemm_gru_h_f32: ht [M, O] = tanh(A Bw + bias), Hnew = Z H + (1 - Z) ht -> out0 (, out1) (== gemm + _gru_h)."""
+    """pgt_gemm_gru_h_f32: ht [M, O] = tanh(A Bw + bias), Hnew = Z H + (1 - Z) ht -> out0 (, out1) (== gemm + _gru_h).
+    out0 may be a RowMap (H_t straight into a [B, T, N, O] tensor)."""
     lib = _lib.get_lib()
-    for t, n in ((A, "A"), (Bw, "Bw"), (ht, "ht"), (zr, "zr"), (H, "H"), (out0, "out0")):
+    for t, n in ((A, "A"), (Bw, "Bw"), (ht, "ht"), (zr, "zr"), (H, "H"), (out0.base if isinstance(out0, RowMap) else out0, "out0")):
         check_tensor(lib, t, n)
     M, O = ht.shape
     hp, ldh = _rows(H, "H")
-    op, ld0 = _rows(out0, "out0")
+    op, ld0, m0 = _rows_or_map(out0, "out0")
     o1, ld1 = _rows(out1, "out1") if out1 is not None else (ptr(None), 0)
     _timed("gemm", 2.0 * M * O * n_seg * seg_k, lambda: lib.call(
         "pgt_gemm_gru_h_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(Bw), sbk, sbn, ptr(bias), ptr(ht), ptr(zr),
-        hp, ldh, op, ld0, o1, ld1, M, O, stream_of(lib, ht)), tag=("NN+h", M, O, n_seg, seg_k, O, 0))
+        hp, ldh, op, ld0, m0, o1, ld1, M, O, stream_of(lib, ht)), tag=("NN+h", M, O, n_seg, seg_k, O, 0))
 
 
 def gemm_tn_acc(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N):
@@ -753,30 +775,46 @@ def _gru_h(pre_h, zr, H, out0, out1=None):
     lib = _lib.get_lib()
     M, O = pre_h.shape
     hp, ldh = _rows(H, "H")
-    op, ld0 = _rows(out0, "out0")
+    op, ld0, m0 = _rows_or_map(out0, "out0")
     o1, ld1 = _rows(out1, "out1") if out1 is not None else (ptr(None), 0)
-    lib.call("pgt_gru_h_f32", ptr(pre_h), ptr(zr), hp, ldh, op, ld0, o1, ld1, M, O, stream_of(lib, pre_h))
+    lib.call("pgt_gru_h_f32", ptr(pre_h), ptr(zr), hp, ldh, op, ld0, m0, o1, ld1, M, O, stream_of(lib, pre_h))
 
 
 def _gru_h_bwd(dHn, zr, H, ht, d_pre_h, d_pre_zr, dH, accumulate, dHn2=None):
+    """dHn and H may be RowMaps (read in place from [B, T, N, O] tensors)."""
     lib = _lib.get_lib()
     M, O = ht.shape
-    gp, ldg = _rows(dHn, "dHn")
+    gp, ldg, mg = _rows_or_map(dHn, "dHn")
     g2, ldg2 = _rows(dHn2, "dHn2") if dHn2 is not None else (ptr(None), 0)
-    hp, ldh = _rows(H, "H")
+    hp, ldh, mh = _rows_or_map(H, "H")
     dp, ldd = _rows(dH, "dH")
-    lib.call("pgt_gru_h_bwd_f32", gp, ldg, g2, ldg2, ptr(zr), hp, ldh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp, ldd,
-             int(bool(accumulate)), M, O, stream_of(lib, ht))
+    lib.call("pgt_gru_h_bwd_f32", gp, ldg, mg, g2, ldg2, ptr(zr), hp, ldh, mh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp,
+             ldd, int(bool(accumulate)), M, O, stream_of(lib, ht))
 
 
 def _gru_zr_bwd(dxhr, f_in, zr, H, d_pre_zr, dH):
     lib = _lib.get_lib()
     M, O2 = zr.shape
     xp, ldx = _rows(dxhr, "dxhr")
-    hp, ldh = _rows(H, "H")
+    hp, ldh, mh = _rows_or_map(H, "H")
     dp, ldd = _rows(dH, "dH")
-    lib.call("pgt_gru_zr_bwd_f32", xp, ldx, f_in, ptr(zr), hp, ldh, ptr(d_pre_zr), dp, ldd, M, O2 // 2,
+    lib.call("pgt_gru_zr_bwd_f32", xp, ldx, f_in, ptr(zr), hp, ldh, mh, ptr(d_pre_zr), dp, ldd, M, O2 // 2,
              stream_of(lib, zr))
+
+
+class _StateLayout:
+    """The [M, O] slice of time step t inside a contiguous [B, T, N, O] tensor, as RowMaps: batch-major rows
+    m = b*N + n -> period N, stride_hi T*N*O, ld O; node-major rows m = n*B + b -> period B, stride_hi O, ld T*N*O."""
+
+    def __init__(self, tensor, T, N, B, O, batch_major):
+        if tensor.shape != (B, T, N, O) or not tensor.is_contiguous():
+            raise ValueError(f"expected a contiguous [B, T, N, O] = {(B, T, N, O)} tensor, got {tuple(tensor.shape)}")
+        self.flat, self.step_stride, self.O = tensor.view(-1), N * O, O
+        self.args = (O, N, T * N * O) if batch_major else (T * N * O, B, O)      # (ld, period, stride_hi)
+
+    def step(self, t):
+        ld, period, hi = self.args
+        return RowMap(self.flat[t * self.step_stride:], ld, period, hi, self.O)
 
 
 class DCRNNSeqFunction(torch.autograd.Function):
@@ -789,9 +827,13 @@ class DCRNNSeqFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, X, H0, Wzr, bzr, Wh, bh, g, K, B, batch_major=False):
+    def forward(ctx, X, H0, Wzr, bzr, Wh, bh, g, K, B, batch_major=False, btno=False):
         """batch_major: rows m = b*N + n and the diffusion stacks run as ONE LDS-resident launch per conv
-        (pgt_dconv_stack_slab_f32; requires slab_fits); otherwise rows m = n*B + b and one launch per hop."""
+        (pgt_dconv_stack_slab_f32; requires slab_fits); otherwise rows m = n*B + b and one launch per hop.
+        btno: the hidden states are returned as the reference returns them, a contiguous [B, T, N, O] tensor
+        (torch.stack(outputs, dim=1), dcrnn.py:463-475): the candidate-gate epilogue of step t stores H_t straight into
+        out[:, t] through a two-level row map (pgt_rowmap) and the backward pass reads the incoming gradient and the
+        previous states in place from that layout — no transposition pass either way."""
         lib = _lib.get_lib()
         check_tensor(lib, X, "X")
         check_tensor(lib, H0, "H0")
@@ -811,8 +853,9 @@ class DCRNNSeqFunction(torch.autograd.Function):
         TSh = torch.empty(S, T, M, C, dtype=F32, device=dev)
         ZR = torch.empty(T, M, 2 * O, dtype=F32, device=dev)
         HT = torch.empty(T, M, O, dtype=F32, device=dev)
-        Hout = torch.empty(T, M, O, dtype=F32, device=dev)
+        Hout = torch.empty((B, T, Nn, O) if btno else (T, M, O), dtype=F32, device=dev)
         H0c = H0.contiguous()
+        state = _StateLayout(Hout, T, Nn, B, O, batch_major) if btno else None
         seg = T * M * C
         slab = bool(batch_major) or (B == 1 and slab_fits(g, C, K))
         if slab and K > 1 and not slab_fits(g, C, K):
@@ -831,22 +874,26 @@ class DCRNNSeqFunction(torch.autograd.Function):
         copy2d(TSh[0].view(T * M, C)[:, :Fin], X.view(T * M, Fin))
         fuse = FUSE_GATE_EPILOGUES and O % 4 == 0
         for t in range(T):
-            Hp = H0c if t == 0 else Hout[t - 1]
+            # H_{t-1}: the plain [M, O] state, or (btno: the states live in the [B, T, N, O] result) the hidden columns of
+            # this step's stack segment 0, which the previous step's blend wrote
+            Hp = H0c if t == 0 else (TSzr[0, t][:, Fin:] if btno else Hout[t - 1])
             if t == 0:
                 copy2d(TSzr[0, t][:, Fin:], Hp)     # later steps: written by the previous step's blend
             Hnext = TSzr[0, t + 1][:, Fin:] if t + 1 < T else None
+            Ht = state.step(t) if btno else Hout[t]
             stack(TSzr, t)
             if fuse:
                 gemm_gru_zr(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, bzr, ZR[t], Hp, TSh[0, t], Fin)
                 stack(TSh, t)
-                gemm_gru_h(TSh[0, t], C, seg, S, C, Wh_c, O, 1, bh, HT[t], ZR[t], Hp, Hout[t], Hnext)
+                gemm_gru_h(TSh[0, t], C, seg, S, C, Wh_c, O, 1, bh, HT[t], ZR[t], Hp, Ht, Hnext)
             else:
                 gemm(TSzr[0, t], C, seg, S, C, Wzr_c, 2 * O, 1, ZR[t], 2 * O, 0, 2 * O, bzr, M, 2 * O)
                 _gru_zr(ZR[t], Hp, TSh[0, t], Fin)
                 stack(TSh, t)
                 gemm(TSh[0, t], C, seg, S, C, Wh_c, O, 1, HT[t], O, 0, O, bh, M, O)
-                _gru_h(HT[t], ZR[t], Hp, Hout[t], Hnext)
+                _gru_h(HT[t], ZR[t], Hp, Ht, Hnext)
         ctx.g, ctx.K, ctx.B, ctx.Fin, ctx.slab = g, K, B, Fin, slab
+        ctx.btno, ctx.batch_major = btno, bool(batch_major)
         ctx.has_bias = (bzr is not None, bh is not None)
         ctx.save_for_backward(TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c)
         return Hout
@@ -860,6 +907,9 @@ class DCRNNSeqFunction(torch.autograd.Function):
         Nn = g.N
         dev = dOut.device
         dOut = dOut.contiguous()
+        if ctx.btno:      # gradient and states in the reference's [B, T, N, O] layout, read in place step by step
+            grad_in = _StateLayout(dOut, T, Nn, ctx.B, O, ctx.batch_major)
+            states = _StateLayout(Hout, T, Nn, ctx.B, O, ctx.batch_major)
         need_x = ctx.needs_input_grad[0]
         dX = torch.zeros(T, M, Fin, dtype=F32, device=dev) if need_x else None
         dH = torch.zeros(M, O, dtype=F32, device=dev)      # running d/dH_t
@@ -926,9 +976,10 @@ class DCRNNSeqFunction(torch.autograd.Function):
                 _stack_bwd(g, G, K, Nn, folded)
 
         for t in range(T - 1, -1, -1):
-            Hp = H0c if t == 0 else Hout[t - 1]
+            Hp = H0c if t == 0 else (states.step(t - 1) if ctx.btno else Hout[t - 1])
             # d/dH_t = dOut[t] + running state gradient, summed inside the gate-backward kernel
-            _gru_h_bwd(dOut[t], ZR[t], Hp, HT[t], dPh[t], dPzr[t], dH, accumulate=False, dHn2=dH)
+            _gru_h_bwd(grad_in.step(t) if ctx.btno else dOut[t], ZR[t], Hp, HT[t], dPh[t], dPzr[t], dH, accumulate=False,
+                       dHn2=dH)
             # candidate conv: dT = dPh Wh^T ; adjoint of the stack
             feature_grad(dPh[t], Wh_b, WhH if skip_x else None, O)
             stack_bwd()
@@ -955,7 +1006,7 @@ class DCRNNSeqFunction(torch.autograd.Function):
             if need_wh:
                 gemm_tn_acc(TSh, C, seg, S, C, dPh, O, dWh, O, dbh, T * M, O)
         dH0 = dH if ctx.needs_input_grad[1] else None
-        return dX, dH0, dWzr, dbzr, dWh, dbh, None, None, None, None
+        return dX, dH0, dWzr, dbzr, dWh, dbh, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- generic building blocks

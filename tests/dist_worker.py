@@ -51,7 +51,6 @@ def main():
     if model_name == "dcrnn":                          # flat parameters + one optimizer update (what bench.py does)
         flat = dp.FlatParameters(model.parameters())
         opt = flat.optimizer(torch.optim.SGD, lr=0.1)
-        model.lazy_output = True
     else:                                              # flat gradients + the ordinary per-parameter optimizer
         flat = dp.FlatGradients(model.parameters())
         opt = torch.optim.SGD(model.parameters(), lr=0.1)

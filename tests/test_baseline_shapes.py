@@ -43,8 +43,7 @@ def _params64(g):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("E", [1515, 1722])
-@pytest.mark.parametrize("lazy", [False, True])
-def test_config2_benchmarked_dcrnn_forward_matches_reference_fixture(E, lazy):
+def test_config2_benchmarked_dcrnn_forward_matches_reference_fixture(E):
     """BatchedDCRNN(2, 64, K=3), 207 nodes, B = 64 x 12 steps: the model bench.py times, through the slab kernels at
     C = 66 and the gate-fused GEMMs, against the reference module's output."""
     dev = torch.device("cuda:0")
@@ -53,10 +52,9 @@ def test_config2_benchmarked_dcrnn_forward_matches_reference_fixture(E, lazy):
     m = BatchedDCRNN(2, 64, 3)
     m.load_state_dict(g["param"], strict=True)
     m = m.to(dev)
-    m.lazy_output = lazy
     with torch.no_grad():
         out = m(X.to(dev), ei.to(dev), ew.to(dev))
-    assert tuple(out.shape) == (64, 12, 207, 64)
+    assert tuple(out.shape) == (64, 12, 207, 64) and out.is_contiguous()
     sample = out[list(BC.METRLA_SAMPLE_B)][:, list(BC.METRLA_SAMPLE_T)]
     assert_close_with_nonfinite(sample, g["out"][f"sample_E{E}"], ATOL, RTOL, f"E={E} sampled (b, t) slices")
     _check_sums(out, g["out"][f"sums_bt_E{E}"], (0, 1), f"E={E}")
@@ -81,6 +79,61 @@ def test_config2_benchmarked_dcrnn_gradients_match_fp64_oracle(E):
     (ref * w.double()).sum().backward()
     assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward vs fp64 oracle")
     _grad_check(m, p64, 2e-4, 2e-4)
+
+
+@pytest.mark.gpu
+def test_config2_bench_batch_1024_sampled_against_the_oracle():
+    """The batch bench.py times: B = 1024 windows (211 968 rows per product: the split-bf16 kernels, the single
+    320-column feature-gradient product, two weight-gradient launches per stack).  Samples are independent
+    (dcrnn.py:363-369 replicates the graph block-diagonally), so the fp64 oracle on samples {0, 511, 1023} pins
+    (a) their forward outputs and (b) — with the loss weights zero elsewhere — every parameter gradient of the whole
+    batch; (c) linearity in the loss weights ties the full-batch gradient to its two halves at size."""
+    dev = torch.device("cuda:0")
+    g = load_golden("baseline_c2_batched_dcrnn64")
+    ei, ew, _ = BC.metrla(1515)
+    B, pick = 1024, [0, 511, 1023]
+    X = BC.rand((B, 12, 207, 2), 1201)
+    w = BC.rand((B, 12, 207, 64), 1202)
+    m = BatchedDCRNN(2, 64, 3)
+    m.load_state_dict(g["param"], strict=True)
+    m = m.to(dev)
+    Xd, eid, ewd = X.to(dev), ei.to(dev), ew.to(dev)
+
+    def grads(wmask):
+        m.zero_grad()
+        out = m(Xd, eid, ewd)
+        (out * wmask).sum().backward()
+        return out.detach(), [p.grad.clone() for p in m.parameters()]
+
+    w3 = torch.zeros_like(w)
+    w3[pick] = w[pick]
+    out, g3 = grads(w3.to(dev))
+    assert tuple(out.shape) == (B, 12, 207, 64) and bool(torch.isfinite(out).all())
+    p64 = _params64(g)
+    ref = F.batched_dcrnn(X[pick].double(), ei, ew.double(), p64)
+    (ref * w[pick].double()).sum().backward()
+    assert_close_with_nonfinite(out[pick], ref, ATOL, RTOL, "samples 0, 511, 1023 vs fp64 oracle")
+    for (name, _), got in zip(m.named_parameters(), g3):
+        r = p64[name].grad
+        assert_close_with_nonfinite(got, r, 2e-4 * float(r.abs().max() + 1), 2e-4, name)
+    # every sample is a valid forward (checksum-level): the batch is a stack of independent samples, so a sample's output
+    # may not depend on its position — samples 0 and 511 swapped give swapped outputs
+    Xs = Xd.clone()
+    Xs[0], Xs[511] = Xd[511], Xd[0]
+    with torch.no_grad():
+        outs = m(Xs, eid, ewd)
+    assert float((outs[0] - out[511]).abs().max()) <= 2e-6 and float((outs[511] - out[0]).abs().max()) <= 2e-6
+    # linearity of the gradient in the loss weights, at size
+    wd = w.to(dev)
+    lo, hi = wd.clone(), wd.clone()
+    lo[B // 2:] = 0
+    hi[:B // 2] = 0
+    _, gf = grads(wd)
+    _, gl = grads(lo)
+    _, gh = grads(hi)
+    for (name, _), a, b, c in zip(m.named_parameters(), gf, gl, gh):
+        scale = float(a.abs().max()) + 1.0
+        assert float((a - (b + c)).abs().max()) <= 3e-4 * scale, name
 
 
 def test_config2_oracle_reproduces_the_reference_fixture():

@@ -169,32 +169,48 @@ def _batched_dcrnn_backward_case(backend, x_grad, O):
 
 
 @pytest.mark.parametrize("n_nodes", [18, 330])
-def test_batched_dcrnn_lazy_output_is_the_same_function(backend, n_nodes):
-    """lazy_output=True returns the [B, T, N, O] states as a zero-copy permuted view and the package's Linear consumes
-    it in memory order: values and every gradient equal the contiguous default (both row layouts: LDS-resident
-    batch-major stack for the small graph, node-major rows for the large one)."""
+def test_batched_dcrnn_output_is_the_references_contiguous_layout(backend, n_nodes):
+    """BatchedDCRNN returns the reference's contiguous [B, T, N, O] tensor (torch.stack(outputs, dim=1), dcrnn.py:463-475);
+    every step's candidate-gate epilogue stores H_t straight into out[:, t] through a two-level row map and the backward
+    reads the gradient in that layout (both row layouts: LDS-resident batch-major stack for the small graph, node-major
+    rows for the large one).  Values and every gradient against the plain time-major sequence ([T, M, O] states + an
+    explicit transposition) — the same kernels without the row map."""
     from pytorch_geometric_temporal_amd.nn.conv import Linear
+    from pytorch_geometric_temporal_amd.nn.recurrent.dcrnn import _cell_weights
     from pytorch_geometric_temporal_amd import ops
     torch.manual_seed(1)
     B, T, fin, K = 3, 2, 2, 2
     O = 4 if n_nodes < 100 else 62            # 330 x 64 floats x 2 blocks > 160 KB of LDS: node-major path
     ei_np, ew_np = syn.sensor_graph(n_nodes, 5 * n_nodes, seed=4, symmetric=False)
     ei, ew = backend.t(ei_np), backend.t(ew_np)
-    assert bool(ops.slab_fits(ops.dconv_graph(ei, ew, n_nodes, strict_dense=False), fin + O, K)) == (n_nodes < 100)
+    g = ops.dconv_graph(ei, ew, n_nodes, strict_dense=False)
+    bm = n_nodes < 100
+    assert bool(ops.slab_fits(g, fin + O, K)) == bm
     X = torch.randn(B, T, n_nodes, fin)
     w = backend.t(torch.randn(B, T, n_nodes, 3))
     res = []
-    for lazy in (False, True):
+    for direct in (True, False):
         torch.manual_seed(2)
         rnn, head = BatchedDCRNN(fin, O, K).to(backend.device), Linear(O, 3).to(backend.device)
-        rnn.lazy_output = lazy
         Xd = backend.t(X).requires_grad_()
-        h = rnn(Xd, ei, ew)
-        assert h.shape == (B, T, n_nodes, O) and h.is_contiguous() != lazy
+        if direct:
+            h = rnn(Xd, ei, ew)
+            assert h.shape == (B, T, n_nodes, O) and h.is_contiguous()
+        else:
+            Wzr, bzr, Wh, bh = _cell_weights(rnn.conv_x_z, rnn.conv_x_r, rnn.conv_x_h)
+            H0 = torch.zeros(B * n_nodes, O, device=backend.device)
+            if bm:
+                Xs = Xd.permute(1, 0, 2, 3).reshape(T, B * n_nodes, fin)
+                h = ops.DCRNNSeqFunction.apply(Xs, H0, Wzr, bzr, Wh, bh, g, K, B, True)
+                h = h.view(T, B, n_nodes, O).permute(1, 0, 2, 3)
+            else:
+                Xs = Xd.permute(1, 2, 0, 3).reshape(T, n_nodes * B, fin)
+                h = ops.DCRNNSeqFunction.apply(Xs, H0, Wzr, bzr, Wh, bh, g, K, B)
+                h = h.view(T, n_nodes, B, O).permute(2, 0, 1, 3)
         y = head(torch.relu(h))
         assert y.shape == (B, T, n_nodes, 3)
         (y * w).sum().backward()
-        res.append((h.detach().clone(), y.detach().clone(), Xd.grad.clone(),
+        res.append((h.detach().clone().contiguous(), y.detach().clone().contiguous(), Xd.grad.clone(),
                     [p.grad.clone() for p in list(rnn.parameters()) + list(head.parameters())]))
     (h0, y0, gx0, gp0), (h1, y1, gx1, gp1) = res
     assert torch.equal(h0, h1) and torch.equal(y0, y1)
@@ -313,7 +329,7 @@ try:
     def test_fuzz_batched_dcrnn_host_paths_agree(emu_backend, data, K, B, T, O, need_x, monkeypatch):
         """The schedules behind BatchedDCRNN are interchangeable: batch-major rows with the LDS-resident stack vs
         node-major rows with one launch per hop, fused vs separate gate epilogues, hidden-columns-only vs full
-        stack gradient, zero-copy vs transposed output -- same outputs, same parameter and input gradients."""
+        stack gradient -- same outputs, same parameter and input gradients."""
         from pytorch_geometric_temporal_amd import ops
         n = data.draw(hst.integers(2, 7))
         pairs = hst.tuples(hst.integers(0, n - 1), hst.integers(0, n - 1))
@@ -334,17 +350,16 @@ try:
         for slab in (True, False):
             for fuse in (True, False):
                 for skip in (True, False):
-                    for lazy in (False, True):
-                        monkeypatch.setattr(ops, "slab_fits", real_fits if slab else (lambda *a, **k: False))
-                        monkeypatch.setattr(ops, "FUSE_GATE_EPILOGUES", fuse)
-                        monkeypatch.setattr(ops, "SKIP_INPUT_COLUMNS_WHEN_UNUSED", skip)
-                        m.lazy_output = lazy
-                        m.zero_grad()
-                        Xd = emu_backend.t(X).requires_grad_(need_x)
-                        out = m(Xd, emu_backend.t(ei), emu_backend.t(ew))
-                        (out * emu_backend.t(W)).sum().backward()
-                        results.append((out.detach().clone().contiguous(), Xd.grad.clone() if need_x else None,
-                                        [p.grad.clone() for p in m.parameters()]))
+                    monkeypatch.setattr(ops, "slab_fits", real_fits if slab else (lambda *a, **k: False))
+                    monkeypatch.setattr(ops, "FUSE_GATE_EPILOGUES", fuse)
+                    monkeypatch.setattr(ops, "SKIP_INPUT_COLUMNS_WHEN_UNUSED", skip)
+                    m.zero_grad()
+                    Xd = emu_backend.t(X).requires_grad_(need_x)
+                    out = m(Xd, emu_backend.t(ei), emu_backend.t(ew))
+                    assert out.is_contiguous()
+                    (out * emu_backend.t(W)).sum().backward()
+                    results.append((out.detach().clone(), Xd.grad.clone() if need_x else None,
+                                    [p.grad.clone() for p in m.parameters()]))
         base = results[0]
         for r in results[1:]:
             assert_close_with_nonfinite(r[0], base[0], 2e-5, 2e-5, "output")

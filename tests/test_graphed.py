@@ -13,7 +13,6 @@ class _Net(torch.nn.Module):
     def __init__(self, hidden):
         super().__init__()
         self.rnn = BatchedDCRNN(2, hidden, K=3)
-        self.rnn.lazy_output = True
         self.head = Linear(hidden, 2)
 
     def forward(self, X, ei, ew):

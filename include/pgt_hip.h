@@ -105,7 +105,7 @@ const char* pgt_build_target(void);
  * "gemm_tn_fullk", "gemm_small_fill", "gemm_bx" (split-bf16 kernel on the bf16 matrix pipe — fp32 operands as three
  * bf16 pieces, six piece products, fp32 accumulation; at least as close to the exact product as the fp32 kernels:
  * 1 where it wins / 2 at any size / 0 never), "gemm_bx_sym" (0: short-K products on its K-split variant).  Diffusion
- * stack: "slab_pairs".  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
+ * stack: "slab_pairs", "slab_split", "slab_wpc", "slab_threads" (pgt_dconv_stack_slab_plan).  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
  * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_ellw" (0: pgt_spmm_ellw_f32 runs
  * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
 int pgt_tune(const char* key, int value);
@@ -238,10 +238,16 @@ int pgt_sddmm_att_f32(const int32_t* rowptr, const int32_t* col, const float* va
  * in ONE launch.  Rows are BATCH-major (m = b*N + n): sample b's [N, C] block of stack segment s starts at
  * TS + s*seg_stride + b*N*C (unit column stride, row stride C).  Segment order: [T0 | T1o T1i | T2o T2i].
  * Reads segment 0, writes segments 1..2K-2:  T1 = P T0,  T2 = 2 P T1 - T0.   K = 2 or 3 (K < 2: no-op).
- * A sample's block and both operators must fit a CU's LDS: pgt_dconv_stack_slab_fits() != 0 (METR-LA, PeMS-BAY at
- * hidden <= 32, Chickenpox, EnglandCovid do); otherwise PGT_ERR_INVALID — run the hops with pgt_spmm_csr_f32.
+ * A sample's block — or a column window of it — and both operators must fit a CU's LDS: pgt_dconv_stack_slab_fits() != 0
+ * (METR-LA, PeMS-BAY, Chickenpox, EnglandCovid do); otherwise PGT_ERR_INVALID — run the hops with pgt_spmm_csr_f32.
  * nnz_o / nnz_i: number of slots of the two operators (host values; E for a DConv graph). */
 int pgt_dconv_stack_slab_fits(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i);
+/* The launch shape the two entry points below will use (reporting / tests): plan[0] = column windows per sample (the
+ * recursion is column-independent: a work item is sample x window, so that two or three workgroups share a CU and one's
+ * LDS gathers overlap another's HBM traffic; 1 with plan[3] = 0: the whole-sample kernels), plan[1] = workgroups per CU,
+ * plan[2] = threads per workgroup, plan[3] = tasks per thread; all 0 when the shape is not supported.  pgt_tune keys
+ * "slab_split" (1 = planned, 0 = whole-sample kernels only, n >= 2 = n windows), "slab_wpc", "slab_threads". */
+int pgt_dconv_stack_slab_plan(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i, int32_t* plan);
 int pgt_dconv_stack_slab_f32(const pgt_csr* fwd_o, const pgt_csr* fwd_i, int64_t nnz_o, int64_t nnz_i, int64_t N,
                              int64_t n_samples, int64_t C, int64_t K, float* TS, int64_t seg_stride,
                              pgt_stream_t stream);

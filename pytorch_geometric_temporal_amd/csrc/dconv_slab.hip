@@ -140,22 +140,22 @@ __device__ __forceinline__ T gather_row(const int* __restrict__ rp, const int2* 
   return acc;
 }
 
-// the same row sum for the two-pair element (`full`: the lane's second pair exists)
-template <typename T>
+// the same row sum for the two-pair element (`full`: the lane's second pair exists); U slots' LDS reads in flight
+template <typename T, int U = 4>
 __device__ __forceinline__ T gather_row_p2(const int* __restrict__ rp, const int2* __restrict__ cv,
                                         const float* __restrict__ buf, int r, int c, int C, bool full) {
   T acc = zero2(T());
   int q = rp[r];
   const int e = rp[r + 1];
-  for (; q + 4 <= e; q += 4) {
-    int2 s4[4];
-    T x[4];
+  for (; q + U <= e; q += U) {
+    int2 s4[U];
+    T x[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s4[u] = cv[q + u];
+    for (int u = 0; u < U; ++u) s4[u] = cv[q + u];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ldT(buf + s4[u].x * C + c, full, x[u]);
+    for (int u = 0; u < U; ++u) ldT(buf + s4[u].x * C + c, full, x[u]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = fma2(as_float(s4[u].y), x[u], acc);
+    for (int u = 0; u < U; ++u) acc = fma2(as_float(s4[u].y), x[u], acc);
   }
   for (; q < e; ++q) {
     const int2 s1 = cv[q];
@@ -542,20 +542,346 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_p2_kernel(SlabArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Column-split form (round 3).  The recursion acts on every column independently, so a sample's C columns are cut into
+// `nsplit` windows of whole column pairs and a work item is (sample, window): the LDS blocks shrink to [N][cw], two or
+// three workgroups fit a CU — one gathers out of LDS while another one's HBM loads and stores are in flight, which the
+// single resident 1024-thread workgroup of the unsplit kernels cannot overlap (0.36 - 0.40 of 8 TB/s) — and a batch of
+// 64 samples fills 128 - 192 CUs instead of 64.  Arithmetic per element is unchanged (same fmaf chain in slot order):
+// bit-identical to the unsplit kernels and to pgt_spmm_csr_f32.
+// Item order: w = ((sample / 8) * nsplit + part) * 8 + sample % 8, grid a multiple of 8 * nsplit: the windows of one
+// sample run at the same time on ONE XCD (block b -> XCD b % 8), so the 128-byte lines they share meet in that XCD's L2,
+// and a workgroup keeps its window for the whole launch (task tables are loop-invariant).
+struct SlabWin { int c0, cw; };
+__host__ __device__ inline SlabWin slab_window(int C, int nsplit, int part) {
+  const int cp = C / 2, base = cp / nsplit, rem = cp % nsplit;
+  SlabWin w;
+  w.c0 = 2 * (part * base + (part < rem ? part : rem));
+  w.cw = 2 * (base + (part < rem ? 1 : 0));
+  return w;
+}
+static size_t slab_w_lds_bytes(int64_t N, int64_t C, int nsplit, int64_t nnz_o, int64_t nnz_i) {
+  const int cwmax = slab_window((int)C, nsplit, 0).cw;
+  const size_t blk = (((size_t)N * cwmax * 4) + 15) & ~(size_t)15;
+  return 2 * blk + 2 * (size_t)(N + 1) * 4 + 2 * (size_t)(nnz_o + nnz_i) * 4;
+}
+
+template <int THREADS>
+__device__ __forceinline__ void stage_csr_t(const SlabArgs& a, const SlabLds& s, int tid) {
+  for (int i = tid; i <= a.N; i += THREADS) { s.rp_o[i] = a.rp_o[i]; s.rp_i[i] = a.rp_i[i]; }
+  for (int i = tid; i < a.nnz_o; i += THREADS) { int2 t; t.x = a.col_o[i]; t.y = as_int(a.val_o[i]); s.cv_o[i] = t; }
+  for (int i = tid; i < a.nnz_i; i += THREADS) { int2 t; t.x = a.col_i[i]; t.y = as_int(a.val_i[i]); s.cv_i[i] = t; }
+}
+
+// what every windowed kernel sets up: LDS carve-up with the widest window's pitch, this workgroup's window, its task table
+template <int THREADS, int MAXT>
+struct SlabTasks {
+  // one register per task: (row << 8) | (window-relative column / 2); offsets, the half-task flag and liveness are
+  // recomputed where they are used (a few integer operations against four registers per task held across the item loop)
+  int rc[MAXT];
+  int cw, c0, C, ntask, tid;
+  __device__ __forceinline__ void init(const SlabArgs& a, int nsplit, int tid_) {
+    const int part = ((int)blockIdx.x >> 3) % nsplit;
+    const SlabWin w = slab_window(a.C, nsplit, part);
+    cw = w.cw; c0 = w.c0; C = a.C; tid = tid_;
+    const int CV = (w.cw + 3) / 4;
+    ntask = a.N * CV;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int idx = tid + j * THREADS;
+      const int ic = idx < ntask ? idx : ntask - 1;
+      const int r = ic / CV, c = (ic - r * CV) * 4;
+      rc[j] = (r << 8) | (c >> 1);
+    }
+  }
+  __device__ __forceinline__ bool live(int j) const { return tid + j * THREADS < ntask; }
+  __device__ __forceinline__ int row(int j) const { return rc[j] >> 8; }
+  __device__ __forceinline__ int col(int j) const { return (rc[j] & 255) << 1; }
+  __device__ __forceinline__ bool full(int j) const { return col(j) + 2 < cw; }
+  __device__ __forceinline__ int goff(int j) const { return row(j) * C + c0 + col(j); }   // inside a sample's [N, C] block
+  __device__ __forceinline__ int loff(int j) const { return row(j) * cw + col(j); }       // inside the [N, cw] LDS block
+};
+__device__ __forceinline__ SlabLds carve_w(char* base, const SlabArgs& a, int nsplit) {
+  SlabLds s;
+  const int cwmax = slab_window(a.C, nsplit, 0).cw;
+  const size_t blk = (((size_t)a.N * cwmax * 4) + 15) & ~(size_t)15;
+  s.bufA = reinterpret_cast<float*>(base);
+  s.bufB = reinterpret_cast<float*>(base + blk);
+  char* p = base + 2 * blk;
+  s.cv_o = reinterpret_cast<int2*>(p); p += (size_t)a.nnz_o * 8;
+  s.cv_i = reinterpret_cast<int2*>(p); p += (size_t)a.nnz_i * 8;
+  s.rp_o = reinterpret_cast<int*>(p); p += (size_t)(a.N + 1) * 4;
+  s.rp_i = reinterpret_cast<int*>(p);
+  return s;
+}
+// sample of item w (item order above); false past the batch
+__device__ __forceinline__ bool slab_item_sample(const SlabArgs& a, int nsplit, int w, int& sample) {
+  sample = (w / (8 * nsplit)) * 8 + (w & 7);
+  return sample < a.n_samples;
+}
+
+template <int THREADS, int MAXT, int WPC>
+__global__ __launch_bounds__(THREADS, (WPC * THREADS + 255) / 256) void dconv_slab_fwd_w_kernel(SlabArgs a, int nsplit, int n_items) {
+  typedef P2 T;
+  constexpr int GU = WPC >= 3 ? 2 : 4;     // LDS reads in flight per gather: more resident wavefronts, fewer registers each
+  constexpr int LDS_BYTES = WPC == 1 ? 160 * 1024 : WPC == 2 ? 80 * 1024 : 54528;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const SlabLds s = carve_w(smem, a, nsplit);
+  const int tid = threadIdx.x;
+  stage_csr_t<THREADS>(a, s, tid);
+  SlabTasks<THREADS, MAXT> k;
+  k.init(a, nsplit, tid);
+  const int G = (int)gridDim.x;
+  T t0n[MAXT];
+  int sample;
+  if (slab_item_sample(a, nsplit, (int)blockIdx.x, sample)) {
+    const float* nb = a.TS + (int64_t)sample * a.N * a.C;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) ldT(nb + k.goff(j), k.full(j), t0n[j]);
+  }
+  for (int w = (int)blockIdx.x; w < n_items; w += G) {
+    if (!slab_item_sample(a, nsplit, w, sample)) break;     // (the last group of eight may be ragged; nothing follows it)
+    float* base = a.TS + (int64_t)sample * a.N * a.C;
+    T t0[MAXT], i1[MAXT];
+    PGT_LDS_BARRIER();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous item
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      t0[j] = t0n[j];
+      if (k.live(j)) stT(s.bufA + k.loff(j), k.full(j), t0[j]);
+    }
+    PGT_LDS_BARRIER();
+    int sn;
+    if (w + G < n_items && slab_item_sample(a, nsplit, w + G, sn)) {
+      const float* nb = a.TS + (int64_t)sn * a.N * a.C;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) ldT(nb + k.goff(j), k.full(j), t0n[j]);
+    }
+    // hop 1: T1o = P_o T0 (into bufB, which nobody reads during this hop), T1i = P_i T0 (registers: bufA is being read)
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (k.live(j)) {
+        const T o1 = gather_row_p2<T, GU>(s.rp_o, s.cv_o, s.bufA, k.row(j), k.col(j), k.cw, k.full(j));
+        i1[j] = gather_row_p2<T, GU>(s.rp_i, s.cv_i, s.bufA, k.row(j), k.col(j), k.cw, k.full(j));
+        stT(base + 1 * a.seg_stride + k.goff(j), k.full(j), o1);
+        stT(base + 2 * a.seg_stride + k.goff(j), k.full(j), i1[j]);
+        if (a.K >= 3) stT(s.bufB + k.loff(j), k.full(j), o1);
+      }
+    }
+    if (a.K < 3) continue;  // (uniform) K == 2: no second hop
+    PGT_LDS_BARRIER();        // everyone has finished reading T0 out of bufA
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+      if (k.live(j)) stT(s.bufA + k.loff(j), k.full(j), i1[j]);
+    PGT_LDS_BARRIER();
+    // hop 2: T2 = 2 P T1 - T0   (Tx_0 is never advanced in the reference, dcrnn.py:106)
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (k.live(j)) {
+        const T o2 = gather_row_p2<T, GU>(s.rp_o, s.cv_o, s.bufB, k.row(j), k.col(j), k.cw, k.full(j));
+        const T i2 = gather_row_p2<T, GU>(s.rp_i, s.cv_i, s.bufA, k.row(j), k.col(j), k.cw, k.full(j));
+        stT(base + 3 * a.seg_stride + k.goff(j), k.full(j), axpby(2.0f, o2, -1.0f, t0[j]));
+        stT(base + 4 * a.seg_stride + k.goff(j), k.full(j), axpby(2.0f, i2, -1.0f, t0[j]));
+      }
+    }
+  }
+}
+
+// backward, column-split; see dconv_slab_bwd_kernel for the recursion
+template <int THREADS, int MAXT, int WPC>
+__global__ __launch_bounds__(THREADS, (WPC * THREADS + 255) / 256) void dconv_slab_bwd_w_kernel(SlabArgs a, int nsplit, int n_items) {
+  typedef P2 T;
+  constexpr int GU = WPC >= 3 ? 2 : 4;     // LDS reads in flight per gather: more resident wavefronts, fewer registers each
+  constexpr int LDS_BYTES = WPC == 1 ? 160 * 1024 : WPC == 2 ? 80 * 1024 : 54528;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const SlabLds s = carve_w(smem, a, nsplit);
+  const int tid = threadIdx.x;
+  stage_csr_t<THREADS>(a, s, tid);
+  SlabTasks<THREADS, MAXT> k;
+  k.init(a, nsplit, tid);
+  const int G = (int)gridDim.x;
+  const int64_t lead = (a.K >= 3 ? 3 : 1) * a.seg_stride;
+  T pa[MAXT], pb[MAXT];
+  auto prefetch = [&](int bb) {
+    const float* nb = a.TS + (int64_t)bb * a.N * a.C + lead;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      ldT(nb + k.goff(j), k.full(j), pa[j]);
+      ldT(nb + a.seg_stride + k.goff(j), k.full(j), pb[j]);
+    }
+  };
+  int sample;
+  if (slab_item_sample(a, nsplit, (int)blockIdx.x, sample)) prefetch(sample);
+  for (int w = (int)blockIdx.x; w < n_items; w += G) {
+    if (!slab_item_sample(a, nsplit, w, sample)) break;
+    float* base = a.TS + (int64_t)sample * a.N * a.C;
+    PGT_LDS_BARRIER();
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (k.live(j)) {
+        stT(s.bufA + k.loff(j), k.full(j), pa[j]);
+        stT(s.bufB + k.loff(j), k.full(j), pb[j]);
+      }
+    }
+    PGT_LDS_BARRIER();
+    int sn;
+    if (w + G < n_items && slab_item_sample(a, nsplit, w + G, sn)) prefetch(sn);
+    if (a.K >= 3) {
+      T g1o[MAXT], g1i[MAXT];
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        ldT(base + 1 * a.seg_stride + k.goff(j), k.full(j), g1o[j]);
+        ldT(base + 2 * a.seg_stride + k.goff(j), k.full(j), g1i[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (k.live(j)) {
+          g1o[j] = axpby(2.0f, gather_row_p2<T, GU>(s.rp_o, s.cv_o, s.bufA, k.row(j), k.col(j), k.cw, k.full(j)), 1.0f, g1o[j]);
+          g1i[j] = axpby(2.0f, gather_row_p2<T, GU>(s.rp_i, s.cv_i, s.bufB, k.row(j), k.col(j), k.cw, k.full(j)), 1.0f, g1i[j]);
+        }
+      }
+      PGT_LDS_BARRIER();
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (k.live(j)) {
+          stT(s.bufA + k.loff(j), k.full(j), g1o[j]);
+          stT(s.bufB + k.loff(j), k.full(j), g1i[j]);
+        }
+      }
+      PGT_LDS_BARRIER();
+    }
+    T g0[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) ldT(base + k.goff(j), k.full(j), g0[j]);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (k.live(j)) {
+        const T po = gather_row_p2<T, GU>(s.rp_o, s.cv_o, s.bufA, k.row(j), k.col(j), k.cw, k.full(j));
+        const T pi = gather_row_p2<T, GU>(s.rp_i, s.cv_i, s.bufB, k.row(j), k.col(j), k.cw, k.full(j));
+        T g = g0[j];
+        if (a.K >= 3 && !a.folded) {  // G0 -= G2o + G2i (re-read: the unfolded form is the rare one)
+          T g2o, g2i;
+          ldT(base + 3 * a.seg_stride + k.goff(j), k.full(j), g2o);
+          ldT(base + 4 * a.seg_stride + k.goff(j), k.full(j), g2i);
+          g = add3(g, axpby(-1.0f, g2o, 0.0f, g2o), axpby(-1.0f, g2i, 0.0f, g2i));
+        }
+        stT(base + k.goff(j), k.full(j), add3(g, po, pi));
+      }
+    }
+  }
+}
+
 int g_slab_pairs = 2;   // pgt_tune("slab_pairs"): column pairs per lane of the LDS-resident stack kernels (1 | 2)
+int g_slab_split = 1;     // pgt_tune("slab_split"): 1 = column-split kernels where they apply (auto), 0 = never, n >= 2 = n windows
+int g_slab_threads = 0;   // pgt_tune("slab_threads"): 0 = planned, else the workgroup size of the column-split kernels (A/B)
+int g_slab_wpc = 0;       // pgt_tune("slab_wpc"): 0 = as many workgroups per CU as the LDS need allows (<= 3), else at most this
+
+struct SlabPlan { int nsplit, threads, maxt, wpc; };
+// Workgroup shapes the windowed kernels are instantiated for, per workgroups-per-CU class: the ones whose register need
+// (82 - 92 with two tasks per thread, 106 - 122 with three: scripts/kernel_resources.py) fits the class's wavefronts per
+// SIMD without spilling.
+static const int kSlabShapes[][3] = {   // {wpc, threads, maxt}
+    {1, 1024, 2}, {1, 1024, 3}, {2, 512, 2}, {2, 640, 2}, {2, 512, 3}, {3, 512, 2}};
+constexpr int kSlabNumShapes = (int)(sizeof(kSlabShapes) / sizeof(kSlabShapes[0]));
+static size_t slab_class_bytes(int wpc) { return wpc == 1 ? 160 * 1024 : wpc == 2 ? 80 * 1024 : 54528; }
+constexpr int SLAB_MAX_SPLIT = 8;
+static bool slab_w_applies(int64_t C) { return C % 2 == 0 && C >= 8; }
+
+// the smallest shape of class `wpc` (optionally of `threads` threads) with a slot for every task; -1 = none
+static int slab_pick_shape(int wpc, int64_t ntask, int threads) {
+  int best = -1;
+  for (int i = 0; i < kSlabNumShapes; ++i) {
+    if (kSlabShapes[i][0] != wpc || (threads > 0 && kSlabShapes[i][1] != threads)) continue;
+    const int64_t slots = (int64_t)kSlabShapes[i][1] * kSlabShapes[i][2];
+    if (slots < ntask) continue;
+    if (best < 0 || slots < (int64_t)kSlabShapes[best][1] * kSlabShapes[best][2]) best = i;
+  }
+  return best;
+}
+// plan for `nsplit` windows: the densest class (most workgroups per CU, at most wpc_cap) that holds the window's blocks
+// and has a shape for its tasks
+static bool slab_plan_for(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i, int nsplit, int wpc_cap, int threads, SlabPlan* p) {
+  if (nsplit < 1 || nsplit > C / 4) return false;                   // at least two column pairs (one full task) per window
+  const size_t need = slab_w_lds_bytes(N, C, nsplit, nnz_o, nnz_i);
+  const int64_t ntask = N * ((slab_window((int)C, nsplit, 0).cw + 3) / 4);
+  for (int wpc = wpc_cap < 3 ? wpc_cap : 3; wpc >= 1; --wpc) {
+    if (need > slab_class_bytes(wpc)) continue;
+    int i = slab_pick_shape(wpc, ntask, threads);
+    if (i < 0 && threads > 0) i = slab_pick_shape(wpc, ntask, 0);   // a forced size nothing fits: as planned
+    if (i < 0) continue;
+    if (p) { p->nsplit = nsplit; p->wpc = wpc; p->threads = kSlabShapes[i][1]; p->maxt = kSlabShapes[i][2]; }
+    return true;
+  }
+  return false;
+}
+// the fewest windows that put at least two workgroups on a CU; failing that, the fewest that run at all
+static bool slab_plan_auto(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i, int wpc_cap, int threads, SlabPlan* p) {
+  SlabPlan q;
+  for (int n = 1; n <= SLAB_MAX_SPLIT; ++n)
+    if (slab_plan_for(N, C, nnz_o, nnz_i, n, wpc_cap, threads, &q) && (q.wpc >= 2 || wpc_cap < 2)) { if (p) *p = q; return true; }
+  for (int n = 1; n <= SLAB_MAX_SPLIT; ++n)
+    if (slab_plan_for(N, C, nnz_o, nnz_i, n, wpc_cap, threads, p)) return true;
+  return false;
+}
+
+static bool slab_plan(const SlabArgs& a, SlabPlan* p) {
+  if (g_slab_split == 0 || g_slab_pairs < 2 || !slab_w_applies(a.C) || !pgt_aligned(a.TS, 8) || a.seg_stride % 2) return false;
+  const int cap = g_slab_wpc > 0 ? g_slab_wpc : 3;
+  if (g_slab_split >= 2 && slab_plan_for(a.N, a.C, a.nnz_o, a.nnz_i, g_slab_split, cap, g_slab_threads, p)) return true;
+  return slab_plan_auto(a.N, a.C, a.nnz_o, a.nnz_i, cap, g_slab_threads, p);
+}
+
+template <bool BWD>
+int launch_slab_w(const SlabArgs& a, const SlabPlan& p, pgt_stream_t stream) {
+  const int groups = (int)pgt_cdiv(a.n_samples, 8);
+  const int unit = 8 * p.nsplit;
+  const int n_items = groups * unit;
+#ifdef PGT_EMU
+  const int cus = 4;
+#else
+  const int cus = 256;
+#endif
+  int grid_n = (p.wpc * cus / unit) * unit;             // whole item groups: a workgroup keeps its window
+  if (grid_n < unit) grid_n = unit;
+  if (grid_n > n_items) grid_n = n_items;
+  dim3 grid((unsigned)grid_n), block((unsigned)p.threads);
+#define PGT_SLABW(W_, T_, M_)                                                                                   \
+  if (p.wpc == W_ && p.threads == T_ && p.maxt == M_) {                                                         \
+    if (BWD) PGT_LAUNCH((dconv_slab_bwd_w_kernel<T_, M_, W_>), grid, block, stream, a, p.nsplit, n_items);      \
+    else PGT_LAUNCH((dconv_slab_fwd_w_kernel<T_, M_, W_>), grid, block, stream, a, p.nsplit, n_items);          \
+    return pgt_check_launch(BWD ? "pgt_dconv_stack_slab_bwd_f32" : "pgt_dconv_stack_slab_f32");                 \
+  }
+  PGT_SLABW(1, 1024, 2) PGT_SLABW(1, 1024, 3) PGT_SLABW(2, 512, 2) PGT_SLABW(2, 640, 2) PGT_SLABW(2, 512, 3) PGT_SLABW(3, 512, 2)
+#undef PGT_SLABW
+  pgt_set_error("pgt_dconv_stack_slab: no kernel for the planned shape");
+  return PGT_ERR_INVALID;
+}
+
+
+// whole-sample kernels: both [N, C] blocks and the operators in one workgroup's LDS
+static bool slab_whole_ok(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i) {
+  const int V = (C % 2 == 0) ? 2 : 1;
+  return N * (C / V) <= (int64_t)MAXT_CAP * SLAB_THREADS &&        // (the narrowest element the launch may pick)
+         slab_lds_bytes(N, C, nnz_o, nnz_i) <= 160 * 1024;
+}
 
 int slab_supported(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i, size_t* bytes) {
   if (N <= 0 || C <= 0 || K < 2 || K > 3) return 0;
-  const int V = (C % 2 == 0) ? 2 : 1;
-  if (N * (C / V) > (int64_t)MAXT_CAP * SLAB_THREADS) return 0;   // (the narrowest element the launch may pick)
   if (nnz_o < 0 || nnz_i < 0 || nnz_o > (1 << 24) || nnz_i > (1 << 24)) return 0;
-  const size_t need = slab_lds_bytes(N, C, nnz_o, nnz_i);
-  if (bytes) *bytes = need;
-  return need <= 160 * 1024;
+  if (bytes) *bytes = slab_lds_bytes(N, C, nnz_o, nnz_i);
+  if (slab_whole_ok(N, C, nnz_o, nnz_i)) return 1;
+  // too large for one workgroup's LDS as a whole: the column-split kernels may still take it window by window
+  // (PeMS-BAY, 325 nodes, at hidden 64: two windows of 34 / 32 columns)
+  return g_slab_split != 0 && g_slab_pairs >= 2 && slab_w_applies(C) && slab_plan_auto(N, C, nnz_o, nnz_i, 3, 0, nullptr);
 }
 
 template <bool BWD>
 int launch_slab(const SlabArgs& a, size_t need, pgt_stream_t stream) {
+  SlabPlan plan;
+  if (slab_plan(a, &plan)) return launch_slab_w<BWD>(a, plan, stream);
+  if (!slab_whole_ok(a.N, a.C, a.nnz_o, a.nnz_i)) {
+    pgt_set_error("pgt_dconv_stack_slab: the block only fits column by column, which needs 8-byte aligned even-width segments");
+    return PGT_ERR_INVALID;
+  }
   int V = (a.C % 2 == 0 && pgt_aligned(a.TS, 8) && a.seg_stride % 2 == 0) ? 2 : 1;
   // two column pairs per lane (half the slot reads) while its register arrays fit: at most 4 tasks per thread
   if (V == 2 && g_slab_pairs >= 2 && a.C >= 8 && (int64_t)a.N * pgt_cdiv(a.C, 4) <= 4 * SLAB_THREADS) V = 4;
@@ -620,9 +946,26 @@ int slab_entry(bool bwd, const pgt_csr* o, const pgt_csr* i, int64_t nnz_o, int6
 }  // namespace
 
 void pgt_slab_set_pairs(int v) { g_slab_pairs = v; }
+void pgt_slab_set_split(int v) { g_slab_split = v; }
+void pgt_slab_set_threads(int v) { g_slab_threads = v; }
+void pgt_slab_set_wpc(int v) { g_slab_wpc = v; }
 
 extern "C" int pgt_dconv_stack_slab_fits(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i) {
   return slab_supported(N, C, K, nnz_o, nnz_i, nullptr);
+}
+
+extern "C" int pgt_dconv_stack_slab_plan(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i, int32_t* plan) {
+  PGT_REQUIRE(plan != nullptr, "pgt_dconv_stack_slab_plan: null pointer");
+  plan[0] = plan[1] = plan[2] = plan[3] = 0;
+  if (!slab_supported(N, C, K, nnz_o, nnz_i, nullptr)) return PGT_OK;
+  plan[0] = 1;                                            // whole-sample kernels: one 1024-thread workgroup per sample
+  plan[1] = 1; plan[2] = SLAB_THREADS; plan[3] = 0;
+  SlabArgs a{};
+  a.N = (int)N; a.C = (int)C; a.K = (int)K; a.nnz_o = (int)nnz_o; a.nnz_i = (int)nnz_i;
+  a.TS = nullptr; a.seg_stride = 0;                       // (alignment of the caller's buffers is checked at launch)
+  SlabPlan p;
+  if (slab_plan(a, &p)) { plan[0] = p.nsplit; plan[1] = p.wpc; plan[2] = p.threads; plan[3] = p.maxt; }
+  return PGT_OK;
 }
 
 extern "C" int pgt_dconv_stack_slab_f32(const pgt_csr* fwd_o, const pgt_csr* fwd_i, int64_t nnz_o, int64_t nnz_i,

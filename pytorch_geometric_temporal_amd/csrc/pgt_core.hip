@@ -60,6 +60,18 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_slab_set_pairs(value);
     return PGT_OK;
   }
+  if (strcmp(key, "slab_split") == 0) {
+    pgt_slab_set_split(value);
+    return PGT_OK;
+  }
+  if (strcmp(key, "slab_threads") == 0) {
+    pgt_slab_set_threads(value);
+    return PGT_OK;
+  }
+  if (strcmp(key, "slab_wpc") == 0) {
+    pgt_slab_set_wpc(value);
+    return PGT_OK;
+  }
   if (strcmp(key, "gemm_db64") == 0) {
     pgt_gemm_set_db64(value);
     return PGT_OK;

@@ -659,6 +659,15 @@ def slab_fits(g, C, K):
     return bool(lib._pgt_dconv_stack_slab_fits(g.N, int(C), int(K), g.E, g.E))
 
 
+def slab_plan(g, C, K):
+    """(column windows per sample, workgroups per CU, threads, tasks per thread) of the stack launch for this shape
+    (pgt_dconv_stack_slab_plan); (1, 1, 1024, 0) = the whole-sample kernels, zeros = not supported."""
+    lib = _lib.get_lib()
+    out = (ctypes.c_int32 * 4)()
+    lib.call("pgt_dconv_stack_slab_plan", g.N, int(C), int(K), g.E, g.E, out)
+    return tuple(out)
+
+
 def _slab_fwd(g, TS0, seg_stride, n_samples, C, K):
     """TS0: the [n_samples*N, C] block of segment 0 (batch-major rows); the other segments follow at seg_stride."""
     lib = _lib.get_lib()

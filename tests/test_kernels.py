@@ -676,14 +676,86 @@ def test_slab_stack_equals_per_hop_launches(backend, n, C, K, B, pairs, request)
 
 
 def test_slab_stack_rejects_what_does_not_fit_lds(backend):
+    lib = _lib.get_lib()
     ei, ew = syn.sensor_graph(600, 3000, seed=0, symmetric=False)
     g = ops.DConvGraph(backend.t(ei), backend.t(ew), 600)
-    assert not ops.slab_fits(g, 66, 3)        # 2 x 600 x 66 x 4 B > 160 KiB
     assert not ops.slab_fits(g, 4, 4)         # K > 3
     assert ops.slab_fits(g, 4, 3)
-    TS = backend.t(torch.zeros(5, 600, 66))
+    assert ops.slab_fits(g, 66, 3)            # 2 x 600 x 66 x 4 B > 160 KiB as a whole, but three column windows fit
+    lib.tune("slab_split", 0)
+    try:
+        assert not ops.slab_fits(g, 66, 3)    # ... which only the column-split kernels can use
+        TS = backend.t(torch.zeros(5, 600, 66))
+        with pytest.raises(_lib.PgtError, match="not supported"):
+            ops._slab_fwd(g, TS[0], 600 * 66, 1, 66, 3)
+    finally:
+        lib.tune("slab_split", 1)
+    ei, ew = syn.sensor_graph(2500, 12000, seed=0, symmetric=False)
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), 2500)
+    assert not ops.slab_fits(g, 66, 3)        # the operators alone (2 x 12 000 slots x 8 B) exceed the LDS
     with pytest.raises(_lib.PgtError, match="not supported"):
-        ops._slab_fwd(g, TS[0], 600 * 66, 1, 66, 3)
+        ops._slab_fwd(g, backend.t(torch.zeros(5, 2500, 66))[0], 2500 * 66, 1, 66, 3)
+
+
+@pytest.mark.parametrize("n,C,K,B", [(207, 66, 3, 11), (207, 64, 3, 9), (325, 66, 3, 3), (40, 24, 2, 19), (60, 10, 3, 17),
+                                     (600, 66, 3, 2)])
+def test_slab_stack_column_split_is_bit_identical(backend, n, C, K, B):
+    """The column-split kernels (work item = sample x column window; two or three workgroups per CU) against the
+    whole-sample kernels and the per-hop path: the recursion is column-independent and every element keeps its fmaf chain,
+    so the results are bit-identical — for every window count, ragged batches (B not a multiple of 8: the item order packs
+    eight samples per group), forced workgroup sizes, forward and both adjoint forms.  N = 325 and 600 at C = 66 only fit
+    column by column."""
+    lib = _lib.get_lib()
+    if backend.name == "emu":
+        B = min(B, 3) if n > 100 else B
+    ei, ew = syn.sensor_graph(n, 6 * n, seed=n, symmetric=False)
+    g = ops.DConvGraph(backend.t(ei), backend.t(ew), n)
+    S = 2 * K - 1
+    gen = torch.Generator().manual_seed(C + n)
+    X = torch.randn(B, n, C, generator=gen)
+    Gsrc = torch.randn(S, B * n, C, generator=gen)
+
+    def run(split, threads=0, wpc=0):
+        lib.tune("slab_split", split)
+        lib.tune("slab_threads", threads)
+        lib.tune("slab_wpc", wpc)
+        try:
+            if not ops.slab_fits(g, C, K):
+                return None
+            TS = torch.zeros(S, 1, B * n, C)
+            TS[0, 0] = X.reshape(B * n, C)
+            TS = backend.t(TS)
+            ops._slab_fwd(g, TS[0, 0], B * n * C, B, C, K)
+            outs = [TS.cpu()]
+            for folded in (False, True):
+                Gb = backend.t(Gsrc)
+                ops._slab_bwd(g, Gb[0], B * n * C, B, C, K, folded)
+                outs.append(Gb.cpu())
+            return outs
+        finally:
+            lib.tune("slab_split", 1)
+            lib.tune("slab_threads", 0)
+            lib.tune("slab_wpc", 0)
+
+    # reference: the per-hop launches on node-major rows
+    TSn = torch.zeros(S, 1, n * B, C)
+    TSn[0, 0] = X.permute(1, 0, 2).reshape(n * B, C)
+    TSn = backend.t(TSn)
+    ops._stack_fwd(g, TSn, 0, K, n)
+    ref_fwd = TSn.cpu().view(S, n, B, C).permute(0, 2, 1, 3).reshape(S, 1, B * n, C)
+    whole = run(0)
+    base = run(1)
+    assert base is not None
+    assert torch.equal(base[0], ref_fwd)
+    if whole is not None:
+        for a, b in zip(whole, base):
+            assert torch.equal(a, b)
+    for split, threads, wpc in ((2, 0, 0), (3, 0, 0), (4, 512, 0), (5, 0, 1), (8, 0, 2), (2, 1024, 1), (3, 640, 0)):
+        got = run(split, threads, wpc)
+        if got is None:
+            continue
+        for a, b in zip(got, base):
+            assert torch.equal(a, b), (split, threads, wpc)
 
 
 def test_batched_dcrnn_node_major_fallback_for_larger_graphs(backend):

@@ -169,7 +169,7 @@ def _batched_dcrnn_backward_case(backend, x_grad, O):
 
 
 @pytest.mark.parametrize("n_nodes", [18, 330])
-def test_batched_dcrnn_output_is_the_references_contiguous_layout(backend, n_nodes):
+def test_batched_dcrnn_output_is_the_references_contiguous_layout(backend, n_nodes, request):
     """BatchedDCRNN returns the reference's contiguous [B, T, N, O] tensor (torch.stack(outputs, dim=1), dcrnn.py:463-475);
     every step's candidate-gate epilogue stores H_t straight into out[:, t] through a two-level row map and the backward
     reads the gradient in that layout (both row layouts: LDS-resident batch-major stack for the small graph, node-major
@@ -180,12 +180,13 @@ def test_batched_dcrnn_output_is_the_references_contiguous_layout(backend, n_nod
     from pytorch_geometric_temporal_amd import ops
     torch.manual_seed(1)
     B, T, fin, K = 3, 2, 2, 2
-    O = 4 if n_nodes < 100 else 62            # 330 x 64 floats x 2 blocks > 160 KB of LDS: node-major path
+    O = 4 if n_nodes < 100 else 62
     ei_np, ew_np = syn.sensor_graph(n_nodes, 5 * n_nodes, seed=4, symmetric=False)
     ei, ew = backend.t(ei_np), backend.t(ew_np)
     g = ops.dconv_graph(ei, ew, n_nodes, strict_dense=False)
     bm = n_nodes < 100
-    assert bool(ops.slab_fits(g, fin + O, K)) == bm
+    if not bm:        # the larger graph on the node-major path (it would fit the LDS column by column)
+        request.getfixturevalue("monkeypatch").setattr(ops, "slab_fits", lambda *a, **k: False)
     X = torch.randn(B, T, n_nodes, fin)
     w = backend.t(torch.randn(B, T, n_nodes, 3))
     res = []

@@ -105,7 +105,7 @@ const char* pgt_build_target(void);
  * "gemm_tn_fullk", "gemm_small_fill", "gemm_bx" (split-bf16 kernel on the bf16 matrix pipe — fp32 operands as three
  * bf16 pieces, six piece products, fp32 accumulation; at least as close to the exact product as the fp32 kernels:
  * 1 where it wins / 2 at any size / 0 never), "gemm_bx_sym" (0: short-K products on its K-split variant).  Diffusion
- * stack: "slab_pairs", "slab_split", "slab_wpc", "slab_threads" (pgt_dconv_stack_slab_plan).  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
+ * stack: "slab_pairs", "slab_split", "slab_wpc", "slab_threads" (pgt_dconv_stack_slab_plan), "slab_quad" (0: 64 / 66-column blocks on the pair-layout kernels).  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
  * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_ellw" (0: pgt_spmm_ellw_f32 runs
  * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
 int pgt_tune(const char* key, int value);
@@ -242,12 +242,14 @@ int pgt_sddmm_att_f32(const int32_t* rowptr, const int32_t* col, const float* va
  * (METR-LA, PeMS-BAY, Chickenpox, EnglandCovid do); otherwise PGT_ERR_INVALID — run the hops with pgt_spmm_csr_f32.
  * nnz_o / nnz_i: number of slots of the two operators (host values; E for a DConv graph). */
 int pgt_dconv_stack_slab_fits(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i);
-/* The launch shape the two entry points below will use (reporting / tests): plan[0] = column windows per sample (the
- * recursion is column-independent: a work item is sample x window, so that two or three workgroups share a CU and one's
- * LDS gathers overlap another's HBM traffic; 1 with plan[3] = 0: the whole-sample kernels), plan[1] = workgroups per CU,
- * plan[2] = threads per workgroup, plan[3] = tasks per thread; all 0 when the shape is not supported.  pgt_tune keys
- * "slab_split" (1 = planned, 0 = whole-sample kernels only, n >= 2 = n windows), "slab_wpc", "slab_threads". */
-int pgt_dconv_stack_slab_plan(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i, int32_t* plan);
+/* The launch shape the two entry points below will use for a batch of n_samples (reporting / tests): plan[0] = column
+ * windows per sample (the recursion is column-independent: a work item is sample x window; used when the batch has fewer
+ * samples than the device has CUs — B = 64 at METR-LA shape: 20.7 -> 12.1 us — and for blocks that only fit the LDS
+ * column by column; 1 with plan[3] = 0: the whole-sample kernels, one 1024-thread workgroup per sample), plan[1] =
+ * workgroups per CU, plan[2] = threads per workgroup, plan[3] = tasks per thread; all 0 when the shape is not supported.
+ * pgt_tune keys "slab_split" (1 = planned, 0 = whole-sample kernels only, n >= 2 = n windows), "slab_wpc", "slab_threads". */
+int pgt_dconv_stack_slab_plan(int64_t N, int64_t n_samples, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i,
+                              int32_t* plan);
 int pgt_dconv_stack_slab_f32(const pgt_csr* fwd_o, const pgt_csr* fwd_i, int64_t nnz_o, int64_t nnz_i, int64_t N,
                              int64_t n_samples, int64_t C, int64_t K, float* TS, int64_t seg_stride,
                              pgt_stream_t stream);

@@ -80,7 +80,7 @@ PROTOTYPES = {
     "pgt_spmm_csr_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
     "pgt_sddmm_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_dconv_stack_slab_fits": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64]),
-    "pgt_dconv_stack_slab_plan": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_dconv_stack_slab_plan": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_dconv_stack_slab_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64,
                                          c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
     "pgt_dconv_stack_slab_bwd_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64,

@@ -11,6 +11,15 @@
 // Accumulation per output row is sequential in slot order, exactly like pgt_spmm_csr_f32 (deterministic).
 #include "pgt_common.h"
 
+// lab/slab_lab.hip defines these to take the kernels apart (phase timeline, stores / gathers / loads removed); in the
+// library they are compile-time constants
+#ifndef PGT_LAB_SKIP
+#define PGT_LAB_SKIP(bit) false
+#endif
+#ifndef PGT_TRACE_MARK2
+#define PGT_TRACE_MARK2(iter, slot) do { } while (0)
+#endif
+
 namespace {
 
 struct SlabArgs {
@@ -385,9 +394,11 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_p2_kernel(SlabArg
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) ldT(nb + OFF(j), FULL(j), t0n[j]);
   }
-  for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
+  int it_ = 0;
+  for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x, ++it_) {
     float* base = a.TS + (int64_t)b * a.N * a.C;
     T t0[MAXT], i1[MAXT];
+    PGT_TRACE_MARK2(it_, 0);
     PGT_LDS_BARRIER();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous sample
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
@@ -395,7 +406,8 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_p2_kernel(SlabArg
       if (LIVE(j)) stT(s.bufA + OFF(j), FULL(j), t0[j]);
     }
     PGT_LDS_BARRIER();
-    if (b + (int)gridDim.x < a.n_samples) {
+    PGT_TRACE_MARK2(it_, 1);
+    if (b + (int)gridDim.x < a.n_samples && !PGT_LAB_SKIP(4)) {
       const float* nb = a.TS + (int64_t)(b + (int)gridDim.x) * a.N * a.C;
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) ldT(nb + OFF(j), FULL(j), t0n[j]);
@@ -407,31 +419,45 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_p2_kernel(SlabArg
       if (LIVE(j)) {
         const int idx = tid + j * SLAB_THREADS;
         const int r = idx / CV, c = (idx - r * CV) * V;
-        const T o1 = gather_row_p2<T>(s.rp_o, s.cv_o, s.bufA, r, c, a.C, FULL(j));
-        i1[j] = gather_row_p2<T>(s.rp_i, s.cv_i, s.bufA, r, c, a.C, FULL(j));
-        stT(base + 1 * a.seg_stride + OFF(j), FULL(j), o1);
-        stT(base + 2 * a.seg_stride + OFF(j), FULL(j), i1[j]);
+        T o1 = t0[j];
+        i1[j] = t0[j];
+        if (!PGT_LAB_SKIP(2)) {
+          o1 = gather_row_p2<T>(s.rp_o, s.cv_o, s.bufA, r, c, a.C, FULL(j));
+          i1[j] = gather_row_p2<T>(s.rp_i, s.cv_i, s.bufA, r, c, a.C, FULL(j));
+        }
+        if (!PGT_LAB_SKIP(1)) {
+          stT(base + 1 * a.seg_stride + OFF(j), FULL(j), o1);
+          stT(base + 2 * a.seg_stride + OFF(j), FULL(j), i1[j]);
+        }
         if (a.K >= 3) stT(s.bufB + OFF(j), FULL(j), o1);
       }
     }
+    PGT_TRACE_MARK2(it_, 2);
     if (a.K < 3) continue;  // (uniform) K == 2: no second hop
     PGT_LDS_BARRIER();        // everyone has finished reading T0 out of bufA
 #pragma unroll
     for (int j = 0; j < MAXT; ++j)
       if (LIVE(j)) stT(s.bufA + OFF(j), FULL(j), i1[j]);
     PGT_LDS_BARRIER();
+    PGT_TRACE_MARK2(it_, 3);
     // hop 2: T2 = 2 P T1 - T0   (Tx_0 is never advanced in the reference, dcrnn.py:106)
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       if (LIVE(j)) {
         const int idx = tid + j * SLAB_THREADS;
         const int r = idx / CV, c = (idx - r * CV) * V;
-        const T o2 = gather_row_p2<T>(s.rp_o, s.cv_o, s.bufB, r, c, a.C, FULL(j));
-        const T i2 = gather_row_p2<T>(s.rp_i, s.cv_i, s.bufA, r, c, a.C, FULL(j));
-        stT(base + 3 * a.seg_stride + OFF(j), FULL(j), axpby(2.0f, o2, -1.0f, t0[j]));
-        stT(base + 4 * a.seg_stride + OFF(j), FULL(j), axpby(2.0f, i2, -1.0f, t0[j]));
+        T o2 = t0[j], i2 = t0[j];
+        if (!PGT_LAB_SKIP(2)) {
+          o2 = gather_row_p2<T>(s.rp_o, s.cv_o, s.bufB, r, c, a.C, FULL(j));
+          i2 = gather_row_p2<T>(s.rp_i, s.cv_i, s.bufA, r, c, a.C, FULL(j));
+        }
+        if (!PGT_LAB_SKIP(1)) {
+          stT(base + 3 * a.seg_stride + OFF(j), FULL(j), axpby(2.0f, o2, -1.0f, t0[j]));
+          stT(base + 4 * a.seg_stride + OFF(j), FULL(j), axpby(2.0f, i2, -1.0f, t0[j]));
+        }
       }
     }
+    PGT_TRACE_MARK2(it_, 4);
   }
 }
 
@@ -540,6 +566,295 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_p2_kernel(SlabArg
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Quad layout (round 3): whole-sample kernels for C = 64 + E columns (E = 0: the hidden-columns-only backward stack;
+// E = 2: [X_t, H] of the benchmarked model).  lab/slab_lab.hip on the kernels above at B = 1024: 88 us whole, 52 us with the
+// gathers replaced by copies, 41 us stores only — the LDS gathers (~36 us) ADD to the memory time, and they run at a
+// quarter of the LDS rate: a 66-float row is 16.5 float2 pairs, so a 32-lane `ds_read_b64` group straddles two source
+// rows whose 264-byte pitch puts them on the same banks (2-way conflict on every feature read), and a slot costs three
+// LDS instructions per lane (slot, two pairs).  Here the 64 hidden columns of the block live in LDS with a 256-byte
+// pitch and a lane owns one 16-byte quad of them: ONE `ds_read_b128` per slot, and the hardware's b128 lane groups
+// ({0-3, 12-15, 20-27}, ...) then cover all 64 banks once whatever rows the lanes point at — conflict-free by
+// construction.  The E leading columns (the input features) sit in a side block of one padded quad per row and are the
+// 17th task of a row, so that every lane executes the same instruction stream.  Same fmaf chain per element as the
+// kernels above: bit-identical results.
+template <bool G4>
+__device__ __forceinline__ void ldQ(const float* p, bool main_, pgt_f4& v) {
+  if constexpr (G4) {
+    v = *reinterpret_cast<const pgt_f4*>(p);
+  } else {
+    const float2 a = *reinterpret_cast<const float2*>(p);
+    const float2 b = *reinterpret_cast<const float2*>(p + (main_ ? 2 : 0));
+    v = pgt_mk4(a.x, a.y, b.x, b.y);
+  }
+}
+template <bool G4>
+__device__ __forceinline__ void stQ(float* p, bool main_, pgt_f4 v) {
+  if constexpr (G4) {
+    *reinterpret_cast<pgt_f4*>(p) = v;
+  } else {
+    *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
+    if (main_) *reinterpret_cast<float2*>(p + 2) = make_float2(v.z, v.w);
+  }
+}
+__device__ __forceinline__ pgt_f4 fma4(float w, pgt_f4 x, pgt_f4 acc) {
+  return pgt_mk4(fmaf(w, x.x, acc.x), fmaf(w, x.y, acc.y), fmaf(w, x.z, acc.z), fmaf(w, x.w, acc.w));
+}
+__device__ __forceinline__ pgt_f4 axpby4(float al, pgt_f4 a, float be, pgt_f4 b) {
+  return pgt_mk4(axpby(al, a.x, be, b.x), axpby(al, a.y, be, b.y), axpby(al, a.z, be, b.z), axpby(al, a.w, be, b.w));
+}
+__device__ __forceinline__ pgt_f4 add34(pgt_f4 a, pgt_f4 b, pgt_f4 c) {
+  return pgt_mk4(add3(a.x, b.x, c.x), add3(a.y, b.y, c.y), add3(a.z, b.z, c.z), add3(a.w, b.w, c.w));
+}
+// row sum over the slots of row r: x = the quad at float offset `qoff + source * pitch` of the block; U slots in flight
+template <int U = 4>
+__device__ __forceinline__ pgt_f4 gather_q(const int* __restrict__ rp, const int2* __restrict__ cv,
+                                           const float* __restrict__ blk, int r, int qoff, int pitch) {
+  pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+  int q = rp[r];
+  const int e = rp[r + 1];
+  for (; q + U <= e; q += U) {
+    int2 s4[U];
+    pgt_f4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s4[u] = cv[q + u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const pgt_f4*>(blk + qoff + s4[u].x * pitch);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = fma4(as_float(s4[u].y), x[u], acc);
+  }
+  for (; q < e; ++q) {
+    const int2 s1 = cv[q];
+    acc = fma4(as_float(s1.y), *reinterpret_cast<const pgt_f4*>(blk + qoff + s1.x * pitch), acc);
+  }
+  return acc;
+}
+// floats of one LDS block: [N][64] hidden quads + (E > 0) one padded quad per row for the leading columns
+__host__ __device__ inline size_t slab_q_block_floats(int64_t N, int E) { return (size_t)N * 64 + (E > 0 ? (size_t)N * 4 : 0); }
+static size_t slab_q_lds_bytes(int64_t N, int E, int64_t nnz_o, int64_t nnz_i) {
+  return 2 * slab_q_block_floats(N, E) * 4 + 2 * (size_t)(N + 1) * 4 + 2 * (size_t)(nnz_o + nnz_i) * 4;
+}
+__device__ __forceinline__ SlabLds carve_q(char* base, const SlabArgs& a, int E) {
+  SlabLds s;
+  const size_t blk = slab_q_block_floats(a.N, E) * 4;
+  s.bufA = reinterpret_cast<float*>(base);
+  s.bufB = reinterpret_cast<float*>(base + blk);
+  char* p = base + 2 * blk;
+  s.cv_o = reinterpret_cast<int2*>(p); p += (size_t)a.nnz_o * 8;
+  s.cv_i = reinterpret_cast<int2*>(p); p += (size_t)a.nnz_i * 8;
+  s.rp_o = reinterpret_cast<int*>(p); p += (size_t)(a.N + 1) * 4;
+  s.rp_i = reinterpret_cast<int*>(p);
+  return s;
+}
+// task tid + j * 1024 of a sample: row, kind, the float offsets it touches
+template <int E, int MAXT>
+struct SlabQTasks {
+  int rj[MAXT];     // (row << 5) | task-in-row (0 .. 16)
+  int N, C, ntask, tid;
+  static constexpr int TPR = 16 + (E > 0 ? 1 : 0);
+  __device__ __forceinline__ void init(const SlabArgs& a, int tid_) {
+    N = a.N; C = a.C; tid = tid_; ntask = a.N * TPR;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int idx = tid + j * SLAB_THREADS, ic = idx < ntask ? idx : ntask - 1;
+      const int r = ic / TPR;
+      rj[j] = (r << 5) | (ic - r * TPR);
+    }
+  }
+  __device__ __forceinline__ bool live(int j) const { return tid + j * SLAB_THREADS < ntask; }
+  __device__ __forceinline__ int row(int j) const { return rj[j] >> 5; }
+  __device__ __forceinline__ bool main_(int j) const { return E == 0 || (rj[j] & 31) != 0; }      // task 0 of a row: the E leading columns
+  __device__ __forceinline__ int quad(int j) const { return (rj[j] & 31) - (E > 0 ? 1 : 0); }
+  __device__ __forceinline__ int goff(int j) const { return row(j) * C + (main_(j) ? E + 4 * quad(j) : 0); }   // in the sample's [N, C] block
+  __device__ __forceinline__ int qoff(int j) const { return main_(j) ? 4 * quad(j) : N * 64; }               // quad column inside an LDS block
+  __device__ __forceinline__ int pitch(int j) const { return main_(j) ? 64 : 4; }
+  __device__ __forceinline__ int loff(int j) const { return qoff(j) + row(j) * pitch(j); }
+};
+
+// forward: segments [T0 | T1o T1i | T2o T2i]; K = 2 or 3 (see dconv_slab_fwd_kernel)
+template <int E, bool G4, int MAXT>
+__global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_q_kernel(SlabArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
+  const SlabLds s = carve_q(smem, a, E);
+  const int tid = threadIdx.x;
+  stage_csr(a, s, tid);
+  SlabQTasks<E, MAXT> k;
+  k.init(a, tid);
+  pgt_f4 t0n[MAXT];
+  if ((int)blockIdx.x < a.n_samples) {
+    const float* nb = a.TS + (int64_t)blockIdx.x * a.N * a.C;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) ldQ<G4>(nb + k.goff(j), k.main_(j), t0n[j]);
+  }
+  int it_ = 0;
+  for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x, ++it_) {
+    float* base = a.TS + (int64_t)b * a.N * a.C;
+    pgt_f4 t0[MAXT], i1[MAXT];
+    PGT_TRACE_MARK2(it_, 0);
+    PGT_LDS_BARRIER();  // CSR staged (first pass) / every lane done with the LDS blocks of the previous sample
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      t0[j] = t0n[j];
+      if (k.live(j)) *reinterpret_cast<pgt_f4*>(s.bufA + k.loff(j)) = t0[j];
+    }
+    PGT_LDS_BARRIER();
+    PGT_TRACE_MARK2(it_, 1);
+    if (b + (int)gridDim.x < a.n_samples && !PGT_LAB_SKIP(4)) {
+      const float* nb = a.TS + (int64_t)(b + (int)gridDim.x) * a.N * a.C;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) ldQ<G4>(nb + k.goff(j), k.main_(j), t0n[j]);
+    }
+    // hop 1: T1o = P_o T0 (into bufB, which nobody reads during this hop), T1i = P_i T0 (registers: bufA is being read)
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (k.live(j)) {
+        pgt_f4 o1 = t0[j];
+        i1[j] = t0[j];
+        if (!PGT_LAB_SKIP(2)) {
+          o1 = gather_q(s.rp_o, s.cv_o, s.bufA, k.row(j), k.qoff(j), k.pitch(j));
+          i1[j] = gather_q(s.rp_i, s.cv_i, s.bufA, k.row(j), k.qoff(j), k.pitch(j));
+        }
+        if (!PGT_LAB_SKIP(1)) {
+          stQ<G4>(base + 1 * a.seg_stride + k.goff(j), k.main_(j), o1);
+          stQ<G4>(base + 2 * a.seg_stride + k.goff(j), k.main_(j), i1[j]);
+        }
+        if (a.K >= 3) *reinterpret_cast<pgt_f4*>(s.bufB + k.loff(j)) = o1;
+      }
+    }
+    PGT_TRACE_MARK2(it_, 2);
+    if (a.K < 3) continue;  // (uniform) K == 2: no second hop
+    PGT_LDS_BARRIER();        // everyone has finished reading T0 out of bufA
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+      if (k.live(j)) *reinterpret_cast<pgt_f4*>(s.bufA + k.loff(j)) = i1[j];
+    PGT_LDS_BARRIER();
+    PGT_TRACE_MARK2(it_, 3);
+    // hop 2: T2 = 2 P T1 - T0   (Tx_0 is never advanced in the reference, dcrnn.py:106)
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (k.live(j)) {
+        pgt_f4 o2 = t0[j], i2 = t0[j];
+        if (!PGT_LAB_SKIP(2)) {
+          o2 = gather_q(s.rp_o, s.cv_o, s.bufB, k.row(j), k.qoff(j), k.pitch(j));
+          i2 = gather_q(s.rp_i, s.cv_i, s.bufA, k.row(j), k.qoff(j), k.pitch(j));
+        }
+        if (!PGT_LAB_SKIP(1)) {
+          stQ<G4>(base + 3 * a.seg_stride + k.goff(j), k.main_(j), axpby4(2.0f, o2, -1.0f, t0[j]));
+          stQ<G4>(base + 4 * a.seg_stride + k.goff(j), k.main_(j), axpby4(2.0f, i2, -1.0f, t0[j]));
+        }
+      }
+    }
+    PGT_TRACE_MARK2(it_, 4);
+  }
+}
+
+// backward on the TRANSPOSED operators; see dconv_slab_bwd_kernel
+template <int E, bool G4, int MAXT>
+__global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_q_kernel(SlabArgs a) {
+  constexpr int GU = (MAXT >= 4 && E > 0) ? 2 : 4;      // (the input-gradient form holds five register blocks: fewer reads in flight)
+  __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
+  const SlabLds s = carve_q(smem, a, E);
+  const int tid = threadIdx.x;
+  stage_csr(a, s, tid);
+  SlabQTasks<E, MAXT> k;
+  k.init(a, tid);
+  const int64_t lead = (a.K >= 3 ? 3 : 1) * a.seg_stride;
+  pgt_f4 pa[MAXT], pb[MAXT];
+  auto prefetch = [&](int bb) {
+    const float* nb = a.TS + (int64_t)bb * a.N * a.C + lead;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      ldQ<G4>(nb + k.goff(j), k.main_(j), pa[j]);
+      ldQ<G4>(nb + a.seg_stride + k.goff(j), k.main_(j), pb[j]);
+    }
+  };
+  if ((int)blockIdx.x < a.n_samples) prefetch((int)blockIdx.x);
+  for (int b = (int)blockIdx.x; b < a.n_samples; b += (int)gridDim.x) {
+    float* base = a.TS + (int64_t)b * a.N * a.C;
+    PGT_LDS_BARRIER();
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (k.live(j)) {
+        *reinterpret_cast<pgt_f4*>(s.bufA + k.loff(j)) = pa[j];
+        *reinterpret_cast<pgt_f4*>(s.bufB + k.loff(j)) = pb[j];
+      }
+    }
+    PGT_LDS_BARRIER();
+    if (b + (int)gridDim.x < a.n_samples) prefetch(b + (int)gridDim.x);
+    if (a.K >= 3) {
+      pgt_f4 g1o[MAXT], g1i[MAXT];
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        ldQ<G4>(base + 1 * a.seg_stride + k.goff(j), k.main_(j), g1o[j]);
+        ldQ<G4>(base + 2 * a.seg_stride + k.goff(j), k.main_(j), g1i[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (k.live(j)) {
+          g1o[j] = axpby4(2.0f, gather_q<GU>(s.rp_o, s.cv_o, s.bufA, k.row(j), k.qoff(j), k.pitch(j)), 1.0f, g1o[j]);
+          g1i[j] = axpby4(2.0f, gather_q<GU>(s.rp_i, s.cv_i, s.bufB, k.row(j), k.qoff(j), k.pitch(j)), 1.0f, g1i[j]);
+        }
+      }
+      PGT_LDS_BARRIER();
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (k.live(j)) {
+          *reinterpret_cast<pgt_f4*>(s.bufA + k.loff(j)) = g1o[j];
+          *reinterpret_cast<pgt_f4*>(s.bufB + k.loff(j)) = g1i[j];
+        }
+      }
+      PGT_LDS_BARRIER();
+    }
+    pgt_f4 g0[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) ldQ<G4>(base + k.goff(j), k.main_(j), g0[j]);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      if (k.live(j)) {
+        const pgt_f4 po = gather_q<GU>(s.rp_o, s.cv_o, s.bufA, k.row(j), k.qoff(j), k.pitch(j));
+        const pgt_f4 pi = gather_q<GU>(s.rp_i, s.cv_i, s.bufB, k.row(j), k.qoff(j), k.pitch(j));
+        pgt_f4 g = g0[j];
+        if (a.K >= 3 && !a.folded) {  // G0 -= G2o + G2i (re-read: the unfolded form is the rare one)
+          pgt_f4 g2o, g2i;
+          ldQ<G4>(base + 3 * a.seg_stride + k.goff(j), k.main_(j), g2o);
+          ldQ<G4>(base + 4 * a.seg_stride + k.goff(j), k.main_(j), g2i);
+          g = add34(g, axpby4(-1.0f, g2o, 0.0f, g2o), axpby4(-1.0f, g2i, 0.0f, g2i));
+        }
+        stQ<G4>(base + k.goff(j), k.main_(j), add34(g, po, pi));
+      }
+    }
+  }
+}
+
+int g_slab_pairs = 2;   // pgt_tune("slab_pairs"): column pairs per lane of the LDS-resident stack kernels (1 | 2)
+int g_slab_quad = 1;      // pgt_tune("slab_quad"): 0 = C = 64 / 66 blocks on the pair-layout kernels (A/B)
+// the quad-layout kernels take C = 64 (16-byte aligned segments) or C = 66 (8-byte aligned), at most 4 tasks per thread
+static int slab_quad_kind(const SlabArgs& a) {
+  if (!g_slab_quad || g_slab_pairs < 2) return 0;
+  const int E = a.C - 64;
+  if (E != 0 && E != 2) return 0;
+  if ((int64_t)a.N * (16 + (E > 0)) > 4 * SLAB_THREADS) return 0;
+  if (slab_q_lds_bytes(a.N, E, a.nnz_o, a.nnz_i) > 160 * 1024) return 0;
+  if (E == 0) return (pgt_aligned(a.TS, 16) && a.seg_stride % 4 == 0) ? 1 : 0;
+  return (pgt_aligned(a.TS, 8) && a.seg_stride % 2 == 0) ? 2 : 0;
+}
+template <bool BWD>
+int launch_slab_q(const SlabArgs& a, int kind, pgt_stream_t stream) {
+  const int tpr = kind == 1 ? 16 : 17;
+  const int tpt = (int)pgt_cdiv((int64_t)a.N * tpr, SLAB_THREADS);
+  const int nblk = a.n_samples < 256 ? a.n_samples : 256;
+  dim3 grid((unsigned)nblk), block(SLAB_THREADS);
+#define PGT_SLABQ(E_, G4_, T_)                                                                        \
+  do {                                                                                                \
+    if (BWD) PGT_LAUNCH((dconv_slab_bwd_q_kernel<E_, G4_, T_>), grid, block, stream, a);              \
+    else PGT_LAUNCH((dconv_slab_fwd_q_kernel<E_, G4_, T_>), grid, block, stream, a);                  \
+  } while (0)
+  if (kind == 1) { if (tpt <= 2) PGT_SLABQ(0, true, 2); else PGT_SLABQ(0, true, 4); }
+  else { if (tpt <= 2) PGT_SLABQ(2, false, 2); else PGT_SLABQ(2, false, 4); }
+#undef PGT_SLABQ
+  return pgt_check_launch(BWD ? "pgt_dconv_stack_slab_bwd_f32" : "pgt_dconv_stack_slab_f32");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -770,7 +1085,6 @@ __global__ __launch_bounds__(THREADS, (WPC * THREADS + 255) / 256) void dconv_sl
   }
 }
 
-int g_slab_pairs = 2;   // pgt_tune("slab_pairs"): column pairs per lane of the LDS-resident stack kernels (1 | 2)
 int g_slab_split = 1;     // pgt_tune("slab_split"): 1 = column-split kernels where they apply (auto), 0 = never, n >= 2 = n windows
 int g_slab_threads = 0;   // pgt_tune("slab_threads"): 0 = planned, else the workgroup size of the column-split kernels (A/B)
 int g_slab_wpc = 0;       // pgt_tune("slab_wpc"): 0 = as many workgroups per CU as the LDS need allows (<= 3), else at most this
@@ -823,11 +1137,39 @@ static bool slab_plan_auto(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i, i
   return false;
 }
 
+// whole-sample kernels: both [N, C] blocks and the operators in one workgroup's LDS
+static bool slab_whole_ok(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i) {
+  const int V = (C % 2 == 0) ? 2 : 1;
+  return N * (C / V) <= (int64_t)MAXT_CAP * SLAB_THREADS &&        // (the narrowest element the launch may pick)
+         slab_lds_bytes(N, C, nnz_o, nnz_i) <= 160 * 1024;
+}
+#ifdef PGT_EMU
+constexpr int SLAB_CUS = 4;
+#else
+constexpr int SLAB_CUS = 256;
+#endif
+
+// Measured on MI355X (scripts/slab_probe.py, METR-LA shape): with at least a sample per CU the whole-sample kernels win
+// (B = 1024, C = 66 forward: 90 us against 103 - 123 us for every windowed shape: a window is an 88-byte piece of each
+// 264-byte row, its 128-byte lines are fetched by two or three workgroups, and two resident workgroups did NOT overlap
+// their phases usefully); with fewer samples than CUs the windows are what fills the chip (B = 64: 20.7 -> 12.1 us with
+// four windows on 1024-thread workgroups, 13.2 with three, 14.6 with eight).  So: as many windows as idle CUs per sample.
 static bool slab_plan(const SlabArgs& a, SlabPlan* p) {
   if (g_slab_split == 0 || g_slab_pairs < 2 || !slab_w_applies(a.C) || !pgt_aligned(a.TS, 8) || a.seg_stride % 2) return false;
   const int cap = g_slab_wpc > 0 ? g_slab_wpc : 3;
-  if (g_slab_split >= 2 && slab_plan_for(a.N, a.C, a.nnz_o, a.nnz_i, g_slab_split, cap, g_slab_threads, p)) return true;
-  return slab_plan_auto(a.N, a.C, a.nnz_o, a.nnz_i, cap, g_slab_threads, p);
+  if (g_slab_split >= 2) {
+    if (slab_plan_for(a.N, a.C, a.nnz_o, a.nnz_i, g_slab_split, cap, g_slab_threads, p)) return true;
+    return slab_plan_auto(a.N, a.C, a.nnz_o, a.nnz_i, cap, g_slab_threads, p);
+  }
+  if (!slab_whole_ok(a.N, a.C, a.nnz_o, a.nnz_i))                    // only fits column by column
+    return slab_plan_auto(a.N, a.C, a.nnz_o, a.nnz_i, cap, g_slab_threads, p);
+  if (2 * (int64_t)a.n_samples > SLAB_CUS) return false;
+  int want = SLAB_CUS / (a.n_samples > 0 ? a.n_samples : 1);
+  if (want > SLAB_MAX_SPLIT) want = SLAB_MAX_SPLIT;
+  for (int n = want; n >= 2; --n)                                     // one workgroup per CU: the 1024-thread shapes first
+    if (slab_plan_for(a.N, a.C, a.nnz_o, a.nnz_i, n, g_slab_wpc > 0 ? cap : 1, g_slab_threads, p) ||
+        slab_plan_for(a.N, a.C, a.nnz_o, a.nnz_i, n, cap, g_slab_threads, p)) return true;
+  return false;
 }
 
 template <bool BWD>
@@ -835,12 +1177,7 @@ int launch_slab_w(const SlabArgs& a, const SlabPlan& p, pgt_stream_t stream) {
   const int groups = (int)pgt_cdiv(a.n_samples, 8);
   const int unit = 8 * p.nsplit;
   const int n_items = groups * unit;
-#ifdef PGT_EMU
-  const int cus = 4;
-#else
-  const int cus = 256;
-#endif
-  int grid_n = (p.wpc * cus / unit) * unit;             // whole item groups: a workgroup keeps its window
+  int grid_n = (p.wpc * SLAB_CUS / unit) * unit;             // whole item groups: a workgroup keeps its window
   if (grid_n < unit) grid_n = unit;
   if (grid_n > n_items) grid_n = n_items;
   dim3 grid((unsigned)grid_n), block((unsigned)p.threads);
@@ -856,13 +1193,6 @@ int launch_slab_w(const SlabArgs& a, const SlabPlan& p, pgt_stream_t stream) {
   return PGT_ERR_INVALID;
 }
 
-
-// whole-sample kernels: both [N, C] blocks and the operators in one workgroup's LDS
-static bool slab_whole_ok(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i) {
-  const int V = (C % 2 == 0) ? 2 : 1;
-  return N * (C / V) <= (int64_t)MAXT_CAP * SLAB_THREADS &&        // (the narrowest element the launch may pick)
-         slab_lds_bytes(N, C, nnz_o, nnz_i) <= 160 * 1024;
-}
 
 int slab_supported(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i, size_t* bytes) {
   if (N <= 0 || C <= 0 || K < 2 || K > 3) return 0;
@@ -882,6 +1212,7 @@ int launch_slab(const SlabArgs& a, size_t need, pgt_stream_t stream) {
     pgt_set_error("pgt_dconv_stack_slab: the block only fits column by column, which needs 8-byte aligned even-width segments");
     return PGT_ERR_INVALID;
   }
+  if (const int kind = slab_quad_kind(a)) return launch_slab_q<BWD>(a, kind, stream);
   int V = (a.C % 2 == 0 && pgt_aligned(a.TS, 8) && a.seg_stride % 2 == 0) ? 2 : 1;
   // two column pairs per lane (half the slot reads) while its register arrays fit: at most 4 tasks per thread
   if (V == 2 && g_slab_pairs >= 2 && a.C >= 8 && (int64_t)a.N * pgt_cdiv(a.C, 4) <= 4 * SLAB_THREADS) V = 4;
@@ -949,12 +1280,14 @@ void pgt_slab_set_pairs(int v) { g_slab_pairs = v; }
 void pgt_slab_set_split(int v) { g_slab_split = v; }
 void pgt_slab_set_threads(int v) { g_slab_threads = v; }
 void pgt_slab_set_wpc(int v) { g_slab_wpc = v; }
+void pgt_slab_set_quad(int v) { g_slab_quad = v; }
 
 extern "C" int pgt_dconv_stack_slab_fits(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i) {
   return slab_supported(N, C, K, nnz_o, nnz_i, nullptr);
 }
 
-extern "C" int pgt_dconv_stack_slab_plan(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i, int32_t* plan) {
+extern "C" int pgt_dconv_stack_slab_plan(int64_t N, int64_t n_samples, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i,
+                                         int32_t* plan) {
   PGT_REQUIRE(plan != nullptr, "pgt_dconv_stack_slab_plan: null pointer");
   plan[0] = plan[1] = plan[2] = plan[3] = 0;
   if (!slab_supported(N, C, K, nnz_o, nnz_i, nullptr)) return PGT_OK;
@@ -962,6 +1295,7 @@ extern "C" int pgt_dconv_stack_slab_plan(int64_t N, int64_t C, int64_t K, int64_
   plan[1] = 1; plan[2] = SLAB_THREADS; plan[3] = 0;
   SlabArgs a{};
   a.N = (int)N; a.C = (int)C; a.K = (int)K; a.nnz_o = (int)nnz_o; a.nnz_i = (int)nnz_i;
+  a.n_samples = (int)(n_samples < ((int64_t)1 << 30) ? n_samples : ((int64_t)1 << 30));
   a.TS = nullptr; a.seg_stride = 0;                       // (alignment of the caller's buffers is checked at launch)
   SlabPlan p;
   if (slab_plan(a, &p)) { plan[0] = p.nsplit; plan[1] = p.wpc; plan[2] = p.threads; plan[3] = p.maxt; }

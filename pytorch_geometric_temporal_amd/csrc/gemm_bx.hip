@@ -510,11 +510,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
         float side[EPI != 0 ? 16 : 1];                 // eX = H r (zr) / the new hidden state (candidate gate)
         if constexpr (EPI != 0) {
           if (e_live) {
-            if (n_iter == 0) BX_DRAIN();
+            // vmcnt counts loads AND stores, and only operations of the same kind retire in order: a store may be
+            // acknowledged before an older load has landed, so "N younger stores are in flight" proves nothing about the
+            // load.  The operand loads were issued a block ago (before that block's stores): drain.
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              BX_WAIT(16, eh[r]);
-              if constexpr (EPI == 2) BX_WAIT(16, ez[r]);
+              BX_WAIT(0, eh[r]);
+              if constexpr (EPI == 2) BX_WAIT(0, ez[r]);
             }
           }
 #pragma unroll
@@ -882,12 +884,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   auto issue_load = [&](int t, const BxRsrc& r) {
     BX_LOAD2(raw[t], goff[t], r);
   };
-  // younger instructions at the wait for element t: the other EPT - 1 loads, and — from the second block on, for a
-  // wavefront that stores — the 16 stores of the previous block
-  auto convert_one = [&](int t, unsigned char* buf, int n_stores) {
-    if (n_stores == 32) BX_WAIT(EPT - 1 + 32, raw[t]);
-    else if (n_stores == 16) BX_WAIT(EPT - 1 + 16, raw[t]);
-    else BX_WAIT(EPT - 1, raw[t]);
+  // The wait for element t may only count the YOUNGER LOADS (the other EPT - 1): loads retire in order among themselves,
+  // but a younger store can be acknowledged before an older load lands (vmcnt is one counter for both kinds, unordered
+  // against each other), so the previous block's stores must not be added to the count.  (Round 2 did add them — 16 / 32
+  // per block — and a launch at M = 211 968, K = 64 -> 320 columns then converted stale registers in about four rows of
+  // 200 000: scripts/bx_sym_race_probe.py.)  The price: the wait also covers the acknowledgement of those stores.
+  auto convert_one = [&](int t, unsigned char* buf) {
+    BX_WAIT(EPT - 1, raw[t]);
     uint32_t p1, p2, p3;
     bx_split2_fast(bx_as_float(raw[t][0]), bx_as_float(raw[t][1]), p1, p2, p3);
     unsigned char* d = buf + lbase + 64 * t;
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
     for (int t = 0; t < EPT; ++t) issue_load(t, r0);
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
-      convert_one(t, lds, 0);
+      convert_one(t, lds);
       issue_load(t, r1);
     }
   }
@@ -910,7 +913,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   BX_WAIT_PLAIN(EPT);      // the B / bias loads above are older than the EPT block loads
   bx_barrier();
   int cur = 0;
-  int stored = 0;                                          // store instructions of the previous block: 0 | 16 | 32
   const int arow = lo * SROW + 16 * hi;
   const uint32_t ldc4 = (uint32_t)(g.ldc * 4);
   for (; rb < n_blocks; rb += nwg) {
@@ -944,7 +946,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
       }
 #pragma unroll
       for (int t = i * EPT / KSTEPS; t < (i + 1) * EPT / KSTEPS; ++t) {
-        convert_one(t, bnxt, stored);
+        convert_one(t, bnxt);
         issue_load(t, r2);
       }
     }
@@ -962,7 +964,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
         const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
         BX_STORE1S(v[r], cvoff, rc, soff);
       }
-      stored = 16;
       if (two) {
         const BxRsrc rc2 = c_rsrc(cbase2, rb);
 #pragma unroll
@@ -976,7 +977,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
           const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
           BX_STORE1S(v[r], cvoff2, rc2, soff);
         }
-        stored = 32;
       }
     }
     bx_barrier();

@@ -659,12 +659,12 @@ def slab_fits(g, C, K):
     return bool(lib._pgt_dconv_stack_slab_fits(g.N, int(C), int(K), g.E, g.E))
 
 
-def slab_plan(g, C, K):
-    """(column windows per sample, workgroups per CU, threads, tasks per thread) of the stack launch for this shape
+def slab_plan(g, C, K, n_samples=1 << 20):
+    """(column windows per sample, workgroups per CU, threads, tasks per thread) of the stack launch for this shape and batch
     (pgt_dconv_stack_slab_plan); (1, 1, 1024, 0) = the whole-sample kernels, zeros = not supported."""
     lib = _lib.get_lib()
     out = (ctypes.c_int32 * 4)()
-    lib.call("pgt_dconv_stack_slab_plan", g.N, int(C), int(K), g.E, g.E, out)
+    lib.call("pgt_dconv_stack_slab_plan", g.N, int(n_samples), int(C), int(K), g.E, g.E, out)
     return tuple(out)
 
 

@@ -47,7 +47,7 @@ def main():
     n, E, K = 207, 1515, 3
     ei, ew = syn.sensor_graph(n, E, seed=0, symmetric=False)
     g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
-    configs = [("whole", 0, 0, 0), ("auto", 1, 0, 0)]
+    configs = [("whole_pair", 0, 0, 0), ("whole", 0, 0, 0), ("auto", 1, 0, 0)]
     for ns in (2, 3, 4, 6, 8):
         for wpc in (1, 2, 3):
             for th in (0, 512, 640, 1024):
@@ -62,6 +62,7 @@ def main():
                 lib.tune("slab_split", split)
                 lib.tune("slab_wpc", wpc)
                 lib.tune("slab_threads", th)
+                lib.tune("slab_quad", 0 if cname == "whole_pair" else 1)
                 try:
                     if bwd:
                         us = timed(lambda: ops._slab_bwd(g, TS[0], seg, B, C, K, True))
@@ -74,8 +75,9 @@ def main():
                     lib.tune("slab_split", 1)
                     lib.tune("slab_wpc", 0)
                     lib.tune("slab_threads", 0)
+                    lib.tune("slab_quad", 1)
                 lib.tune("slab_split", split); lib.tune("slab_wpc", wpc); lib.tune("slab_threads", th)
-                plan = ops.slab_plan(g, C, K)
+                plan = ops.slab_plan(g, C, K, B) + (cname == "whole_pair",)
                 lib.tune("slab_split", 1); lib.tune("slab_wpc", 0); lib.tune("slab_threads", 0)
                 if plan in seen:
                     continue

@@ -704,7 +704,7 @@ def test_slab_stack_column_split_is_bit_identical(backend, n, C, K, B):
     whole-sample kernels and the per-hop path: the recursion is column-independent and every element keeps its fmaf chain,
     so the results are bit-identical — for every window count, ragged batches (B not a multiple of 8: the item order packs
     eight samples per group), forced workgroup sizes, forward and both adjoint forms.  N = 325 and 600 at C = 66 only fit
-    column by column."""
+    column by column.  C = 64 / 66 also covers the quad-layout whole-sample kernels against the pair-layout ones."""
     lib = _lib.get_lib()
     if backend.name == "emu":
         B = min(B, 3) if n > 100 else B
@@ -715,10 +715,11 @@ def test_slab_stack_column_split_is_bit_identical(backend, n, C, K, B):
     X = torch.randn(B, n, C, generator=gen)
     Gsrc = torch.randn(S, B * n, C, generator=gen)
 
-    def run(split, threads=0, wpc=0):
+    def run(split, threads=0, wpc=0, quad=1):
         lib.tune("slab_split", split)
         lib.tune("slab_threads", threads)
         lib.tune("slab_wpc", wpc)
+        lib.tune("slab_quad", quad)
         try:
             if not ops.slab_fits(g, C, K):
                 return None
@@ -736,6 +737,7 @@ def test_slab_stack_column_split_is_bit_identical(backend, n, C, K, B):
             lib.tune("slab_split", 1)
             lib.tune("slab_threads", 0)
             lib.tune("slab_wpc", 0)
+            lib.tune("slab_quad", 1)
 
     # reference: the per-hop launches on node-major rows
     TSn = torch.zeros(S, 1, n * B, C)
@@ -749,6 +751,9 @@ def test_slab_stack_column_split_is_bit_identical(backend, n, C, K, B):
     assert torch.equal(base[0], ref_fwd)
     if whole is not None:
         for a, b in zip(whole, base):
+            assert torch.equal(a, b)
+        # whole-sample kernels in the pair layout against the quad layout (C = 64 / 66: one conflict-free ds_read_b128 per slot)
+        for a, b in zip(run(0, quad=0), whole):
             assert torch.equal(a, b)
     for split, threads, wpc in ((2, 0, 0), (3, 0, 0), (4, 512, 0), (5, 0, 1), (8, 0, 2), (2, 1024, 1), (3, 640, 0)):
         got = run(split, threads, wpc)

@@ -580,14 +580,20 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_p2_kernel(SlabArg
 // construction.  The E leading columns (the input features) sit in a side block of one padded quad per row and are the
 // 17th task of a row, so that every lane executes the same instruction stream.  Same fmaf chain per element as the
 // kernels above: bit-identical results.
+// global access of a task's element.  G4: 16-byte aligned quads.  Otherwise (C = 66: a row starts every 264 bytes) a hidden
+// quad is 8-byte aligned: still ONE dwordx4 access — the hardware takes any dword-aligned address — and the leading pair of
+// a row is a float2 (its upper half mirrors the lower on loads and is never stored).
 template <bool G4>
 __device__ __forceinline__ void ldQ(const float* p, bool main_, pgt_f4& v) {
   if constexpr (G4) {
     v = *reinterpret_cast<const pgt_f4*>(p);
   } else {
-    const float2 a = *reinterpret_cast<const float2*>(p);
-    const float2 b = *reinterpret_cast<const float2*>(p + (main_ ? 2 : 0));
-    v = pgt_mk4(a.x, a.y, b.x, b.y);
+    if (main_) {
+      __builtin_memcpy(&v, __builtin_assume_aligned(p, 8), 16);
+    } else {
+      const float2 a = *reinterpret_cast<const float2*>(p);
+      v = pgt_mk4(a.x, a.y, a.x, a.y);
+    }
   }
 }
 template <bool G4>
@@ -595,8 +601,8 @@ __device__ __forceinline__ void stQ(float* p, bool main_, pgt_f4 v) {
   if constexpr (G4) {
     *reinterpret_cast<pgt_f4*>(p) = v;
   } else {
-    *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
-    if (main_) *reinterpret_cast<float2*>(p + 2) = make_float2(v.z, v.w);
+    if (main_) __builtin_memcpy(__builtin_assume_aligned(p, 8), &v, 16);
+    else *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
   }
 }
 __device__ __forceinline__ pgt_f4 fma4(float w, pgt_f4 x, pgt_f4 acc) {
@@ -631,6 +637,8 @@ __device__ __forceinline__ pgt_f4 gather_q(const int* __restrict__ rp, const int
   }
   return acc;
 }
+// (Measured and dropped: both directions of a row in ONE loop over the longer slot list, 2 x 2 reads in flight — 108 - 127 us
+// against 78 us: the predicated tail and the extra live registers cost more than the shorter chain saves.)
 // floats of one LDS block: [N][64] hidden quads + (E > 0) one padded quad per row for the leading columns
 __host__ __device__ inline size_t slab_q_block_floats(int64_t N, int E) { return (size_t)N * 64 + (E > 0 ? (size_t)N * 4 : 0); }
 static size_t slab_q_lds_bytes(int64_t N, int E, int64_t nnz_o, int64_t nnz_i) {
@@ -648,25 +656,24 @@ __device__ __forceinline__ SlabLds carve_q(char* base, const SlabArgs& a, int E)
   s.rp_i = reinterpret_cast<int*>(p);
   return s;
 }
-// task tid + j * 1024 of a sample: row, kind, the float offsets it touches
+// Task tid + j * 1024 of a sample.  Tasks 0 .. 16 N - 1 are the hidden quads, sixteen per row, so that a wavefront's lanes
+// 16 i .. 16 i + 15 own one row (the b128 lane groups then never meet on a bank); the N leading-pair tasks follow.
 template <int E, int MAXT>
 struct SlabQTasks {
-  int rj[MAXT];     // (row << 5) | task-in-row (0 .. 16)
+  int rj[MAXT];     // main: (row << 5) | quad (0 .. 15);  leading pair of a row: (row << 5) | 16
   int N, C, ntask, tid;
-  static constexpr int TPR = 16 + (E > 0 ? 1 : 0);
   __device__ __forceinline__ void init(const SlabArgs& a, int tid_) {
-    N = a.N; C = a.C; tid = tid_; ntask = a.N * TPR;
+    N = a.N; C = a.C; tid = tid_; ntask = a.N * (16 + (E > 0 ? 1 : 0));
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * SLAB_THREADS, ic = idx < ntask ? idx : ntask - 1;
-      const int r = ic / TPR;
-      rj[j] = (r << 5) | (ic - r * TPR);
+      rj[j] = ic < 16 * a.N ? (((ic >> 4) << 5) | (ic & 15)) : (((ic - 16 * a.N) << 5) | 16);
     }
   }
   __device__ __forceinline__ bool live(int j) const { return tid + j * SLAB_THREADS < ntask; }
   __device__ __forceinline__ int row(int j) const { return rj[j] >> 5; }
-  __device__ __forceinline__ bool main_(int j) const { return E == 0 || (rj[j] & 31) != 0; }      // task 0 of a row: the E leading columns
-  __device__ __forceinline__ int quad(int j) const { return (rj[j] & 31) - (E > 0 ? 1 : 0); }
+  __device__ __forceinline__ bool main_(int j) const { return E == 0 || (rj[j] & 16) == 0; }
+  __device__ __forceinline__ int quad(int j) const { return rj[j] & 15; }
   __device__ __forceinline__ int goff(int j) const { return row(j) * C + (main_(j) ? E + 4 * quad(j) : 0); }   // in the sample's [N, C] block
   __device__ __forceinline__ int qoff(int j) const { return main_(j) ? 4 * quad(j) : N * 64; }               // quad column inside an LDS block
   __device__ __forceinline__ int pitch(int j) const { return main_(j) ? 64 : 4; }
@@ -751,9 +758,8 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_q_kernel(SlabArgs
 }
 
 // backward on the TRANSPOSED operators; see dconv_slab_bwd_kernel
-template <int E, bool G4, int MAXT>
+template <int E, bool G4, int MAXT, int GU>
 __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_q_kernel(SlabArgs a) {
-  constexpr int GU = (MAXT >= 4 && E > 0) ? 2 : 4;      // (the input-gradient form holds five register blocks: fewer reads in flight)
   __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
   const SlabLds s = carve_q(smem, a, E);
   const int tid = threadIdx.x;
@@ -829,6 +835,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_q_kernel(SlabArgs
 }
 
 int g_slab_pairs = 2;   // pgt_tune("slab_pairs"): column pairs per lane of the LDS-resident stack kernels (1 | 2)
+int g_slab_gu = 2;        // pgt_tune("slab_gu"): LDS reads in flight per gather of the four-task backward quad kernels (2 | 4)
 int g_slab_quad = 1;      // pgt_tune("slab_quad"): 0 = C = 64 / 66 blocks on the pair-layout kernels (A/B)
 // the quad-layout kernels take C = 64 (16-byte aligned segments) or C = 66 (8-byte aligned), at most 4 tasks per thread
 static int slab_quad_kind(const SlabArgs& a) {
@@ -846,9 +853,12 @@ int launch_slab_q(const SlabArgs& a, int kind, pgt_stream_t stream) {
   const int tpt = (int)pgt_cdiv((int64_t)a.N * tpr, SLAB_THREADS);
   const int nblk = a.n_samples < 256 ? a.n_samples : 256;
   dim3 grid((unsigned)nblk), block(SLAB_THREADS);
+  // backward, four tasks per thread: five register blocks are live, so the gathers keep two reads in flight instead of
+  // four (no spills: 77.5 us against 89 us at B = 1024, C = 64; pgt_tune("slab_gu", 4) for the A/B)
 #define PGT_SLABQ(E_, G4_, T_)                                                                        \
   do {                                                                                                \
-    if (BWD) PGT_LAUNCH((dconv_slab_bwd_q_kernel<E_, G4_, T_>), grid, block, stream, a);              \
+    if (BWD && T_ >= 4 && g_slab_gu != 4) PGT_LAUNCH((dconv_slab_bwd_q_kernel<E_, G4_, T_, 2>), grid, block, stream, a); \
+    else if (BWD) PGT_LAUNCH((dconv_slab_bwd_q_kernel<E_, G4_, T_, 4>), grid, block, stream, a);      \
     else PGT_LAUNCH((dconv_slab_fwd_q_kernel<E_, G4_, T_>), grid, block, stream, a);                  \
   } while (0)
   if (kind == 1) { if (tpt <= 2) PGT_SLABQ(0, true, 2); else PGT_SLABQ(0, true, 4); }
@@ -1281,6 +1291,7 @@ void pgt_slab_set_split(int v) { g_slab_split = v; }
 void pgt_slab_set_threads(int v) { g_slab_threads = v; }
 void pgt_slab_set_wpc(int v) { g_slab_wpc = v; }
 void pgt_slab_set_quad(int v) { g_slab_quad = v; }
+void pgt_slab_set_gu(int v) { g_slab_gu = v; }
 
 extern "C" int pgt_dconv_stack_slab_fits(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i) {
   return slab_supported(N, C, K, nnz_o, nnz_i, nullptr);

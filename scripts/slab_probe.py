@@ -43,12 +43,13 @@ def timed(fn, launches=20):
 def main():
     lib = _lib.get_lib()
     dev = torch.device("cuda:0")
-    Bs = [int(a) for a in sys.argv[1:]] or [1024, 64]
+    whole_only = "whole" in sys.argv[1:]
+    Bs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1024, 64]
     n, E, K = 207, 1515, 3
     ei, ew = syn.sensor_graph(n, E, seed=0, symmetric=False)
     g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
-    configs = [("whole_pair", 0, 0, 0), ("whole", 0, 0, 0), ("auto", 1, 0, 0)]
-    for ns in (2, 3, 4, 6, 8):
+    configs = [("whole_pair", 0, 0, 0), ("whole", 0, 0, 0), ("whole_gu4", 0, 0, 0), ("auto", 1, 0, 0)]
+    for ns in (() if whole_only else (2, 3, 4, 6, 8)):
         for wpc in (1, 2, 3):
             for th in (0, 512, 640, 1024):
                 configs.append((f"split{ns}_wpc{wpc}_t{th}", ns, wpc, th))
@@ -63,6 +64,7 @@ def main():
                 lib.tune("slab_wpc", wpc)
                 lib.tune("slab_threads", th)
                 lib.tune("slab_quad", 0 if cname == "whole_pair" else 1)
+                lib.tune("slab_gu", 4 if cname == "whole_gu4" else 2)
                 try:
                     if bwd:
                         us = timed(lambda: ops._slab_bwd(g, TS[0], seg, B, C, K, True))
@@ -76,8 +78,9 @@ def main():
                     lib.tune("slab_wpc", 0)
                     lib.tune("slab_threads", 0)
                     lib.tune("slab_quad", 1)
+                    lib.tune("slab_gu", 2)
                 lib.tune("slab_split", split); lib.tune("slab_wpc", wpc); lib.tune("slab_threads", th)
-                plan = ops.slab_plan(g, C, K, B) + (cname == "whole_pair",)
+                plan = ops.slab_plan(g, C, K, B) + (cname,) if cname.startswith("whole") else ops.slab_plan(g, C, K, B)
                 lib.tune("slab_split", 1); lib.tune("slab_wpc", 0); lib.tune("slab_threads", 0)
                 if plan in seen:
                     continue

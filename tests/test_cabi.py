@@ -137,7 +137,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     keys = set(re.findall(r'"([a-z][a-z0-9_]+)"', doc))
     assert {"gemm_bx", "gemm_bx_sym", "gemm_db", "spmm_ellw", "slab_pairs"} <= keys
     defaults = {"gemm_small_fill": 256, "gemm_small_tiles": 0, "spmm_tile_rows": 32, "spmm_unroll": 8, "spmm_ellw_rows": 0,
-                "spmm_ellw_cus": 0, "spmm_ellw_cfg": 0, "slab_pairs": 2, "slab_wpc": 0, "slab_threads": 0}   # every other switch defaults to 1
+                "spmm_ellw_cus": 0, "spmm_ellw_cfg": 0, "slab_pairs": 2, "slab_wpc": 0, "slab_threads": 0, "slab_gu": 2}   # every other switch defaults to 1
     for k in sorted(keys):
         lib.tune(k, defaults.get(k, 1))
     assert lib.prep_workspace_bytes(2, 2) > 8

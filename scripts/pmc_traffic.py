@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Condense the rocprofv3 passes of scripts/pmc_bench.sh into profiles/r02_pmc_traffic.json (what bench.py reports as
-`roofline.traffic`) and profiles/r02_bench_kernel_stats.csv.
+"""Condense the rocprofv3 passes of scripts/pmc_bench.sh into profiles/r03_pmc_traffic.json (what bench.py reports as
+`roofline.traffic`) and profiles/r03_bench_kernel_stats.csv.
 
 Per kernel class (gemm / gemm_tn / stack / ns_spmm ...): mean over the dispatches of FETCH_SIZE x 2 (the gfx950
 correction of MI355X_MICROARCH.md section HBM: FETCH_SIZE reports half the bytes of wide coalesced reads) and of
@@ -60,8 +60,8 @@ def reduce(path, wanted):
     return acc, per_kernel
 
 
-fetch, fetch_k = reduce(newest(os.path.join(src, "r02_pmc_fetch", "**", "*counter_collection.csv")), {"FETCH_SIZE"})
-write, write_k = reduce(newest(os.path.join(src, "r02_pmc_write", "**", "*counter_collection.csv")), {"WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"})
+fetch, fetch_k = reduce(newest(os.path.join(src, "r03_pmc_fetch", "**", "*counter_collection.csv")), {"FETCH_SIZE"})
+write, write_k = reduce(newest(os.path.join(src, "r03_pmc_write", "**", "*counter_collection.csv")), {"WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"})
 out = {"command": sys.argv[1] if len(sys.argv) > 1 else "", "units": "bytes per launch; FETCH_SIZE (KB) x 2 x 1000, WRITE_SIZE (KB) x 1000",
        "kernels": {}, "per_kernel": {}}
 for store_f, store_w, dest in ((fetch, write, out["kernels"]), (fetch_k, write_k, out["per_kernel"])):
@@ -76,10 +76,12 @@ for store_f, store_w, dest in ((fetch, write, out["kernels"]), (fetch_k, write_k
                    "bytes_per_launch": (fb or 0) + (wb or 0) if (fb is not None and wb is not None) else None,
                    "l2_hit_rate": (h[0] / (h[0] + m[0])) if (h[0] + m[0]) > 0 else None}
 os.makedirs(dst, exist_ok=True)
-with open(os.path.join(dst, "r02_pmc_traffic.json"), "w") as fh:
-    json.dump(out, fh, indent=1)
+for d in (dst, src):      # profiles/ when run in the build container; gpurun_out/prof travels back from the GPU box
+    with open(os.path.join(d, "r03_pmc_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
 print(json.dumps(out["kernels"], indent=1))
-st = newest(os.path.join(src, "r02_stats", "**", "*kernel_stats.csv"))
+st = newest(os.path.join(src, "r03_stats", "**", "*kernel_stats.csv"))
 if st:
-    shutil.copy(st, os.path.join(dst, "r02_bench_kernel_stats.csv"))
+    shutil.copy(st, os.path.join(dst, "r03_bench_kernel_stats.csv"))
+    shutil.copy(st, os.path.join(src, "r03_bench_kernel_stats.csv"))
     print("copied", st)

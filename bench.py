@@ -217,7 +217,10 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
     res = {}
     n = 200_000
     for name, gen, deg in (("local", syn.local_graph, 8), ("uniform", syn.uniform_graph, 8), ("local_deg16", syn.local_graph, 16),
-                           ("local_hubs_20x2000", syn.hub_graph, 8)):
+                           ("local_hubs_20x2000", syn.hub_graph, 8),
+                           ("grid2d_hilbert", lambda n_, d_, seed: syn.grid2d_graph(447, "hilbert", seed), 8),
+                           ("grid2d_rowmajor", lambda n_, d_, seed: syn.grid2d_graph(447, "rowmajor", seed), 8)):
+        n = 447 * 447 if name.startswith("grid2d") else 200_000      # a 447 x 447 mesh: 199 809 nodes
         ei_np, ew_np = gen(n, deg, seed=0)
         g = ops.DConvGraph(torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device), n)
         Xs = [torch.randn(n, 64, device=device) for _ in range(pairs)]
@@ -247,7 +250,7 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
             times.append(1e3 * e0.elapsed_time(e1) / launches)
         us = sum(times) / len(times)                       # the MEAN of three replays of 60 launches (not the best)
         nbytes = ops.spmm_algorithmic_bytes(n, g.E, 64, False)
-        e = g.fwd_o.ellw
+        e = g.fwd_o.ellw or None
         res[name] = {"us_per_launch": us, "us_per_launch_replays": times, "algorithmic_MB": nbytes / 1e6,
                      "achieved_GBs": nbytes / us / 1e3, "frac": nbytes / us / 1e3 / HBM_PEAK_GBS, "edges": int(g.E),
                      "in_degree": deg,

@@ -164,9 +164,11 @@ typedef struct pgt_ellw {
   int32_t config;         /* launch shape, from pgt_ellw_plan: 1 = one 1024-thread workgroup per CU (456 window rows),
                              2 = two 512-thread workgroups per CU (240 window rows) */
   int64_t n_tiles;
-  const int32_t* far_col; /* [n_tiles * far_rows] sources outside a tile's window that get an LDS row of their own (their
-                             slots hold window_rows + 1 + k; -1 = unused entry), or NULL: every out-of-window slot is
-                             0xFFFF and comes through the CSR */
+  const int32_t* far_col; /* [n_tiles * far_rows] the DISTINCT sources outside a tile's window that get an LDS row of their
+                             own (a hash set: entry k holds the source whose slots read window_rows + 1 + k; -1 = unused
+                             entry), or NULL: every out-of-window slot is 0xFFFF and comes through the CSR.  This is what
+                             carries numberings whose tiles are compact without being a band: a 2-D mesh numbered along a
+                             space-filling curve names ~85 outside rows per 392-row tile (its ring) */
   int32_t far_rows;       /* from pgt_ellw_plan (depends on config and mode) */
 } pgt_ellw;
 
@@ -183,7 +185,7 @@ int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t sou
  * geometry in `op` (its pointers are ignored).  `scale` (float [n_rows], may be NULL) receives the candidate
  * per-source table scale[col[q]] = val[q]; it also states the mode the layout is built for (NULL: per-slot mode,
  * op->far_rows must be the per-slot plan's).  `far_col` (int32 [n_tiles * op->far_rows]) / `far_cnt` (int32 [n_tiles],
- * scratch) receive the out-of-window table; both NULL: no table.  info (int32 [4], device): [0] = slots outside their
+ * scratch: the number of distinct outside sources that got a row) receive the out-of-window table; both NULL: no table.  info (int32 [4], device): [0] = slots outside their
  * window, [1] = slots whose val differs bitwise from scale[col] (0 = the source-scale mode applies; otherwise rebuild
  * with scale = NULL and the per-slot plan), [2] = rows longer than `width` (must be 0: their tail is not represented),
  * [3] = out-of-window slots that did not fit their tile's table (0xFFFF: served through the CSR at run time — correct,

@@ -446,11 +446,21 @@ __global__ __launch_bounds__(256) void ellw_build_kernel(const int32_t* __restri
       else {
         // out of the window: one of the tile's far_max LDS rows behind the zero row if one is left (the slot then points
         // at it and the kernel prefetches X[c] into it), otherwise 0xFFFF = fetched through the CSR inside the gather
+        // (the table is a small hash set: every slot that names the same source shares ONE LDS row — a tile of a mesh
+        // numbered along a space-filling curve names ~85 distinct outside rows through ~230 slots)
         d = 0xffffu;
         atomicAdd(&info[0], 1);
         if (far_cnt != nullptr) {
-          const int k = atomicAdd(&far_cnt[tile], 1);
-          if (k < far_max) { far_col[(int64_t)tile * far_max + k] = c; d = (unsigned)(WR + 1 + k); }
+          int32_t* tab = far_col + (int64_t)tile * far_max;
+          unsigned h = ((unsigned)c * 2654435761u) % (unsigned)far_max;
+          int k = -1;
+          for (int probe = 0; probe < far_max; ++probe) {
+            const int old = atomicCAS(&tab[h], -1, c);
+            if (old == -1) { atomicAdd(&far_cnt[tile], 1); k = (int)h; break; }
+            if (old == c) { k = (int)h; break; }
+            h = h + 1 == (unsigned)far_max ? 0u : h + 1;
+          }
+          if (k >= 0) d = (unsigned)(WR + 1 + k);
           else atomicAdd(&info[3], 1);
         }
       }
@@ -857,7 +867,7 @@ extern "C" int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const f
   tmp.far_col = far_col;
   if (int rc = ellw_check("pgt_ellw_build", &tmp, n_rows)) return rc;
   if (far_col != nullptr) {
-    // -1 = unused entry of the far table; far_cnt counts a tile's out-of-window slots (may exceed far_rows)
+    // -1 = unused entry of the far table; far_cnt counts a tile's DISTINCT out-of-window sources that got an LDS row
     if (hipMemsetAsync(far_col, 0xff, (size_t)op->n_tiles * op->far_rows * sizeof(int32_t), (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(far_cnt, 0, (size_t)op->n_tiles * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
       pgt_set_error("pgt_ellw_build: memset failed");

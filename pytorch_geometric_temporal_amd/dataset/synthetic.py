@@ -101,6 +101,53 @@ def uniform_graph(num_nodes=200_000, degree=8, seed=0):
     return _row_major(src, dst, w)
 
 
+def _hilbert_d(order, x, y):
+    """Index of cell (x, y) along the Hilbert curve of a 2**order x 2**order square (vectorised)."""
+    x, y = x.astype(np.int64).copy(), y.astype(np.int64).copy()
+    d = np.zeros_like(x)
+    s = 1 << (order - 1)
+    while s > 0:
+        rx = ((x & s) > 0).astype(np.int64)
+        ry = ((y & s) > 0).astype(np.int64)
+        d += s * s * ((3 * rx) ^ ry)
+        flip = ry == 0
+        swap = flip & (rx == 1)
+        x = np.where(swap, s - 1 - x, x)
+        y = np.where(swap, s - 1 - y, y)
+        x, y = np.where(flip, y, x), np.where(flip, x, y)
+        s >>= 1
+    return d
+
+
+def grid2d_graph(side=447, order="hilbert", seed=0):
+    """A 2-D mesh (side x side nodes, 8-neighbourhood: in-degree 8 in the interior — a road / sensor network embedded in
+    the plane) numbered along a space-filling curve ("hilbert": consecutive nodes form compact patches, the ordering a
+    locality-aware partitioner yields) or row by row ("rowmajor": the bandwidth-`side` ordering reverse Cuthill-McKee gives
+    a mesh).  N = side**2 (447**2 = 199 809), E ~ 8 N.  Weights are random: a diffusion operator, not a stencil."""
+    rng = np.random.default_rng(seed)
+    n_side = int(side)
+    yy, xx = np.divmod(np.arange(n_side * n_side), n_side)
+    if order == "hilbert":
+        bits = max(1, int(np.ceil(np.log2(n_side))))
+        rank = np.empty(n_side * n_side, dtype=np.int64)
+        rank[np.argsort(_hilbert_d(bits, xx, yy), kind="stable")] = np.arange(n_side * n_side)
+    elif order == "rowmajor":
+        rank = np.arange(n_side * n_side, dtype=np.int64)
+    else:
+        raise ValueError(order)
+    src, dst = [], []
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            if dx == 0 and dy == 0:
+                continue
+            ok = (xx + dx >= 0) & (xx + dx < n_side) & (yy + dy >= 0) & (yy + dy < n_side)
+            dst.append(rank[ok])
+            src.append(rank[(yy[ok] + dy) * n_side + xx[ok] + dx])
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    w = (0.5 + rng.random(src.size)).astype(np.float32)
+    return _row_major(src, dst, w)
+
+
 def traffic_series(num_steps, num_nodes, seed=0):
     """[T, N, 2] float32: z-scored AR(1) "speed" channel + time-of-day channel (layout of dataset/metr_la.py:143-176)."""
     rng = np.random.default_rng(seed)

@@ -24,7 +24,7 @@ class Csr:
     """CSR operator by destination row.  `halo` is the operator's measured locality: 32 / 96 when at least 95 % of the
     slots have |col - row| within that distance (locality-ordered node numbering), else 0; `max_len` the longest row.
     `ellw` caches the ELLW layout (pgt_ellw) built for the F = 64 LDS-window kernel on first use."""
-    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows")
+    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows")   # ellw: None | Ellw | False
 
     def __init__(self, n_rows, cap, device):
         self.n_rows = n_rows
@@ -127,11 +127,26 @@ class Ellw:
                           self.config, self.n_tiles, ptr(self.far_col), self.far_rows)
 
 
+# an operator that is NOT a band (fewer than 95 % of the slots within +-96 rows) may still have compact tiles — a mesh
+# numbered along a space-filling curve: 83 % within +-32, the rest in the patch's ring — which the layout's per-tile table
+# of distinct outside rows carries: build it with the narrow halo and keep it when (almost) every slot found a place
+ELLW_COMPACT_MAX_CSR_FRACTION = 0.002      # slots left to the CSR path (0xFFFF) for the layout to be kept
+
+
 def ellw_of(csr):
     """The cached ELLW layout of `csr`, built on first use; None when the layout does not apply."""
     e = getattr(csr, "ellw", None)
-    if e is None and getattr(csr, "halo", 0) > 0 and 0 <= getattr(csr, "max_len", -1) <= 32 and csr.nnz > 0:
-        e = csr.ellw = Ellw(csr, csr.halo)
+    if e is False:                     # tried and rejected
+        return None
+    if e is None and 0 <= getattr(csr, "max_len", -1) <= 32 and getattr(csr, "nnz", 0) > 0:
+        if getattr(csr, "halo", 0) > 0:
+            e = csr.ellw = Ellw(csr, csr.halo)
+        elif csr.n_rows >= ELLW_MIN_ROWS:
+            cand = Ellw(csr, 32)
+            if cand.far_csr <= ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz:
+                e = csr.ellw = cand
+            else:
+                csr.ellw = False
     return e
 
 
@@ -391,7 +406,7 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
     st = stream_of(lib, X)
     op = None
     if X.size(1) % 64 == 0 and X.size(1) > 0 and (ellw if ellw is not None else USE_ELLW):
-        if ellw and getattr(csr, "ellw", None) is None:
+        if ellw and not getattr(csr, "ellw", None):
             _force_ellw(csr)
         op = ellw_of(csr)
     work = spmm_algorithmic_bytes(csr.n_rows, csr.col.numel(), X.size(1), T is not None) if KERNEL_TIMER else 0

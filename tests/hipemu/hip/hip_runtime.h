@@ -297,3 +297,4 @@ static inline pgt_emu_f32x16 pgt_emu_mfma_32x32x2(float a, float b, pgt_emu_f32x
 }
 
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicCAS(int* p, int expected, int v) { int o = *p; if (o == expected) *p = v; return o; }

@@ -518,10 +518,16 @@ def test_spmm_ellw_out_of_window_sources_get_lds_rows(backend, source_scaled):
             e = ops._force_ellw(csr, 32)
             assert e is not None and (e.scale is not None) == source_scaled and e.width == 8 and e.config == 1
             assert e.far_rows == (128 if source_scaled else 32) and e.far > 0 and e.far_col is not None
-            assert (e.far_csr == 0) if all_fit else (0 < e.far_csr < e.far)
             table = e.far_col.view(e.n_tiles, e.far_rows).cpu()
             used = (table >= 0).sum().item()
-            assert used == e.far - e.far_csr and int(table.max()) < n
+            # overflow (slots left to the CSR path) only once a tile's table is full
+            assert e.far_csr == 0 if all_fit else (0 <= e.far_csr < e.far and (e.far_csr == 0 or int((table >= 0).sum(1).max()) == e.far_rows))
+            if not (source_scaled and backend.name == "emu"):
+                assert all_fit or e.far_csr > 0
+            assert 0 < used <= e.far - e.far_csr and int(table.max()) < n              # a hash set of DISTINCT sources per tile
+            for row in table[:50]:
+                live = row[row >= 0]
+                assert live.numel() == live.unique().numel()
             X = torch.randn(n, 64, generator=torch.Generator().manual_seed(1)).to(backend.device)
             T = torch.randn(n, 64, generator=torch.Generator().manual_seed(2)).to(backend.device)
             Y = torch.full((n, 64), float("nan"), device=backend.device)
@@ -535,6 +541,34 @@ def test_spmm_ellw_out_of_window_sources_get_lds_rows(backend, source_scaled):
             assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 0.5, 2.0), 5e-5, 1e-5, "far rows")
     finally:
         lib.tune("spmm_ellw_rows", 0)
+
+
+def test_spmm_ellw_compact_tiles_of_a_mesh_on_a_space_filling_curve(backend):
+    """A 2-D mesh numbered along a Hilbert curve is not a band (under 95 % of the slots within +-96 rows), but its tiles are
+    compact patches whose ring (~85 distinct outside rows per 392-row tile, named by ~230 slots) fits the per-tile table:
+    ops.ellw_of keeps the layout when no slot is left to the CSR path.  Row-major numbering (bandwidth = the mesh side:
+    two thirds of a tile's sources in the rows above and below) and a uniform-random graph are rejected and run the CSR
+    row tiles.  Source-scale mode: bit for bit the reference's roundings."""
+    side = 64 if backend.name == "emu" else 200
+    n = side * side
+    X = torch.randn(n, 64, generator=torch.Generator().manual_seed(3)).to(backend.device)
+    # (at the test double's 64 x 64 mesh the row-major numbering IS a +-96 band: the negative case there is a random graph)
+    for order, takes in (("hilbert", True), ("rowmajor" if side > 96 else "uniform", False)):
+        ei, ew = syn.uniform_graph(n, 8, seed=1) if order == "uniform" else syn.grid2d_graph(side, order, seed=1)
+        G = ops.DConvGraph(backend.t(ei), backend.t(ew), n)
+        csr = G.fwd_o
+        assert csr.halo == 0, order
+        Y = torch.full((n, 64), float("nan"), device=backend.device)
+        ops.spmm(csr, X, Y)
+        e = csr.ellw
+        if takes:
+            assert e and e.scale is not None and e.far_csr == 0 and e.far > 0
+            assert torch.equal(Y.cpu(), source_scaled_reference(csr, X))
+        else:
+            assert e is False
+        Yc = torch.empty_like(Y)
+        ops.spmm(csr, X, Yc, ellw=False)
+        assert_close_with_nonfinite(Y, Yc, 1e-5, 1e-5, order)
 
 
 def test_spmm_ellw_strided_nonfinite_and_fallback_shapes(backend):
@@ -1560,8 +1594,13 @@ def test_aggregation_at_north_star_size():
     n, F_ = 200_000, 64
     gen = torch.Generator(device="cpu").manual_seed(11)
     X1, X2 = torch.randn(n, F_, generator=gen).to(dev), torch.randn(n, F_, generator=gen).to(dev)
-    for kind, graph in (("local", syn.local_graph), ("uniform", syn.uniform_graph)):
+    for kind, graph in (("local", syn.local_graph), ("uniform", syn.uniform_graph),
+                        ("grid2d_hilbert", lambda n_, d_, seed: syn.grid2d_graph(447, "hilbert", seed)),
+                        ("grid2d_rowmajor", lambda n_, d_, seed: syn.grid2d_graph(447, "rowmajor", seed))):
         ei, ew = graph(n, 8, seed=0)
+        if kind.startswith("grid2d"):          # 447 x 447 = 199 809 nodes
+            n = 447 * 447
+            X1, X2 = X1[:n].contiguous(), X2[:n].contiguous()
         G = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
         csr = G.fwd_o
         nnz = int(csr.rowptr[-1])
@@ -1578,8 +1617,12 @@ def test_aggregation_at_north_star_size():
         if kind == "local":
             assert e is not None and e.scale is not None and e.vals is None and (e.tile_rows, e.width) == (392, 8)
             assert 0 < e.far < 1000                                                        # the wrap-around rows
+        elif kind == "grid2d_hilbert":
+            # not a band (83 % of the slots within +-32 rows) but compact tiles: the ring of a tile's patch rides in the table
+            # of distinct outside rows (~85 per tile through ~230 slots)
+            assert csr.halo == 0 and e is not None and e.scale is not None and e.far_csr == 0 and e.far > 50_000
         else:
-            assert e is None and csr.halo == 0
+            assert not e and csr.halo == 0
         ops.spmm(csr, X2, Y2)
         ref1 = reference(X1)
         assert_close_with_nonfinite(Y1, ref1.cpu(), 1e-5, 1e-5, f"{kind}: aggregation vs fp64")
@@ -1598,9 +1641,10 @@ def test_aggregation_at_north_star_size():
         finally:
             lib.tune("spmm_tile_nt", 1)
             lib.tune("spmm_tile_rows", 32)
-        if kind == "local":
+        if kind in ("local", "grid2d_hilbert"):
             assert torch.equal(Y1.cpu(), source_scaled_reference(csr, X1))                 # the reference's roundings
             assert_close_with_nonfinite(Yc, Y1.cpu(), 1e-5, 1e-5, "CSR tiles vs ELLW")
+        if kind == "local":
             # per-slot coefficient mode of the same layout: the CSR kernels' fmaf chain, bit for bit
             e.vals, e.scale = csr.val.new_zeros(e.n_tiles * e.tile_rows * e.width), None
             perslot = ops.Ellw.__new__(ops.Ellw)
@@ -1613,6 +1657,7 @@ def test_aggregation_at_north_star_size():
             ops.spmm(csr, X1, Yc2, ellw=False)
             assert torch.equal(Yv, Yc2)
         del G, csr
+        n = 200_000
 
 
 # ------------------------------------------------------------------------------------------------ fuzzing the graph prep

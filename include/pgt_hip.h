@@ -386,6 +386,29 @@ int pgt_att_softmax_rows_bwd_f32(const float* S, const float* dS, int64_t B, int
 int pgt_att_sigmoid_bwd_f32(const float* sig, const float* dsig, int64_t B, int64_t n, float* dP, float* dbias,
                             pgt_stream_t stream);
 
+/* Strided batched product of small matrices: C[b, i, j] (+)= sum_k A[b, i, k] B[b, k, j] for b < nb, every operand given by
+ * a base pointer and three strides in floats (a batch stride of 0 shares one matrix across the batch; swapping two
+ * strides transposes).  The embeddings around ASTGCN's attention matrices and their adjoints (astgcn.py:252-256, :318-322,
+ * :437: products with 1 .. 64 rows or columns), instead of one library batched GEMM each.  fmaf chain in k order,
+ * deterministic.  nb and ceil(M / 16) at most 65 535. */
+int pgt_bmm_f32(const float* A, int64_t sab, int64_t sai, int64_t sak, const float* B, int64_t sbb, int64_t sbk, int64_t sbj,
+                float* C, int64_t scb, int64_t sci, int64_t scj, int64_t nb, int64_t M, int64_t N, int64_t K, int accumulate,
+                pgt_stream_t stream);
+
+/* Y[r, 0:C] = LayerNorm(relu(Z[row(r), 0:C])) with gamma / beta [C] (torch.nn.LayerNorm: biased variance, eps inside the
+ * root) — the tail of an ASTGCN block, `self._layer_norm(F.relu(X + X_hat))` (astgcn.py:476-478), on the buffer the two
+ * convolutions were summed into.  row(r) = (r / row_period) * stride_hi + (r % row_period) * stride_lo (in rows of C
+ * floats): a strided time convolution's outputs are picked and its padding rows skipped.  stats [2 * rows] receives
+ * (mean, 1 / std) for the adjoint.  C <= 256.
+ * Adjoint: dZ[row(r)] from dY[r] (rows of dZ the map does not reach are not written); dgamma / dbeta [C] are ACCUMULATED
+ * into (fp32 atomics). */
+int pgt_relu_layernorm_f32(const float* Z, int64_t row_period, int64_t stride_hi, int64_t stride_lo, const float* gamma,
+                           const float* beta, float eps, int64_t rows, int64_t C, float* Y, float* stats,
+                           pgt_stream_t stream);
+int pgt_relu_layernorm_bwd_f32(const float* Z, int64_t row_period, int64_t stride_hi, int64_t stride_lo, const float* gamma,
+                               const float* stats, const float* dY, int64_t rows, int64_t C, float* dZ, float* dgamma,
+                               float* dbeta, pgt_stream_t stream);
+
 /* Index-batch window gather (signal/index_dataset.py:32-57; examples/indexBatching: "GPU-index-batching"): for every
  * sample b, X[b] = data[idx[b] : idx[b] + h], Y[b] = data[idx[b] + h : idx[b] + 2 h] from the resident series
  * data [T_total, W] (W = nodes * features), both windows of all B samples in one launch.  time_major != 0 writes

@@ -80,6 +80,124 @@ __global__ __launch_bounds__(256) void att_sigmoid_bwd_kernel(const float* __res
   if (dbias != nullptr) dbias[ij] = acc;
 }
 
+// ---- strided batched product of SMALL matrices: C[b, i, j] (+)= sum_k A[b, i, k] B[b, k, j], every operand through
+// three strides (batch stride 0 = one matrix shared by the batch, swapped strides = a transposed view).  The embeddings
+// around ASTGCN's attention are products with 1 .. 64 columns or rows (X W1, (X W1) W2, W3 X, X E; astgcn.py:252-256,
+// :318-322, :437 and their adjoints): too small and too oddly shaped for the tile kernels of gemm.hip, and a library
+// batched GEMM per product is what the reference pays for.  16 x 16 output tile per 256-thread workgroup, the K loop in
+// 16-deep LDS stages, plain fmaf chains in k order (deterministic).
+struct BmmArgs {
+  const float* A; int64_t sab, sai, sak;
+  const float* B; int64_t sbb, sbk, sbj;
+  float* C; int64_t scb, sci, scj;
+  int M, N, K, accumulate;
+};
+__global__ __launch_bounds__(256) void bmm_small_kernel(BmmArgs g) {
+  __shared__ float sa[16][17], sb[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int b = blockIdx.z, i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const float* A = g.A + (int64_t)b * g.sab;
+  const float* Bm = g.B + (int64_t)b * g.sbb;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const int ia = i0 + ty, ka = k0 + tx;
+    sa[ty][tx] = (ia < g.M && ka < g.K) ? A[(int64_t)ia * g.sai + (int64_t)ka * g.sak] : 0.f;
+    const int kb = k0 + ty, jb = j0 + tx;
+    sb[ty][tx] = (kb < g.K && jb < g.N) ? Bm[(int64_t)kb * g.sbk + (int64_t)jb * g.sbj] : 0.f;
+    __syncthreads();
+    const int kk = g.K - k0 < 16 ? g.K - k0 : 16;     // (the zero padding must not enter the chain: 0 * inf = nan)
+    for (int t = 0; t < kk; ++t) acc = fmaf(sa[ty][t], sb[t][tx], acc);
+    __syncthreads();
+  }
+  const int i = i0 + ty, j = j0 + tx;
+  if (i < g.M && j < g.N) {
+    float* c = g.C + (int64_t)b * g.scb + (int64_t)i * g.sci + (int64_t)j * g.scj;
+    *c = g.accumulate ? *c + acc : acc;
+  }
+}
+
+// ---- Y = LayerNorm(relu(Z)) over the C columns of every row, and its adjoint (ASTGCN block tail, astgcn.py:476-478:
+// `self._layer_norm(F.relu(X + X_hat))` — Z is the sum the two convolutions left in one buffer).  One 64-lane wavefront per
+// row group: a row of C <= 256 floats sits in registers (C / 64 per lane), mean / variance by shuffles.  eps as
+// torch.nn.LayerNorm (biased variance).  Rows are picked by a two-level map (row r of Y <- row (r / rp) * hi + (r % rp) * lo
+// of Z) so that a strided time convolution reads its own outputs and skips the padding rows.
+template <int CPL>
+__global__ __launch_bounds__(256) void relu_layernorm_kernel(const float* __restrict__ Z, int64_t rp, int64_t hi, int64_t lo,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int64_t rows, int C, float* __restrict__ Y,
+                                                             float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* z = Z + ((r / rp) * hi + (r % rp) * lo) * C;
+  float v[CPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int c = lane + 64 * q;
+    v[q] = c < C ? fmaxf(z[c], 0.f) : 0.f;
+    sum += v[q];
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float var = 0.f;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int c = lane + 64 * q;
+    const float d = c < C ? v[q] - mean : 0.f;
+    var = fmaf(d, d, var);
+  }
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = 1.f / sqrtf(var / (float)C + eps);
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int c = lane + 64 * q;
+    if (c < C) Y[r * C + c] = (v[q] - mean) * rstd * gamma[c] + beta[c];
+  }
+  if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+}
+
+// adjoint: dZ (same row map as Z; rows the map does not reach stay untouched: the caller zeroes the buffer) and
+// per-row-group partial sums of dgamma / dbeta (added with atomics)
+template <int CPL>
+__global__ __launch_bounds__(256) void relu_layernorm_bwd_kernel(const float* __restrict__ Z, int64_t rp, int64_t hi, int64_t lo,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                                 const float* __restrict__ dY, int64_t rows, int C,
+                                                                 float* __restrict__ dZ, float* dgamma, float* dbeta) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t zr = ((r / rp) * hi + (r % rp) * lo) * C;
+  const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+  float zv[CPL], xh[CPL], g[CPL];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int c = lane + 64 * q;
+    zv[q] = c < C ? Z[zr + c] : 0.f;
+    const float a = fmaxf(zv[q], 0.f);
+    xh[q] = c < C ? (a - mean) * rstd : 0.f;
+    const float dy = c < C ? dY[r * C + c] : 0.f;
+    g[q] = c < C ? dy * gamma[c] : 0.f;
+    s1 += g[q];
+    s2 = fmaf(g[q], xh[q], s2);
+    if (c < C) {
+      atomicAdd(&dgamma[c], dy * xh[q]);
+      atomicAdd(&dbeta[c], dy);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  const float inv = 1.f / (float)C;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int c = lane + 64 * q;
+    if (c < C) {
+      const float da = rstd * (g[q] - inv * s1 - xh[q] * inv * s2);
+      dZ[zr + c] = zv[q] > 0.f ? da : 0.f;
+    }
+  }
+}
+
 inline int grid1d(int64_t total, const char* what, dim3* grid) {
   const int64_t nb = pgt_cdiv(total, 256);
   if (nb >= ((int64_t)1 << 31)) {
@@ -137,4 +255,50 @@ extern "C" int pgt_att_sigmoid_bwd_f32(const float* sig, const float* dsig, int6
   if (int e = grid1d(n * n, "pgt_att_sigmoid_bwd_f32", &grid)) return e;
   PGT_LAUNCH(att_sigmoid_bwd_kernel, grid, dim3(256), stream, sig, dsig, (int)B, (int)n, dP, dbias);
   return pgt_check_launch("pgt_att_sigmoid_bwd_f32");
+}
+
+extern "C" int pgt_bmm_f32(const float* A, int64_t sab, int64_t sai, int64_t sak, const float* B, int64_t sbb, int64_t sbk,
+                           int64_t sbj, float* C, int64_t scb, int64_t sci, int64_t scj, int64_t nb, int64_t M, int64_t N,
+                           int64_t K, int accumulate, pgt_stream_t stream) {
+  PGT_REQUIRE(nb >= 0 && M >= 0 && N >= 0 && K >= 0, "pgt_bmm_f32: negative size");
+  if (nb == 0 || M == 0 || N == 0) return PGT_OK;
+  PGT_REQUIRE(C != nullptr && (K == 0 || (A && B)), "pgt_bmm_f32: null pointer");
+  PGT_REQUIRE(M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31) && K < ((int64_t)1 << 31), "pgt_bmm_f32: size exceeds int32");
+  PGT_REQUIRE(nb <= 65535 && pgt_cdiv(M, 16) <= 65535, "pgt_bmm_f32: more than 65 535 batches or row tiles (fold the batch into the rows)");
+  BmmArgs g{A, sab, sai, sak, B, sbb, sbk, sbj, C, scb, sci, scj, (int)M, (int)N, (int)K, accumulate};
+  dim3 grid((unsigned)pgt_cdiv(N, 16), (unsigned)pgt_cdiv(M, 16), (unsigned)nb);
+  PGT_LAUNCH(bmm_small_kernel, grid, dim3(256), stream, g);
+  return pgt_check_launch("pgt_bmm_f32");
+}
+
+extern "C" int pgt_relu_layernorm_f32(const float* Z, int64_t row_period, int64_t stride_hi, int64_t stride_lo, const float* gamma,
+                                      const float* beta, float eps, int64_t rows, int64_t C, float* Y, float* stats,
+                                      pgt_stream_t stream) {
+  PGT_REQUIRE(rows >= 0 && C >= 0, "pgt_relu_layernorm_f32: negative size");
+  if (rows == 0 || C == 0) return PGT_OK;
+  PGT_REQUIRE(Z && gamma && beta && Y && stats, "pgt_relu_layernorm_f32: null pointer");
+  PGT_REQUIRE(C <= 256 && row_period >= 1, "pgt_relu_layernorm_f32: at most 256 columns, row_period >= 1");
+  dim3 grid;
+  if (int e = grid1d(rows * 64, "pgt_relu_layernorm_f32", &grid)) return e;
+  const int cpl = (int)pgt_cdiv(C, 64);
+#define PGT_LN_GO(Q_) PGT_LAUNCH((relu_layernorm_kernel<Q_>), grid, dim3(256), stream, Z, row_period, stride_hi, stride_lo, gamma, beta, eps, rows, (int)C, Y, stats)
+  if (cpl == 1) PGT_LN_GO(1); else if (cpl == 2) PGT_LN_GO(2); else PGT_LN_GO(4);
+#undef PGT_LN_GO
+  return pgt_check_launch("pgt_relu_layernorm_f32");
+}
+
+extern "C" int pgt_relu_layernorm_bwd_f32(const float* Z, int64_t row_period, int64_t stride_hi, int64_t stride_lo,
+                                          const float* gamma, const float* stats, const float* dY, int64_t rows, int64_t C,
+                                          float* dZ, float* dgamma, float* dbeta, pgt_stream_t stream) {
+  PGT_REQUIRE(rows >= 0 && C >= 0, "pgt_relu_layernorm_bwd_f32: negative size");
+  if (rows == 0 || C == 0) return PGT_OK;
+  PGT_REQUIRE(Z && gamma && stats && dY && dZ && dgamma && dbeta, "pgt_relu_layernorm_bwd_f32: null pointer");
+  PGT_REQUIRE(C <= 256 && row_period >= 1, "pgt_relu_layernorm_bwd_f32: at most 256 columns, row_period >= 1");
+  dim3 grid;
+  if (int e = grid1d(rows * 64, "pgt_relu_layernorm_bwd_f32", &grid)) return e;
+  const int cpl = (int)pgt_cdiv(C, 64);
+#define PGT_LN_GO(Q_) PGT_LAUNCH((relu_layernorm_bwd_kernel<Q_>), grid, dim3(256), stream, Z, row_period, stride_hi, stride_lo, gamma, stats, dY, rows, (int)C, dZ, dgamma, dbeta)
+  if (cpl == 1) PGT_LN_GO(1); else if (cpl == 2) PGT_LN_GO(2); else PGT_LN_GO(4);
+#undef PGT_LN_GO
+  return pgt_check_launch("pgt_relu_layernorm_bwd_f32");
 }

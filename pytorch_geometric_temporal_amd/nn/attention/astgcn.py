@@ -77,8 +77,9 @@ def _init_like_reference(module):
 
 class SpatialAttention(torch.nn.Module):
     r"""Spatial attention of ASTGCN (reference: astgcn.py:201-262): X [B, N, F, T] -> S [B, N, N],
-    S = softmax_dim1( Vs . sigmoid( (X W1 W2) (W3 X)^T + bs ) ).  The two embeddings are small torch products; the
-    [B, N, N] part (product, bias, sigmoid, Vs product, softmax) is ops.AttentionScoresFunction (csrc/attention.hip)."""
+    S = softmax_dim1( Vs . sigmoid( (X W1 W2) (W3 X)^T + bs ) ).  The embeddings are strided small products on pgt_bmm_f32
+    (ops.bmm: no transposed copies); the [B, N, N] part (product, bias, sigmoid, Vs product, softmax) is
+    ops.AttentionScoresFunction (csrc/attention.hip)."""
 
     def __init__(self, in_channels: int, num_of_vertices: int, num_of_timesteps: int):
         super().__init__()
@@ -90,8 +91,13 @@ class SpatialAttention(torch.nn.Module):
         _init_like_reference(self)
 
     def forward(self, X):
-        lhs = torch.matmul(torch.matmul(X, self._W1), self._W2)          # [B, N, T]
-        rhs = torch.matmul(self._W3, X).transpose(-1, -2)                # [B, T, N]
+        B, N, F_, T = X.shape
+        Xc = X.contiguous()
+        # (X W1) W2: [B N F, T] x [T, 1], then [B N, F] x [F, T]  (astgcn.py:252)
+        a = ops.bmm(Xc.view(1, B * N * F_, T), self._W1.view(1, T, 1)).view(1, B * N, F_)
+        lhs = ops.bmm(a, self._W2.unsqueeze(0)).view(B, N, T)                                        # [B, N, T]
+        # W3 X: the contraction runs over F inside every [F, T] block — a [1, F] row vector shared by the B N blocks (:256)
+        rhs = ops.bmm(self._W3.view(1, F_), Xc.view(B * N, F_, T)).view(B, N, T).transpose(-1, -2)   # [B, T, N]
         # V . sigmoid(lhs rhs + b) and the softmax over dim 1: fused score kernel, one MFMA GEMM for the batch, softmax
         return ops.AttentionScoresFunction.apply(lhs, rhs, self._bs, self._Vs)
 
@@ -109,8 +115,13 @@ class TemporalAttention(torch.nn.Module):
         _init_like_reference(self)
 
     def forward(self, X):
-        lhs = torch.matmul(torch.matmul(X.permute(0, 3, 2, 1), self._U1), self._U2)   # [B, T, N]
-        rhs = torch.matmul(self._U3, X)                                                # [B, N, T]
+        B, N, F_, T = X.shape
+        Xc = X.contiguous()
+        # (X^T U1) U2: the contraction over the nodes is a [1, N] row vector times the [N, F T] view of every batch entry,
+        # then a[b] viewed [T, F] (strides 1, T) times U2 [F, N]  (astgcn.py:318)
+        a = ops.bmm(self._U1.view(1, N), Xc.view(B, N, F_ * T)).view(B, F_, T)
+        lhs = ops.bmm(a.transpose(1, 2), self._U2)                                                    # [B, T, N]
+        rhs = ops.bmm(self._U3.view(1, F_), Xc.view(B * N, F_, T)).view(B, N, T)                      # [B, N, T]  (:322)
         return ops.AttentionScoresFunction.apply(lhs, rhs, self._be, self._Ve)
 
 
@@ -145,25 +156,26 @@ class ASTGCNBlock(torch.nn.Module):
     def forward(self, X, edge_index):
         B, N, Fin, T = X.shape
         E = self._temporal_attention(X)                                               # [B, T, T]
-        X_tilde = torch.matmul(X.reshape(B, -1, T), E).reshape(B, N, Fin, T)
+        X_tilde = ops.bmm(X.contiguous().view(B, N * Fin, T), E).view(B, N, Fin, T)   # X E per batch entry (astgcn.py:437)
         S = self._spatial_attention(X_tilde)                                          # [B, N, N]
         conv = self._chebconv_attention
+        Xcl = X.permute(0, 1, 3, 2).contiguous()                                      # [B, N, T, Fin] channels last
         if not isinstance(edge_index, list):
             lam = self._lambda_max(edge_index, N)
             if conv._normalization != "sym" and lam is None:
                 raise ValueError("You need to pass `lambda_max` to `forward() in`case the normalization is non-symmetric.")
             g = ops.cheb_graph(edge_index, None, N, conv._normalization, 2.0 if lam is None else lam, variant=1)
-            out = ops.ChebConvAttentionFunction.apply(X.permute(0, 1, 3, 2), S, conv._weight, conv._bias, g,
-                                                      conv._weight.size(0))           # [B, N, T, O]
-            X_hat = torch.relu(out.permute(0, 1, 3, 2))                               # [B, N, O, T]
+            out = ops.ChebConvAttentionFunction.apply(Xcl, S, conv._weight, conv._bias, g, conv._weight.size(0))   # [B, N, T, O]
         else:                                                                         # one graph per time step
-            steps = [conv(X[:, :, :, t], edge_index[t], S, lambda_max=self._lambda_max(edge_index[t], N)).unsqueeze(-1)
+            steps = [conv(X[:, :, :, t], edge_index[t], S, lambda_max=self._lambda_max(edge_index[t], N)).unsqueeze(2)
                      for t in range(T)]
-            X_hat = torch.relu(torch.cat(steps, dim=-1))
-        X_hat = self._time_convolution(X_hat.permute(0, 2, 1, 3))
-        Xr = self._residual_convolution(X.permute(0, 2, 1, 3))
-        out = self._layer_norm(torch.relu(Xr + X_hat).permute(0, 3, 2, 1))
-        return out.permute(0, 2, 3, 1)
+            out = torch.cat(steps, dim=2)                                             # [B, N, T, O]
+        # time convolution + residual convolution + relu + LayerNorm on channels-last rows: one segmented GEMM for the three
+        # taps, the residual accumulated into it, relu + LayerNorm in one pass (ops.TimeConvResidualNormFunction)
+        tc, rc, ln = self._time_convolution, self._residual_convolution, self._layer_norm
+        y = ops.TimeConvResidualNormFunction.apply(torch.relu(out), Xcl, tc.weight, tc.bias, rc.weight, rc.bias, ln.weight,
+                                                   ln.bias, tc.stride[1], ln.eps)    # [B, N, T_out, Ft]
+        return y.permute(0, 1, 3, 2)                                                  # [B, N, Ft, T_out]
 
 
 class ASTGCN(torch.nn.Module):

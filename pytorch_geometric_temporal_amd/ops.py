@@ -1344,8 +1344,8 @@ class AttentionScoresFunction(torch.autograd.Function):
     astgcn.py:226-262, and TemporalAttention, :291-328): L [B, n, m], R [B, m, n], bias [1, n, n] or [n, n], V [n, n]
     -> S [B, n, n].  Three launches forward (fused L R + bias + sigmoid; ONE MFMA GEMM for the whole batch on the
     [i][b][j] layout; softmax over dim 1) instead of five torch ops with [B, n, n] temporaries; hand-written backward
-    (softmax and sigmoid adjoints, two GEMMs); the two small products with L and R that close the chain are batched
-    library GEMMs."""
+    (softmax and sigmoid adjoints, two GEMMs); the two small products with L and R that close the chain run on
+    pgt_bmm_f32."""
 
     @staticmethod
     def forward(ctx, L, R, bias, V):
@@ -1392,10 +1392,145 @@ class AttentionScoresFunction(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 dbias = db.view(ctx.bias_shape)
             if ctx.needs_input_grad[0]:
-                dL = torch.bmm(dP, Rc.transpose(1, 2))                                    # [B, n, m]
+                dL = _bmm_raw(dP, Rc.transpose(1, 2), torch.empty(B, n, m, dtype=F32, device=dev))     # [B, n, m]
             if ctx.needs_input_grad[1]:
-                dR = torch.bmm(Lc.transpose(1, 2), dP)                                    # [B, m, n]
+                dR = _bmm_raw(Lc.transpose(1, 2), dP, torch.empty(B, m, n, dtype=F32, device=dev))     # [B, m, n]
         return dL, dR, dbias, dV
+
+
+# --------------------------------------------------------------------------------------------- small batched products
+
+def _bmm_raw(A, B, C, accumulate=False):
+    """pgt_bmm_f32 on 3-D views [nb, M, K] x [nb, K, N] -> [nb, M, N]; strides are taken as they are (an expanded
+    dimension has stride 0, a transposed view swapped strides): no copies."""
+    lib = _lib.get_lib()
+    for t, n in ((A, "A"), (B, "B"), (C, "C")):
+        check_tensor(lib, t, n)
+    nb, M, K = A.shape
+    N = B.size(2)
+    if B.shape != (nb, K, N) or C.shape != (nb, M, N):
+        raise ValueError(f"bmm: shapes {tuple(A.shape)} x {tuple(B.shape)} -> {tuple(C.shape)}")
+    lib.call("pgt_bmm_f32", ptr(A), *A.stride(), ptr(B), *B.stride(), ptr(C), *C.stride(), nb, M, N, K,
+             int(bool(accumulate)), stream_of(lib, C))
+    return C
+
+
+class BmmFunction(torch.autograd.Function):
+    """C[b] = A[b] B[b] for small matrices on pgt_bmm_f32 (the embeddings around ASTGCN's attention: astgcn.py:252-256,
+    :318-322, :437).  Operands are 3-D views with any strides; gradients come back in the operands' (possibly expanded)
+    shapes, so a matrix shared by the batch gets its sum over the batch from `expand`'s own adjoint."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        C = torch.empty(A.size(0), A.size(1), B.size(2), dtype=F32, device=A.device)
+        _bmm_raw(A, B, C)
+        ctx.save_for_backward(A, B)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty(A.shape, dtype=F32, device=dC.device)
+            _bmm_raw(dC, B.transpose(1, 2), dA)
+        if ctx.needs_input_grad[1]:
+            dB = torch.empty(B.shape, dtype=F32, device=dC.device)
+            _bmm_raw(A.transpose(1, 2), dC, dB)
+        return dA, dB
+
+
+def bmm(A, B):
+    """[nb, M, K] x [nb, K, N] (2-D operands are shared by the batch) -> [nb, M, N]."""
+    nb = A.size(0) if A.dim() == 3 else B.size(0)
+    if A.dim() == 2:
+        A = A.unsqueeze(0).expand(nb, -1, -1)
+    if B.dim() == 2:
+        B = B.unsqueeze(0).expand(nb, -1, -1)
+    return BmmFunction.apply(A, B)
+
+
+class TimeConvResidualNormFunction(torch.autograd.Function):
+    """The tail of an ASTGCN block (astgcn.py:463-478): time convolution Conv2d(O -> Ft, (1, 3), stride (1, s), padding
+    (0, 1)) of the graph convolution's output + residual Conv2d(Fin -> Ft, (1, 1), stride (1, s)) of the block input ->
+    relu -> LayerNorm(Ft), on channels-last rows (b, n, t).
+
+    Xh [B, N, T, O] (already relu'd), Xcl [B, N, T, Fin] -> [B, N, T_out, Ft].  The three taps of the time convolution are
+    ONE product on pgt_gemm_f32: the rows live in a buffer with a zero row before and after every (b, n) series, and the
+    K-segmented operand takes segment j = the same buffer shifted by j rows (segment stride = one row), so no im2col copy
+    exists; the residual convolution accumulates into the same output; relu + LayerNorm pick the strided rows and skip the
+    padding rows (pgt_relu_layernorm_f32).  Backward: LayerNorm / relu adjoint, two weight-gradient products on
+    pgt_gemm_tn_acc_f32 with the same shifted segments, three accumulating products for the taps' input gradient."""
+
+    @staticmethod
+    def forward(ctx, Xh, Xcl, Wt, bt, Wr, br, gamma, beta, stride, eps):
+        lib = _lib.get_lib()
+        for t, n in ((Xh, "Xh"), (Xcl, "Xcl"), (Wt, "Wt"), (Wr, "Wr"), (gamma, "gamma"), (beta, "beta")):
+            check_tensor(lib, t, n)
+        B, N, T, O = Xh.shape
+        Fin, Ft = Xcl.size(3), Wt.size(0)
+        if Xcl.shape != (B, N, T, Fin) or Wt.shape != (Ft, O, 1, 3) or Wr.shape != (Ft, Fin, 1, 1):
+            raise ValueError("TimeConvResidualNormFunction: inconsistent operand shapes")
+        dev = Xh.device
+        BN, Tp, s = B * N, T + 2, int(stride)
+        M = BN * Tp
+        P = torch.zeros(M + 2, O, dtype=F32, device=dev)          # row (bn, tp) = Xh at t = tp - 1; zero rows at tp = 0, T + 1
+        P[:M].view(BN, Tp, O)[:, 1:T + 1].copy_(Xh.reshape(BN, T, O))
+        Q = torch.zeros(M, Fin, dtype=F32, device=dev)            # row (bn, tp) = X at t = tp
+        Q.view(BN, Tp, Fin)[:, :T].copy_(Xcl.reshape(BN, T, Fin))
+        W3 = Wt[:, :, 0, :].permute(2, 1, 0).reshape(3 * O, Ft).contiguous()        # W3[dt * O + o, c] = Wt[c, o, 0, dt]
+        WrT = Wr[:, :, 0, 0].t().contiguous()                                        # [Fin, Ft]
+        bias = None
+        if bt is not None or br is not None:
+            bias = (bt if bt is not None else 0) + (br if br is not None else 0)
+            bias = bias.contiguous()
+        Z = torch.empty(M, Ft, dtype=F32, device=dev)
+        gemm(P, O, O, 3, O, W3, Ft, 1, Z, Ft, 0, Ft, bias, M, Ft)                     # segment j = the buffer shifted by j rows
+        gemm(Q, Fin, 0, 1, Fin, WrT, Ft, 1, Z, Ft, 0, Ft, None, M, Ft, accumulate=True)
+        T_out = (T - 1) // s + 1
+        rows = BN * T_out
+        Y = torch.empty(rows, Ft, dtype=F32, device=dev)
+        stats = torch.empty(rows, 2, dtype=F32, device=dev)
+        gc, bc = gamma.contiguous(), beta.contiguous()
+        lib.call("pgt_relu_layernorm_f32", ptr(Z), T_out, Tp, s, ptr(gc), ptr(bc), float(eps), rows, Ft, ptr(Y), ptr(stats),
+                 stream_of(lib, Z))
+        ctx.save_for_backward(P, Q, W3, WrT, Z, stats, gc)
+        ctx.dims = (B, N, T, O, Fin, Ft, s, T_out)
+        ctx.has_bias = (bt is not None, br is not None)
+        return Y.view(B, N, T_out, Ft)
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = _lib.get_lib()
+        P, Q, W3, WrT, Z, stats, gc = ctx.saved_tensors
+        B, N, T, O, Fin, Ft, s, T_out = ctx.dims
+        dev = dY.device
+        BN, Tp = B * N, T + 2
+        M, rows = BN * Tp, BN * T_out
+        dYc = dY.contiguous().view(rows, Ft)
+        dZ = torch.zeros(M, Ft, dtype=F32, device=dev)            # padding / skipped rows carry no gradient
+        dgamma, dbeta = torch.zeros(Ft, dtype=F32, device=dev), torch.zeros(Ft, dtype=F32, device=dev)
+        lib.call("pgt_relu_layernorm_bwd_f32", ptr(Z), T_out, Tp, s, ptr(gc), ptr(stats), ptr(dYc), rows, Ft, ptr(dZ),
+                 ptr(dgamma), ptr(dbeta), stream_of(lib, dZ))
+        dW3 = torch.zeros(3 * O, Ft, dtype=F32, device=dev)
+        db = torch.zeros(Ft, dtype=F32, device=dev)
+        gemm_tn_acc(P, O, O, 3, O, dZ, Ft, dW3, Ft, db, M, Ft)
+        dWt = dW3.view(3, O, Ft).permute(2, 1, 0).unsqueeze(2).contiguous()          # [Ft, O, 1, 3]
+        dWrT = torch.zeros(Fin, Ft, dtype=F32, device=dev)
+        gemm_tn_acc(Q, Fin, 0, 1, Fin, dZ, Ft, dWrT, Ft, None, M, Ft)
+        dWr = dWrT.t().contiguous().view(Ft, Fin, 1, 1)
+        dXh = dXcl = None
+        if ctx.needs_input_grad[0]:
+            dP = torch.zeros(M + 2, O, dtype=F32, device=dev)
+            for dt in range(3):          # dP[m + dt] += dZ[m] W3[dt]^T : B(k = c, n = o) = W3[dt * O + o, c]
+                gemm(dZ, Ft, 0, 1, Ft, W3[dt * O:(dt + 1) * O], 1, Ft, dP[dt:], O, 0, O, None, M, O, accumulate=True)
+            dXh = dP[:M].view(BN, Tp, O)[:, 1:T + 1].reshape(B, N, T, O)
+        if ctx.needs_input_grad[1]:
+            dQ = torch.empty(M, Fin, dtype=F32, device=dev)
+            gemm(dZ, Ft, 0, 1, Ft, WrT, 1, Ft, dQ, Fin, 0, Fin, None, M, Fin)          # B(k = c, n = f) = WrT[f, c]
+            dXcl = dQ.view(BN, Tp, Fin)[:, :T].reshape(B, N, T, Fin)
+        return (dXh, dXcl, dWt, db if ctx.has_bias[0] else None, dWr, db if ctx.has_bias[1] else None, dgamma, dbeta,
+                None, None)
 
 
 # --------------------------------------------------------------------------------------------- attention Chebyshev conv

@@ -422,6 +422,65 @@ def test_gconvgru_oracle_reproduces_the_reference_fixture():
     assert_close_with_nonfinite(b, g["out"]["H_state_rw"], 2e-6, 2e-6, "rw")
 
 
+@pytest.mark.parametrize("stride,Fin,O,Ft,T", [(1, 1, 8, 16, 6), (2, 3, 5, 64, 7), (3, 4, 12, 70, 12)])
+def test_time_conv_residual_layernorm_block_tail_against_torch_modules(backend, stride, Fin, O, Ft, T):
+    """ops.TimeConvResidualNormFunction (three conv taps as ONE row-shifted segmented GEMM, the residual 1 x 1 convolution
+    accumulated into it, relu + LayerNorm in one pass) against the reference's module chain (astgcn.py:463-478:
+    Conv2d(1 x 3, stride (1, s), padding (0, 1)) + Conv2d(1 x 1, stride (1, s)) -> relu -> LayerNorm), forward and every
+    gradient, for strides 1 - 3 and widths beyond one wavefront's 64 lanes."""
+    from pytorch_geometric_temporal_amd import ops
+    torch.manual_seed(stride + Ft)
+    B, N = 2, 5
+    tc = torch.nn.Conv2d(O, Ft, kernel_size=(1, 3), stride=(1, stride), padding=(0, 1))
+    rc = torch.nn.Conv2d(Fin, Ft, kernel_size=(1, 1), stride=(1, stride))
+    ln = torch.nn.LayerNorm(Ft)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.5, 0.5)
+    Xh = torch.rand(B, N, T, O)                       # the relu'd graph convolution, channels last
+    X = torch.randn(B, N, Fin, T)
+    w = torch.randn(B, N, Ft, (T - 1) // stride + 1)
+    Xh_r, X_r = Xh.clone().requires_grad_(), X.clone().requires_grad_()
+    ref = ln(torch.relu(rc(X_r.permute(0, 2, 1, 3)) + tc(Xh_r.permute(0, 3, 1, 2))).permute(0, 3, 2, 1)).permute(0, 2, 3, 1)
+    (ref * w).sum().backward()
+    ref_grads = [p.grad.clone() for p in list(tc.parameters()) + list(rc.parameters()) + list(ln.parameters())]
+    for m in (tc, rc, ln):
+        m.zero_grad()
+        m.to(backend.device)
+    Xh_d, X_d = backend.t(Xh).requires_grad_(), backend.t(X).requires_grad_()
+    y = ops.TimeConvResidualNormFunction.apply(Xh_d, X_d.permute(0, 1, 3, 2).contiguous(), tc.weight, tc.bias, rc.weight,
+                                               rc.bias, ln.weight, ln.bias, stride, ln.eps).permute(0, 1, 3, 2)
+    (y * backend.t(w)).sum().backward()
+    assert_close_with_nonfinite(y, ref, 2e-5, 2e-5, "block tail")
+    assert_close_with_nonfinite(Xh_d.grad, Xh_r.grad, 5e-5, 1e-4, "d/d conv output")
+    assert_close_with_nonfinite(X_d.grad, X_r.grad, 5e-5, 1e-4, "d/d block input")
+    for p, r in zip(list(tc.parameters()) + list(rc.parameters()) + list(ln.parameters()), ref_grads):
+        assert_close_with_nonfinite(p.grad, r, 1e-4 * float(r.abs().max() + 1), 1e-4, "parameter gradient")
+
+
+def test_small_batched_product_with_strided_and_shared_operands(backend):
+    """pgt_bmm_f32 / ops.bmm: transposed views, a matrix shared by the batch (stride 0), row and column vectors, odd sizes;
+    values and gradients against torch.matmul."""
+    from pytorch_geometric_temporal_amd import ops
+    g = torch.Generator().manual_seed(5)
+    cases = [((7, 33, 12), (7, 12, 12), False), ((4, 19, 5), (5, 40), False), ((1, 50, 9), (1, 9, 1), False),
+             ((6, 3, 17), (6, 17, 21), True)]
+    for sa, sb, transpose_a in cases:
+        A, Bm = torch.randn(*sa, generator=g), torch.randn(*sb, generator=g)
+        if transpose_a:
+            A = A.transpose(1, 2).contiguous()
+        Ar, Br = A.clone().requires_grad_(), Bm.clone().requires_grad_()
+        ref = torch.matmul(Ar.transpose(1, 2) if transpose_a else Ar, Br)
+        w = torch.randn(ref.shape, generator=g)
+        (ref * w).sum().backward()
+        Ad, Bd = backend.t(A).requires_grad_(), backend.t(Bm).requires_grad_()
+        out = ops.bmm(Ad.transpose(1, 2) if transpose_a else Ad, Bd)
+        (out * backend.t(w)).sum().backward()
+        assert_close_with_nonfinite(out, ref, 1e-5, 1e-5, "bmm")
+        assert_close_with_nonfinite(Ad.grad, Ar.grad, 1e-5, 1e-5, "dA")
+        assert_close_with_nonfinite(Bd.grad, Br.grad, 2e-5, 2e-5, "dB")
+
+
 # ------------------------------------------------------------------------------------------------ ASTGCN / MSTGCN (§8f)
 
 def test_astgcn_matches_reference_fixture_and_backpropagates(backend):

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void window_gather_kernel(const float* __restr
   const int64_t b = (e / (WV * h)) % B;
   const int which = (int)(e / (WV * h * B));         // 0: the input window, 1: the target window
   int64_t row = idx[b] + t + (which ? h : 0);
-  row = row < 0 ? 0 : (row < T_total ? row : T_total - 1);   // the host validates the indices; never read outside
+  row = row < 0 ? 0 : (row < T_total ? row : T_total - 1);   // never read outside the series: the CALLER guarantees the range (IndexDataset.gather checks it once)
   float v[V];
   pgt_ldv<V>(data + row * W + w, v);
   float* out = which ? Y : X;

@@ -435,11 +435,13 @@ class PemsDatasetLoader(object):
     def get_index_dataset(self, lags: int = 12, batch_size: int = 64, shuffle: bool = False, allGPU: int = -1,
                           ratio: Tuple[float, float, float] = (0.7, 0.1, 0.2), world_size: int = -1,
                           ddp_rank: int = -1, dask_batching: bool = False):
-        """(train, val, test DataLoaders, edges [2, E], edge_weights [E], means, stds) exactly as pems.py:71-179
-        returns them: float64 windows on the CPU path, float32 device-resident windows when `allGPU` names a GPU."""
+        """(train, val, test DataLoaders, edges [2, E], edge_weights [E], means, stds) as pems.py:71-179 returns them:
+        float64 windows on the CPU path, float32 device-resident windows when `allGPU` names a GPU.  One difference in
+        the last digits: the z-score statistics are the cache's (numpy, population std, float64) on both paths, where the
+        reference's allGPU path uses torch.std (unbiased, float32) — a factor sqrt(T / (T - 1)) on `stds`."""
         edges = torch.from_numpy(np.array(self._cache.edge_index, dtype=np.int64))
         edge_weights = torch.from_numpy(np.array(self._cache.edge_weight))
-        data = np.array(self._cache.series)
+        data = np.asarray(self._cache.series)         # (no copy: the loaders index it, the GPU path converts it once)
         means = torch.tensor(np.asarray(self._cache.means), dtype=torch.float)
         stds = torch.tensor(np.asarray(self._cache.stds), dtype=torch.float)
         if allGPU != -1:

@@ -259,6 +259,10 @@ class _GraphCache:
         return (t.data_ptr(), tensor_version(t), tuple(t.shape), tuple(t.stride()), str(t.device), t.dtype)
 
     def get(self, tag, edge_index, edge_weight, extra, builder):
+        # inference tensors carry no version counter, so an in-place edit under torch.inference_mode() would go unnoticed:
+        # graphs given as inference tensors are prepared on every call instead of being cached
+        if any(t is not None and t.is_inference() for t in (edge_index, edge_weight)):
+            return builder()
         key = (tag, self._tkey(edge_index), self._tkey(edge_weight), extra)
         hit = self._d.get(key)
         if hit is not None:
@@ -521,6 +525,19 @@ def gemm_gru_h(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, bias, ht, zr, H
         hp, ldh, op, ld0, m0, o1, ld1, M, O, stream_of(lib, ht)), tag=("NN+h", M, O, n_seg, seg_k, O, 0))
 
 
+_DET_WS = {}
+
+
+def _det_workspace(device, n_floats):
+    """Scratch of the atomics-free weight gradient, one buffer per device, grown on demand (the entry point sizes it for
+    the most slabs any schedule launches; allocating it per call — T times per BPTT — is what the advisor flagged)."""
+    key = (device.type, device.index)
+    ws = _DET_WS.get(key)
+    if ws is None or ws.numel() < n_floats:
+        ws = _DET_WS[key] = torch.empty(n_floats, dtype=F32, device=device)
+    return ws
+
+
 def gemm_tn_acc(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N):
     lib = _lib.get_lib()
     for t, n in ((A, "A"), (G, "G"), (dW, "dW")):
@@ -531,7 +548,7 @@ def gemm_tn_acc(A, lda, a_seg_stride, n_seg, seg_k, G, ldg, dW, lddw, db, M, N):
     if DETERMINISTIC_WEIGHT_GRADIENTS:
         # no float atomics: per-slab partial sums in a scratch buffer, added in slab order (bitwise reproducible)
         nbytes = int(lib._pgt_gemm_tn_det_ws_bytes(n_seg, seg_k, N, lddw))
-        ws = torch.empty(max(nbytes // 4, 1), dtype=F32, device=G.device)
+        ws = _det_workspace(G.device, max(nbytes // 4, 1))
         _timed("gemm_tn", 2.0 * M * N * n_seg * seg_k, lambda: lib.call(
             "pgt_gemm_tn_det_f32", ptr(A), lda, a_seg_stride, n_seg, seg_k, ptr(G), ldg, ptr(dW), lddw, ptr(db), M, N,
             ptr(ws), nbytes, st), tag=(M, N, n_seg, seg_k))
@@ -591,7 +608,9 @@ def swap01(src, D0, D1, W):
 def window_gather(data, starts, horizon, time_major=False):
     """(X, Y) index-batch windows of a resident series `data` [T, ...] at the int64 start indices `starts` [B]
     (pgt_window_gather_f32): X[b] = data[s_b : s_b + h], Y[b] = data[s_b + h : s_b + 2 h]; shapes [B, h, ...] or, with
-    time_major, [h, B, ...]."""
+    time_major, [h, B, ...].  The caller guarantees 0 <= s_b <= T - 2 h (the start indices live on the device: checking
+    them here would be a host sync per batch; IndexDataset.gather validates its index array once) — the kernel clamps rows
+    that fall outside instead of reading past the series."""
     lib = _lib.get_lib()
     check_tensor(lib, data, "data")
     check_tensor(lib, starts, "starts", torch.int64)

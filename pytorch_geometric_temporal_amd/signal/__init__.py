@@ -255,8 +255,25 @@ class IndexDataset(torch.utils.data.Dataset):
                     torch.from_numpy(self.data[y_start:y_start + self.horizon, ...].compute()))
         return torch.from_numpy(self.data[idx:y_start, ...]), torch.from_numpy(self.data[y_start:y_start + self.horizon, ...])
 
+    def _check_window_range(self):
+        """Every start index must leave room for both windows (idx + 2 h <= T): the reference's slicing would hand back a
+        short window, the fused gather kernel clamps rows instead of reading outside the series — neither is what a
+        caller wants, so the range is checked once, where the indices are (one reduction; cached)."""
+        if getattr(self, "_range_checked", False):
+            return
+        n = int(self.data.shape[0])
+        idx = self.indices
+        if len(idx):
+            lo = int(idx.min())
+            hi = int(idx.max())
+            if lo < 0 or hi + 2 * int(self.horizon) > n:
+                raise IndexError(f"IndexDataset: start indices span [{lo}, {hi}] but windows of 2 x {self.horizon} steps "
+                                 f"need 0 <= idx <= {n - 2 * int(self.horizon)} (series length {n})")
+        self._range_checked = True
+
     def gather(self, batch_indices, device=None):
         """Whole batch in one fused gather from a resident [T, N, F] tensor: -> (X [B,h,N,F], Y [B,h,N,F])."""
+        self._check_window_range()
         data = self.data if isinstance(self.data, torch.Tensor) else torch.from_numpy(np.asarray(self.data))
         if device is not None:
             data = data.to(device)

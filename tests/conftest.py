@@ -31,7 +31,8 @@ def build_emu_library():
     csrc = os.path.join(ROOT, "pytorch_geometric_temporal_amd", "csrc")
     srcs = sorted(glob.glob(os.path.join(csrc, "*.hip")))
     deps = srcs + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(ROOT, "include", "pgt_hip.h"),
-                                                          os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h")]
+                                                          os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h")] + \
+        glob.glob(os.path.join(ROOT, "tests", "hipemu", "*.h"))
     if os.path.exists(EMU_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(EMU_PATH) for d in deps):
         return EMU_PATH
     os.makedirs(EMU_DIR, exist_ok=True)

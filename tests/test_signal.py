@@ -156,3 +156,17 @@ def test_resident_signal_and_index_batches_on_the_gpu():
         assert torch.equal(X[j].cpu(), x) and torch.equal(Y[j].cpu(), y)
     xg, yg = gpu_ds[230]
     assert torch.equal(xg.cpu(), cpu_ds[230][0])
+
+
+def test_index_dataset_gather_rejects_windows_that_leave_the_series():
+    """An index that leaves no room for both windows would be clamped by the fused gather kernel (and silently shortened by
+    the reference's slicing): IndexDataset.gather checks the index array once and raises."""
+    import numpy as np
+    from pytorch_geometric_temporal_amd.signal import IndexDataset
+    data = np.arange(40 * 3 * 2, dtype=np.float32).reshape(40, 3, 2)
+    ok = IndexDataset(np.arange(0, 40 - 2 * 6 + 1), data, 6)
+    X, Y = ok.gather(np.array([0, 28]))
+    assert X.shape == (2, 6, 3, 2) and float(Y[1, -1, 0, 0]) == float(data[39, 0, 0])
+    bad = IndexDataset(np.arange(0, 40 - 2 * 6 + 2), data, 6)
+    with pytest.raises(IndexError, match="start indices"):
+        bad.gather(np.array([0]))

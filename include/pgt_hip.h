@@ -312,6 +312,24 @@ int pgt_gemm_gru_h_f32(const float* A, int64_t lda, int64_t a_seg_stride, int64_
                        const float* H, int64_t ldh, float* out0, int64_t ld0, const pgt_rowmap* map0, float* out1,
                        int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream);
 
+/* ---------------------------------------------------------------- DCRNN cell plumbing (one launch each) */
+
+/* The three DConv weights of a DCRNN cell, Wz / Wr / Wh [2, K, C, O] (conv_x_{z,r,h}.weight, dcrnn.py:26-37, :138-160),
+ * packed into the operands of the two gate products: Wzr [(2K-1) C, 2O] (update | reset), Whs [(2K-1) C, O] (candidate);
+ * segment 0 = W[0,0] + W[1,0] (the reference multiplies X by both, dcrnn.py:81-83), segment 2k-1+d = W[d,k]; bzr [2O] =
+ * bz | br (all three NULL for bias-free cells).  The adjoint scatters the packed gradients back into the parameters'
+ * shapes (NULL dWzr / dWhs count as zero).  One launch each way instead of the ~8 / ~10 torch slice / add / cat launches per
+ * call — the bulk of a per-snapshot step on a 20-node graph. */
+int pgt_dcrnn_pack_weights_f32(const float* Wz, const float* Wr, const float* Wh, const float* bz, const float* br, int64_t K,
+                               int64_t C, int64_t O, float* Wzr, float* bzr, float* Whs, pgt_stream_t stream);
+int pgt_dcrnn_unpack_weight_grads_f32(const float* dWzr, const float* dbzr, const float* dWhs, int64_t K, int64_t C, int64_t O,
+                                      float* dWz, float* dWr, float* dWh, float* dbz, float* dbr, pgt_stream_t stream);
+/* Inputs of a DCRNN sequence into its diffusion stacks: X [T * M, Fin] into the input columns of segment 0 of both stacks
+ * (TSzr0 / TSh0: [T * M, Fin + O], dcrnn.py:173,185 `torch.cat([X, H])`) and the initial state H0 [M, O] into step 0 of the
+ * gate stack — one launch for three strided copies. */
+int pgt_dcrnn_stage_f32(const float* X, const float* H0, int64_t T, int64_t M, int64_t Fin, int64_t O, float* TSzr0,
+                        float* TSh0, pgt_stream_t stream);
+
 /* ---------------------------------------------------------------- GRU gate chains */
 
 /* DCRNN (dcrnn.py:172-192):  pre_zr [M,2*O] holds the two DConv outputs (bias included).

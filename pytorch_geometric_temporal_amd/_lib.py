@@ -114,6 +114,10 @@ PROTOTYPES = {
     "pgt_att_softmax_rows_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "pgt_att_sigmoid_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "pgt_window_gather_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
+    "pgt_dcrnn_pack_weights_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "pgt_dcrnn_unpack_weight_grads_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                                  c_ptr]),
+    "pgt_dcrnn_stage_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "pgt_bmm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64,
                             c_i64, c_i64, c_int, c_ptr]),
     "pgt_relu_layernorm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -297,6 +297,79 @@ __global__ __launch_bounds__(256) void window_gather_kernel(const float* __restr
   pgt_stv<V>(out + (time_major ? (t * B + b) : (b * h + t)) * W + w, v);
 }
 
+// ---- DCRNN cell weights (dcrnn.py:26-37, :138-160): the three DConv weights [2, K, C, O] -> the stacked operands of the
+// two gate products, [(2K-1) C, 2O] (z | r) and [(2K-1) C, O] (candidate); segment 0 = W[0,0] + W[1,0] (the reference
+// computes X W[0,0] + X W[1,0], dcrnn.py:81-83), segment 2k-1+d = W[d,k]; the z | r bias is the concatenation.  ONE launch
+// each way instead of the ~8 / ~10 torch slice / add / cat launches a forward / backward pass paid for it — which is
+// what a per-snapshot loop over a small graph (Chickenpox: 20 nodes) spends its time on.
+__global__ __launch_bounds__(256) void dcrnn_pack_weights_kernel(const float* __restrict__ Wz, const float* __restrict__ Wr,
+                                                                 const float* __restrict__ Wh, const float* __restrict__ bz,
+                                                                 const float* __restrict__ br, int K, int C, int O,
+                                                                 float* __restrict__ Wzr, float* __restrict__ bzr,
+                                                                 float* __restrict__ Whs) {
+  const int S = 2 * K - 1;
+  const int64_t total = (int64_t)S * C * 3 * O;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < 2 * O && bzr != nullptr) bzr[e] = e < O ? bz[e] : br[e - O];
+  if (e >= total) return;
+  const int o3 = (int)(e % (3 * O));
+  const int64_t sc = e / (3 * O);
+  const int c = (int)(sc % C), seg = (int)(sc / C);
+  const int gate = o3 / O, o = o3 - gate * O;                       // 0 = z, 1 = r, 2 = candidate
+  const float* W = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);          // [2][K][C][O]
+  const int64_t KCO = (int64_t)K * C * O;
+  float v;
+  if (seg == 0) v = W[(int64_t)c * O + o] + W[KCO + (int64_t)c * O + o];
+  else {
+    const int k = (seg + 1) >> 1, d = (seg + 1) & 1;                // seg = 2k - 1 + d
+    v = W[d * KCO + ((int64_t)k * C + c) * O + o];
+  }
+  if (gate < 2) Wzr[((int64_t)seg * C + c) * 2 * O + gate * O + o] = v;
+  else Whs[((int64_t)seg * C + c) * O + o] = v;
+}
+// adjoint: dW[0,0] = dW[1,0] = d segment 0; dW[d,k] = d segment 2k-1+d; dbz | dbr = the halves of dbzr
+__global__ __launch_bounds__(256) void dcrnn_unpack_grads_kernel(const float* __restrict__ dWzr, const float* __restrict__ dbzr,
+                                                                 const float* __restrict__ dWhs, int K, int C, int O,
+                                                                 float* __restrict__ dWz, float* __restrict__ dWr,
+                                                                 float* __restrict__ dWh, float* dbz, float* dbr) {
+  const int64_t KCO = (int64_t)K * C * O;
+  const int64_t total = 3 * 2 * KCO;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < 2 * O && dbzr != nullptr) { if (e < O) dbz[e] = dbzr[e]; else dbr[e - O] = dbzr[e]; }
+  if (e >= total) return;
+  const int gate = (int)(e / (2 * KCO));
+  const int64_t r = e - gate * 2 * KCO;
+  const int d = (int)(r / KCO);
+  const int64_t kco = r - d * KCO;
+  const int o = (int)(kco % O), c = (int)((kco / O) % C), k = (int)(kco / ((int64_t)C * O));
+  const int seg = k == 0 ? 0 : 2 * k - 1 + d;
+  float v;
+  if (gate < 2) v = dWzr != nullptr ? dWzr[((int64_t)seg * C + c) * 2 * O + gate * O + o] : 0.f;
+  else v = dWhs != nullptr ? dWhs[((int64_t)seg * C + c) * O + o] : 0.f;
+  (gate == 0 ? dWz : (gate == 1 ? dWr : dWh))[e - gate * 2 * KCO] = v;
+}
+
+// ---- DCRNN sequence inputs: the input columns of segment 0 of both stacks for all T steps and the initial state into
+// step 0 of the gate stack — one launch for what was three strided copies
+__global__ __launch_bounds__(256) void dcrnn_stage_kernel(const float* __restrict__ X, const float* __restrict__ H0, int64_t TM,
+                                                          int64_t M, int Fin, int O, float* __restrict__ TSzr0,
+                                                          float* __restrict__ TSh0) {
+  const int C = Fin + O;
+  const int64_t nx = TM * Fin, total = nx + M * O;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  if (e < nx) {
+    const int64_t m = e / Fin;
+    const int f = (int)(e - m * Fin);
+    const float v = X[e];
+    TSzr0[m * C + f] = v;
+    TSh0[m * C + f] = v;
+  } else {
+    const int64_t q = e - nx, m = q / O;
+    TSzr0[m * C + Fin + (int)(q - m * O)] = H0[q];
+  }
+}
+
 inline int grid_for(int64_t total, const char* what, dim3* grid) {
   const int64_t nb = pgt_cdiv(total, 256);
   if (nb >= ((int64_t)1 << 31)) {
@@ -442,6 +515,44 @@ extern "C" int pgt_lstm_gates_bwd_f32(const float* gates, const float* C, int64_
   PGT_VDISPATCH(v, lstm_gates_bwd_kernel, grid, block, stream, gates, C, ldc, Cn, ldcn, wci, wcf, wco, dH, lddh, dCn,
                 lddcn, dP, dC, lddc, dw, M, (int)O, (int)rpb);
   return pgt_check_launch("pgt_lstm_gates_bwd_f32");
+}
+
+extern "C" int pgt_dcrnn_pack_weights_f32(const float* Wz, const float* Wr, const float* Wh, const float* bz, const float* br,
+                                          int64_t K, int64_t C, int64_t O, float* Wzr, float* bzr, float* Whs,
+                                          pgt_stream_t stream) {
+  PGT_REQUIRE(K >= 1 && C >= 1 && O >= 1, "pgt_dcrnn_pack_weights_f32: bad size");
+  PGT_REQUIRE(Wz && Wr && Wh && Wzr && Whs, "pgt_dcrnn_pack_weights_f32: null pointer");
+  PGT_REQUIRE((bzr == nullptr) == (bz == nullptr) && (bz == nullptr) == (br == nullptr),
+              "pgt_dcrnn_pack_weights_f32: the gate biases go together");
+  dim3 grid;
+  const int64_t total = (2 * K - 1) * C * 3 * O;
+  if (int e = grid_for(total > 2 * O ? total : 2 * O, "pgt_dcrnn_pack_weights_f32", &grid)) return e;
+  PGT_LAUNCH(dcrnn_pack_weights_kernel, grid, dim3(256), stream, Wz, Wr, Wh, bz, br, (int)K, (int)C, (int)O, Wzr, bzr, Whs);
+  return pgt_check_launch("pgt_dcrnn_pack_weights_f32");
+}
+
+extern "C" int pgt_dcrnn_unpack_weight_grads_f32(const float* dWzr, const float* dbzr, const float* dWhs, int64_t K, int64_t C,
+                                                 int64_t O, float* dWz, float* dWr, float* dWh, float* dbz, float* dbr,
+                                                 pgt_stream_t stream) {
+  PGT_REQUIRE(K >= 1 && C >= 1 && O >= 1, "pgt_dcrnn_unpack_weight_grads_f32: bad size");
+  PGT_REQUIRE(dWz && dWr && dWh, "pgt_dcrnn_unpack_weight_grads_f32: null pointer");
+  PGT_REQUIRE(dbzr == nullptr || (dbz && dbr), "pgt_dcrnn_unpack_weight_grads_f32: null bias gradient");
+  dim3 grid;
+  const int64_t total = 6 * K * C * O;
+  if (int e = grid_for(total > 2 * O ? total : 2 * O, "pgt_dcrnn_unpack_weight_grads_f32", &grid)) return e;
+  PGT_LAUNCH(dcrnn_unpack_grads_kernel, grid, dim3(256), stream, dWzr, dbzr, dWhs, (int)K, (int)C, (int)O, dWz, dWr, dWh, dbz, dbr);
+  return pgt_check_launch("pgt_dcrnn_unpack_weight_grads_f32");
+}
+
+extern "C" int pgt_dcrnn_stage_f32(const float* X, const float* H0, int64_t T, int64_t M, int64_t Fin, int64_t O, float* TSzr0,
+                                   float* TSh0, pgt_stream_t stream) {
+  PGT_REQUIRE(T >= 0 && M >= 0 && Fin >= 0 && O >= 1, "pgt_dcrnn_stage_f32: bad size");
+  if (T == 0 || M == 0) return PGT_OK;
+  PGT_REQUIRE((Fin == 0 || X) && H0 && TSzr0 && TSh0, "pgt_dcrnn_stage_f32: null pointer");
+  dim3 grid;
+  if (int e = grid_for(T * M * Fin + M * O, "pgt_dcrnn_stage_f32", &grid)) return e;
+  PGT_LAUNCH(dcrnn_stage_kernel, grid, dim3(256), stream, X, H0, T * M, M, (int)Fin, (int)O, TSzr0, TSh0);
+  return pgt_check_launch("pgt_dcrnn_stage_f32");
 }
 
 extern "C" int pgt_copy2d_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t M, int64_t W,

@@ -63,11 +63,9 @@ class BatchedDConv(DConv):
 
 
 def _cell_weights(conv_z, conv_r, conv_h):
-    Wz, Wr, Wh = ops.stack_weight(conv_z.weight), ops.stack_weight(conv_r.weight), ops.stack_weight(conv_h.weight)
-    Wzr = torch.cat([Wz, Wr], dim=1)
-    bzr = None
-    if conv_z.bias is not None:
-        bzr = torch.cat([conv_z.bias, conv_r.bias])
+    """The stacked operands of the two gate products from the three convolutions' parameters: one launch
+    (ops.CellWeightsFunction) instead of three weight re-stackings and two concatenations."""
+    Wzr, bzr, Wh = ops.CellWeightsFunction.apply(conv_z.weight, conv_r.weight, conv_h.weight, conv_z.bias, conv_r.bias)
     return Wzr, bzr, Wh, conv_h.bias
 
 

@@ -752,6 +752,53 @@ def stack_weight(weight):
     return _StackWeight.apply(weight)
 
 
+class CellWeightsFunction(torch.autograd.Function):
+    """conv_x_{z,r,h}.weight [2, K, C, O] (+ the z / r biases) -> (Wzr [(2K-1) C, 2O], bzr [2O] | None, Wh [(2K-1) C, O]):
+    the stacked operands of the two gate products, one launch forward and one backward (pgt_dcrnn_pack_weights_f32)."""
+
+    @staticmethod
+    def forward(ctx, Wz, Wr, Wh, bz, br):
+        lib = _lib.get_lib()
+        for t, n in ((Wz, "conv_x_z.weight"), (Wr, "conv_x_r.weight"), (Wh, "conv_x_h.weight")):
+            check_tensor(lib, t, n)
+        _, K, C, O = Wz.shape
+        if Wr.shape != Wz.shape or Wh.shape != Wz.shape or (bz is None) != (br is None):
+            raise ValueError("CellWeightsFunction: the three convolutions must have one shape and agree on bias")
+        dev = Wz.device
+        S = 2 * K - 1
+        Wzr = torch.empty(S * C, 2 * O, dtype=F32, device=dev)
+        Whs = torch.empty(S * C, O, dtype=F32, device=dev)
+        bzr = torch.empty(2 * O, dtype=F32, device=dev) if bz is not None else None
+        Wzc, Wrc, Whc = Wz.contiguous(), Wr.contiguous(), Wh.contiguous()
+        lib.call("pgt_dcrnn_pack_weights_f32", ptr(Wzc), ptr(Wrc), ptr(Whc), ptr(bz.contiguous() if bz is not None else None),
+                 ptr(br.contiguous() if br is not None else None), K, C, O, ptr(Wzr), ptr(bzr), ptr(Whs), stream_of(lib, Wzr))
+        ctx.dims = (K, C, O)
+        ctx.has_bias = bz is not None
+        if bzr is None:
+            return Wzr, None, Whs
+        return Wzr, bzr, Whs
+
+    @staticmethod
+    def backward(ctx, dWzr, dbzr, dWhs):
+        lib = _lib.get_lib()
+        K, C, O = ctx.dims
+        ref = dWzr if dWzr is not None else dWhs
+        if ref is None:
+            return None, None, None, None, None
+        dev = ref.device
+        dWz, dWr, dWh = (torch.empty(2, K, C, O, dtype=F32, device=dev) for _ in range(3))
+        dbz = dbr = None
+        if ctx.has_bias:
+            dbz, dbr = torch.empty(O, dtype=F32, device=dev), torch.empty(O, dtype=F32, device=dev)
+            if dbzr is None:
+                dbzr = torch.zeros(2 * O, dtype=F32, device=dev)
+        lib.call("pgt_dcrnn_unpack_weight_grads_f32", ptr(dWzr.contiguous() if dWzr is not None else None),
+                 ptr(dbzr.contiguous() if (ctx.has_bias and dbzr is not None) else None),
+                 ptr(dWhs.contiguous() if dWhs is not None else None), K, C, O, ptr(dWz), ptr(dWr), ptr(dWh), ptr(dbz), ptr(dbr),
+                 stream_of(lib, dWz))
+        return dWz, dWr, dWh, dbz, dbr
+
+
 class DConvFunction(torch.autograd.Function):
     """H = DConv(X) for node-major X [N*B, C]: diffusion stack (SpMM) + one segmented MFMA GEMM."""
 
@@ -912,16 +959,13 @@ class DCRNNSeqFunction(torch.autograd.Function):
             else:
                 _stack_fwd(g, TSx, t, K, Nn)
 
-        # the input columns of segment 0 of both stacks, all T steps in one launch each
-        copy2d(TSzr[0].view(T * M, C)[:, :Fin], X.view(T * M, Fin))
-        copy2d(TSh[0].view(T * M, C)[:, :Fin], X.view(T * M, Fin))
+        # the input columns of segment 0 of both stacks (all T steps) and H0 into step 0 of the gate stack: one launch
+        lib.call("pgt_dcrnn_stage_f32", ptr(X), ptr(H0c), T, M, Fin, O, ptr(TSzr[0]), ptr(TSh[0]), stream_of(lib, X))
         fuse = FUSE_GATE_EPILOGUES and O % 4 == 0
         for t in range(T):
             # H_{t-1}: the plain [M, O] state, or (btno: the states live in the [B, T, N, O] result) the hidden columns of
             # this step's stack segment 0, which the previous step's blend wrote
             Hp = H0c if t == 0 else (TSzr[0, t][:, Fin:] if btno else Hout[t - 1])
-            if t == 0:
-                copy2d(TSzr[0, t][:, Fin:], Hp)     # later steps: written by the previous step's blend
             Hnext = TSzr[0, t + 1][:, Fin:] if t + 1 < T else None
             Ht = state.step(t) if btno else Hout[t]
             stack(TSzr, t)

@@ -330,6 +330,26 @@ int pgt_dcrnn_unpack_weight_grads_f32(const float* dWzr, const float* dbzr, cons
 int pgt_dcrnn_stage_f32(const float* X, const float* H0, int64_t T, int64_t M, int64_t Fin, int64_t O, float* TSzr0,
                         float* TSh0, pgt_stream_t stream);
 
+/* ---------------------------------------------------------------- EvolveGCN weight evolution (one launch) */
+
+/* W_t from W_{t-1} for one snapshot (evolvegcnh.py:78-102: TopKPooling summary of X_t -> torch.nn.GRU -> weight;
+ * evolvegcno.py:170-191 with pool = 0: the weight is the GRU's input and hidden state):
+ *   pool != 0:  s_i = tanh(X_i . p / |p|), perm = the k rows with the largest s (ties: lowest index; nan ranks first, as
+ *               torch.sort(descending) has it), xt_j = X[perm_j] * s[perm_j];   pool == 0:  xt = Wprev
+ *   GRU cell with torch.nn.GRU's parameters (weight_ih_l0 / weight_hh_l0 [3F, F], gates r | z | n; biases [3F] or both NULL)
+ *   on the k rows of Wprev [k, F] as its batch -> Wnew [k, F].
+ * perm [k] (int32), score [k], gates [4 k F] (r, z, n, W_hn h + b_hn), xt [k F] are kept for the adjoint, which returns
+ * every gradient in one launch as well: dWih / dWhh [3F, F], dbih / dbhh [3F], dWprev [k, F], and for pool != 0 dp [F] and
+ * the k selected rows of dX [N, F] (the caller zero-fills dX; the selection carries no gradient).  F, k <= 64, N <= 4096.
+ * One workgroup each: ~25 (forward) / ~40 (backward) torch and MIOpen launches per snapshot become one. */
+int pgt_evolve_weight_f32(const float* X, int64_t ldx, int64_t N, const float* p, const float* Wih, const float* Whh,
+                          const float* bih, const float* bhh, const float* Wprev, int64_t F, int64_t k, int pool, float* Wnew,
+                          int32_t* perm, float* score, float* gates, float* xt, pgt_stream_t stream);
+int pgt_evolve_weight_bwd_f32(const float* dWnew, const float* X, int64_t ldx, int64_t N, const float* p, const float* Wih,
+                              const float* Whh, const float* Wprev, const int32_t* perm, const float* score, const float* gates,
+                              const float* xt, int64_t F, int64_t k, int pool, float* dX, int64_t lddx, float* dp, float* dWih,
+                              float* dWhh, float* dbih, float* dbhh, float* dWprev, pgt_stream_t stream);
+
 /* ---------------------------------------------------------------- GRU gate chains */
 
 /* DCRNN (dcrnn.py:172-192):  pre_zr [M,2*O] holds the two DConv outputs (bias included).

@@ -118,6 +118,10 @@ PROTOTYPES = {
     "pgt_dcrnn_unpack_weight_grads_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_ptr]),
     "pgt_dcrnn_stage_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "pgt_evolve_weight_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr,
+                                      c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "pgt_evolve_weight_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                          c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_bmm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64,
                             c_i64, c_i64, c_int, c_ptr]),
     "pgt_relu_layernorm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -3,13 +3,29 @@ torch_geometric_temporal/nn/recurrent/evolvegcnh.py and evolvegcno.py.
 
 The per-snapshot work that scales with the graph — gcn_norm of the (changing) edge list and the aggregation
 A_hat (X W_t) — runs on the HIP kernels (graph prep on the device, one aggregation launch, MFMA GEMM for X W_t).
-The weight evolution W_t = GRU(., W_{t-1}) acts on an F x F matrix (8 x 8 in the reference's example): it stays a
-torch.nn.GRU so that `recurrent_layer.*` keeps the reference's parameter names and initialisation.
+The weight evolution W_t = GRU(., W_{t-1}) acts on an F x F matrix (8 x 8 in the reference's example): the modules stay a
+TopKPooling / torch.nn.GRU pair so that `pooling_layer.*` / `recurrent_layer.*` keep the reference's parameter names and
+initialisation, but the arithmetic — scoring, top-k, the GRU cell and every gradient — is ONE launch each way
+(csrc/evolve.hip) instead of ~25 / ~40 torch and MIOpen launches per snapshot.
 """
 import torch
 
 from ... import ops
 from ..conv import TopKPooling, glorot_
+
+
+def _pooled_rows(ratio, n, dtype):
+    """k of TopKPooling: an int ratio as it is, else ceil(ratio * N) computed in the score dtype (PyG)."""
+    if isinstance(ratio, int):
+        return min(ratio, n)
+    return int((float(ratio) * torch.tensor(n).to(dtype)).ceil().to(torch.long))
+
+
+def _fused_evolution_applies(X, in_channels, k, pooled=True):
+    """The one-launch weight evolution covers the reference's shapes: fp32, the GRU's batch = the k pooled rows = in_channels
+    <= 64, at most 4096 nodes; anything else keeps the module path (TopKPooling + torch.nn.GRU)."""
+    return (X.dtype == torch.float32 and k == in_channels and 1 <= in_channels <= 64 and X.dim() == 2 and
+            (not pooled or (k <= X.size(0) <= 4096)))
 
 
 class GCNConv_Fixed_W(torch.nn.Module):
@@ -73,10 +89,19 @@ class EvolveGCNH(torch.nn.Module):
                                           add_self_loops=self.add_self_loops)
 
     def forward(self, X, edge_index, edge_weight=None):
-        X_tilde = self.pooling_layer(X, edge_index)
-        X_tilde = X_tilde[0][None, :, :]
         h0 = self.initial_weight if self.weight is None else self.weight
-        _, self.weight = self.recurrent_layer(X_tilde, h0)
+        k = _pooled_rows(self.pooling_layer.ratio, X.size(0), X.dtype)
+        if _fused_evolution_applies(X, self.in_channels, k):
+            # top-k summary -> GRU cell -> W_t, and every gradient, in one launch each way (ops.EvolveWeightFunction); the
+            # modules keep the reference's parameters (pooling_layer.select.weight, recurrent_layer.*_l0)
+            rl = self.recurrent_layer
+            self.weight = ops.EvolveWeightFunction.apply(X, self.pooling_layer.select.weight, rl.weight_ih_l0, rl.weight_hh_l0,
+                                                         getattr(rl, "bias_ih_l0", None), getattr(rl, "bias_hh_l0", None),
+                                                         h0, k).unsqueeze(0)
+        else:
+            X_tilde = self.pooling_layer(X, edge_index)
+            X_tilde = X_tilde[0][None, :, :]
+            _, self.weight = self.recurrent_layer(X_tilde, h0)
         return self.conv_layer(self.weight.squeeze(dim=0), X, edge_index, edge_weight)
 
 
@@ -110,5 +135,11 @@ class EvolveGCNO(torch.nn.Module):
 
     def forward(self, X, edge_index, edge_weight=None):
         w = self.initial_weight if self.weight is None else self.weight
-        _, self.weight = self.recurrent_layer(w, w)
+        if _fused_evolution_applies(X, self.in_channels, self.in_channels, pooled=False):
+            rl = self.recurrent_layer
+            self.weight = ops.EvolveWeightFunction.apply(None, None, rl.weight_ih_l0, rl.weight_hh_l0,
+                                                         getattr(rl, "bias_ih_l0", None), getattr(rl, "bias_hh_l0", None),
+                                                         w, self.in_channels).unsqueeze(0)
+        else:
+            _, self.weight = self.recurrent_layer(w, w)
         return self.conv_layer(self.weight.squeeze(dim=0), X, edge_index, edge_weight)

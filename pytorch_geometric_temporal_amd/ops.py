@@ -1461,6 +1461,59 @@ class AttentionScoresFunction(torch.autograd.Function):
         return dL, dR, dbias, dV
 
 
+# --------------------------------------------------------------------------------------------- EvolveGCN weight evolution
+
+class EvolveWeightFunction(torch.autograd.Function):
+    """W_t = GRU(summary(X_t), W_{t-1}) (EvolveGCN-H, evolvegcnh.py:93-100) or GRU(W_{t-1}, W_{t-1}) (EvolveGCN-O,
+    evolvegcno.py:185-187) in ONE launch forward and ONE backward (pgt_evolve_weight(_bwd)_f32): top-k scoring / selection,
+    the GRU cell on the 8 x 8 state and every gradient.  X may be None (O variant)."""
+
+    @staticmethod
+    def forward(ctx, X, p, Wih, Whh, bih, bhh, Wprev, k):
+        lib = _lib.get_lib()
+        pool = X is not None
+        for t, n in ((Wih, "weight_ih"), (Whh, "weight_hh"), (Wprev, "weight")) + (((X, "X"), (p, "select.weight")) if pool else ()):
+            check_tensor(lib, t, n)
+        F_ = Wprev.size(-1)
+        k = int(k)
+        Wp = Wprev.reshape(-1, F_).contiguous()
+        if Wp.size(0) != k or Wih.shape != (3 * F_, F_) or Whh.shape != (3 * F_, F_):
+            raise ValueError("EvolveWeightFunction: the GRU's batch must be the k pooled rows (k == in_channels in the reference)")
+        dev = Wp.device
+        Xc = X.contiguous() if pool else None
+        pc = p.reshape(-1).contiguous() if pool else None
+        Wihc, Whhc = Wih.contiguous(), Whh.contiguous()
+        Wnew = torch.empty(k, F_, dtype=F32, device=dev)
+        perm = torch.empty(k, dtype=I32, device=dev)
+        score = torch.empty(k, dtype=F32, device=dev)
+        gates = torch.empty(4, k, F_, dtype=F32, device=dev)
+        xt = torch.empty(k, F_, dtype=F32, device=dev)
+        lib.call("pgt_evolve_weight_f32", ptr(Xc), Xc.stride(0) if pool else 0, Xc.size(0) if pool else 0, ptr(pc), ptr(Wihc),
+                 ptr(Whhc), ptr(bih.contiguous() if bih is not None else None), ptr(bhh.contiguous() if bhh is not None else None),
+                 ptr(Wp), F_, k, int(pool), ptr(Wnew), ptr(perm), ptr(score), ptr(gates), ptr(xt), stream_of(lib, Wp))
+        ctx.save_for_backward(Xc, pc, Wihc, Whhc, Wp, perm, score, gates, xt)
+        ctx.pool, ctx.has_bias, ctx.prev_shape, ctx.p_shape = pool, bih is not None, Wprev.shape, (p.shape if pool else None)
+        return Wnew
+
+    @staticmethod
+    def backward(ctx, dWnew):
+        lib = _lib.get_lib()
+        Xc, pc, Wihc, Whhc, Wp, perm, score, gates, xt = ctx.saved_tensors
+        k, F_ = Wp.shape
+        dev = dWnew.device
+        dWih, dWhh = torch.empty_like(Wihc), torch.empty_like(Whhc)
+        dbih = torch.empty(3 * F_, dtype=F32, device=dev) if ctx.has_bias else None
+        dbhh = torch.empty(3 * F_, dtype=F32, device=dev) if ctx.has_bias else None
+        dWprev = torch.empty(k, F_, dtype=F32, device=dev)
+        dX = torch.zeros_like(Xc) if ctx.pool else None
+        dp = torch.empty(F_, dtype=F32, device=dev) if ctx.pool else None
+        lib.call("pgt_evolve_weight_bwd_f32", ptr(dWnew.contiguous()), ptr(Xc), Xc.stride(0) if ctx.pool else 0,
+                 Xc.size(0) if ctx.pool else 0, ptr(pc), ptr(Wihc), ptr(Whhc), ptr(Wp), ptr(perm), ptr(score), ptr(gates), ptr(xt),
+                 F_, k, int(ctx.pool), ptr(dX), dX.stride(0) if ctx.pool else 0, ptr(dp), ptr(dWih), ptr(dWhh), ptr(dbih),
+                 ptr(dbhh), ptr(dWprev), stream_of(lib, dWprev))
+        return (dX, dp.view(ctx.p_shape) if ctx.pool else None, dWih, dWhh, dbih, dbhh, dWprev.view(ctx.prev_shape), None)
+
+
 # --------------------------------------------------------------------------------------------- small batched products
 
 def _bmm_raw(A, B, C, accumulate=False):

@@ -481,6 +481,60 @@ def test_small_batched_product_with_strided_and_shared_operands(backend):
         assert_close_with_nonfinite(Bd.grad, Br.grad, 2e-5, 2e-5, "dB")
 
 
+@pytest.mark.parametrize("variant,n,F_,bias", [("H", 129, 8, True), ("H", 40, 5, False), ("O", 129, 8, True), ("H", 300, 16, True)])
+def test_evolve_weight_one_launch_against_topk_pooling_and_torch_gru(backend, variant, n, F_, bias):
+    """ops.EvolveWeightFunction (scoring, top-k, GRU cell and every gradient in one launch each way) against the module
+    chain it replaces — TopKPooling(select.weight) -> torch.nn.GRU over one step (evolvegcnh.py:93-100), or GRU(W, W)
+    (evolvegcno.py:185-187) — over three chained snapshots: the evolved weights and the gradients of X, the projection,
+    the four GRU parameters and the initial weight."""
+    from pytorch_geometric_temporal_amd import ops
+    from pytorch_geometric_temporal_amd.nn.conv import TopKPooling
+    torch.manual_seed(n + F_)
+    gru = torch.nn.GRU(input_size=F_, hidden_size=F_, num_layers=1, bias=bias)
+    pool = TopKPooling(F_, F_ / n)
+    W0 = torch.randn(1, F_, F_) * 0.5
+    Xs = [torch.randn(n, F_) for _ in range(3)]
+    ws = [torch.randn(F_, F_) for _ in range(3)]
+    # reference chain (CPU torch)
+    W0r = W0.clone().requires_grad_()
+    Xr = [x.clone().requires_grad_() for x in Xs]
+    w, loss = W0r, 0.0
+    ref_w = []
+    for x, wt in zip(Xr, ws):
+        if variant == "H":
+            xt = pool(x)[0][None]
+            _, w = gru(xt, w)
+        else:
+            _, w = gru(w, w)
+        ref_w.append(w.detach().clone())
+        loss = loss + (w[0] * wt).sum()
+    loss.backward()
+    ref_grads = [p.grad.clone() for p in list(gru.parameters()) + list(pool.parameters())] if variant == "H" else \
+                [p.grad.clone() for p in gru.parameters()]
+    ref_gx = [x.grad.clone() if x.grad is not None else None for x in Xr]
+    ref_gw0 = W0r.grad.clone()
+    for m in (gru, pool):
+        m.zero_grad()
+        m.to(backend.device)
+    W0d = backend.t(W0).requires_grad_()
+    Xd = [backend.t(x).requires_grad_() for x in Xs]
+    w, loss = W0d, 0.0
+    for i, (x, wt) in enumerate(zip(Xd, ws)):
+        args = (x, pool.select.weight) if variant == "H" else (None, None)
+        w = ops.EvolveWeightFunction.apply(*args, gru.weight_ih_l0, gru.weight_hh_l0, getattr(gru, "bias_ih_l0", None),
+                                           getattr(gru, "bias_hh_l0", None), w, F_).unsqueeze(0)
+        assert_close_with_nonfinite(w, ref_w[i], 2e-6, 2e-6, f"W_{i + 1}")
+        loss = loss + (w[0] * backend.t(wt)).sum()
+    loss.backward()
+    params = list(gru.parameters()) + (list(pool.parameters()) if variant == "H" else [])
+    for p, r in zip(params, ref_grads):
+        assert_close_with_nonfinite(p.grad, r, 2e-5 * float(r.abs().max() + 1), 1e-4, "parameter gradient")
+    assert_close_with_nonfinite(W0d.grad, ref_gw0, 2e-5, 1e-4, "d/dW_0")
+    if variant == "H":
+        for x, r in zip(Xd, ref_gx):
+            assert_close_with_nonfinite(x.grad, r, 2e-5, 1e-4, "d/dX")
+
+
 # ------------------------------------------------------------------------------------------------ ASTGCN / MSTGCN (§8f)
 
 def test_astgcn_matches_reference_fixture_and_backpropagates(backend):

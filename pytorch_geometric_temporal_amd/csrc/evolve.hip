@@ -39,19 +39,14 @@ __device__ __forceinline__ float ev_sigmoid(float x) { return 1.f / (1.f + expf(
 __global__ __launch_bounds__(EV_THREADS) void evolve_fwd_kernel(EvolveArgs a) {
   __shared__ float s_score[4096];
   __shared__ float s_xt[EV_MAX_K * EV_MAX_F];
-  __shared__ float s_red[EV_THREADS];
-  __shared__ int s_idx[EV_THREADS];
+  __shared__ int s_perm[EV_MAX_K];
+  __shared__ float s_sel[EV_MAX_K];
   __shared__ float s_norm;
   const int tid = threadIdx.x, F = a.F, k = a.k;
   if (a.pool) {
-    // |p|
-    float acc = 0.f;
-    for (int f = tid; f < F; f += EV_THREADS) acc = fmaf(a.p[f], a.p[f], acc);
-    s_red[tid] = acc;
-    __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {                                       // |p| (F <= 64 terms, index order)
       float t = 0.f;
-      for (int i = 0; i < EV_THREADS; ++i) t += s_red[i];
+      for (int f = 0; f < F; ++f) t = fmaf(a.p[f], a.p[f], t);
       s_norm = sqrtf(t);
     }
     __syncthreads();
@@ -63,49 +58,26 @@ __global__ __launch_bounds__(EV_THREADS) void evolve_fwd_kernel(EvolveArgs a) {
       s_score[i] = tanhf(d / nrm);
     }
     __syncthreads();
-    // top-k by k rounds of arg-max (k and N are tiny); key: nan above everything, ties to the lowest index
-    for (int j = 0; j < k; ++j) {
-      float best = -INFINITY;
-      int bi = -1;
-      bool best_nan = false;
-      for (int i = tid; i < a.N; i += EV_THREADS) {
-        const float v = s_score[i];
-        if (v == -INFINITY) continue;                  // taken in an earlier round
-        const bool vn = v != v;
-        const bool better = bi < 0 || (vn && !best_nan) || (!vn && !best_nan && v > best);   // ascending i: ties keep the first
-        if (better) { best = v; bi = i; best_nan = vn; }
+    // top-k by RANK: element i counts the elements ahead of it in the descending order (larger score; nan above everything,
+    // as torch.sort(descending=True) has it; ties to the lower index) out of LDS — every thread scans all N scores, no
+    // serial rounds; the k elements of rank < k write themselves to perm[rank]
+    for (int i = tid; i < a.N; i += EV_THREADS) {
+      const float v = s_score[i];
+      const bool vn = v != v;
+      int rank = 0;
+      for (int j = 0; j < a.N; ++j) {
+        const float u = s_score[j];
+        const bool un = u != u;
+        const bool ahead = un ? (!vn || j < i) : (!vn && (u > v || (u == v && j < i)));
+        rank += ahead ? 1 : 0;
       }
-      s_red[tid] = best;
-      s_idx[tid] = bi;
-      __syncthreads();
-      if (tid == 0) {
-        float bv = 0.f; int b = -1; bool bn = false;
-        for (int t = 0; t < EV_THREADS; ++t) {
-          const int i = s_idx[t];
-          if (i < 0) continue;
-          const float v = s_red[t];
-          const bool vn = v != v;
-          bool better;
-          if (b < 0) better = true;
-          else if (vn != bn) better = vn;
-          else if (vn) better = i < b;
-          else better = v > bv || (v == bv && i < b);
-          if (better) { bv = v; b = i; bn = vn; }
-        }
-        a.perm[j] = b;
-        a.score[j] = bv;
-        s_idx[0] = b;
-      }
-      __syncthreads();
-      const int sel = s_idx[0];
-      __syncthreads();
-      if (tid == 0 && sel >= 0) s_score[sel] = -INFINITY;   // taken (a real score is a tanh: never -inf)
-      __syncthreads();
+      if (rank < k) { a.perm[rank] = i; a.score[rank] = v; s_perm[rank] = i; s_sel[rank] = v; }
     }
+    __syncthreads();
     for (int e = tid; e < k * F; e += EV_THREADS) {
       const int j = e / F, f = e - j * F;
-      const int r = a.perm[j];
-      const float v = r >= 0 ? a.X[(int64_t)r * a.ldx + f] * a.score[j] : 0.f;
+      const int r = s_perm[j];
+      const float v = a.X[(int64_t)r * a.ldx + f] * s_sel[j];
       s_xt[e] = v;
       a.xt[e] = v;
     }

@@ -32,6 +32,11 @@ struct SlabArgs {
   int folded;           // backward only: the "- Tx_0" adjoint was folded into the weights (ops.fold_backward_weight)
 };
 
+#ifdef PGT_EMU
+constexpr int SLAB_CUS = 4;
+#else
+constexpr int SLAB_CUS = 256;
+#endif
 constexpr int SLAB_THREADS = 1024;
 constexpr int MAXT_CAP = 8;  // tasks (row, V-float column group) per thread: N * C / V <= MAXT_CAP * 1024
                              // (the kernels are instantiated for 2 / 4 / 7 / 8 tasks per thread: register arrays)
@@ -658,7 +663,7 @@ __device__ __forceinline__ SlabLds carve_q(char* base, const SlabArgs& a, int E)
 }
 // Task tid + j * 1024 of a sample.  Tasks 0 .. 16 N - 1 are the hidden quads, sixteen per row, so that a wavefront's lanes
 // 16 i .. 16 i + 15 own one row (the b128 lane groups then never meet on a bank); the N leading-pair tasks follow.
-template <int E, int MAXT>
+template <int E, int MAXT, int THREADS = SLAB_THREADS>
 struct SlabQTasks {
   int rj[MAXT];     // main: (row << 5) | quad (0 .. 15);  leading pair of a row: (row << 5) | 16
   int N, C, ntask, tid;
@@ -666,11 +671,11 @@ struct SlabQTasks {
     N = a.N; C = a.C; tid = tid_; ntask = a.N * (16 + (E > 0 ? 1 : 0));
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
-      const int idx = tid + j * SLAB_THREADS, ic = idx < ntask ? idx : ntask - 1;
+      const int idx = tid + j * THREADS, ic = idx < ntask ? idx : ntask - 1;
       rj[j] = ic < 16 * a.N ? (((ic >> 4) << 5) | (ic & 15)) : (((ic - 16 * a.N) << 5) | 16);
     }
   }
-  __device__ __forceinline__ bool live(int j) const { return tid + j * SLAB_THREADS < ntask; }
+  __device__ __forceinline__ bool live(int j) const { return tid + j * THREADS < ntask; }
   __device__ __forceinline__ int row(int j) const { return rj[j] >> 5; }
   __device__ __forceinline__ bool main_(int j) const { return E == 0 || (rj[j] & 16) == 0; }
   __device__ __forceinline__ int quad(int j) const { return rj[j] & 15; }
@@ -835,6 +840,12 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_q_kernel(SlabArgs
 }
 
 int g_slab_pairs = 2;   // pgt_tune("slab_pairs"): column pairs per lane of the LDS-resident stack kernels (1 | 2)
+// (Measured and dropped in round 3: a single-block form of these kernels — ONE [N, 64] block + the packed slots in LDS, 80.5 KB,
+// so that TWO 512-thread workgroups per CU work on whole samples and one's gathers run under the other's memory phase.  Seven
+// tasks per thread, the hop's two directions taking turns in the block: 112 us forward / 99 us backward against 77 - 78 us for
+// the kernels above.  With the column windows (103 - 123 us) that is the second design whose point was a second resident
+// workgroup, and the second that lost: on this part the phases of co-resident workgroups do not interleave usefully for this
+// access pattern.)
 int g_slab_gu = 2;        // pgt_tune("slab_gu"): LDS reads in flight per gather of the four-task backward quad kernels (2 | 4)
 int g_slab_quad = 1;      // pgt_tune("slab_quad"): 0 = C = 64 / 66 blocks on the pair-layout kernels (A/B)
 // the quad-layout kernels take C = 64 (16-byte aligned segments) or C = 66 (8-byte aligned), at most 4 tasks per thread
@@ -1153,11 +1164,6 @@ static bool slab_whole_ok(int64_t N, int64_t C, int64_t nnz_o, int64_t nnz_i) {
   return N * (C / V) <= (int64_t)MAXT_CAP * SLAB_THREADS &&        // (the narrowest element the launch may pick)
          slab_lds_bytes(N, C, nnz_o, nnz_i) <= 160 * 1024;
 }
-#ifdef PGT_EMU
-constexpr int SLAB_CUS = 4;
-#else
-constexpr int SLAB_CUS = 256;
-#endif
 
 // Measured on MI355X (scripts/slab_probe.py, METR-LA shape): with at least a sample per CU the whole-sample kernels win
 // (B = 1024, C = 66 forward: 90 us against 103 - 123 us for every windowed shape: a window is an 88-byte piece of each

@@ -48,7 +48,7 @@ def main():
     n, E, K = 207, 1515, 3
     ei, ew = syn.sensor_graph(n, E, seed=0, symmetric=False)
     g = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
-    configs = [("whole_pair", 0, 0, 0), ("whole", 0, 0, 0), ("whole_gu4", 0, 0, 0), ("auto", 1, 0, 0)]
+    configs = [("whole_pair", 0, 0, 0), ("whole", 0, 0, 0), ("whole_gu4", 0, 0, 0), ("whole_again", 0, 0, 0), ("auto", 1, 0, 0)]
     for ns in (() if whole_only else (2, 3, 4, 6, 8)):
         for wpc in (1, 2, 3):
             for th in (0, 512, 640, 1024):

@@ -47,7 +47,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 9
+#define PGT_ABI_VERSION 10
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -329,6 +329,26 @@ int pgt_dcrnn_unpack_weight_grads_f32(const float* dWzr, const float* dbzr, cons
  * gate stack — one launch for three strided copies. */
 int pgt_dcrnn_stage_f32(const float* X, const float* H0, int64_t T, int64_t M, int64_t Fin, int64_t O, float* TSzr0,
                         float* TSh0, pgt_stream_t stream);
+
+/* ---------------------------------------------------------------- DCRNN cell without diffusion (K = 1), one launch */
+
+/* The whole cell of DCRNN(in, out, K = 1) (dcrnn.py:79-82: DConv is `X @ W[0,0] + X @ W[1,0] + b`, the hop loop never
+ * runs; gates dcrnn.py:172-192) — BASELINE configs[0], examples/recurrent/dcrnn_example.py:19-28.  X [N, in] (row stride
+ * ldx), H [N, out] or NULL (= zeros, dcrnn.py:167-170), Wz / Wr / Wh in the parameters' own layout [2, 1, in + out, out],
+ * bz / br / bh [out] or NULL.  Writes H' [N, out] (row stride ldo) and saved [N, 3 out] = Z | R | candidate for the
+ * adjoint.  Limits (pgt_dcrnn_cell_k1_fits): 1 <= N <= 4096, out <= 64, in + out <= 128; PGT_ERR_INVALID beyond them
+ * (larger cells run through the general path).
+ * Adjoint (one workgroup): G = d/dH' [N, out]; dX [N, in] and dH [N, out] are written when non-NULL; dWz / dWr / dWh
+ * [2, 1, in + out, out] are WRITTEN (both halves receive the same gradient), dbz / dbr / dbh [out] written when non-NULL;
+ * dP is caller scratch of N * 3 out floats.  Sums run in index order: deterministic. */
+int pgt_dcrnn_cell_k1_fits(int64_t N, int64_t Fin, int64_t O);
+int pgt_dcrnn_cell_k1_f32(const float* X, int64_t ldx, const float* H, int64_t ldh, const float* Wz, const float* Wr,
+                          const float* Wh, const float* bz, const float* br, const float* bh, float* Hnew, int64_t ldo,
+                          float* saved, int64_t N, int64_t Fin, int64_t O, pgt_stream_t stream);
+int pgt_dcrnn_cell_k1_bwd_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* H, int64_t ldh,
+                              const float* Wz, const float* Wr, const float* Wh, const float* saved, float* dX, int64_t lddx,
+                              float* dH, int64_t lddh, float* dWz, float* dWr, float* dWh, float* dbz, float* dbr, float* dbh,
+                              float* dP, int64_t N, int64_t Fin, int64_t O, pgt_stream_t stream);
 
 /* ---------------------------------------------------------------- EvolveGCN weight evolution (one launch) */
 

@@ -118,6 +118,12 @@ PROTOTYPES = {
     "pgt_dcrnn_unpack_weight_grads_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_ptr]),
     "pgt_dcrnn_stage_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "pgt_dcrnn_cell_k1_fits": (c_int, [c_i64, c_i64, c_i64]),
+    "pgt_dcrnn_cell_k1_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
+                                      c_i64, c_i64, c_i64, c_ptr]),
+    "pgt_dcrnn_cell_k1_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                          c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
+                                          c_ptr]),
     "pgt_evolve_weight_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr,
                                       c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_evolve_weight_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
@@ -129,7 +135,7 @@ PROTOTYPES = {
                                            c_ptr]),
 }
 
-EXPECTED_ABI = 9
+EXPECTED_ABI = 10
 
 
 class PgtLib:
@@ -244,11 +250,19 @@ def check_tensor(lib, t, name, dtype=torch.float32):
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(lib, t):
+    """torch's current stream on t's device as the ABI's pgt_stream_t (plain int: ctypes converts it; no argument
+    objects per call — a step of the launch-bound configs makes hundreds of these)."""
     if lib.target == "gfx950":
-        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-    return ctypes.c_void_p(0)
+        if _raw_stream is not None:
+            return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    """Device address as a plain int (None = NULL): ctypes converts it per its argtypes / structure field."""
+    return t.data_ptr() if t is not None else None

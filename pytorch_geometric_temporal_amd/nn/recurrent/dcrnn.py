@@ -96,6 +96,11 @@ class DCRNN(torch.nn.Module):
 
     def forward(self, X, edge_index, edge_weight=None, H=None):
         """X [N, in], edge_index [2,E], edge_weight [E]|None, H [N, out]|None -> H' [N, out] (dcrnn.py:194-219)."""
+        if self.K == 1 and X.dim() == 2 and ops.cell_k1_fits(X.size(0), self.in_channels, self.out_channels):
+            # no diffusion: the reference's graph preparation feeds nothing (dcrnn.py:79-82) and the cell is dense -- one
+            # launch, H = None as a null pointer (csrc/small_cell.hip; BASELINE configs[0])
+            cz, cr, ch = self.conv_x_z, self.conv_x_r, self.conv_x_h
+            return ops.DCRNNCellK1Function.apply(X, H, cz.weight, cr.weight, ch.weight, cz.bias, cr.bias, ch.bias)
         H = self._set_hidden_state(X, H)
         g = ops.dconv_graph(edge_index, edge_weight, X.size(0), strict_dense=self.K > 1)
         Wzr, bzr, Wh, bh = _cell_weights(self.conv_x_z, self.conv_x_r, self.conv_x_h)

@@ -799,6 +799,67 @@ class CellWeightsFunction(torch.autograd.Function):
         return dWz, dWr, dWh, dbz, dbr
 
 
+def cell_k1_fits(N, Fin, O):
+    """Whether the one-launch K = 1 cell (csrc/small_cell.hip) takes this shape (else: the general path)."""
+    return bool(_lib.get_lib()._pgt_dcrnn_cell_k1_fits(int(N), int(Fin), int(O)))
+
+
+class DCRNNCellK1Function(torch.autograd.Function):
+    """DCRNN(in, out, K = 1) cell step, one launch forward and one backward (pgt_dcrnn_cell_k1_f32; dcrnn.py:79-82 +
+    172-192): X [N, in], H [N, out] | None, the three convolutions' parameters as they are ([2, 1, in + out, out], [out])."""
+
+    @staticmethod
+    def forward(ctx, X, H, Wz, Wr, Wh, bz, br, bh):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        N, Fin = X.shape
+        O = Wz.shape[3]
+        if Wz.shape != (2, 1, Fin + O, O) or Wr.shape != Wz.shape or Wh.shape != Wz.shape:
+            raise ValueError(f"DCRNN cell (K = 1): weights must be [2, 1, {Fin + O}, {O}], got {tuple(Wz.shape)}")
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        if H is not None:
+            check_tensor(lib, H, "H")
+            if H.shape != (N, O):
+                raise ValueError(f"H must be [{N}, {O}], got {tuple(H.shape)}")
+            if H.stride(1) != 1:
+                H = H.contiguous()
+        Wz, Wr, Wh = Wz.contiguous(), Wr.contiguous(), Wh.contiguous()
+        out = torch.empty(N, O, dtype=F32, device=X.device)
+        saved = torch.empty(N, 3 * O, dtype=F32, device=X.device)
+        lib.call("pgt_dcrnn_cell_k1_f32", ptr(X), X.stride(0) if N > 1 else Fin, ptr(H),
+                 (H.stride(0) if N > 1 else O) if H is not None else 0, ptr(Wz), ptr(Wr), ptr(Wh), ptr(bz), ptr(br), ptr(bh),
+                 ptr(out), O, ptr(saved), N, Fin, O, stream_of(lib, X))
+        ctx.save_for_backward(X, H, Wz, Wr, Wh, saved)
+        ctx.has_bias = (bz is not None, br is not None, bh is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        lib = _lib.get_lib()
+        X, H, Wz, Wr, Wh, saved = ctx.saved_tensors
+        N, Fin = X.shape
+        O = Wz.shape[3]
+        C = Fin + O
+        if G.stride(1) != 1 or (N > 1 and G.stride(0) < O):
+            G = G.contiguous()
+        need = ctx.needs_input_grad
+        dev = X.device
+        # one allocation: the three weight gradients, the three bias gradients, the kernel's scratch
+        nW = 2 * C * O
+        buf = torch.empty(3 * nW + 3 * O + N * 3 * O, dtype=F32, device=dev)
+        dWz, dWr, dWh = (buf[i * nW:(i + 1) * nW].view(2, 1, C, O) for i in range(3))
+        dbz, dbr, dbh = (buf[3 * nW + i * O:3 * nW + (i + 1) * O] if ctx.has_bias[i] else None for i in range(3))
+        dP = buf[3 * nW + 3 * O:]
+        dX = torch.empty(N, Fin, dtype=F32, device=dev) if need[0] else None
+        dH = torch.empty(N, O, dtype=F32, device=dev) if (H is not None and need[1]) else None
+        lib.call("pgt_dcrnn_cell_k1_bwd_f32", ptr(G), G.stride(0) if N > 1 else O, ptr(X), X.stride(0) if N > 1 else Fin,
+                 ptr(H), (H.stride(0) if N > 1 else O) if H is not None else 0, ptr(Wz), ptr(Wr), ptr(Wh), ptr(saved),
+                 ptr(dX), Fin, ptr(dH), O, ptr(dWz), ptr(dWr), ptr(dWh), ptr(dbz), ptr(dbr), ptr(dbh), ptr(dP), N, Fin, O,
+                 stream_of(lib, G))
+        return dX, dH, dWz, dWr, dWh, dbz, dbr, dbh
+
+
 class DConvFunction(torch.autograd.Function):
     """H = DConv(X) for node-major X [N*B, C]: diffusion stack (SpMM) + one segmented MFMA GEMM."""
 

@@ -372,3 +372,57 @@ try:
         assert_close_with_nonfinite(base[0], ref, 2e-5, 2e-5, "oracle")
 except ImportError:      # hypothesis is optional
     pass
+
+
+@pytest.mark.parametrize("n,fin,O,bias,hidden,x_grad", [(20, 4, 32, True, False, False),     # BASELINE configs[0]: H = None
+                                                        (75, 3, 5, True, True, True),        # three row groups, ragged last
+                                                        (33, 6, 64, False, True, False),     # widest hidden, bias-free
+                                                        (1, 2, 3, True, True, True)])
+def test_dcrnn_k1_cell_is_one_launch_each_way_and_matches_the_oracle(backend, n, fin, O, bias, hidden, x_grad):
+    """K = 1 (dcrnn.py:79-82: no hop ever runs): the cell goes through csrc/small_cell.hip — forward, d/dX, d/dH and all
+    parameter gradients against the fp64 oracle; H = None is the reference's zero state (dcrnn.py:167-170)."""
+    from pytorch_geometric_temporal_amd import ops
+    torch.manual_seed(n + O)
+    ei_np, ew_np = syn.sensor_graph(n, max(1, 4 * n), seed=n, symmetric=False) if n > 1 else \
+        (torch.zeros(2, 1, dtype=torch.long).numpy(), torch.ones(1).numpy())
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    assert ops.cell_k1_fits(n, fin, O) and not ops.cell_k1_fits(n, fin, 65) and not ops.cell_k1_fits(5000, fin, O)
+    m = DCRNN(fin, O, 1, bias=bias)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.6, 0.6)
+    params64 = {k: v.detach().double().requires_grad_() for k, v in m.state_dict().items()}
+    m = m.to(backend.device)
+    X, H, w = torch.randn(n, fin), torch.randn(n, O), torch.randn(n, O)
+    Xd = backend.t(X).requires_grad_(x_grad)
+    Hd = backend.t(H).requires_grad_() if hidden else None
+    calls = []
+    orig = ops.DCRNNCellK1Function.apply
+    try:
+        ops.DCRNNCellK1Function.apply = lambda *a: (calls.append(1), orig(*a))[1]
+        out = m(Xd, backend.t(ei), backend.t(ew), Hd)
+    finally:
+        ops.DCRNNCellK1Function.apply = orig
+    assert calls == [1]
+    (out * backend.t(w)).sum().backward()
+    X64 = X.double().requires_grad_()
+    H64 = H.double().requires_grad_() if hidden else None
+    ref = F.dcrnn_cell(X64, ei, ew.double(), H64, params64)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, ATOL, RTOL, "forward")
+    if x_grad:
+        assert_close_with_nonfinite(Xd.grad, X64.grad, 2e-5, 1e-4, "dX")
+    else:
+        assert Xd.grad is None
+    if hidden:
+        assert_close_with_nonfinite(Hd.grad, H64.grad, 2e-5, 1e-4, "dH")
+    for name, p in m.named_parameters():
+        assert_close_with_nonfinite(p.grad, params64[name].grad, 5e-5, 1e-4, name)
+    # the same cell through the general path (diffusion-stack kernels with K = 1) agrees to rounding
+    g = ops.dconv_graph(backend.t(ei), backend.t(ew), n, strict_dense=False)
+    from pytorch_geometric_temporal_amd.nn.recurrent.dcrnn import _cell_weights
+    with torch.no_grad():
+        Wzr, bzr, Wh, bh = _cell_weights(m.conv_x_z, m.conv_x_r, m.conv_x_h)
+        H0 = backend.t(H) if hidden else torch.zeros(n, O, device=backend.device)
+        general = ops.DCRNNSeqFunction.apply(backend.t(X).unsqueeze(0), H0, Wzr, bzr, Wh, bh, g, 1, 1)[0]
+    assert_close_with_nonfinite(out.detach(), general, 2e-6, 1e-5, "one-launch cell vs general path")

@@ -350,6 +350,29 @@ int pgt_dcrnn_cell_k1_bwd_f32(const float* G, int64_t ldg, const float* X, int64
                               float* dH, int64_t lddh, float* dWz, float* dWr, float* dWh, float* dbz, float* dbr, float* dbh,
                               float* dP, int64_t N, int64_t Fin, int64_t O, pgt_stream_t stream);
 
+/* ---------------------------------------------------------------- one GCN layer on a small graph, one launch */
+
+/* out = A_hat (X W) straight from the edge list (GCNConv_Fixed_W.forward, evolvegcno.py:76-101; gcn_norm as PyG 2.5 / 2.6
+ * has it: add_remaining_self_loops — self-loop edges leave the list, node i's loop weighs what its LAST self-loop edge
+ * weighed, else 1 (2 for `improved`; always 1 when edge_weight is NULL) —, deg = scatter_add(w, col), coefficient
+ * (deg^-1/2[row] w) deg^-1/2[col] with inf -> 0; normalize = 0: the edge list as it is, no loops) for graphs that fit one
+ * workgroup's LDS (pgt_gcn_small_fits: N <= 512, E <= 4096, widths <= 64, N * Fo <= 8192) — BASELINE configs[4], a new
+ * edge list per snapshot: no sorted operator is built, no workspace, no host check.  edge_index [2, E] int64 (row 0 =
+ * sources), edge_weight [E] or NULL, X [N, Fi] (row stride ldx), W [Fi, Fo].  Writes out [N, Fo] (contiguous) and coef
+ * [E + N] (the edges' coefficients, 0 for removed / out-of-range edges, then the N loop coefficients) for the adjoint;
+ * info[0] is incremented per edge with an endpoint outside [0, N) (such edges are skipped; the caller keeps info zeroed).
+ * Every sum runs in edge order (destination lists by counting + a fill in edge order; products rounded before they are
+ * added, as message + index_add_ do): deterministic, no float atomics.
+ * Adjoint: G = d/d out [N, Fo] (row stride ldg); writes dW [Fi, Fo] = X^T (A_hat^T G) and, when dX != NULL, dX [N, Fi]
+ * (row stride lddx) = (A_hat^T G) W^T.  Edge weights receive no gradient (as everywhere in this library). */
+int pgt_gcn_small_fits(int64_t N, int64_t E, int64_t Fi, int64_t Fo);
+int pgt_gcn_small_f32(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N, int improved,
+                      int add_self_loops, int normalize, const float* X, int64_t ldx, const float* W, int64_t Fi, int64_t Fo,
+                      float* out, float* coef, int32_t* info, pgt_stream_t stream);
+int pgt_gcn_small_bwd_f32(const int64_t* edge_index, const float* coef, int64_t E, int64_t N, int add_self_loops, int normalize,
+                          const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, int64_t Fi, int64_t Fo,
+                          float* dW, float* dX, int64_t lddx, pgt_stream_t stream);
+
 /* ---------------------------------------------------------------- EvolveGCN weight evolution (one launch) */
 
 /* W_t from W_{t-1} for one snapshot (evolvegcnh.py:78-102: TopKPooling summary of X_t -> torch.nn.GRU -> weight;

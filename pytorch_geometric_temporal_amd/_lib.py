@@ -124,6 +124,11 @@ PROTOTYPES = {
     "pgt_dcrnn_cell_k1_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                           c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
                                           c_ptr]),
+    "pgt_gcn_small_fits": (c_int, [c_i64, c_i64, c_i64, c_i64]),
+    "pgt_gcn_small_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr,
+                                  c_ptr, c_ptr]),
+    "pgt_gcn_small_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64,
+                                      c_ptr, c_ptr, c_i64, c_ptr]),
     "pgt_evolve_weight_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr,
                                       c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_evolve_weight_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,

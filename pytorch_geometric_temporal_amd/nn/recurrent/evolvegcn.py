@@ -14,11 +14,19 @@ from ... import ops
 from ..conv import TopKPooling, glorot_
 
 
+_POOLED_ROWS = {}
+
+
 def _pooled_rows(ratio, n, dtype):
-    """k of TopKPooling: an int ratio as it is, else ceil(ratio * N) computed in the score dtype (PyG)."""
+    """k of TopKPooling: an int ratio as it is, else ceil(ratio * N) computed in the score dtype (PyG); remembered per
+    (ratio, N, dtype) — the tensor arithmetic costs more host time than the weight evolution's launch."""
     if isinstance(ratio, int):
         return min(ratio, n)
-    return int((float(ratio) * torch.tensor(n).to(dtype)).ceil().to(torch.long))
+    key = (float(ratio), int(n), dtype)
+    k = _POOLED_ROWS.get(key)
+    if k is None:
+        k = _POOLED_ROWS[key] = int((float(ratio) * torch.tensor(n).to(dtype)).ceil().to(torch.long))
+    return k
 
 
 def _fused_evolution_applies(X, in_channels, k, pooled=True):
@@ -48,6 +56,11 @@ class GCNConv_Fixed_W(torch.nn.Module):
         pass
 
     def forward(self, W, x, edge_index, edge_weight=None):
+        if (x.dim() == 2 and W.dim() == 2 and x.dtype == torch.float32 and edge_index.dim() == 2 and
+                ops.gcn_small_fits(x.size(0), edge_index.size(1), W.size(0), W.size(1))):
+            # a graph that fits one workgroup's LDS: normalisation, lists, product and aggregation from the raw edge list in
+            # ONE launch (csrc/small_gcn.hip) -- a new edge list per snapshot costs no device preparation
+            return ops.gcn_small(x, W, edge_index, edge_weight, self.improved, self.add_self_loops, self.normalize)
         if self.normalize:
             g = ops.gcn_graph(edge_index, edge_weight, x.size(-2), self.improved, self.add_self_loops)
         else:                                      # the edge list as it is: no gcn_norm, no self-loops (:83-90 skipped)

@@ -323,6 +323,81 @@ def raw_graph(edge_index, edge_weight, num_nodes):
                            lambda: RawGraph(edge_index, edge_weight, num_nodes))
 
 
+class SmallEdges:
+    """An edge list handed to the one-launch small-graph kernels as it is (csrc/small_gcn.hip builds its lists in LDS):
+    shape / dtype / range checked ONCE per tensor (identity-keyed, like every prepared graph), nothing sorted, no workspace."""
+    _info = {}
+
+    def __init__(self, edge_index, edge_weight, num_nodes):
+        lib = _lib.get_lib()
+        ei, ew = _edge_inputs(lib, edge_index, edge_weight)
+        N, E = int(num_nodes), ei.size(1)
+        if E and (int(ei.min()) < 0 or int(ei.max()) >= N):
+            raise IndexError(f"edge_index has endpoint(s) outside [0, {N})")
+        self.ei, self.ew, self.E, self.N = ei, ew, E, N
+        key = str(ei.device)
+        if key not in SmallEdges._info:
+            SmallEdges._info[key] = torch.zeros(4, dtype=I32, device=ei.device)
+        self.info = SmallEdges._info[key]
+
+
+def small_edges(edge_index, edge_weight, num_nodes):
+    return GRAPH_CACHE.get("small", edge_index, edge_weight, (int(num_nodes),),
+                           lambda: SmallEdges(edge_index, edge_weight, num_nodes))
+
+
+def gcn_small_fits(N, E, Fi, Fo):
+    return bool(_lib.get_lib()._pgt_gcn_small_fits(int(N), int(E), int(Fi), int(Fo)))
+
+
+class GcnSmallFunction(torch.autograd.Function):
+    """out = A_hat (x W) from the raw edge list in one launch each way (pgt_gcn_small_f32; evolvegcno.py:76-101)."""
+
+    @staticmethod
+    def forward(ctx, x, W, edges, improved, add_self_loops, normalize):
+        lib = _lib.get_lib()
+        check_tensor(lib, x, "x")
+        check_tensor(lib, W, "W")
+        N, Fi = x.shape
+        if W.dim() != 2 or W.size(0) != Fi:
+            raise ValueError(f"W must be [{Fi}, out], got {tuple(W.shape)}")
+        if N != edges.N:
+            raise ValueError(f"x has {N} rows, the graph {edges.N} nodes")
+        Fo = W.size(1)
+        if x.stride(1) != 1 or (N > 1 and x.stride(0) < Fi):
+            x = x.contiguous()
+        W = W.contiguous()
+        out = torch.empty(N, Fo, dtype=F32, device=x.device)
+        coef = torch.empty(edges.E + N, dtype=F32, device=x.device)
+        lib.call("pgt_gcn_small_f32", ptr(edges.ei), ptr(edges.ew), edges.E, N, int(bool(improved)), int(bool(add_self_loops)),
+                 int(bool(normalize)), ptr(x), x.stride(0) if N > 1 else Fi, ptr(W), Fi, Fo, ptr(out), ptr(coef),
+                 ptr(edges.info), stream_of(lib, x))
+        ctx.save_for_backward(x, W, coef)
+        ctx.edges = edges
+        ctx.flags = (int(bool(add_self_loops)), int(bool(normalize)))
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        lib = _lib.get_lib()
+        x, W, coef = ctx.saved_tensors
+        edges = ctx.edges
+        N, Fi = x.shape
+        Fo = W.size(1)
+        if G.stride(1) != 1 or (N > 1 and G.stride(0) < Fo):
+            G = G.contiguous()
+        dW = torch.empty(Fi, Fo, dtype=F32, device=x.device)
+        dX = torch.empty(N, Fi, dtype=F32, device=x.device) if ctx.needs_input_grad[0] else None
+        lib.call("pgt_gcn_small_bwd_f32", ptr(edges.ei), ptr(coef), edges.E, N, ctx.flags[0], ctx.flags[1], ptr(G),
+                 G.stride(0) if N > 1 else Fo, ptr(x), x.stride(0) if N > 1 else Fi, ptr(W), Fi, Fo, ptr(dW), ptr(dX), Fi,
+                 stream_of(lib, G))
+        return dX, dW, None, None, None, None
+
+
+def gcn_small(x, W, edge_index, edge_weight, improved=False, add_self_loops=True, normalize=True):
+    return GcnSmallFunction.apply(x, W, small_edges(edge_index, edge_weight, x.size(0)), improved, add_self_loops, normalize)
+
+
 def cheb_graph(edge_index, edge_weight, num_nodes, normalization="sym", lambda_max=None, variant=0):
     lam = None if lambda_max is None else float(lambda_max)
     return GRAPH_CACHE.get("cheb", edge_index, edge_weight, (int(num_nodes), normalization, lam, int(variant)),

@@ -673,3 +673,60 @@ def test_attention_scores_function_matches_torch_forward_and_backward(backend, B
     assert_close_with_nonfinite(out, ref, ATOL, RTOL, "S")
     for a, r, nm in zip(args, ref_args, ("dL", "dR", "dbias", "dV")):
         assert_close_with_nonfinite(a.grad, r.grad, 2e-5, 1e-4, nm)
+
+
+@pytest.mark.parametrize("n,E,Fi,Fo,weighted,improved,loops,normalize,x_grad", [
+    (129, 2158, 8, 8, True, False, True, True, False),      # BASELINE configs[4]'s largest snapshot
+    (40, 333, 5, 7, True, True, True, True, True),          # E not a multiple of 8, improved fill, d/dX
+    (40, 200, 3, 3, False, True, True, True, False),        # no weights: every loop weighs 1 (improved has no effect)
+    (37, 150, 6, 4, True, False, False, True, True),        # add_self_loops=False: isolated nodes -> deg^-1/2 = inf -> 0
+    (25, 90, 4, 4, True, False, True, False, True),         # normalize=False: the edge list as it is
+    (1, 3, 2, 2, True, False, True, True, True),
+    (12, 0, 3, 5, True, False, True, True, True)])
+def test_gcn_layer_on_a_small_graph_from_the_raw_edge_list(backend, n, E, Fi, Fo, weighted, improved, loops, normalize, x_grad):
+    """csrc/small_gcn.hip: gcn_norm (self-loop edges replaced, the last one's weight kept), destination lists, X W and the
+    aggregation in one workgroup, against PyG's semantics as restated in the oracle — forward, d/dW, d/dX; deterministic."""
+    from oracle import pyg_restated as P
+    from pytorch_geometric_temporal_amd import ops
+    from pytorch_geometric_temporal_amd.nn.recurrent.evolvegcn import GCNConv_Fixed_W
+    g = torch.Generator().manual_seed(n * 1000 + E)
+    ei = torch.randint(0, n, (2, E), generator=g)
+    if E > 8:
+        ei[:, 3] = ei[0, 3]                      # self-loops in the list, one node with two of them
+        ei[:, 5] = ei[0, 3]
+        ei[:, 7] = ei[:, 6]                      # a duplicate edge
+    if n > 5 and E:
+        ei[ei == n - 2] = 0                      # an isolated node
+    ew = (torch.rand(E, generator=g) + 0.1) if weighted else None
+    X, W, w = torch.randn(n, Fi, generator=g), torch.randn(Fi, Fo, generator=g), torch.randn(n, Fo, generator=g)
+    assert ops.gcn_small_fits(n, E, Fi, Fo) and not ops.gcn_small_fits(513, E, Fi, Fo) and not ops.gcn_small_fits(n, 4097, Fi, Fo)
+    conv = GCNConv_Fixed_W(Fi, Fo, improved=improved, add_self_loops=loops, normalize=normalize)
+    Xd, Wd = backend.t(X).requires_grad_(x_grad), backend.t(W).requires_grad_()
+    eid, ewd = backend.t(ei), (backend.t(ew) if weighted else None)
+    out = conv(Wd, Xd, eid, ewd)
+    (out * backend.t(w)).sum().backward()
+    X64, W64 = X.double().requires_grad_(), W.double().requires_grad_()
+    if normalize:
+        e2, c2 = P.gcn_norm(ei, ew.double() if weighted else None, n, improved, loops, dtype=torch.float64)
+    else:
+        e2, c2 = ei, (ew.double() if weighted else torch.ones(E, dtype=torch.float64))
+    ref = F.propagate_add(e2, X64 @ W64, c2)
+    (ref * w.double()).sum().backward()
+    assert_close_with_nonfinite(out, ref, 1e-5, 1e-5, "forward")
+    assert_close_with_nonfinite(Wd.grad, W64.grad, 5e-5, 1e-4, "dW")
+    if x_grad:
+        assert_close_with_nonfinite(Xd.grad, X64.grad, 2e-5, 1e-4, "dX")
+    with torch.no_grad():
+        assert torch.equal(conv(Wd, Xd, eid, ewd), out)                       # deterministic
+        # the same layer through the prepared-operator path (device graph preparation + product + aggregation launches)
+        gg = ops.gcn_graph(eid, ewd, n, improved, loops) if normalize else ops.raw_graph(eid, ewd, n)
+        general = ops.propagate(gg, ops.linear(Xd, Wd, None))
+    assert_close_with_nonfinite(out.detach(), general, 2e-6, 1e-5, "one launch vs prepared operator")
+    assert int(ops.small_edges(eid, ewd, n).info[0]) == 0
+
+
+def test_small_graph_edge_list_is_range_checked_once(backend):
+    from pytorch_geometric_temporal_amd import ops
+    bad = backend.t(torch.tensor([[0, 1, 7], [1, 2, 0]]))
+    with pytest.raises(IndexError):
+        ops.small_edges(bad, None, 5)

@@ -403,13 +403,15 @@ int pgt_gru_zr_f32(float* pre_zr, const float* H, int64_t ldh, float* xhr, int64
  *   and, when out1 != NULL, also to out1 (row stride ld1). */
 int pgt_gru_h_f32(float* pre_h, const float* zr, const float* H, int64_t ldh, float* out0, int64_t ld0,
                   const pgt_rowmap* map0, float* out1, int64_t ld1, int64_t M, int64_t O, pgt_stream_t stream);
-/* backward of pgt_gru_h_f32: given dHnew (+ dHnew2 when non-NULL: the output gradient and the running state
- *   gradient are summed on the fly), writes d_pre_h [M,O], d_pre_zr[:, 0:O] (update gate), and
+/* backward of pgt_gru_h_f32: given dHnew (+ dHnew2 + dHnew3 when non-NULL: the output gradient, the running state
+ *   gradient and the later step's gate-stack gradient of H are summed on the fly — no separate accumulation pass),
+ *   writes d_pre_h [M,O], d_pre_zr[:, 0:O] (update gate), and
  *   dH (=|+=) dHnew * Z  depending on accumulate_dh.  dH may alias dHnew2.  map_dh / map_h (NULL = plain rows): dHnew / H
  *   in a two-level row layout (pgt_rowmap): the incoming gradient and the previous state are read in place from
  *   [B, T, N, O] tensors. */
 int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const pgt_rowmap* map_dh, const float* dHnew2, int64_t lddh2,
-                      const float* zr, const float* H, int64_t ldh, const pgt_rowmap* map_h, const float* ht,
+                      const float* dHnew3, int64_t lddh3, const float* zr, const float* H, int64_t ldh,
+                      const pgt_rowmap* map_h, const float* ht,
                       float* d_pre_h, float* d_pre_zr, float* dH, int64_t lddhp, int accumulate_dh, int64_t M, int64_t O,
                       pgt_stream_t stream);
 /* backward of pgt_gru_zr_f32: dxhr[:, f_in:] is d(H*R);  d_pre_zr[:, O:2O] = dHR*H*R*(1-R);  dH += dHR*R */

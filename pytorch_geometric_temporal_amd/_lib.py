@@ -98,8 +98,8 @@ PROTOTYPES = {
                                     c_i64, c_ptr, c_size, c_ptr]),
     "pgt_gru_zr_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
     "pgt_gru_h_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
-    "pgt_gru_h_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr,
-                                  c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr]),
+    "pgt_gru_h_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
+                                  c_ptr, c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr]),
     "pgt_gru_zr_bwd_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
                                    c_ptr]),
     "pgt_lstm_gates_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr]),

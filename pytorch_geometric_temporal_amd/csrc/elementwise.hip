@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void gru_h_kernel(float* pre_h, const float* _
 template <int V>
 __global__ __launch_bounds__(256) void gru_h_bwd_kernel(const float* __restrict__ dHn, int64_t lddh, pgt_rowmap map_dh,
                                                          const float* dHn2, int64_t lddh2,
+                                                         const float* __restrict__ dHn3, int64_t lddh3,
                                                          const float* __restrict__ zr,
                                                          const float* __restrict__ H, int64_t ldh, pgt_rowmap map_h,
                                                          const float* __restrict__ ht, float* d_pre_h,
@@ -72,6 +73,11 @@ __global__ __launch_bounds__(256) void gru_h_bwd_kernel(const float* __restrict_
   pgt_ldv<V>(dHn + pgt_row_off(m, lddh, map_dh.period, map_dh.stride_hi) + o, g);
   if (dHn2) {
     pgt_ldv<V>(dHn2 + m * lddh2 + o, g2);
+#pragma unroll
+    for (int i = 0; i < V; ++i) g[i] += g2[i];
+  }
+  if (dHn3) {
+    pgt_ldv<V>(dHn3 + m * lddh3 + o, g2);
 #pragma unroll
     for (int i = 0; i < V; ++i) g[i] += g2[i];
   }
@@ -422,7 +428,8 @@ extern "C" int pgt_gru_h_f32(float* pre_h, const float* zr, const float* H, int6
 }
 
 extern "C" int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const pgt_rowmap* map_dh, const float* dHnew2,
-                                 int64_t lddh2, const float* zr, const float* H, int64_t ldh, const pgt_rowmap* map_h,
+                                 int64_t lddh2, const float* dHnew3, int64_t lddh3, const float* zr, const float* H,
+                                 int64_t ldh, const pgt_rowmap* map_h,
                                  const float* ht, float* d_pre_h, float* d_pre_zr, float* dH, int64_t lddhp,
                                  int accumulate_dh, int64_t M, int64_t O, pgt_stream_t stream) {
   PGT_REQUIRE(M >= 0 && O >= 0, "pgt_gru_h_bwd_f32: negative size");
@@ -432,12 +439,13 @@ extern "C" int pgt_gru_h_bwd_f32(const float* dHnew, int64_t lddh, const pgt_row
   PGT_REQUIRE(pgt_rowmap_take(map_dh, M, &mg) && pgt_rowmap_take(map_h, M, &mh), "pgt_gru_h_bwd_f32: row map out of range");
   PgtVecPick pick;
   pick.width(O);
-  pick.operand(dHnew, lddh, mg); pick.operand(dHnew2, lddh2); pick.operand(zr, 2 * O); pick.operand(H, ldh, mh);
-  pick.operand(ht, O); pick.operand(d_pre_h, O); pick.operand(d_pre_zr, 2 * O); pick.operand(dH, lddhp);
+  pick.operand(dHnew, lddh, mg); pick.operand(dHnew2, lddh2); pick.operand(dHnew3, lddh3); pick.operand(zr, 2 * O);
+  pick.operand(H, ldh, mh); pick.operand(ht, O); pick.operand(d_pre_h, O); pick.operand(d_pre_zr, 2 * O);
+  pick.operand(dH, lddhp);
   dim3 grid, block(256);
   if (int e = grid_for(M * (O / pick.v), "pgt_gru_h_bwd_f32", &grid)) return e;
-  PGT_VDISPATCH(pick.v, gru_h_bwd_kernel, grid, block, stream, dHnew, lddh, mg, dHnew2, lddh2, zr, H, ldh, mh, ht,
-                d_pre_h, d_pre_zr, dH, lddhp, accumulate_dh, M, (int)O);
+  PGT_VDISPATCH(pick.v, gru_h_bwd_kernel, grid, block, stream, dHnew, lddh, mg, dHnew2, lddh2, dHnew3, lddh3, zr, H, ldh,
+                mh, ht, d_pre_h, d_pre_zr, dH, lddhp, accumulate_dh, M, (int)O);
   return pgt_check_launch("pgt_gru_h_bwd_f32");
 }
 

@@ -544,7 +544,10 @@ FUSE_GATE_EPILOGUES = os.environ.get("PGT_FUSE_GATES", "1") != "0"
 # deferred-store kernel + a 64-column remainder, 0 = one 320-column product (three 128-wide column tiles, the last masked)
 SPLIT_FEATURE_GRADIENT = os.environ.get("PGT_SPLIT_FG", "1") != "0"
 ONE_FEATURE_GRADIENT = os.environ.get("PGT_ONE_FG", "1") != "0"
-ONE_FEATURE_GRADIENT_MIN_ROWS = 32768      # tests lower it to drive the 320-column product at small sizes
+# DCRNN backward: the gate stack's d/dH joins the running state gradient inside the next gate-backward kernel (A/B: PGT_FOLD_DH=0
+# = a separate accumulation pass per time step)
+FOLD_STATE_GRADIENT = os.environ.get("PGT_FOLD_DH", "1") != "0"
+ONE_FEATURE_GRADIENT_MIN_ROWS = int(os.environ.get("PGT_ONE_FG_MIN_ROWS", "8192"))   # tests lower it to drive the 320-column product at small sizes
 # weight / bias gradients without float atomics (pgt_gemm_tn_det_f32): bitwise reproducible run to run, one extra pass
 # over the per-slab partial sums.  Off by default (the atomics are ~2 % faster at the benchmark shape); PGT_DETERMINISTIC=1
 # or ops.DETERMINISTIC_WEIGHT_GRADIENTS = True turns it on.
@@ -1006,15 +1009,16 @@ def _gru_h(pre_h, zr, H, out0, out1=None):
     lib.call("pgt_gru_h_f32", ptr(pre_h), ptr(zr), hp, ldh, op, ld0, m0, o1, ld1, M, O, stream_of(lib, pre_h))
 
 
-def _gru_h_bwd(dHn, zr, H, ht, d_pre_h, d_pre_zr, dH, accumulate, dHn2=None):
-    """dHn and H may be RowMaps (read in place from [B, T, N, O] tensors)."""
+def _gru_h_bwd(dHn, zr, H, ht, d_pre_h, d_pre_zr, dH, accumulate, dHn2=None, dHn3=None):
+    """dHn and H may be RowMaps (read in place from [B, T, N, O] tensors); dHn2 / dHn3: further addends of d/dH'."""
     lib = _lib.get_lib()
     M, O = ht.shape
     gp, ldg, mg = _rows_or_map(dHn, "dHn")
     g2, ldg2 = _rows(dHn2, "dHn2") if dHn2 is not None else (ptr(None), 0)
+    g3, ldg3 = _rows(dHn3, "dHn3") if dHn3 is not None else (ptr(None), 0)
     hp, ldh, mh = _rows_or_map(H, "H")
     dp, ldd = _rows(dH, "dH")
-    lib.call("pgt_gru_h_bwd_f32", gp, ldg, mg, g2, ldg2, ptr(zr), hp, ldh, mh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp,
+    lib.call("pgt_gru_h_bwd_f32", gp, ldg, mg, g2, ldg2, g3, ldg3, ptr(zr), hp, ldh, mh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp,
              ldd, int(bool(accumulate)), M, O, stream_of(lib, ht))
 
 
@@ -1156,8 +1160,8 @@ class DCRNNSeqFunction(torch.autograd.Function):
             n1 = (NH // 128) * 128 if (SPLIT_FEATURE_GRADIENT and NH % 128 != 0 and NH > 128 and ((NH // 128) * 128) % O == 0) else NH
             # tall batches: ONE product over all S*O <= 320 columns on the symmetric split-bf16 kernel (dP is read once;
             # column blocks 8 and 9 ride along as second blocks) instead of 256 columns + a 64-column remainder
-            # (from 32 768 rows: at B = 64, M = 13 248, the two-block wavefronts leave the second round of row blocks
-            # half empty and the whole step is 15 % slower than with the 256 + 64 split)
+            # (from 8 192 rows, the split-bf16 kernels' own floor: at B = 64, M = 13 248, the one product is 4.5 % of the step
+            # faster than 256 + 64 since the round-3 kernels, 2.55 -> 2.44 ms)
             if ONE_FEATURE_GRADIENT and M >= ONE_FEATURE_GRADIENT_MIN_ROWS and 128 < NH <= 320 and NH % 32 == 0 and 2 * O <= 128 and O % 32 == 0:
                 n1 = NH
 
@@ -1201,8 +1205,9 @@ class DCRNNSeqFunction(torch.autograd.Function):
         for t in range(T - 1, -1, -1):
             Hp = H0c if t == 0 else (states.step(t - 1) if ctx.btno else Hout[t - 1])
             # d/dH_t = dOut[t] + running state gradient, summed inside the gate-backward kernel
+            # (+ the later step's gate-stack gradient of H, still sitting in G[0]: no accumulation pass of its own)
             _gru_h_bwd(grad_in.step(t) if ctx.btno else dOut[t], ZR[t], Hp, HT[t], dPh[t], dPzr[t], dH, accumulate=False,
-                       dHn2=dH)
+                       dHn2=dH, dHn3=None if (t == T - 1 or not FOLD_STATE_GRADIENT) else G[0][:, Fb:])
             # candidate conv: dT = dPh Wh^T ; adjoint of the stack
             feature_grad(dPh[t], Wh_b, WhH if skip_x else None, O)
             stack_bwd()
@@ -1218,9 +1223,12 @@ class DCRNNSeqFunction(torch.autograd.Function):
             # gate convs
             feature_grad(dPzr[t], Wzr_b, WzrH if skip_x else None, 2 * O)
             stack_bwd()
-            add2d(dH, G[0][:, Fb:])
+            if not FOLD_STATE_GRADIENT:
+                add2d(dH, G[0][:, Fb:])
             if need_x:
                 add2d(dX[t], G[0][:, :Fin])
+        if ctx.needs_input_grad[1] and FOLD_STATE_GRADIENT:
+            add2d(dH, G[0][:, Fb:])              # d/dH0: the first step's gate-stack gradient joins here
         if overlap:
             main.wait_stream(side)
         else:

@@ -9,7 +9,7 @@ import time
 import torch
 import torch.nn.functional as TF
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pytorch_geometric_temporal_amd.dataset import ChickenpoxDatasetLoader, EnglandCovidDatasetLoader
 from pytorch_geometric_temporal_amd.nn.recurrent import DCRNN, EvolveGCNH
 from pytorch_geometric_temporal_amd.signal import temporal_signal_split

@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from pytorch_geometric_temporal_amd import _lib
 
 dev = torch.device("cuda:0")

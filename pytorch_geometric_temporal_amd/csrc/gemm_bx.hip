@@ -58,6 +58,10 @@ __device__ __forceinline__ BxRsrc bx_make_rsrc(const void* p, int64_t bytes) {
 #define BX_LOAD1(dst, voff, rs) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory")
 #define BX_LOAD1S(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory")
 #define BX_STORE1S(val, voff, rs, soff) asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(val), "v"(voff), "s"(rs), "s"(soff) : "memory")
+#define BX_LOAD4(dst, voff, rs) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory")
+// (a store of more than 8 bytes reads its data registers over several cycles: a VALU write to them in the next two issue
+// slots corrupts the stored value — the compiler pads its own stores for this hazard and cannot see into the asm)
+#define BX_STORE4(val, voff, rs) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" :: "v"(val), "v"(voff), "s"(rs) : "memory")
 // hand-counted waits, tied to the registers they release so that the consumer cannot be scheduled above them
 #define BX_WAIT(n, reg) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n))
 #define BX_WAIT2(n, r0, r1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(n))
@@ -165,6 +169,20 @@ __device__ __forceinline__ void bx_exact_tile(const PgtGemmArgs& g, const BxRsrc
   for (int r = 0; r < 16; ++r) acc[r] += bias;
 }
 
+// compile-time integers handed to lambdas (s_waitcnt takes an immediate)
+template <int V> struct BxInt { static constexpr int value = V; };
+// the row-sliced epilogue's descriptors: a 2 GB window over an array, and the offset that lies outside it
+constexpr uint32_t BX_WIN = 0x80000000u, BX_OOR = 0xc0000000u;
+
+// lab/gemm_bx_trace_lab.hip defines this to record a per-wavefront timeline of the K-split kernel; a no-op in the library
+#ifndef BX_TRACE
+#define BX_TRACE(slot) do { } while (0)
+#endif
+// ... and this to take the kernel apart (1: no MFMAs, 4: no epilogue stores, 8: no loads of A, 16: no gate-operand loads)
+#ifndef BX_LAB_SKIP
+#define BX_LAB_SKIP(bit) false
+#endif
+
 // KSTEPS: 16-deep k-steps covering K (zero padded); WN: 32-column blocks per wavefront; EPI: 0 bias, 1 / 2 the GRU
 // epilogues of PgtGemmArgs.  A: n_seg segments of seg_k (even) columns, consumed as one [M, n_seg * seg_k] operand.
 // Q4 (N <= 64): only two column blocks exist, so K is cut four ways instead — consumers 0, 1 (epilogue) and 2, 3, producers
@@ -177,10 +195,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
   constexpr int NPART = Q4 ? 4 : 2, NCOL = Q4 ? 2 : 4;     // parts of K x column blocks = the eight wavefronts
   constexpr int KQ = KSTEPS / NPART, KMAX = KSTEPS - (NPART - 1) * KQ;   // k-steps of a part / of the last part
   constexpr int NREG = (NPART - 1) * NCOL;                 // partial-sum regions
-  static_assert((KP / 2) % 8 == 0 && KQ >= 1 && (!Q4 || WN == 1), "shape");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NREG * PART + 16];
+  // ---- WN == 1: the block's sums leave through a ROW-SLICED epilogue on all eight wavefronts.  (Round 3's timeline,
+  // lab/gemm_bx_trace_lab.hip: with the epilogue on the part-0 wavefronts alone — 16 rows x 1 .. 3 arrays of 128-byte row
+  // pieces per lane, 64-bit address chains — a block's stores took 2.8 - 3.3 us of a 6.3 - 7.4 us iteration while the other
+  // wavefronts waited at the barrier.)  The part-0 wavefronts add the partial sums as before and leave the block's sums in
+  // LDS ([column block][row][32]); after a second barrier wavefront w owns rows 4w .. 4w + 3: a lane is a column (two at 128
+  // columns), every load / store instruction is one whole row piece (256 contiguous bytes) through a per-row buffer
+  // descriptor — scalar row addressing, masking by the descriptor's range, no branches, no vector address arithmetic.
+  constexpr bool ROWS = WN == 1;
+  constexpr int CPL = ROWS ? NCOL / 2 : 1;                 // 64-column groups of the block = columns per lane
+  // gate operands live in ONE 64-column group: the candidate gate has a single group; of the z | r gates' 2 O columns only
+  // the reset half needs H, and that half is the LAST group (N = 2 O = 128 at two groups, N <= 64 at one)
+  constexpr int OPG = CPL - 1;                             // the group that carries gate operands
+  constexpr int NOP = !ROWS || EPI == 0 ? 0 : (EPI == 1 ? 1 : 2);   // gate-operand loads (16 bytes per lane) per wavefront and block
+  static_assert((KP / 2) % 8 == 0 && KQ >= 1 && (!Q4 || WN == 1) && (EPI == 0 || WN == 1), "shape");
+  static_assert(EPT - 1 + NOP < 64, "vmcnt is six bits");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NREG * PART + 64];
   unsigned char* const stage_part = lds + 2 * BUF;
   bx_lds_vint* const part_seen = (bx_lds_vint*)(lds + 2 * BUF + NREG * PART);
+  bx_lds_vint* const tile_seen = part_seen + 4;            // [8]: wavefront w has taken its rows of block n_iter - 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = BX_SGPR(tid >> 6);
   const int wc = wave & 3;
@@ -213,12 +246,118 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
   }
   // ---- zero both A buffers once (the K padding columns are never written again)
   for (int i = tid; i < 2 * BUF / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
-  if (tid < 4) part_seen[tid] = 0;
+  if (tid < 12) part_seen[tid] = 0;
   int rb = blockIdx.x;
   if (rb >= n_blocks) return;
   __syncthreads();
   const int arow = (lane & 31) * SROW + 16 * (lane >> 5);
   int n_iter = 0;
+
+  // ---- the row-sliced epilogue (ROWS), 16-byte accesses.  Wavefront w owns rows 4w .. 4w + 3 of the block; lane l is row
+  // 4w + (l >> 4) and the four columns 4 (l & 15) .. + 3 of each 64-column group: ONE buffer_load / buffer_store_dwordx4
+  // moves four whole 256-byte row pieces (1 KB per instruction — a CU keeps a bounded number of vector-memory
+  // instructions in flight, so bytes per instruction is what its stream rate is made of).  Offsets are absolute inside
+  // an array (the host side checks that they fit 32 bits); rows past M / columns past N / the update half of the z | r
+  // gates get an offset past the descriptor (a 2 GB window; the offset 3 GB: no wrap-around inside the 16-byte range check):
+  // read zero, are dropped.
+  const int r4 = lane >> 4, q4 = lane & 15;
+  uint32_t ccol[CPL];                   // byte offset of the quad inside a row of C, its segment folded in
+  bool live[CPL];
+#pragma unroll
+  for (int s = 0; s < CPL; ++s) {
+    const int col0 = 64 * s + 4 * q4;
+    live[s] = ROWS && col0 < g.N;
+    const int js = live[s] ? col0 / g.c_seg_n : 0;
+    ccol[s] = (uint32_t)(((int64_t)js * g.c_seg_stride + (col0 - js * g.c_seg_n)) * 4);
+  }
+  const int ocol = 64 * OPG + 4 * q4;                                  // the quad that carries gate operands
+  const bool olive = ROWS && EPI != 0 && ocol < g.N && (EPI == 2 || ocol >= g.eO);
+  const uint32_t hcol4 = (uint32_t)((EPI == 1 ? ocol - g.eO : ocol) * 4);
+  const BxRsrc rs_c = bx_make_rsrc(g.C, BX_WIN);
+  const BxRsrc rs_h = bx_make_rsrc(EPI != 0 ? g.eH : nullptr, EPI != 0 ? BX_WIN : 0);
+  const BxRsrc rs_z = bx_make_rsrc(EPI == 2 ? g.eZ : nullptr, EPI == 2 ? BX_WIN : 0);
+  const BxRsrc rs_x = bx_make_rsrc(EPI == 1 ? g.eX + g.efin : nullptr, EPI == 1 ? BX_WIN : 0);
+  const BxRsrc rs_0 = bx_make_rsrc(EPI == 2 ? g.eO0 : nullptr, EPI == 2 ? BX_WIN : 0);
+  const BxRsrc rs_1 = bx_make_rsrc(EPI == 2 ? g.eO1 : nullptr, (EPI == 2 && g.eO1) ? BX_WIN : 0);
+  bx_u32x4 eh = {0, 0, 0, 0}, ez = {0, 0, 0, 0};
+  // gate operands of this lane's row of block `b`: always NOP load instructions (the producers' hand-counted waits count them)
+  auto e_issue_rows = [&](int b) {
+    if (BX_LAB_SKIP(16)) return;
+    if constexpr (NOP > 0) {
+      const int gm = b * BM + 4 * wave + r4;
+      const bool ok = olive && gm < g.M;
+      BX_LOAD4(eh, ok ? (uint32_t)gm * (uint32_t)(g.eldh * 4) + hcol4 : BX_OOR, rs_h);
+      if constexpr (EPI == 2) BX_LOAD4(ez, ok ? (uint32_t)gm * (uint32_t)(g.eO * 8) + hcol4 : BX_OOR, rs_z);
+    }
+  };
+  // NY: loads of this wavefront that are younger than its gate operands when they are due (a producer: the EPT loads of the
+  // block after next; everyone else: none)
+  auto row_epilogue = [&](int b, auto NY) {
+    constexpr int ny = decltype(NY)::value;
+    BX_TRACE(5);
+    if constexpr (NOP > 0) {
+      if (!BX_LAB_SKIP(32)) {
+        BX_WAIT(ny, eh);
+        if constexpr (EPI == 2) BX_WAIT(ny, ez);
+      }
+    }
+    const int gm = b * BM + 4 * wave + r4;
+    const bool row_ok = gm < g.M;
+#pragma unroll
+    for (int s = 0; s < CPL; ++s) {
+      const bool ok = row_ok && live[s] && !BX_LAB_SKIP(4);
+      // (the gate products write one segment, c_seg_n = N: the quad's offset is its column, no register kept for it)
+      const uint32_t cq = EPI != 0 ? (uint32_t)((64 * s + 4 * q4) * 4) : ccol[s];
+      const uint32_t co = ok ? (uint32_t)gm * (uint32_t)(g.ldc * 4) + cq : BX_OOR;
+      const int col0 = 64 * s + 4 * q4;
+      const float4 v = *reinterpret_cast<const float4*>(stage_part + (col0 >> 5) * PART + ((4 * wave + r4) * 32 + (col0 & 31)) * 4);
+      if (s == CPL - 1 && lane == 0) tile_seen[wave] = n_iter + 1;   // after the last read of the block's sums: a wavefront's
+                                                                     // LDS operations complete in order
+      float x[4] = {v.x, v.y, v.z, v.w};
+      if constexpr (EPI == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = bx_sigmoidf(x[i]);
+      } else if constexpr (EPI == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = bx_tanhf(x[i]);
+      }
+      const bx_u32x4 xo = {bx_as_uint(x[0]), bx_as_uint(x[1]), bx_as_uint(x[2]), bx_as_uint(x[3])};
+      BX_STORE4(xo, co, rs_c);
+      if constexpr (EPI != 0) {
+        if (s == OPG) {
+          const bool sok = ok && olive;
+          bx_u32x4 so;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float h = bx_as_float(eh[i]);
+            so[i] = bx_as_uint(EPI == 1 ? h * x[i] : pgt_gru_blend(bx_as_float(ez[i]), h, x[i]));
+          }
+          if constexpr (EPI == 1) {
+            BX_STORE4(so, sok ? (uint32_t)gm * (uint32_t)(g.eldx * 4) + hcol4 : BX_OOR, rs_x);
+          } else {
+            // out0 in a two-level row layout (pgt_rowmap: H_t straight into the [B, T, N, O] result)
+            const uint32_t o0 = (uint32_t)pgt_row_off(sok ? gm : 0, g.eld0, g.e0_period, g.e0_hi);
+            BX_STORE4(so, sok ? o0 * 4u + hcol4 : BX_OOR, rs_0);
+            BX_STORE4(so, sok ? (uint32_t)gm * (uint32_t)(g.eld1 * 4) + hcol4 : BX_OOR, rs_1);
+          }
+        }
+      }
+    }
+    BX_FENCE();
+    e_issue_rows(b + nwg);                              // the next block's operands: behind every load of this iteration
+    BX_TRACE(6);
+  };
+  // a partial-sum region is free again when its reader has added the previous block's sums (part_seen) and — it carries
+  // the block's sums between the two barriers — every wavefront has taken its rows (tile_seen)
+  auto wait_regions_free = [&]() {
+    while (part_seen[cb] != n_iter) { BX_YIELD(); }
+    if constexpr (ROWS) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        while (tile_seen[q] != n_iter) { BX_YIELD(); }
+    }
+  };
+
   if (producer) {
     // ---- element map of a 32-row block over the 256 producer threads: row = ptid / 8, pairs (ptid % 8) + 8 t
     const int ptid = tid - 256, erow = ptid >> 3, el = ptid & 7;
@@ -240,14 +379,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       return bx_make_rsrc(g.A + (int64_t)(rows_left > 0 ? b : 0) * BM * g.lda, bytes);
     };
     // Loads return in order and every conversion is followed by the reload of its register pair, so exactly EPT - 1
-    // younger loads are in flight when element t of the previous round is due.
+    // younger loads of A are in flight when element t of the previous round is due — plus, in the steady state, the NOP
+    // gate-operand loads issued between the two rounds (at the end of the previous block's epilogue).
     bx_u32x2 raw[EPT];
     auto issue_load = [&](int t, const BxRsrc& r) {
+      if (BX_LAB_SKIP(8)) return;
       BX_LOAD2(raw[t], goff[t], r);
     };
-    auto convert_one = [&](int t, unsigned char* buf) {
+    auto convert_one = [&](int t, unsigned char* buf, auto NYOUNG) {
       uint32_t p1, p2, p3;
-      BX_WAIT(EPT - 1, raw[t]);
+      BX_WAIT(decltype(NYOUNG)::value, raw[t]);
       bx_split2_fast(bx_as_float(raw[t][0]), bx_as_float(raw[t][1]), p1, p2, p3);
       unsigned char* d = buf + lbase + 32 * t;
       *reinterpret_cast<uint32_t*>(d) = p1;
@@ -260,14 +401,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       for (int t = 0; t < EPT; ++t) issue_load(t, r0);
 #pragma unroll
       for (int t = 0; t < EPT; ++t) {
-        convert_one(t, lds);
+        convert_one(t, lds, BxInt<EPT - 1>{});
         issue_load(t, r1);
       }
+      e_issue_rows(rb);
     }
     BX_SETPRIO(1);        // the younger half of the workgroup loses the VALU arbitration otherwise
     bx_barrier();
     int cur = 0;
     for (; rb < n_blocks; rb += nwg, ++n_iter) {
+      BX_TRACE(0);
       unsigned char* bcur = lds + cur * BUF;
       unsigned char* bnxt = lds + (cur ^ 1) * BUF;
       const BxRsrc r2 = block_rsrc(rb + 2 * nwg);
@@ -284,6 +427,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
           for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (kbase + i) * 32);
 #pragma unroll
           for (int j = 0; j < WN; ++j) {
+            if (BX_LAB_SKIP(1)) continue;
             am[j] = bx_mfma(fa[0], bf[i][j][0], am[j]);
             ac[j] = bx_mfma(fa[0], bf[i][j][1], ac[j]);
             ac[j] = bx_mfma(fa[1], bf[i][j][0], ac[j]);
@@ -297,12 +441,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
         if (i < KQ) {
 #pragma unroll
           for (int t = i * EPT / KQ; t < (i + 1) * EPT / KQ; ++t) {
-            convert_one(t, bnxt);
+            convert_one(t, bnxt, BxInt<EPT - 1 + NOP>{});
             issue_load(t, r2);
           }
         }
       }
-      while (part_seen[cb] != n_iter) { BX_YIELD(); }     // the consumer has picked up the previous block's partial sums (long ago)
+      BX_TRACE(1);
+      wait_regions_free();
+      BX_TRACE(2);
       {
         float4* d = reinterpret_cast<float4*>(stage_part + ((part - 1) * NCOL + cb) * PART);
 #pragma unroll
@@ -312,12 +458,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
             d[(j * 4 + r4) * 64 + lane] = make_float4(am[j][4 * r4] + ac[j][4 * r4], am[j][4 * r4 + 1] + ac[j][4 * r4 + 1],
                                                       am[j][4 * r4 + 2] + ac[j][4 * r4 + 2], am[j][4 * r4 + 3] + ac[j][4 * r4 + 3]);
       }
+      BX_TRACE(3);
       bx_barrier();      // partial sums visible; everyone is done with this block's planes and the next block's are complete
+      BX_TRACE(4);
+      if constexpr (ROWS) {
+        bx_barrier();    // the block's sums are in LDS
+        row_epilogue(rb, BxInt<EPT>{});
+      }
       cur ^= 1;
     }
     BX_DRAIN();
   } else if (Q4 && part != 0) {
     // ---- compute-only consumers (Q4): their part of K, then the partial sums, like a producer without a block to fetch
+    e_issue_rows(rb);
     bx_barrier();
     int cur = 0;
     for (; rb < n_blocks; rb += nwg, ++n_iter) {
@@ -334,6 +487,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
         for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (kbase + i) * 32);
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
+          if (BX_LAB_SKIP(1)) continue;
           am[j] = bx_mfma(fa[0], bf[i][j][0], am[j]);
           ac[j] = bx_mfma(fa[0], bf[i][j][1], ac[j]);
           ac[j] = bx_mfma(fa[1], bf[i][j][0], ac[j]);
@@ -342,7 +496,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
           ac[j] = bx_mfma(fa[2], bf[i][j][0], ac[j]);
         }
       }
-      while (part_seen[cb] != n_iter) { BX_YIELD(); }
+      wait_regions_free();
       {
         float4* d = reinterpret_cast<float4*>(stage_part + ((part - 1) * NCOL + cb) * PART);
 #pragma unroll
@@ -353,8 +507,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
                                                       am[j][4 * r4 + 2] + ac[j][4 * r4 + 2], am[j][4 * r4 + 3] + ac[j][4 * r4 + 3]);
       }
       bx_barrier();
+      if constexpr (ROWS) {
+        bx_barrier();
+        row_epilogue(rb, BxInt<0>{});
+      }
       cur ^= 1;
     }
+    BX_DRAIN();
   } else {
     const int lo = lane & 31, hi = lane >> 5;
     float bias_r[WN];
@@ -364,44 +523,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       bias_r[j] = (g.bias && gn < g.N) ? g.bias[gn] : 0.f;
     }
     const bool cols_live = cb * WN * 32 < g.N;           // N <= 96: the last column wavefronts only keep the barriers company
-    // ---- operands of the fused GRU epilogues (H, and Z for the candidate gate), accumulator layout: register r of lane
-    // (lo, hi) is row (r & 3) + 8 (r >> 2) + 4 hi, column lo.  They are fetched one block ahead with hand-issued buffer
-    // loads (rows past M read zero) placed BEFORE the previous block's stores: loads and stores share vmcnt and return in
-    // order, so a load issued behind a block's stores would wait for their write acknowledgements (measured: + 4 us per
-    // block).  At the use, at least 16 younger instructions (the previous block's C stores) are in flight: vmcnt(16).
-    const int egn = cb * 32 + lo;                                        // EPI != 0 implies WN == 1
-    const bool e_live = EPI != 0 && cols_live && (EPI == 2 || cb * 32 >= g.eO);
-    const int eo = EPI == 1 ? egn - g.eO : egn;
-    float eh[EPI != 0 ? 16 : 1], ez[EPI == 2 ? 16 : 1];
-    const uint32_t evoff_h = (uint32_t)((4 * hi * g.eldh + eo) * 4), evoff_z = (uint32_t)((4 * hi * 2 * g.eO + egn) * 4);
-    auto e_rsrc = [&](const float* p, int64_t ld, int cols, int b) {
-      const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
-      const int64_t rows = rows_left < BM ? rows_left : BM;
-      const int64_t bytes = rows_left > 0 ? ((rows - 1) * ld + cols) * 4 : 0;
-      return bx_make_rsrc(p + (int64_t)(rows_left > 0 ? b : 0) * BM * ld, bytes);
-    };
-    auto e_issue = [&](int b) {
-      if constexpr (EPI != 0) {
-        const BxRsrc rh = e_rsrc(g.eH, g.eldh, g.eO, b);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int soff = BX_SGPR(((r & 3) + 8 * (r >> 2)) * (int)g.eldh * 4);
-          BX_LOAD1S(eh[r], evoff_h, rh, soff);
-        }
-        if constexpr (EPI == 2) {
-          const BxRsrc rz = e_rsrc(g.eZ, 2 * g.eO, 2 * g.eO, b);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int soff = BX_SGPR(((r & 3) + 8 * (r >> 2)) * 2 * g.eO * 4);
-            BX_LOAD1S(ez[r], evoff_z, rz, soff);
-          }
-        }
-      }
-    };
-    if (e_live) e_issue(rb);
+    e_issue_rows(rb);
     bx_barrier();
     int cur = 0;
     for (; rb < n_blocks; rb += nwg, ++n_iter) {
+      BX_TRACE(0);
       unsigned char* bcur = lds + cur * BUF;
       pgt_f32x16 am[WN], ac[WN];
 #pragma unroll
@@ -415,6 +541,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
         for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + i * 32);
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
+          if (BX_LAB_SKIP(1)) continue;
           am[j] = bx_mfma(fa[0], bf[i][j][0], am[j]);
           ac[j] = bx_mfma(fa[0], bf[i][j][1], ac[j]);
           ac[j] = bx_mfma(fa[1], bf[i][j][0], ac[j]);
@@ -428,9 +555,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = am[j][r] + ac[j][r] + bias_r[j];
+      BX_TRACE(1);
       bx_barrier();
-      // ---- the producer's partial sums join in registers; the block is stored straight from the accumulator layout: a
-      // register is one 128-byte row piece per half-wavefront
+      BX_TRACE(2);
+      // ---- the other parts' partial sums join in registers (accumulator layout)
 #pragma unroll
       for (int p = 1; p < NPART; ++p) {
         const float4* d = reinterpret_cast<const float4*>(stage_part + ((p - 1) * NCOL + cb) * PART);
@@ -455,43 +583,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
             bx_exact_tile(g, ra, (cb * WN + j) * 32 + lo, hi, bias_r[j], acc[j]);
           }
       }
-      if (cols_live) {
-        float side[EPI != 0 ? 16 : 1];                 // eX = H r (zr) / the new hidden state (candidate gate)
-        if constexpr (EPI != 0) {
-          if (e_live) {
-            // vmcnt counts loads AND stores, and only operations of the same kind retire in order: a store may be
-            // acknowledged before an older load has landed, so "N younger stores are in flight" proves nothing about the
-            // load.  The operand loads were issued a block ago (before that block's stores): drain.
+      if constexpr (ROWS) {
+        // the block's sums -> LDS, [column block][row][32] in the region its own part-1 sums came through (this wavefront
+        // has just read them); register r of lane (lo, hi) is row (r & 3) + 8 (r >> 2) + 4 hi, column lo
+        float* tile = reinterpret_cast<float*>(stage_part + cb * PART);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              BX_WAIT(0, eh[r]);
-              if constexpr (EPI == 2) BX_WAIT(0, ez[r]);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if constexpr (EPI == 1) {
-              acc[0][r] = bx_sigmoidf(acc[0][r]);
-              side[r] = eh[r] * acc[0][r];
-            } else {
-              acc[0][r] = bx_tanhf(acc[0][r]);
-              side[r] = pgt_gru_blend(ez[r], eh[r], acc[0][r]);
-            }
-          }
-          if (e_live) e_issue(rb + nwg);               // the next block's operands, ahead of this block's stores
-          BX_FENCE();
-        }
-        // eO0 in a two-level row layout (pgt_rowmap: H_t straight into the [B, T, N, O] result): one uniform division per
-        // block, a compare per row (a block of 32 rows crosses at most one period boundary when period >= 32)
-        int64_t o0_q = 0;
-        int o0_rem = 0;
-        if constexpr (EPI == 2) {
-          if (g.e0_period > 0) {
-            const uint32_t q = (uint32_t)BX_SGPR((int)((uint32_t)(rb * BM) / (uint32_t)g.e0_period));
-            o0_q = (int64_t)q * g.e0_hi;
-            o0_rem = rb * BM - (int)(q * (uint32_t)g.e0_period);
-          }
-        }
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lo] = acc[0][r];
+        BX_TRACE(3);
+        bx_barrier();
+        BX_TRACE(4);
+        row_epilogue(rb, BxInt<0>{});
+      } else if (cols_live) {
+        // two column blocks per wavefront (plain products with K <= 128): stored straight from the accumulator layout, a
+        // register is one 128-byte row piece per half-wavefront
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
           const int gn = (cb * WN + j) * 32 + lo;
@@ -503,20 +607,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
             const int gm = rb * BM + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (gm >= g.M) continue;
             cp[(int64_t)gm * g.ldc] = acc[j][r];
-            if constexpr (EPI == 1) {
-              if (gn >= g.eO) g.eX[(int64_t)gm * g.eldx + g.efin + (gn - g.eO)] = side[r];
-            } else if constexpr (EPI == 2) {
-              int64_t o0;
-              if (g.e0_period >= BM) {
-                const int rr = o0_rem + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const bool wrap = rr >= (int)g.e0_period;
-                o0 = o0_q + (wrap ? g.e0_hi : 0) + (int64_t)(rr - (wrap ? (int)g.e0_period : 0)) * g.eld0;
-              } else {
-                o0 = pgt_row_off(gm, g.eld0, g.e0_period, g.e0_hi);
-              }
-              g.eO0[o0 + gn] = side[r];
-              if (g.eO1) g.eO1[(int64_t)gm * g.eld1 + gn] = side[r];
-            }
           }
         }
       }
@@ -965,6 +1055,12 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (((int64_t)g.n_seg * g.a_seg_stride + 33 * g.lda + g.seg_k) * 4 >= (int64_t)0xfff00000) return 0;
   const int wn = g.N <= 128 ? 1 : 2;
   if (g.N > 320 || (wn == 2 && K > 128)) return 0;
+  // one column block per wavefront: the row-sliced epilogue moves quads (16 bytes) at absolute 32-bit byte offsets
+  if (wn == 1) {
+    auto fits = [&](int64_t ld, int64_t extra) { return ld >= 0 && ((int64_t)g.M * ld + extra + 4) * 4 < (int64_t)0x7ffffff0; };
+    if (g.N % 4 || g.c_seg_n % 4 || g.c_seg_stride < 0 ||
+        !fits(g.ldc, (int64_t)((g.N - 1) / g.c_seg_n) * g.c_seg_stride + g.c_seg_n)) return 0;
+  }
   // Where it does not pay (measured inside the training step, M = 211 968; g_bx = 2 runs them anyway for the tests):
   //  * short K into <= 128 columns: little arithmetic per row block, the fp32 tile kernels are as fast (48 vs 50 us);
   //  * K <= 64 into 256 columns: 85 vs 85 us.
@@ -975,10 +1071,19 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
     // the gate epilogues: whole 32-column blocks on either side of the z | r boundary, hidden width = N (h) or N / 2 (zr),
     // one output segment, K in the 21-step bucket (the short-K kernels have no epilogue variants)
     if (wn != 1 || K <= 128 || g.c_seg_n != g.N) return 0;
-    if (g.epi == 1 && (g.eO % 32 || g.N != 2 * g.eO)) return 0;
+    if (g.epi == 1 && (g.eO % 32 || g.N != 2 * g.eO || (g.N > 64 && g.eO != 64))) return 0;   // reset half = the last 64-column group
     // candidate gate: N = hidden <= 64 (the 128-wide instantiation would spill registers: scripts/bx_isa_audit.py)
     if (g.epi == 2 && (g.N != g.eO || g.N > 64)) return 0;
     if (g.epi != 1 && g.epi != 2) return 0;
+    auto fits = [&](int64_t ld, int64_t extra) { return ld >= 0 && ((int64_t)g.M * ld + extra + 4) * 4 < (int64_t)0x7ffffff0; };
+    if (!fits(g.eldh, g.eO)) return 0;
+    if (g.epi == 1 && !fits(g.eldx, g.efin + g.eO)) return 0;
+    if (g.epi == 2) {
+      if (!fits(2 * (int64_t)g.eO, 0) || (g.eO1 && !fits(g.eld1, g.N))) return 0;
+      const int64_t last = g.e0_period > 0 ? ((int64_t)(g.M - 1) / g.e0_period) * g.e0_hi + (g.e0_period - 1) * g.eld0
+                                           : (int64_t)(g.M - 1) * g.eld0;
+      if (g.eld0 < 0 || g.e0_hi < 0 || (last + g.N + 4) * 4 >= (int64_t)0x7ffffff0) return 0;
+    }
   }
   const int n_blocks = (int)pgt_cdiv(g.M, 32);
   // short K: the symmetric kernel (one column block per wavefront) when the output layout allows its buffer stores

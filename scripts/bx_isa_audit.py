@@ -4,10 +4,14 @@
 The kernels issue their block loads with inline asm and wait for them with inline-asm `s_waitcnt vmcnt(N)` statements
 tied to the destination registers ("+v").  The compiler does not know those registers are in flight, so two things must
 hold in the emitted code, in program order, for every kernel:
-  1. between an asm load and the first instruction that READS one of its destination registers there is a
-     hand-written `s_waitcnt vmcnt` (or a compiler `s_waitcnt vmcnt(0)`);
+  1. on EVERY control-flow path between an asm load and an instruction that READS one of its destination registers there
+     is a hand-written `s_waitcnt vmcnt` (or a compiler `s_waitcnt vmcnt(0)`) — the in-flight set is propagated over the
+     basic-block graph to a fixed point;
   2. no scratch (spill) instruction exists — a spilled in-flight register would be stored before it has landed, and
-     scratch accesses would change the vmcnt arithmetic.
+     scratch accesses would change the vmcnt arithmetic;
+  3. every hand-issued store of more than 8 bytes is followed, inside its asm statement, by `s_nop` (the store reads its
+     data registers over several cycles; the compiler pads its own wide stores against a VALU write in the next two issue
+     slots and cannot see into the asm — round 3 shipped corrupted quads to the GPU tests before this rule).
 Usage: python scripts/bx_isa_audit.py   (compiles the file with hipcc -S; exit code 1 on a violation)."""
 import os
 import re
@@ -39,7 +43,9 @@ def main():
     bad = 0
     for m in re.finditer(r"^(_ZN\S*gemm_bx\S*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
         name, body = m.group(1), m.group(2)
-        pending, in_asm, n_loads, n_waits, violations, scratch = {}, False, 0, 0, 0, 0
+        # ---- basic blocks (the compiler places loop blocks wherever it likes: text order says nothing about what runs
+        # between a load and a read, so the in-flight set is propagated over the control-flow graph to a fixed point)
+        blocks, cur, in_asm = [], {"label": None, "ins": [], "succ": [], "fall": True}, False
         for ln in body.split("\n"):
             s = ln.strip()
             if s.startswith(";;#ASMSTART"):
@@ -48,35 +54,84 @@ def main():
             if s.startswith(";;#ASMEND"):
                 in_asm = False
                 continue
+            lab = re.match(r"^(\.LBB\d+_\d+):", s)
+            if lab:
+                blocks.append(cur)
+                cur = {"label": lab.group(1), "ins": [], "succ": [], "fall": True}
+                continue
             if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
                 continue
             op, _, rest = s.partition(" ")
-            if "scratch_" in op:
-                scratch += 1
-            if op == "s_waitcnt" and "vmcnt" in rest:
-                if in_asm or "vmcnt(0)" in rest:
-                    pending.clear()
-                    n_waits += in_asm
-                continue
-            operands = rest.split(",")
-            if in_asm and op.startswith("buffer_load"):
-                n_loads += 1
-                for r in regs(operands[0]):
-                    pending[r] = True
-                continue
-            srcs = set()
-            start = 0 if op.startswith(("buffer_store", "global_store", "ds_write", "global_atomic", "v_cmp", "s_")) else 1
-            for tok in operands[start:]:
-                srcs |= regs(tok)
-            hit = srcs & set(pending)
-            if hit:
+            cur["ins"].append((op, rest.strip(), in_asm, s))
+            if op == "s_branch":
+                cur["succ"].append(rest.strip()); cur["fall"] = False
+                blocks.append(cur); cur = {"label": None, "ins": [], "succ": [], "fall": True}
+            elif op.startswith("s_cbranch"):
+                cur["succ"].append(rest.strip())
+                blocks.append(cur); cur = {"label": None, "ins": [], "succ": [], "fall": True}
+            elif op == "s_endpgm":
+                cur["fall"] = False
+                blocks.append(cur); cur = {"label": None, "ins": [], "succ": [], "fall": True}
+        blocks.append(cur)
+        index = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
+        succ = []
+        for i, b in enumerate(blocks):
+            out = [index[t] for t in b["succ"] if t in index]
+            if b["fall"] and i + 1 < len(blocks):
+                out.append(i + 1)
+            succ.append(out)
+
+        def transfer(b, pend, report):
+            pend = set(pend)
+            found = []
+            for op, rest, in_asm, s in b["ins"]:
+                if op == "s_waitcnt" and "vmcnt" in rest:
+                    if in_asm or "vmcnt(0)" in rest:
+                        pend.clear()
+                    continue
+                operands = rest.split(",")
+                if in_asm and op.startswith("buffer_load"):
+                    pend |= regs(operands[0])
+                    continue
+                start = 0 if op.startswith(("buffer_store", "global_store", "ds_write", "global_atomic", "v_cmp", "s_")) else 1
+                srcs = set()
+                for tok in operands[start:]:
+                    srcs |= regs(tok)
+                hit = srcs & pend
+                if hit and report:
+                    found.append((sorted(hit), s))
+                if start == 1:                      # an overwritten register is no longer the load's
+                    pend -= regs(operands[0])
+            return pend, found
+
+        ins = [set() for _ in blocks]
+        changed = True
+        while changed:
+            changed = False
+            for i, b in enumerate(blocks):
+                out, _ = transfer(b, ins[i], False)
+                for j in succ[i]:
+                    if not out <= ins[j]:
+                        ins[j] |= out
+                        changed = True
+        violations, n_loads, n_waits, scratch = 0, 0, 0, 0
+        for b in blocks:                            # rule 3
+            for k, (op, rest, in_asm, s) in enumerate(b["ins"]):
+                if in_asm and re.match(r"buffer_store_dwordx[34]", op):
+                    nxt = b["ins"][k + 1] if k + 1 < len(b["ins"]) else None
+                    if not (nxt and nxt[2] and nxt[0] == "s_nop"):
+                        violations += 1
+                        print(f"  {name[:60]}: wide asm store without s_nop: `{s}`")
+        for i, b in enumerate(blocks):
+            _, found = transfer(b, ins[i], True)
+            for hit, s in found:
                 violations += 1
                 if violations <= 3:
-                    print(f"  {name[:60]}: reads in-flight v{sorted(hit)} in `{s}`")
-            # a register that is overwritten is no longer the load's (the load result is dead)
-            if start == 1:
-                for r in regs(operands[0]):
-                    pending.pop(r, None)
+                    print(f"  {name[:60]}: reads in-flight v{hit} in `{s}`")
+            for op, rest, in_asm, s in b["ins"]:
+                n_loads += in_asm and op.startswith("buffer_load")
+                n_waits += in_asm and op == "s_waitcnt" and "vmcnt" in rest
+                scratch += "scratch_" in op
         print(f"{name[22:72]:52s} asm loads {n_loads:3d}  hand waits {n_waits:3d}  early reads {violations}  scratch {scratch}")
         bad += violations + scratch
     return 1 if bad else 0

@@ -6,3 +6,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include -I py
 for h in ellw_lab ellw_prod_lab gemm_lab gemm_bx_lab gemm_bx_tn_lab slab_lab; do
   /opt/rocm/bin/hipcc $FLAGS lab/$h.hip -o lab/$h || exit 1
 done
+# the shipped K-split split-bf16 kernel, taken apart at compile time (BX_SKIP mask: 1 no MFMAs, 4 no epilogue stores, 8 no loads
+# of A, 16 no gate-operand loads, 32 no wait for them); mask 0 also prints the per-wavefront timeline
+for m in 0 1 4 8 16 20 21 28 9 29 32; do
+  /opt/rocm/bin/hipcc $FLAGS -DBX_SKIP=$m lab/gemm_bx_trace_lab.hip -o lab/gemm_bx_trace_lab_$m || exit 1
+done

@@ -193,7 +193,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
   constexpr int EPT = (KP / 2) / 8;                       // float pairs per producer thread and block (8 threads per row)
   constexpr int PART = 64 * 16 * WN * 4;                  // a column's partial sums, accumulator layout
   constexpr int NPART = Q4 ? 4 : 2, NCOL = Q4 ? 2 : 4;     // parts of K x column blocks = the eight wavefronts
-  constexpr int KQ = KSTEPS / NPART, KMAX = KSTEPS - (NPART - 1) * KQ;   // k-steps of a part / of the last part
+  // k-steps of the parts.  The producers also convert the next block (round 3's timeline: their k-loop took 2.6 - 4.1 us
+  // against the consumers' 1.5 - 3.1, and the consumers waited for them at the barrier), so they get FEWER k-steps:
+  // four parts (registers to spare): consumers 0, 1 KC0 = 8 of 21, consumers 2, 3 KC1 = 9, producers KPR = 2 each (same box,
+  // inside the step: 130 - 133 us; 7 / 8 / 3 / 3: 128 - 147, two modes; the even split of round 2: 131 - 146); two parts:
+  // consumers KC0 = 11, producers KPR = 10 (136 -> 132 us) — 12 / 9 would balance them, but 144 registers of B spill.
+  constexpr int KPR = Q4 ? (KSTEPS / 10 > 0 ? KSTEPS / 10 : 1) : (KSTEPS * 10 / 21 > 0 ? KSTEPS * 10 / 21 : 1);
+  constexpr int KC0 = Q4 ? (KSTEPS - 2 * KPR) / 2 : KSTEPS - KPR, KC1 = Q4 ? KSTEPS - 2 * KPR - KC0 : 0;
+  constexpr int KMAX = KC0 > KC1 ? (KC0 > KPR ? KC0 : KPR) : (KC1 > KPR ? KC1 : KPR);
   constexpr int NREG = (NPART - 1) * NCOL;                 // partial-sum regions
   // ---- WN == 1: the block's sums leave through a ROW-SLICED epilogue on all eight wavefronts.  (Round 3's timeline,
   // lab/gemm_bx_trace_lab.hip: with the epilogue on the part-0 wavefronts alone — 16 rows x 1 .. 3 arrays of 128-byte row
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
   // the reset half needs H, and that half is the LAST group (N = 2 O = 128 at two groups, N <= 64 at one)
   constexpr int OPG = CPL - 1;                             // the group that carries gate operands
   constexpr int NOP = !ROWS || EPI == 0 ? 0 : (EPI == 1 ? 1 : 2);   // gate-operand loads (16 bytes per lane) per wavefront and block
-  static_assert((KP / 2) % 8 == 0 && KQ >= 1 && (!Q4 || WN == 1) && (EPI == 0 || WN == 1), "shape");
+  static_assert((KP / 2) % 8 == 0 && KPR >= 1 && KC0 >= 1 && (!Q4 || KC1 >= 1) && (!Q4 || WN == 1) && (EPI == 0 || WN == 1), "shape");
   static_assert(EPT - 1 + NOP < 64, "vmcnt is six bits");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NREG * PART + 64];
   unsigned char* const stage_part = lds + 2 * BUF;
@@ -220,7 +227,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
   const bool producer = wave >= 4;
   const int cb = Q4 ? (wc & 1) : wc;                                       // column block
   const int part = (producer ? NPART / 2 : 0) + (Q4 ? (wc >> 1) : 0);      // part of K
-  const int kbase = part * KQ, ksteps = part == NPART - 1 ? KMAX : KQ;
+  const int kbase = producer ? KC0 + KC1 + (Q4 ? (wc >> 1) * KPR : 0) : (part == 0 ? 0 : KC0);
+  const int ksteps = producer ? KPR : (part == 0 ? KC0 : KC1);
   const int nwg = gridDim.x;
   const int Ktot = g.n_seg * g.seg_k;
   // ---- B slice -> registers (this wavefront's columns x its part of K); every piece rounded to nearest
@@ -420,8 +428,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
 #pragma unroll
         for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac[j][r] = 0.f; }
 #pragma unroll
-      for (int i = 0; i < KMAX; ++i) {
-        if (i < ksteps) {
+      for (int i = 0; i < KPR; ++i) {
+        {
           bx_u32x4 fa[3];
 #pragma unroll
           for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (kbase + i) * 32);
@@ -438,9 +446,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
         }
         // this k-step's share of the next block: fp32 (in registers since the previous iteration) -> bf16 planes in the
         // other buffer, and the load of the block after it into the freed registers
-        if (i < KQ) {
+        {
 #pragma unroll
-          for (int t = i * EPT / KQ; t < (i + 1) * EPT / KQ; ++t) {
+          for (int t = i * EPT / KPR; t < (i + 1) * EPT / KPR; ++t) {
             convert_one(t, bnxt, BxInt<EPT - 1 + NOP>{});
             issue_load(t, r2);
           }
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
 #pragma unroll
         for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac[j][r] = 0.f; }
 #pragma unroll
-      for (int i = 0; i < KQ; ++i) {
+      for (int i = 0; i < KC1; ++i) {
         bx_u32x4 fa[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (kbase + i) * 32);
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_kernel(PgtGemmArgs g, int n_bl
 #pragma unroll
         for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac[j][r] = 0.f; }
 #pragma unroll
-      for (int i = 0; i < KQ; ++i) {
+      for (int i = 0; i < KC0; ++i) {
         bx_u32x4 fa[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + i * 32);

@@ -110,8 +110,9 @@ def masked_mae_loss(y_pred, y_true):
 
 class Model(torch.nn.Module):
     """BatchedDCRNN in its default configuration (contiguous [B, T, N, O] result, as the reference returns it) + the per-node
-    read-out of the reference's examples; `dropin`: that read-out as torch.nn.Linear (what swapping the import alone gives)
-    instead of this package's Linear (same parameters, the product on the library's streaming kernels)."""
+    read-out of the reference's examples; `dropin`: that read-out as torch.nn.Linear (what swapping the import alone gives:
+    BatchedDCRNN's result routes a skinny F.linear to the package's streaming kernels, nn/recurrent/dcrnn.py:_StatesTensor)
+    instead of this package's Linear (same parameters, the same kernels)."""
 
     def __init__(self, hidden, dropin=False):
         super().__init__()
@@ -496,7 +497,8 @@ def main():
                 variants[name] = {"error": repr(e)}
             torch.cuda.empty_cache()
 
-        variant("dropin_default", "import swap only: BatchedDCRNN defaults + torch.nn.Linear read-out", dropin=True)
+        variant("dropin_default", "import swap only: BatchedDCRNN defaults + the user's torch.nn.Linear read-out (its F.linear call on "
+                "the returned states runs on the package's streaming kernels: BatchedDCRNN.readout_interception)", dropin=True)
         variant("edges_1722", "1 722-edge graph (the reference's METR-LA data)", edges=1722)
         lib.tune("gemm_bx", 0)
         try:
@@ -511,6 +513,13 @@ def main():
         if not args.graph:
             variant("hipgraph_step", "--graph: forward+backward and the update as two hipGraphs, the all-reduce between them eager",
                     graph=True)
+        # last: the BLAS library brings its own workspaces into the pool
+        BatchedDCRNN.readout_interception = False
+        try:
+            variant("dropin_blas_readout", "dropin_default with readout_interception = False: torch's own BLAS product for the 64 -> 2 "
+                    "read-out over 2.5 M rows", dropin=True)
+        finally:
+            BatchedDCRNN.readout_interception = True
     if rank == 0 and world == 1 and not args.no_extra:
         import bench_configs as BCfg
         cores = min(os.cpu_count() or 1, 32)
@@ -547,7 +556,7 @@ def main():
                        "parallelism": f"dp{world}", "hidden": args.hidden, "K": 3, "init_passes": 1,
                        "graphed": bool(args.graph),
                        "output_layout": "BatchedDCRNN default (contiguous [B,T,N,O], stored by the gate epilogues) + this package's Linear "
-                                        "read-out; torch.nn.Linear read-out = variants.dropin_default"},
+                                        "read-out; torch.nn.Linear read-out = variants.dropin_default (routed to the same kernels) / dropin_blas_readout (torch's BLAS)"},
             "edge_messages_per_s": head["edge_messages_per_s"],
             "epoch_time_s_23974_windows": 23974.0 / (world * args.batch) * dt / args.steps,
             "final_loss": final_loss,

@@ -62,6 +62,42 @@ class BatchedDConv(DConv):
         return super().forward(X, edge_index, edge_weight)
 
 
+class _StatesTensor(torch.Tensor):
+    """What `BatchedDCRNN.forward` returns: a plain tensor in every respect but one — the reference's examples feed the
+    `[B, T, N, out]` states to a per-node read-out `torch.nn.Linear(out, 1 … 4)` (examples/indexBatching/DCRNN/*_main.py,
+    examples/recurrent/dcrnn_example.py:24-31), and for 1 – 4 output features over millions of rows the BLAS library
+    behind `F.linear` picks a pathological tile (≈ 5 ms per call at 2.5 M rows against 0.14 ms for one streaming pass:
+    bench.py `variants.dropin_default`).  `F.linear(states, weight, bias)` with a skinny fp32 weight is therefore routed to
+    this package's streaming kernels (same parameters, same arithmetic type, ordinary autograd); every other operation —
+    and `F.linear` with any other operand — runs as usual and returns plain tensors.
+    `BatchedDCRNN.readout_interception = False` hands out plain tensors instead."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.nn.functional.linear and not kwargs and 2 <= len(args) <= 3:
+            x, w = args[0], args[1]
+            b = args[2] if len(args) == 3 else None
+            if (type(x) is _StatesTensor and type(w) in (torch.Tensor, torch.nn.Parameter) and w.dim() == 2 and
+                    1 <= w.size(0) <= 4 and w.size(1) == x.size(-1) and x.dtype == w.dtype == torch.float32 and
+                    x.device == w.device and (b is None or (type(b) in (torch.Tensor, torch.nn.Parameter) and
+                                                            b.dtype == torch.float32 and b.device == w.device))):
+                from ..conv import _rows_in_memory_order
+                x2, restore = _rows_in_memory_order(x.as_subclass(torch.Tensor))
+                return restore(ops.linear(x2, w.t(), b))
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        return _plain(out)
+
+
+def _plain(out):
+    if type(out) is _StatesTensor:
+        return out.as_subclass(torch.Tensor)
+    if isinstance(out, (tuple, list)):
+        return type(out)(_plain(o) for o in out)
+    return out
+
+
 def _cell_weights(conv_z, conv_r, conv_h):
     """The stacked operands of the two gate products from the three convolutions' parameters: one launch
     (ops.CellWeightsFunction) instead of three weight re-stackings and two concatenations."""
@@ -114,6 +150,9 @@ class BatchedDCRNN(torch.nn.Module):
     B-times replicated edge list in a Python loop, dcrnn.py:363-369): rows are laid out node-major [N][B][C] so one
     aggregation launch covers the whole batch with B*C-float coalesced neighbour reads."""
 
+    # a skinny `torch.nn.Linear` read-out applied to the result runs on this package's streaming kernels (_StatesTensor)
+    readout_interception = True
+
     def __init__(self, in_channels: int, out_channels: int, K: int, bias: bool = True):
         super().__init__()
         self.in_channels = in_channels
@@ -140,8 +179,11 @@ class BatchedDCRNN(torch.nn.Module):
             # [B][T][N*F] -> [T][B][N*F]
             Xbm = ops.Swap01.apply(X.contiguous().view(B, T, N * Fin), B, T, N * Fin).view(T, B * N, Fin)
             H0 = torch.zeros(B * N, O, device=X.device, dtype=X.dtype)
-            return ops.DCRNNSeqFunction.apply(Xbm, H0, Wzr, bzr, Wh, bh, g, self.K, B, True, True)       # [B, T, N, O]
+            return self._states(ops.DCRNNSeqFunction.apply(Xbm, H0, Wzr, bzr, Wh, bh, g, self.K, B, True, True))   # [B, T, N, O]
         # [B][T*N][F] -> [T*N][B][F]  (node-major rows m = n*B + b per step: one aggregation launch per hop)
         Xnm = ops.Swap01.apply(X.contiguous().view(B, T * N, Fin), B, T * N, Fin).view(T, N * B, Fin)
         H0 = torch.zeros(N * B, O, device=X.device, dtype=X.dtype)
-        return ops.DCRNNSeqFunction.apply(Xnm, H0, Wzr, bzr, Wh, bh, g, self.K, B, False, True)        # [B, T, N, O]
+        return self._states(ops.DCRNNSeqFunction.apply(Xnm, H0, Wzr, bzr, Wh, bh, g, self.K, B, False, True))   # [B, T, N, O]
+
+    def _states(self, out):
+        return out.as_subclass(_StatesTensor) if self.readout_interception else out

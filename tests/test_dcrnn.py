@@ -426,3 +426,49 @@ def test_dcrnn_k1_cell_is_one_launch_each_way_and_matches_the_oracle(backend, n,
         H0 = backend.t(H) if hidden else torch.zeros(n, O, device=backend.device)
         general = ops.DCRNNSeqFunction.apply(backend.t(X).unsqueeze(0), H0, Wzr, bzr, Wh, bh, g, 1, 1)[0]
     assert_close_with_nonfinite(out.detach(), general, 2e-6, 1e-5, "one-launch cell vs general path")
+
+
+def test_batched_dcrnn_states_route_a_skinny_torch_linear_readout_to_the_streaming_kernels(backend):
+    """The reference's examples apply `torch.nn.Linear(out, 1 … 4)` to BatchedDCRNN's `[B, T, N, out]` result
+    (pems_bay_main.py / dcrnn_example.py): that one call runs on this package's skinny kernels (same values, same
+    gradients as torch's own product); anything else done with the result is ordinary torch and yields plain tensors."""
+    import torch.nn.functional as TF
+    from pytorch_geometric_temporal_amd import ops
+    from pytorch_geometric_temporal_amd.nn.recurrent.dcrnn import _StatesTensor
+    torch.manual_seed(3)
+    n, B, T, fin, O = 12, 3, 4, 2, 8
+    ei_np, ew_np = syn.sensor_graph(n, 60, seed=1, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    m = BatchedDCRNN(fin, O, 2).to(backend.device)
+    head = torch.nn.Linear(O, 2).to(backend.device)
+    wide = torch.nn.Linear(O, 16).to(backend.device)
+    X = backend.t(torch.randn(B, T, n, fin))
+    calls = []
+    orig = ops.linear
+    try:
+        ops.linear = lambda *a: (calls.append(1), orig(*a))[1]
+        h = m(X, ei, ew)
+        assert type(h) is _StatesTensor and h.shape == (B, T, n, O) and h.is_contiguous()
+        y = head(h)                                   # routed
+        assert calls == [1] and type(y) is torch.Tensor
+        z = wide(h)                                   # 16 output features: torch's own product
+        assert calls == [1] and type(z) is torch.Tensor
+        assert type(h * 2) is torch.Tensor and type(h.sum()) is torch.Tensor and type(torch.relu(h)) is torch.Tensor
+        assert type(TF.linear(torch.relu(h), head.weight, head.bias)) is torch.Tensor and calls == [1]
+    finally:
+        ops.linear = orig
+    (y.square().mean() + z.mean()).backward()
+    g_head, g_conv = head.weight.grad.clone(), m.conv_x_z.weight.grad.clone()
+    # the same computation on plain tensors
+    head.zero_grad(); wide.zero_grad(); m.zero_grad()
+    m.readout_interception = False
+    h2 = m(X, ei, ew)
+    assert type(h2) is torch.Tensor
+    y2, z2 = head(h2), wide(h2)
+    (y2.square().mean() + z2.mean()).backward()
+    assert_close_with_nonfinite(y, y2, 1e-6, 1e-5, "read-out")
+    assert_close_with_nonfinite(g_head, head.weight.grad, 1e-6, 1e-4, "d/d read-out weight")
+    assert_close_with_nonfinite(g_conv, m.conv_x_z.weight.grad, 1e-6, 1e-4, "d/d conv weight")
+    m.readout_interception = True
+    sd = m.state_dict()                                # nothing about the module's parameters changes
+    assert all(type(v) is torch.Tensor for v in sd.values())

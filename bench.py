@@ -490,9 +490,12 @@ def main():
         def variant(name, what, edges=args.edges, **kw):
             torch.cuda.empty_cache()
             try:
-                d, _, st, _ = train_run(device, rank, world, series, edges, args.batch, args.hidden, 8, 3, **kw)
-                del st
-                variants[name] = dict(throughput(d, edges, args.batch, 8), what=what)
+                best = None
+                for _ in range(2):                            # short auxiliary runs on a shared box: the better of two
+                    d, _, st, _ = train_run(device, rank, world, series, edges, args.batch, args.hidden, 8, 3, **kw)
+                    del st
+                    best = d if best is None or d < best else best
+                variants[name] = dict(throughput(best, edges, args.batch, 8), what=what + " (8 steps, better of two runs)")
             except Exception as e:                            # an auxiliary line must never cost the bench line
                 variants[name] = {"error": repr(e)}
             torch.cuda.empty_cache()

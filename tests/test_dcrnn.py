@@ -472,3 +472,18 @@ def test_batched_dcrnn_states_route_a_skinny_torch_linear_readout_to_the_streami
     m.readout_interception = True
     sd = m.state_dict()                                # nothing about the module's parameters changes
     assert all(type(v) is torch.Tensor for v in sd.values())
+
+
+def test_dcrnn_k1_cell_takes_strided_rows(backend):
+    """X and H handed in as column slices of wider tensors (row stride > row width): read in place."""
+    torch.manual_seed(5)
+    n, fin, O = 40, 3, 6
+    m = DCRNN(fin, O, 1).to(backend.device)
+    big_x, big_h = backend.t(torch.randn(n, fin + 5)), backend.t(torch.randn(n, O + 3))
+    X, H = big_x[:, 2:2 + fin], big_h[:, 1:1 + O]
+    assert X.stride(0) == fin + 5 and not X.is_contiguous()
+    ei = backend.t(torch.zeros(2, 1, dtype=torch.long))
+    with torch.no_grad():
+        a = m(X, ei, None, H)
+        b = m(X.contiguous(), ei, None, H.contiguous())
+    assert torch.equal(a, b)

@@ -730,3 +730,26 @@ def test_small_graph_edge_list_is_range_checked_once(backend):
     bad = backend.t(torch.tensor([[0, 1, 7], [1, 2, 0]]))
     with pytest.raises(IndexError):
         ops.small_edges(bad, None, 5)
+
+
+def test_small_graph_gcn_layer_at_its_limits(backend):
+    """N = 512 nodes, E = 4 096 edges, 16 output features (N * out = the LDS block's 8 192 floats): the largest graph
+    the one-workgroup layer takes, against the prepared-operator path."""
+    from pytorch_geometric_temporal_amd import ops
+    from pytorch_geometric_temporal_amd.nn.recurrent.evolvegcn import GCNConv_Fixed_W
+    g = torch.Generator().manual_seed(11)
+    n, E, Fi, Fo = 512, 4096, 7, 16
+    ei = torch.randint(0, n, (2, E), generator=g)
+    ew = torch.rand(E, generator=g) + 0.05
+    X, W = torch.randn(n, Fi, generator=g), torch.randn(Fi, Fo, generator=g)
+    assert ops.gcn_small_fits(n, E, Fi, Fo) and not ops.gcn_small_fits(n, E, Fi, Fo + 1)
+    conv = GCNConv_Fixed_W(Fi, Fo)
+    Xd, Wd = backend.t(X), backend.t(W).requires_grad_()
+    eid, ewd = backend.t(ei), backend.t(ew)
+    out = conv(Wd, Xd, eid, ewd)
+    out.square().sum().backward()
+    Wp = backend.t(W).requires_grad_()
+    ref = ops.propagate(ops.gcn_graph(eid, ewd, n, False, True), ops.linear(Xd, Wp, None))
+    ref.square().sum().backward()
+    assert_close_with_nonfinite(out, ref, 2e-6, 1e-5, "forward")
+    assert_close_with_nonfinite(Wd.grad, Wp.grad, 1e-4, 1e-4, "dW")

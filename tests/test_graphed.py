@@ -89,3 +89,41 @@ def test_graphed_forward_backward_reproduces_eager_gradients():
         le = float(fwd_bwd(X, y))
         assert lg == pytest.approx(le, rel=1e-6, abs=1e-7)
         torch.testing.assert_close(gg, flat.flat, rtol=2e-4, atol=1e-5)      # dW: fp32 atomics in a different order
+
+
+@pytest.mark.gpu
+def test_graphed_step_with_a_torch_linear_readout_on_the_states():
+    """The import-swap user's model (BatchedDCRNN + torch.nn.Linear read-out): the routed F.linear call is captured like any
+    other launch — the first replayed loss equals the eager one."""
+    from pytorch_geometric_temporal_amd.graphed import GraphedStep
+    dev = torch.device("cuda:0")
+    n_nodes, hidden, T, B = 40, 8, 4, 6
+    ei_np, ew_np = syn.sensor_graph(n_nodes, 7 * n_nodes, seed=2, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np).to(dev), torch.from_numpy(ew_np).to(dev)
+    series = torch.from_numpy(syn.traffic_series(200, n_nodes, seed=3)).to(dev)
+    ar = torch.arange(T, device=dev)
+    i = torch.randint(0, 200 - 2 * T, (B,), generator=torch.Generator().manual_seed(1)).to(dev)
+    pair = (i[:, None] + ar[None, :], i[:, None] + T + ar[None, :])
+
+    def build():
+        torch.manual_seed(0)
+        rnn, head = BatchedDCRNN(2, hidden, K=3).to(dev), torch.nn.Linear(hidden, 2).to(dev)
+        params = list(rnn.parameters()) + list(head.parameters())
+        flat = dp.FlatParameters(params)
+        opt = flat.optimizer(torch.optim.Adam, lr=1e-2, capturable=True)
+
+        def step(xi, yi):
+            loss = (head(rnn(series[xi], ei, ew)) - series[yi]).abs().mean()
+            flat.zero()
+            loss.backward()
+            opt.step()
+            return loss
+        return flat, step
+
+    _, step_e = build()
+    eager = float(step_e(*pair))
+    flat_g, step_g = build()
+    snapshot = flat_g.data.clone()
+    graphed = GraphedStep(step_g, pair, warmup=2)
+    flat_g.data.copy_(snapshot)
+    assert float(graphed(*pair)) == pytest.approx(eager, rel=1e-5, abs=1e-6)

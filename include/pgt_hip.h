@@ -47,7 +47,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 10
+#define PGT_ABI_VERSION 11
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -491,6 +491,35 @@ int pgt_relu_layernorm_f32(const float* Z, int64_t row_period, int64_t stride_hi
 int pgt_relu_layernorm_bwd_f32(const float* Z, int64_t row_period, int64_t stride_hi, int64_t stride_lo, const float* gamma,
                                const float* stats, const float* dY, int64_t rows, int64_t C, float* dZ, float* dgamma,
                                float* dbeta, pgt_stream_t stream);
+
+/* Gated temporal convolution of an ST-Conv block — TemporalConv.forward (nn/attention/stgcn.py:27-44): three
+ * Conv2d(Cin -> Cout, (1, k)) over the time axis and H = relu(P * sigmoid(Q) + R), on the reference's own layout:
+ * X [B, T, N, Cin] (rows of ldx floats) -> H [B, T - k + 1, N, Cout] contiguous, no permutes, no im2col: tap dt is the same
+ * matrix dt * N rows further down, the three convolutions are ONE product [rows, k Cin] x [k Cin, 3 Cout] on the matrix
+ * cores and the gate is computed on the accumulators.  Wp [k * Cin, 3 * Cout]: Wp[dt * Cin + ci, g * Cout + c] =
+ * conv_{g+1}.weight[c, ci, 0, dt]; bias3 [3 * Cout] (conv_1 | conv_2 | conv_3) or NULL.  P, S [B, T', N, Cout] (both or
+ * neither) receive conv_1's output and sigmoid(conv_2's) for the adjoint.
+ * Adjoint of the gate: dZ [(k - 1) N + B T N, 3 Cout] = (dP | dQ | dR) in INPUT row numbering behind (k - 1) N zero rows,
+ * zero where a step has no output — the operand of the two gradient products: weight gradient = pgt_gemm_tn_acc_f32 of X
+ * as k segments N rows apart against dZ + (k - 1) N rows over (B T - k + 1) N rows; input gradient = pgt_gemm_f32 of dZ as k
+ * segments N rows apart against the taps in reverse order. */
+int pgt_tconv_glu_f32(const float* X, int64_t ldx, int64_t B, int64_t T, int64_t N, int64_t Cin, int64_t Cout, int64_t k,
+                      const float* Wp, const float* bias3, float* H, float* P, float* S, pgt_stream_t stream);
+int pgt_tconv_glu_bwd_f32(const float* dH, const float* H, const float* P, const float* S, int64_t B, int64_t T, int64_t N,
+                          int64_t Cout, int64_t k, float* dZ, pgt_stream_t stream);
+
+/* BatchNorm2d(num_nodes) of STConv (nn/attention/stgcn.py:129, :156-159; the reference permutes [B, T', N, C] to
+ * [B, N, T', C] so that the NODE is the normalised channel) in place on X [R = B T', N, C] contiguous: per node n, mean and
+ * biased variance over the R * C values (training) or the running statistics (evaluation), Y = (X - mean) / sqrt(var + eps)
+ * * gamma[n] + beta[n] (gamma / beta NULL = 1 / 0).  Training also updates running_mean / running_var [N] (either may be
+ * NULL) with `momentum` (torch semantics: unbiased variance) in the same launch.  stats [2 N] receives (mean, 1 / std) for
+ * the adjoint (may be NULL in evaluation).  One workgroup per node, sums in a fixed order (deterministic).
+ * Adjoint: dX (may be NULL), dgamma / dbeta [N] (STORED, may be NULL); training = 0 treats the statistics as constants. */
+int pgt_batchnorm_nodes_f32(const float* X, int64_t R, int64_t N, int64_t C, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, int training, float* Y,
+                            float* stats, pgt_stream_t stream);
+int pgt_batchnorm_nodes_bwd_f32(const float* dY, const float* X, const float* stats, const float* gamma, int64_t R, int64_t N,
+                                int64_t C, int training, float* dX, float* dgamma, float* dbeta, pgt_stream_t stream);
 
 /* Index-batch window gather (signal/index_dataset.py:32-57; examples/indexBatching: "GPU-index-batching"): for every
  * sample b, X[b] = data[idx[b] : idx[b] + h], Y[b] = data[idx[b] + h : idx[b] + 2 h] from the resident series

@@ -138,9 +138,16 @@ PROTOTYPES = {
     "pgt_relu_layernorm_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_f32, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "pgt_relu_layernorm_bwd_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr,
                                            c_ptr]),
+    "pgt_tconv_glu_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                  c_ptr]),
+    "pgt_tconv_glu_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    "pgt_batchnorm_nodes_f32": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_ptr,
+                                        c_ptr, c_ptr]),
+    "pgt_batchnorm_nodes_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
+                                            c_ptr]),
 }
 
-EXPECTED_ABI = 10
+EXPECTED_ABI = 11
 
 
 class PgtLib:

@@ -3,12 +3,16 @@
 The graph convolution of the ST-Conv block is the message-passing part: the reference calls ChebConv once per
 (batch, time) slice in a Python double loop (stgcn.py:151-153), recomputing the Laplacian normalisation each time.
 Here all B*T' slices are folded into the feature dimension of ONE Chebyshev stack (K-1 aggregation launches + one MFMA
-GEMM in total).  The temporal gated convolutions and the batch norm are dense torch modules, as in the reference.
+GEMM in total).  The gated temporal convolutions (three Conv2d + the gate: ONE launch on the matrix cores, csrc/tconv.hip)
+and the node-wise batch norm run on the reference's own [B, T, N, C] layout — the reference's four permutes per block do
+not exist here; `conv_1/2/3` and `_batch_norm` remain the torch modules that HOLD the parameters and buffers, so reference
+checkpoints load with strict=True.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
 from ..conv import ChebConv
 
 
@@ -22,11 +26,7 @@ class TemporalConv(nn.Module):
         self.conv_3 = nn.Conv2d(in_channels, out_channels, (1, kernel_size))
 
     def forward(self, X):
-        X = X.permute(0, 3, 2, 1)
-        P = self.conv_1(X)
-        Q = torch.sigmoid(self.conv_2(X))
-        H = F.relu(P * Q + self.conv_3(X))
-        return H.permute(0, 3, 2, 1)
+        return ops.temporal_conv(X, self.conv_1, self.conv_2, self.conv_3)     # relu(P * sigmoid(Q) + R), stgcn.py:36-44
 
 
 class STConv(nn.Module):
@@ -54,6 +54,4 @@ class STConv(nn.Module):
         T = self._graph_conv(T_0, edge_index, edge_weight)             # every (b, t) slice in one Chebyshev stack
         T = F.relu(T)
         T = self._temporal_conv2(T)
-        T = T.permute(0, 2, 1, 3)
-        T = self._batch_norm(T)
-        return T.permute(0, 2, 1, 3)
+        return ops.batch_norm_nodes(T, self._batch_norm, self.training)  # BatchNorm2d over the node axis, stgcn.py:156-159

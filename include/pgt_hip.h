@@ -521,6 +521,21 @@ int pgt_batchnorm_nodes_f32(const float* X, int64_t R, int64_t N, int64_t C, con
 int pgt_batchnorm_nodes_bwd_f32(const float* dY, const float* X, const float* stats, const float* gamma, int64_t R, int64_t N,
                                 int64_t C, int training, float* dX, float* dgamma, float* dbeta, pgt_stream_t stream);
 
+/* T-GCN cell parameters (nn/recurrent/temporalgcn.py:38-70, :82-102): a gate is linear_g(cat[conv_g(X), H']) with conv_g a
+ * PyG GCNConv; both maps are linear, so with AX = A_hat X (one aggregation at the input width for the three gates)
+ *   pre_g = [AX | H'] W'_g + b'_g,  W'_g = [Wc_g^T L_g[:, :O]^T ; L_g[:, O:]^T] (Fin + O rows),  b'_g = lb_g + L_g[:, :O] bc_g
+ * and the cell runs on pgt_gemm_gru_zr_f32 / pgt_gemm_gru_h_f32.  pack: Wc[g] = conv_g.lin.weight [O, Fin], bc[g] = conv_g.bias
+ * [O] | NULL, L[g] = linear_g.weight [O, 2 O], lb[g] = linear_g.bias [O] | NULL for g = z, r, h (host arrays of three device
+ * pointers) -> Wzr [Fin + O, 2 O], bzr [2 O], Wh [Fin + O, O], bh [O].  unpack: the adjoint — dWc[g], dL[g] (and dbc[g], dlb[g]
+ * where non-NULL) STORED from (dWzr, dbzr, dWh, dbh); one launch each, sums in index order. */
+int pgt_tgcn_pack_weights_f32(const float* const Wc[3], const float* const bc[3], const float* const L[3],
+                              const float* const lb[3], int64_t Fin, int64_t O, float* Wzr, float* bzr, float* Wh, float* bh,
+                              pgt_stream_t stream);
+int pgt_tgcn_unpack_weight_grads_f32(const float* dWzr, const float* dbzr, const float* dWh, const float* dbh,
+                                     const float* const Wc[3], const float* const bc[3], const float* const L[3], int64_t Fin,
+                                     int64_t O, float* const dWc[3], float* const dbc[3], float* const dL[3],
+                                     float* const dlb[3], pgt_stream_t stream);
+
 /* Index-batch window gather (signal/index_dataset.py:32-57; examples/indexBatching: "GPU-index-batching"): for every
  * sample b, X[b] = data[idx[b] : idx[b] + h], Y[b] = data[idx[b] + h : idx[b] + 2 h] from the resident series
  * data [T_total, W] (W = nodes * features), both windows of all B samples in one launch.  time_major != 0 writes

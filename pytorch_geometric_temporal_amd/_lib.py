@@ -19,6 +19,8 @@ c_int = ctypes.c_int
 c_f32 = ctypes.c_float
 c_ptr = ctypes.c_void_p
 c_size = ctypes.c_size_t
+Ptr3 = c_ptr * 3                      # a host array of three device pointers (the z, r, h parameters of a gated cell)
+c_p3 = ctypes.POINTER(Ptr3)
 
 
 class PgtError(RuntimeError):
@@ -145,6 +147,9 @@ PROTOTYPES = {
                                         c_ptr, c_ptr]),
     "pgt_batchnorm_nodes_bwd_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
                                             c_ptr]),
+    "pgt_tgcn_pack_weights_f32": (c_int, [c_p3, c_p3, c_p3, c_p3, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "pgt_tgcn_unpack_weight_grads_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_p3, c_p3, c_p3, c_i64, c_i64, c_p3, c_p3, c_p3,
+                                                 c_p3, c_ptr]),
 }
 
 EXPECTED_ABI = 11
@@ -273,6 +278,11 @@ def stream_of(lib, t):
             return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
         return torch.cuda.current_stream(t.device).cuda_stream
     return None
+
+
+def ptr3(a, b, c):
+    """Three device pointers as the host array a `const float* const [3]` parameter takes (None = NULL)."""
+    return ctypes.byref(Ptr3(ptr(a), ptr(b), ptr(c)))
 
 
 def ptr(t):

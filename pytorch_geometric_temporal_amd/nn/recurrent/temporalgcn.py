@@ -2,8 +2,9 @@
 
 Same constructor arguments, parameter names (`conv_{z,r,h}.lin.weight [out,in]`, `conv_{z,r,h}.bias`,
 `linear_{z,r,h}.{weight [out, 2*out], bias}`), forward signatures and outputs; the cell is ONE fused call
-(ops.TGCNCellFunction): one aggregation of X shared by the three gates, MFMA GEMMs for the `lin`/`linear` layers,
-fused gate kernels, hand-written backward on the transposed operator.
+(ops.TGCNCellFunction): one aggregation of X at the INPUT width shared by the three gates, `lin` and `linear` folded into
+one product per gate pair with the gate chains in the GEMM epilogues (ops.TGCNWeightsFunction builds the folded operands
+from the module's parameters in one launch), hand-written backward on the transposed operator.
 """
 import torch
 
@@ -11,12 +12,13 @@ from ... import ops
 from ..conv import GCNConv
 
 
-def _cell(mod, Xnm, Hnm, g, Bt):
+def _cell(mod, X2, H2, g, Bt, batch_major=False):
+    """One cell step on [num_nodes * Bt, .] rows (node-major, or batch-major as TGCN2 holds them)."""
     cz, cr, ch = mod.conv_z, mod.conv_r, mod.conv_h
-    Wc = torch.cat([cz.lin.weight, cr.lin.weight, ch.lin.weight], dim=0)
-    bc = torch.cat([cz.bias, cr.bias, ch.bias], dim=0)
-    return ops.TGCNCellFunction.apply(Xnm, Hnm, Wc, bc, mod.linear_z.weight, mod.linear_z.bias, mod.linear_r.weight,
-                                      mod.linear_r.bias, mod.linear_h.weight, mod.linear_h.bias, g, Bt)
+    Wzr, bzr, Wh, bh = ops.TGCNWeightsFunction.apply(
+        cz.lin.weight, cr.lin.weight, ch.lin.weight, cz.bias, cr.bias, ch.bias,
+        mod.linear_z.weight, mod.linear_r.weight, mod.linear_h.weight, mod.linear_z.bias, mod.linear_r.bias, mod.linear_h.bias)
+    return ops.TGCNCellFunction.apply(X2, H2, Wzr, bzr, Wh, bh, g, Bt, batch_major)
 
 
 class TGCN(torch.nn.Module):
@@ -75,8 +77,6 @@ class TGCN2(TGCN):
         B, N, Fin = X.shape
         O = self.out_channels
         g = self._graph(edge_index, edge_weight, N)
-        # batch-major [B][N][C] -> node-major rows m = n*B + b: the whole batch is one aggregation launch
-        Xnm = ops.Swap01.apply(X.contiguous(), B, N, Fin).view(N * B, Fin)
-        Hnm = ops.Swap01.apply(H.contiguous(), B, N, O).view(N * B, O)
-        out = _cell(self, Xnm, Hnm, g, B)
-        return ops.Swap01.apply(out.view(N, B, O), N, B, O)
+        # rows stay batch-major (m = b*N + n), as the caller holds X and H: only the `in_channels` input columns are taken to
+        # the node-major layout of the aggregation (one launch for the whole batch) and back; H is never transposed
+        return _cell(self, X.reshape(B * N, Fin), H.reshape(B * N, O), g, B, batch_major=True).view(B, N, O)

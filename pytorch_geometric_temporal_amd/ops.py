@@ -1305,90 +1305,159 @@ def linear(X2d, W_kn, bias=None):
 
 # --------------------------------------------------------------------------------------------- T-GCN cell
 
-class TGCNCellFunction(torch.autograd.Function):
-    """One T-GCN GRU step (temporalgcn.py:82-130) on node-major rows m = n*Bt + b.
-
-    X [M, Fin], H [M, O] -> H' [M, O].  The three GCNConv gates share ONE aggregation (the reference aggregates the
-    same X three times at width O; here A_hat X is taken once at width Fin and the three `lin` weights are applied
-    afterwards: A_hat (X W) == (A_hat X) W).  Wc = cat(conv_{z,r,h}.lin.weight) [3O, Fin], bc = cat(conv biases) [3O],
-    L* = linear_*.weight [O, 2O], lb* = linear_*.bias [O].
-    """
+class TGCNWeightsFunction(torch.autograd.Function):
+    """The module's parameters -> the operands of the two gate products of the fused cell (csrc/tgcn.hip):
+    conv_{z,r,h}.lin.weight [O, Fin], conv_{z,r,h}.bias, linear_{z,r,h}.weight [O, 2O], linear_{z,r,h}.bias
+    -> Wzr [Fin + O, 2O], bzr [2O], Wh [Fin + O, O], bh [O]; one launch forward, one backward."""
 
     @staticmethod
-    def forward(ctx, X, H, Wc, bc, Lz, lbz, Lr, lbr, Lh, lbh, g, Bt):
+    def forward(ctx, Wcz, Wcr, Wch, bcz, bcr, bch, Lz, Lr, Lh, lbz, lbr, lbh):
+        lib = _lib.get_lib()
+        Wc = [t.contiguous() for t in (Wcz, Wcr, Wch)]
+        L = [t.contiguous() for t in (Lz, Lr, Lh)]
+        bc = [None if t is None else t.contiguous() for t in (bcz, bcr, bch)]
+        lb = [None if t is None else t.contiguous() for t in (lbz, lbr, lbh)]
+        for t in Wc + L:
+            check_tensor(lib, t, "T-GCN parameter")
+        O, Fin = Wc[0].shape
+        if any(w.shape != (O, Fin) for w in Wc) or any(l.shape != (O, 2 * O) for l in L):
+            raise ValueError("T-GCN: the three gates must share one shape (lin.weight [out, in], linear.weight [out, 2 out])")
+        dev = Wc[0].device
+        C = Fin + O
+        buf = torch.empty(C * 3 * O + 3 * O, dtype=F32, device=dev)
+        Wzr, Wh = buf[:C * 2 * O].view(C, 2 * O), buf[C * 2 * O:C * 3 * O].view(C, O)
+        bzr, bh = buf[C * 3 * O:C * 3 * O + 2 * O], buf[C * 3 * O + 2 * O:]
+        lib.call("pgt_tgcn_pack_weights_f32", _lib.ptr3(*Wc), _lib.ptr3(*bc), _lib.ptr3(*L), _lib.ptr3(*lb), Fin, O, ptr(Wzr),
+                 ptr(bzr), ptr(Wh), ptr(bh), stream_of(lib, buf))
+        ctx.save_for_backward(*Wc, *L, *[t for t in bc if t is not None])
+        ctx.bias_mask = tuple(t is not None for t in bc)
+        ctx.lb_mask = tuple(t is not None for t in lb)
+        ctx.dims = (Fin, O)
+        return Wzr, bzr, Wh, bh
+
+    @staticmethod
+    def backward(ctx, dWzr, dbzr, dWh, dbh):
+        lib = _lib.get_lib()
+        saved = ctx.saved_tensors
+        Wc, L, rest = list(saved[:3]), list(saved[3:6]), list(saved[6:])
+        bc = [rest.pop(0) if m else None for m in ctx.bias_mask]
+        Fin, O = ctx.dims
+        dev = Wc[0].device
+        C = Fin + O
+        z = lambda *shape: torch.zeros(*shape, dtype=F32, device=dev)
+        dWzr = dWzr.contiguous() if dWzr is not None else z(C, 2 * O)
+        dbzr = dbzr.contiguous() if dbzr is not None else z(2 * O)
+        dWh = dWh.contiguous() if dWh is not None else z(C, O)
+        dbh = dbh.contiguous() if dbh is not None else z(O)
+        per = O * Fin + O + O * 2 * O + O
+        buf = torch.empty(3 * per, dtype=F32, device=dev)
+        dWc = [buf[g * per:g * per + O * Fin].view(O, Fin) for g in range(3)]
+        dbc = [buf[g * per + O * Fin:g * per + O * Fin + O] if ctx.bias_mask[g] else None for g in range(3)]
+        dL = [buf[g * per + O * Fin + O:g * per + O * Fin + O + 2 * O * O].view(O, 2 * O) for g in range(3)]
+        dlb = [buf[(g + 1) * per - O:(g + 1) * per] if ctx.lb_mask[g] else None for g in range(3)]
+        lib.call("pgt_tgcn_unpack_weight_grads_f32", ptr(dWzr), ptr(dbzr), ptr(dWh), ptr(dbh), _lib.ptr3(*Wc), _lib.ptr3(*bc),
+                 _lib.ptr3(*L), Fin, O, _lib.ptr3(*dWc), _lib.ptr3(*dbc), _lib.ptr3(*dL), _lib.ptr3(*dlb), stream_of(lib, buf))
+        return (*dWc, *dbc, *dL, *dlb)
+
+
+class TGCNCellFunction(torch.autograd.Function):
+    """One T-GCN GRU step (temporalgcn.py:82-130).  X [M, Fin], H [M, O] -> H' [M, O] with M = num_nodes * Bt rows, either
+    node-major (m = n * Bt + b) or — `batch_major` — batch-major (m = b * N + n: TGCN2's own [B, N, .] layout, so the hidden
+    state is never transposed; only the Fin input columns travel to the node-major layout the aggregation wants and back).
+
+    The three GCNConv gates share ONE aggregation AX = A_hat X at the input width (the reference aggregates three times at
+    width O), and conv_g -> linear_g is folded into one product per gate pair on the operand [AX | H'] (TGCNWeightsFunction):
+        Z | R = sigmoid([AX | H] Wzr + bzr)  + H * R          pgt_gemm_gru_zr_f32 (gate chain in the GEMM epilogue)
+        H'    = Z H + (1 - Z) tanh([AX | H * R] Wh + bh)      pgt_gemm_gru_h_f32
+    Backward: the gate adjoints of the DCRNN cell (pgt_gru_h_bwd_f32 / pgt_gru_zr_bwd_f32), two input-gradient products,
+    two weight-gradient products, one transposed aggregation when X needs a gradient."""
+
+    @staticmethod
+    def forward(ctx, X, H, Wzr, bzr, Wh, bh, g, Bt, batch_major):
         lib = _lib.get_lib()
         check_tensor(lib, X, "X")
         check_tensor(lib, H, "H")
-        Xc, Hc = X.contiguous(), H.contiguous()
+        Xc = X.contiguous()
         M, Fin = Xc.shape
-        O = Hc.size(1)
+        O = Wh.size(1)
+        C = Fin + O
         N = g.N
-        if M != N * Bt or Hc.size(0) != M:
-            raise ValueError(f"TGCN: X has {M} rows, H {Hc.size(0)}, expected num_nodes*B = {N * Bt}")
+        if M != N * Bt or H.shape != (M, O):
+            raise ValueError(f"TGCN: X has {M} rows, H {tuple(H.shape)}, expected num_nodes*B = {N * Bt} rows of {O}")
         dev = Xc.device
-        AX = torch.empty(M, Fin, dtype=F32, device=dev)
-        spmm(g.fwd, Xc.view(N, Bt * Fin), AX.view(N, Bt * Fin))
-        G = torch.empty(3, 2, M, O, dtype=F32, device=dev)     # [gate][0 = conv(X), 1 = H or H*R]
-        Wc_c, Lz_c, Lr_c, Lh_c = Wc.contiguous(), Lz.contiguous(), Lr.contiguous(), Lh.contiguous()
-        # conv_g(X) = (A_hat X) W_g^T + b_g for the three gates in one GEMM; column segment g lands in G[g, 0]
-        gemm(AX, Fin, 0, 1, Fin, Wc_c, 1, Fin, G, O, 2 * M * O, O, bc, M, 3 * O)
-        copy2d(G[0, 1], Hc)
-        copy2d(G[1, 1], Hc)
+        AX = TGCNCellFunction._aggregate(g.fwd, Xc, N, Bt, Fin, batch_major)
+        XH = torch.empty(M, C, dtype=F32, device=dev)          # [AX | H]
+        XHR = torch.empty(M, C, dtype=F32, device=dev)         # [AX | H * R]
+        copy2d(XH[:, :Fin], AX)
+        copy2d(XH[:, Fin:], H if H.stride(1) == 1 else H.contiguous())
+        copy2d(XHR[:, :Fin], AX)
+        Hv = XH[:, Fin:]
         ZR = torch.empty(M, 2 * O, dtype=F32, device=dev)
-        for gi, (L, lb) in enumerate(((Lz_c, lbz), (Lr_c, lbr))):
-            # linear_g([conv_g(X), H]) : A = two K-segments of O columns, B(k, n) = L[n, k]
-            gemm(G[gi], O, M * O, 2, O, L, 1, 2 * O, ZR[:, gi * O:], 2 * O, 0, O, lb, M, O)
-        _gru_zr(ZR, Hc, G[2, 1], 0)                            # Z, R = sigmoid(.) in place; G[2,1] = H * R
         HT = torch.empty(M, O, dtype=F32, device=dev)
-        gemm(G[2], O, M * O, 2, O, Lh_c, 1, 2 * O, HT, O, 0, O, lbh, M, O)
         Hn = torch.empty(M, O, dtype=F32, device=dev)
-        _gru_h(HT, ZR, Hc, Hn)                                 # HT = tanh(.) in place; Hn = Z*H + (1-Z)*HT
-        ctx.g, ctx.Bt = g, Bt
-        ctx.has_bias = (bc is not None, lbz is not None, lbr is not None, lbh is not None)
-        ctx.save_for_backward(AX, G, ZR, HT, Hc, Wc_c, Lz_c, Lr_c, Lh_c)
+        Wzr_c, Wh_c = Wzr.contiguous(), Wh.contiguous()
+        if FUSE_GATE_EPILOGUES and O % 4 == 0:
+            gemm_gru_zr(XH, C, 0, 1, C, Wzr_c, 2 * O, 1, bzr, ZR, Hv, XHR, Fin)
+            gemm_gru_h(XHR, C, 0, 1, C, Wh_c, O, 1, bh, HT, ZR, Hv, Hn)
+        else:
+            gemm(XH, C, 0, 1, C, Wzr_c, 2 * O, 1, ZR, 2 * O, 0, 2 * O, bzr, M, 2 * O)
+            _gru_zr(ZR, Hv, XHR, Fin)
+            gemm(XHR, C, 0, 1, C, Wh_c, O, 1, HT, O, 0, O, bh, M, O)
+            _gru_h(HT, ZR, Hv, Hn)
+        ctx.g, ctx.Bt, ctx.batch_major = g, Bt, batch_major
+        ctx.save_for_backward(XH, XHR, ZR, HT, Wzr_c, Wh_c)
         return Hn
 
     @staticmethod
+    def _aggregate(csr, Xc, N, Bt, W, batch_major):
+        """A X on [M, W] rows (node-major, or batch-major through two small transposition passes of the W columns)."""
+        M = Xc.size(0)
+        if batch_major and Bt > 1:
+            Xnm = swap01(Xc, Bt, N, W)
+            Y = torch.empty(N, Bt * W, dtype=F32, device=Xc.device)
+            spmm(csr, Xnm.view(N, Bt * W), Y)
+            return swap01(Y, N, Bt, W).view(M, W)
+        Y = torch.empty(M, W, dtype=F32, device=Xc.device)
+        spmm(csr, Xc.view(N, Bt * W), Y.view(N, Bt * W))
+        return Y
+
+    @staticmethod
     def backward(ctx, dHn):
-        AX, G, ZR, HT, Hc, Wc_c, Lz_c, Lr_c, Lh_c = ctx.saved_tensors
+        XH, XHR, ZR, HT, Wzr_c, Wh_c = ctx.saved_tensors
         g, Bt = ctx.g, ctx.Bt
-        M, Fin = AX.shape
-        O = Hc.size(1)
+        M, C = XH.shape
+        O = Wh_c.size(1)
+        Fin = C - O
         N = g.N
-        dev = AX.device
+        dev = XH.device
         dHn = dHn.contiguous()
+        Hv = XH[:, Fin:]
         d_pre_h = torch.empty(M, O, dtype=F32, device=dev)
         d_pre_zr = torch.empty(M, 2 * O, dtype=F32, device=dev)
         dH = torch.empty(M, O, dtype=F32, device=dev)
-        _gru_h_bwd(dHn, ZR, Hc, HT, d_pre_h, d_pre_zr, dH, accumulate=False)
-        dG = torch.empty(3, 2, M, O, dtype=F32, device=dev)
-        # d[conv_h(X), H*R] = d_pre_h @ Lh   (B(k, n) = Lh[k, n]; the 2O output columns split into dG[2,0], dG[2,1])
-        gemm(d_pre_h, O, 0, 1, O, Lh_c, 2 * O, 1, dG[2], O, M * O, O, None, M, 2 * O)
-        _gru_zr_bwd(dG[2, 1], 0, ZR, Hc, d_pre_zr, dH)         # d_pre_r, dH += d(HR) * R
-        for gi, L in ((0, Lz_c), (1, Lr_c)):
-            gemm(d_pre_zr[:, gi * O:], 2 * O, 0, 1, O, L, 2 * O, 1, dG[gi], O, M * O, O, None, M, 2 * O)
-            add2d(dH, dG[gi, 1])
-        # weight gradients (dW^T layouts come out of the TN kernel; transposed views go back to autograd)
-        hb = ctx.has_bias
-        dLt = torch.zeros(3, 2 * O, O, dtype=F32, device=dev)
-        dlb = torch.zeros(3, O, dtype=F32, device=dev)
-        for gi, dpre in ((0, d_pre_zr[:, :O]), (1, d_pre_zr[:, O:]), (2, d_pre_h)):
-            gemm_tn_acc(G[gi], O, M * O, 2, O, dpre, dpre.stride(0), dLt[gi], O, dlb[gi], M, O)
-        dWct = torch.zeros(Fin, 3 * O, dtype=F32, device=dev)
-        dbc = torch.zeros(3 * O, dtype=F32, device=dev)
-        for gi in range(3):
-            gemm_tn_acc(AX, Fin, 0, 1, Fin, dG[gi, 0], O, dWct[:, gi * O:], 3 * O, dbc[gi * O:], M, O)
+        _gru_h_bwd(dHn, ZR, Hv, HT, d_pre_h, d_pre_zr, dH, accumulate=False)
+        dXHR = torch.empty(M, C, dtype=F32, device=dev)
+        gemm(d_pre_h, O, 0, 1, O, Wh_c, 1, O, dXHR, C, 0, C, None, M, C)             # B(k = o, n = c) = Wh[c, o]
+        _gru_zr_bwd(dXHR, Fin, ZR, Hv, d_pre_zr, dH)                                  # d_pre_r; dH += d(H R) R
+        dXH = torch.empty(M, C, dtype=F32, device=dev)
+        gemm(d_pre_zr, 2 * O, 0, 1, 2 * O, Wzr_c, 1, 2 * O, dXH, C, 0, C, None, M, C)
+        add2d(dH, dXH[:, Fin:])
+        need = ctx.needs_input_grad
+        dWzr = dbzr = dWh = dbh = None
+        if need[2] or need[3]:
+            dWzr = torch.zeros(C, 2 * O, dtype=F32, device=dev)
+            dbzr = torch.zeros(2 * O, dtype=F32, device=dev)
+            gemm_tn_acc(XH, C, 0, 1, C, d_pre_zr, 2 * O, dWzr, 2 * O, dbzr, M, 2 * O)
+        if need[4] or need[5]:
+            dWh = torch.zeros(C, O, dtype=F32, device=dev)
+            dbh = torch.zeros(O, dtype=F32, device=dev)
+            gemm_tn_acc(XHR, C, 0, 1, C, d_pre_h, O, dWh, O, dbh, M, O)
         dX = None
-        if ctx.needs_input_grad[0]:
+        if need[0]:
             dAX = torch.empty(M, Fin, dtype=F32, device=dev)
-            # d(A_hat X) = sum_g d conv_g @ W_g : three K-segments (dG[g, 0]) against Wc [3O, Fin]
-            gemm(dG, O, 2 * M * O, 3, O, Wc_c, Fin, 1, dAX, Fin, 0, Fin, None, M, Fin)
-            dX = torch.empty(M, Fin, dtype=F32, device=dev)
-            spmm(g.bwd, dAX.view(N, Bt * Fin), dX.view(N, Bt * Fin))
-        return (dX, dH, dWct.t().contiguous(), dbc if hb[0] else None,
-                dLt[0].t().contiguous(), dlb[0] if hb[1] else None,
-                dLt[1].t().contiguous(), dlb[1] if hb[2] else None,
-                dLt[2].t().contiguous(), dlb[2] if hb[3] else None, None, None)
+            axpby2d(dAX, dXH[:, :Fin], 1.0, dXHR[:, :Fin], 1.0)
+            dX = TGCNCellFunction._aggregate(g.bwd, dAX, N, Bt, Fin, ctx.batch_major)
+        return dX, (dH if need[1] else None), dWzr, dbzr, dWh, dbh, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- Chebyshev convolution

@@ -96,6 +96,49 @@ def split_bf16_shape(tag):
     return M >= 16384 and 128 < n_seg * seg_k <= 351 and N <= 128
 
 
+def kernel_class_rooflines(kernels, shapes):
+    """Price every timed kernel class of a step the same way (all of them are HBM-bound — the dense products since they moved
+    to the bf16 matrix pipe: six bf16 MFMAs per fp32 product are 2.67x the fp32 MFMA rate, csrc/gemm_bx.hip): ALGORITHMIC
+    bytes (operands read once + results written once) / launch time against 8 TB/s.  `kernels` = KernelTimer.summary(),
+    `shapes` = KernelTimer.by_tag(); adds achieved_GBs / hbm_frac (and per-shape lines for the products) in place."""
+    for kk, v in kernels.items():
+        recs = [r for r in shapes if r["tag"][0] == kk]
+        if kk in ("gemm", "gemm_tn"):
+            tot_b = sum(gemm_operand_bytes(r["tag"][1:]) * r["launches"] for r in recs)
+            tot_f = sum(r["work_per_launch"] * r["launches"] for r in recs)
+            tot_s = sum(r["total_ms"] for r in recs) * 1e-3
+            bx_f = sum(r["work_per_launch"] * r["launches"] for r in recs if split_bf16_shape(r["tag"][1:]))
+            bx_s = sum(r["total_ms"] for r in recs if split_bf16_shape(r["tag"][1:])) * 1e-3
+            v["algorithmic_bytes_per_launch"] = tot_b / max(v["launches"], 1)
+            v["achieved_GBs"] = tot_b / tot_s / 1e9            # time-weighted over the class's shapes
+            v["hbm_frac"] = v["achieved_GBs"] / HBM_PEAK_GBS
+            v["fp32_product_TFLOPs"] = tot_f / tot_s / 1e12    # 2 M N K of the fp32 product (what the caller asked for)
+            # the split-bf16 launches on the pipe they run on: six bf16 MFMAs per fp32 product against 2.5 PFLOP/s
+            v["bf16_pipe_frac"] = (6.0 * bx_f / bx_s / 1e12 / MFMA_BF16_PEAK_TFLOPS) if bx_s > 0 else None
+            v["by_shape"] = [{"shape": r["tag"][1:], "launches": r["launches"], "avg_us": r["avg_us"],
+                              "split_bf16": split_bf16_shape(r["tag"][1:]),
+                              "algorithmic_MB": gemm_operand_bytes(r["tag"][1:]) / 1e6,
+                              "achieved_GBs": gemm_operand_bytes(r["tag"][1:]) / (r["avg_us"] * 1e-6) / 1e9,
+                              "hbm_frac": gemm_operand_bytes(r["tag"][1:]) / (r["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              "fp32_product_TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12}
+                             for r in recs]
+        else:
+            v["algorithmic_bytes_per_launch"] = v["work_per_launch"]
+            v["achieved_GBs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
+            v["hbm_frac"] = v["achieved_GBs"] / HBM_PEAK_GBS
+    return kernels
+
+
+def all_kernel_classes(kernels, profile_steps):
+    """The step as a whole: algorithmic bytes of EVERY timed launch (aggregations, stacks, products, weight gradients, gate
+    and gate-backward kernels, movers) / their summed time."""
+    all_b = sum(v["algorithmic_bytes_per_launch"] * v["launches"] for v in kernels.values())
+    all_s = sum(v["total_ms"] for v in kernels.values()) * 1e-3
+    return {"achieved_GBs": all_b / all_s / 1e9, "hbm_frac": all_b / all_s / 1e9 / HBM_PEAK_GBS,
+            "ms_per_step_in_timed_kernels": 1e3 * all_s / profile_steps,
+            "classes": {k: round(v["total_ms"] / profile_steps, 4) for k, v in kernels.items()}}
+
+
 MEAN, STD = 54.0, 19.5       # METR-LA-like speed statistics used to de-normalise inside the loss
 
 
@@ -355,7 +398,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step (weak scaling)")
+    ap.add_argument("--config", default="dcrnn_metrla", choices=["dcrnn_metrla", "tgcn50k"],
+                    help="dcrnn_metrla = BASELINE configs[1] (the headline); tgcn50k = configs[3]: the T = 12 BatchedTGCN training "
+                         "step on the 50 000-node graph (bench_tgcn.py), same protocol, --gpus N through the same dp path")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (weak scaling; default 1024, tgcn50k: 8)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: total windows per step, split evenly over the ranks (overrides --batch)")
     ap.add_argument("--edges", type=int, default=N_EDGES, help="edges of the METR-LA-shaped graph (1722 = the reference's data)")
@@ -368,6 +414,9 @@ def main():
                     help="forward+backward and the update as two hipGraphs per step, the all-reduce between them eager "
                          "(per-GPU batches whose step is host-launch bound, e.g. --global-batch 1024 on 8 GPUs)")
     args = ap.parse_args()
+    args.batch_given = args.batch is not None
+    if args.batch is None:
+        args.batch = 1024
     # multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC); the launcher's value wins
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -381,6 +430,12 @@ def main():
     device = torch.device("cuda", dev_index)
     lib = _lib.get_lib()
     assert lib.target == "gfx950"
+    if args.config == "tgcn50k":
+        import bench_tgcn
+        bench_tgcn.main(args, rank, local_rank, world, device, sys.modules[__name__])
+        if world > 1:
+            dist.destroy_process_group()
+        return
     scaling = "weak"
     if args.global_batch > 0:
         assert args.global_batch % world == 0, "--global-batch must be a multiple of the number of ranks"
@@ -416,34 +471,7 @@ def main():
         kernels = ops.KERNEL_TIMER.summary()
         shapes = ops.KERNEL_TIMER.by_tag()
         ops.KERNEL_TIMER = None
-        # Every kernel class of the step is HBM-bound now (the dense products since they moved to the bf16 matrix pipe:
-        # six bf16 MFMAs per fp32 product are 2.67x the fp32 MFMA rate, csrc/gemm_bx.hip), so every class is priced the
-        # same way: ALGORITHMIC bytes (operands read once + results written once) / launch time against 8 TB/s.
-        for kk, v in kernels.items():
-            recs = [r for r in shapes if r["tag"][0] == kk]
-            if kk in ("gemm", "gemm_tn"):
-                tot_b = sum(gemm_operand_bytes(r["tag"][1:]) * r["launches"] for r in recs)
-                tot_f = sum(r["work_per_launch"] * r["launches"] for r in recs)
-                tot_s = sum(r["total_ms"] for r in recs) * 1e-3
-                bx_f = sum(r["work_per_launch"] * r["launches"] for r in recs if split_bf16_shape(r["tag"][1:]))
-                bx_s = sum(r["total_ms"] for r in recs if split_bf16_shape(r["tag"][1:])) * 1e-3
-                v["algorithmic_bytes_per_launch"] = tot_b / max(v["launches"], 1)
-                v["achieved_GBs"] = tot_b / tot_s / 1e9            # time-weighted over the class's shapes
-                v["hbm_frac"] = v["achieved_GBs"] / HBM_PEAK_GBS
-                v["fp32_product_TFLOPs"] = tot_f / tot_s / 1e12    # 2 M N K of the fp32 product (what the caller asked for)
-                # the split-bf16 launches on the pipe they run on: six bf16 MFMAs per fp32 product against 2.5 PFLOP/s
-                v["bf16_pipe_frac"] = (6.0 * bx_f / bx_s / 1e12 / MFMA_BF16_PEAK_TFLOPS) if bx_s > 0 else None
-                v["by_shape"] = [{"shape": r["tag"][1:], "launches": r["launches"], "avg_us": r["avg_us"],
-                                  "split_bf16": split_bf16_shape(r["tag"][1:]),
-                                  "algorithmic_MB": gemm_operand_bytes(r["tag"][1:]) / 1e6,
-                                  "achieved_GBs": gemm_operand_bytes(r["tag"][1:]) / (r["avg_us"] * 1e-6) / 1e9,
-                                  "hbm_frac": gemm_operand_bytes(r["tag"][1:]) / (r["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                  "fp32_product_TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12}
-                                 for r in recs]
-            else:
-                v["algorithmic_bytes_per_launch"] = v["work_per_launch"]
-                v["achieved_GBs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
-                v["hbm_frac"] = v["achieved_GBs"] / HBM_PEAK_GBS
+        kernel_class_rooflines(kernels, shapes)
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
         k = kernels[dom]
         names = {"spmm": "spmm_wide_kernel<4> (pgt_spmm_csr_f32)",
@@ -461,11 +489,7 @@ def main():
             roof["bf16_pipe_frac"] = k["bf16_pipe_frac"]
             roof["fp32_product_TFLOPs"] = k["fp32_product_TFLOPs"]
         roof.update(pmc_traffic(dom))
-        # the step as a whole: algorithmic bytes of every timed launch / their summed time
-        all_b = sum(v["algorithmic_bytes_per_launch"] * v["launches"] for v in kernels.values())
-        all_s = sum(v["total_ms"] for v in kernels.values()) * 1e-3
-        roof["all_kernel_classes"] = {"achieved_GBs": all_b / all_s / 1e9, "hbm_frac": all_b / all_s / 1e9 / HBM_PEAK_GBS,
-                                      "ms_per_step_in_timed_kernels": 1e3 * all_s / args.profile_steps}
+        roof["all_kernel_classes"] = all_kernel_classes(kernels, args.profile_steps)
     del step
 
     cpu = None
@@ -531,7 +555,7 @@ def main():
             "small_batch": lambda: BCfg.small_batch(device, Model, masked_mae_loss, series, ei, ew, args.edges, SEQ, MEAN, STD, cores),
             "config1_chickenpox": lambda: BCfg.chickenpox_epoch(device, cores),
             "config3_pemsbay_a3tgcn2": lambda: BCfg.config3_pemsbay(device, cores),
-            "config4_50k_tgcn2": lambda: BCfg.config4_50k(device, cores),
+            "config4_50k_tgcn2": lambda: BCfg.config4_50k(device, cores, sys.modules[__name__]),
             "config5_covid_evolvegcnh": lambda: BCfg.covid_epoch(device, cores),
         }
         for name, fn in blocks.items():

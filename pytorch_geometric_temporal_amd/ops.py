@@ -653,7 +653,8 @@ def copy2d(dst, src):
     check_tensor(lib, dst, "dst"); check_tensor(lib, src, "src")
     dp, ldd = _rows(dst, "dst")
     sp, lds = _rows(src, "src")
-    lib.call("pgt_copy2d_f32", dp, ldd, sp, lds, src.size(0), src.size(1), stream_of(lib, dst))
+    _timed("mover", 8.0 * src.numel() if KERNEL_TIMER else 0, lambda: lib.call(
+        "pgt_copy2d_f32", dp, ldd, sp, lds, src.size(0), src.size(1), stream_of(lib, dst)))
 
 
 def add2d(dst, src):
@@ -661,7 +662,8 @@ def add2d(dst, src):
     check_tensor(lib, dst, "dst"); check_tensor(lib, src, "src")
     dp, ldd = _rows(dst, "dst")
     sp, lds = _rows(src, "src")
-    lib.call("pgt_add2d_f32", dp, ldd, sp, lds, src.size(0), src.size(1), stream_of(lib, dst))
+    _timed("mover", 12.0 * src.numel() if KERNEL_TIMER else 0, lambda: lib.call(
+        "pgt_add2d_f32", dp, ldd, sp, lds, src.size(0), src.size(1), stream_of(lib, dst)))
 
 
 def axpby2d(dst, x, a, y=None, b=0.0):
@@ -670,7 +672,8 @@ def axpby2d(dst, x, a, y=None, b=0.0):
     dp, ldd = _rows(dst, "dst")
     xp, ldx = _rows(x, "x")
     yp, ldy = _rows(y, "y") if y is not None else (ptr(None), 0)
-    lib.call("pgt_axpby2d_f32", dp, ldd, xp, ldx, float(a), yp, ldy, float(b), x.size(0), x.size(1), stream_of(lib, dst))
+    _timed("mover", 4.0 * x.numel() * (2 if y is None else 3) if KERNEL_TIMER else 0, lambda: lib.call(
+        "pgt_axpby2d_f32", dp, ldd, xp, ldx, float(a), yp, ldy, float(b), x.size(0), x.size(1), stream_of(lib, dst)))
 
 
 def swap01(src, D0, D1, W):
@@ -679,7 +682,8 @@ def swap01(src, D0, D1, W):
     check_tensor(lib, src, "src")
     src = src.contiguous()
     dst = torch.empty(D1, D0, W, dtype=F32, device=src.device)
-    lib.call("pgt_swap01_f32", ptr(dst), ptr(src), D0, D1, W, stream_of(lib, src))
+    _timed("mover", 8.0 * src.numel() if KERNEL_TIMER else 0, lambda: lib.call(
+        "pgt_swap01_f32", ptr(dst), ptr(src), D0, D1, W, stream_of(lib, src)))
     return dst
 
 
@@ -997,7 +1001,8 @@ def _gru_zr(pre_zr, H, xhr, f_in):
     M, O2 = pre_zr.shape
     hp, ldh = _rows(H, "H")
     xp, ldx = _rows(xhr, "xhr")
-    lib.call("pgt_gru_zr_f32", ptr(pre_zr), hp, ldh, xp, ldx, f_in, M, O2 // 2, stream_of(lib, pre_zr))
+    _timed("gate", 12.0 * M * O2 if KERNEL_TIMER else 0, lambda: lib.call(
+        "pgt_gru_zr_f32", ptr(pre_zr), hp, ldh, xp, ldx, f_in, M, O2 // 2, stream_of(lib, pre_zr)))
 
 
 def _gru_h(pre_h, zr, H, out0, out1=None):
@@ -1006,7 +1011,8 @@ def _gru_h(pre_h, zr, H, out0, out1=None):
     hp, ldh = _rows(H, "H")
     op, ld0, m0 = _rows_or_map(out0, "out0")
     o1, ld1 = _rows(out1, "out1") if out1 is not None else (ptr(None), 0)
-    lib.call("pgt_gru_h_f32", ptr(pre_h), ptr(zr), hp, ldh, op, ld0, m0, o1, ld1, M, O, stream_of(lib, pre_h))
+    _timed("gate", 4.0 * M * O * (5 if out1 is None else 6) if KERNEL_TIMER else 0, lambda: lib.call(
+        "pgt_gru_h_f32", ptr(pre_h), ptr(zr), hp, ldh, op, ld0, m0, o1, ld1, M, O, stream_of(lib, pre_h)))
 
 
 def _gru_h_bwd(dHn, zr, H, ht, d_pre_h, d_pre_zr, dH, accumulate, dHn2=None, dHn3=None):
@@ -1018,8 +1024,11 @@ def _gru_h_bwd(dHn, zr, H, ht, d_pre_h, d_pre_zr, dH, accumulate, dHn2=None, dHn
     g3, ldg3 = _rows(dHn3, "dHn3") if dHn3 is not None else (ptr(None), 0)
     hp, ldh, mh = _rows_or_map(H, "H")
     dp, ldd = _rows(dH, "dH")
-    lib.call("pgt_gru_h_bwd_f32", gp, ldg, mg, g2, ldg2, g3, ldg3, ptr(zr), hp, ldh, mh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp,
-             ldd, int(bool(accumulate)), M, O, stream_of(lib, ht))
+    # algorithmic bytes: dH' (+ its further addends), z, H, tanh in; d_pre_h, d_pre_z, dH out (+ dH in when accumulating)
+    work = 4.0 * M * O * (7 + (dHn2 is not None) + (dHn3 is not None) + bool(accumulate)) if KERNEL_TIMER else 0
+    _timed("gate_bwd", work, lambda: lib.call(
+        "pgt_gru_h_bwd_f32", gp, ldg, mg, g2, ldg2, g3, ldg3, ptr(zr), hp, ldh, mh, ptr(ht), ptr(d_pre_h), ptr(d_pre_zr), dp,
+        ldd, int(bool(accumulate)), M, O, stream_of(lib, ht)), tag=("h", M, O))
 
 
 def _gru_zr_bwd(dxhr, f_in, zr, H, d_pre_zr, dH):
@@ -1028,8 +1037,10 @@ def _gru_zr_bwd(dxhr, f_in, zr, H, d_pre_zr, dH):
     xp, ldx = _rows(dxhr, "dxhr")
     hp, ldh, mh = _rows_or_map(H, "H")
     dp, ldd = _rows(dH, "dH")
-    lib.call("pgt_gru_zr_bwd_f32", xp, ldx, f_in, ptr(zr), hp, ldh, mh, ptr(d_pre_zr), dp, ldd, M, O2 // 2,
-             stream_of(lib, zr))
+    # algorithmic bytes: d(H R), r, H, dH in; d_pre_r, dH out
+    _timed("gate_bwd", 12.0 * M * O2 if KERNEL_TIMER else 0, lambda: lib.call(
+        "pgt_gru_zr_bwd_f32", xp, ldx, f_in, ptr(zr), hp, ldh, mh, ptr(d_pre_zr), dp, ldd, M, O2 // 2,
+        stream_of(lib, zr)), tag=("zr", M, O2 // 2))
 
 
 class _StateLayout:

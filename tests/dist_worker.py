@@ -21,13 +21,33 @@ def build(model_name):
     torch.manual_seed(1234)
     if model_name == "dcrnn":
         return BatchedDCRNN(2, 4, K=2)
+    if model_name in ("ddp", "ddp_flat"):             # pems_ddp.py:80-85's model + a per-node torch.nn.Linear read-out (the
+        class Net(torch.nn.Module):                   # returned states are a Tensor subclass: _StatesTensor must survive DDP)
+            def __init__(self):
+                super().__init__()
+                self.rnn = BatchedDCRNN(2, 4, K=3)
+                self.head = torch.nn.Linear(4, 2)
+
+            def forward(self, X, ei, ew):
+                return self.head(self.rnn(X, ei, ew))
+        return Net()
+    if model_name == "tgcn_seq":                      # BASELINE configs[3]'s model: the T-step loop of bench_tgcn.BatchedTGCN
+        import bench_tgcn
+        return bench_tgcn.BatchedTGCN(2, 4, 2)
     return TGCN2(2, 4, batch_size=1)
 
 
 def batch_loss(model_name, model, X, y, ei, ew):
+    if model_name in ("ddp", "ddp_flat"):
+        out = model(X, ei, ew)                       # [B, T, N, 2]
+        return (out[..., 0] - y).abs().mean() + 0.1 * out[..., 1].square().mean()
     if model_name == "dcrnn":
         out = model(X, ei, ew)                       # [B, T, N, O]
         return (out.mean(dim=-1) - y).abs().mean()
+    if model_name == "tgcn_seq":
+        import bench_tgcn
+        out = model(X.permute(0, 2, 3, 1), ei, ew)   # x [B, N, F, T] -> [B, T, N, 2]; the example's de-normalised masked MAE
+        return bench_tgcn.masked_mae_loss(out[..., 0] * bench_tgcn.STD + bench_tgcn.MEAN, y * bench_tgcn.STD + bench_tgcn.MEAN)
     out = model(X[:, -1], ei, ew)                    # [B, N, O]
     return (out.mean(dim=-1) - y[:, -1]).abs().mean()
 
@@ -48,7 +68,17 @@ def main():
             for p in model.parameters():
                 p.add_(1.0)
     dp.broadcast_parameters(model, src=0)
-    if model_name == "dcrnn":                          # flat parameters + one optimizer update (what bench.py does)
+    ddp = None
+    if model_name == "ddp":                            # torch's own wrapper exactly as the reference uses it (pems_ddp.py:83-85)
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        if world == 1:                                 # DDP wants a process group even for one rank
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if not dist.is_initialized():
+                dist.init_process_group("gloo", rank=0, world_size=1)
+        ddp = DDP(model, gradient_as_bucket_view=True)
+        opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+        flat = None
+    elif model_name == "dcrnn":                          # flat parameters + one optimizer update (what bench.py does)
         flat = dp.FlatParameters(model.parameters())
         opt = flat.optimizer(torch.optim.SGD, lr=0.1)
     else:                                              # flat gradients + the ordinary per-parameter optimizer
@@ -60,16 +90,20 @@ def main():
         ar = torch.arange(T)
         X = series[mine[:, None] + ar[None, :]]                      # [b, T, N, 2]
         y = series[mine[:, None] + T + ar[None, :]][..., 0]          # [b, T, N]
-        loss = batch_loss(model_name, model, X, y, ei, ew)
-        flat.zero()
-        loss.backward()
-        flat.all_reduce_mean(world)
+        loss = batch_loss(model_name, ddp if ddp is not None else model, X, y, ei, ew)
+        if ddp is not None:
+            opt.zero_grad()
+            loss.backward()                            # DDP's bucket hooks average the gradients
+        else:
+            flat.zero()
+            loss.backward()
+            flat.all_reduce_mean(world)
         opt.step()
         losses.append(float(dp.reduce_scalars([float(loss)])[0]) / world)
     if rank == 0:
         torch.save({"params": {k: v.detach().clone() for k, v in model.state_dict().items()}, "losses": losses,
                     "world": world}, out_path)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

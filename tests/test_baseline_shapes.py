@@ -224,6 +224,59 @@ def test_config4_tgcn2_50k_nodes_forward_and_gradients(kind):
     _grad_check(m, p64, 2e-4, 2e-4)
 
 
+def _batched_tgcn_against_oracle(device, ei, ew, X, y, hidden, atol_fwd, grad_tol):
+    """The reference example's model and loss (examples/indexBatching/tgcn/metr_la_main.py:29-56, :86-87) through bench_tgcn's
+    BatchedTGCN on `device` against the fp64 oracle running the same T-step loop (oracle/functional.py tgcn_cell per step, torch
+    relu / Linear / masked MAE): forward within `atol_fwd`, every parameter gradient within `grad_tol` of its largest entry."""
+    import bench_tgcn as BT
+    torch.manual_seed(5)
+    m = BT.BatchedTGCN(2, hidden, 2)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.4, 0.4)
+    p64 = {k: v.detach().double().clone().requires_grad_() for k, v in m.state_dict().items()}
+    cell64 = {k[len("tgnn."):]: v for k, v in p64.items() if k.startswith("tgnn.")}
+    x64 = X.double()
+    h = torch.zeros(X.size(0), X.size(1), hidden, dtype=torch.float64)
+    outs = []
+    for t in range(X.size(-1)):
+        h = F.tgcn_cell(x64[..., t], ei, ew.double(), h, cell64)
+        outs.append(torch.nn.functional.linear(torch.relu(h), p64["linear.weight"], p64["linear.bias"]).unsqueeze(1))
+    ref = torch.cat(outs, 1)
+    BT.masked_mae_loss(ref * BT.STD + BT.MEAN, y.double() * BT.STD + BT.MEAN).backward()
+    m = m.to(device)
+    out = m(X.to(device), ei.to(device), ew.to(device))
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close_with_nonfinite(out, ref, atol_fwd, atol_fwd, "forward of the T-step loop")
+    BT.masked_mae_loss(out * BT.STD + BT.MEAN, y.to(device) * BT.STD + BT.MEAN).backward()
+    for name, p in m.named_parameters():
+        g64 = p64[name].grad
+        assert_close_with_nonfinite(p.grad, g64, grad_tol * float(g64.abs().max()) + 1e-9, grad_tol, name)
+
+
+def test_config4_batched_tgcn_training_loop_small(backend):
+    """The T-step BatchedTGCN loop (TGCN2 -> relu -> Linear per step, hidden state carried, masked-MAE) at a size the CPU
+    double runs in seconds: 60 nodes, B = 3, T = 5."""
+    from pytorch_geometric_temporal_amd.dataset import synthetic as syn
+    ei_np, ew_np = syn.local_graph(60, 6, seed=2)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    torch.manual_seed(3)
+    X, y = torch.randn(3, 60, 2, 5), torch.randn(3, 5, 60, 2)
+    y[0, 0, :7] = 0.0                                              # the mask of the loss has something to mask
+    _batched_tgcn_against_oracle(backend.device, ei, ew, X, y, 8, 1e-5, 2e-4)
+
+
+@pytest.mark.gpu
+def test_config4_batched_tgcn_training_loop_at_size():
+    """configs[3] as SURVEY 8(d) defines it: 50 000 nodes / 400 000 edges, T = 12, hidden 32 (B = 2 keeps the fp64 oracle to
+    a few seconds): forward 1e-5 and every gradient against the oracle."""
+    import bench_tgcn as BT
+    ei, ew, _, _ = BC.graph50k("local")
+    series = torch.from_numpy(__import__("pytorch_geometric_temporal_amd.dataset.synthetic", fromlist=["x"]).traffic_series(40, 50_000, seed=1))
+    x, y = BT.windows(series, torch.tensor([0, 9]))
+    _batched_tgcn_against_oracle(torch.device("cuda:0"), ei, ew, x.contiguous(), y, 32, 1e-5, 2e-4)
+
+
 # ------------------------------------------------------------------------------------------------ config 5
 
 def _covid_signal():

@@ -32,7 +32,7 @@ def _run(model, world, out_path):
     return torch.load(out_path)
 
 
-@pytest.mark.parametrize("model", ["dcrnn", "tgcn"])
+@pytest.mark.parametrize("model", ["dcrnn", "tgcn", "tgcn_seq"])
 def test_two_rank_step_equals_single_process_step(tmp_path, model):
     one = _run(model, 1, str(tmp_path / "w1.pt"))
     two = _run(model, 2, str(tmp_path / "w2.pt"))
@@ -41,6 +41,21 @@ def test_two_rank_step_equals_single_process_step(tmp_path, model):
         # mean of the two half-batch gradients == gradient of the full-batch mean loss (equal shard sizes)
         assert torch.allclose(one["params"][k], two["params"][k], atol=2e-6, rtol=1e-5), k
     assert one["losses"] == pytest.approx(two["losses"], rel=1e-5, abs=1e-6)
+
+
+def test_torch_ddp_wrapper_as_the_reference_uses_it_equals_flat_gradients(tmp_path):
+    """examples/indexBatching/DCRNN/pems_ddp.py:80-85 wraps the model in torch's DistributedDataParallel(gradient_as_bucket_view=
+    True).  BatchedDCRNN + torch.nn.Linear (whose input is the Tensor subclass BatchedDCRNN returns) under that wrapper at world
+    2 must train exactly like this package's one-flat-all-reduce path at world 2 — and like one process on the union."""
+    flat1 = _run("ddp_flat", 1, str(tmp_path / "f1.pt"))
+    flat2 = _run("ddp_flat", 2, str(tmp_path / "f2.pt"))
+    ddp2 = _run("ddp", 2, str(tmp_path / "d2.pt"))
+    ddp1 = _run("ddp", 1, str(tmp_path / "d1.pt"))
+    for k in flat1["params"]:
+        assert torch.allclose(ddp2["params"][k], flat2["params"][k], atol=2e-6, rtol=1e-5), k
+        assert torch.allclose(ddp2["params"][k], flat1["params"][k], atol=2e-6, rtol=1e-5), k
+        assert torch.allclose(ddp1["params"][k], flat1["params"][k], atol=2e-6, rtol=1e-5), k
+    assert ddp2["losses"] == pytest.approx(flat2["losses"], rel=1e-5, abs=1e-6)
 
 
 @pytest.mark.parametrize("world,total", [(2, 10), (4, 10), (8, 21)])

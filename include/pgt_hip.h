@@ -473,7 +473,9 @@ int pgt_att_sigmoid_bwd_f32(const float* sig, const float* dsig, int64_t B, int6
  * a base pointer and three strides in floats (a batch stride of 0 shares one matrix across the batch; swapping two
  * strides transposes).  The embeddings around ASTGCN's attention matrices and their adjoints (astgcn.py:252-256, :318-322,
  * :437: products with 1 .. 64 rows or columns), instead of one library batched GEMM each.  fmaf chain in k order,
- * deterministic.  nb and ceil(M / 16) at most 65 535. */
+ * deterministic — except a tall contraction into fewer than 512 tiles (K >= 4096: the adjoint of a batch-shared embedding),
+ * which is cut along K over the chip and summed into C with fp32 atomics.  Up to 2^31 row tiles and batches (PEMS07 at
+ * B = 32: M = B N F = 1.8 M rows), N <= 1 048 560. */
 int pgt_bmm_f32(const float* A, int64_t sab, int64_t sai, int64_t sak, const float* B, int64_t sbb, int64_t sbk, int64_t sbj,
                 float* C, int64_t scb, int64_t sci, int64_t scj, int64_t nb, int64_t M, int64_t N, int64_t K, int accumulate,
                 pgt_stream_t stream);

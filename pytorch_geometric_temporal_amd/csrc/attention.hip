@@ -91,29 +91,45 @@ struct BmmArgs {
   const float* B; int64_t sbb, sbk, sbj;
   float* C; int64_t scb, sci, scj;
   int M, N, K, accumulate;
+  int nb, ksplit, kper;      // batches; K cut into `ksplit` ranges of `kper` (a multiple of 16): partial sums meet in C by atomics
 };
+// grid: x = row tiles (up to 2^31), y = column tiles, z = (batch chunk, K range); a workgroup walks the batches b = z / ksplit,
+// + gridDim.z / ksplit, ... (more than 65 535 batches) and owns one K range.
 __global__ __launch_bounds__(256) void bmm_small_kernel(BmmArgs g) {
   __shared__ float sa[16][17], sb[16][17];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int b = blockIdx.z, i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
-  const float* A = g.A + (int64_t)b * g.sab;
-  const float* Bm = g.B + (int64_t)b * g.sbb;
-  float acc = 0.f;
-  for (int k0 = 0; k0 < g.K; k0 += 16) {
-    const int ia = i0 + ty, ka = k0 + tx;
-    sa[ty][tx] = (ia < g.M && ka < g.K) ? A[(int64_t)ia * g.sai + (int64_t)ka * g.sak] : 0.f;
-    const int kb = k0 + ty, jb = j0 + tx;
-    sb[ty][tx] = (kb < g.K && jb < g.N) ? Bm[(int64_t)kb * g.sbk + (int64_t)jb * g.sbj] : 0.f;
-    __syncthreads();
-    const int kk = g.K - k0 < 16 ? g.K - k0 : 16;     // (the zero padding must not enter the chain: 0 * inf = nan)
-    for (int t = 0; t < kk; ++t) acc = fmaf(sa[ty][t], sb[t][tx], acc);
-    __syncthreads();
+  const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  const int ks = blockIdx.z % g.ksplit, bstep = gridDim.z / g.ksplit;
+  const int kbeg = ks * g.kper, kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
+  for (int b = blockIdx.z / g.ksplit; b < g.nb; b += bstep) {
+    const float* A = g.A + (int64_t)b * g.sab;
+    const float* Bm = g.B + (int64_t)b * g.sbb;
+    float acc = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+      const int ia = i0 + ty, ka = k0 + tx;
+      sa[ty][tx] = (ia < g.M && ka < kend) ? A[(int64_t)ia * g.sai + (int64_t)ka * g.sak] : 0.f;
+      const int kb = k0 + ty, jb = j0 + tx;
+      sb[ty][tx] = (kb < kend && jb < g.N) ? Bm[(int64_t)kb * g.sbk + (int64_t)jb * g.sbj] : 0.f;
+      __syncthreads();
+      const int kk = kend - k0 < 16 ? kend - k0 : 16;     // (the zero padding must not enter the chain: 0 * inf = nan)
+      for (int t = 0; t < kk; ++t) acc = fmaf(sa[ty][t], sb[t][tx], acc);
+      __syncthreads();
+    }
+    const int i = i0 + ty, j = j0 + tx;
+    if (i < g.M && j < g.N) {
+      float* c = g.C + (int64_t)b * g.scb + (int64_t)i * g.sci + (int64_t)j * g.scj;
+      if (g.ksplit > 1) atomicAdd(c, acc);                // C was zeroed (or holds the addend) before the launch
+      else *c = g.accumulate ? *c + acc : acc;
+    }
   }
-  const int i = i0 + ty, j = j0 + tx;
-  if (i < g.M && j < g.N) {
-    float* c = g.C + (int64_t)b * g.scb + (int64_t)i * g.sci + (int64_t)j * g.scj;
-    *c = g.accumulate ? *c + acc : acc;
-  }
+}
+// C = 0 through its strides (before a K-split product that does not accumulate)
+__global__ __launch_bounds__(256) void bmm_zero_kernel(BmmArgs g) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (int64_t)g.M * g.N;
+  if (e >= per * g.nb) return;
+  const int64_t b = e / per, r = e - b * per;
+  g.C[b * g.scb + (r / g.N) * g.sci + (r % g.N) * g.scj] = 0.f;
 }
 
 // ---- Y = LayerNorm(relu(Z)) over the C columns of every row, and its adjoint (ASTGCN block tail, astgcn.py:476-478:
@@ -264,9 +280,28 @@ extern "C" int pgt_bmm_f32(const float* A, int64_t sab, int64_t sai, int64_t sak
   if (nb == 0 || M == 0 || N == 0) return PGT_OK;
   PGT_REQUIRE(C != nullptr && (K == 0 || (A && B)), "pgt_bmm_f32: null pointer");
   PGT_REQUIRE(M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31) && K < ((int64_t)1 << 31), "pgt_bmm_f32: size exceeds int32");
-  PGT_REQUIRE(nb <= 65535 && pgt_cdiv(M, 16) <= 65535, "pgt_bmm_f32: more than 65 535 batches or row tiles (fold the batch into the rows)");
-  BmmArgs g{A, sab, sai, sak, B, sbb, sbk, sbj, C, scb, sci, scj, (int)M, (int)N, (int)K, accumulate};
-  dim3 grid((unsigned)pgt_cdiv(N, 16), (unsigned)pgt_cdiv(M, 16), (unsigned)nb);
+  const int64_t tx = pgt_cdiv(M, 16), ty = pgt_cdiv(N, 16);
+  PGT_REQUIRE(tx < ((int64_t)1 << 31) && ty <= 65535 && nb < ((int64_t)1 << 31), "pgt_bmm_f32: more than 2^31 row tiles / batches or 65 535 column tiles");
+  // a tall contraction into a handful of tiles (the adjoint of a batch-shared embedding: K = B N F, one 16 x 16 tile) would be one
+  // workgroup walking the whole K: cut K so that the launch fills the chip, the ranges meet in C by fp32 atomics
+  int64_t ksplit = 1;
+  const int64_t tiles = tx * ty * nb;
+  if (K >= 4096 && tiles < 512) {
+    ksplit = pgt_cdiv(1024, tiles);
+    if (ksplit > pgt_cdiv(K, 512)) ksplit = pgt_cdiv(K, 512);
+    if (ksplit > 4096) ksplit = 4096;
+  }
+  int64_t kper = pgt_cdiv(pgt_cdiv(K, ksplit), 16) * 16;
+  if (kper < 16) kper = 16;
+  ksplit = K > 0 ? pgt_cdiv(K, kper) : 1;
+  int64_t bz = nb;
+  if (bz * ksplit > 65535) bz = 65535 / ksplit;
+  BmmArgs g{A, sab, sai, sak, B, sbb, sbk, sbj, C, scb, sci, scj, (int)M, (int)N, (int)K, accumulate, (int)nb, (int)ksplit, (int)kper};
+  if (ksplit > 1 && !accumulate) {
+    const int64_t nz = pgt_cdiv(nb * M * N, 256);
+    PGT_LAUNCH(bmm_zero_kernel, dim3((unsigned)nz), dim3(256), stream, g);
+  }
+  dim3 grid((unsigned)tx, (unsigned)ty, (unsigned)(bz * ksplit));
   PGT_LAUNCH(bmm_small_kernel, grid, dim3(256), stream, g);
   return pgt_check_launch("pgt_bmm_f32");
 }

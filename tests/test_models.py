@@ -481,6 +481,52 @@ def test_small_batched_product_with_strided_and_shared_operands(backend):
         assert_close_with_nonfinite(Bd.grad, Br.grad, 2e-5, 2e-5, "dB")
 
 
+def test_small_batched_product_tall_contraction_is_cut_along_k(backend):
+    """The adjoint of a batch-shared embedding (SpatialAttention's W1, astgcn.py:252: dW1 = X^T dC with K = B N F) is a
+    contraction of >= 4096 terms into one tile: pgt_bmm_f32 cuts K over the chip (atomics).  Values and gradients vs torch."""
+    from pytorch_geometric_temporal_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (nb, M, K, N) in ((1, 12, 20_000, 1), (2, 5, 4_100, 3), (1, 3, 70_001, 20)):
+        A, Bm = torch.randn(nb, M, K, generator=g), torch.randn(nb, K, N, generator=g)
+        ref = torch.matmul(A.double(), Bm.double())
+        out = ops.bmm(backend.t(A), backend.t(Bm))
+        assert_close_with_nonfinite(out, ref, 2e-3, 1e-4, f"bmm K = {K}")            # |sum| ~ sqrt(K): fp32 sums of K terms
+        acc = backend.t(torch.ones(nb, M, N))
+        ops._bmm_raw(backend.t(A), backend.t(Bm), acc, accumulate=True)
+        assert_close_with_nonfinite(acc, ref + 1.0, 2e-3, 1e-4, "accumulating K-split product")
+    # the shape the advisor reproduced: [1, B N F, T] x [1, T, 1] and its adjoints, here with the tall side at 40 000 rows
+    X, W1 = torch.randn(1, 40_000, 12, generator=g), torch.randn(1, 12, 1, generator=g)
+    Xr, Wr = X.double().requires_grad_(), W1.double().requires_grad_()
+    w = torch.randn(1, 40_000, 1, generator=g)
+    (torch.matmul(Xr, Wr) * w.double()).sum().backward()
+    Xd, Wd = backend.t(X).requires_grad_(), backend.t(W1).requires_grad_()
+    (ops.bmm(Xd, Wd) * backend.t(w)).sum().backward()
+    assert_close_with_nonfinite(Xd.grad, Xr.grad, 1e-5, 1e-5, "dX")
+    assert_close_with_nonfinite(Wd.grad, Wr.grad, 2e-3, 1e-4, "dW1 (K = 40 000)")
+
+
+@pytest.mark.gpu
+def test_small_batched_product_beyond_65535_row_tiles_and_batches():
+    """PEMS07 at B = 32 (N = 883, F = 64): SpatialAttention's X W1 has M = B N F = 1 808 384 rows = 113 024 row tiles, W3 X has
+    nb = B N = 28 256... and at B = 80 more than 65 535 batches (the advisor's reproduction raised PgtError in round 3)."""
+    from pytorch_geometric_temporal_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    X, W1 = torch.randn(1, 32 * 883 * 64, 12, device=dev), torch.randn(1, 12, 1, device=dev)
+    out = ops.bmm(X, W1)
+    ref = torch.matmul(X.double(), W1.double())
+    assert_close_with_nonfinite(out, ref, 1e-5, 1e-5, "1.8 M rows")
+    A, Bm = torch.randn(70_000, 3, 5, device=dev), torch.randn(70_000, 5, 2, device=dev)
+    assert_close_with_nonfinite(ops.bmm(A, Bm), torch.matmul(A.double(), Bm.double()), 1e-5, 1e-5, "70 000 batches")
+
+
+def test_small_batched_product_beyond_65535_row_tiles_on_the_cpu_double(emu_backend):
+    from pytorch_geometric_temporal_amd import ops
+    torch.manual_seed(0)
+    X, W1 = torch.randn(1, 16 * 65_540, 2), torch.randn(1, 2, 1)          # 65 540 row tiles
+    assert_close_with_nonfinite(ops.bmm(X, W1), torch.matmul(X.double(), W1.double()), 1e-5, 1e-5, "65 540 row tiles")
+
+
 @pytest.mark.parametrize("variant,n,F_,bias", [("H", 129, 8, True), ("H", 40, 5, False), ("O", 129, 8, True), ("H", 300, 16, True)])
 def test_evolve_weight_one_launch_against_topk_pooling_and_torch_gru(backend, variant, n, F_, bias):
     """ops.EvolveWeightFunction (scoring, top-k, GRU cell and every gradient in one launch each way) against the module

@@ -484,9 +484,10 @@ int pgt_bmm_f32(const float* A, int64_t sab, int64_t sai, int64_t sak, const flo
  * root) — the tail of an ASTGCN block, `self._layer_norm(F.relu(X + X_hat))` (astgcn.py:476-478), on the buffer the two
  * convolutions were summed into.  row(r) = (r / row_period) * stride_hi + (r % row_period) * stride_lo (in rows of C
  * floats): a strided time convolution's outputs are picked and its padding rows skipped.  stats [2 * rows] receives
- * (mean, 1 / std) for the adjoint.  C <= 256.
+ * (mean, 1 / std) for the adjoint.  C <= 1024.
  * Adjoint: dZ[row(r)] from dY[r] (rows of dZ the map does not reach are not written); dgamma / dbeta [C] are ACCUMULATED
- * into (fp32 atomics). */
+ * into (fp32 atomics: one per column and workgroup, at most 2048 workgroups — the sums over a workgroup's rows are taken
+ * in registers and LDS first). */
 int pgt_relu_layernorm_f32(const float* Z, int64_t row_period, int64_t stride_hi, int64_t stride_lo, const float* gamma,
                            const float* beta, float eps, int64_t rows, int64_t C, float* Y, float* stats,
                            pgt_stream_t stream);

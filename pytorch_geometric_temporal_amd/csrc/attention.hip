@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void bmm_zero_kernel(BmmArgs g) {
 
 // ---- Y = LayerNorm(relu(Z)) over the C columns of every row, and its adjoint (ASTGCN block tail, astgcn.py:476-478:
 // `self._layer_norm(F.relu(X + X_hat))` — Z is the sum the two convolutions left in one buffer).  One 64-lane wavefront per
-// row group: a row of C <= 256 floats sits in registers (C / 64 per lane), mean / variance by shuffles.  eps as
+// row group: a row of C <= 1024 floats sits in registers (C / 64 per lane), mean / variance by shuffles.  eps as
 // torch.nn.LayerNorm (biased variance).  Rows are picked by a two-level map (row r of Y <- row (r / rp) * hi + (r % rp) * lo
 // of Z) so that a strided time convolution reads its own outputs and skips the padding rows.
 template <int CPL>
@@ -173,44 +173,58 @@ __global__ __launch_bounds__(256) void relu_layernorm_kernel(const float* __rest
   if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
 }
 
-// adjoint: dZ (same row map as Z; rows the map does not reach stay untouched: the caller zeroes the buffer) and
-// per-row-group partial sums of dgamma / dbeta (added with atomics)
+// adjoint: dZ (same row map as Z; rows the map does not reach stay untouched: the caller zeroes the buffer).  A workgroup walks
+// rows r = 4 blockIdx.x + wave, + 4 gridDim.x, ...: every lane keeps the dgamma / dbeta sums of its columns in registers over all
+// of its rows, the four wavefronts meet in LDS and ONE atomic per column and workgroup goes out (round 3 issued one per
+// (row, column): rows * C contended atomics onto C addresses).
 template <int CPL>
 __global__ __launch_bounds__(256) void relu_layernorm_bwd_kernel(const float* __restrict__ Z, int64_t rp, int64_t hi, int64_t lo,
                                                                  const float* __restrict__ gamma, const float* __restrict__ stats,
                                                                  const float* __restrict__ dY, int64_t rows, int C,
                                                                  float* __restrict__ dZ, float* dgamma, float* dbeta) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  const int64_t zr = ((r / rp) * hi + (r % rp) * lo) * C;
-  const float mean = stats[2 * r], rstd = stats[2 * r + 1];
-  float zv[CPL], xh[CPL], g[CPL];
-  float s1 = 0.f, s2 = 0.f;
+  __shared__ float red[2][4][64 * CPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[CPL], ab[CPL], gm[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
-    const int c = lane + 64 * q;
-    zv[q] = c < C ? Z[zr + c] : 0.f;
-    const float a = fmaxf(zv[q], 0.f);
-    xh[q] = c < C ? (a - mean) * rstd : 0.f;
-    const float dy = c < C ? dY[r * C + c] : 0.f;
-    g[q] = c < C ? dy * gamma[c] : 0.f;
-    s1 += g[q];
-    s2 = fmaf(g[q], xh[q], s2);
-    if (c < C) {
-      atomicAdd(&dgamma[c], dy * xh[q]);
-      atomicAdd(&dbeta[c], dy);
+    ag[q] = ab[q] = 0.f;
+    gm[q] = lane + 64 * q < C ? gamma[lane + 64 * q] : 0.f;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    const int64_t zr = ((r / rp) * hi + (r % rp) * lo) * C;
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    float zv[CPL], xh[CPL], g[CPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int c = lane + 64 * q;
+      zv[q] = c < C ? Z[zr + c] : 0.f;
+      const float a = fmaxf(zv[q], 0.f);
+      xh[q] = c < C ? (a - mean) * rstd : 0.f;
+      const float dy = c < C ? dY[r * C + c] : 0.f;
+      g[q] = dy * gm[q];
+      s1 += g[q];
+      s2 = fmaf(g[q], xh[q], s2);
+      ag[q] = fmaf(dy, xh[q], ag[q]);
+      ab[q] += dy;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    const float inv = 1.f / (float)C;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int c = lane + 64 * q;
+      if (c < C) {
+        const float da = rstd * (g[q] - inv * s1 - xh[q] * inv * s2);
+        dZ[zr + c] = zv[q] > 0.f ? da : 0.f;
+      }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-  const float inv = 1.f / (float)C;
 #pragma unroll
-  for (int q = 0; q < CPL; ++q) {
-    const int c = lane + 64 * q;
-    if (c < C) {
-      const float da = rstd * (g[q] - inv * s1 - xh[q] * inv * s2);
-      dZ[zr + c] = zv[q] > 0.f ? da : 0.f;
-    }
+  for (int q = 0; q < CPL; ++q) { red[0][wave][lane + 64 * q] = ag[q]; red[1][wave][lane + 64 * q] = ab[q]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(&dgamma[c], ((red[0][0][c] + red[0][1][c]) + red[0][2][c]) + red[0][3][c]);
+    atomicAdd(&dbeta[c], ((red[1][0][c] + red[1][1][c]) + red[1][2][c]) + red[1][3][c]);
   }
 }
 
@@ -312,12 +326,12 @@ extern "C" int pgt_relu_layernorm_f32(const float* Z, int64_t row_period, int64_
   PGT_REQUIRE(rows >= 0 && C >= 0, "pgt_relu_layernorm_f32: negative size");
   if (rows == 0 || C == 0) return PGT_OK;
   PGT_REQUIRE(Z && gamma && beta && Y && stats, "pgt_relu_layernorm_f32: null pointer");
-  PGT_REQUIRE(C <= 256 && row_period >= 1, "pgt_relu_layernorm_f32: at most 256 columns, row_period >= 1");
+  PGT_REQUIRE(C <= 1024 && row_period >= 1, "pgt_relu_layernorm_f32: at most 1024 columns, row_period >= 1");
   dim3 grid;
   if (int e = grid1d(rows * 64, "pgt_relu_layernorm_f32", &grid)) return e;
   const int cpl = (int)pgt_cdiv(C, 64);
 #define PGT_LN_GO(Q_) PGT_LAUNCH((relu_layernorm_kernel<Q_>), grid, dim3(256), stream, Z, row_period, stride_hi, stride_lo, gamma, beta, eps, rows, (int)C, Y, stats)
-  if (cpl == 1) PGT_LN_GO(1); else if (cpl == 2) PGT_LN_GO(2); else PGT_LN_GO(4);
+  if (cpl == 1) PGT_LN_GO(1); else if (cpl == 2) PGT_LN_GO(2); else if (cpl <= 4) PGT_LN_GO(4); else if (cpl <= 8) PGT_LN_GO(8); else PGT_LN_GO(16);
 #undef PGT_LN_GO
   return pgt_check_launch("pgt_relu_layernorm_f32");
 }
@@ -328,12 +342,13 @@ extern "C" int pgt_relu_layernorm_bwd_f32(const float* Z, int64_t row_period, in
   PGT_REQUIRE(rows >= 0 && C >= 0, "pgt_relu_layernorm_bwd_f32: negative size");
   if (rows == 0 || C == 0) return PGT_OK;
   PGT_REQUIRE(Z && gamma && stats && dY && dZ && dgamma && dbeta, "pgt_relu_layernorm_bwd_f32: null pointer");
-  PGT_REQUIRE(C <= 256 && row_period >= 1, "pgt_relu_layernorm_bwd_f32: at most 256 columns, row_period >= 1");
-  dim3 grid;
-  if (int e = grid1d(rows * 64, "pgt_relu_layernorm_bwd_f32", &grid)) return e;
+  PGT_REQUIRE(C <= 1024 && row_period >= 1, "pgt_relu_layernorm_bwd_f32: at most 1024 columns, row_period >= 1");
+  int64_t wgs = pgt_cdiv(rows, 4);
+  if (wgs > 2048) wgs = 2048;                                  // <= 2048 atomics per column for the dgamma / dbeta sums
+  dim3 grid((unsigned)wgs);
   const int cpl = (int)pgt_cdiv(C, 64);
 #define PGT_LN_GO(Q_) PGT_LAUNCH((relu_layernorm_bwd_kernel<Q_>), grid, dim3(256), stream, Z, row_period, stride_hi, stride_lo, gamma, stats, dY, rows, (int)C, dZ, dgamma, dbeta)
-  if (cpl == 1) PGT_LN_GO(1); else if (cpl == 2) PGT_LN_GO(2); else PGT_LN_GO(4);
+  if (cpl == 1) PGT_LN_GO(1); else if (cpl == 2) PGT_LN_GO(2); else if (cpl <= 4) PGT_LN_GO(4); else if (cpl <= 8) PGT_LN_GO(8); else PGT_LN_GO(16);
 #undef PGT_LN_GO
   return pgt_check_launch("pgt_relu_layernorm_bwd_f32");
 }

@@ -303,8 +303,11 @@ class RawGraph:
         lib = _lib.get_lib()
         ei, ew = _edge_inputs(lib, edge_index, edge_weight)
         dev, E, N = ei.device, ei.size(1), int(num_nodes)
-        if E and (int(ei.min()) < 0 or int(ei.max()) >= N):
-            raise IndexError(f"edge_index has endpoint(s) outside [0, {N})")
+        if E:
+            lo, hi = torch.aminmax(ei)                            # ONE reduction and one host read per new edge tensor
+            lo, hi = torch.stack((lo, hi)).tolist()
+            if lo < 0 or hi >= N:
+                raise IndexError(f"edge_index has endpoint(s) outside [0, {N})")
         w = ew if ew is not None else torch.ones(E, dtype=F32, device=dev)
         self.N, self.E, self.device = N, E, dev
         self.fwd, self.bwd = Csr(N, E, dev), Csr(N, E, dev)
@@ -332,8 +335,11 @@ class SmallEdges:
         lib = _lib.get_lib()
         ei, ew = _edge_inputs(lib, edge_index, edge_weight)
         N, E = int(num_nodes), ei.size(1)
-        if E and (int(ei.min()) < 0 or int(ei.max()) >= N):
-            raise IndexError(f"edge_index has endpoint(s) outside [0, {N})")
+        if E:
+            lo, hi = torch.aminmax(ei)                            # ONE reduction and one host read per new edge tensor
+            lo, hi = torch.stack((lo, hi)).tolist()
+            if lo < 0 or hi >= N:
+                raise IndexError(f"edge_index has endpoint(s) outside [0, {N})")
         self.ei, self.ew, self.E, self.N = ei, ew, E, N
         key = str(ei.device)
         if key not in SmallEdges._info:

@@ -453,8 +453,24 @@ def test_batched_dcrnn_states_route_a_skinny_torch_linear_readout_to_the_streami
         assert calls == [1] and type(y) is torch.Tensor
         z = wide(h)                                   # 16 output features: torch's own product
         assert calls == [1] and type(z) is torch.Tensor
-        assert type(h * 2) is torch.Tensor and type(h.sum()) is torch.Tensor and type(torch.relu(h)) is torch.Tensor
-        assert type(TF.linear(torch.relu(h), head.weight, head.bias)) is torch.Tensor and calls == [1]
+        assert type(h * 2) is torch.Tensor and type(h.sum()) is torch.Tensor and type(h.shape) is torch.Size
+        # the reference's own models put a relu before the read-out (dcrnn_example.py:27-28, tgcn/metr_la_main.py:43-44):
+        # relu(states) keeps the routing, so that read-out runs on the streaming kernels as well
+        for r in (torch.relu(h), TF.relu(h), h.relu()):
+            assert type(r) is _StatesTensor
+        yr = TF.linear(torch.relu(h), head.weight, head.bias)
+        assert type(yr) is torch.Tensor and calls == [1, 1]
+        assert_close_with_nonfinite(yr, TF.linear(torch.relu(h.as_subclass(torch.Tensor)), head.weight, head.bias), 1e-6, 1e-5,
+                                    "relu -> read-out")
+        with torch.autocast(device_type=backend.device.type, dtype=torch.bfloat16):       # under autocast: the stock op, stock dtype
+            ya = head(h)
+        assert calls == [1, 1] and ya.dtype == torch.bfloat16
+        import io, pickle
+        buf = io.BytesIO()
+        torch.save(h.detach(), buf)
+        buf.seek(0)
+        assert type(torch.load(buf)) is torch.Tensor
+        assert type(pickle.loads(pickle.dumps(h.detach()))) is torch.Tensor
     finally:
         ops.linear = orig
     (y.square().mean() + z.mean()).backward()

@@ -422,7 +422,7 @@ def test_gconvgru_oracle_reproduces_the_reference_fixture():
     assert_close_with_nonfinite(b, g["out"]["H_state_rw"], 2e-6, 2e-6, "rw")
 
 
-@pytest.mark.parametrize("stride,Fin,O,Ft,T", [(1, 1, 8, 16, 6), (2, 3, 5, 64, 7), (3, 4, 12, 70, 12)])
+@pytest.mark.parametrize("stride,Fin,O,Ft,T", [(1, 1, 8, 16, 6), (2, 3, 5, 64, 7), (3, 4, 12, 70, 12), (1, 2, 4, 300, 3)])
 def test_time_conv_residual_layernorm_block_tail_against_torch_modules(backend, stride, Fin, O, Ft, T):
     """ops.TimeConvResidualNormFunction (three conv taps as ONE row-shifted segmented GEMM, the residual 1 x 1 convolution
     accumulated into it, relu + LayerNorm in one pass) against the reference's module chain (astgcn.py:463-478:

@@ -107,10 +107,12 @@ def small_batch(device, make_model, masked_mae_loss, series, ei, ew, n_edges, se
     return out
 
 
-def chickenpox_epoch(device, cores):
-    """BASELINE.json configs[0]: ChickenpoxDatasetLoader + DCRNN(4, 32, K=1) + Linear(32, 1), the loop of
+def chickenpox_epoch(device, cores, K=1):
+    """BASELINE.json configs[0]: ChickenpoxDatasetLoader + DCRNN(4, 32, K) + Linear(32, 1), the loop of
     examples/recurrent/dcrnn_example.py:38-46 (103 train snapshots, one backward per epoch, Adam): GPU eager, GPU as one
-    hipGraph per epoch, and the CPU oracle."""
+    hipGraph per epoch, and the CPU oracle.  K = 1 is the example's own model (one launch per snapshot each way:
+    csrc/small_cell.hip); K = 2, 3 are the reference's test shapes (test/recurrent_test.py:274-315) — the hops, both gate
+    products and the blend in ONE workgroup, csrc/seq_small.hip."""
     import torch.nn.functional as TF
     from oracle import functional as F
     from pytorch_geometric_temporal_amd.dataset import ChickenpoxDatasetLoader
@@ -120,7 +122,7 @@ def chickenpox_epoch(device, cores):
     class RecurrentGCN(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.recurrent = DCRNN(4, 32, 1)
+            self.recurrent = DCRNN(4, 32, K)
             self.linear = torch.nn.Linear(32, 1)
 
         def forward(self, x, edge_index, edge_weight):
@@ -167,7 +169,7 @@ def chickenpox_epoch(device, cores):
     t_cpu, reps = _time_cpu(cpu_epoch, 3.0)
     E = int(snaps[0][1].shape[1])
     n = len(snaps)
-    return {"what": "Chickenpox DCRNN(4,32,K=1)+Linear, 1 epoch = 103 snapshots, full-batch backward, Adam",
+    return {"what": f"Chickenpox DCRNN(4,32,K={K})+Linear, 1 epoch = 103 snapshots, full-batch backward, Adam",
             "gpu_eager_ms_per_epoch": 1e3 * t_eager, "gpu_graphed_ms_per_epoch": 1e3 * t_graph,
             "cpu_oracle_ms_per_epoch": 1e3 * t_cpu, "cpu_cores": cores, "cpu_sample": f"{reps} epochs",
             "snapshot_edges_per_s_graphed": n * E / t_graph, "snapshot_edges_per_s_cpu": n * E / t_cpu,

@@ -539,6 +539,48 @@ int pgt_tgcn_unpack_weight_grads_f32(const float* dWzr, const float* dbzr, const
                                      int64_t O, float* const dWc[3], float* const dbc[3], float* const dL[3],
                                      float* const dlb[3], pgt_stream_t stream);
 
+/* Whole DCRNN sequences of small graphs, one workgroup per sample (csrc/seq_small.hip): BatchedDCRNN.forward (nn/recurrent/
+ * dcrnn.py:429-475; cell :194-219, gates :172-192, diffusion :85-106) for graphs and widths whose per-sample state fits a
+ * workgroup's LDS (pgt_dcrnn_seq_small_fits: both operators, the [2K - 1][N][Fin + O] stack and the gate buffers within 150 KB:
+ * METR-LA / PeMS-BAY at hidden <= 8, Chickenpox at hidden 32) — the reference's own configuration BatchedDCRNN(2, 2, K = 3) on 64
+ * windows is ~220 launches per training step on the general path and ONE launch each way here.
+ *   X[b, t] = X + b * x_stride_b + t * x_stride_t: [N, Fin] rows; out likewise [N, O] rows; H0 [B, N, O] or NULL (zeros);
+ *   Wzr [(2K - 1)(Fin + O), 2 O], bzr [2 O] | NULL, Wh [(2K - 1)(Fin + O), O], bh [O] | NULL (pgt_dcrnn_pack_weights_f32's
+ *   stacked operands); save [B][T][pgt_dcrnn_seq_small_save_floats] or NULL (inference): both stacks, Z | R and the candidate of
+ *   every step for the adjoint.
+ * Adjoint (hand-written BPTT): tp_o / tp_i are the TRANSPOSED operators; dX (may be NULL) in X's layout, dH0 [B, N, O] (may be
+ * NULL), dWpart [B][(2K - 1)(Fin + O) 3 O + 3 O] = per-sample (dWzr | dWh | dbzr | dbh), ZEROED by the caller and summed over
+ * the samples by it (index order: deterministic, no atomics). */
+int pgt_dcrnn_seq_small_fits(int64_t N, int64_t E_o, int64_t E_i, int64_t Fin, int64_t O, int64_t K);
+int64_t pgt_dcrnn_seq_small_save_floats(int64_t N, int64_t Fin, int64_t O, int64_t K);
+int pgt_dcrnn_seq_small_f32(const pgt_csr* op_o, const pgt_csr* op_i, int64_t E_o, int64_t E_i, int64_t N, const float* X,
+                            int64_t x_stride_b, int64_t x_stride_t, const float* H0, const float* Wzr, const float* bzr,
+                            const float* Wh, const float* bh, int64_t B, int64_t T, int64_t Fin, int64_t O, int64_t K, float* out,
+                            int64_t out_stride_b, int64_t out_stride_t, float* save, pgt_stream_t stream);
+int pgt_dcrnn_seq_small_bwd_f32(const pgt_csr* tp_o, const pgt_csr* tp_i, int64_t E_o, int64_t E_i, int64_t N, const float* dOut,
+                                int64_t g_stride_b, int64_t g_stride_t, const float* out, int64_t out_stride_b,
+                                int64_t out_stride_t, const float* H0, const float* save, const float* Wzr, const float* Wh,
+                                int64_t B, int64_t T, int64_t Fin, int64_t O, int64_t K, float* dX, int64_t x_stride_b,
+                                int64_t x_stride_t, float* dH0, float* dWpart, pgt_stream_t stream);
+
+/* Fused T-GCN cell for hidden width 32 (nn/recurrent/temporalgcn.py:82-130; csrc/tgcn_cell.hip): with AX = A_hat X [M, Fin] and
+ * the folded operands of pgt_tgcn_pack_weights_f32,
+ *   Z | R = sigmoid([AX | H] Wzr + bzr),  H' = Z H + (1 - Z) tanh([AX | H * R] Wh + bh)
+ * in ONE launch: ZR [M, 64] and HT [M, 32] (the candidate) are written for the adjoint, Hn [M, 32] (row stride ldhn) is the new
+ * state.  pgt_tgcn_cell_fits: O == 32 and 1 <= Fin <= 30.
+ * Adjoint in one launch + a reduction: dH [M, 32] (STORED), dWzr [Fin + 32, 64], dbzr [64] | NULL, dWh [Fin + 32, 32], dbh [32] |
+ * NULL (STORED: per-workgroup partial sums in ws — pgt_tgcn_cell_bwd_ws_floats floats — added in index order, deterministic).
+ * d/dAX is not produced: a caller that needs the input gradient runs the unfused adjoint (pgt_gru_*_bwd_f32 + pgt_gemm_f32). */
+int pgt_tgcn_cell_fits(int64_t Fin, int64_t O);
+int64_t pgt_tgcn_cell_bwd_ws_floats(int64_t Fin, int64_t O);
+int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, int64_t ldh, const float* Wzr, const float* bzr,
+                      const float* Wh, const float* bh, int64_t M, int64_t Fin, int64_t O, float* ZR, float* HT, float* Hn,
+                      int64_t ldhn, pgt_stream_t stream);
+int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const float* AX, int64_t ldax, const float* H, int64_t ldh,
+                          const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin, int64_t O,
+                          float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, float* ws, int64_t ws_floats,
+                          pgt_stream_t stream);
+
 /* Index-batch window gather (signal/index_dataset.py:32-57; examples/indexBatching: "GPU-index-batching"): for every
  * sample b, X[b] = data[idx[b] : idx[b] + h], Y[b] = data[idx[b] + h : idx[b] + 2 h] from the resident series
  * data [T_total, W] (W = nodes * features), both windows of all B samples in one launch.  time_major != 0 writes

@@ -150,6 +150,20 @@ PROTOTYPES = {
     "pgt_tgcn_pack_weights_f32": (c_int, [c_p3, c_p3, c_p3, c_p3, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_tgcn_unpack_weight_grads_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_p3, c_p3, c_p3, c_i64, c_i64, c_p3, c_p3, c_p3,
                                                  c_p3, c_ptr]),
+    "pgt_dcrnn_seq_small_fits": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "pgt_dcrnn_seq_small_save_floats": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
+    "pgt_dcrnn_seq_small_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64, c_ptr, c_i64,
+                                        c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64,
+                                        c_i64, c_ptr, c_ptr]),
+    "pgt_dcrnn_seq_small_bwd_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64, c_ptr, c_i64,
+                                            c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64,
+                                            c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "pgt_tgcn_cell_fits": (c_int, [c_i64, c_i64]),
+    "pgt_tgcn_cell_bwd_ws_floats": (c_i64, [c_i64, c_i64]),
+    "pgt_tgcn_cell_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr,
+                                  c_i64, c_ptr]),
+    "pgt_tgcn_cell_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
+                                      c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
 EXPECTED_ABI = 11

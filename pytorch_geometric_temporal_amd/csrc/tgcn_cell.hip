@@ -1,0 +1,292 @@
+// Fused T-GCN cell (temporalgcn.py:82-130) for hidden width 32 — BASELINE configs[2] / [3]: A3TGCN2(2, 32), TGCN2(2, 32).
+//
+// With the aggregation AX = A_hat X taken once at the input width and conv_g -> linear_g folded into one operand per gate pair
+// (csrc/tgcn.hip), everything else in the cell is ROW-LOCAL: Z | R = sigmoid([AX | H] Wzr + bzr), the candidate
+// tanh([AX | H * R] Wh + bh), the blend.  Round 4's first form ran that as two fused-epilogue products plus movers (read / write
+// ~1.4 KB per row forward, eight launches backward); here a row makes ONE trip through a CU each way:
+//   tgcn_cell_fwd_kernel   a wavefront owns 32 rows: H is fetched in the accumulator layout (lane = column, 16 rows per lane), parked
+//       k-major in the wavefront's own LDS strip as the A operand, Z | R on two v_mfma_f32_32x32x2_f32 accumulators, sigmoid, H * R
+//       written over H in the strip (the lane that parked an element owns it), the candidate on a third accumulator, tanh and
+//       the blend against the H values still in registers.  Reads 4 (Fin + 32) bytes per row, writes Z | R, the candidate (for
+//       the adjoint) and H': 648 B per row at Fin = 2.  No workgroup barrier: the four wavefronts never touch each other's rows.
+//   tgcn_cell_bwd_kernel   the whole adjoint: gate chains on registers, d(H R) = d_pre_h Wh^T and dH += d_pre_zr Wzr^T as two
+//       products against the weights' hidden rows, and BOTH weight gradients as row-contracting products ([AX | 1 | H]^T d_pre:
+//       the row of ones makes the bias gradients fall out) on six accumulators that live across the tiles of a persistent
+//       workgroup; per-workgroup partial sums go to a scratch buffer and tgcn_cell_reduce_kernel adds them in index order
+//       (deterministic, no float atomics).  776 B per row; replaces eight launches that moved ~3.3 KB per row.
+//   d/dX (the transposed aggregation's operand) is not produced here: a caller that needs it runs the unfused adjoint.
+#include "pgt_common.h"
+
+namespace {
+
+constexpr int TC_O = 32;            // hidden width these kernels are built for
+constexpr int TC_LD = 33;           // LDS row pitch of a wavefront's strips (32 rows + 1: conflict-free both ways)
+
+struct TcArgs {
+  const float* AX; int64_t ldax; const float* H; int64_t ldh;
+  const float* Wzr; const float* bzr; const float* Wh; const float* bh;     // [Fin + 32, 64], [64] | null, [Fin + 32, 32], [32] | null
+  float* ZR; float* HT; float* Hn; int64_t ldhn;
+  int M, Fin, tiles;
+  // adjoint
+  const float* dHn; int64_t lddhn; float* dH; int64_t lddh; float* part; int n_wg;
+};
+
+// accumulator (D) layout of v_mfma_f32_32x32x2_f32: register r of a lane = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+__device__ __forceinline__ int tc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
+  // per wavefront: A strip [K2][33]; shared: Wzr [K2][65], Wh [K2][33]
+  __shared__ float s_w[64 * 65 + 64 * 33];
+  __shared__ float s_a[4][64 * TC_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+  const int C = g.Fin + TC_O, K2 = (C + 1) & ~1;
+  float* wzr = s_w;                   // [K2][65]
+  float* wh = s_w + 64 * 65;          // [K2][33]
+  for (int e = tid; e < K2 * 64; e += 256) { const int k = e >> 6, j = e & 63; wzr[k * 65 + j] = k < C ? g.Wzr[(int64_t)k * 64 + j] : 0.f; }
+  for (int e = tid; e < K2 * 32; e += 256) { const int k = e >> 5, j = e & 31; wh[k * 33 + j] = k < C ? g.Wh[(int64_t)k * 32 + j] : 0.f; }
+  float* As = s_a[wave];
+  if (K2 > C) for (int i = lane; i < TC_LD; i += 64) As[C * TC_LD + i] = 0.f;      // the padding k-row stays zero
+  __syncthreads();
+  const float b_z = g.bzr ? g.bzr[lo] : 0.f, b_r = g.bzr ? g.bzr[32 + lo] : 0.f, b_h = g.bh ? g.bh[lo] : 0.f;
+  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+    const int64_t m0 = (int64_t)tile * 128 + wave * 32;
+    float h[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tc_row(r, hi);
+      const int64_t m = m0 + row < g.M ? m0 + row : g.M - 1;
+      h[r] = g.H[m * g.ldh + lo];
+      As[(g.Fin + lo) * TC_LD + row] = h[r];
+      if (lo < g.Fin) As[lo * TC_LD + row] = g.AX[m * g.ldax + lo];
+    }
+    PGT_WAVE_SYNC();
+    pgt_f32x16 az, ar, ah;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { az[r] = 0.f; ar[r] = 0.f; ah[r] = 0.f; }
+    for (int kk = 0; kk < K2; kk += 2) {
+      const float a = As[(kk + hi) * TC_LD + lo];
+      az = PGT_MFMA_32x32x2(a, wzr[(kk + hi) * 65 + lo], az);
+      ar = PGT_MFMA_32x32x2(a, wzr[(kk + hi) * 65 + 32 + lo], ar);
+    }
+    PGT_WAVE_SYNC();
+    float z[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tc_row(r, hi);
+      z[r] = pgt_sigmoidf(az[r] + b_z);
+      const float rr = pgt_sigmoidf(ar[r] + b_r);
+      As[(g.Fin + lo) * TC_LD + row] = h[r] * rr;                       // [AX | H * R]: this lane parked (row, lo) itself
+      if (m0 + row < g.M) {
+        float* zr = g.ZR + (m0 + row) * 64;
+        zr[lo] = z[r];
+        zr[32 + lo] = rr;
+      }
+    }
+    PGT_WAVE_SYNC();
+    for (int kk = 0; kk < K2; kk += 2) ah = PGT_MFMA_32x32x2(As[(kk + hi) * TC_LD + lo], wh[(kk + hi) * 33 + lo], ah);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tc_row(r, hi);
+      if (m0 + row < g.M) {
+        const float ht = tanhf(ah[r] + b_h);
+        g.HT[(m0 + row) * 32 + lo] = ht;
+        g.Hn[(m0 + row) * g.ldhn + lo] = pgt_gru_blend(z[r], h[r], ht);
+      }
+    }
+    PGT_WAVE_SYNC();                                                       // the strip is rewritten by the next tile
+  }
+}
+
+// partial layout per workgroup (floats): dWzr [C][64] | dbzr [64] | dWh [C][32] | dbh [32]
+__device__ __forceinline__ int tc_part_floats(int Fin) { return (Fin + TC_O) * 96 + 96; }
+
+__global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
+  // shared: the hidden rows of the weights, transposed for "d_pre x W^T": whT [k = o][n = i] = Wh[Fin + i][o]  (32 x 33),
+  //         wzrT [k = j][n = i] = Wzr[Fin + i][j] (64 x 33).  per wavefront: Dz [64][33] (d_pre_z | d_pre_r), Dh [32][33],
+  //         Xs [64][33]: rows 0 .. Fin - 1 = AX columns, row Fin = ones, Fin + 1 .. 31 = zero, rows 32 .. 63 = H (then H * R)
+  __shared__ float s_wt[32 * 33 + 64 * 33];
+  __shared__ float s_t[4][(64 + 32 + 64) * TC_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+  const int Fin = g.Fin, C = Fin + TC_O;
+  float* whT = s_wt;
+  float* wzrT = s_wt + 32 * 33;
+  for (int e = tid; e < 32 * 32; e += 256) { const int o = e >> 5, i = e & 31; whT[o * 33 + i] = g.Wh[(int64_t)(Fin + i) * 32 + o]; }
+  for (int e = tid; e < 64 * 32; e += 256) { const int j = e >> 5, i = e & 31; wzrT[j * 33 + i] = g.Wzr[(int64_t)(Fin + i) * 64 + j]; }
+  float* Dz = s_t[wave];
+  float* Dh = Dz + 64 * TC_LD;
+  float* Xs = Dh + 32 * TC_LD;
+  for (int e = lane; e < 32 * TC_LD; e += 64) Xs[e] = (e / TC_LD == Fin) ? 1.f : 0.f;   // ones row, zero padding (AX rows are rewritten per tile)
+  __syncthreads();
+  pgt_f32x16 wz0a, wz0b, wz1a, wz1b, wh0, wh1;         // [AX | 1]^T dzr (two column blocks), H^T dzr, [AX | 1]^T dph, (H R)^T dph
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { wz0a[r] = wz0b[r] = wz1a[r] = wz1b[r] = wh0[r] = wh1[r] = 0.f; }
+  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+    const int64_t m0 = (int64_t)tile * 128 + wave * 32;
+    float gz[16], rr[16], h[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tc_row(r, hi);
+      const bool ok = m0 + row < g.M;
+      const int64_t m = ok ? m0 + row : g.M - 1;
+      const float gg = ok ? g.dHn[m * g.lddhn + lo] : 0.f;             // rows past the end contribute nothing
+      const float z = g.ZR[m * 64 + lo], ht = g.HT[m * 32 + lo];
+      rr[r] = g.ZR[m * 64 + 32 + lo];
+      h[r] = g.H[m * g.ldh + lo];
+      Dh[lo * TC_LD + row] = gg * (1.f - z) * (1.f - ht * ht);           // d_pre_h
+      Dz[lo * TC_LD + row] = gg * (h[r] - ht) * z * (1.f - z);           // d_pre_z
+      gz[r] = gg * z;
+      Xs[(32 + lo) * TC_LD + row] = ok ? h[r] : 0.f;
+      if (lo < Fin) Xs[lo * TC_LD + row] = ok ? g.AX[m * g.ldax + lo] : 0.f;
+      if (lo == Fin) Xs[Fin * TC_LD + row] = ok ? 1.f : 0.f;
+    }
+    PGT_WAVE_SYNC();
+    pgt_f32x16 p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = 0.f;
+    for (int kk = 0; kk < 32; kk += 2) p = PGT_MFMA_32x32x2(Dh[(kk + hi) * TC_LD + lo], whT[(kk + hi) * 33 + lo], p);   // d(H R)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tc_row(r, hi);
+      Dz[(32 + lo) * TC_LD + row] = (m0 + row < g.M) ? p[r] * h[r] * rr[r] * (1.f - rr[r]) : 0.f;   // d_pre_r
+      gz[r] = fmaf(p[r], rr[r], gz[r]);
+    }
+    PGT_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = 0.f;
+    for (int kk = 0; kk < 64; kk += 2) p = PGT_MFMA_32x32x2(Dz[(kk + hi) * TC_LD + lo], wzrT[(kk + hi) * 33 + lo], p);  // d_pre_zr Wzr_H^T
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tc_row(r, hi);
+      if (m0 + row < g.M) g.dH[(m0 + row) * g.lddh + lo] = gz[r] + p[r];
+    }
+    // weight gradients: D[i][j] += sum_m Xs[i][m] d[m][j]  (A operand = Xs rows, k = the tile's rows; B operand = d, stored [j][m])
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float a0 = Xs[lo * TC_LD + kk + hi], a1 = Xs[(32 + lo) * TC_LD + kk + hi];
+      const float bz = Dz[lo * TC_LD + kk + hi], br = Dz[(32 + lo) * TC_LD + kk + hi];
+      wz0a = PGT_MFMA_32x32x2(a0, bz, wz0a);
+      wz0b = PGT_MFMA_32x32x2(a0, br, wz0b);
+      wz1a = PGT_MFMA_32x32x2(a1, bz, wz1a);
+      wz1b = PGT_MFMA_32x32x2(a1, br, wz1b);
+    }
+    PGT_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Xs[(32 + lo) * TC_LD + tc_row(r, hi)] *= rr[r];       // H -> H * R (rows past the end are zero)
+    PGT_WAVE_SYNC();
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float b = Dh[lo * TC_LD + kk + hi];
+      wh0 = PGT_MFMA_32x32x2(Xs[lo * TC_LD + kk + hi], b, wh0);
+      wh1 = PGT_MFMA_32x32x2(Xs[(32 + lo) * TC_LD + kk + hi], b, wh1);
+    }
+    PGT_WAVE_SYNC();
+  }
+  // ---- the four wavefronts' sums meet in LDS (the strips are dead), one partial per workgroup
+  __syncthreads();
+  // six accumulators x 1024 floats per wavefront would be 24 KB each; the (dead) strips hold 4 x 21 KB: three accumulators at a time
+  float* red = &s_t[0][0];
+  float* part = g.part + (int64_t)blockIdx.x * tc_part_floats(Fin);
+  float* pWzr = part;
+  float* pbzr = part + (int64_t)C * 64;
+  float* pWh = pbzr + 64;
+  float* pbh = pWh + (int64_t)C * 32;
+  for (int round = 0; round < 2; ++round) {
+    float* mine = red + wave * 3 * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = tc_row(r, hi);
+      if (round == 0) { mine[i * 32 + lo] = wz0a[r]; mine[1024 + i * 32 + lo] = wz0b[r]; mine[2048 + i * 32 + lo] = wh0[r]; }
+      else { mine[i * 32 + lo] = wz1a[r]; mine[1024 + i * 32 + lo] = wz1b[r]; mine[2048 + i * 32 + lo] = wh1[r]; }
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * 1024; e += 256) {
+      const float v = ((red[e] + red[3 * 1024 + e]) + red[6 * 1024 + e]) + red[9 * 1024 + e];
+      const int blk = e >> 10, i = (e >> 5) & 31, j = e & 31;
+      if (round == 0) {                    // rows of [AX | 1]: i < Fin -> weight rows, i == Fin -> bias
+        if (blk < 2) { if (i < Fin) pWzr[(int64_t)i * 64 + blk * 32 + j] = v; else if (i == Fin) pbzr[blk * 32 + j] = v; }
+        else { if (i < Fin) pWh[(int64_t)i * 32 + j] = v; else if (i == Fin) pbh[j] = v; }
+      } else {                             // the hidden rows
+        if (blk < 2) pWzr[(int64_t)(Fin + i) * 64 + blk * 32 + j] = v;
+        else pWh[(int64_t)(Fin + i) * 32 + j] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[e] = sum over the workgroups' partials in index order
+__global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __restrict__ part, int n_wg, int n, float* __restrict__ dWzr,
+                                                               float* __restrict__ dbzr, float* __restrict__ dWh, float* __restrict__ dbh,
+                                                               int C) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float acc = 0.f;
+  for (int w = 0; w < n_wg; ++w) acc += part[(int64_t)w * n + e];
+  const int nWzr = C * 64, nWh = C * 32;
+  if (e < nWzr) dWzr[e] = acc;
+  else if (e < nWzr + 64) { if (dbzr) dbzr[e - nWzr] = acc; }
+  else if (e < nWzr + 64 + nWh) dWh[e - nWzr - 64] = acc;
+  else if (dbh) dbh[e - nWzr - 64 - nWh] = acc;
+}
+
+#ifdef PGT_EMU
+constexpr int TC_WGS = 3;
+#else
+constexpr int TC_WGS = 256;
+#endif
+
+}  // namespace
+
+extern "C" int pgt_tgcn_cell_fits(int64_t Fin, int64_t O) { return (O == TC_O && Fin >= 1 && Fin <= 30) ? 1 : 0; }
+
+extern "C" int64_t pgt_tgcn_cell_bwd_ws_floats(int64_t Fin, int64_t O) {
+  if (!pgt_tgcn_cell_fits(Fin, O)) return 0;
+  return (int64_t)TC_WGS * ((Fin + TC_O) * 96 + 96);
+}
+
+extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, int64_t ldh, const float* Wzr, const float* bzr,
+                                 const float* Wh, const float* bh, int64_t M, int64_t Fin, int64_t O, float* ZR, float* HT, float* Hn,
+                                 int64_t ldhn, pgt_stream_t stream) {
+  PGT_REQUIRE(M >= 0, "pgt_tgcn_cell_f32: negative size");
+  PGT_REQUIRE(pgt_tgcn_cell_fits(Fin, O), "pgt_tgcn_cell_f32: built for hidden width 32 and 1 .. 30 input columns (got %lld, %lld)",
+              (long long)O, (long long)Fin);
+  if (M == 0) return PGT_OK;
+  PGT_REQUIRE(AX && H && Wzr && Wh && ZR && HT && Hn, "pgt_tgcn_cell_f32: null pointer");
+  PGT_REQUIRE(M < ((int64_t)1 << 31) - 256 && ldax >= Fin && ldh >= O && ldhn >= O, "pgt_tgcn_cell_f32: extent out of range");
+  TcArgs g{};
+  g.AX = AX; g.ldax = ldax; g.H = H; g.ldh = ldh; g.Wzr = Wzr; g.bzr = bzr; g.Wh = Wh; g.bh = bh;
+  g.ZR = ZR; g.HT = HT; g.Hn = Hn; g.ldhn = ldhn; g.M = (int)M; g.Fin = (int)Fin; g.tiles = (int)pgt_cdiv(M, 128);
+  int64_t wgs = g.tiles < 4 * TC_WGS ? g.tiles : 4 * TC_WGS;
+  PGT_LAUNCH(tgcn_cell_fwd_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
+  return pgt_check_launch("pgt_tgcn_cell_f32");
+}
+
+extern "C" int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const float* AX, int64_t ldax, const float* H, int64_t ldh,
+                                     const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin,
+                                     int64_t O, float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, float* ws,
+                                     int64_t ws_floats, pgt_stream_t stream) {
+  PGT_REQUIRE(M >= 0, "pgt_tgcn_cell_bwd_f32: negative size");
+  PGT_REQUIRE(pgt_tgcn_cell_fits(Fin, O), "pgt_tgcn_cell_bwd_f32: built for hidden width 32 and 1 .. 30 input columns");
+  PGT_REQUIRE(dWzr && dWh, "pgt_tgcn_cell_bwd_f32: null weight gradient");
+  const int C = (int)Fin + TC_O, n = C * 96 + 96;
+  if (M == 0) {
+    if (hipMemsetAsync(dWzr, 0, (size_t)C * 64 * 4, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(dWh, 0, (size_t)C * 32 * 4, (hipStream_t)stream) != hipSuccess ||
+        (dbzr && hipMemsetAsync(dbzr, 0, 64 * 4, (hipStream_t)stream) != hipSuccess) ||
+        (dbh && hipMemsetAsync(dbh, 0, 32 * 4, (hipStream_t)stream) != hipSuccess)) {
+      pgt_set_error("pgt_tgcn_cell_bwd_f32: memset failed");
+      return PGT_ERR_LAUNCH;
+    }
+    return PGT_OK;
+  }
+  PGT_REQUIRE(dHn && AX && H && ZR && HT && Wzr && Wh && dH && ws, "pgt_tgcn_cell_bwd_f32: null pointer");
+  PGT_REQUIRE(ws_floats >= pgt_tgcn_cell_bwd_ws_floats(Fin, O), "pgt_tgcn_cell_bwd_f32: scratch too small (pgt_tgcn_cell_bwd_ws_floats)");
+  PGT_REQUIRE(M < ((int64_t)1 << 31) - 256 && ldax >= Fin && ldh >= O && lddh >= O && lddhn >= O, "pgt_tgcn_cell_bwd_f32: extent out of range");
+  TcArgs g{};
+  g.AX = AX; g.ldax = ldax; g.H = H; g.ldh = ldh; g.Wzr = Wzr; g.Wh = Wh; g.ZR = const_cast<float*>(ZR); g.HT = const_cast<float*>(HT);
+  g.dHn = dHn; g.lddhn = lddhn; g.dH = dH; g.lddh = lddh; g.part = ws;
+  g.M = (int)M; g.Fin = (int)Fin; g.tiles = (int)pgt_cdiv(M, 128);
+  const int wgs = g.tiles < TC_WGS ? g.tiles : TC_WGS;
+  g.n_wg = wgs;
+  PGT_LAUNCH(tgcn_cell_bwd_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
+  PGT_LAUNCH(tgcn_cell_reduce_kernel, dim3((unsigned)pgt_cdiv(n, 256)), dim3(256), stream, ws, wgs, n, dWzr, dbzr, dWh, dbh, C);
+  return pgt_check_launch("pgt_tgcn_cell_bwd_f32");
+}

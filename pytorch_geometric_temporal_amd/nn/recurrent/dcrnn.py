@@ -161,11 +161,23 @@ class DCRNN(torch.nn.Module):
             # launch, H = None as a null pointer (csrc/small_cell.hip; BASELINE configs[0])
             cz, cr, ch = self.conv_x_z, self.conv_x_r, self.conv_x_h
             return ops.DCRNNCellK1Function.apply(X, H, cz.weight, cr.weight, ch.weight, cz.bias, cr.bias, ch.bias)
-        H = self._set_hidden_state(X, H)
         g = ops.dconv_graph(edge_index, edge_weight, X.size(0), strict_dense=self.K > 1)
         Wzr, bzr, Wh, bh = _cell_weights(self.conv_x_z, self.conv_x_r, self.conv_x_h)
+        if ops.USE_SEQ_SMALL and X.dim() == 2 and self._one_workgroup(g):
+            # a small graph with K > 1 (test/recurrent_test.py:274-315, Chickenpox at K = 2, 3): stack, both gate products and the
+            # blend in ONE workgroup, one launch each way (csrc/seq_small.hip) instead of ~10 launches per snapshot
+            out = ops.DCRNNSeqSmallFunction.apply(X.view(1, 1, X.size(0), X.size(1)), None if H is None else H.unsqueeze(0),
+                                                  Wzr, bzr, Wh, bh, g, self.K)
+            return out[0, 0]
+        H = self._set_hidden_state(X, H)
         out = ops.DCRNNSeqFunction.apply(X.contiguous().unsqueeze(0), H, Wzr, bzr, Wh, bh, g, self.K, 1)
         return out[0]
+
+    def _one_workgroup(self, g):
+        """One cell step of one sample: worth a single workgroup while its scalar products stay small (N S C 3O multiply-adds)."""
+        C = self.in_channels + self.out_channels
+        work = g.N * (2 * self.K - 1) * C * 3 * self.out_channels
+        return work <= 4_000_000 and ops.seq_small_fits(g, self.in_channels, self.out_channels, self.K)
 
 
 class BatchedDCRNN(torch.nn.Module):
@@ -198,6 +210,10 @@ class BatchedDCRNN(torch.nn.Module):
         g = ops.dconv_graph(edge_index, edge_weight, N, strict_dense=False)
         Wzr, bzr, Wh, bh = _cell_weights(self.conv_x_z, self.conv_x_r, self.conv_x_h)
         O = self.out_channels
+        if ops.USE_SEQ_SMALL and O <= ops.SEQ_SMALL_MAX_O and ops.seq_small_fits(g, Fin, O, self.K):
+            # narrow states on a small graph (the reference's own BatchedDCRNN(2, 2, K = 3), pems_ddp.py:80): the whole 12-step
+            # sequence of a sample in one workgroup, ONE launch forward and one backward (csrc/seq_small.hip)
+            return self._states(ops.DCRNNSeqSmallFunction.apply(X, None, Wzr, bzr, Wh, bh, g, self.K))
         if ops.slab_fits(g, Fin + O, self.K):
             # small graph: batch-major rows m = b*N + n; every diffusion stack is ONE LDS-resident launch.
             # [B][T][N*F] -> [T][B][N*F]

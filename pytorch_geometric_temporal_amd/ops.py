@@ -1064,6 +1064,82 @@ class _StateLayout:
         return RowMap(self.flat[t * self.step_stride:], ld, period, hi, self.O)
 
 
+# widest hidden state the one-workgroup-per-sample sequence kernels are used for (beyond it the in-kernel scalar products lose to
+# the MFMA path even where the state would still fit the LDS); PGT_SEQ_SMALL=0 turns them off (A/B)
+# T-GCN cell at hidden width 32: the fused one-launch forward / adjoint (csrc/tgcn_cell.hip); PGT_TGCN_FUSED=0 = the two
+# fused-epilogue products + gate kernels (A/B, and the path of every other width)
+USE_TGCN_FUSED = os.environ.get("PGT_TGCN_FUSED", "1") != "0"
+SEQ_SMALL_MAX_O = int(os.environ.get("PGT_SEQ_SMALL_MAX_O", "8"))
+USE_SEQ_SMALL = os.environ.get("PGT_SEQ_SMALL", "1") != "0"
+
+
+def seq_small_fits(g, Fin, O, K):
+    """Whether pgt_dcrnn_seq_small_f32 takes this graph / width (per-sample state within a workgroup's LDS)."""
+    return bool(_lib.get_lib()._pgt_dcrnn_seq_small_fits(g.N, g.E, g.E, int(Fin), int(O), int(K)))
+
+
+class DCRNNSeqSmallFunction(torch.autograd.Function):
+    """BatchedDCRNN.forward / a DCRNN cell step for small graphs and narrow states: the whole sequence of a sample in one
+    workgroup, one launch forward and one backward (csrc/seq_small.hip).  X [B, T, N, Fin], H0 [B, N, O] | None ->
+    [B, T, N, O] (the reference's layout); Wzr / bzr / Wh / bh = the stacked operands of CellWeightsFunction."""
+
+    @staticmethod
+    def forward(ctx, X, H0, Wzr, bzr, Wh, bh, g, K):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        B, T, N, Fin = X.shape
+        O = Wh.size(1)
+        Xc = X.contiguous()
+        H0c = None
+        if H0 is not None:
+            check_tensor(lib, H0, "H")
+            H0c = H0.contiguous()
+        dev = X.device
+        Wzr_c, Wh_c = Wzr.contiguous(), Wh.contiguous()
+        out = torch.empty(B, T, N, O, dtype=F32, device=dev)
+        need = any(ctx.needs_input_grad)
+        save = None
+        if need:
+            per = int(lib._pgt_dcrnn_seq_small_save_floats(N, Fin, O, K))
+            save = torch.empty(B * T * per, dtype=F32, device=dev)
+        so, si = g.fwd_o.struct(), g.fwd_i.struct()
+        _timed("seq_small", 4.0 * (Xc.numel() + out.numel() + (save.numel() if need else 0)) if KERNEL_TIMER else 0, lambda: lib.call(
+            "pgt_dcrnn_seq_small_f32", ctypes.byref(so), ctypes.byref(si), g.E, g.E, N, ptr(Xc), T * N * Fin, N * Fin, ptr(H0c),
+            ptr(Wzr_c), ptr(bzr), ptr(Wh_c), ptr(bh), B, T, Fin, O, K, ptr(out), T * N * O, N * O, ptr(save), stream_of(lib, out)))
+        ctx.g, ctx.K = g, K
+        ctx.has = (H0 is not None, bzr is not None, bh is not None)
+        if need:
+            ctx.save_for_backward(out, H0c, save, Wzr_c, Wh_c)
+        ctx.dims = (B, T, N, Fin, O)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        lib = _lib.get_lib()
+        out, H0c, save, Wzr_c, Wh_c = ctx.saved_tensors
+        g, K = ctx.g, ctx.K
+        B, T, N, Fin, O = ctx.dims
+        C, S = Fin + O, 2 * K - 1
+        dev = out.device
+        dOc = dOut.contiguous()
+        need = ctx.needs_input_grad
+        dX = torch.empty(B, T, N, Fin, dtype=F32, device=dev) if need[0] and Fin > 0 else None
+        dH0 = torch.empty(B, N, O, dtype=F32, device=dev) if (ctx.has[0] and need[1]) else None
+        nW = S * C * 3 * O + 3 * O
+        part = torch.zeros(B, nW, dtype=F32, device=dev)
+        to, ti = g.bwd_o.struct(), g.bwd_i.struct()
+        _timed("seq_small", 4.0 * (dOc.numel() + out.numel() + save.numel()) if KERNEL_TIMER else 0, lambda: lib.call(
+            "pgt_dcrnn_seq_small_bwd_f32", ctypes.byref(to), ctypes.byref(ti), g.E, g.E, N, ptr(dOc), T * N * O, N * O, ptr(out),
+            T * N * O, N * O, ptr(H0c), ptr(save), ptr(Wzr_c), ptr(Wh_c), B, T, Fin, O, K, ptr(dX), T * N * Fin, N * Fin, ptr(dH0),
+            ptr(part), stream_of(lib, out)))
+        dW = part.sum(dim=0) if B > 1 else part[0]            # the samples in index order: deterministic
+        n1, n2 = S * C * 2 * O, S * C * 3 * O
+        dWzr, dWh = dW[:n1].view(S * C, 2 * O), dW[n1:n2].view(S * C, O)
+        dbzr = dW[n2:n2 + 2 * O] if ctx.has[1] else None
+        dbh = dW[n2 + 2 * O:] if ctx.has[2] else None
+        return dX, dH0, dWzr, dbzr, dWh, dbh, None, None
+
+
 class DCRNNSeqFunction(torch.autograd.Function):
     """T steps of the DCRNN GRU cell (dcrnn.py:172-219 / :406-475) on node-major rows m = n*B + b.
 
@@ -1403,16 +1479,27 @@ class TGCNCellFunction(torch.autograd.Function):
             raise ValueError(f"TGCN: X has {M} rows, H {tuple(H.shape)}, expected num_nodes*B = {N * Bt} rows of {O}")
         dev = Xc.device
         AX = TGCNCellFunction._aggregate(g.fwd, Xc, N, Bt, Fin, batch_major)
+        ZR = torch.empty(M, 2 * O, dtype=F32, device=dev)
+        HT = torch.empty(M, O, dtype=F32, device=dev)
+        Hn = torch.empty(M, O, dtype=F32, device=dev)
+        Wzr_c, Wh_c = Wzr.contiguous(), Wh.contiguous()
+        ctx.g, ctx.Bt, ctx.batch_major = g, Bt, batch_major
+        if USE_TGCN_FUSED and lib._pgt_tgcn_cell_fits(Fin, O):
+            # hidden width 32: the whole row-local part of the cell in ONE launch (csrc/tgcn_cell.hip), H read in place
+            Hs = H if H.stride(1) == 1 else H.contiguous()
+            hp, ldh = _rows(Hs, "H")
+            _timed("tgcn_cell", 4.0 * M * (Fin + 5 * O) if KERNEL_TIMER else 0, lambda: lib.call(
+                "pgt_tgcn_cell_f32", ptr(AX), Fin, hp, ldh, ptr(Wzr_c), ptr(bzr), ptr(Wh_c), ptr(bh), M, Fin, O, ptr(ZR), ptr(HT),
+                ptr(Hn), O, stream_of(lib, Hn)), tag=("fwd", M, Fin, O))
+            ctx.fused = True
+            ctx.save_for_backward(AX, Hs, ZR, HT, Wzr_c, Wh_c)
+            return Hn
         XH = torch.empty(M, C, dtype=F32, device=dev)          # [AX | H]
         XHR = torch.empty(M, C, dtype=F32, device=dev)         # [AX | H * R]
         copy2d(XH[:, :Fin], AX)
         copy2d(XH[:, Fin:], H if H.stride(1) == 1 else H.contiguous())
         copy2d(XHR[:, :Fin], AX)
         Hv = XH[:, Fin:]
-        ZR = torch.empty(M, 2 * O, dtype=F32, device=dev)
-        HT = torch.empty(M, O, dtype=F32, device=dev)
-        Hn = torch.empty(M, O, dtype=F32, device=dev)
-        Wzr_c, Wh_c = Wzr.contiguous(), Wh.contiguous()
         if FUSE_GATE_EPILOGUES and O % 4 == 0:
             gemm_gru_zr(XH, C, 0, 1, C, Wzr_c, 2 * O, 1, bzr, ZR, Hv, XHR, Fin)
             gemm_gru_h(XHR, C, 0, 1, C, Wh_c, O, 1, bh, HT, ZR, Hv, Hn)
@@ -1421,7 +1508,7 @@ class TGCNCellFunction(torch.autograd.Function):
             _gru_zr(ZR, Hv, XHR, Fin)
             gemm(XHR, C, 0, 1, C, Wh_c, O, 1, HT, O, 0, O, bh, M, O)
             _gru_h(HT, ZR, Hv, Hn)
-        ctx.g, ctx.Bt, ctx.batch_major = g, Bt, batch_major
+        ctx.fused = False
         ctx.save_for_backward(XH, XHR, ZR, HT, Wzr_c, Wh_c)
         return Hn
 
@@ -1440,12 +1527,43 @@ class TGCNCellFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dHn):
-        XH, XHR, ZR, HT, Wzr_c, Wh_c = ctx.saved_tensors
         g, Bt = ctx.g, ctx.Bt
+        N = g.N
+        need = ctx.needs_input_grad
+        if ctx.fused:
+            AX, Hs, ZR, HT, Wzr_c, Wh_c = ctx.saved_tensors
+            M, Fin = AX.shape
+            O = Wh_c.size(1)
+            C = Fin + O
+            dev = AX.device
+            dHn = dHn if (dHn.dim() == 2 and dHn.stride(1) == 1) else dHn.contiguous()
+            if not need[0]:
+                # the whole adjoint in one launch + a reduction of the per-workgroup weight-gradient sums (csrc/tgcn_cell.hip)
+                lib = _lib.get_lib()
+                gp, ldg = _rows(dHn, "dHn")
+                hp, ldh = _rows(Hs, "H")
+                dH = torch.empty(M, O, dtype=F32, device=dev)
+                buf = torch.empty(C * 3 * O + 3 * O, dtype=F32, device=dev)
+                dWzr, dWh = buf[:C * 2 * O].view(C, 2 * O), buf[C * 2 * O:C * 3 * O].view(C, O)
+                dbzr, dbh = buf[C * 3 * O:C * 3 * O + 2 * O], buf[C * 3 * O + 2 * O:]
+                nws = int(lib._pgt_tgcn_cell_bwd_ws_floats(Fin, O))
+                ws = _det_workspace(dev, nws)
+                _timed("tgcn_cell", 4.0 * M * (Fin + 6 * O) if KERNEL_TIMER else 0, lambda: lib.call(
+                    "pgt_tgcn_cell_bwd_f32", gp, ldg, ptr(AX), Fin, hp, ldh, ptr(ZR), ptr(HT), ptr(Wzr_c), ptr(Wh_c), M, Fin, O,
+                    ptr(dH), O, ptr(dWzr), ptr(dbzr), ptr(dWh), ptr(dbh), ptr(ws), nws, stream_of(lib, dH)), tag=("bwd", M, Fin, O))
+                return None, (dH if need[1] else None), dWzr, dbzr, dWh, dbh, None, None, None
+            # the input gradient is wanted: rebuild the unfused operands ([AX | H], [AX | H * R]) and run the general adjoint
+            XH = torch.empty(M, C, dtype=F32, device=dev)
+            XHR = torch.empty(M, C, dtype=F32, device=dev)
+            copy2d(XH[:, :Fin], AX)
+            copy2d(XH[:, Fin:], Hs)
+            copy2d(XHR[:, :Fin], AX)
+            torch.mul(Hs, ZR[:, O:], out=XHR[:, Fin:])
+        else:
+            XH, XHR, ZR, HT, Wzr_c, Wh_c = ctx.saved_tensors
         M, C = XH.shape
         O = Wh_c.size(1)
         Fin = C - O
-        N = g.N
         dev = XH.device
         dHn = dHn.contiguous()
         Hv = XH[:, Fin:]
@@ -1459,7 +1577,6 @@ class TGCNCellFunction(torch.autograd.Function):
         dXH = torch.empty(M, C, dtype=F32, device=dev)
         gemm(d_pre_zr, 2 * O, 0, 1, 2 * O, Wzr_c, 1, 2 * O, dXH, C, 0, C, None, M, C)
         add2d(dH, dXH[:, Fin:])
-        need = ctx.needs_input_grad
         dWzr = dbzr = dWh = dbh = None
         if need[2] or need[3]:
             dWzr = torch.zeros(C, 2 * O, dtype=F32, device=dev)

@@ -15,7 +15,7 @@ def header_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(pgt_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|int64_t|size_t|const char\*)\s+(pgt_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return out

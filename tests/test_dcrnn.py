@@ -503,3 +503,80 @@ def test_dcrnn_k1_cell_takes_strided_rows(backend):
         a = m(X, ei, None, H)
         b = m(X.contiguous(), ei, None, H.contiguous())
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("Fin,O,K,B,T", [(2, 2, 3, 5, 4), (2, 8, 2, 3, 3), (1, 4, 1, 2, 2), (3, 5, 3, 1, 1)])
+def test_one_workgroup_sequence_kernels_equal_the_general_path(backend, Fin, O, K, B, T):
+    """csrc/seq_small.hip (the whole sequence of a sample in one workgroup, one launch each way) against the general path
+    (LDS-resident stacks + MFMA products + gate kernels, one launch per phase): the states, dX and every parameter gradient of
+    BatchedDCRNN — the reference's own BatchedDCRNN(2, 2, K = 3) among the shapes."""
+    from pytorch_geometric_temporal_amd import ops
+    torch.manual_seed(Fin * 10 + O)
+    n = 23
+    ei_np, ew_np = syn.sensor_graph(n, 110, seed=4, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    m = BatchedDCRNN(Fin, O, K).to(backend.device)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.5, 0.5)
+    X = torch.randn(B, T, n, Fin)
+    w = backend.t(torch.randn(B, T, n, O))
+    res = {}
+    for small in (True, False):
+        ops.USE_SEQ_SMALL = small
+        try:
+            m.zero_grad()
+            Xd = backend.t(X).requires_grad_()
+            out = m(Xd, ei, ew)
+            (out * w).sum().backward()
+            res[small] = (out.detach().clone(), Xd.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+        finally:
+            ops.USE_SEQ_SMALL = True
+    assert ops.seq_small_fits(ops.dconv_graph(ei, ew, n), Fin, O, K)
+    assert_close_with_nonfinite(res[True][0], res[False][0], 2e-6, 1e-5, "states")
+    assert_close_with_nonfinite(res[True][1], res[False][1], 1e-5, 1e-4, "dX")
+    for k in res[True][2]:
+        ref = res[False][2][k]
+        assert_close_with_nonfinite(res[True][2][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, k)
+
+
+@pytest.mark.parametrize("K,hidden", [(2, True), (3, True), (3, False)])
+def test_dcrnn_cell_with_hops_on_a_small_graph_is_one_launch_each_way(backend, K, hidden):
+    """DCRNN(in, out, K > 1) on a graph of tens of nodes (Chickenpox; test/recurrent_test.py:274-315 uses K = 2, 3): one
+    pgt_dcrnn_seq_small_f32 call forward, one backward, equal to the general path incl. d/dH."""
+    from pytorch_geometric_temporal_amd import _lib, ops
+    torch.manual_seed(K)
+    n, fin, O = 20, 4, 32
+    ei_np, ew_np = syn.sensor_graph(n, 102, seed=1, symmetric=True)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    m = DCRNN(fin, O, K).to(backend.device)
+    X, H = torch.randn(n, fin), torch.randn(n, O)
+    w = backend.t(torch.randn(n, O))
+    lib = _lib.get_lib()
+    calls = []
+    orig = lib.call
+    res = {}
+    for small in (True, False):
+        ops.USE_SEQ_SMALL = small
+        lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            m.zero_grad()
+            Xd, Hd = backend.t(X).requires_grad_(), (backend.t(H).requires_grad_() if hidden else None)
+            calls.clear()
+            out = m(Xd, ei, ew, Hd)
+            fwd_calls = [c for c in calls if c not in ("pgt_dcrnn_pack_weights_f32", "pgt_dconv_prep", "pgt_csr_locality")]
+            (out * w).sum().backward()
+            res[small] = (out.detach().clone(), Xd.grad.clone(), None if Hd is None else Hd.grad.clone(),
+                          {k: p.grad.clone() for k, p in m.named_parameters()}, fwd_calls, list(calls))
+        finally:
+            lib.call = orig
+            ops.USE_SEQ_SMALL = True
+    assert res[True][4] == ["pgt_dcrnn_seq_small_f32"], res[True][4]
+    assert [c for c in res[True][5] if "seq_small" in c] == ["pgt_dcrnn_seq_small_f32", "pgt_dcrnn_seq_small_bwd_f32"]
+    assert_close_with_nonfinite(res[True][0], res[False][0], 2e-6, 1e-5, "H'")
+    assert_close_with_nonfinite(res[True][1], res[False][1], 1e-5, 1e-4, "dX")
+    if hidden:
+        assert_close_with_nonfinite(res[True][2], res[False][2], 1e-5, 1e-4, "dH")
+    for k in res[True][3]:
+        ref = res[False][3][k]
+        assert_close_with_nonfinite(res[True][3][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, k)

@@ -120,8 +120,10 @@ __device__ __forceinline__ float sq_dot(const SeqArgs& a, const float* TS, const
   return acc;
 }
 
+// LDS_BYTES: the static LDS of the instantiation (three sizes: small samples leave room for 2 - 4 resident workgroups per CU)
+template <int LDS_BYTES>
 __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[SQ_LDS];
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
   const int C = a.Fin + a.O, O = a.O, S = 2 * a.K - 1, NC = a.N * C, NO = a.N * O;
   const SqLds s = sq_carve(smem, a, false);
@@ -218,8 +220,9 @@ __device__ __forceinline__ void sq_product_adjoint(const SeqArgs& a, const SqLds
   }
 }
 
+template <int LDS_BYTES>
 __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[SQ_LDS];
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
   const int C = a.Fin + a.O, O = a.O, S = 2 * a.K - 1, NC = a.N * C, NO = a.N * O;
   const SqLds s = sq_carve(smem, a, true);
@@ -315,7 +318,10 @@ extern "C" int pgt_dcrnn_seq_small_f32(const pgt_csr* op_o, const pgt_csr* op_i,
   a.X = X; a.x_sb = x_stride_b; a.x_st = x_stride_t; a.H0 = H0; a.Wzr = Wzr; a.bzr = bzr; a.Wh = Wh; a.bh = bh;
   a.out = out; a.o_sb = out_stride_b; a.o_st = out_stride_t; a.save = save;
   const int64_t wgs = B < 2048 ? B : 2048;
-  PGT_LAUNCH(dcrnn_seq_small_fwd_kernel, dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
+  const size_t need = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, false);
+  if (need <= 38 * 1024) PGT_LAUNCH((dcrnn_seq_small_fwd_kernel<38 * 1024>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
+  else if (need <= 78 * 1024) PGT_LAUNCH((dcrnn_seq_small_fwd_kernel<78 * 1024>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
+  else PGT_LAUNCH((dcrnn_seq_small_fwd_kernel<SQ_LDS>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
   return pgt_check_launch("pgt_dcrnn_seq_small_f32");
 }
 
@@ -333,6 +339,9 @@ extern "C" int pgt_dcrnn_seq_small_bwd_f32(const pgt_csr* tp_o, const pgt_csr* t
   a.H0 = H0; a.save = const_cast<float*>(save); a.Wzr = Wzr; a.Wh = Wh;
   a.dX = dX; a.x_sb = x_stride_b; a.x_st = x_stride_t; a.dH0 = dH0; a.dWpart = dWpart;
   const int64_t wgs = B < 2048 ? B : 2048;
-  PGT_LAUNCH(dcrnn_seq_small_bwd_kernel, dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
+  const size_t need = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, true);
+  if (need <= 38 * 1024) PGT_LAUNCH((dcrnn_seq_small_bwd_kernel<38 * 1024>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
+  else if (need <= 78 * 1024) PGT_LAUNCH((dcrnn_seq_small_bwd_kernel<78 * 1024>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
+  else PGT_LAUNCH((dcrnn_seq_small_bwd_kernel<SQ_LDS>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
   return pgt_check_launch("pgt_dcrnn_seq_small_bwd_f32");
 }

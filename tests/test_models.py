@@ -799,3 +799,73 @@ def test_small_graph_gcn_layer_at_its_limits(backend):
     ref.square().sum().backward()
     assert_close_with_nonfinite(out, ref, 2e-6, 1e-5, "forward")
     assert_close_with_nonfinite(Wd.grad, Wp.grad, 1e-4, 1e-4, "dW")
+
+
+@pytest.mark.parametrize("n,B,Fin,with_dx", [(37, 3, 2, False), (130, 1, 1, False), (9, 2, 5, False), (50, 4, 30, False), (41, 2, 2, True)])
+def test_fused_tgcn_cell_at_hidden_32_equals_the_unfused_path(backend, n, B, Fin, with_dx):
+    """csrc/tgcn_cell.hip (hidden width 32: the row-local part of the T-GCN cell in one launch forward, the whole adjoint in one
+    launch + a reduction) against the two fused-epilogue products + gate kernels it replaces: H', dH, every parameter
+    gradient; with d/dX wanted the fused forward is followed by the general adjoint.  Row counts that are not multiples of the
+    32-row strips / 128-row tiles, one to thirty input columns."""
+    from pytorch_geometric_temporal_amd import ops
+    from pytorch_geometric_temporal_amd.nn.recurrent import TGCN2
+    torch.manual_seed(n + Fin)
+    ei_np, ew_np = syn.sensor_graph(n, 5 * n, seed=2, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    m = TGCN2(Fin, 32, B).to(backend.device)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.4, 0.4)
+    X, H = torch.randn(B, n, Fin), torch.randn(B, n, 32)
+    w = backend.t(torch.randn(B, n, 32))
+    res = {}
+    for fused in (True, False):
+        ops.USE_TGCN_FUSED = fused
+        try:
+            m.zero_grad()
+            Xd, Hd = backend.t(X).requires_grad_(with_dx), backend.t(H).requires_grad_()
+            out = m(Xd, ei, ew, Hd)
+            (out * w).sum().backward()
+            res[fused] = (out.detach().clone(), Hd.grad.clone(), Xd.grad.clone() if with_dx else None,
+                          {k: p.grad.clone() for k, p in m.named_parameters()})
+        finally:
+            ops.USE_TGCN_FUSED = True
+    assert_close_with_nonfinite(res[True][0], res[False][0], 1e-6, 1e-5, "H'")
+    assert_close_with_nonfinite(res[True][1], res[False][1], 1e-5, 1e-4, "dH")
+    if with_dx:
+        assert_close_with_nonfinite(res[True][2], res[False][2], 1e-5, 1e-4, "dX")
+    for k in res[True][3]:
+        ref = res[False][3][k]
+        assert_close_with_nonfinite(res[True][3][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, k)
+
+
+def test_fused_tgcn_cell_against_the_oracle_and_strided_state(backend):
+    """TGCN(2, 32) (the cell of BASELINE configs[2] / [3]) on the fused kernels against the fp64 oracle, H handed in as a column
+    slice of a wider tensor (read in place), and the inference path."""
+    from pytorch_geometric_temporal_amd.nn.recurrent import TGCN
+    torch.manual_seed(11)
+    n = 70
+    ei_np, ew_np = syn.sensor_graph(n, 400, seed=5, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    m = TGCN(2, 32)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.5, 0.5)
+    p64 = {k: v.detach().double().clone().requires_grad_() for k, v in m.state_dict().items()}
+    X, Hbig = torch.randn(n, 2), torch.randn(n, 40)
+    H = Hbig[:, 3:35]
+    H64 = H.double().requires_grad_()
+    ref = F.tgcn_cell(X.double(), ei, ew.double(), H64, p64)
+    ref.square().sum().backward()
+    m = m.to(backend.device)
+    Hd = backend.t(Hbig).requires_grad_()
+    out = m(backend.t(X), backend.t(ei), backend.t(ew), Hd[:, 3:35])
+    assert_close_with_nonfinite(out, ref, 1e-5, 1e-5, "forward")
+    out.square().sum().backward()
+    assert_close_with_nonfinite(Hd.grad[:, 3:35], H64.grad, 2e-5, 1e-4, "dH")
+    assert float(Hd.grad[:, :3].abs().sum()) == 0.0
+    for name, p in m.named_parameters():
+        gref = p64[name].grad
+        assert_close_with_nonfinite(p.grad, gref, 2e-5 * float(gref.abs().max()) + 1e-7, 1e-4, name)
+    with torch.no_grad():
+        assert torch.equal(m(backend.t(X), backend.t(ei), backend.t(ew), backend.t(H.contiguous())), out.detach())

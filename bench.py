@@ -37,7 +37,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 
 N_NODES, N_EDGES, SEQ = 207, 1515, 12
 PROPAGATES_PER_CELL = 12     # the reference's op count per DCRNN cell step: 6 (K - 1) propagate calls at K = 3
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")]
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
 
 
 def _safe(fn):
@@ -73,7 +73,8 @@ def pmc_traffic(kind):
             with open(path) as fh:
                 d = json.load(fh)
             e = d["kernels"][kind]
-            return {"traffic": e["bytes_per_launch"], "traffic_source": f"profiles/{os.path.basename(path)} ({d.get('command', '')}): "
+            return {"traffic": e["bytes_per_launch"], "traffic_measured_in_this_run": False,
+                    "traffic_source": f"BUILDER-BOX PMC, not this run: profiles/{os.path.basename(path)} ({d.get('command', '')}): "
                     f"FETCH_SIZE x2 {e['fetch_bytes_per_launch']:.3e} + WRITE_SIZE {e['write_bytes_per_launch']:.3e} B per launch "
                     f"over {e['dispatches']} dispatches"}
         except Exception:
@@ -157,13 +158,16 @@ class Model(torch.nn.Module):
     BatchedDCRNN's result routes a skinny F.linear to the package's streaming kernels, nn/recurrent/dcrnn.py:_StatesTensor)
     instead of this package's Linear (same parameters, the same kernels)."""
 
-    def __init__(self, hidden, dropin=False):
+    def __init__(self, hidden, dropin=False, relu=False):
         super().__init__()
         self.rnn = BatchedDCRNN(2, hidden, K=3)
         self.head = None if hidden == 2 else (torch.nn.Linear(hidden, 2) if dropin else Linear(hidden, 2))
+        self.relu = relu             # relu between the recurrent layer and the read-out, as the reference's own models have it
 
     def forward(self, X, ei, ew):
         h = self.rnn(X, ei, ew)
+        if self.relu:
+            h = torch.relu(h)
         return h if self.head is None else self.head(h)
 
 
@@ -181,14 +185,10 @@ def make_batches(series, batch, n_batches, seed, device):
     return out
 
 
-def cpu_baseline(hidden, target_seconds=12.0):
+def cpu_baseline(hidden, target_seconds=10.0):
     """The CPU oracle (op-for-op the reference: graph prep every conv call, 3 convs per step, gather -> mul ->
     index_add_ -> matmul) on a bounded sample of the same workload, all host cores."""
     from oracle import functional as F
-    # PyTorch's intra-op pool on these small operands stops scaling (and then collapses) well before the 256
-    # hardware threads of the GPU host; 32 is at/after the knee.  `cores` reports the threads actually used.
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
     ei_np, ew_np = syn.sensor_graph(N_NODES, N_EDGES, seed=0, symmetric=False)
     ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
     torch.manual_seed(0)
@@ -211,7 +211,20 @@ def cpu_baseline(hidden, target_seconds=12.0):
         loss.backward()
         opt.step()
 
+    # thread sweep first (1 / 8 / 32 / every hardware thread, two steps each): PyTorch's intra-op pool on these small operands
+    # stops scaling well before the GPU host's hardware threads; the baseline proper then runs at the best count found
     one_step(0)
+    sweep = {}
+    ncpu = os.cpu_count() or 1
+    for n in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
+        torch.set_num_threads(n)
+        one_step(1)
+        t0 = time.perf_counter()
+        one_step(2)
+        one_step(3)
+        sweep[str(n)] = Bc * SEQ * N_EDGES * 2 / (time.perf_counter() - t0)
+    cores = int(max(sweep, key=sweep.get))
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     one_step(1)
     per = time.perf_counter() - t0
@@ -221,8 +234,9 @@ def cpu_baseline(hidden, target_seconds=12.0):
         one_step(2 + i)
     dt = time.perf_counter() - t0
     return {"value": reps * Bc * SEQ * N_EDGES / dt, "unit": "snapshot-edges/s", "cores": cores, "kind": "port",
+            "thread_sweep_snapshot_edges_per_s": sweep, "host_hardware_threads": ncpu,
             "sample": f"{reps} training steps of the same model on {Bc} windows x {SEQ} steps (oracle/functional.py, "
-                      f"fp32, torch.set_num_threads({cores})), {dt:.1f} s"}
+                      f"fp32, torch.set_num_threads({cores}) = the best of the sweep), {dt:.1f} s"}
 
 
 def cpu_spmm_ns(cores, seconds=2.0):
@@ -310,7 +324,8 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
     return res
 
 
-def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup, profile_steps=0, dropin=False, graph=False):
+def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup, profile_steps=0, dropin=False, graph=False,
+              relu=False):
     """Build the model on the `n_edges`-edge METR-LA-shaped graph, run one initialisation pass, `warmup` untimed steps,
     then EXACTLY `steps` timed steps bracketed by barrier + synchronize; MAX over ranks.  `dropin`: torch.nn.Linear as the
     read-out (what swapping the import alone gives) instead of this package's Linear.  `graph`: forward + loss + backward
@@ -320,7 +335,7 @@ def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup
     ei_np, ew_np = syn.sensor_graph(N_NODES, n_edges, seed=0, symmetric=False)
     ei, ew = torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device)
     torch.manual_seed(0)
-    model = Model(hidden, dropin=dropin).to(device)
+    model = Model(hidden, dropin=dropin, relu=relu).to(device)
     flat = dp.FlatParameters(model.parameters())   # one gradient buffer, one parameter buffer
     opt_kw = {"capturable": True} if graph else {}
     opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)  # Adam over the flat parameter: one (fused) update per step
@@ -526,6 +541,9 @@ def main():
 
         variant("dropin_default", "import swap only: BatchedDCRNN defaults + the user's torch.nn.Linear read-out (its F.linear call on "
                 "the returned states runs on the package's streaming kernels: BatchedDCRNN.readout_interception)", dropin=True)
+        variant("dropin_relu_readout", "import swap only, with the relu the reference's own models put between the recurrent layer and "
+                "the torch.nn.Linear read-out (dcrnn_example.py:27-28, tgcn/metr_la_main.py:43-44): relu(states) keeps the routing, the "
+                "relu itself is torch's", dropin=True, relu=True)
         variant("edges_1722", "1 722-edge graph (the reference's METR-LA data)", edges=1722)
         lib.tune("gemm_bx", 0)
         try:

@@ -199,6 +199,7 @@ def cpu_baseline(hidden, target_seconds=10.0):
     series = torch.from_numpy(syn.traffic_series(2000, N_NODES, seed=1))
 
     def one_step(i):
+        nonlocal Bc
         g = torch.Generator().manual_seed(i)
         idx = torch.randint(0, 2000 - 2 * SEQ, (Bc,), generator=g)
         ar = torch.arange(SEQ)
@@ -211,18 +212,20 @@ def cpu_baseline(hidden, target_seconds=10.0):
         loss.backward()
         opt.step()
 
-    # thread sweep first (1 / 8 / 32 / every hardware thread, two steps each): PyTorch's intra-op pool on these small operands
-    # stops scaling well before the GPU host's hardware threads; the baseline proper then runs at the best count found
+    # thread sweep first (1 / 8 / 32 / 64 / every hardware thread): PyTorch's intra-op pool on these small operands stops
+    # scaling - and then collapses - well before the GPU host's hardware threads, so the sweep runs ONE step of a quarter batch
+    # per count (bounded even where a step is tens of times slower); the baseline proper then runs at the best count found
     one_step(0)
     sweep = {}
     ncpu = os.cpu_count() or 1
-    for n in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
+    Bc_full, Bc = Bc, 16
+    for n in sorted({1, min(8, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
         torch.set_num_threads(n)
         one_step(1)
         t0 = time.perf_counter()
         one_step(2)
-        one_step(3)
-        sweep[str(n)] = Bc * SEQ * N_EDGES * 2 / (time.perf_counter() - t0)
+        sweep[str(n)] = Bc * SEQ * N_EDGES / (time.perf_counter() - t0)
+    Bc = Bc_full
     cores = int(max(sweep, key=sweep.get))
     torch.set_num_threads(cores)
     t0 = time.perf_counter()
@@ -234,7 +237,7 @@ def cpu_baseline(hidden, target_seconds=10.0):
         one_step(2 + i)
     dt = time.perf_counter() - t0
     return {"value": reps * Bc * SEQ * N_EDGES / dt, "unit": "snapshot-edges/s", "cores": cores, "kind": "port",
-            "thread_sweep_snapshot_edges_per_s": sweep, "host_hardware_threads": ncpu,
+            "thread_sweep_snapshot_edges_per_s": sweep, "thread_sweep_sample": "one step of 16 windows per thread count", "host_hardware_threads": ncpu,
             "sample": f"{reps} training steps of the same model on {Bc} windows x {SEQ} steps (oracle/functional.py, "
                       f"fp32, torch.set_num_threads({cores}) = the best of the sweep), {dt:.1f} s"}
 
@@ -428,7 +431,12 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="forward+backward and the update as two hipGraphs per step, the all-reduce between them eager "
                          "(per-GPU batches whose step is host-launch bound, e.g. --global-batch 1024 on 8 GPUs)")
+    ap.add_argument("--aux-seconds", type=float, default=240.0,
+                    help="wall-clock budget of the whole run after which the remaining AUXILIARY lines (variants, other configs) are "
+                         "skipped and recorded as such: the default run has to finish within minutes on any box")
     args = ap.parse_args()
+    t_start = time.time()
+    over_budget = lambda: time.time() - t_start > args.aux_seconds      # noqa: E731
     args.batch_given = args.batch is not None
     if args.batch is None:
         args.batch = 1024
@@ -527,6 +535,9 @@ def main():
         variants = {}
 
         def variant(name, what, edges=args.edges, **kw):
+            if over_budget():
+                variants[name] = {"skipped": f"--aux-seconds {args.aux_seconds:g} spent"}
+                return
             torch.cuda.empty_cache()
             try:
                 best = None
@@ -562,6 +573,8 @@ def main():
         # (as hipGraphs: that batch is host-launch bound when issued eagerly) against the B = 1024 step is the ceiling of the
         # speed-up, measurable on one GPU
         try:
+            if over_budget():
+                raise TimeoutError(f"--aux-seconds {args.aux_seconds:g} spent")
             torch.cuda.empty_cache()
             d128 = min(train_run(device, rank, world, series, args.edges, 128, args.hidden, 8, 3, graph=True)[0] for _ in range(2))
             variants["strong_scaling_projection"] = {
@@ -593,6 +606,9 @@ def main():
             "config5_covid_evolvegcnh": lambda: BCfg.covid_epoch(device, cores),
         }
         for name, fn in blocks.items():
+            if over_budget():
+                extra[name] = {"skipped": f"--aux-seconds {args.aux_seconds:g} spent"}
+                continue
             try:
                 extra[name] = fn()
             except Exception as e:                             # an auxiliary line must never cost the bench line

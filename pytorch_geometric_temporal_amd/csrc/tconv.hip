@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void bn_nodes_kernel(const float* __restrict__
   float mean, invstd;
   if (training) {
     float s = 0.f;
-    for (int64_t e = threadIdx.x; e < total; e += 256) {
+#pragma unroll 4
+  #pragma unroll 4
+  for (int64_t e = threadIdx.x; e < total; e += 256) {
       const int64_t r = e / CV;
       float v[V];
       pgt_ldv<V>(x0 + r * row_stride + (e - r * CV) * V, v);
@@ -238,7 +240,9 @@ __global__ __launch_bounds__(256) void bn_nodes_kernel(const float* __restrict__
     const float cnt = (float)(R * C);
     mean = block_sum256(s, red) / cnt;
     float q = 0.f;
-    for (int64_t e = threadIdx.x; e < total; e += 256) {
+#pragma unroll 4
+  #pragma unroll 4
+  for (int64_t e = threadIdx.x; e < total; e += 256) {
       const int64_t r = e / CV;
       float v[V];
       pgt_ldv<V>(x0 + r * row_stride + (e - r * CV) * V, v);
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(256) void bn_nodes_kernel(const float* __restrict__
   if (threadIdx.x == 0 && stats) { stats[2 * n] = mean; stats[2 * n + 1] = invstd; }
   const float w = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
   float* y0 = Y + n * C;
+#pragma unroll 4
   for (int64_t e = threadIdx.x; e < total; e += 256) {
     const int64_t r = e / CV;
     const int64_t o = r * row_stride + (e - r * CV) * V;
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(256) void bn_nodes_bwd_kernel(const float* __restri
   const float* x0 = X + n * C;
   const float* g0 = dY + n * C;
   float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
   for (int64_t e = threadIdx.x; e < total; e += 256) {
     const int64_t r = e / CV;
     const int64_t o = r * row_stride + (e - r * CV) * V;
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(256) void bn_nodes_bwd_kernel(const float* __restri
   const float inv = 1.f / (float)(R * C);
   const float k1 = training ? s1 * inv : 0.f, k2 = training ? s2 * inv : 0.f;
   float* d0 = dX + n * C;
+#pragma unroll 4
   for (int64_t e = threadIdx.x; e < total; e += 256) {
     const int64_t r = e / CV;
     const int64_t o = r * row_stride + (e - r * CV) * V;

@@ -48,16 +48,29 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
   if (K2 > C) for (int i = lane; i < TC_LD; i += 64) As[C * TC_LD + i] = 0.f;      // the padding k-row stays zero
   __syncthreads();
   const float b_z = g.bzr ? g.bzr[lo] : 0.f, b_r = g.bzr ? g.bzr[32 + lo] : 0.f, b_h = g.bh ? g.bh[lo] : 0.f;
+  const float* __restrict__ Hg = g.H;
+  const float* __restrict__ AXg = g.AX;
+  float* __restrict__ ZRg = g.ZR;
+  float* __restrict__ HTg = g.HT;
+  float* __restrict__ Hng = g.Hn;
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
     const int64_t m0 = (int64_t)tile * 128 + wave * 32;
-    float h[16];
+    // every global load of the strip is issued before the first LDS write (a load followed by its own ds_write makes the compiler
+    // wait for each load in turn: 32 serialised round trips per tile, 220 us per launch in the first version of this kernel)
+    float h[16], ax[16];
+    const int axc = lo < g.Fin ? lo : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t mr = m0 + tc_row(r, hi);
+      const int64_t m = mr < g.M ? mr : g.M - 1;
+      h[r] = Hg[m * g.ldh + lo];
+      ax[r] = AXg[m * g.ldax + axc];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
-      const int64_t m = m0 + row < g.M ? m0 + row : g.M - 1;
-      h[r] = g.H[m * g.ldh + lo];
       As[(g.Fin + lo) * TC_LD + row] = h[r];
-      if (lo < g.Fin) As[lo * TC_LD + row] = g.AX[m * g.ldax + lo];
+      if (lo < g.Fin) As[lo * TC_LD + row] = ax[r];
     }
     PGT_WAVE_SYNC();
     pgt_f32x16 az, ar, ah;
@@ -70,14 +83,15 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
     }
     PGT_WAVE_SYNC();
     float z[16];
+    const bool full = m0 + 32 <= g.M;                                      // wavefront-uniform: whole strips store without per-row branches
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
       z[r] = pgt_sigmoidf(az[r] + b_z);
       const float rr = pgt_sigmoidf(ar[r] + b_r);
       As[(g.Fin + lo) * TC_LD + row] = h[r] * rr;                       // [AX | H * R]: this lane parked (row, lo) itself
-      if (m0 + row < g.M) {
-        float* zr = g.ZR + (m0 + row) * 64;
+      if (full || m0 + row < g.M) {
+        float* zr = ZRg + (m0 + row) * 64;
         zr[lo] = z[r];
         zr[32 + lo] = rr;
       }
@@ -87,10 +101,10 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
-      if (m0 + row < g.M) {
+      if (full || m0 + row < g.M) {
         const float ht = tanhf(ah[r] + b_h);
-        g.HT[(m0 + row) * 32 + lo] = ht;
-        g.Hn[(m0 + row) * g.ldhn + lo] = pgt_gru_blend(z[r], h[r], ht);
+        HTg[(m0 + row) * 32 + lo] = ht;
+        Hng[(m0 + row) * g.ldhn + lo] = pgt_gru_blend(z[r], h[r], ht);
       }
     }
     PGT_WAVE_SYNC();                                                       // the strip is rewritten by the next tile
@@ -117,27 +131,44 @@ __global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
   float* Xs = Dh + 32 * TC_LD;
   for (int e = lane; e < 32 * TC_LD; e += 64) Xs[e] = (e / TC_LD == Fin) ? 1.f : 0.f;   // ones row, zero padding (AX rows are rewritten per tile)
   __syncthreads();
+  const float* __restrict__ dHg = g.dHn;
+  const float* __restrict__ ZRg = g.ZR;
+  const float* __restrict__ HTg = g.HT;
+  const float* __restrict__ Hg = g.H;
+  const float* __restrict__ AXg = g.AX;
   pgt_f32x16 wz0a, wz0b, wz1a, wz1b, wh0, wh1;         // [AX | 1]^T dzr (two column blocks), H^T dzr, [AX | 1]^T dph, (H R)^T dph
 #pragma unroll
   for (int r = 0; r < 16; ++r) { wz0a[r] = wz0b[r] = wz1a[r] = wz1b[r] = wh0[r] = wh1[r] = 0.f; }
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
     const int64_t m0 = (int64_t)tile * 128 + wave * 32;
     float gz[16], rr[16], h[16];
+    {
+      // all global loads first (see the forward kernel), then the gate chains and the LDS writes
+      float gg[16], zz[16], ht[16], ax[16];
+      const int axc = lo < Fin ? lo : 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = tc_row(r, hi);
-      const bool ok = m0 + row < g.M;
-      const int64_t m = ok ? m0 + row : g.M - 1;
-      const float gg = ok ? g.dHn[m * g.lddhn + lo] : 0.f;             // rows past the end contribute nothing
-      const float z = g.ZR[m * 64 + lo], ht = g.HT[m * 32 + lo];
-      rr[r] = g.ZR[m * 64 + 32 + lo];
-      h[r] = g.H[m * g.ldh + lo];
-      Dh[lo * TC_LD + row] = gg * (1.f - z) * (1.f - ht * ht);           // d_pre_h
-      Dz[lo * TC_LD + row] = gg * (h[r] - ht) * z * (1.f - z);           // d_pre_z
-      gz[r] = gg * z;
-      Xs[(32 + lo) * TC_LD + row] = ok ? h[r] : 0.f;
-      if (lo < Fin) Xs[lo * TC_LD + row] = ok ? g.AX[m * g.ldax + lo] : 0.f;
-      if (lo == Fin) Xs[Fin * TC_LD + row] = ok ? 1.f : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int64_t mr = m0 + tc_row(r, hi);
+        const int64_t m = mr < g.M ? mr : g.M - 1;
+        gg[r] = dHg[m * g.lddhn + lo];
+        zz[r] = ZRg[m * 64 + lo];
+        rr[r] = ZRg[m * 64 + 32 + lo];
+        ht[r] = HTg[m * 32 + lo];
+        h[r] = Hg[m * g.ldh + lo];
+        ax[r] = AXg[m * g.ldax + axc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tc_row(r, hi);
+        const bool ok = m0 + row < g.M;
+        const float g1 = ok ? gg[r] : 0.f;                                 // rows past the end contribute nothing
+        Dh[lo * TC_LD + row] = g1 * (1.f - zz[r]) * (1.f - ht[r] * ht[r]);  // d_pre_h
+        Dz[lo * TC_LD + row] = g1 * (h[r] - ht[r]) * zz[r] * (1.f - zz[r]); // d_pre_z
+        gz[r] = g1 * zz[r];
+        Xs[(32 + lo) * TC_LD + row] = ok ? h[r] : 0.f;
+        if (lo < Fin) Xs[lo * TC_LD + row] = ok ? ax[r] : 0.f;
+        if (lo == Fin) Xs[Fin * TC_LD + row] = ok ? 1.f : 0.f;
+      }
     }
     PGT_WAVE_SYNC();
     pgt_f32x16 p;

@@ -229,7 +229,6 @@ __global__ __launch_bounds__(256) void bn_nodes_kernel(const float* __restrict__
   if (training) {
     float s = 0.f;
 #pragma unroll 4
-  #pragma unroll 4
   for (int64_t e = threadIdx.x; e < total; e += 256) {
       const int64_t r = e / CV;
       float v[V];
@@ -241,7 +240,6 @@ __global__ __launch_bounds__(256) void bn_nodes_kernel(const float* __restrict__
     mean = block_sum256(s, red) / cnt;
     float q = 0.f;
 #pragma unroll 4
-  #pragma unroll 4
   for (int64_t e = threadIdx.x; e < total; e += 256) {
       const int64_t r = e / CV;
       float v[V];

@@ -40,6 +40,14 @@ PROPAGATES_PER_CELL = 12     # the reference's op count per DCRNN cell step: 6 (
 PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """Stage marks on stderr (stdout carries the one JSON line): where a slow box spends the run."""
+    print(f"[bench {time.time() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def _safe(fn):
     """Auxiliary figures must never cost the bench line."""
     try:
@@ -219,13 +227,28 @@ def cpu_baseline(hidden, target_seconds=10.0):
     sweep = {}
     ncpu = os.cpu_count() or 1
     Bc_full, Bc = Bc, 16
-    for n in sorted({1, min(8, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
+    for n in sorted({1, min(8, ncpu), min(32, ncpu), min(64, ncpu)}):
         torch.set_num_threads(n)
         one_step(1)
         t0 = time.perf_counter()
         one_step(2)
         sweep[str(n)] = Bc * SEQ * N_EDGES / (time.perf_counter() - t0)
+        log(f"cpu oracle, {n} thread(s): {sweep[str(n)]:.3e} snapshot-edges/s")
     Bc = Bc_full
+    all_threads = None
+    if ncpu > 64:
+        # every hardware thread (256 on the GPU host): torch's intra-op pool on operands this small may take minutes per step
+        # there, so that point runs in a child process under a clock and is recorded as a timeout when it does not return
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-sweep-worker", str(ncpu), "--hidden", str(hidden)],
+                               capture_output=True, text=True, timeout=45)
+            all_threads = float(r.stdout.strip().splitlines()[-1])
+        except subprocess.TimeoutExpired:
+            all_threads = "no result within 45 s (import + two steps of 16 windows)"
+        except Exception as e:
+            all_threads = repr(e)
+        log(f"cpu oracle, {ncpu} threads (child process): {all_threads}")
     cores = int(max(sweep, key=sweep.get))
     torch.set_num_threads(cores)
     t0 = time.perf_counter()
@@ -237,9 +260,39 @@ def cpu_baseline(hidden, target_seconds=10.0):
         one_step(2 + i)
     dt = time.perf_counter() - t0
     return {"value": reps * Bc * SEQ * N_EDGES / dt, "unit": "snapshot-edges/s", "cores": cores, "kind": "port",
-            "thread_sweep_snapshot_edges_per_s": sweep, "thread_sweep_sample": "one step of 16 windows per thread count", "host_hardware_threads": ncpu,
+            "thread_sweep_snapshot_edges_per_s": sweep, "thread_sweep_sample": "one step of 16 windows per thread count",
+            "all_hardware_threads_snapshot_edges_per_s": all_threads, "host_hardware_threads": ncpu,
             "sample": f"{reps} training steps of the same model on {Bc} windows x {SEQ} steps (oracle/functional.py, "
                       f"fp32, torch.set_num_threads({cores}) = the best of the sweep), {dt:.1f} s"}
+
+
+def cpu_sweep_point(hidden, threads, Bc=16):
+    """One point of the CPU oracle's thread sweep (the same step as cpu_baseline on 16 windows), snapshot-edges/s."""
+    from oracle import functional as F
+    torch.set_num_threads(threads)
+    ei_np, ew_np = syn.sensor_graph(N_NODES, N_EDGES, seed=0, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    torch.manual_seed(0)
+    m = Model(hidden)
+    params = {k[len("rnn."):]: v for k, v in m.named_parameters() if k.startswith("rnn.")}
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    series = torch.from_numpy(syn.traffic_series(200, N_NODES, seed=1))
+    ar = torch.arange(SEQ)
+
+    def one_step(i):
+        idx = torch.randint(0, 200 - 2 * SEQ, (Bc,), generator=torch.Generator().manual_seed(i))
+        X, y = series[idx[:, None] + ar], series[idx[:, None] + SEQ + ar]
+        out = F.batched_dcrnn(X, ei, ew, params)
+        if m.head is not None:
+            out = torch.nn.functional.linear(out, m.head.weight, m.head.bias)
+        loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    one_step(0)
+    t0 = time.perf_counter()
+    one_step(1)
+    return Bc * SEQ * N_EDGES / (time.perf_counter() - t0)
 
 
 def cpu_spmm_ns(cores, seconds=2.0):
@@ -431,10 +484,14 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="forward+backward and the update as two hipGraphs per step, the all-reduce between them eager "
                          "(per-GPU batches whose step is host-launch bound, e.g. --global-batch 1024 on 8 GPUs)")
-    ap.add_argument("--aux-seconds", type=float, default=240.0,
+    ap.add_argument("--cpu-sweep-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--aux-seconds", type=float, default=200.0,
                     help="wall-clock budget of the whole run after which the remaining AUXILIARY lines (variants, other configs) are "
                          "skipped and recorded as such: the default run has to finish within minutes on any box")
     args = ap.parse_args()
+    if args.cpu_sweep_worker:                  # child of cpu_baseline's thread sweep: one thread count, CPU only, prints the rate
+        print(cpu_sweep_point(args.hidden, args.cpu_sweep_worker))
+        return
     t_start = time.time()
     over_budget = lambda: time.time() - t_start > args.aux_seconds      # noqa: E731
     args.batch_given = args.batch is not None
@@ -470,10 +527,12 @@ def main():
     ns = None
     if rank == 0 and world == 1 and not args.no_ns:
         ns = spmm_roofline_ns(device)
+        log("north-star aggregation block done")
 
     dt, final_loss, step, (ei, ew) = train_run(device, rank, world, series, args.edges, args.batch, args.hidden,
                                                args.steps, args.warmup, 0 if args.graph else args.profile_steps,
                                                graph=args.graph)
+    log(f"headline: {1e3 * dt / args.steps:.3f} ms/step")
     if args.graph:
         args.profile_steps = 0       # per-launch events cannot be recorded inside a captured step
     n_total = args.warmup + args.steps + args.profile_steps
@@ -517,7 +576,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline ...")
         cpu = cpu_baseline(args.hidden)
+        log("cpu baseline done")
         try:                                                   # beside roofline_ns_spmm_N200k_F64 (same operator)
             cpu["optimised_spmm"] = cpu_spmm_ns(cpu["cores"])
         except Exception as e:                                 # an auxiliary line must never cost the bench line
@@ -546,6 +607,7 @@ def main():
                     del st
                     best = d if best is None or d < best else best
                 variants[name] = dict(throughput(best, edges, args.batch, 8), what=what + " (8 steps, better of two runs)")
+                log(f"variant {name}: {1e3 * best / 8:.3f} ms/step")
             except Exception as e:                            # an auxiliary line must never cost the bench line
                 variants[name] = {"error": repr(e)}
             torch.cuda.empty_cache()
@@ -614,6 +676,7 @@ def main():
             except Exception as e:                             # an auxiliary line must never cost the bench line
                 extra[name] = {"error": repr(e)}
             torch.cuda.synchronize()
+            log(f"other config {name} done")
 
     if rank == 0:
         head = throughput(dt, args.edges, args.batch, args.steps)

@@ -72,25 +72,50 @@ def windows(series, idx, seq=SEQ):
     return X.permute(0, 2, 3, 1), y
 
 
-def training_step_fn(model, flat, opt, series, ei, ew, world, seq=SEQ):
-    """forward + loss + backward + ONE flat all-reduce + update on the windows starting at `idx` (a device LongTensor)."""
-    def step(idx):
+def training_step_fn(model, flat, opt, series, ei, ew, world, seq=SEQ, graph=False):
+    """forward + loss + backward + ONE flat all-reduce + update on the windows starting at `idx` (a device LongTensor).  `graph`:
+    forward + loss + backward as one hipGraph and the update as a second one, the all-reduce between them eager (bench.py --graph)."""
+    def forward_backward(idx):
         x, y = windows(series, idx, seq)
         out = model(x, ei, ew)
         loss = masked_mae_loss(out * STD + MEAN, y * STD + MEAN)
         flat.zero()
         loss.backward()
+        return loss
+
+    if graph:
+        from pytorch_geometric_temporal_amd.graphed import GraphedStep
+        snapshot = flat.data.clone()
+        g_fb = GraphedStep(forward_backward, [torch.zeros(model.batch_hint, dtype=torch.long, device=series.device)], warmup=1)
+        g_opt = GraphedStep(lambda: opt.step(), [], warmup=1)
+        flat.data.copy_(snapshot)
+        for st in opt.state.values():
+            for v in st.values():
+                if isinstance(v, torch.Tensor):
+                    v.zero_()
+
+        def step(idx):
+            loss = g_fb(idx)
+            flat.all_reduce_mean(world)
+            g_opt()
+            return loss
+        return step
+
+    def step(idx):
+        loss = forward_backward(idx)
         flat.all_reduce_mean(world)
         opt.step()
         return loss
     return step
 
 
-def train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile_steps=0, hidden=32, dropin=False):
+def train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile_steps=0, hidden=32, dropin=False, graph=False):
     torch.manual_seed(0)
     model = BatchedTGCN(2, hidden, 2, dropin=dropin).to(device)
+    model.batch_hint = batch
     flat = dp.FlatParameters(model.parameters())
-    opt = flat.optimizer(torch.optim.Adam, lr=1e-3)
+    opt_kw = {"capturable": True} if graph else {}
+    opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)
     rng = np.random.default_rng(1000 + rank)
     n_total = warmup + steps + profile_steps
     T_total = series.shape[0]
@@ -99,8 +124,8 @@ def train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile
     snapshot = flat.data.clone()
     run(batches[n_total])                                   # initialisation pass (graph preparation, code objects, allocator)
     flat.data.copy_(snapshot)
-    opt = flat.optimizer(torch.optim.Adam, lr=1e-3)
-    run = training_step_fn(model, flat, opt, series, ei, ew, world)
+    opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)
+    run = training_step_fn(model, flat, opt, series, ei, ew, world, graph=graph)
     step = lambda i: run(batches[i])                        # noqa: E731
     for i in range(warmup):
         step(i)
@@ -149,9 +174,11 @@ def cpu_oracle(cores, batch=1, seconds=10.0):
                       f"torch.set_num_threads({cores}))"}
 
 
-def measure(device, rank, world, batch, steps, warmup, profile_steps, series, ei, ew, bench):
+def measure(device, rank, world, batch, steps, warmup, profile_steps, series, ei, ew, bench, graph=False):
     """One configuration: timed steps + instrumented steps -> the dict that goes into the JSON line."""
-    dt, loss, step, model = train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile_steps)
+    if graph:
+        profile_steps = 0                                  # per-launch events cannot be recorded inside a captured step
+    dt, loss, step, model = train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile_steps, graph=graph)
     edges = int(ei.shape[1])
     res = {"batch_per_gpu": batch, "ms_per_step": 1e3 * dt / steps, "snapshot_edges_per_s": world * batch * SEQ * edges * steps / dt,
            "final_loss": loss}
@@ -215,7 +242,10 @@ def main(args, rank, local_rank, world, device, bench):
     if args.global_batch > 0:
         assert args.global_batch % world == 0
         batch, scaling = args.global_batch // world, "strong"
-    res = measure(device, rank, world, batch, args.steps, args.warmup, 0 if args.graph else args.profile_steps, series, ei, ew, bench)
+    res = measure(device, rank, world, batch, args.steps, args.warmup, args.profile_steps, series, ei, ew, bench, graph=args.graph)
+    graphed = None
+    if world == 1 and not args.graph and not args.no_extra:
+        graphed = bench._safe(lambda: measure(device, rank, world, batch, args.steps, args.warmup, 0, series, ei, ew, bench, graph=True))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = bench._safe(lambda: cpu_oracle(min(os.cpu_count() or 1, 32)))
@@ -229,6 +259,9 @@ def main(args, rank, local_rank, world, device, bench):
                 "config": {"workload": f"index-batched synthetic {N_NODES}-node / {edges}-edge static graph, BatchedTGCN = 12 x "
                                        "(TGCN2(2,32) -> relu -> Linear(32,2)) training step (fwd+bwd+allreduce+Adam)",
                            "batch_per_gpu": batch, "global_batch": world * batch, "seq_len": SEQ, "parallelism": f"dp{world}",
-                           "hidden": 32},
+                           "hidden": 32, "graphed": bool(args.graph)},
+                "variants": {"hipgraph_step": None if graphed is None else {
+                    "ms_per_step": graphed["ms_per_step"], "snapshot_edges_per_s": graphed["snapshot_edges_per_s"],
+                    "what": "--graph: forward+backward and the update as two hipGraphs (B = 8 is host-launch bound when issued eagerly)"}},
                 "final_loss": res["final_loss"], "roofline": res.get("roofline"), "kernels": res.get("kernels"), "cpu_baseline": cpu}
         print(json.dumps(line))

@@ -53,25 +53,32 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
   float* __restrict__ ZRg = g.ZR;
   float* __restrict__ HTg = g.HT;
   float* __restrict__ Hng = g.Hn;
-  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
-    const int64_t m0 = (int64_t)tile * 128 + wave * 32;
-    // every global load of the strip is issued before the first LDS write (a load followed by its own ds_write makes the compiler
-    // wait for each load in turn: 32 serialised round trips per tile, 220 us per launch in the first version of this kernel)
-    float h[16], ax[16];
-    const int axc = lo < g.Fin ? lo : 0;
+  // the strip of the NEXT tile is fetched while this one is on the matrix cores (two register sets): a wavefront's phases would
+  // otherwise run load -> products -> stores strictly in turn, with two wavefronts per SIMD to hide all of it
+  const int axc = lo < g.Fin ? lo : 0;
+  float hn[16], axn[16];
+  auto fetch = [&](int t) {
+    const int64_t mt = (int64_t)t * 128 + wave * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t mr = m0 + tc_row(r, hi);
+      const int64_t mr = mt + tc_row(r, hi);
       const int64_t m = mr < g.M ? mr : g.M - 1;
-      h[r] = Hg[m * g.ldh + lo];
-      ax[r] = AXg[m * g.ldax + axc];
+      hn[r] = Hg[m * g.ldh + lo];
+      axn[r] = AXg[m * g.ldax + axc];
     }
+  };
+  if ((int)blockIdx.x < g.tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+    const int64_t m0 = (int64_t)tile * 128 + wave * 32;
+    float h[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
+      h[r] = hn[r];
       As[(g.Fin + lo) * TC_LD + row] = h[r];
-      if (lo < g.Fin) As[lo * TC_LD + row] = ax[r];
+      if (lo < g.Fin) As[lo * TC_LD + row] = axn[r];
     }
+    if (tile + (int)gridDim.x < g.tiles) fetch(tile + gridDim.x);
     PGT_WAVE_SYNC();
     pgt_f32x16 az, ar, ah;
 #pragma unroll
@@ -139,37 +146,42 @@ __global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
   pgt_f32x16 wz0a, wz0b, wz1a, wz1b, wh0, wh1;         // [AX | 1]^T dzr (two column blocks), H^T dzr, [AX | 1]^T dph, (H R)^T dph
 #pragma unroll
   for (int r = 0; r < 16; ++r) { wz0a[r] = wz0b[r] = wz1a[r] = wz1b[r] = wh0[r] = wh1[r] = 0.f; }
+  const int axc = lo < Fin ? lo : 0;
+  float ggn[16], zzn[16], rrn[16], htn[16], hn[16], axn[16];       // the next tile's operands (see the forward kernel)
+  auto fetch = [&](int t) {
+    const int64_t mt = (int64_t)t * 128 + wave * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t mr = mt + tc_row(r, hi);
+      const int64_t m = mr < g.M ? mr : g.M - 1;
+      ggn[r] = dHg[m * g.lddhn + lo];
+      zzn[r] = ZRg[m * 64 + lo];
+      rrn[r] = ZRg[m * 64 + 32 + lo];
+      htn[r] = HTg[m * 32 + lo];
+      hn[r] = Hg[m * g.ldh + lo];
+      axn[r] = AXg[m * g.ldax + axc];
+    }
+  };
+  if ((int)blockIdx.x < g.tiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
     const int64_t m0 = (int64_t)tile * 128 + wave * 32;
     float gz[16], rr[16], h[16];
-    {
-      // all global loads first (see the forward kernel), then the gate chains and the LDS writes
-      float gg[16], zz[16], ht[16], ax[16];
-      const int axc = lo < Fin ? lo : 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t mr = m0 + tc_row(r, hi);
-        const int64_t m = mr < g.M ? mr : g.M - 1;
-        gg[r] = dHg[m * g.lddhn + lo];
-        zz[r] = ZRg[m * 64 + lo];
-        rr[r] = ZRg[m * 64 + 32 + lo];
-        ht[r] = HTg[m * 32 + lo];
-        h[r] = Hg[m * g.ldh + lo];
-        ax[r] = AXg[m * g.ldax + axc];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = tc_row(r, hi);
-        const bool ok = m0 + row < g.M;
-        const float g1 = ok ? gg[r] : 0.f;                                 // rows past the end contribute nothing
-        Dh[lo * TC_LD + row] = g1 * (1.f - zz[r]) * (1.f - ht[r] * ht[r]);  // d_pre_h
-        Dz[lo * TC_LD + row] = g1 * (h[r] - ht[r]) * zz[r] * (1.f - zz[r]); // d_pre_z
-        gz[r] = g1 * zz[r];
-        Xs[(32 + lo) * TC_LD + row] = ok ? h[r] : 0.f;
-        if (lo < Fin) Xs[lo * TC_LD + row] = ok ? ax[r] : 0.f;
-        if (lo == Fin) Xs[Fin * TC_LD + row] = ok ? 1.f : 0.f;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = tc_row(r, hi);
+      const bool ok = m0 + row < g.M;
+      const float g1 = ok ? ggn[r] : 0.f;                                  // rows past the end contribute nothing
+      const float z1 = zzn[r], t1 = htn[r];
+      rr[r] = rrn[r];
+      h[r] = hn[r];
+      Dh[lo * TC_LD + row] = g1 * (1.f - z1) * (1.f - t1 * t1);              // d_pre_h
+      Dz[lo * TC_LD + row] = g1 * (h[r] - t1) * z1 * (1.f - z1);             // d_pre_z
+      gz[r] = g1 * z1;
+      Xs[(32 + lo) * TC_LD + row] = ok ? h[r] : 0.f;
+      if (lo < Fin) Xs[lo * TC_LD + row] = ok ? axn[r] : 0.f;
+      if (lo == Fin) Xs[Fin * TC_LD + row] = ok ? 1.f : 0.f;
     }
+    if (tile + (int)gridDim.x < g.tiles) fetch(tile + gridDim.x);
     PGT_WAVE_SYNC();
     pgt_f32x16 p;
 #pragma unroll

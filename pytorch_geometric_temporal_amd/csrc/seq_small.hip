@@ -32,6 +32,7 @@ struct SeqArgs {
   // backward only
   const float* dOut; int64_t g_sb, g_st;
   float* dX; float* dH0; float* dWpart;     // dX [B, T, N, Fin] (x strides) | null; dH0 [B, N, O] | null; dWpart [B][S C 3 O + 3 O]
+  int w_lds;                                // the two stacked weights are parked in LDS for the whole launch (they fit)
 };
 
 __device__ __forceinline__ float sq_as_float(int v) { union { int i; float f; } u; u.i = v; return u.f; }
@@ -46,12 +47,14 @@ struct SqLds {
   float* HT;      // [N][O]   (backward)
   float* dH;      // [N][O]   running state gradient (backward)
   float* dP;      // [N][3 O] pre-activation gradients: zr | h (backward)
+  const float* Wzr; const float* Wh;        // the weights as the kernel reads them: LDS copies, or the global arrays
 };
 
-static size_t sq_lds_bytes(int64_t N, int64_t E_o, int64_t E_i, int64_t C, int64_t O, int64_t K, bool bwd) {
+static size_t sq_lds_bytes(int64_t N, int64_t E_o, int64_t E_i, int64_t C, int64_t O, int64_t K, bool bwd, bool w_lds = false) {
   const int64_t S = 2 * K - 1;
   size_t b = 2 * (size_t)(N + 1) * 4 + (size_t)(E_o + E_i) * 8 + (size_t)S * N * C * 4 + (size_t)N * O * 4 + (size_t)N * 2 * O * 4;
   if (bwd) b += (size_t)S * N * C * 4 + (size_t)N * O * 4 * 2 + (size_t)N * 3 * O * 4;
+  if (w_lds) b += (size_t)S * C * 3 * O * 4;
   return b + 64;
 }
 
@@ -72,7 +75,17 @@ __device__ __forceinline__ SqLds sq_carve(char* base, const SeqArgs& a, bool bwd
     s.TV = reinterpret_cast<float*>(p); p += (size_t)S * a.N * C * 4;
     s.HT = reinterpret_cast<float*>(p); p += (size_t)a.N * a.O * 4;
     s.dH = reinterpret_cast<float*>(p); p += (size_t)a.N * a.O * 4;
-    s.dP = reinterpret_cast<float*>(p);
+    s.dP = reinterpret_cast<float*>(p); p += (size_t)a.N * 3 * a.O * 4;
+  }
+  s.Wzr = a.Wzr; s.Wh = a.Wh;
+  if (a.w_lds) {
+    // (a product entry is S C multiply-adds against a column of W: read from global memory every element is its own dependent
+    // round trip — 280 us per Chickenpox snapshot in the first version; out of LDS the products run at LDS rate)
+    float* wz = reinterpret_cast<float*>(p); p += (size_t)S * C * 2 * a.O * 4;
+    float* wh = reinterpret_cast<float*>(p);
+    for (int i = threadIdx.x; i < S * C * 2 * a.O; i += SQ_THREADS) wz[i] = a.Wzr[i];
+    for (int i = threadIdx.x; i < S * C * a.O; i += SQ_THREADS) wh[i] = a.Wh[i];
+    s.Wzr = wz; s.Wh = wh;
   }
   return s;
 }
@@ -86,8 +99,19 @@ __device__ __forceinline__ void sq_stage_csr(const SeqArgs& a, const SqLds& s, i
 // sum over the slots of row n of one operator, sequential fma chain in slot order (as the general path's kernels)
 __device__ __forceinline__ float sq_row(const int* rp, const int2* cv, const float* src, int n, int c, int C) {
   float acc = 0.f;
+  int q = rp[n];
   const int e = rp[n + 1];
-  for (int q = rp[n]; q < e; ++q) {
+  for (; q + 4 <= e; q += 4) {                        // four slots' LDS reads in flight; the sum stays in slot order
+    int2 s4[4];
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] = cv[q + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = src[s4[u].x * C + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fmaf(sq_as_float(s4[u].y), x[u], acc);
+  }
+  for (; q < e; ++q) {
     const int2 s = cv[q];
     acc = fmaf(sq_as_float(s.y), src[s.x * C + c], acc);
   }
@@ -115,6 +139,7 @@ __device__ __forceinline__ float sq_dot(const SeqArgs& a, const float* TS, const
   for (int sg = 0; sg < S; ++sg) {
     const float* t = TS + (size_t)sg * NC + n * C;
     const float* w = W + (size_t)sg * C * ldw + j;
+#pragma unroll 4
     for (int c = 0; c < C; ++c) acc = fmaf(t[c], w[(size_t)c * ldw], acc);
   }
   return acc;
@@ -126,7 +151,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
   const int C = a.Fin + a.O, O = a.O, S = 2 * a.K - 1, NC = a.N * C, NO = a.N * O;
-  const SqLds s = sq_carve(smem, a, false);
+  SqLds s = sq_carve(smem, a, false);
   sq_stage_csr(a, s, tid);
   const int64_t per_step = (int64_t)2 * S * NC + 3 * NO;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -143,7 +168,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
       sq_hops(a, s, tid);
       for (int e = tid; e < 2 * NO; e += SQ_THREADS) {       // Z | R = sigmoid(stack Wzr + bzr)
         const int n = e / (2 * O), j = e - n * 2 * O;
-        const float v = pgt_sigmoidf(sq_dot(a, s.TS, a.Wzr, 2 * O, n, j) + (a.bzr ? a.bzr[j] : 0.f));
+        const float v = pgt_sigmoidf(sq_dot(a, s.TS, s.Wzr, 2 * O, n, j) + (a.bzr ? a.bzr[j] : 0.f));
         s.ZR[e] = v;
         if (sv) sv[(int64_t)2 * S * NC + e] = v;
       }
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
       float* o_t = a.out + b * a.o_sb + t * a.o_st;
       for (int e = tid; e < NO; e += SQ_THREADS) {           // candidate, blend, H_t
         const int n = e / O, o = e - n * O;
-        const float ht = tanhf(sq_dot(a, s.TS, a.Wh, O, n, o) + (a.bh ? a.bh[o] : 0.f));
+        const float ht = tanhf(sq_dot(a, s.TS, s.Wh, O, n, o) + (a.bh ? a.bh[o] : 0.f));
         const float hn = pgt_gru_blend(s.ZR[n * 2 * O + o], s.H[e], ht);
         if (sv) sv[(int64_t)2 * S * NC + 2 * NO + e] = ht;
         o_t[e] = hn;
@@ -202,6 +227,7 @@ __device__ __forceinline__ void sq_product_adjoint(const SeqArgs& a, const SqLds
     const int sc = e / ldw, j = e - sc * ldw, sg = sc / C, c = sc - sg * C;
     const float* tv = s.TV + (size_t)sg * NC + c;
     float acc = 0.f;
+#pragma unroll 4
     for (int n = 0; n < a.N; ++n) acc = fmaf(tv[n * C], s.dP[n * 3 * O + j0 + j], acc);
     dW[e] += acc;
   }
@@ -215,6 +241,7 @@ __device__ __forceinline__ void sq_product_adjoint(const SeqArgs& a, const SqLds
     const float* w = W + ((size_t)sg * C + c) * ldw;
     const float* g = s.dP + n * 3 * O + j0;
     float acc = 0.f;
+#pragma unroll 4
     for (int j = 0; j < ldw; ++j) acc = fmaf(g[j], w[j], acc);
     s.TS[e] = acc;
   }
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
   const int C = a.Fin + a.O, O = a.O, S = 2 * a.K - 1, NC = a.N * C, NO = a.N * O;
-  const SqLds s = sq_carve(smem, a, true);
+  SqLds s = sq_carve(smem, a, true);
   sq_stage_csr(a, s, tid);                                   // (the caller passes the transposed operators)
   const int64_t per_step = (int64_t)2 * S * NC + 3 * NO;
   const int64_t nW = (int64_t)S * C * 3 * O + 3 * O;
@@ -254,7 +281,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
       }
       for (int e = tid; e < S * NC; e += SQ_THREADS) s.TV[e] = sv[(int64_t)S * NC + e];
       __syncthreads();
-      sq_product_adjoint(a, s, a.Wh, O, 2 * O, dWh, dbh, tid);
+      sq_product_adjoint(a, s, s.Wh, O, 2 * O, dWh, dbh, tid);
       __syncthreads();
       sq_hops_adjoint(a, s, s.TS, tid);
       // ---- d(H R): the reset gate's pre-activation, the state; the input columns of this stack's d/dT0
@@ -268,7 +295,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
       if (dx) for (int e = tid; e < a.N * a.Fin; e += SQ_THREADS) { const int n = e / a.Fin, f = e - n * a.Fin; dx[e] = s.TS[n * C + f]; }
       for (int e = tid; e < S * NC; e += SQ_THREADS) s.TV[e] = sv[e];
       __syncthreads();
-      sq_product_adjoint(a, s, a.Wzr, 2 * O, 0, dWzr, dbzr, tid);
+      sq_product_adjoint(a, s, s.Wzr, 2 * O, 0, dWzr, dbzr, tid);
       __syncthreads();
       sq_hops_adjoint(a, s, s.TS, tid);
       for (int e = tid; e < NO; e += SQ_THREADS) { const int n = e / O, o = e - n * O; s.dH[e] += s.TS[n * C + a.Fin + o]; }
@@ -318,7 +345,8 @@ extern "C" int pgt_dcrnn_seq_small_f32(const pgt_csr* op_o, const pgt_csr* op_i,
   a.X = X; a.x_sb = x_stride_b; a.x_st = x_stride_t; a.H0 = H0; a.Wzr = Wzr; a.bzr = bzr; a.Wh = Wh; a.bh = bh;
   a.out = out; a.o_sb = out_stride_b; a.o_st = out_stride_t; a.save = save;
   const int64_t wgs = B < 2048 ? B : 2048;
-  const size_t need = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, false);
+  a.w_lds = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, false, true) <= (size_t)SQ_LDS ? 1 : 0;
+  const size_t need = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, false, a.w_lds != 0);
   if (need <= 38 * 1024) PGT_LAUNCH((dcrnn_seq_small_fwd_kernel<38 * 1024>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
   else if (need <= 78 * 1024) PGT_LAUNCH((dcrnn_seq_small_fwd_kernel<78 * 1024>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
   else PGT_LAUNCH((dcrnn_seq_small_fwd_kernel<SQ_LDS>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
@@ -339,7 +367,8 @@ extern "C" int pgt_dcrnn_seq_small_bwd_f32(const pgt_csr* tp_o, const pgt_csr* t
   a.H0 = H0; a.save = const_cast<float*>(save); a.Wzr = Wzr; a.Wh = Wh;
   a.dX = dX; a.x_sb = x_stride_b; a.x_st = x_stride_t; a.dH0 = dH0; a.dWpart = dWpart;
   const int64_t wgs = B < 2048 ? B : 2048;
-  const size_t need = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, true);
+  a.w_lds = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, true, true) <= (size_t)SQ_LDS ? 1 : 0;
+  const size_t need = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, true, a.w_lds != 0);
   if (need <= 38 * 1024) PGT_LAUNCH((dcrnn_seq_small_bwd_kernel<38 * 1024>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
   else if (need <= 78 * 1024) PGT_LAUNCH((dcrnn_seq_small_bwd_kernel<78 * 1024>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);
   else PGT_LAUNCH((dcrnn_seq_small_bwd_kernel<SQ_LDS>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);

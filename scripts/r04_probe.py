@@ -31,7 +31,7 @@ def tgcn_cell(dev):
     ei_np, ew_np = syn.local_graph(50_000, 8, seed=0)
     ei, ew = torch.from_numpy(ei_np).to(dev), torch.from_numpy(ew_np).to(dev)
     for B in (8, 32):
-        for fused in (True, False):
+        for fused in (True,):
             ops.USE_TGCN_FUSED = fused
             torch.manual_seed(0)
             m = TGCN2(2, 32, B).to(dev)
@@ -59,7 +59,7 @@ def small_batch(dev):
     series = torch.from_numpy(syn.traffic_series(4000, 207, seed=1)).to(dev)
     ar = torch.arange(12, device=dev)
     for hidden in (2, 8):
-        for small in (True, False):
+        for small in (True,):
             ops.USE_SEQ_SMALL = small
             torch.manual_seed(0)
             model = bench.Model(hidden).to(dev) if hidden == 2 else bench.Model(hidden).to(dev)
@@ -85,10 +85,20 @@ def small_batch(dev):
     ops.USE_SEQ_SMALL = True
 
 
+def chickenpox(dev):
+    import bench_configs as BC
+    for K in (1, 2, 3):
+        r = BC.chickenpox_epoch(dev, 8, K=K)
+        print(json.dumps({"chickenpox": {"K": K, "eager_ms": r["gpu_eager_ms_per_epoch"], "graphed_ms": r["gpu_graphed_ms_per_epoch"],
+                                          "cpu_ms": r["cpu_oracle_ms_per_epoch"]}}), flush=True)
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
-    which = sys.argv[1:] or ["tgcn_cell", "small_batch"]
+    which = sys.argv[1:] or ["tgcn_cell", "small_batch", "chickenpox"]
     if "tgcn_cell" in which:
         tgcn_cell(dev)
     if "small_batch" in which:
         small_batch(dev)
+    if "chickenpox" in which:
+        chickenpox(dev)

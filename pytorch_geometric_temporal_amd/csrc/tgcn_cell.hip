@@ -31,6 +31,25 @@ struct TcArgs {
   const float* dHn; int64_t lddhn; float* dH; int64_t lddh; float* part; int n_wg;
 };
 
+// sigmoid / tanh on the hardware exp / reciprocal (<= 3e-7 from the library functions; tanh by its odd series below |x| = 0.04,
+// where 1 - 2 / (1 + e^2x) loses relative accuracy) — the same forms as the fused gate epilogues of csrc/gemm_bx.hip.  The library
+// expf + IEEE division + tanhf are ~80 VALU instructions per element: 48 elements per lane and strip cost more issue cycles than
+// the strip's 51 MFMAs.
+#ifdef PGT_EMU
+__device__ __forceinline__ float tc_rcp(float x) { return 1.f / x; }
+__device__ __forceinline__ float tc_exp(float x) { return expf(x); }
+#else
+__device__ __forceinline__ float tc_rcp(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float tc_exp(float x) { return __expf(x); }
+#endif
+__device__ __forceinline__ float tc_sigmoidf(float x) { return tc_rcp(1.f + tc_exp(-x)); }
+__device__ __forceinline__ float tc_tanhf(float x) {
+  const float x2 = x * x;
+  const float small = x * fmaf(x2, fmaf(x2, 0.13333334f, -0.33333334f), 1.f);
+  const float big = 1.f - 2.f * tc_rcp(1.f + tc_exp(2.f * x));
+  return fabsf(x) < 0.04f ? small : big;
+}
+
 // accumulator (D) layout of v_mfma_f32_32x32x2_f32: register r of a lane = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
 __device__ __forceinline__ int tc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -94,8 +113,8 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
-      z[r] = pgt_sigmoidf(az[r] + b_z);
-      const float rr = pgt_sigmoidf(ar[r] + b_r);
+      z[r] = tc_sigmoidf(az[r] + b_z);
+      const float rr = tc_sigmoidf(ar[r] + b_r);
       As[(g.Fin + lo) * TC_LD + row] = h[r] * rr;                       // [AX | H * R]: this lane parked (row, lo) itself
       if (full || m0 + row < g.M) {
         float* zr = ZRg + (m0 + row) * 64;
@@ -109,7 +128,7 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
       if (full || m0 + row < g.M) {
-        const float ht = tanhf(ah[r] + b_h);
+        const float ht = tc_tanhf(ah[r] + b_h);
         HTg[(m0 + row) * 32 + lo] = ht;
         Hng[(m0 + row) * g.ldhn + lo] = pgt_gru_blend(z[r], h[r], ht);
       }

@@ -127,3 +127,51 @@ def test_graphed_step_with_a_torch_linear_readout_on_the_states():
     graphed = GraphedStep(step_g, pair, warmup=2)
     flat_g.data.copy_(snapshot)
     assert float(graphed(*pair)) == pytest.approx(eager, rel=1e-5, abs=1e-6)
+
+
+@pytest.mark.gpu
+def test_graphed_dynamic_graph_epoch_takes_new_edge_lists_as_inputs():
+    """BASELINE configs[4]'s loop (EvolveGCN-H over snapshots whose edge list changes every step, weight carried from snapshot to
+    snapshot) captured ONCE with the edge tensors as graph inputs: the one-workgroup GCN layer builds its lists from the RAW
+    edge list inside the kernel (csrc/small_gcn.hip), so a replay on NEW edge lists of the same sizes — copied into the captured
+    buffers — is the eager computation on those lists: losses and every gradient."""
+    from pytorch_geometric_temporal_amd.graphed import GraphedStep
+    from pytorch_geometric_temporal_amd.nn.recurrent import EvolveGCNH
+    dev = torch.device("cuda:0")
+    n, Fdim, S = 40, 8, 6
+    sizes = [150 + 17 * s for s in range(S)]
+
+    def graphs(seed):
+        out = []
+        for s, E in enumerate(sizes):
+            ei_np, ew_np = syn.sensor_graph(n, E, seed=seed * 100 + s, symmetric=False)
+            out += [torch.from_numpy(ei_np).to(dev), torch.from_numpy(ew_np).to(dev)]
+        return out
+
+    torch.manual_seed(0)
+    model = EvolveGCNH(n, Fdim).to(dev)
+    head = torch.nn.Linear(Fdim, 1).to(dev)
+    params = list(model.parameters()) + list(head.parameters())
+    flat = dp.FlatGradients(params)
+    Xs = [torch.randn(n, Fdim, device=dev) for _ in range(S)]
+    ys = [torch.randn(n, device=dev) for _ in range(S)]
+
+    def epoch(*edges):
+        model.reinitialize_weight()
+        cost = 0
+        for s in range(S):
+            cost = cost + torch.mean((head(torch.relu(model(Xs[s], edges[2 * s], edges[2 * s + 1]))).view(-1) - ys[s]) ** 2)
+        flat.zero()
+        cost.backward()
+        return cost
+
+    first = graphs(1)
+    graphed = GraphedStep(epoch, first, warmup=2)
+    for seed in (1, 2, 3):                                   # seed 1 = the captured lists, 2 and 3 = new graphs of the same sizes
+        g = graphs(seed)
+        lg = float(graphed(*g))
+        gg = flat.flat.clone()
+        le = float(epoch(*g))
+        assert lg == pytest.approx(le, rel=1e-5, abs=1e-6), seed
+        torch.testing.assert_close(gg, flat.flat, rtol=1e-4, atol=1e-6)
+    assert float(graphed(*graphs(2))) != pytest.approx(float(graphed(*graphs(3))), rel=1e-3)      # the edge lists really are inputs

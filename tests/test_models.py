@@ -258,19 +258,51 @@ def test_evolvegcn_sequence_matches_reference_fixture(backend, which):
         assert_close_with_nonfinite(m(X, ei, ew), g["out"]["out0"], 2e-5, 2e-5, "after reinitialize_weight")
 
 
-def test_evolvegcn_backward_through_the_weight_recurrence(backend):
+@pytest.mark.parametrize("which", ["o", "h"])
+def test_evolvegcn_backward_through_the_weight_recurrence(backend, which):
+    """The weight recurrence across FOUR snapshots with four different edge lists (evolvegcno.py:185-191 / evolvegcnh.py:93-102: W_t
+    depends on W_{t-1}, so the gradient of a later snapshot's output reaches every earlier GRU application): every parameter
+    gradient against autograd through the reference's OWN module file (fp64 copy) when /root/reference is present, against the
+    fp64 oracle's step otherwise for EvolveGCN-H."""
+    from oracle import ref_import as R
     torch.manual_seed(1)
     n, Fdim = 15, 4
-    m = EvolveGCNO(Fdim).to(backend.device)
+    graphs = [syn.sensor_graph(n, 60 + 7 * s, seed=s, symmetric=False) for s in range(4)]
+    Xs = [torch.randn(n, Fdim) for _ in range(4)]
+    ws = [torch.randn(n, Fdim) for _ in range(4)]
+    m = (EvolveGCNO(Fdim) if which == "o" else EvolveGCNH(n, Fdim))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.5, 0.5)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(backend.device)
     loss = 0
-    for s in range(3):
-        ei_np, ew_np = syn.sensor_graph(n, 60 + 5 * s, seed=s, symmetric=False)
-        X = backend.t(torch.randn(n, Fdim))
-        loss = loss + m(X, backend.t(ei_np), backend.t(ew_np)).square().sum()
+    for (ei_np, ew_np), X, w in zip(graphs, Xs, ws):
+        loss = loss + (m(backend.t(X), backend.t(ei_np), backend.t(ew_np)) * backend.t(w)).sum()
     loss.backward()
-    assert m.initial_weight.grad is not None and float(m.initial_weight.grad.abs().sum()) > 0
-    for name, p in m.recurrent_layer.named_parameters():
-        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert float(m.initial_weight.grad.abs().sum()) > 0
+    if not R.reference_available():
+        for name, p in m.recurrent_layer.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        return
+    mod = R.load("nn.recurrent.evolvegcno" if which == "o" else "nn.recurrent.evolvegcnh")
+    ref = (mod.EvolveGCNO(Fdim) if which == "o" else mod.EvolveGCNH(n, Fdim))
+    ref.load_state_dict(state, strict=True)
+    ref = ref.double()
+    if hasattr(ref, "reinitialize_weight"):
+        ref.reinitialize_weight()
+    else:
+        ref.weight = None
+    loss_r = 0
+    for (ei_np, ew_np), X, w in zip(graphs, Xs, ws):
+        out = ref(X.double(), torch.from_numpy(ei_np), torch.from_numpy(ew_np).double())
+        loss_r = loss_r + (out * w.double()).sum()
+    loss_r.backward()
+    refp = dict(ref.named_parameters())
+    for name, p in m.named_parameters():
+        g = refp[name].grad
+        assert p.grad is not None, name
+        assert_close_with_nonfinite(p.grad, g, 1e-4 * float(g.abs().max()) + 1e-7, 1e-4, name)
 
 
 def test_evolvegcn_without_normalisation_propagates_the_raw_edge_list(backend):

@@ -53,12 +53,16 @@ __device__ __forceinline__ float tc_tanhf(float x) {
 // accumulator (D) layout of v_mfma_f32_32x32x2_f32: register r of a lane = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
 __device__ __forceinline__ int tc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// KF: the padded contraction length Fin + 32 (+ 1) when known at compile time (34: one or two input columns — TGCN2(2, 32) — so the
+// product loops unroll completely and the LDS operand reads run ahead of the MFMAs instead of one read-wait-MFMA round per
+// k-step), 0 = run time
+template <int KF>
 __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
   // per wavefront: A strip [K2][33]; shared: Wzr [K2][65], Wh [K2][33]
   __shared__ float s_w[64 * 65 + 64 * 33];
   __shared__ float s_a[4][64 * TC_LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
-  const int C = g.Fin + TC_O, K2 = (C + 1) & ~1;
+  const int C = g.Fin + TC_O, K2 = KF > 0 ? KF : ((C + 1) & ~1);
   float* wzr = s_w;                   // [K2][65]
   float* wh = s_w + 64 * 65;          // [K2][33]
   for (int e = tid; e < K2 * 64; e += 256) { const int k = e >> 6, j = e & 63; wzr[k * 65 + j] = k < C ? g.Wzr[(int64_t)k * 64 + j] : 0.f; }
@@ -67,6 +71,17 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
   if (K2 > C) for (int i = lane; i < TC_LD; i += 64) As[C * TC_LD + i] = 0.f;      // the padding k-row stays zero
   __syncthreads();
   const float b_z = g.bzr ? g.bzr[lo] : 0.f, b_r = g.bzr ? g.bzr[32 + lo] : 0.f, b_h = g.bh ? g.bh[lo] : 0.f;
+  // KF > 0: the B operands of this lane (its column of the three weight blocks, k = kk + hi) live in REGISTERS for the whole launch
+  constexpr int KS = KF > 0 ? KF / 2 : 1;
+  float wbz[KS], wbr[KS], wbh[KS];
+  if constexpr (KF > 0) {
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      wbz[i] = wzr[(2 * i + hi) * 65 + lo];
+      wbr[i] = wzr[(2 * i + hi) * 65 + 32 + lo];
+      wbh[i] = wh[(2 * i + hi) * 33 + lo];
+    }
+  }
   const float* __restrict__ Hg = g.H;
   const float* __restrict__ AXg = g.AX;
   float* __restrict__ ZRg = g.ZR;
@@ -102,10 +117,22 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
     pgt_f32x16 az, ar, ah;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { az[r] = 0.f; ar[r] = 0.f; ah[r] = 0.f; }
-    for (int kk = 0; kk < K2; kk += 2) {
-      const float a = As[(kk + hi) * TC_LD + lo];
-      az = PGT_MFMA_32x32x2(a, wzr[(kk + hi) * 65 + lo], az);
-      ar = PGT_MFMA_32x32x2(a, wzr[(kk + hi) * 65 + 32 + lo], ar);
+    if constexpr (KF > 0) {
+      float aop[KS];                                       // every A operand of the product is requested before the first MFMA
+#pragma unroll
+      for (int i = 0; i < KS; ++i) aop[i] = As[(2 * i + hi) * TC_LD + lo];
+      PGT_SCHED_FENCE();                                   // (the scheduler otherwise sinks every read back next to its MFMA)
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        az = PGT_MFMA_32x32x2(aop[i], wbz[i], az);
+        ar = PGT_MFMA_32x32x2(aop[i], wbr[i], ar);
+      }
+    } else {
+      for (int kk = 0; kk < K2; kk += 2) {
+        const float a = As[(kk + hi) * TC_LD + lo];
+        az = PGT_MFMA_32x32x2(a, wzr[(kk + hi) * 65 + lo], az);
+        ar = PGT_MFMA_32x32x2(a, wzr[(kk + hi) * 65 + 32 + lo], ar);
+      }
     }
     PGT_WAVE_SYNC();
     float z[16];
@@ -123,7 +150,16 @@ __global__ __launch_bounds__(256) void tgcn_cell_fwd_kernel(TcArgs g) {
       }
     }
     PGT_WAVE_SYNC();
-    for (int kk = 0; kk < K2; kk += 2) ah = PGT_MFMA_32x32x2(As[(kk + hi) * TC_LD + lo], wh[(kk + hi) * 33 + lo], ah);
+    if constexpr (KF > 0) {
+      float aop[KS];
+#pragma unroll
+      for (int i = 0; i < KS; ++i) aop[i] = As[(2 * i + hi) * TC_LD + lo];
+      PGT_SCHED_FENCE();
+#pragma unroll
+      for (int i = 0; i < KS; ++i) ah = PGT_MFMA_32x32x2(aop[i], wbh[i], ah);
+    } else {
+      for (int kk = 0; kk < K2; kk += 2) ah = PGT_MFMA_32x32x2(As[(kk + hi) * TC_LD + lo], wh[(kk + hi) * 33 + lo], ah);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
@@ -157,6 +193,12 @@ __global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
   float* Xs = Dh + 32 * TC_LD;
   for (int e = lane; e < 32 * TC_LD; e += 64) Xs[e] = (e / TC_LD == Fin) ? 1.f : 0.f;   // ones row, zero padding (AX rows are rewritten per tile)
   __syncthreads();
+  // this lane's B operands of the two "d_pre x W^T" products, in registers for the whole launch
+  float wbh[16], wbz[32];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wbh[i] = whT[(2 * i + hi) * 33 + lo];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) wbz[i] = wzrT[(2 * i + hi) * 33 + lo];
   const float* __restrict__ dHg = g.dHn;
   const float* __restrict__ ZRg = g.ZR;
   const float* __restrict__ HTg = g.HT;
@@ -205,7 +247,14 @@ __global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
     pgt_f32x16 p;
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = 0.f;
-    for (int kk = 0; kk < 32; kk += 2) p = PGT_MFMA_32x32x2(Dh[(kk + hi) * TC_LD + lo], whT[(kk + hi) * 33 + lo], p);   // d(H R)
+    {
+      float aop[16];                                       // operands requested before the first MFMA (no read-wait-MFMA rounds)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) aop[i] = Dh[(2 * i + hi) * TC_LD + lo];
+      PGT_SCHED_FENCE();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p = PGT_MFMA_32x32x2(aop[i], wbh[i], p);                          // d(H R)
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
@@ -215,29 +264,55 @@ __global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
     PGT_WAVE_SYNC();
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = 0.f;
-    for (int kk = 0; kk < 64; kk += 2) p = PGT_MFMA_32x32x2(Dz[(kk + hi) * TC_LD + lo], wzrT[(kk + hi) * 33 + lo], p);  // d_pre_zr Wzr_H^T
+    {
+      float aop[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) aop[i] = Dz[(2 * i + hi) * TC_LD + lo];
+      PGT_SCHED_FENCE();
+#pragma unroll
+      for (int i = 0; i < 32; ++i) p = PGT_MFMA_32x32x2(aop[i], wbz[i], p);                          // d_pre_zr Wzr_H^T
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = tc_row(r, hi);
       if (m0 + row < g.M) g.dH[(m0 + row) * g.lddh + lo] = gz[r] + p[r];
     }
     // weight gradients: D[i][j] += sum_m Xs[i][m] d[m][j]  (A operand = Xs rows, k = the tile's rows; B operand = d, stored [j][m])
-    for (int kk = 0; kk < 32; kk += 2) {
-      const float a0 = Xs[lo * TC_LD + kk + hi], a1 = Xs[(32 + lo) * TC_LD + kk + hi];
-      const float bz = Dz[lo * TC_LD + kk + hi], br = Dz[(32 + lo) * TC_LD + kk + hi];
-      wz0a = PGT_MFMA_32x32x2(a0, bz, wz0a);
-      wz0b = PGT_MFMA_32x32x2(a0, br, wz0b);
-      wz1a = PGT_MFMA_32x32x2(a1, bz, wz1a);
-      wz1b = PGT_MFMA_32x32x2(a1, br, wz1b);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                 // eight k-steps' operands at a time ahead of their 32 MFMAs
+      float a0[8], a1[8], bz[8], br[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = 16 * half + 2 * i + hi;
+        a0[i] = Xs[lo * TC_LD + kk]; a1[i] = Xs[(32 + lo) * TC_LD + kk];
+        bz[i] = Dz[lo * TC_LD + kk]; br[i] = Dz[(32 + lo) * TC_LD + kk];
+      }
+      PGT_SCHED_FENCE();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        wz0a = PGT_MFMA_32x32x2(a0[i], bz[i], wz0a);
+        wz0b = PGT_MFMA_32x32x2(a0[i], br[i], wz0b);
+        wz1a = PGT_MFMA_32x32x2(a1[i], bz[i], wz1a);
+        wz1b = PGT_MFMA_32x32x2(a1[i], br[i], wz1b);
+      }
     }
     PGT_WAVE_SYNC();
 #pragma unroll
     for (int r = 0; r < 16; ++r) Xs[(32 + lo) * TC_LD + tc_row(r, hi)] *= rr[r];       // H -> H * R (rows past the end are zero)
     PGT_WAVE_SYNC();
-    for (int kk = 0; kk < 32; kk += 2) {
-      const float b = Dh[lo * TC_LD + kk + hi];
-      wh0 = PGT_MFMA_32x32x2(Xs[lo * TC_LD + kk + hi], b, wh0);
-      wh1 = PGT_MFMA_32x32x2(Xs[(32 + lo) * TC_LD + kk + hi], b, wh1);
+    {
+      float a0[16], a1[16], b[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = 2 * i + hi;
+        a0[i] = Xs[lo * TC_LD + kk]; a1[i] = Xs[(32 + lo) * TC_LD + kk]; b[i] = Dh[lo * TC_LD + kk];
+      }
+      PGT_SCHED_FENCE();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        wh0 = PGT_MFMA_32x32x2(a0[i], b[i], wh0);
+        wh1 = PGT_MFMA_32x32x2(a1[i], b[i], wh1);
+      }
     }
     PGT_WAVE_SYNC();
   }
@@ -317,7 +392,8 @@ extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, 
   g.AX = AX; g.ldax = ldax; g.H = H; g.ldh = ldh; g.Wzr = Wzr; g.bzr = bzr; g.Wh = Wh; g.bh = bh;
   g.ZR = ZR; g.HT = HT; g.Hn = Hn; g.ldhn = ldhn; g.M = (int)M; g.Fin = (int)Fin; g.tiles = (int)pgt_cdiv(M, 128);
   int64_t wgs = g.tiles < 4 * TC_WGS ? g.tiles : 4 * TC_WGS;
-  PGT_LAUNCH(tgcn_cell_fwd_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
+  if (Fin <= 2) PGT_LAUNCH((tgcn_cell_fwd_kernel<34>), dim3((unsigned)wgs), dim3(256), stream, g);
+  else PGT_LAUNCH((tgcn_cell_fwd_kernel<0>), dim3((unsigned)wgs), dim3(256), stream, g);
   return pgt_check_launch("pgt_tgcn_cell_f32");
 }
 

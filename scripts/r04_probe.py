@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_geometric_temporal_amd import dp, ops  # noqa: E402
 from pytorch_geometric_temporal_amd.dataset import synthetic as syn  # noqa: E402
 from pytorch_geometric_temporal_amd.graphed import GraphedStep  # noqa: E402

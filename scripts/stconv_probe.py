@@ -8,7 +8,7 @@ import time
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_geometric_temporal_amd.nn.attention import STConv, TemporalConv  # noqa: E402
 
 

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void tgcn_pack_kernel(TgcnParams p, int Fin, i
     const int c = (int)(e / (3 * O));
     if (c < Fin) {
       v = 0.f;
+#pragma unroll 8
       for (int j = 0; j < O; ++j) v = fmaf(p.Wc[gate][(int64_t)j * Fin + c], L[j], v);
     } else {
       v = L[O + (c - Fin)];
@@ -45,7 +46,10 @@ __global__ __launch_bounds__(256) void tgcn_pack_kernel(TgcnParams p, int Fin, i
     else Wh[(int64_t)c * O + o] = v;
   } else {
     v = p.lb[gate] ? p.lb[gate][o] : 0.f;
-    if (p.bc[gate]) for (int j = 0; j < O; ++j) v = fmaf(p.bc[gate][j], L[j], v);
+    if (p.bc[gate]) {
+#pragma unroll 8
+      for (int j = 0; j < O; ++j) v = fmaf(p.bc[gate][j], L[j], v);
+    }
     if (gate < 2) bzr[gate * O + o] = v;
     else bh[o] = v;
   }
@@ -67,12 +71,14 @@ __global__ __launch_bounds__(256) void tgcn_unpack_kernel(TgcnParams p, TgcnGrad
   if (r < nWc) {                                            // dWc[j, f] = sum_o dW'[f, o] L[o, j]
     const int j = (int)(r / Fin), f = (int)(r - (int64_t)j * Fin);
     float v = 0.f;
+#pragma unroll 8
     for (int o = 0; o < O; ++o) v = fmaf(dW(f, o), L[(int64_t)o * 2 * O + j], v);
     d.dWc[gate][r] = v;
   } else if (r < nWc + O) {                                 // dbc[j] = sum_o db'[o] L[o, j]
     const int j = (int)(r - nWc);
     if (d.dbc[gate]) {
       float v = 0.f;
+#pragma unroll 8
       for (int o = 0; o < O; ++o) v = fmaf(db(o), L[(int64_t)o * 2 * O + j], v);
       d.dbc[gate][j] = v;
     }

@@ -349,14 +349,32 @@ __global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
   }
 }
 
-// out[e] = sum over the workgroups' partials in index order
+// out[e] = sum over the workgroups' partials, in a FIXED order: a workgroup owns 64 elements, its four wavefronts each add a
+// contiguous quarter of the partials (eight loads in flight per lane), the quarters meet in LDS in index order.  (One thread per
+// element walking all 256 partials in turn was a 61 us launch - a third of the adjoint kernel it follows.)
 __global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __restrict__ part, int n_wg, int n, float* __restrict__ dWzr,
                                                                float* __restrict__ dbzr, float* __restrict__ dWh, float* __restrict__ dbh,
                                                                int C) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const int per = (n_wg + 3) / 4, w0 = q * per, w1 = (w0 + per < n_wg) ? w0 + per : n_wg;
   float acc = 0.f;
-  for (int w = 0; w < n_wg; ++w) acc += part[(int64_t)w * n + e];
+  if (e < n) {
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(w + u) * n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; w < w1; ++w) acc += part[(int64_t)w * n + e];
+  }
+  red[q][lane] = acc;
+  __syncthreads();
+  if (q != 0 || e >= n) return;
+  acc = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
   const int nWzr = C * 64, nWh = C * 32;
   if (e < nWzr) dWzr[e] = acc;
   else if (e < nWzr + 64) { if (dbzr) dbzr[e - nWzr] = acc; }
@@ -425,6 +443,6 @@ extern "C" int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const floa
   const int wgs = g.tiles < TC_WGS ? g.tiles : TC_WGS;
   g.n_wg = wgs;
   PGT_LAUNCH(tgcn_cell_bwd_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
-  PGT_LAUNCH(tgcn_cell_reduce_kernel, dim3((unsigned)pgt_cdiv(n, 256)), dim3(256), stream, ws, wgs, n, dWzr, dbzr, dWh, dbh, C);
+  PGT_LAUNCH(tgcn_cell_reduce_kernel, dim3((unsigned)pgt_cdiv(n, 64)), dim3(256), stream, ws, wgs, n, dWzr, dbzr, dWh, dbh, C);
   return pgt_check_launch("pgt_tgcn_cell_bwd_f32");
 }

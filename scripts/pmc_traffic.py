@@ -23,7 +23,18 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r04"
+
+
 def klass(name):
+    if "tgcn_cell_fwd" in name:
+        return "tgcn_cell_fwd"
+    if "tgcn_cell_bwd" in name:
+        return "tgcn_cell_bwd"
+    if "tconv_glu" in name:
+        return "tconv"
+    if "seq_small" in name:
+        return "seq_small"
     if "gemm_tn" in name or "gemm_bx_tn" in name:
         return "gemm_tn"
     if "gemm" in name:
@@ -60,8 +71,8 @@ def reduce(path, wanted):
     return acc, per_kernel
 
 
-fetch, fetch_k = reduce(newest(os.path.join(src, "r03_pmc_fetch", "**", "*counter_collection.csv")), {"FETCH_SIZE"})
-write, write_k = reduce(newest(os.path.join(src, "r03_pmc_write", "**", "*counter_collection.csv")), {"WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"})
+fetch, fetch_k = reduce(newest(os.path.join(src, TAG + "_pmc_fetch", "**", "*counter_collection.csv")), {"FETCH_SIZE"})
+write, write_k = reduce(newest(os.path.join(src, TAG + "_pmc_write", "**", "*counter_collection.csv")), {"WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"})
 out = {"command": sys.argv[1] if len(sys.argv) > 1 else "", "units": "bytes per launch; FETCH_SIZE (KB) x 2 x 1000, WRITE_SIZE (KB) x 1000",
        "kernels": {}, "per_kernel": {}}
 for store_f, store_w, dest in ((fetch, write, out["kernels"]), (fetch_k, write_k, out["per_kernel"])):
@@ -77,11 +88,11 @@ for store_f, store_w, dest in ((fetch, write, out["kernels"]), (fetch_k, write_k
                    "l2_hit_rate": (h[0] / (h[0] + m[0])) if (h[0] + m[0]) > 0 else None}
 os.makedirs(dst, exist_ok=True)
 for d in (dst, src):      # profiles/ when run in the build container; gpurun_out/prof travels back from the GPU box
-    with open(os.path.join(d, "r03_pmc_traffic.json"), "w") as fh:
+    with open(os.path.join(d, TAG + "_pmc_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
 print(json.dumps(out["kernels"], indent=1))
-st = newest(os.path.join(src, "r03_stats", "**", "*kernel_stats.csv"))
+st = newest(os.path.join(src, TAG + "_stats", "**", "*kernel_stats.csv"))
 if st:
-    shutil.copy(st, os.path.join(dst, "r03_bench_kernel_stats.csv"))
-    shutil.copy(st, os.path.join(src, "r03_bench_kernel_stats.csv"))
+    shutil.copy(st, os.path.join(dst, TAG + "_bench_kernel_stats.csv"))
+    shutil.copy(st, os.path.join(src, TAG + "_bench_kernel_stats.csv"))
     print("copied", st)

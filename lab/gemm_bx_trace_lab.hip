@@ -34,6 +34,7 @@ void pgt_slab_set_threads(int) {}
 void pgt_slab_set_wpc(int) {}
 void pgt_slab_set_quad(int) {}
 void pgt_slab_set_gu(int) {}
+void pgt_slab_set_sort(int) {}
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm_bx.hip"

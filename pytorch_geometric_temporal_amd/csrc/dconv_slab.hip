@@ -30,6 +30,7 @@ struct SlabArgs {
   float* TS;            // segment s of sample b starts at TS + s*seg_stride + b*N*C
   int64_t seg_stride;
   int folded;           // backward only: the "- Tx_0" adjoint was folded into the weights (ops.fold_backward_weight)
+  int sorted;           // quad kernels: rows handed out in descending order of their slot counts (pgt_tune("slab_sort"))
 };
 
 #ifdef PGT_EMU
@@ -647,7 +648,7 @@ __device__ __forceinline__ pgt_f4 gather_q(const int* __restrict__ rp, const int
 // floats of one LDS block: [N][64] hidden quads + (E > 0) one padded quad per row for the leading columns
 __host__ __device__ inline size_t slab_q_block_floats(int64_t N, int E) { return (size_t)N * 64 + (E > 0 ? (size_t)N * 4 : 0); }
 static size_t slab_q_lds_bytes(int64_t N, int E, int64_t nnz_o, int64_t nnz_i) {
-  return 2 * slab_q_block_floats(N, E) * 4 + 2 * (size_t)(N + 1) * 4 + 2 * (size_t)(nnz_o + nnz_i) * 4;
+  return 2 * slab_q_block_floats(N, E) * 4 + 2 * (size_t)(N + 1) * 4 + 2 * (size_t)(nnz_o + nnz_i) * 4 + 2 * (size_t)N * 4 + 16;
 }
 __device__ __forceinline__ SlabLds carve_q(char* base, const SlabArgs& a, int E) {
   SlabLds s;
@@ -667,12 +668,15 @@ template <int E, int MAXT, int THREADS = SLAB_THREADS>
 struct SlabQTasks {
   int rj[MAXT];     // main: (row << 5) | quad (0 .. 15);  leading pair of a row: (row << 5) | 16
   int N, C, ntask, tid;
-  __device__ __forceinline__ void init(const SlabArgs& a, int tid_) {
+  // `order` (LDS, may be null): position p -> row; the sixteen lanes of position p own row order[p]
+  __device__ __forceinline__ void init(const SlabArgs& a, int tid_, const int* order = nullptr) {
     N = a.N; C = a.C; tid = tid_; ntask = a.N * (16 + (E > 0 ? 1 : 0));
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int idx = tid + j * THREADS, ic = idx < ntask ? idx : ntask - 1;
-      rj[j] = ic < 16 * a.N ? (((ic >> 4) << 5) | (ic & 15)) : (((ic - 16 * a.N) << 5) | 16);
+      const int pos = ic < 16 * a.N ? (ic >> 4) : ic - 16 * a.N;
+      const int row = order ? order[pos] : pos;
+      rj[j] = ic < 16 * a.N ? ((row << 5) | (ic & 15)) : ((row << 5) | 16);
     }
   }
   __device__ __forceinline__ bool live(int j) const { return tid + j * THREADS < ntask; }
@@ -685,6 +689,28 @@ struct SlabQTasks {
   __device__ __forceinline__ int loff(int j) const { return qoff(j) + row(j) * pitch(j); }
 };
 
+// Rows by slot count.  A wavefront's four rows are gathered in lock step, so it runs as long as its LONGEST row (METR-LA: 7.3 slots
+// per row on average, up to 3x that): rows are handed to the lane groups in descending order of their two operators' slot counts —
+// position p of the order is the row with p longer-or-earlier rows — so a wavefront's four rows end together and every wavefront
+// gets rows from each quartile (its j-th task is 64 positions further down).  Which lane computes a row changes nothing in the
+// row's sum: bit-identical.  Computed once per workgroup from the staged rowptr arrays (N <= ~330: a rank by counting).
+__device__ __forceinline__ const int* slab_row_order(const SlabArgs& a, const SlabLds& s, int tid, bool enabled) {
+  if (!enabled) return nullptr;
+  int* keys = s.rp_i + (a.N + 1);
+  int* order = keys + a.N;
+  __syncthreads();                                            // rowptr arrays staged
+  for (int r = tid; r < a.N; r += SLAB_THREADS) keys[r] = (s.rp_o[r + 1] - s.rp_o[r]) + (s.rp_i[r + 1] - s.rp_i[r]);
+  __syncthreads();
+  for (int r = tid; r < a.N; r += SLAB_THREADS) {
+    const int kr = keys[r];
+    int rank = 0;
+    for (int q = 0; q < a.N; ++q) { const int kq = keys[q]; rank += (kq > kr) || (kq == kr && q < r); }
+    order[rank] = r;
+  }
+  __syncthreads();
+  return order;
+}
+
 // forward: segments [T0 | T1o T1i | T2o T2i]; K = 2 or 3 (see dconv_slab_fwd_kernel)
 template <int E, bool G4, int MAXT>
 __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_q_kernel(SlabArgs a) {
@@ -693,7 +719,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_fwd_q_kernel(SlabArgs
   const int tid = threadIdx.x;
   stage_csr(a, s, tid);
   SlabQTasks<E, MAXT> k;
-  k.init(a, tid);
+  k.init(a, tid, slab_row_order(a, s, tid, a.sorted != 0));
   pgt_f4 t0n[MAXT];
   if ((int)blockIdx.x < a.n_samples) {
     const float* nb = a.TS + (int64_t)blockIdx.x * a.N * a.C;
@@ -770,7 +796,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void dconv_slab_bwd_q_kernel(SlabArgs
   const int tid = threadIdx.x;
   stage_csr(a, s, tid);
   SlabQTasks<E, MAXT> k;
-  k.init(a, tid);
+  k.init(a, tid, slab_row_order(a, s, tid, a.sorted != 0));
   const int64_t lead = (a.K >= 3 ? 3 : 1) * a.seg_stride;
   pgt_f4 pa[MAXT], pb[MAXT];
   auto prefetch = [&](int bb) {
@@ -846,6 +872,7 @@ int g_slab_pairs = 2;   // pgt_tune("slab_pairs"): column pairs per lane of the 
 // the kernels above.  With the column windows (103 - 123 us) that is the second design whose point was a second resident
 // workgroup, and the second that lost: on this part the phases of co-resident workgroups do not interleave usefully for this
 // access pattern.)
+int g_slab_sort = 1;      // pgt_tune("slab_sort"): 1 = the quad kernels hand rows out by slot count (wavefronts' rows end together), 0 = in row order (A/B)
 int g_slab_gu = 2;        // pgt_tune("slab_gu"): LDS reads in flight per gather of the four-task backward quad kernels (2 | 4)
 int g_slab_quad = 1;      // pgt_tune("slab_quad"): 0 = C = 64 / 66 blocks on the pair-layout kernels (A/B)
 // the quad-layout kernels take C = 64 (16-byte aligned segments) or C = 66 (8-byte aligned), at most 4 tasks per thread
@@ -1286,7 +1313,7 @@ int slab_entry(bool bwd, const pgt_csr* o, const pgt_csr* i, int64_t nnz_o, int6
               (long long)N, (long long)C, (long long)K);
   PGT_REQUIRE(n_samples < ((int64_t)1 << 31) && n_samples * N * C < ((int64_t)1 << 40), "%s: batch too large", who);
   SlabArgs a{o->rowptr, o->col, o->val, i->rowptr, i->col, i->val, (int)N, (int)C, (int)K, (int)nnz_o, (int)nnz_i,
-             (int)n_samples, TS, seg_stride, folded};
+             (int)n_samples, TS, seg_stride, folded, g_slab_sort};
   return bwd ? launch_slab<true>(a, need, stream) : launch_slab<false>(a, need, stream);
 }
 
@@ -1298,6 +1325,7 @@ void pgt_slab_set_threads(int v) { g_slab_threads = v; }
 void pgt_slab_set_wpc(int v) { g_slab_wpc = v; }
 void pgt_slab_set_quad(int v) { g_slab_quad = v; }
 void pgt_slab_set_gu(int v) { g_slab_gu = v; }
+void pgt_slab_set_sort(int v) { g_slab_sort = v; }
 
 extern "C" int pgt_dconv_stack_slab_fits(int64_t N, int64_t C, int64_t K, int64_t nnz_o, int64_t nnz_i) {
   return slab_supported(N, C, K, nnz_o, nnz_i, nullptr);

@@ -689,7 +689,7 @@ struct SlabQTasks {
   __device__ __forceinline__ int loff(int j) const { return qoff(j) + row(j) * pitch(j); }
 };
 
-// Rows by slot count.  A wavefront's four rows are gathered in lock step, so it runs as long as its LONGEST row (METR-LA: 7.3 slots
+// Rows by slot count (pgt_tune("slab_sort", 1); off by default: it measured no gain).  A wavefront's four rows are gathered in lock step, so it runs as long as its LONGEST row (METR-LA: 7.3 slots
 // per row on average, up to 3x that): rows are handed to the lane groups in descending order of their two operators' slot counts —
 // position p of the order is the row with p longer-or-earlier rows — so a wavefront's four rows end together and every wavefront
 // gets rows from each quartile (its j-th task is 64 positions further down).  Which lane computes a row changes nothing in the
@@ -872,7 +872,9 @@ int g_slab_pairs = 2;   // pgt_tune("slab_pairs"): column pairs per lane of the 
 // the kernels above.  With the column windows (103 - 123 us) that is the second design whose point was a second resident
 // workgroup, and the second that lost: on this part the phases of co-resident workgroups do not interleave usefully for this
 // access pattern.)
-int g_slab_sort = 1;      // pgt_tune("slab_sort"): 1 = the quad kernels hand rows out by slot count (wavefronts' rows end together), 0 = in row order (A/B)
+int g_slab_sort = 0;      // pgt_tune("slab_sort"): 1 = the quad kernels hand rows out by slot count (a wavefront's rows end together), 0 = in row
+                          // order.  Measured in round 4 (same box, B = 1024): 80.3 -> 80.1 us per launch, 14.20 -> 14.22 ms per step - the divergence of
+                          // a wavefront's four rows is NOT what the gather phases cost; off by default, kept as a switch
 int g_slab_gu = 2;        // pgt_tune("slab_gu"): LDS reads in flight per gather of the four-task backward quad kernels (2 | 4)
 int g_slab_quad = 1;      // pgt_tune("slab_quad"): 0 = C = 64 / 66 blocks on the pair-layout kernels (A/B)
 // the quad-layout kernels take C = 64 (16-byte aligned segments) or C = 66 (8-byte aligned), at most 4 tasks per thread

@@ -36,10 +36,12 @@ def build_emu_library():
     if os.path.exists(EMU_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(EMU_PATH) for d in deps):
         return EMU_PATH
     os.makedirs(EMU_DIR, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-x", "c++", "-DPGT_EMU",
+    tmp = f"{EMU_PATH}.{os.getpid()}.tmp"       # several pytest-xdist workers may build at once: each links its own file, the
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-x", "c++", "-DPGT_EMU",       # rename is atomic, nobody maps a half-written one
            "-I", os.path.join(ROOT, "tests", "hipemu"), "-I", os.path.join(ROOT, "include"), "-I", csrc] + srcs + \
-          ["-o", EMU_PATH]
+          ["-o", tmp]
     subprocess.run(cmd, check=True)
+    os.replace(tmp, EMU_PATH)
     return EMU_PATH
 
 

@@ -238,26 +238,9 @@ def covid_epoch(device, cores):
         t_graph = _time_gpu(lambda: graphed(), 20)
     except Exception as e:                          # an auxiliary line must never cost the bench line
         t_graph_err = repr(e)
-    # the same epoch captured with the 53 edge lists (index + weight tensors) as GRAPH INPUTS and replayed on fresh copies of
-    # them every epoch: what a stream of new graphs of these sizes costs as one hipGraph (the GCN layer reads the RAW edge list
-    # inside its kernel, so nothing is prepared on the host per new list)
-    t_graph_fresh = None
-    try:
-        def epoch_on(*edges):
-            nonlocal snaps
-            keep = snaps
-            snaps = [(x, edges[2 * i], edges[2 * i + 1], y) for i, (x, _, _, y) in enumerate(keep)]
-            try:
-                return epoch()
-            finally:
-                snaps = keep
-        flat_edges = [t for (_, e, w, _) in snaps for t in (e, w)]
-        graphed_e = GraphedStep(epoch_on, flat_edges, warmup=2)
-        fresh = [t.clone() for t in flat_edges]
-        t_graph_fresh = _time_gpu(lambda: graphed_e(*fresh), 20)
-        del graphed_e
-    except Exception as e:
-        t_graph_fresh = repr(e)
+    # (A graphed epoch with the 53 edge lists as hipGraph INPUTS — tests/test_graphed.py shows it on six snapshots — is not timed
+    # here: the 53-snapshot form ended a builder run of round 4 with a GPU memory access fault that the six-snapshot test does
+    # not reproduce; withdrawn from the bench until it is understood.)
     torch.set_num_threads(cores)
     cm = RecurrentGCN()
     cp = {k[len("recurrent."):]: v for k, v in cm.named_parameters() if k.startswith("recurrent.")}
@@ -280,8 +263,7 @@ def covid_epoch(device, cores):
            "cpu_sample": f"{reps} epochs", "snapshot_edges_per_s_eager": edges / t_eager,
            "snapshot_edges_per_s_cpu": edges / t_cpu,
            "gpu_eager_ms_per_epoch_new_edge_tensors": 1e3 * t_fresh,
-           "gpu_eager_ms_per_epoch_new_edge_tensors_prepared_operator_path": 1e3 * t_fresh_prepared,
-           "gpu_graphed_ms_per_epoch_new_edge_tensors": (1e3 * t_graph_fresh if isinstance(t_graph_fresh, float) else t_graph_fresh)}
+           "gpu_eager_ms_per_epoch_new_edge_tensors_prepared_operator_path": 1e3 * t_fresh_prepared}
     if t_graph is not None:
         res.update({"gpu_graphed_ms_per_epoch": 1e3 * t_graph, "snapshot_edges_per_s_graphed": edges / t_graph,
                     "gpu_wins": bool(t_graph < t_cpu)})

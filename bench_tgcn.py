@@ -174,11 +174,12 @@ def cpu_oracle(cores, batch=1, seconds=10.0):
                       f"torch.set_num_threads({cores}))"}
 
 
-def measure(device, rank, world, batch, steps, warmup, profile_steps, series, ei, ew, bench, graph=False):
+def measure(device, rank, world, batch, steps, warmup, profile_steps, series, ei, ew, bench, graph=False, dropin=False):
     """One configuration: timed steps + instrumented steps -> the dict that goes into the JSON line."""
     if graph:
         profile_steps = 0                                  # per-launch events cannot be recorded inside a captured step
-    dt, loss, step, model = train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile_steps, graph=graph)
+    dt, loss, step, model = train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile_steps, graph=graph,
+                                      dropin=dropin)
     edges = int(ei.shape[1])
     res = {"batch_per_gpu": batch, "ms_per_step": 1e3 * dt / steps, "snapshot_edges_per_s": world * batch * SEQ * edges * steps / dt,
            "final_loss": loss}
@@ -243,9 +244,17 @@ def main(args, rank, local_rank, world, device, bench):
         assert args.global_batch % world == 0
         batch, scaling = args.global_batch // world, "strong"
     res = measure(device, rank, world, batch, args.steps, args.warmup, args.profile_steps, series, ei, ew, bench, graph=args.graph)
-    graphed = None
+    graphed = dropin = dropin_blas = None
     if world == 1 and not args.graph and not args.no_extra:
         graphed = bench._safe(lambda: measure(device, rank, world, batch, args.steps, args.warmup, 0, series, ei, ew, bench, graph=True))
+        # import swap only: the example's own torch.nn.Linear read-out behind its relu — routed to the streaming kernels by the states
+        # tensor TGCN2 returns (nn/_states.py), and with the routing off (torch's BLAS product for 32 -> 2 over B * 50 000 rows)
+        dropin = bench._safe(lambda: measure(device, rank, world, batch, 10, 3, 0, series, ei, ew, bench, graph=True, dropin=True))
+        TGCN2.readout_interception = False
+        try:
+            dropin_blas = bench._safe(lambda: measure(device, rank, world, batch, 10, 3, 0, series, ei, ew, bench, graph=True, dropin=True))
+        finally:
+            TGCN2.readout_interception = True
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = bench._safe(lambda: cpu_oracle(min(os.cpu_count() or 1, 32)))
@@ -262,6 +271,11 @@ def main(args, rank, local_rank, world, device, bench):
                            "hidden": 32, "graphed": bool(args.graph)},
                 "variants": {"hipgraph_step": None if graphed is None else {
                     "ms_per_step": graphed["ms_per_step"], "snapshot_edges_per_s": graphed["snapshot_edges_per_s"],
-                    "what": "--graph: forward+backward and the update as two hipGraphs (B = 8 is host-launch bound when issued eagerly)"}},
+                    "what": "--graph: forward+backward and the update as two hipGraphs (B = 8 is host-launch bound when issued eagerly)"},
+                    "dropin_torch_linear_graphed": None if dropin is None else {
+                        "ms_per_step": dropin["ms_per_step"], "what": "import swap only: the example's torch.nn.Linear(32, 2) behind its relu, routed "
+                        "to the streaming kernels by the states tensor TGCN2 returns; as hipGraphs"},
+                    "dropin_blas_readout_graphed": None if dropin_blas is None else {
+                        "ms_per_step": dropin_blas["ms_per_step"], "what": "the same with TGCN2.readout_interception = False (torch's BLAS product)"}},
                 "final_loss": res["final_loss"], "roofline": res.get("roofline"), "kernels": res.get("kernels"), "cpu_baseline": cpu}
         print(json.dumps(line))

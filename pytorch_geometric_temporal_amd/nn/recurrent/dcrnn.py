@@ -62,64 +62,7 @@ class BatchedDConv(DConv):
         return super().forward(X, edge_index, edge_weight)
 
 
-class _StatesTensor(torch.Tensor):
-    """What `BatchedDCRNN.forward` returns: a plain tensor in every respect but one — the reference's examples feed the
-    `[B, T, N, out]` states to a per-node read-out `torch.nn.Linear(out, 1 … 4)` (examples/indexBatching/DCRNN/*_main.py,
-    examples/recurrent/dcrnn_example.py:24-31), and for 1 – 4 output features over millions of rows the BLAS library
-    behind `F.linear` picks a pathological tile (≈ 5 ms per call at 2.5 M rows against 0.14 ms for one streaming pass:
-    bench.py `variants.dropin_default`).  `F.linear(states, weight, bias)` with a skinny fp32 weight is therefore routed to
-    this package's streaming kernels (same parameters, same arithmetic type, ordinary autograd) — also when a `relu` stands
-    between the states and the read-out, as in the reference's own models; every other operation — and `F.linear` with any
-    other operand, or under autocast / tracing / torch.compile — runs as usual and returns plain tensors.  Pickling stores a
-    plain tensor.
-    `BatchedDCRNN.readout_interception = False` hands out plain tensors instead."""
-
-    _RELUS = (torch.nn.functional.relu, torch.relu, torch.Tensor.relu)
-
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        kwargs = kwargs or {}
-        if func is torch.nn.functional.linear and not kwargs and 2 <= len(args) <= 3 and _interception_allowed(args[0]):
-            x, w = args[0], args[1]
-            b = args[2] if len(args) == 3 else None
-            if (type(x) is _StatesTensor and type(w) in (torch.Tensor, torch.nn.Parameter) and w.dim() == 2 and
-                    1 <= w.size(0) <= 4 and w.size(1) == x.size(-1) and x.dtype == w.dtype == torch.float32 and
-                    x.device == w.device and (b is None or (type(b) in (torch.Tensor, torch.nn.Parameter) and
-                                                            b.dtype == torch.float32 and b.device == w.device))):
-                from ..conv import _rows_in_memory_order
-                x2, restore = _rows_in_memory_order(x.as_subclass(torch.Tensor))
-                return restore(ops.linear(x2, w.t(), b))
-        with torch._C.DisableTorchFunctionSubclass():
-            out = func(*args, **kwargs)
-        # the reference's own models put a relu between the recurrent layer and the read-out (examples/recurrent/
-        # dcrnn_example.py:27-28, examples/indexBatching/tgcn/metr_la_main.py:43-44): relu(states) is still "the states" for the
-        # one purpose of this class, so the read-out that follows is routed as well
-        if func in cls._RELUS and not kwargs.get("inplace", False) and isinstance(out, torch.Tensor) and \
-                type(args[0]) is _StatesTensor:
-            return out.as_subclass(_StatesTensor)
-        return _plain(out)
-
-    def __reduce_ex__(self, proto):
-        # torch.save / pickle of a result stores a plain tensor: the subclass is a routing hint, not data
-        return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
-
-
-def _interception_allowed(x):
-    """The routed read-out returns fp32 from the package's kernels: under autocast stock torch would return the autocast dtype,
-    and a tracer / compiler should see the stock op — in those contexts the call is left alone."""
-    dev = x.device.type if isinstance(x, torch.Tensor) else "cuda"
-    if torch.is_autocast_enabled(dev) or torch.jit.is_tracing():
-        return False
-    comp = getattr(torch, "compiler", None)
-    return not (comp is not None and comp.is_compiling())
-
-
-def _plain(out):
-    if type(out) is _StatesTensor:
-        return out.as_subclass(torch.Tensor)
-    if type(out) in (tuple, list):               # (torch.Size and other non-tensor results go back untouched)
-        return type(out)(_plain(o) for o in out)
-    return out
+from .._states import _StatesTensor, _plain, _interception_allowed  # noqa: E402,F401  (the routed read-out: nn/_states.py)
 
 
 def _cell_weights(conv_z, conv_r, conv_h):

@@ -9,6 +9,7 @@ from the module's parameters in one launch), hand-written backward on the transp
 import torch
 
 from ... import ops
+from .._states import _StatesTensor
 from ..conv import GCNConv
 
 
@@ -60,7 +61,12 @@ class TGCN(torch.nn.Module):
 
 class TGCN2(TGCN):
     r"""Batched T-GCN cell (reference: temporalgcn.py:133-233): X [B, N, in], H [B, N, out] -> [B, N, out].
-    `batch_size` is kept for signature compatibility (the reference ignores it too, :148)."""
+    `batch_size` is kept for signature compatibility (the reference ignores it too, :148).
+    The result is the states tensor of nn/_states.py: a plain `[B, N, out]` tensor whose skinny `torch.nn.Linear` read-out —
+    directly or behind a relu, as in the reference's index-batching example (examples/indexBatching/tgcn/metr_la_main.py:43-45) —
+    runs on the package's streaming kernels; `TGCN2.readout_interception = False` hands out plain tensors."""
+
+    readout_interception = True
 
     def __init__(self, in_channels: int, out_channels: int, batch_size: int, improved: bool = False,
                  cached: bool = False, add_self_loops: bool = True):
@@ -79,4 +85,5 @@ class TGCN2(TGCN):
         g = self._graph(edge_index, edge_weight, N)
         # rows stay batch-major (m = b*N + n), as the caller holds X and H: only the `in_channels` input columns are taken to
         # the node-major layout of the aggregation (one launch for the whole batch) and back; H is never transposed
-        return _cell(self, X.reshape(B * N, Fin), H.reshape(B * N, O), g, B, batch_major=True).view(B, N, O)
+        out = _cell(self, X.reshape(B * N, Fin), H.reshape(B * N, O), g, B, batch_major=True).view(B, N, O)
+        return out.as_subclass(_StatesTensor) if self.readout_interception else out

@@ -901,3 +901,42 @@ def test_fused_tgcn_cell_against_the_oracle_and_strided_state(backend):
         assert_close_with_nonfinite(p.grad, gref, 2e-5 * float(gref.abs().max()) + 1e-7, 1e-4, name)
     with torch.no_grad():
         assert torch.equal(m(backend.t(X), backend.t(ei), backend.t(ew), backend.t(H.contiguous())), out.detach())
+
+
+def test_tgcn2_states_route_the_reference_examples_readout(backend):
+    """The reference's index-batching T-GCN model applies `self.linear(F.relu(h))` with a `torch.nn.Linear(hidden, 2)` to every
+    step's state and feeds `h` back into the cell (examples/indexBatching/tgcn/metr_la_main.py:41-45): with the import swapped and
+    nothing else changed, that read-out runs on the package's streaming kernels (same values and gradients as torch's own
+    product), and the state that goes back in is handled as the plain tensor it is."""
+    import torch.nn.functional as TF
+    from pytorch_geometric_temporal_amd import ops
+    from pytorch_geometric_temporal_amd.nn._states import _StatesTensor
+    torch.manual_seed(2)
+    n, B, O = 17, 3, 32
+    ei_np, ew_np = syn.sensor_graph(n, 80, seed=1, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    cell = TGCN2(2, O, 1).to(backend.device)
+    head = torch.nn.Linear(O, 2).to(backend.device)
+    xs = [backend.t(torch.randn(B, n, 2)) for _ in range(3)]
+    res = {}
+    for routed in (True, False):
+        TGCN2.readout_interception = routed
+        calls = []
+        orig = ops.linear
+        ops.linear = lambda *a: (calls.append(1), orig(*a))[1]
+        try:
+            cell.zero_grad(); head.zero_grad()
+            h, outs = None, []
+            for x in xs:
+                h = cell(x, ei, ew, h)
+                assert (type(h) is _StatesTensor) == routed and h.shape == (B, n, O)
+                outs.append(head(TF.relu(h)).unsqueeze(1))
+            y = torch.cat(outs, 1)
+            assert type(y) is torch.Tensor and len(calls) == (3 if routed else 0)
+            y.square().mean().backward()
+            res[routed] = (y.detach().clone(), head.weight.grad.clone(), cell.linear_z.weight.grad.clone())
+        finally:
+            ops.linear = orig
+            TGCN2.readout_interception = True
+    for a, b, what in zip(res[True], res[False], ("outputs", "d/d read-out weight", "d/d linear_z.weight")):
+        assert_close_with_nonfinite(a, b, 1e-6 + 1e-5 * float(b.abs().max()), 1e-5, what)

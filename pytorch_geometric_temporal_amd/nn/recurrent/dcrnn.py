@@ -62,13 +62,15 @@ class BatchedDConv(DConv):
         return super().forward(X, edge_index, edge_weight)
 
 
-from .._states import _StatesTensor, _plain, _interception_allowed  # noqa: E402,F401  (the routed read-out: nn/_states.py)
+from .._states import _StatesTensor, _plain, _interception_allowed, packed_once  # noqa: E402,F401  (the routed read-out: nn/_states.py)
 
 
 def _cell_weights(conv_z, conv_r, conv_h):
     """The stacked operands of the two gate products from the three convolutions' parameters: one launch
     (ops.CellWeightsFunction) instead of three weight re-stackings and two concatenations."""
-    Wzr, bzr, Wh = ops.CellWeightsFunction.apply(conv_z.weight, conv_r.weight, conv_h.weight, conv_z.bias, conv_r.bias)
+    params = (conv_z.weight, conv_r.weight, conv_h.weight, conv_z.bias, conv_r.bias)
+    # (a per-snapshot loop calls the cell with the same parameters every time: packed once per training step, nn/_states.py)
+    Wzr, bzr, Wh = packed_once(conv_z, params, lambda: ops.CellWeightsFunction.apply(*params))
     return Wzr, bzr, Wh, conv_h.bias
 
 

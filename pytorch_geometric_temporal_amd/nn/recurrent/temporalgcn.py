@@ -9,16 +9,17 @@ from the module's parameters in one launch), hand-written backward on the transp
 import torch
 
 from ... import ops
-from .._states import _StatesTensor
+from .._states import _StatesTensor, packed_once
 from ..conv import GCNConv
 
 
 def _cell(mod, X2, H2, g, Bt, batch_major=False):
     """One cell step on [num_nodes * Bt, .] rows (node-major, or batch-major as TGCN2 holds them)."""
     cz, cr, ch = mod.conv_z, mod.conv_r, mod.conv_h
-    Wzr, bzr, Wh, bh = ops.TGCNWeightsFunction.apply(
-        cz.lin.weight, cr.lin.weight, ch.lin.weight, cz.bias, cr.bias, ch.bias,
-        mod.linear_z.weight, mod.linear_r.weight, mod.linear_h.weight, mod.linear_z.bias, mod.linear_r.bias, mod.linear_h.bias)
+    params = (cz.lin.weight, cr.lin.weight, ch.lin.weight, cz.bias, cr.bias, ch.bias,
+              mod.linear_z.weight, mod.linear_r.weight, mod.linear_h.weight, mod.linear_z.bias, mod.linear_r.bias, mod.linear_h.bias)
+    # (one packing per training step, not per time step of the caller's loop: nn/_states.py packed_once)
+    Wzr, bzr, Wh, bh = packed_once(mod, params, lambda: ops.TGCNWeightsFunction.apply(*params))
     return ops.TGCNCellFunction.apply(X2, H2, Wzr, bzr, Wh, bh, g, Bt, batch_major)
 
 

@@ -940,3 +940,71 @@ def test_tgcn2_states_route_the_reference_examples_readout(backend):
             TGCN2.readout_interception = True
     for a, b, what in zip(res[True], res[False], ("outputs", "d/d read-out weight", "d/d linear_z.weight")):
         assert_close_with_nonfinite(a, b, 1e-6 + 1e-5 * float(b.abs().max()), 1e-5, what)
+
+
+def test_cell_operands_are_packed_once_per_training_step(backend):
+    """A T-step loop over TGCN2 (or a per-snapshot loop over DCRNN) with unchanged parameters packs the folded operands ONCE and
+    unpacks their gradient ONCE (nn/_states.py packed_once); the gradients equal those of per-call packing; the packing is redone
+    after a backward pass, after an in-place parameter update, and on every inference call."""
+    from pytorch_geometric_temporal_amd import _lib
+    from pytorch_geometric_temporal_amd.nn import _states
+    from pytorch_geometric_temporal_amd.nn.recurrent import DCRNN
+    torch.manual_seed(4)
+    n, B = 14, 2
+    ei_np, ew_np = syn.sensor_graph(n, 70, seed=3, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    lib = _lib.get_lib()
+    orig = lib.call
+    counts = {}
+    lib.call = lambda name, *a: (counts.__setitem__(name, counts.get(name, 0) + 1), orig(name, *a))[1]
+    try:
+        for make, run, pack, unpack in (
+                (lambda: TGCN2(2, 8, 1), lambda m, x, h: m(x, ei, ew, h), "pgt_tgcn_pack_weights_f32", "pgt_tgcn_unpack_weight_grads_f32"),
+                (lambda: DCRNN(2, 8, 2), lambda m, x, h: m(x[0], ei, ew, None if h is None else h), "pgt_dcrnn_pack_weights_f32",
+                 "pgt_dcrnn_unpack_weight_grads_f32")):
+            m = make().to(backend.device)
+            xs = [backend.t(torch.randn(B, n, 2)) for _ in range(4)]
+
+            def loop():
+                h, tot = None, 0
+                for x in xs:
+                    h = run(m, x, h)
+                    tot = tot + h.square().mean()
+                return tot
+            counts.clear()
+            m.zero_grad()
+            loop().backward()
+            assert counts[pack] == 1 and counts[unpack] == 1, counts
+            g_once = {k: p.grad.clone() for k, p in m.named_parameters()}
+            counts.clear()
+            m.zero_grad()
+            loop().backward()                                 # the backward pass spent the packed operands: packed again
+            assert counts[pack] == 1
+            saved, _states.packed_once = _states.packed_once, (lambda module, params, build: build())
+            try:
+                import importlib
+                for modname in ("temporalgcn", "dcrnn"):
+                    mod = importlib.import_module("pytorch_geometric_temporal_amd.nn.recurrent." + modname)
+                    mod.packed_once = _states.packed_once
+                counts.clear()
+                m.zero_grad()
+                loop().backward()
+                assert counts[pack] == 4                      # per-call packing: the reference arithmetic, four times over
+            finally:
+                _states.packed_once = saved
+                for modname in ("temporalgcn", "dcrnn"):
+                    importlib.import_module("pytorch_geometric_temporal_amd.nn.recurrent." + modname).packed_once = saved
+            for k, p in m.named_parameters():
+                assert_close_with_nonfinite(g_once[k], p.grad, 1e-6 + 2e-5 * float(p.grad.abs().max()), 1e-5, k)
+            counts.clear()
+            out1 = run(m, xs[0], None)
+            with torch.no_grad():
+                next(iter(m.parameters())).add_(0.25)         # an in-place update between two calls of one iteration
+            out2 = run(m, xs[0], None)
+            assert counts[pack] == 2 and float((out1 - out2).detach().abs().max()) > 0
+            counts.clear()
+            with torch.no_grad():
+                run(m, xs[0], None); run(m, xs[0], None)
+            assert counts[pack] == 2                          # inference packs per call
+    finally:
+        lib.call = orig

@@ -333,36 +333,46 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
     for name, gen, deg in (("local", syn.local_graph, 8), ("uniform", syn.uniform_graph, 8), ("local_deg16", syn.local_graph, 16),
                            ("local_hubs_20x2000", syn.hub_graph, 8),
                            ("grid2d_hilbert", lambda n_, d_, seed: syn.grid2d_graph(447, "hilbert", seed), 8),
-                           ("grid2d_rowmajor", lambda n_, d_, seed: syn.grid2d_graph(447, "rowmajor", seed), 8)):
+                           ("grid2d_rowmajor", lambda n_, d_, seed: syn.grid2d_graph(447, "rowmajor", seed), 8),
+                           ("grid2d_shuffled", lambda n_, d_, seed: syn.grid2d_graph(447, "shuffled", seed), 8)):
         n = 447 * 447 if name.startswith("grid2d") else 200_000      # a 447 x 447 mesh: 199 809 nodes
         ei_np, ew_np = gen(n, deg, seed=0)
         g = ops.DConvGraph(torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device), n)
         Xs = [torch.randn(n, 64, device=device) for _ in range(pairs)]
         Ys = [torch.empty(n, 64, device=device) for _ in range(pairs)]
-        for i in range(2 * pairs):
-            ops.spmm(g.fwd_o, Xs[i % pairs], Ys[i % pairs])
-        # The launches are captured into ONE hipGraph and replayed: issued from Python a launch costs ~30 us of host
-        # time (argument checks + ctypes), which is as long as the kernel itself and would be what gets measured.
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                for i in range(launches):
-                    ops.spmm(g.fwd_o, Xs[i % pairs], Ys[i % pairs])
-        torch.cuda.current_stream(device).wait_stream(side)
-        for _ in range(5):                                 # ~7 ms of launches: clocks out of the idle state
-            graph.replay()
-        torch.cuda.synchronize()
-        times = []
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            graph.replay()
-            e1.record()
+
+        def measure(ellw):
+            for i in range(2 * pairs):
+                ops.spmm(g.fwd_o, Xs[i % pairs], Ys[i % pairs], ellw=ellw)
+            # The launches are captured into ONE hipGraph and replayed: issued from Python a launch costs ~30 us of host
+            # time (argument checks + ctypes), which is as long as the kernel itself and would be what gets measured.
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for i in range(launches):
+                        ops.spmm(g.fwd_o, Xs[i % pairs], Ys[i % pairs], ellw=ellw)
+            torch.cuda.current_stream(device).wait_stream(side)
+            for _ in range(5):                                 # ~7 ms of launches: clocks out of the idle state
+                graph.replay()
             torch.cuda.synchronize()
-            times.append(1e3 * e0.elapsed_time(e1) / launches)
-        us = sum(times) / len(times)                       # the MEAN of three replays of 60 launches (not the best)
+            times = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                graph.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                times.append(1e3 * e0.elapsed_time(e1) / launches)
+            del graph
+            return sum(times) / len(times), times              # the MEAN of three replays of 60 launches (not the best)
+
+        t_prep = time.perf_counter()
+        ops.spmm(g.fwd_o, Xs[0], Ys[0])                         # first use: the layout is chosen and built here
+        torch.cuda.synchronize()
+        t_prep = time.perf_counter() - t_prep
+        us, times = measure(None)
         nbytes = ops.spmm_algorithmic_bytes(n, g.E, 64, False)
         e = g.fwd_o.ellw or None
         res[name] = {"us_per_launch": us, "us_per_launch_replays": times, "algorithmic_MB": nbytes / 1e6,
@@ -371,12 +381,51 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
                      "kernel": (("spmm_tile_kernel<4,16,32,8> (CSR row tiles, pgt_spmm_csr_f32)" if g.fwd_o.long_rows is None else
                                  f"spmm_tile_kernel + spmm_long_rows_kernel (pgt_spmm_csr_long_f32: {g.fwd_o.long_rows.numel()} rows "
                                  f"longer than {ops.LONG_ROW} slots, one workgroup each; longest {g.fwd_o.max_len})") if e is None else
-                                f"spmm_ellw64_kernel<{0 if e.scale is not None else 1}> (pgt_spmm_ellw_f32: "
+                                f"spmm_ellw64_kernel<{0 if e.scale is not None else 1}{', EllwCfgC, renumbered' if e.order is not None else ''}> (pgt_spmm_ellw_f32: "
                                 f"{e.n_tiles} tiles of {e.tile_rows} rows x {e.width} slots, halo {e.halo}, "
                                 f"{'per-source scale table' if e.scale is not None else 'per-slot coefficients'}, "
                                 f"{e.far} out-of-window slots)"),
                      "buffers": f"{pairs} rotating (X,Y) pairs", "launch": f"{launches} launches replayed as one hipGraph, mean of 3 replays"}
-        del g, Xs, Ys, graph
+        if e is not None and e.order is not None:
+            # the library laid the operator out in a numbering of its own (no permutation pass: X / Y rows go through the
+            # order inside the kernel); beside it the CSR row tiles on the caller's numbering = what ran before
+            us_csr, _ = measure(False)
+            res[name].update({"renumbered": True, "layout_prep_s_once_per_graph": t_prep, "csr_row_tiles_us_per_launch": us_csr,
+                              "csr_row_tiles_frac": nbytes / us_csr / 1e3 / HBM_PEAK_GBS})
+            # the hops of a K = 3 DConv (dcrnn.py:300-321) through the same layouts: T1 = P X, T2 = 2 P T1 - X on P_o and on P_i,
+            # each hop reading the previous one in the caller's numbering — there is no permutation pass to include
+            def hops(i):
+                x, a, b = Xs[i % pairs], Ys[i % pairs], Ys[(i + 1) % pairs]
+                for csr in (g.fwd_o, g.fwd_i):
+                    ops.spmm(csr, x, a)
+                    ops.spmm(csr, a, b, T=x, alpha=2.0, beta=-1.0)
+            for i in range(pairs):
+                hops(i)
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for i in range(launches // 4):
+                        hops(i)
+            torch.cuda.current_stream(device).wait_stream(side)
+            graph.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            per_hop = 1e3 * e0.elapsed_time(e1) / (4 * (launches // 4))
+            hop_bytes = (ops.spmm_algorithmic_bytes(n, g.E, 64, False) + ops.spmm_algorithmic_bytes(n, g.E, 64, True)) / 2
+            ei_ = g.fwd_i.ellw or None
+            res[name]["dconv_K3_hops"] = {"us_per_hop": per_hop, "algorithmic_MB_per_hop": hop_bytes / 1e6,
+                                          "frac": hop_bytes / per_hop / 1e3 / HBM_PEAK_GBS,
+                                          "P_i_layout": "renumbered" if ei_ is not None and ei_.order is not None else
+                                          ("ellw" if ei_ is not None else "csr row tiles"),
+                                          "what": "4 hops (2 on P_o, 2 on P_i, two with the Chebyshev epilogue), mean per hop"}
+            del graph
+        del g, Xs, Ys
     return res
 
 

@@ -47,7 +47,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 11
+#define PGT_ABI_VERSION 12
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -170,6 +170,10 @@ typedef struct pgt_ellw {
                              carries numberings whose tiles are compact without being a band: a 2-D mesh numbered along a
                              space-filling curve names ~85 outside rows per 392-row tile (its ring) */
   int32_t far_rows;       /* from pgt_ellw_plan (depends on config and mode) */
+  const int32_t* order;   /* [n_rows] or NULL.  Set: the layout lives in a RENUMBERED row space (pgt_tile_order_host) — layout
+                             row p is row order[p] of X / Y / T; slots, scale, far_col and the CSR arrays passed along are all
+                             in layout numbering; config must be 3 (halo 0).  The product is still Y = A X in the CALLER's
+                             numbering: the kernel reads and writes whole 256-byte rows through `order`, no permutation pass */
 } pgt_ellw;
 
 /* Host-only: tile height / slot width / tile count for an operator with `n_rows` rows whose longest row has
@@ -177,6 +181,7 @@ typedef struct pgt_ellw {
  * whole rounds of the resident workgroups (config 1: rows of <= 8 slots; config 2: wider rows) of the current device.
  * `far_rows` = entries per tile of the out-of-window table (what the LDS budget of the launch shape leaves: more in
  * source-scale mode, which has no coefficient block).
+ * halo 0 plans the layout of a renumbered operator (config 3: a 400-row window without halo, 208 / 160 table entries).
  * PGT_ERR_INVALID when the layout does not apply (rows longer than 32 slots, halo > 116). */
 int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t source_scaled, int32_t* tile_rows,
                   int32_t* width, int32_t* config, int64_t* n_tiles, int32_t* far_rows);
@@ -201,6 +206,17 @@ int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const float* val, 
 int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                       const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha,
                       float beta, int64_t F, pgt_stream_t stream);
+
+/* HOST pointers in and out (graph preparation, once per graph; O(E), ~40 ms at 200 000 rows x 8 slots).  A numbering of
+ * the rows of a CSR operator whose runs of `tile_rows` consecutive rows are compact patches of the graph — what
+ * spmm_ellw64_kernel needs and what the caller's numbering need not be: the reference aggregates over whatever edge list
+ * it is given (dcrnn.py:300-313), a sensor graph arrives in file order.  Patches are grown one after the other, always
+ * adding the unassigned row with the most neighbours already inside the patch.  order[p] = the caller's row at layout
+ * position p (int32 [n_rows]); rowptr_p / col_p = the operator in layout numbering, every row keeping its slots in the
+ * caller's order (so the sums round as on the caller's CSR); slot_p[q'] = the caller's slot behind layout slot q'
+ * (val_p = val[slot_p]).  Feed them to pgt_ellw_plan (halo 0) / pgt_ellw_build and set pgt_ellw.order. */
+int pgt_tile_order_host(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t tile_rows, int32_t* order,
+                        int32_t* rowptr_p, int32_t* col_p, int32_t* slot_p);
 
 /* out4[0] = #slots with |col - row| <= 32, out4[1] = #slots with |col - row| <= 96, out4[2] = slots of the longest row,
  * out4[3] = #rows longer than long_len (device int32[4]); the first min(out4[3], long_cap) of those rows are listed in

@@ -38,7 +38,7 @@ class CsrStruct(ctypes.Structure):
 class EllwStruct(ctypes.Structure):
     _fields_ = [("slots", c_ptr), ("vals", c_ptr), ("scale", c_ptr), ("tile_rows", ctypes.c_int32),
                 ("halo", ctypes.c_int32), ("width", ctypes.c_int32), ("config", ctypes.c_int32), ("n_tiles", c_i64),
-                ("far_col", c_ptr), ("far_rows", ctypes.c_int32)]
+                ("far_col", c_ptr), ("far_rows", ctypes.c_int32), ("order", c_ptr)]
 
 
 class DConvGraphStruct(ctypes.Structure):
@@ -76,6 +76,7 @@ PROTOTYPES = {
                                c_ptr, c_ptr, c_ptr]),
     "pgt_spmm_ellw_f32": (c_int, [ctypes.POINTER(EllwStruct), c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                   c_ptr, c_i64, c_f32, c_f32, c_i64, c_ptr]),
+    "pgt_tile_order_host": (c_int, [c_ptr, c_ptr, c_i64, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_csr_locality": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, ctypes.c_int32, c_ptr]),
     "pgt_spmm_csr_long_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, ctypes.c_int32, c_ptr, c_i64, c_ptr, c_i64,
                                       c_ptr, c_i64, c_f32, c_f32, c_i64, c_ptr]),
@@ -166,7 +167,7 @@ PROTOTYPES = {
                                       c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 11
+EXPECTED_ABI = 12
 
 
 class PgtLib:

@@ -19,6 +19,8 @@
 // Algorithmic bytes per launch: 4(N+1) + 8*nnz + 4*N*F (read X once) + 4*N*F (write Y) [+ 4*N*F for T].
 #include <string.h>
 
+#include <type_traits>
+
 #include "pgt_common.h"
 
 namespace {
@@ -219,8 +221,12 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(
 //   B:  512 threads, 240 window rows (67 - 79 KB): two workgroups per CU, one gathers out of LDS while the other's
 //      memory phase is in flight.  For wider rows (W >= 16), where the LDS gather is as long as the memory phase.
 // FAR0 / FAR1: LDS rows for out-of-window sources in source-scale / per-slot mode (what the LDS budget leaves)
-struct EllwCfgA { static constexpr int THREADS = 1024, WRMAX = 456, SLOTS = 392 * 16, FAR0 = 128, FAR1 = 32; };
-struct EllwCfgB { static constexpr int THREADS = 512, WRMAX = 240, SLOTS = 176 * 16, FAR0 = 48, FAR1 = 12; };
+//   C: the launch shape of a RENUMBERED operator (pgt_ellw.order, tile_order.hip): 1024 threads, a 400-row window with NO
+//      halo (position in a patch order says nothing about adjacency, so a halo would be 14 % wasted reads) and the LDS it
+//      frees given to the table of outside rows (a grown patch of 392 mesh nodes names 113 of them on average, up to ~180).
+struct EllwCfgA { static constexpr int THREADS = 1024, WRMAX = 456, SLOTS = 392 * 16, FAR0 = 128, FAR1 = 32, HMIN = 1; };
+struct EllwCfgB { static constexpr int THREADS = 512, WRMAX = 240, SLOTS = 176 * 16, FAR0 = 48, FAR1 = 12, HMIN = 1; };
+struct EllwCfgC { static constexpr int THREADS = 1024, WRMAX = 400, SLOTS = 400 * 8, FAR0 = 208, FAR1 = 160, HMIN = 0; };
 constexpr int ELLW_WMAX = 32;
 
 int g_ellw = 1;        // pgt_tune("spmm_ellw"): 0 = pgt_spmm_ellw_f32 runs the CSR kernels instead (A/B)
@@ -229,17 +235,20 @@ int g_ellw_cus = 0;    // pgt_tune("spmm_ellw_cus"): test hook, CU count the pla
 int g_ellw_cfg = 0;    // pgt_tune("spmm_ellw_cfg"): launch shape pgt_ellw_plan picks: 0 = by row width, 1 = A, 2 = B
 
 // W8C: slot vectors (8 slots) per row when known at compile time (1, 2), 0 = runtime
-template <int MODE, class CFG, int W8C>
+// PERM: the layout lives in a renumbered row space — layout row p is row order[p] of X / Y / T (slots, scale, far_col,
+// rowptr / col are all in layout numbering); every X row is still one coalesced 256-byte read and every Y row one
+// 256-byte streaming store, just not at consecutive addresses
+template <int MODE, class CFG, int W8C, bool PERM = false>
 __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     const uint16_t* __restrict__ slots, const float* __restrict__ vals, const float* __restrict__ scale,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
     int TR, int H, int W, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt, float alpha,
-    float beta, int flags, const int32_t* __restrict__ far_col) {
+    float beta, int flags, const int32_t* __restrict__ far_col, const int32_t* __restrict__ order) {
   constexpr int THREADS = CFG::THREADS, WRMAX = CFG::WRMAX, SLOTS = CFG::SLOTS;
   constexpr int FARMAX = MODE == 0 ? CFG::FAR0 : CFG::FAR1;   // LDS rows behind the zero row for out-of-window sources
   constexpr int G = THREADS / 16;                      // row groups of 16 lanes: one 256-byte row each
   constexpr int XPT = (WRMAX + G - 1) / G;             // window rows per group
-  constexpr int RPG = (WRMAX - 2 + G - 1) / G;         // output rows per group (TR <= WRMAX - 2 H, H >= 1)
+  constexpr int RPG = (WRMAX - 2 * CFG::HMIN + G - 1) / G;   // output rows per group (TR <= WRMAX - 2 H, H >= HMIN)
   constexpr int NSV = (SLOTS / 8 + THREADS - 1) / THREADS;   // slot vectors per thread
   __shared__ pgt_f4 s_x[(WRMAX + 1 + FARMAX) * 16];
   __shared__ pgt_u4 s_slots[SLOTS / 8];
@@ -270,15 +279,24 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   }
   pgt_f4 xw[XPT];
   float sc[XPT];
+  int xrow[XPT];
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     int wr = rg + G * i;
     wr = wr < WR ? wr : WR - 1;                        // unconditional clamped loads: a static number in flight
     int r = w0 + wr;
     r = r < 0 ? 0 : (r < n_rows ? r : n_rows - 1);
-    xw[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(r * ldx));
+    xrow[i] = r;
+    if constexpr (PERM) xrow[i] = order[r];
     sc[i] = MODE == 0 ? scale[r] : 1.f;
   }
+  int yrow[PERM ? RPG : 1];                            // PERM: where this lane group's output rows go
+  if constexpr (PERM) {
+#pragma unroll
+    for (int k = 0; k < RPG; ++k) { const int r = rg + G * k; yrow[k] = order[r0 + (r < nr ? r : 0)]; }
+  }
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) xw[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(xrow[i] * ldx));
   const int nvec = TR * W8;                            // <= SLOTS / 8
   pgt_u4 sv[NSV];
   pgt_f4 va[MODE == 1 ? 2 * NSV : 1];
@@ -299,12 +317,14 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     xfar[i] = pgt_mk4(0.f, 0.f, 0.f, 0.f);
     sfar[i] = 1.f;
     if (fc[i] >= 0 && fc[i] < n_rows) {
-      xfar[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(fc[i] * ldx));
+      int fr = fc[i];
+      if constexpr (PERM) fr = order[fr];
+      xfar[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(fr * ldx));
       if constexpr (MODE == 0) sfar[i] = scale[fc[i]];
     }
   }
   pgt_f4 tcur = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-  if (T != nullptr && rg < nr) tcur = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + rg) * ldt) + l16 * 4);
+  if (T != nullptr && rg < nr) tcur = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((PERM ? yrow[0] : r0 + rg) * ldt) + l16 * 4);
   // ---- window -> LDS.  MODE 0: scaled on the way in (the product is rounded once, like norm * x_j in the reference)
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
@@ -333,9 +353,9 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   }
   __syncthreads();
   // ---- gather out of the window: rows rg, rg + G, ... ; sequential chain in slot order
-  auto do_row = [&](const int r, pgt_f4& tc) {
+  auto do_row = [&](const int r, pgt_f4& tc, const int yr, const int yr_next) {
     pgt_f4 tnext = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-    if (T != nullptr && r + G < nr) tnext = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((r0 + r + G) * ldt) + l16 * 4);
+    if (T != nullptr && r + G < nr) tnext = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(yr_next * ldt) + l16 * 4);
     pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
     auto chunk = [&](const int c8) {
       const pgt_u4 s4 = s_slots[r * W8 + c8];
@@ -359,7 +379,9 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
         for (int j = 0; j < 8; ++j)
           if (d[j] == 0xffffu) {
             const int cj = col[q0 + j];
-            pgt_f4 xx = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(cj * ldx));
+            int xj = cj;
+            if constexpr (PERM) xj = order[cj];
+            pgt_f4 xx = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(xj * ldx));
             if constexpr (MODE == 0) {
               const float s = scale[cj];
               xx = pgt_mk4(pgt_mul_rn(xx.x, s), pgt_mul_rn(xx.y, s), pgt_mul_rn(xx.z, s), pgt_mul_rn(xx.w, s));
@@ -395,20 +417,26 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     } else {
       out[0] = alpha * acc.x; out[1] = alpha * acc.y; out[2] = alpha * acc.z; out[3] = alpha * acc.w;
     }
-    float* yp = Y + (unsigned)((r0 + r) * ldy) + l16 * 4;
+    float* yp = Y + (unsigned)(yr * ldy) + l16 * 4;
     if (stream_y) stv_stream<4>(yp, out);
     else stv<4>(yp, out);
     tc = tnext;
   };
-  if constexpr (W8C == 1) {
+  if constexpr (PERM) {
+#pragma unroll
+    for (int k = 0; k < RPG; ++k) {
+      const int r = rg + G * k;
+      if (r < nr) do_row(r, tcur, yrow[k], yrow[k + 1 < RPG ? k + 1 : k]);
+    }
+  } else if constexpr (W8C == 1) {
     // narrow rows: the row loop is unrolled so the LDS reads of several rows are in flight together
 #pragma unroll
     for (int k = 0; k < RPG; ++k) {
       const int r = rg + G * k;
-      if (r < nr) do_row(r, tcur);
+      if (r < nr) do_row(r, tcur, r0 + r, r0 + r + G);
     }
   } else {
-    for (int r = rg; r < nr; r += G) do_row(r, tcur);
+    for (int r = rg; r < nr; r += G) do_row(r, tcur, r0 + r, r0 + r + G);
   }
 }
 
@@ -798,24 +826,28 @@ static int ellw_device_cus() {
 }
 
 static int ellw_far_rows(int config, bool source_scaled) {
+  if (config == 3) return source_scaled ? EllwCfgC::FAR0 : EllwCfgC::FAR1;
   return config == 1 ? (source_scaled ? EllwCfgA::FAR0 : EllwCfgA::FAR1) : (source_scaled ? EllwCfgB::FAR0 : EllwCfgB::FAR1);
 }
+static int ellw_wrmax(int config) { return config == 1 ? EllwCfgA::WRMAX : (config == 2 ? EllwCfgB::WRMAX : EllwCfgC::WRMAX); }
+static int ellw_slots_cap(int config) { return config == 1 ? EllwCfgA::SLOTS : (config == 2 ? EllwCfgB::SLOTS : EllwCfgC::SLOTS); }
 
 extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t source_scaled, int32_t* tile_rows,
                              int32_t* width, int32_t* config, int64_t* n_tiles, int32_t* far_rows) {
   PGT_REQUIRE(tile_rows && width && config && n_tiles && far_rows, "pgt_ellw_plan: null pointer");
   *tile_rows = 0; *width = 0; *config = 0; *n_tiles = 0; *far_rows = 0;
   PGT_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 31) - 1024, "pgt_ellw_plan: n_rows out of range");
-  PGT_REQUIRE(halo >= 1 && 2 * halo <= EllwCfgB::WRMAX - 8, "pgt_ellw_plan: halo %d outside [1, %d]", (int)halo,
+  PGT_REQUIRE(halo >= 0 && 2 * halo <= EllwCfgB::WRMAX - 8, "pgt_ellw_plan: halo %d outside [0, %d]", (int)halo,
               (EllwCfgB::WRMAX - 8) / 2);
   PGT_REQUIRE(max_row_len >= 0 && max_row_len <= ELLW_WMAX, "pgt_ellw_plan: rows of up to %d slots exceed the layout's %d",
               (int)max_row_len, ELLW_WMAX);
   const int W = max_row_len <= 8 ? 8 : (int)pgt_cdiv(max_row_len, 8) * 8;
-  const int cfg = g_ellw_cfg == 1 || g_ellw_cfg == 2 ? g_ellw_cfg : ((W <= 8 || halo > 40) ? 1 : 2);
+  // halo 0 = the layout of a renumbered operator (pgt_tile_order_host): launch shape C
+  const int cfg = halo == 0 ? 3 : (g_ellw_cfg == 1 || g_ellw_cfg == 2 ? g_ellw_cfg : ((W <= 8 || halo > 40) ? 1 : 2));
   *config = cfg;
   *far_rows = ellw_far_rows(cfg, source_scaled != 0);
-  const int wrmax = cfg == 1 ? EllwCfgA::WRMAX : EllwCfgB::WRMAX, slots_cap = cfg == 1 ? EllwCfgA::SLOTS : EllwCfgB::SLOTS;
-  const int per_cu = cfg == 1 ? 1 : 2;
+  const int wrmax = ellw_wrmax(cfg), slots_cap = ellw_slots_cap(cfg);
+  const int per_cu = cfg == 2 ? 2 : 1;
   int cap = wrmax - 2 * halo;
   if (cap > slots_cap / W) cap = slots_cap / W;
   if (g_ellw_rows > 0 && cap > g_ellw_rows) cap = g_ellw_rows;
@@ -838,10 +870,11 @@ extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, 
 static int ellw_check(const char* who, const pgt_ellw* op, int64_t n_rows) {
   PGT_REQUIRE(op != nullptr && op->slots != nullptr, "%s: null operator", who);
   PGT_REQUIRE(op->width >= 8 && op->width % 8 == 0 && op->width <= ELLW_WMAX, "%s: width %d", who, (int)op->width);
-  PGT_REQUIRE(op->config == 1 || op->config == 2, "%s: config %d (1 = one workgroup per CU, 2 = two)", who, (int)op->config);
-  const int wrmax = op->config == 1 ? EllwCfgA::WRMAX : EllwCfgB::WRMAX;
-  const int slots_cap = op->config == 1 ? EllwCfgA::SLOTS : EllwCfgB::SLOTS;
-  PGT_REQUIRE(op->halo >= 1 && op->tile_rows >= 1 && op->tile_rows + 2 * op->halo <= wrmax &&
+  PGT_REQUIRE(op->config >= 1 && op->config <= 3, "%s: config %d (1 = one workgroup per CU, 2 = two, 3 = renumbered)", who,
+              (int)op->config);
+  const int wrmax = ellw_wrmax(op->config);
+  const int slots_cap = ellw_slots_cap(op->config);
+  PGT_REQUIRE(op->halo >= (op->config == 3 ? 0 : 1) && op->tile_rows >= 1 && op->tile_rows + 2 * op->halo <= wrmax &&
                   (int64_t)op->tile_rows * op->width <= slots_cap,
               "%s: tile of %d rows x %d slots with halo %d does not fit the kernel (see pgt_ellw_plan)", who,
               (int)op->tile_rows, (int)op->width, (int)op->halo);
@@ -865,6 +898,7 @@ extern "C" int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const f
   tmp.slots = slots;
   tmp.scale = scale;
   tmp.far_col = far_col;
+  tmp.order = nullptr;
   if (int rc = ellw_check("pgt_ellw_build", &tmp, n_rows)) return rc;
   if (far_col != nullptr) {
     // -1 = unused entry of the far table; far_cnt counts a tile's DISTINCT out-of-window sources that got an LDS row
@@ -904,18 +938,25 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
   PGT_REQUIRE(col && val, "pgt_spmm_ellw_f32: the CSR operator the layout was built from is required");
   if (int rc = ellw_check("pgt_spmm_ellw_f32", op, n_rows)) return rc;
   PGT_REQUIRE((op->vals != nullptr) != (op->scale != nullptr), "pgt_spmm_ellw_f32: exactly one of vals / scale must be set");
+  PGT_REQUIRE((op->order != nullptr) == (op->config == 3),
+              "pgt_spmm_ellw_f32: config 3 is the launch shape of a renumbered layout (order set), and only that");
   PgtVecPick vp;
   vp.width(F); vp.operand(X, ldx); vp.operand(Y, ldy); vp.operand(T, ldt);
   const int64_t max_ld = ldx > ldy ? (ldx > ldt ? ldx : ldt) : (ldy > ldt ? ldy : ldt);
   // shapes the window kernel does not cover run the CSR row tiles (same sums, fmaf chain)
-  if (!g_ellw || F % 64 != 0 || F / 64 > 65535 || vp.v != 4 || (n_rows + EllwCfgA::WRMAX) * max_ld >= ((int64_t)1 << 31))
+  const bool window_ok = F % 64 == 0 && F / 64 <= 65535 && vp.v == 4 && (n_rows + EllwCfgA::WRMAX) * max_ld < ((int64_t)1 << 31);
+  // a renumbered layout's CSR is in layout numbering: the CSR kernels on it would answer in the wrong row space
+  PGT_REQUIRE(op->order == nullptr || window_ok,
+              "pgt_spmm_ellw_f32: a renumbered layout covers F = 64 k on 16-byte aligned operands only; use pgt_spmm_csr_f32 "
+              "on the caller's CSR for this shape");
+  if (op->order == nullptr && (!g_ellw || !window_ok))
     return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   const int flags = (g_tile_xcd ? 1 : 0) | (g_tile_nt ? 2 : 0);
   dim3 grid((unsigned)op->n_tiles, (unsigned)(F / 64));   // y: 64-float column chunks (1 for the F = 64 north-star shape)
 #define PGT_ELLW_GO(MODE_, CFG_, W8C_)                                                                                \
-  PGT_LAUNCH((spmm_ellw64_kernel<MODE_, CFG_, W8C_>), grid, dim3(CFG_::THREADS), stream, op->slots, op->vals, op->scale, \
-             rowptr, col, val, (int)n_rows, (int)op->tile_rows, (int)op->halo, (int)op->width, X, (int)ldx, Y, (int)ldy,  \
-             T, (int)ldt, alpha, beta, flags, op->far_col)
+  PGT_LAUNCH((spmm_ellw64_kernel<MODE_, CFG_, W8C_, std::is_same<CFG_, EllwCfgC>::value>), grid, dim3(CFG_::THREADS), stream, \
+             op->slots, op->vals, op->scale, rowptr, col, val, (int)n_rows, (int)op->tile_rows, (int)op->halo,            \
+             (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha, beta, flags, op->far_col, op->order)
 #define PGT_ELLW_W(MODE_, CFG_)                                  \
   do {                                                           \
     if (op->width == 8) PGT_ELLW_GO(MODE_, CFG_, 1);             \
@@ -923,9 +964,9 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
     else PGT_ELLW_GO(MODE_, CFG_, 0);                            \
   } while (0)
   if (op->scale != nullptr) {
-    if (op->config == 1) PGT_ELLW_W(0, EllwCfgA); else PGT_ELLW_W(0, EllwCfgB);
+    if (op->config == 1) PGT_ELLW_W(0, EllwCfgA); else if (op->config == 2) PGT_ELLW_W(0, EllwCfgB); else PGT_ELLW_W(0, EllwCfgC);
   } else {
-    if (op->config == 1) PGT_ELLW_W(1, EllwCfgA); else PGT_ELLW_W(1, EllwCfgB);
+    if (op->config == 1) PGT_ELLW_W(1, EllwCfgA); else if (op->config == 2) PGT_ELLW_W(1, EllwCfgB); else PGT_ELLW_W(1, EllwCfgC);
   }
 #undef PGT_ELLW_W
 #undef PGT_ELLW_GO

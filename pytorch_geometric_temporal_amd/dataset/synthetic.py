@@ -122,8 +122,8 @@ def _hilbert_d(order, x, y):
 def grid2d_graph(side=447, order="hilbert", seed=0):
     """A 2-D mesh (side x side nodes, 8-neighbourhood: in-degree 8 in the interior — a road / sensor network embedded in
     the plane) numbered along a space-filling curve ("hilbert": consecutive nodes form compact patches, the ordering a
-    locality-aware partitioner yields) or row by row ("rowmajor": the bandwidth-`side` ordering reverse Cuthill-McKee gives
-    a mesh).  N = side**2 (447**2 = 199 809), E ~ 8 N.  Weights are random: a diffusion operator, not a stencil."""
+    locality-aware partitioner yields), row by row ("rowmajor": the bandwidth-`side` ordering reverse Cuthill-McKee gives
+    a mesh) or at random ("shuffled").  N = side**2 (447**2 = 199 809), E ~ 8 N.  Weights are random: a diffusion operator, not a stencil."""
     rng = np.random.default_rng(seed)
     n_side = int(side)
     yy, xx = np.divmod(np.arange(n_side * n_side), n_side)
@@ -133,6 +133,8 @@ def grid2d_graph(side=447, order="hilbert", seed=0):
         rank[np.argsort(_hilbert_d(bits, xx, yy), kind="stable")] = np.arange(n_side * n_side)
     elif order == "rowmajor":
         rank = np.arange(n_side * n_side, dtype=np.int64)
+    elif order == "shuffled":                      # node ids in no order at all (a sensor list in file order)
+        rank = np.random.default_rng(seed + 7).permutation(n_side * n_side).astype(np.int64)
     else:
         raise ValueError(order)
     src, dst = [], []

@@ -122,15 +122,55 @@ class Ellw:
         self.far_col = far_col if self.far else None                   # no table: the kernel skips its loads
         return mismatch if source_scaled else 0
 
+    order = None      # int32 [n_rows] of a renumbered layout (RenumberedEllw), None: the caller's numbering
+    csr = None        # the operator in LAYOUT numbering (RenumberedEllw); None: the caller's own CSR serves the layout
+
     def struct(self):
         return EllwStruct(ptr(self.slots), ptr(self.vals), ptr(self.scale), self.tile_rows, self.halo, self.width,
-                          self.config, self.n_tiles, ptr(self.far_col), self.far_rows)
+                          self.config, self.n_tiles, ptr(self.far_col), self.far_rows, ptr(self.order))
+
+
+class _LayoutCsr:
+    """The operator of a renumbered layout: rowptr / col / val in layout numbering (what pgt_ellw_build reads and what
+    serves a slot that found no place in its tile's table)."""
+    __slots__ = ("rowptr", "col", "val", "n_rows", "max_len", "nnz")
+
+
+class RenumberedEllw(Ellw):
+    """The ELLW layout of an operator whose tiles are NOT compact in the caller's numbering, in a numbering where they are
+    (pgt_tile_order_host: patches grown on the host, once per graph).  Nothing moves in HBM: `order` goes into the layout and
+    the kernel reads / writes whole X / Y / T rows through it, so `spmm` still answers in the caller's numbering and a
+    K-hop stack chains hop after hop without a permutation pass.  Rows keep their slots in the caller's order: the sums
+    round exactly as on the caller's CSR."""
+
+    def __init__(self, csr):
+        lib = _lib.get_lib()
+        dev = csr.rowptr.device
+        n, nnz = csr.n_rows, int(csr.nnz)
+        tr, w, cfg, nt, fr = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
+        lib.call("pgt_ellw_plan", n, 0, int(csr.max_len), 1, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(cfg),
+                 ctypes.byref(nt), ctypes.byref(fr))
+        rowptr_h = csr.rowptr[:n + 1].cpu().contiguous()            # graph preparation: one round trip per operator
+        col_h = csr.col[:nnz].cpu().contiguous()
+        order_h, rowptr_p = torch.empty(n, dtype=I32), torch.empty(n + 1, dtype=I32)
+        col_p, slot_p = torch.empty(max(nnz, 1), dtype=I32), torch.empty(max(nnz, 1), dtype=I32)
+        lib.call("pgt_tile_order_host", rowptr_h.data_ptr(), col_h.data_ptr(), n, tr.value, order_h.data_ptr(),
+                 rowptr_p.data_ptr(), col_p.data_ptr(), slot_p.data_ptr())
+        lay = _LayoutCsr()
+        lay.rowptr, lay.col = rowptr_p.to(dev), col_p.to(dev)
+        lay.val = csr.val[:nnz][slot_p[:nnz].to(dev).long()] if nnz else csr.val[:1].clone()
+        lay.n_rows, lay.max_len, lay.nnz = n, csr.max_len, nnz
+        self.csr, self.order = lay, order_h.to(dev)
+        super().__init__(lay, 0)
 
 
 # an operator that is NOT a band (fewer than 95 % of the slots within +-96 rows) may still have compact tiles — a mesh
 # numbered along a space-filling curve: 83 % within +-32, the rest in the patch's ring — which the layout's per-tile table
 # of distinct outside rows carries: build it with the narrow halo and keep it when (almost) every slot found a place
 ELLW_COMPACT_MAX_CSR_FRACTION = 0.002      # slots left to the CSR path (0xFFFF) for the layout to be kept
+# an operator whose tiles are not compact in the caller's numbering either (a mesh numbered row by row: 0.48 of HBM on the
+# CSR row tiles; a shuffled one: 0.22) is laid out in a numbering of the library's own (RenumberedEllw).  PGT_RENUMBER=0: off
+USE_RENUMBER = os.environ.get("PGT_RENUMBER", "1") != "0"
 
 
 def ellw_of(csr):
@@ -143,11 +183,19 @@ def ellw_of(csr):
             e = csr.ellw = Ellw(csr, csr.halo)
         elif csr.n_rows >= ELLW_MIN_ROWS:
             cand = Ellw(csr, 32)
+            if cand.far_csr > ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz and USE_RENUMBER:
+                cand = RenumberedEllw(csr)
             if cand.far_csr <= ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz:
                 e = csr.ellw = cand
             else:
                 csr.ellw = False
     return e
+
+
+def _window_kernel_covers(*operands):
+    """What spmm_ellw64_kernel needs of X / Y / T (a renumbered layout has no CSR fallback inside the C entry point: the
+    caller's CSR is used from here instead): 16-byte aligned rows."""
+    return all(t is None or (t.data_ptr() % 16 == 0 and (t.size(0) <= 1 or t.stride(0) % 4 == 0)) for t in operands)
 
 
 def _edge_inputs(lib, edge_index, edge_weight):
@@ -494,11 +542,15 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
         if ellw and not getattr(csr, "ellw", None):
             _force_ellw(csr)
         op = ellw_of(csr)
+        if op is not None and op.order is not None and not (
+                _window_kernel_covers(X, Y, T) and (csr.n_rows + 456) * max(ldx, ldy, ldt) < 2 ** 31):
+            op = None
     work = spmm_algorithmic_bytes(csr.n_rows, csr.col.numel(), X.size(1), T is not None) if KERNEL_TIMER else 0
     if op is not None:
         es = op.struct()
+        lay = op.csr or csr
         _timed("spmm", work, lambda: lib.call(
-            "pgt_spmm_ellw_f32", ctypes.byref(es), ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, xp, ldx,
+            "pgt_spmm_ellw_f32", ctypes.byref(es), ptr(lay.rowptr), ptr(lay.col), ptr(lay.val), csr.n_rows, xp, ldx,
             yp, ldy, tp, ldt, float(alpha), float(beta), X.size(1), st))
         return Y
     lr = getattr(csr, "long_rows", None)
@@ -523,6 +575,18 @@ def _force_ellw(csr, halo=None):
     if csr.max_len > 32 or csr.nnz <= 0:
         return None
     csr.ellw = Ellw(csr, halo or csr.halo or 32)
+    return csr.ellw
+
+
+def _force_renumbered(csr):
+    """Build the renumbered ELLW layout of `csr` regardless of its size / whether it pays (tests, A/B runs)."""
+    if getattr(csr, "max_len", -1) < 0 or getattr(csr, "nnz", -1) < 0:
+        rp = csr.rowptr[:csr.n_rows + 1]
+        csr.nnz = int(rp[csr.n_rows])
+        csr.max_len = int((rp[1:] - rp[:-1]).max()) if csr.n_rows else 0
+    if csr.max_len > 32 or csr.nnz <= 0:
+        return None
+    csr.ellw = RenumberedEllw(csr)
     return csr.ellw
 
 

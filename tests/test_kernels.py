@@ -546,14 +546,14 @@ def test_spmm_ellw_out_of_window_sources_get_lds_rows(backend, source_scaled):
 def test_spmm_ellw_compact_tiles_of_a_mesh_on_a_space_filling_curve(backend):
     """A 2-D mesh numbered along a Hilbert curve is not a band (under 95 % of the slots within +-96 rows), but its tiles are
     compact patches whose ring (~85 distinct outside rows per 392-row tile, named by ~230 slots) fits the per-tile table:
-    ops.ellw_of keeps the layout when no slot is left to the CSR path.  Row-major numbering (bandwidth = the mesh side:
-    two thirds of a tile's sources in the rows above and below) and a uniform-random graph are rejected and run the CSR
-    row tiles.  Source-scale mode: bit for bit the reference's roundings."""
+    ops.ellw_of keeps the layout when no slot is left to the CSR path.  A uniform-random graph has no numbering with
+    compact tiles: rejected (also by the renumbering attempt), it runs the CSR row tiles.  Source-scale mode: bit for bit
+    the reference's roundings."""
     side = 64 if backend.name == "emu" else 200
     n = side * side
     X = torch.randn(n, 64, generator=torch.Generator().manual_seed(3)).to(backend.device)
-    # (at the test double's 64 x 64 mesh the row-major numbering IS a +-96 band: the negative case there is a random graph)
-    for order, takes in (("hilbert", True), ("rowmajor" if side > 96 else "uniform", False)):
+    # (a row-major or shuffled mesh is laid out in a numbering of the library's own: test_spmm_ellw_renumbered_layout_*)
+    for order, takes in (("hilbert", True), ("uniform", False)):
         ei, ew = syn.uniform_graph(n, 8, seed=1) if order == "uniform" else syn.grid2d_graph(side, order, seed=1)
         G = ops.DConvGraph(backend.t(ei), backend.t(ew), n)
         csr = G.fwd_o
@@ -1596,7 +1596,8 @@ def test_aggregation_at_north_star_size():
     X1, X2 = torch.randn(n, F_, generator=gen).to(dev), torch.randn(n, F_, generator=gen).to(dev)
     for kind, graph in (("local", syn.local_graph), ("uniform", syn.uniform_graph),
                         ("grid2d_hilbert", lambda n_, d_, seed: syn.grid2d_graph(447, "hilbert", seed)),
-                        ("grid2d_rowmajor", lambda n_, d_, seed: syn.grid2d_graph(447, "rowmajor", seed))):
+                        ("grid2d_rowmajor", lambda n_, d_, seed: syn.grid2d_graph(447, "rowmajor", seed)),
+                        ("grid2d_shuffled", lambda n_, d_, seed: syn.grid2d_graph(447, "shuffled", seed))):
         ei, ew = graph(n, 8, seed=0)
         if kind.startswith("grid2d"):          # 447 x 447 = 199 809 nodes
             n = 447 * 447
@@ -1621,6 +1622,12 @@ def test_aggregation_at_north_star_size():
             # not a band (83 % of the slots within +-32 rows) but compact tiles: the ring of a tile's patch rides in the table
             # of distinct outside rows (~85 per tile through ~230 slots)
             assert csr.halo == 0 and e is not None and e.scale is not None and e.far_csr == 0 and e.far > 50_000
+            assert e.order is None
+        elif kind in ("grid2d_rowmajor", "grid2d_shuffled"):
+            # the caller's numbering hides the mesh's locality (bandwidth 447 / none at all): the library lays the operator
+            # out in patches of its own (pgt_tile_order_host) and the kernel goes through the order — same answer, same roundings
+            assert csr.halo == 0 and e is not None and e.order is not None and e.scale is not None and e.config == 3
+            assert e.far_csr <= 0.002 * nnz and e.tile_rows == 392
         else:
             assert not e and csr.halo == 0
         ops.spmm(csr, X2, Y2)
@@ -1641,7 +1648,7 @@ def test_aggregation_at_north_star_size():
         finally:
             lib.tune("spmm_tile_nt", 1)
             lib.tune("spmm_tile_rows", 32)
-        if kind in ("local", "grid2d_hilbert"):
+        if kind != "uniform":
             assert torch.equal(Y1.cpu(), source_scaled_reference(csr, X1))                 # the reference's roundings
             assert_close_with_nonfinite(Yc, Y1.cpu(), 1e-5, 1e-5, "CSR tiles vs ELLW")
         if kind == "local":
@@ -2046,3 +2053,85 @@ def test_split_bf16_kernels_reproduce_their_output_bit_for_bit_at_benchmark_size
         same(outs, "deterministic weight gradient")
     finally:
         ops.DETERMINISTIC_WEIGHT_GRADIENTS = False
+
+
+@pytest.mark.parametrize("cap,cus", [(0, 0), (48, 3)])
+def test_spmm_ellw_renumbered_layout_answers_in_the_callers_numbering(backend, cap, cus):
+    """An operator whose tiles are not compact in the caller's numbering (a mesh under a random permutation of its node
+    ids; a banded graph shuffled the same way, with 30 % long-range edges so that tiles overflow their table of outside
+    rows) laid out in a numbering of the library's own (pgt_tile_order_host + pgt_ellw.order): `spmm` still answers in the
+    CALLER's numbering, per-slot mode bit for bit the CSR kernels' fmaf chain, source-scale mode bit for bit the
+    reference's roundings (the rows keep their slots in the caller's order), with the epilogue, an aliased T, column
+    chunks, strided operands; shapes the window kernel does not cover run the caller's CSR."""
+    lib = _lib.get_lib()
+    lib.tune("spmm_ellw_rows", cap)
+    lib.tune("spmm_ellw_cus", cus)
+    try:
+        side = 30 if backend.name == "emu" else 150
+        n = side * side
+        rng = np.random.default_rng(11)
+        ei, ew = syn.grid2d_graph(side, "rowmajor", seed=2)
+        shuffle = rng.permutation(n)
+        G = ops.DConvGraph(backend.t(shuffle[ei]), backend.t(ew), n)
+        g = torch.Generator().manual_seed(5)
+        X, T = torch.randn(n, 64, generator=g).to(backend.device), torch.randn(n, 64, generator=g).to(backend.device)
+        for csr, scaled in ((G.fwd_o, True), (G.fwd_i, False)):
+            e = ops._force_renumbered(csr)
+            assert e is not None and e.order is not None and e.config == 3 and e.halo == 0
+            assert (e.scale is not None) == scaled and (cap == 0 or e.tile_rows <= cap)
+            assert torch.equal(torch.sort(e.order.cpu()).values, torch.arange(n, dtype=torch.int32))
+            assert e.far_csr == 0 and (e.far > 0 or e.n_tiles == 1)          # a patch's ring fits its table
+            Y = torch.full((n, 64), float("nan"), device=backend.device)
+            ops.spmm(csr, X, Y)
+            Yc = torch.empty_like(Y)
+            ops.spmm(csr, X, Yc, ellw=False)
+            if scaled:
+                assert torch.equal(Y.cpu(), source_scaled_reference(csr, X))
+                assert_close_with_nonfinite(Y, Yc, 1e-5, 1e-5, "source-scaled vs CSR kernels")
+            else:
+                assert torch.equal(Y, Yc)
+            Ya, Yb = T.clone(), T.clone()
+            ops.spmm(csr, X, Ya, T=Ya, alpha=0.5, beta=2.0)
+            ops.spmm(csr, X, Yb, T=Yb, alpha=0.5, beta=2.0, ellw=False)
+            if scaled:
+                assert_close_with_nonfinite(Ya, Yb, 1e-5, 1e-5, "epilogue")
+            else:
+                assert torch.equal(Ya, Yb)
+        # overflowing tables (slots served through the layout's CSR inside the gather), ragged rows, empty rows, wide operands
+        n2 = 500 if backend.name == "emu" else 20_000
+        base = banded_csr(n2, 0, 20, 12, seed=9, device=backend.device, far_frac=0.3)
+        sh = torch.from_numpy(rng.permutation(n2).astype(np.int32))
+        rp = base.rowptr.cpu().long()
+        lens = (rp[1:] - rp[:-1])
+        inv = torch.empty(n2, dtype=torch.long)
+        inv[sh.long()] = torch.arange(n2)
+        csr = ops.Csr.__new__(ops.Csr)
+        csr.n_rows, csr.halo, csr.max_len, csr.nnz, csr.ellw, csr.long_rows = n2, 0, -1, -1, None, None
+        new_lens = lens[inv]                                   # row i of the shuffled operator = row inv[i] of the banded one
+        new_rp = torch.zeros(n2 + 1, dtype=torch.long)
+        new_rp[1:] = torch.cumsum(new_lens, 0)
+        take = torch.cat([torch.arange(rp[inv[i]], rp[inv[i] + 1]) for i in range(n2)]) if backend.name == "emu" else \
+            (torch.repeat_interleave(rp[inv], new_lens) + torch.arange(int(new_rp[-1])) - torch.repeat_interleave(new_rp[:-1], new_lens))
+        csr.rowptr = new_rp.to(torch.int32).to(backend.device)
+        csr.col = sh[base.col.cpu().long()[take]].to(backend.device)
+        csr.val = base.val.cpu()[take].to(backend.device)
+        e = ops._force_renumbered(csr)
+        assert e is not None and e.vals is not None and (e.far_csr > 0 or cap != 0)      # uncapped tiles overflow their table
+        big = torch.randn(n2, 200, generator=g).to(backend.device)
+        Xw, Tw = big[:, 4:196], torch.randn(n2, 192, generator=g).to(backend.device)
+        Ya, Yb = torch.full((n2, 192), float("nan"), device=backend.device), torch.empty(n2, 192, device=backend.device)
+        ops.spmm(csr, Xw, Ya, T=Tw, alpha=2.0, beta=-1.0)
+        ops.spmm(csr, Xw, Yb, T=Tw, alpha=2.0, beta=-1.0, ellw=False)
+        assert torch.equal(Ya, Yb)
+        assert_close_with_nonfinite(Ya, spmm_reference(csr, Xw, Tw, 2.0, -1.0), 5e-5, 1e-5, "renumbered, wide")
+        for F_ in (32, 66):                                   # not a multiple of 64 / unaligned: the caller's CSR
+            Xf = torch.randn(n2, F_, generator=g).to(backend.device)
+            Yf = torch.empty_like(Xf)
+            ops.spmm(csr, Xf, Yf)
+            assert_close_with_nonfinite(Yf, spmm_reference(csr, Xf, None, 1.0, 0.0), 5e-5, 1e-5, f"F={F_}")
+        Xo, Yo = torch.randn(n2, 65, generator=g).to(backend.device)[:, 1:], torch.empty(n2, 64, device=backend.device)
+        ops.spmm(csr, Xo, Yo)
+        assert_close_with_nonfinite(Yo, spmm_reference(csr, Xo, None, 1.0, 0.0), 5e-5, 1e-5, "unaligned X")
+    finally:
+        lib.tune("spmm_ellw_rows", 0)
+        lib.tune("spmm_ellw_cus", 0)

@@ -465,7 +465,10 @@ def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup
     # (cached by tensor identity afterwards), code-object load of every kernel, growth of torch's caching allocator to the
     # 12.5 GB of saved activations (0.5-0.7 s the first time, 20 ms afterwards).  Its parameter update is undone.
     snapshot = flat.data.clone()
+    log("model, optimizer and batches built")
     step(0)
+    torch.cuda.synchronize()
+    log("initialisation pass done")
     flat.data.copy_(snapshot)
     opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)
     if graph:
@@ -585,6 +588,9 @@ def main():
         print(cpu_sweep_point(args.hidden, args.cpu_sweep_worker))
         return
     t_start = time.time()
+    if os.environ.get("PGT_BENCH_STACKS"):          # diagnostic: the Python stack on stderr every N seconds (where a slow box sits)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PGT_BENCH_STACKS"]), repeat=True, file=sys.stderr)
     over_budget = lambda: time.time() - t_start > args.aux_seconds      # noqa: E731
     args.batch_given = args.batch is not None
     if args.batch is None:

@@ -580,3 +580,36 @@ def test_dcrnn_cell_with_hops_on_a_small_graph_is_one_launch_each_way(backend, K
     for k in res[True][3]:
         ref = res[False][3][k]
         assert_close_with_nonfinite(res[True][3][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, k)
+
+
+def test_dconv_on_a_graph_whose_numbering_hides_its_locality(backend):
+    """`DConv(64, 64, K=3)` on a mesh whose node ids are shuffled (a sensor list in file order: dcrnn.py:300-313 aggregates over any
+    edge list): every hop of the stack and of its adjoint runs the window kernel through a patch order of the library's own
+    (ops.RenumberedEllw) — the module's output and every gradient equal the CSR row tiles' on the caller's numbering."""
+    from pytorch_geometric_temporal_amd import ops
+    side = 64 if backend.name == "emu" else 120
+    n = side * side
+    ei, ew = syn.grid2d_graph(side, "shuffled", seed=4)
+    ei, ew = backend.t(ei), backend.t(ew)
+    torch.manual_seed(2)
+    m = DConv(64, 64, 3).to(backend.device)
+    X0 = backend.t(torch.randn(n, 64))
+    outs = []
+    for renumber in (True, False):
+        ops.GRAPH_CACHE.clear()
+        saved, ops.USE_RENUMBER = ops.USE_RENUMBER, renumber
+        try:
+            X = X0.clone().requires_grad_(True)
+            m.zero_grad()
+            H = m(X, ei, ew)
+            (H * torch.linspace(-1, 1, 64, device=H.device)).sum().backward()
+            graphs = [v for v in ops.GRAPH_CACHE._d.values() if hasattr(v, "fwd_o")] + \
+                     [w for v in ops.GRAPH_CACHE._d.values() if isinstance(v, tuple) for w in v if hasattr(w, "fwd_o")]
+        finally:
+            ops.USE_RENUMBER = saved
+        assert graphs
+        for csr in (graphs[0].fwd_o, graphs[0].fwd_i, graphs[0].bwd_o, graphs[0].bwd_i):
+            assert bool(csr.ellw and csr.ellw.order is not None) == renumber
+        outs.append((H.detach(), X.grad.clone(), m.weight.grad.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("H", "dX", "dW")):
+        assert_close_with_nonfinite(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, what)

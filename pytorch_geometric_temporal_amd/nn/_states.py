@@ -70,6 +70,11 @@ def _plain(out):
 import weakref
 
 _PACKED = weakref.WeakKeyDictionary()
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+
+
+def _in_backward():
+    return _graph_task_id is not None and _graph_task_id() != -1
 
 
 def packed_once(module, params, build):
@@ -80,8 +85,11 @@ def packed_once(module, params, build):
     parameters change (`_version`) or a backward pass has run through them (a hook on the first operand: their
     autograd node is spent after that), so a T-step loop packs once and autograd sums the T gradients at the packed level.  Only
     while gradients are being recorded: an inference call packs for itself."""
-    if not (torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)):
-        return build()            # inference: one cheap launch per call and nothing to accumulate — and no way to go stale
+    if not (torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)) or _in_backward():
+        # inference: one cheap launch per call and nothing to accumulate — and no way to go stale.  A forward that runs INSIDE a
+        # backward pass (torch.utils.checkpoint re-running a segment) gets operands of its own: the cached ones belong to the graph
+        # being walked right now, and a second walk through their node would find it freed
+        return build()
     key = tuple((p.data_ptr(), p._version) if p is not None else None for p in params)
     hit = _PACKED.get(module)
     if hit is not None and hit[0] == key:

@@ -1008,3 +1008,29 @@ def test_cell_operands_are_packed_once_per_training_step(backend):
             assert counts[pack] == 2                          # inference packs per call
     finally:
         lib.call = orig
+
+
+def test_packed_operands_under_reentrant_checkpointing(backend):
+    """torch.utils.checkpoint(use_reentrant=True) re-runs a cell call INSIDE the backward pass: that forward must not pick up
+    the operands cached by the outer forward (their node is being walked; a second walk would find it freed) — gradients
+    equal the plain loop's."""
+    from torch.utils.checkpoint import checkpoint
+    torch.manual_seed(8)
+    n, B = 12, 2
+    ei_np, ew_np = syn.sensor_graph(n, 50, seed=1, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    m = TGCN2(2, 8, 1).to(backend.device)
+    xs = [backend.t(torch.randn(B, n, 2)) for _ in range(3)]
+    grads = []
+    for use_ckpt in (False, True):
+        m.zero_grad()
+        h = backend.t(torch.zeros(B, n, 8)).requires_grad_(True)
+        tot = 0
+        for i, x in enumerate(xs):                             # the first call outside a checkpoint: it caches the operands
+            h = checkpoint(lambda x_, h_: m(x_, ei, ew, h_).as_subclass(torch.Tensor), x, h, use_reentrant=True) \
+                if use_ckpt and i > 0 else m(x, ei, ew, h)
+            tot = tot + h.square().mean()
+        tot.backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for k in grads[0]:
+        assert_close_with_nonfinite(grads[1][k], grads[0][k], 1e-6 + 2e-5 * float(grads[0][k].abs().max()), 1e-5, k)

@@ -11,6 +11,12 @@
 //   backward (hand-written BPTT): the TRANSPOSED operators in LDS; per step the gate adjoints, the stack gradients d_pre W^T, the
 //     adjoint hops, the weight-gradient sums (each (k, n) entry owned by one thread of the sample's workgroup and accumulated
 //     over the steps in a per-sample buffer: no atomics, the samples are summed by the caller in index order).
+// Global memory is never a hand-off between the threads of a launch (X, the saved activations and the output are read or written,
+// never both; a weight-gradient partial belongs to one thread): every barrier is an LDS-only barrier (PGT_LDS_BARRIER), so the
+// stores of a step drain while the next phases run instead of being acknowledged at each of the 2K + 2 barriers (1.02 -> 0.985 ms
+// per training step of the reference's BatchedDCRNN(2, 2, K = 3) at 64 windows).  Measured and dropped (profiles/r04l_*): the
+// reads of a step requested a phase ahead into registers and the weight-gradient sums kept in registers — 1.035 ms, and 100
+// more VGPRs: a phase is bound by its dependent LDS chains at two wavefronts per SIMD, not by its few global round trips.
 // The forward saves, per (sample, step), both stacks, Z | R and the candidate (2 S N C + 3 N O floats: 40 KB at the METR-LA
 // shape) for the backward pass; sums run in the order of the general path (slot order per row, k order per product).
 #include "pgt_common.h"
@@ -47,13 +53,14 @@ struct SqLds {
   float* HT;      // [N][O]   (backward)
   float* dH;      // [N][O]   running state gradient (backward)
   float* dP;      // [N][3 O] pre-activation gradients: zr | h (backward)
+  float* red;     // [SQ_THREADS] partial sums of the weight-gradient entries (backward)
   const float* Wzr; const float* Wh;        // the weights as the kernel reads them: LDS copies, or the global arrays
 };
 
 static size_t sq_lds_bytes(int64_t N, int64_t E_o, int64_t E_i, int64_t C, int64_t O, int64_t K, bool bwd, bool w_lds = false) {
   const int64_t S = 2 * K - 1;
   size_t b = 2 * (size_t)(N + 1) * 4 + (size_t)(E_o + E_i) * 8 + (size_t)S * N * C * 4 + (size_t)N * O * 4 + (size_t)N * 2 * O * 4;
-  if (bwd) b += (size_t)S * N * C * 4 + (size_t)N * O * 4 * 2 + (size_t)N * 3 * O * 4;
+  if (bwd) b += (size_t)S * N * C * 4 + (size_t)N * O * 4 * 2 + (size_t)N * 3 * O * 4 + (size_t)SQ_THREADS * 4;
   if (w_lds) b += (size_t)S * C * 3 * O * 4;
   return b + 64;
 }
@@ -70,12 +77,13 @@ __device__ __forceinline__ SqLds sq_carve(char* base, const SeqArgs& a, bool bwd
   s.TS = reinterpret_cast<float*>(p); p += (size_t)S * a.N * C * 4;
   s.H = reinterpret_cast<float*>(p); p += (size_t)a.N * a.O * 4;
   s.ZR = reinterpret_cast<float*>(p); p += (size_t)a.N * 2 * a.O * 4;
-  s.TV = s.HT = s.dH = s.dP = nullptr;
+  s.TV = s.HT = s.dH = s.dP = s.red = nullptr;
   if (bwd) {
     s.TV = reinterpret_cast<float*>(p); p += (size_t)S * a.N * C * 4;
     s.HT = reinterpret_cast<float*>(p); p += (size_t)a.N * a.O * 4;
     s.dH = reinterpret_cast<float*>(p); p += (size_t)a.N * a.O * 4;
     s.dP = reinterpret_cast<float*>(p); p += (size_t)a.N * 3 * a.O * 4;
+    s.red = reinterpret_cast<float*>(p); p += (size_t)SQ_THREADS * 4;
   }
   s.Wzr = a.Wzr; s.Wh = a.Wh;
   if (a.w_lds) {
@@ -128,7 +136,7 @@ __device__ __forceinline__ void sq_hops(const SeqArgs& a, const SqLds& s, int ti
       const float g = d ? sq_row(s.rp_i, s.cv_i, src, n, c, C) : sq_row(s.rp_o, s.cv_o, src, n, c, C);
       s.TS[(size_t)(2 * k - 1 + d) * NC + r] = k == 1 ? g : 2.f * g - s.TS[r];
     }
-    __syncthreads();
+    PGT_LDS_BARRIER();
   }
 }
 
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
   const int64_t per_step = (int64_t)2 * S * NC + 3 * NO;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     for (int e = tid; e < NO; e += SQ_THREADS) s.H[e] = a.H0 ? a.H0[(int64_t)b * NO + e] : 0.f;
-    __syncthreads();
+    PGT_LDS_BARRIER();
     for (int t = 0; t < a.T; ++t) {
       const float* x = a.X + b * a.x_sb + t * a.x_st;
       float* sv = a.save ? a.save + ((int64_t)b * a.T + t) * per_step : nullptr;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
         const int n = e / C, c = e - n * C;
         s.TS[e] = c < a.Fin ? x[n * a.Fin + c] : s.H[n * O + (c - a.Fin)];
       }
-      __syncthreads();
+      PGT_LDS_BARRIER();
       sq_hops(a, s, tid);
       for (int e = tid; e < 2 * NO; e += SQ_THREADS) {       // Z | R = sigmoid(stack Wzr + bzr)
         const int n = e / (2 * O), j = e - n * 2 * O;
@@ -173,12 +181,12 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
         if (sv) sv[(int64_t)2 * S * NC + e] = v;
       }
       if (sv) for (int e = tid; e < S * NC; e += SQ_THREADS) sv[e] = s.TS[e];
-      __syncthreads();
+      PGT_LDS_BARRIER();
       for (int e = tid; e < NO; e += SQ_THREADS) {           // segment 0 = [X_t | H * R]
         const int n = e / O, o = e - n * O;
         s.TS[n * C + a.Fin + o] = s.H[e] * s.ZR[n * 2 * O + O + o];
       }
-      __syncthreads();
+      PGT_LDS_BARRIER();
       sq_hops(a, s, tid);
       float* o_t = a.out + b * a.o_sb + t * a.o_st;
       for (int e = tid; e < NO; e += SQ_THREADS) {           // candidate, blend, H_t
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
         s.H[e] = hn;                                          // (n, o) is read by this thread only in this phase
       }
       if (sv) for (int e = tid; e < S * NC; e += SQ_THREADS) sv[(int64_t)S * NC + e] = s.TS[e];
-      __syncthreads();
+      PGT_LDS_BARRIER();
     }
   }
 }
@@ -207,14 +215,14 @@ __device__ __forceinline__ void sq_hops_adjoint(const SeqArgs& a, const SqLds& s
       G[(size_t)(2 * (k - 1) - 1 + d) * NC + r] += 2.f * g;
     }
     for (int r = tid; r < NC; r += SQ_THREADS) G[r] -= G[(size_t)(2 * k - 1) * NC + r] + G[(size_t)(2 * k) * NC + r];
-    __syncthreads();
+    PGT_LDS_BARRIER();
   }
   if (a.K >= 2) {
     for (int r = tid; r < NC; r += SQ_THREADS) {
       const int n = r / C, c = r - n * C;
       G[r] += sq_row(s.rp_o, s.cv_o, G + NC, n, c, C) + sq_row(s.rp_i, s.cv_i, G + 2 * (size_t)NC, n, c, C);
     }
-    __syncthreads();
+    PGT_LDS_BARRIER();
   }
 }
 
@@ -223,18 +231,51 @@ __device__ __forceinline__ void sq_hops_adjoint(const SeqArgs& a, const SqLds& s
 __device__ __forceinline__ void sq_product_adjoint(const SeqArgs& a, const SqLds& s, const float* __restrict__ W, int ldw, int j0,
                                                    float* dW, float* db, int tid) {
   const int C = a.Fin + a.O, O = a.O, S = 2 * a.K - 1, NC = a.N * C;
-  for (int e = tid; e < S * C * ldw; e += SQ_THREADS) {
-    const int sc = e / ldw, j = e - sc * ldw, sg = sc / C, c = sc - sg * C;
-    const float* tv = s.TV + (size_t)sg * NC + c;
-    float acc = 0.f;
+  const int nE = S * C * ldw, nAll = nE + ldw;               // weight entries, then the bias entries
+  int P = SQ_THREADS / nAll;
+  if (P > 16) P = 16;
+  if (P >= 2) {
+    // narrow cells (the reference's BatchedDCRNN(2, 2, K = 3): 80 + 4 entries): one thread per entry would walk all N nodes in a
+    // dependent chain while 400 threads idle — the nodes are cut into P runs, a thread sums one run of one entry, the runs of an
+    // entry are added in run order (a fixed order: deterministic)
+    const int run = (a.N + P - 1) / P;
+    if (tid < nAll * P) {
+      const int p = tid / nAll, e = tid - p * nAll;
+      const int n0 = p * run, n1 = n0 + run < a.N ? n0 + run : a.N;
+      float acc = 0.f;
+      if (e < nE) {
+        const int sc = e / ldw, j = e - sc * ldw, sg = sc / C, c = sc - sg * C;
+        const float* tv = s.TV + (size_t)sg * NC + c;
 #pragma unroll 4
-    for (int n = 0; n < a.N; ++n) acc = fmaf(tv[n * C], s.dP[n * 3 * O + j0 + j], acc);
-    dW[e] += acc;
-  }
-  for (int j = tid; j < ldw; j += SQ_THREADS) {
-    float acc = 0.f;
-    for (int n = 0; n < a.N; ++n) acc += s.dP[n * 3 * O + j0 + j];
-    db[j] += acc;
+        for (int n = n0; n < n1; ++n) acc = fmaf(tv[n * C], s.dP[n * 3 * O + j0 + j], acc);
+      } else {
+#pragma unroll 4
+        for (int n = n0; n < n1; ++n) acc += s.dP[n * 3 * O + j0 + (e - nE)];
+      }
+      s.red[tid] = acc;
+    }
+    PGT_LDS_BARRIER();
+    if (tid < nAll) {
+      float t = 0.f;
+      for (int p = 0; p < P; ++p) t += s.red[p * nAll + tid];
+      if (tid < nE) dW[tid] += t;
+      else db[tid - nE] += t;
+    }
+  } else {
+    for (int e = tid; e < nE; e += SQ_THREADS) {
+      const int sc = e / ldw, j = e - sc * ldw, sg = sc / C, c = sc - sg * C;
+      const float* tv = s.TV + (size_t)sg * NC + c;
+      float acc = 0.f;
+#pragma unroll 4
+      for (int n = 0; n < a.N; ++n) acc = fmaf(tv[n * C], s.dP[n * 3 * O + j0 + j], acc);
+      dW[e] += acc;
+    }
+    for (int j = tid; j < ldw; j += SQ_THREADS) {
+      float acc = 0.f;
+#pragma unroll 4
+      for (int n = 0; n < a.N; ++n) acc += s.dP[n * 3 * O + j0 + j];
+      db[j] += acc;
+    }
   }
   for (int e = tid; e < S * NC; e += SQ_THREADS) {
     const int sg = e / NC, r = e - sg * NC, n = r / C, c = r - n * C;
@@ -262,7 +303,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
     float* dbzr = dWh + (int64_t)S * C * O;
     float* dbh = dbzr + 2 * O;
     for (int e = tid; e < NO; e += SQ_THREADS) s.dH[e] = 0.f;
-    __syncthreads();
+    PGT_LDS_BARRIER();
     for (int t = a.T - 1; t >= 0; --t) {
       const float* sv = a.save + ((int64_t)b * a.T + t) * per_step;
       const float* g_t = a.dOut + b * a.g_sb + t * a.g_st;
@@ -280,9 +321,9 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
         s.dH[e] = g * z;
       }
       for (int e = tid; e < S * NC; e += SQ_THREADS) s.TV[e] = sv[(int64_t)S * NC + e];
-      __syncthreads();
+      PGT_LDS_BARRIER();
       sq_product_adjoint(a, s, s.Wh, O, 2 * O, dWh, dbh, tid);
-      __syncthreads();
+      PGT_LDS_BARRIER();
       sq_hops_adjoint(a, s, s.TS, tid);
       // ---- d(H R): the reset gate's pre-activation, the state; the input columns of this stack's d/dT0
       float* dx = a.dX ? a.dX + b * a.x_sb + t * a.x_st : nullptr;
@@ -294,16 +335,16 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
       }
       if (dx) for (int e = tid; e < a.N * a.Fin; e += SQ_THREADS) { const int n = e / a.Fin, f = e - n * a.Fin; dx[e] = s.TS[n * C + f]; }
       for (int e = tid; e < S * NC; e += SQ_THREADS) s.TV[e] = sv[e];
-      __syncthreads();
+      PGT_LDS_BARRIER();
       sq_product_adjoint(a, s, s.Wzr, 2 * O, 0, dWzr, dbzr, tid);
-      __syncthreads();
+      PGT_LDS_BARRIER();
       sq_hops_adjoint(a, s, s.TS, tid);
       for (int e = tid; e < NO; e += SQ_THREADS) { const int n = e / O, o = e - n * O; s.dH[e] += s.TS[n * C + a.Fin + o]; }
       if (dx) for (int e = tid; e < a.N * a.Fin; e += SQ_THREADS) { const int n = e / a.Fin, f = e - n * a.Fin; dx[e] += s.TS[n * C + f]; }
-      __syncthreads();
+      PGT_LDS_BARRIER();
     }
     if (a.dH0) for (int e = tid; e < NO; e += SQ_THREADS) a.dH0[(int64_t)b * NO + e] = s.dH[e];
-    __syncthreads();
+    PGT_LDS_BARRIER();
   }
 }
 

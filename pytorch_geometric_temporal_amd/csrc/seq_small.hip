@@ -126,15 +126,52 @@ __device__ __forceinline__ float sq_row(const int* rp, const int2* cv, const flo
   return acc;
 }
 
+// the same row sum for the four channels of a quad at once (C a multiple of 4: the reference's BatchedDCRNN(2, 2) has C = 4, a
+// node's whole row): a slot is read ONCE per quad instead of once per channel and the source as one ds_read_b128 — a quarter of the
+// LDS instructions, and a hop level is one element per thread instead of four in a row.  Per channel the same fmaf chain.
+__device__ __forceinline__ pgt_f4 sq_row4(const int* rp, const int2* cv, const float* src, int n, int c4, int C) {
+  pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+  int q = rp[n];
+  const int e = rp[n + 1];
+  for (; q < e; q += 4) {                              // up to four slots in flight; a short last batch re-reads slot q (never added)
+    int2 s4[4];
+    pgt_f4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] = cv[q + u < e ? q + u : q];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const pgt_f4*>(src + s4[u].x * C + c4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = sq_as_float(s4[u].y);
+      if (q + u < e) acc = pgt_mk4(fmaf(v, x[u].x, acc.x), fmaf(v, x[u].y, acc.y), fmaf(v, x[u].z, acc.z), fmaf(v, x[u].w, acc.w));
+    }
+  }
+  return acc;
+}
+__device__ __forceinline__ pgt_f4 sq_ld4(const float* p) { return *reinterpret_cast<const pgt_f4*>(p); }
+__device__ __forceinline__ void sq_st4(float* p, pgt_f4 v) { *reinterpret_cast<pgt_f4*>(p) = v; }
+
 // the K - 1 hop levels on TS (segment 0 given): T1d = P_d T0, Tkd = 2 P_d T(k-1)d - T0   (dcrnn.py:85-106; Tx_0 is never advanced)
 __device__ __forceinline__ void sq_hops(const SeqArgs& a, const SqLds& s, int tid) {
   const int C = a.Fin + a.O, NC = a.N * C;
   for (int k = 1; k < a.K; ++k) {
-    for (int e = tid; e < 2 * NC; e += SQ_THREADS) {
-      const int d = e >= NC, r = e - d * NC, n = r / C, c = r - n * C;
-      const float* src = s.TS + (size_t)(k == 1 ? 0 : 2 * (k - 1) - 1 + d) * NC;
-      const float g = d ? sq_row(s.rp_i, s.cv_i, src, n, c, C) : sq_row(s.rp_o, s.cv_o, src, n, c, C);
-      s.TS[(size_t)(2 * k - 1 + d) * NC + r] = k == 1 ? g : 2.f * g - s.TS[r];
+    if ((C & 3) == 0) {
+      const int Q = C >> 2, NQ = a.N * Q;
+      for (int e = tid; e < 2 * NQ; e += SQ_THREADS) {
+        const int d = e >= NQ, r = e - d * NQ, n = r / Q, off = n * C + 4 * (r - n * Q);
+        const float* src = s.TS + (size_t)(k == 1 ? 0 : 2 * (k - 1) - 1 + d) * NC;
+        const pgt_f4 g = sq_row4(d ? s.rp_i : s.rp_o, d ? s.cv_i : s.cv_o, src, n, off - n * C, C);
+        const pgt_f4 t0 = sq_ld4(s.TS + off);
+        sq_st4(s.TS + (size_t)(2 * k - 1 + d) * NC + off,
+               k == 1 ? g : pgt_mk4(2.f * g.x - t0.x, 2.f * g.y - t0.y, 2.f * g.z - t0.z, 2.f * g.w - t0.w));
+      }
+    } else {
+      for (int e = tid; e < 2 * NC; e += SQ_THREADS) {
+        const int d = e >= NC, r = e - d * NC, n = r / C, c = r - n * C;
+        const float* src = s.TS + (size_t)(k == 1 ? 0 : 2 * (k - 1) - 1 + d) * NC;
+        const float g = d ? sq_row(s.rp_i, s.cv_i, src, n, c, C) : sq_row(s.rp_o, s.cv_o, src, n, c, C);
+        s.TS[(size_t)(2 * k - 1 + d) * NC + r] = k == 1 ? g : 2.f * g - s.TS[r];
+      }
     }
     PGT_LDS_BARRIER();
   }
@@ -207,20 +244,45 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
 //   Tkd = 2 P_d T(k-1)d - T0 (k >= 2)  ->  G(k-1)d += 2 P_d^T Gkd,  G0 -= Gkd;     T1d = P_d T0  ->  G0 += P_d^T G1d
 __device__ __forceinline__ void sq_hops_adjoint(const SeqArgs& a, const SqLds& s, float* G, int tid) {
   const int C = a.Fin + a.O, NC = a.N * C;
+  const bool quads = (C & 3) == 0;
+  const int Q = C >> 2, NQ = a.N * Q;
   for (int k = a.K - 1; k >= 2; --k) {
-    for (int e = tid; e < 2 * NC; e += SQ_THREADS) {
-      const int d = e >= NC, r = e - d * NC, n = r / C, c = r - n * C;
-      const float* src = G + (size_t)(2 * k - 1 + d) * NC;
-      const float g = d ? sq_row(s.rp_i, s.cv_i, src, n, c, C) : sq_row(s.rp_o, s.cv_o, src, n, c, C);
-      G[(size_t)(2 * (k - 1) - 1 + d) * NC + r] += 2.f * g;
+    if (quads) {
+      for (int e = tid; e < 2 * NQ; e += SQ_THREADS) {
+        const int d = e >= NQ, r = e - d * NQ, n = r / Q, c4 = 4 * (r - n * Q);
+        const float* src = G + (size_t)(2 * k - 1 + d) * NC;
+        const pgt_f4 g = sq_row4(d ? s.rp_i : s.rp_o, d ? s.cv_i : s.cv_o, src, n, c4, C);
+        float* at = G + (size_t)(2 * (k - 1) - 1 + d) * NC + n * C + c4;
+        const pgt_f4 old = sq_ld4(at);
+        sq_st4(at, pgt_mk4(old.x + 2.f * g.x, old.y + 2.f * g.y, old.z + 2.f * g.z, old.w + 2.f * g.w));
+      }
+    } else {
+      for (int e = tid; e < 2 * NC; e += SQ_THREADS) {
+        const int d = e >= NC, r = e - d * NC, n = r / C, c = r - n * C;
+        const float* src = G + (size_t)(2 * k - 1 + d) * NC;
+        const float g = d ? sq_row(s.rp_i, s.cv_i, src, n, c, C) : sq_row(s.rp_o, s.cv_o, src, n, c, C);
+        G[(size_t)(2 * (k - 1) - 1 + d) * NC + r] += 2.f * g;
+      }
     }
     for (int r = tid; r < NC; r += SQ_THREADS) G[r] -= G[(size_t)(2 * k - 1) * NC + r] + G[(size_t)(2 * k) * NC + r];
     PGT_LDS_BARRIER();
   }
   if (a.K >= 2) {
-    for (int r = tid; r < NC; r += SQ_THREADS) {
-      const int n = r / C, c = r - n * C;
-      G[r] += sq_row(s.rp_o, s.cv_o, G + NC, n, c, C) + sq_row(s.rp_i, s.cv_i, G + 2 * (size_t)NC, n, c, C);
+    if (quads) {
+      for (int r = tid; r < NQ; r += SQ_THREADS) {
+        const int n = r / Q, c4 = 4 * (r - n * Q);
+        const pgt_f4 go = sq_row4(s.rp_o, s.cv_o, G + NC, n, c4, C);
+        PGT_SCHED_FENCE();                                   // one direction after the other: interleaved they only cost registers
+        const pgt_f4 gi = sq_row4(s.rp_i, s.cv_i, G + 2 * (size_t)NC, n, c4, C);
+        float* at = G + n * C + c4;
+        const pgt_f4 old = sq_ld4(at);
+        sq_st4(at, pgt_mk4(old.x + (go.x + gi.x), old.y + (go.y + gi.y), old.z + (go.z + gi.z), old.w + (go.w + gi.w)));
+      }
+    } else {
+      for (int r = tid; r < NC; r += SQ_THREADS) {
+        const int n = r / C, c = r - n * C;
+        G[r] += sq_row(s.rp_o, s.cv_o, G + NC, n, c, C) + sq_row(s.rp_i, s.cv_i, G + 2 * (size_t)NC, n, c, C);
+      }
     }
     PGT_LDS_BARRIER();
   }
@@ -238,6 +300,7 @@ __device__ __forceinline__ void sq_product_adjoint(const SeqArgs& a, const SqLds
     // narrow cells (the reference's BatchedDCRNN(2, 2, K = 3): 80 + 4 entries): one thread per entry would walk all N nodes in a
     // dependent chain while 400 threads idle — the nodes are cut into P runs, a thread sums one run of one entry, the runs of an
     // entry are added in run order (a fixed order: deterministic)
+    // (unroll 2, not 4: with the deeper unroll the kernel needs 142 VGPRs and only ONE workgroup fits a CU — B = 1024 loses 12 %)
     const int run = (a.N + P - 1) / P;
     if (tid < nAll * P) {
       const int p = tid / nAll, e = tid - p * nAll;
@@ -246,10 +309,10 @@ __device__ __forceinline__ void sq_product_adjoint(const SeqArgs& a, const SqLds
       if (e < nE) {
         const int sc = e / ldw, j = e - sc * ldw, sg = sc / C, c = sc - sg * C;
         const float* tv = s.TV + (size_t)sg * NC + c;
-#pragma unroll 4
+#pragma unroll 2
         for (int n = n0; n < n1; ++n) acc = fmaf(tv[n * C], s.dP[n * 3 * O + j0 + j], acc);
       } else {
-#pragma unroll 4
+#pragma unroll 2
         for (int n = n0; n < n1; ++n) acc += s.dP[n * 3 * O + j0 + (e - nE)];
       }
       s.red[tid] = acc;

@@ -465,10 +465,14 @@ def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup
     # (cached by tensor identity afterwards), code-object load of every kernel, growth of torch's caching allocator to the
     # 12.5 GB of saved activations (0.5-0.7 s the first time, 20 ms afterwards).  Its parameter update is undone.
     snapshot = flat.data.clone()
-    log("model, optimizer and batches built")
+    first = not getattr(train_run, "_marked", False)      # stage marks for the headline run only (the variants repeat them)
+    train_run._marked = True
+    if first:
+        log("model, optimizer and batches built")
     step(0)
-    torch.cuda.synchronize()
-    log("initialisation pass done")
+    if first:
+        torch.cuda.synchronize()
+        log("initialisation pass done")
     flat.data.copy_(snapshot)
     opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)
     if graph:

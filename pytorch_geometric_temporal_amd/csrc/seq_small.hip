@@ -21,6 +21,11 @@
 // shape) for the backward pass; sums run in the order of the general path (slot order per row, k order per product).
 #include "pgt_common.h"
 
+// lab/seq_small_lab.hip defines this to record a per-workgroup phase timeline (step, slot); a no-op in the library
+#ifndef PGT_SEQ_MARK
+#define PGT_SEQ_MARK(step, slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int SQ_THREADS = 512;
@@ -210,7 +215,9 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
         s.TS[e] = c < a.Fin ? x[n * a.Fin + c] : s.H[n * O + (c - a.Fin)];
       }
       PGT_LDS_BARRIER();
+      PGT_SEQ_MARK(t, 0);                                    // [X_t | H] staged
       sq_hops(a, s, tid);
+      PGT_SEQ_MARK(t, 1);                                    // hops of the z | r stack
       for (int e = tid; e < 2 * NO; e += SQ_THREADS) {       // Z | R = sigmoid(stack Wzr + bzr)
         const int n = e / (2 * O), j = e - n * 2 * O;
         const float v = pgt_sigmoidf(sq_dot(a, s.TS, s.Wzr, 2 * O, n, j) + (a.bzr ? a.bzr[j] : 0.f));
@@ -219,12 +226,14 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
       }
       if (sv) for (int e = tid; e < S * NC; e += SQ_THREADS) sv[e] = s.TS[e];
       PGT_LDS_BARRIER();
+      PGT_SEQ_MARK(t, 2);                                    // z | r product, sigmoid, stack saved
       for (int e = tid; e < NO; e += SQ_THREADS) {           // segment 0 = [X_t | H * R]
         const int n = e / O, o = e - n * O;
         s.TS[n * C + a.Fin + o] = s.H[e] * s.ZR[n * 2 * O + O + o];
       }
       PGT_LDS_BARRIER();
       sq_hops(a, s, tid);
+      PGT_SEQ_MARK(t, 3);                                    // H * R, hops of the candidate's stack
       float* o_t = a.out + b * a.o_sb + t * a.o_st;
       for (int e = tid; e < NO; e += SQ_THREADS) {           // candidate, blend, H_t
         const int n = e / O, o = e - n * O;
@@ -236,6 +245,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
       }
       if (sv) for (int e = tid; e < S * NC; e += SQ_THREADS) sv[(int64_t)S * NC + e] = s.TS[e];
       PGT_LDS_BARRIER();
+      PGT_SEQ_MARK(t, 4);                                    // candidate product, blend, H_t out, stack saved
     }
   }
 }
@@ -385,9 +395,12 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
       }
       for (int e = tid; e < S * NC; e += SQ_THREADS) s.TV[e] = sv[(int64_t)S * NC + e];
       PGT_LDS_BARRIER();
+      PGT_SEQ_MARK(a.T - 1 - t, 0);                          // gate adjoints, the candidate's saved stack in LDS
       sq_product_adjoint(a, s, s.Wh, O, 2 * O, dWh, dbh, tid);
       PGT_LDS_BARRIER();
+      PGT_SEQ_MARK(a.T - 1 - t, 1);                          // candidate product adjoint (weight sums + stack gradient)
       sq_hops_adjoint(a, s, s.TS, tid);
+      PGT_SEQ_MARK(a.T - 1 - t, 2);                          // adjoint hops
       // ---- d(H R): the reset gate's pre-activation, the state; the input columns of this stack's d/dT0
       float* dx = a.dX ? a.dX + b * a.x_sb + t * a.x_st : nullptr;
       for (int e = tid; e < NO; e += SQ_THREADS) {
@@ -399,9 +412,12 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
       if (dx) for (int e = tid; e < a.N * a.Fin; e += SQ_THREADS) { const int n = e / a.Fin, f = e - n * a.Fin; dx[e] = s.TS[n * C + f]; }
       for (int e = tid; e < S * NC; e += SQ_THREADS) s.TV[e] = sv[e];
       PGT_LDS_BARRIER();
+      PGT_SEQ_MARK(a.T - 1 - t, 3);                          // d(H R), the z | r stack in LDS
       sq_product_adjoint(a, s, s.Wzr, 2 * O, 0, dWzr, dbzr, tid);
       PGT_LDS_BARRIER();
+      PGT_SEQ_MARK(a.T - 1 - t, 4);                          // z | r product adjoint
       sq_hops_adjoint(a, s, s.TS, tid);
+      PGT_SEQ_MARK(a.T - 1 - t, 5);                          // adjoint hops
       for (int e = tid; e < NO; e += SQ_THREADS) { const int n = e / O, o = e - n * O; s.dH[e] += s.TS[n * C + a.Fin + o]; }
       if (dx) for (int e = tid; e < a.N * a.Fin; e += SQ_THREADS) { const int n = e / a.Fin, f = e - n * a.Fin; dx[e] += s.TS[n * C + f]; }
       PGT_LDS_BARRIER();

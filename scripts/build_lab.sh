@@ -3,7 +3,7 @@
 # GPU box with gpurun)
 cd "$(dirname "$0")/.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include -I pytorch_geometric_temporal_amd/csrc"
-for h in ellw_lab ellw_prod_lab gemm_lab gemm_bx_lab gemm_bx_tn_lab slab_lab; do
+for h in ellw_lab ellw_prod_lab gemm_lab gemm_bx_lab gemm_bx_tn_lab slab_lab seq_small_lab; do
   /opt/rocm/bin/hipcc $FLAGS lab/$h.hip -o lab/$h || exit 1
 done
 # the shipped K-split split-bf16 kernel, taken apart at compile time (BX_SKIP mask: 1 no MFMAs, 4 no epilogue stores, 8 no loads

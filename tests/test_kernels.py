@@ -2135,3 +2135,75 @@ def test_spmm_ellw_renumbered_layout_answers_in_the_callers_numbering(backend, c
     finally:
         lib.tune("spmm_ellw_rows", 0)
         lib.tune("spmm_ellw_cus", 0)
+
+
+try:
+    from hypothesis import HealthCheck, given, settings, strategies as hst
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(n=hst.integers(1, 90), deg=hst.integers(0, 12), components=hst.integers(1, 4), tile=hst.sampled_from([4, 8, 20, 0]),
+           far=hst.floats(0.0, 0.5), scaled=hst.booleans(), epilogue=hst.booleans(), seed=hst.integers(0, 10_000))
+    def test_fuzz_renumbered_layout(emu_backend, n, deg, components, tile, far, scaled, epilogue, seed):
+        """pgt_tile_order_host + the renumbered window kernel over random operators: empty rows, self-loops, duplicate slots,
+        several components, fewer rows than a tile, tiles forced down to four rows, long-range slots that overflow the table —
+        the order is a permutation, the layout operator is the caller's in that numbering with every row's slots in the
+        caller's order, and the product equals the CSR kernels' on the caller's numbering (per-slot mode bit for bit)."""
+        lib = _lib.get_lib()
+        rng = np.random.default_rng(seed)
+        degs = rng.integers(0, deg + 1, size=n)
+        rowptr = np.zeros(n + 1, dtype=np.int32)
+        rowptr[1:] = np.cumsum(degs)
+        rows = np.repeat(np.arange(n), degs)
+        comp = rows % components                                        # sources mostly in the row's own component, nearby
+        col = (rows + components * rng.integers(-3, 4, size=rows.size)) % n
+        col = np.where(col % components == comp, col, rows)             # (wrap-around may leave the component: self-loop then)
+        jump = rng.random(rows.size) < far
+        col[jump] = rng.integers(0, n, size=int(jump.sum()))
+        val = (0.25 + rng.random(n)).astype(np.float32)[col] if scaled else rng.standard_normal(rows.size).astype(np.float32)
+        shuffle = rng.permutation(n)                                    # the caller's numbering hides whatever structure there is
+        inv = np.empty(n, dtype=np.int64)
+        inv[shuffle] = np.arange(n)
+        new_rows = shuffle[rows]
+        order = np.argsort(new_rows, kind="stable")                     # keeps every row's slots in their original order
+        csr = ops.Csr.__new__(ops.Csr)
+        csr.n_rows, csr.halo, csr.max_len, csr.nnz, csr.ellw, csr.long_rows = n, 0, -1, -1, None, None
+        rp2 = np.zeros(n + 1, dtype=np.int32)
+        rp2[1:] = np.cumsum(np.bincount(new_rows, minlength=n))
+        dev = emu_backend.device
+        csr.rowptr = torch.from_numpy(rp2).to(dev)
+        csr.col = torch.from_numpy(shuffle[col][order].astype(np.int32)).to(dev) if rows.size else torch.zeros(1, dtype=torch.int32)
+        csr.val = torch.from_numpy(val[order]).to(dev) if rows.size else torch.zeros(1)
+        lib.tune("spmm_ellw_rows", tile)
+        lib.tune("spmm_ellw_cus", 2)
+        try:
+            e = ops._force_renumbered(csr)
+            if rows.size == 0:
+                assert e is None
+                return
+            assert e is not None and e.order is not None and e.config == 3
+            o = e.order.cpu().numpy()
+            assert np.array_equal(np.sort(o), np.arange(n))
+            pos = np.empty(n, dtype=np.int64)
+            pos[o] = np.arange(n)
+            lay_rp, lay_col = e.csr.rowptr.cpu().numpy(), e.csr.col.cpu().numpy()
+            for p in range(n):                                          # layout row p = the caller's row o[p], slots in the caller's order
+                a, b = rp2[o[p]], rp2[o[p] + 1]
+                assert lay_rp[p + 1] - lay_rp[p] == b - a
+                assert np.array_equal(lay_col[lay_rp[p]:lay_rp[p + 1]], pos[csr.col.cpu().numpy()[a:b]])
+            g = torch.Generator().manual_seed(seed)
+            X, T = torch.randn(n, 64, generator=g).to(dev), torch.randn(n, 64, generator=g).to(dev)
+            Ya, Yb = torch.full((n, 64), float("nan")), torch.empty(n, 64)
+            kw = dict(T=T, alpha=1.5, beta=-0.5) if epilogue else {}
+            ops.spmm(csr, X, Ya, **kw)
+            ops.spmm(csr, X, Yb, ellw=False, **kw)
+            if e.vals is not None:
+                assert torch.equal(Ya, Yb)
+            else:
+                assert_close_with_nonfinite(Ya, Yb, 1e-5, 1e-5, "source-scale mode vs the CSR kernels")
+                if not epilogue:
+                    assert torch.equal(Ya, source_scaled_reference(csr, X))
+        finally:
+            lib.tune("spmm_ellw_rows", 0)
+            lib.tune("spmm_ellw_cus", 0)
+except ImportError:      # hypothesis is optional
+    pass

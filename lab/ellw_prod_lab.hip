@@ -8,17 +8,8 @@
 #include <algorithm>
 #include <vector>
 
-void pgt_gemm_set_force_small(int) {}
-void pgt_gemm_set_small_fill(int) {}
-void pgt_gemm_set_tn_fullk(int) {}
-void pgt_gemm_set_db(int) {}
-void pgt_gemm_set_db64(int) {}
-void pgt_slab_set_pairs(int) {}
-void pgt_gemm_set_tn_pipe(int) {}
-void pgt_gemm_set_skinny(int) {}
-void pgt_gemm_set_dbp(int) {}
-void pgt_gemm_bx_set(int) {}
-void pgt_gemm_bx_sym_set(int) {}
+#define LAB_HAS_SPMM
+#include "lab_stubs.h"
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/spmm.hip"
 

@@ -14,16 +14,14 @@
 #include <algorithm>
 #include <vector>
 
-int pgt_spmm_tune(const char*, int) { return 0; }
-void pgt_slab_set_pairs(int) {}
+#define LAB_HAS_GEMM
+#include "lab_stubs.h"
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm.hip"
 // gemm.hip routes tall products to csrc/gemm_bx.hip; this harness links without it (its own copy of the kernels below)
 int pgt_gemm_bx_launch(const PgtGemmArgs&, pgt_stream_t) { return 0; }
 int pgt_gemm_bx_tn_plan(const PgtTnArgs&, int64_t*) { return 0; }
 int pgt_gemm_bx_tn_launch(const PgtTnArgs&, pgt_stream_t) { return PGT_ERR_INVALID; }
-void pgt_gemm_bx_set(int) {}
-void pgt_gemm_bx_sym_set(int) {}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 

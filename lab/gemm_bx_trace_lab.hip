@@ -27,14 +27,9 @@ constexpr int TR_FIRST = 6, TR_ITERS = 6, TR_SLOTS = 8;
 #endif
 #define BX_LAB_SKIP(bit) ((BX_SKIP & (bit)) != 0)
 
-int pgt_spmm_tune(const char*, int) { return 0; }
-void pgt_slab_set_pairs(int) {}
-void pgt_slab_set_split(int) {}
-void pgt_slab_set_threads(int) {}
-void pgt_slab_set_wpc(int) {}
-void pgt_slab_set_quad(int) {}
-void pgt_slab_set_gu(int) {}
-void pgt_slab_set_sort(int) {}
+#define LAB_HAS_GEMM
+#define LAB_HAS_GEMM_BX
+#include "lab_stubs.h"
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm_bx.hip"

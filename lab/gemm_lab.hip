@@ -17,16 +17,14 @@ __device__ long long* g_trace_buf = nullptr;
 __device__ int g_lab_dbg = 0;
 #define PGT_LAB_KT(kt) (g_lab_dbg == 1 ? 0 : (kt))
 #define PGT_LAB_SKIP_EPI() (g_lab_dbg == 2)
-int pgt_spmm_tune(const char*, int) { return 0; }
-void pgt_slab_set_pairs(int) {}
+#define LAB_HAS_GEMM
+#include "lab_stubs.h"
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/gemm.hip"
 // gemm.hip routes tall products to csrc/gemm_bx.hip; this harness links without it (its own copy of the kernels below)
 int pgt_gemm_bx_launch(const PgtGemmArgs&, pgt_stream_t) { return 0; }
 int pgt_gemm_bx_tn_plan(const PgtTnArgs&, int64_t*) { return 0; }
 int pgt_gemm_bx_tn_launch(const PgtTnArgs&, pgt_stream_t) { return PGT_ERR_INVALID; }
-void pgt_gemm_bx_set(int) {}
-void pgt_gemm_bx_sym_set(int) {}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -105,7 +103,7 @@ int main(int argc, char** argv) {
       snprintf(nm, 80, "dbp %d  NN+zr [M,330]->128 fused", stg);
       timeit(nm, [&]() { pgt_gemm_gru_zr_f32(A, C, (int64_t)M * C, S, C, W, 128, 1, bias, ZR, H, 64, XHR, C, 2, M, 64, st); }, 2.0 * M * K * 128);
       snprintf(nm, 80, "dbp %d  NN+h [M,330]->64 fused", stg);
-      timeit(nm, [&]() { pgt_gemm_gru_h_f32(A, C, (int64_t)M * C, S, C, W, 64, 1, bias, Cout, ZR, H, 64, XHR, 64, nullptr, 0, M, 64, st); }, 2.0 * M * K * 64);
+      timeit(nm, [&]() { pgt_gemm_gru_h_f32(A, C, (int64_t)M * C, S, C, W, 64, 1, bias, Cout, ZR, H, 64, XHR, 64, nullptr, nullptr, 0, M, 64, st); }, 2.0 * M * K * 64);
     }
     return 0;
   }

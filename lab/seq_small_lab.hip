@@ -20,24 +20,8 @@ constexpr int SEQ_STEPS = 12, SEQ_SLOTS = 6;
       g_seq_trace[(step) * SEQ_SLOTS + (slot)] = (long long)wall_clock64();                                        \
   } while (0)
 
-int pgt_spmm_tune(const char*, int) { return 0; }
-void pgt_gemm_set_force_small(int) {}
-void pgt_gemm_set_small_fill(int) {}
-void pgt_gemm_set_tn_fullk(int) {}
-void pgt_gemm_set_db(int) {}
-void pgt_gemm_set_db64(int) {}
-void pgt_gemm_set_tn_pipe(int) {}
-void pgt_gemm_set_skinny(int) {}
-void pgt_gemm_set_dbp(int) {}
-void pgt_gemm_bx_set(int) {}
-void pgt_gemm_bx_sym_set(int) {}
-void pgt_slab_set_pairs(int) {}
-void pgt_slab_set_split(int) {}
-void pgt_slab_set_threads(int) {}
-void pgt_slab_set_wpc(int) {}
-void pgt_slab_set_quad(int) {}
-void pgt_slab_set_gu(int) {}
-void pgt_slab_set_sort(int) {}
+#define LAB_HAS_SEQ
+#include "lab_stubs.h"
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/seq_small.hip"
 

@@ -18,17 +18,8 @@ constexpr int TR_ITERS = 8, TR_SLOTS = 5;
       g_trace_buf[((size_t)blockIdx.x * TR_ITERS + (iter)) * TR_SLOTS + (slot)] = (long long)wall_clock64();          \
   } while (0)
 
-int pgt_spmm_tune(const char*, int) { return 0; }
-void pgt_gemm_set_force_small(int) {}
-void pgt_gemm_set_small_fill(int) {}
-void pgt_gemm_set_tn_fullk(int) {}
-void pgt_gemm_set_db(int) {}
-void pgt_gemm_set_db64(int) {}
-void pgt_gemm_set_tn_pipe(int) {}
-void pgt_gemm_set_skinny(int) {}
-void pgt_gemm_set_dbp(int) {}
-void pgt_gemm_bx_set(int) {}
-void pgt_gemm_bx_sym_set(int) {}
+#define LAB_HAS_SLAB
+#include "lab_stubs.h"
 #include "../pytorch_geometric_temporal_amd/csrc/pgt_core.hip"
 #include "../pytorch_geometric_temporal_amd/csrc/dconv_slab.hip"
 

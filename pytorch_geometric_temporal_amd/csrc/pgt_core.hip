@@ -80,6 +80,10 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_slab_set_sort(value);
     return PGT_OK;
   }
+  if (strcmp(key, "seq_vdot") == 0) {
+    pgt_seq_set_vdot(value);
+    return PGT_OK;
+  }
   if (strcmp(key, "slab_gu") == 0) {
     pgt_slab_set_gu(value);
     return PGT_OK;

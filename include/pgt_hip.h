@@ -214,9 +214,11 @@ int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, const int32_t* 
  * adding the unassigned row with the most neighbours already inside the patch.  order[p] = the caller's row at layout
  * position p (int32 [n_rows]); rowptr_p / col_p = the operator in layout numbering, every row keeping its slots in the
  * caller's order (so the sums round as on the caller's CSR); slot_p[q'] = the caller's slot behind layout slot q'
- * (val_p = val[slot_p]).  Feed them to pgt_ellw_plan (halo 0) / pgt_ellw_build and set pgt_ellw.order. */
-int pgt_tile_order_host(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t tile_rows, int32_t* order,
-                        int32_t* rowptr_p, int32_t* col_p, int32_t* slot_p);
+ * (val_p = val[slot_p]).  Feed them to pgt_ellw_plan (halo 0) / pgt_ellw_build and set pgt_ellw.order.  order_given != 0:
+ * `order` is an INPUT — the order found for another operator of the same graph (its transpose, the other diffusion direction:
+ * the same undirected neighbourhoods) — and only the operator in that numbering is produced. */
+int pgt_tile_order_host(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t tile_rows, int32_t order_given,
+                        int32_t* order, int32_t* rowptr_p, int32_t* col_p, int32_t* slot_p);
 
 /* out4[0] = #slots with |col - row| <= 32, out4[1] = #slots with |col - row| <= 96, out4[2] = slots of the longest row,
  * out4[3] = #rows longer than long_len (device int32[4]); the first min(out4[3], long_cap) of those rows are listed in

@@ -76,7 +76,7 @@ PROTOTYPES = {
                                c_ptr, c_ptr, c_ptr]),
     "pgt_spmm_ellw_f32": (c_int, [ctypes.POINTER(EllwStruct), c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
                                   c_ptr, c_i64, c_f32, c_f32, c_i64, c_ptr]),
-    "pgt_tile_order_host": (c_int, [c_ptr, c_ptr, c_i64, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "pgt_tile_order_host": (c_int, [c_ptr, c_ptr, c_i64, ctypes.c_int32, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_csr_locality": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, ctypes.c_int32, c_ptr]),
     "pgt_spmm_csr_long_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, ctypes.c_int32, c_ptr, c_i64, c_ptr, c_i64,
                                       c_ptr, c_i64, c_f32, c_f32, c_i64, c_ptr]),

@@ -15,15 +15,10 @@
 
 #include "pgt_common.h"
 
-extern "C" int pgt_tile_order_host(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t tile_rows,
-                                   int32_t* order, int32_t* rowptr_p, int32_t* col_p, int32_t* slot_p) {
-  PGT_REQUIRE(rowptr && col && order && rowptr_p && col_p && slot_p, "pgt_tile_order_host: null pointer");
-  PGT_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 31) - 1024 && tile_rows >= 1, "pgt_tile_order_host: bad size");
-  const int n = (int)n_rows;
-  const int64_t nnz = rowptr[n];
-  PGT_REQUIRE(rowptr[0] == 0 && nnz >= 0 && nnz < ((int64_t)1 << 31), "pgt_tile_order_host: bad rowptr");
-  for (int i = 0; i < n; ++i) PGT_REQUIRE(rowptr[i + 1] >= rowptr[i], "pgt_tile_order_host: rowptr not monotone");
-  for (int64_t q = 0; q < nnz; ++q) PGT_REQUIRE(col[q] >= 0 && col[q] < n, "pgt_tile_order_host: column out of range");
+namespace {
+
+// order[p] = the row at position p: patches of tile_rows rows, grown one after the other
+void grow_patches(const int32_t* rowptr, const int32_t* col, int n, int64_t nnz, int32_t tile_rows, int32_t* order) {
   // undirected neighbourhood: a row's sources and the rows it is a source of
   std::vector<int32_t> aptr((size_t)n + 1, 0), adj((size_t)2 * nnz);
   for (int i = 0; i < n; ++i)
@@ -78,6 +73,30 @@ extern "C" int pgt_tile_order_host(const int32_t* rowptr, const int32_t* col, in
     for (int u : seen) if (!taken[u]) rim.push_back(u);
     placed += got;
     ++patch;
+  }
+}
+
+}  // namespace
+
+extern "C" int pgt_tile_order_host(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t tile_rows,
+                                   int32_t order_given, int32_t* order, int32_t* rowptr_p, int32_t* col_p, int32_t* slot_p) {
+  PGT_REQUIRE(rowptr && col && order && rowptr_p && col_p && slot_p, "pgt_tile_order_host: null pointer");
+  PGT_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 31) - 1024 && tile_rows >= 1, "pgt_tile_order_host: bad size");
+  const int n = (int)n_rows;
+  const int64_t nnz = rowptr[n];
+  PGT_REQUIRE(rowptr[0] == 0 && nnz >= 0 && nnz < ((int64_t)1 << 31), "pgt_tile_order_host: bad rowptr");
+  for (int i = 0; i < n; ++i) PGT_REQUIRE(rowptr[i + 1] >= rowptr[i], "pgt_tile_order_host: rowptr not monotone");
+  for (int64_t q = 0; q < nnz; ++q) PGT_REQUIRE(col[q] >= 0 && col[q] < n, "pgt_tile_order_host: column out of range");
+  if (order_given) {
+    // the order found for another operator of the same graph (its transpose, the other direction: the same undirected
+    // neighbourhoods, so the same patches serve): only the operator in that numbering is produced
+    std::vector<uint8_t> hit((size_t)n, 0);
+    for (int p = 0; p < n; ++p) {
+      PGT_REQUIRE(order[p] >= 0 && order[p] < n && !hit[order[p]], "pgt_tile_order_host: the given order is not a permutation");
+      hit[order[p]] = 1;
+    }
+  } else {
+    grow_patches(rowptr, col, n, nnz, tile_rows, order);
   }
   // the operator in the new numbering, every row keeping its slots IN THE ORDER of the caller's CSR (the sums then round
   // exactly as on the caller's CSR); slot_p[q'] = the caller's slot behind new slot q' (values: val_p = val[slot_p])

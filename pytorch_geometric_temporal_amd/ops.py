@@ -24,7 +24,7 @@ class Csr:
     """CSR operator by destination row.  `halo` is the operator's measured locality: 32 / 96 when at least 95 % of the
     slots have |col - row| within that distance (locality-ordered node numbering), else 0; `max_len` the longest row.
     `ellw` caches the ELLW layout (pgt_ellw) built for the F = 64 LDS-window kernel on first use."""
-    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows")   # ellw: None | Ellw | False
+    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows", "family")   # ellw: None | Ellw | False
 
     def __init__(self, n_rows, cap, device):
         self.n_rows = n_rows
@@ -33,6 +33,8 @@ class Csr:
         self.nnz = -1
         self.ellw = None
         self.long_rows = None      # int32 device list of the rows longer than LONG_ROW slots (hubs), or None
+        self.family = None         # dict shared by the operators of one graph (forward / transposed, both directions): what one of
+        #                            them learned about a renumbering serves the others (same undirected neighbourhoods)
         self.rowptr = torch.zeros(n_rows + 1, dtype=I32, device=device)
         self.col = torch.zeros(max(cap, 1), dtype=I32, device=device)
         self.val = torch.zeros(max(cap, 1), dtype=F32, device=device)
@@ -69,6 +71,9 @@ def measure_locality(csrs):
     todo = [c for c in csrs if c.n_rows >= ELLW_MIN_ROWS]
     if not todo:
         return
+    family = {}
+    for c in todo:
+        c.family = family
     dev = todo[0].rowptr.device
     out = torch.zeros(len(todo), 5, dtype=I32, device=dev)
     lists = [torch.empty(LONG_ROW_CAP, dtype=I32, device=dev) for _ in todo]
@@ -143,7 +148,8 @@ class RenumberedEllw(Ellw):
     K-hop stack chains hop after hop without a permutation pass.  Rows keep their slots in the caller's order: the sums
     round exactly as on the caller's CSR."""
 
-    def __init__(self, csr):
+    def __init__(self, csr, order=None):
+        """order: (host int32 order, tile_rows) found for another operator of the same graph, or None: grow the patches here."""
         lib = _lib.get_lib()
         dev = csr.rowptr.device
         n, nnz = csr.n_rows, int(csr.nnz)
@@ -152,10 +158,13 @@ class RenumberedEllw(Ellw):
                  ctypes.byref(nt), ctypes.byref(fr))
         rowptr_h = csr.rowptr[:n + 1].cpu().contiguous()            # graph preparation: one round trip per operator
         col_h = csr.col[:nnz].cpu().contiguous()
-        order_h, rowptr_p = torch.empty(n, dtype=I32), torch.empty(n + 1, dtype=I32)
+        given = order is not None and order[1] == tr.value and order[0].numel() == n
+        order_h = order[0] if given else torch.empty(n, dtype=I32)
+        rowptr_p = torch.empty(n + 1, dtype=I32)
         col_p, slot_p = torch.empty(max(nnz, 1), dtype=I32), torch.empty(max(nnz, 1), dtype=I32)
-        lib.call("pgt_tile_order_host", rowptr_h.data_ptr(), col_h.data_ptr(), n, tr.value, order_h.data_ptr(),
+        lib.call("pgt_tile_order_host", rowptr_h.data_ptr(), col_h.data_ptr(), n, tr.value, 1 if given else 0, order_h.data_ptr(),
                  rowptr_p.data_ptr(), col_p.data_ptr(), slot_p.data_ptr())
+        self.order_host = (order_h, tr.value)
         lay = _LayoutCsr()
         lay.rowptr, lay.col = rowptr_p.to(dev), col_p.to(dev)
         lay.val = csr.val[:nnz][slot_p[:nnz].to(dev).long()] if nnz else csr.val[:1].clone()
@@ -183,8 +192,15 @@ def ellw_of(csr):
             e = csr.ellw = Ellw(csr, csr.halo)
         elif csr.n_rows >= ELLW_MIN_ROWS:
             cand = Ellw(csr, 32)
-            if cand.far_csr > ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz and USE_RENUMBER:
-                cand = RenumberedEllw(csr)
+            fam = getattr(csr, "family", None)
+            if fam is None:
+                fam = {}
+            if cand.far_csr > ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz and USE_RENUMBER and not fam.get("no_patches"):
+                cand = RenumberedEllw(csr, fam.get("order"))
+                if cand.far_csr <= ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz:
+                    fam["order"] = cand.order_host          # the graph's other operators lay themselves out in the same patches
+                else:
+                    fam["no_patches"] = True                # (a graph without locality: its other operators need not try)
             if cand.far_csr <= ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz:
                 e = csr.ellw = cand
             else:

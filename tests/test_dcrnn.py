@@ -625,6 +625,8 @@ def test_dconv_on_a_graph_whose_numbering_hides_its_locality(backend):
         assert graphs
         for csr in (graphs[0].fwd_o, graphs[0].fwd_i, graphs[0].bwd_o, graphs[0].bwd_i):
             assert bool(csr.ellw and csr.ellw.order is not None) == renumber
+            if renumber:      # the four operators of a graph (two directions, forward / transposed) share ONE set of patches
+                assert torch.equal(csr.ellw.order, graphs[0].fwd_o.ellw.order)
         outs.append((H.detach(), X.grad.clone(), m.weight.grad.clone()))
     for a, b, what in zip(outs[0], outs[1], ("H", "dX", "dW")):
         assert_close_with_nonfinite(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, what)

@@ -84,7 +84,7 @@ def main():
             loss.backward()
             flat.all_reduce_mean(world)
             optimizer.step()
-            total, n = total + float(loss), n + 1
+            total, n = total + float(loss.detach()), n + 1
         torch.cuda.synchronize()
         if rank == 0:
             print(f"epoch {epoch}: train MAE {total / max(n, 1):.4f}  ({time.time() - t0:.2f} s, {n} steps of {args.batch_size} windows "

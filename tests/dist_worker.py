@@ -31,7 +31,7 @@ def build(model_name):
             def forward(self, X, ei, ew):
                 return self.head(self.rnn(X, ei, ew))
         return Net()
-    if model_name == "tgcn_seq":                      # BASELINE configs[3]'s model: the T-step loop of bench_tgcn.BatchedTGCN
+    if model_name in ("tgcn_seq", "tgcn_ddp"):        # BASELINE configs[3]'s model: the T-step loop of bench_tgcn.BatchedTGCN
         import bench_tgcn
         return bench_tgcn.BatchedTGCN(2, 4, 2)
     return TGCN2(2, 4, batch_size=1)
@@ -44,7 +44,7 @@ def batch_loss(model_name, model, X, y, ei, ew):
     if model_name == "dcrnn":
         out = model(X, ei, ew)                       # [B, T, N, O]
         return (out.mean(dim=-1) - y).abs().mean()
-    if model_name == "tgcn_seq":
+    if model_name in ("tgcn_seq", "tgcn_ddp"):
         import bench_tgcn
         out = model(X.permute(0, 2, 3, 1), ei, ew)   # x [B, N, F, T] -> [B, T, N, 2]; the example's de-normalised masked MAE
         return bench_tgcn.masked_mae_loss(out[..., 0] * bench_tgcn.STD + bench_tgcn.MEAN, y * bench_tgcn.STD + bench_tgcn.MEAN)
@@ -69,7 +69,7 @@ def main():
                 p.add_(1.0)
     dp.broadcast_parameters(model, src=0)
     ddp = None
-    if model_name == "ddp":                            # torch's own wrapper exactly as the reference uses it (pems_ddp.py:83-85)
+    if model_name in ("ddp", "tgcn_ddp"):              # torch's own wrapper exactly as the reference uses it (pems_ddp.py:83-85)
         from torch.nn.parallel import DistributedDataParallel as DDP
         if world == 1:                                 # DDP wants a process group even for one rank
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -58,6 +58,18 @@ def test_torch_ddp_wrapper_as_the_reference_uses_it_equals_flat_gradients(tmp_pa
     assert ddp2["losses"] == pytest.approx(flat2["losses"], rel=1e-5, abs=1e-6)
 
 
+def test_torch_ddp_around_the_tgcn_sequence_loop(tmp_path):
+    """The T-step loop over TGCN2 packs the cell's folded operands ONCE per training step (nn/_states.py: packed_once), so every
+    parameter receives its gradient once, from one adjoint launch, at the end of the backward pass — under torch's
+    DistributedDataParallel (bucket hooks on the parameters' gradient accumulators) that must train exactly like the one
+    flat all-reduce, at world 2."""
+    flat2 = _run("tgcn_seq", 2, str(tmp_path / "f2.pt"))
+    ddp2 = _run("tgcn_ddp", 2, str(tmp_path / "d2.pt"))
+    for k in flat2["params"]:
+        assert torch.allclose(ddp2["params"][k], flat2["params"][k], atol=2e-6, rtol=1e-5), k
+    assert ddp2["losses"] == pytest.approx(flat2["losses"], rel=1e-5, abs=1e-6)
+
+
 @pytest.mark.parametrize("world,total", [(2, 10), (4, 10), (8, 21)])
 def test_bench_protocol_under_gloo_with_uneven_shards(tmp_path, world, total):
     """bench.py's multi-rank protocol (dp.timed_steps + async flat all-reduce + DistributedSampler-style padding) with

@@ -77,14 +77,14 @@ def main(argv=None, device=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", choices=sorted(MODELS), default="dcrnn")
     ap.add_argument("--epochs", type=int, default=20)
-    ap.add_argument("--snapshots", type=int, default=0, help="use only the first N training snapshots (0 = all)")
+    ap.add_argument("--snapshots", type=int, default=0, help="use only the first N training and N test snapshots (0 = all)")
     ap.add_argument("--graph", action="store_true", help="the whole training epoch as one hipGraph")
     args = ap.parse_args(argv)
     device = device or torch.device("cuda:0")
     dataset = ChickenpoxDatasetLoader().get_dataset(lags=LAGS)
     train, test = temporal_signal_split(dataset, train_ratio=0.2)
     if args.snapshots:
-        train = train[:args.snapshots]
+        train, test = train[:args.snapshots], test[:args.snapshots]
     train, test = train.to(device), test.to(device)
     torch.manual_seed(0)
     model = RecurrentGCN(args.model).to(device)

@@ -176,7 +176,7 @@ def test_torch_cpu_batchnorm_backward_disagrees_with_itself_on_the_reference_str
 
 
 @pytest.mark.skipif(not R.reference_available(), reason="reference checkout not mounted")
-@pytest.mark.parametrize("B,T,train", [(10, 5, True), (10, 5, False), (3, 7, True)])
+@pytest.mark.parametrize("B,T,train", [(10, 5, True), (4, 5, False), (3, 7, True)])      # (eval mode on a smaller batch: the CPU double is slow)
 def test_stconv_forward_and_every_gradient_at_the_reference_test_shape(emu_backend, B, T, train):
     """STConv(300, 100, 8, 10, kernel_size 3, K = 2) on [10, 5, 300, 100] (and on 7 steps, where torch's batch norm can be
     used as the reference calls it): forward, dX and every parameter gradient against autograd through the reference's OWN

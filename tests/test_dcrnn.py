@@ -605,30 +605,32 @@ def test_dconv_on_a_graph_whose_numbering_hides_its_locality(backend):
     side = 34 if backend.name == "emu" else 120           # (the CPU double is slow: a smaller mesh, the size gate lowered for it)
     n = side * side
     min_rows, ops.ELLW_MIN_ROWS = ops.ELLW_MIN_ROWS, min(ops.ELLW_MIN_ROWS, n)
-    ei, ew = syn.grid2d_graph(side, "shuffled", seed=4)
-    ei, ew = backend.t(ei), backend.t(ew)
-    torch.manual_seed(2)
-    m = DConv(64, 64, 3).to(backend.device)
-    X0 = backend.t(torch.randn(n, 64))
-    outs = []
-    for renumber in (True, False):
-        ops.GRAPH_CACHE.clear()
-        saved, ops.USE_RENUMBER = ops.USE_RENUMBER, renumber
-        try:
-            X = X0.clone().requires_grad_(True)
-            m.zero_grad()
-            H = m(X, ei, ew)
-            (H * torch.linspace(-1, 1, 64, device=H.device)).sum().backward()
-            graphs = [v for v in ops.GRAPH_CACHE._d.values() if hasattr(v, "fwd_o")] + \
-                     [w for v in ops.GRAPH_CACHE._d.values() if isinstance(v, tuple) for w in v if hasattr(w, "fwd_o")]
-        finally:
-            ops.USE_RENUMBER = saved
-        assert graphs
-        for csr in (graphs[0].fwd_o, graphs[0].fwd_i, graphs[0].bwd_o, graphs[0].bwd_i):
-            assert bool(csr.ellw and csr.ellw.order is not None) == renumber
-            if renumber:      # the four operators of a graph (two directions, forward / transposed) share ONE set of patches
-                assert torch.equal(csr.ellw.order, graphs[0].fwd_o.ellw.order)
-        outs.append((H.detach(), X.grad.clone(), m.weight.grad.clone()))
-    ops.ELLW_MIN_ROWS = min_rows
+    try:
+        ei, ew = syn.grid2d_graph(side, "shuffled", seed=4)
+        ei, ew = backend.t(ei), backend.t(ew)
+        torch.manual_seed(2)
+        m = DConv(64, 64, 3).to(backend.device)
+        X0 = backend.t(torch.randn(n, 64))
+        outs = []
+        for renumber in (True, False):
+            ops.GRAPH_CACHE.clear()
+            saved, ops.USE_RENUMBER = ops.USE_RENUMBER, renumber
+            try:
+                X = X0.clone().requires_grad_(True)
+                m.zero_grad()
+                H = m(X, ei, ew)
+                (H * torch.linspace(-1, 1, 64, device=H.device)).sum().backward()
+                graphs = [v for v in ops.GRAPH_CACHE._d.values() if hasattr(v, "fwd_o")] + \
+                         [w for v in ops.GRAPH_CACHE._d.values() if isinstance(v, tuple) for w in v if hasattr(w, "fwd_o")]
+            finally:
+                ops.USE_RENUMBER = saved
+            assert graphs
+            for csr in (graphs[0].fwd_o, graphs[0].fwd_i, graphs[0].bwd_o, graphs[0].bwd_i):
+                assert bool(csr.ellw and csr.ellw.order is not None) == renumber
+                if renumber:      # the four operators of a graph (two directions, forward / transposed) share ONE set of patches
+                    assert torch.equal(csr.ellw.order, graphs[0].fwd_o.ellw.order)
+            outs.append((H.detach(), X.grad.clone(), m.weight.grad.clone()))
+    finally:
+        ops.ELLW_MIN_ROWS = min_rows
     for a, b, what in zip(outs[0], outs[1], ("H", "dX", "dW")):
         assert_close_with_nonfinite(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, what)

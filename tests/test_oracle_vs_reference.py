@@ -85,3 +85,39 @@ def test_chebconv_matches_stub_module():
             out = F.cheb_conv(x, ei, ew, [l.weight for l in conv.lins], conv.bias, norm,
                               None if lam is None else torch.tensor(lam))
         assert_close_with_nonfinite(out, ref, 1e-6, 1e-6)
+
+
+def test_constructor_and_forward_signatures_equal_the_references():
+    """Drop-in means the call sites do not change: every in-scope class takes the reference's constructor and forward arguments —
+    names, order, defaults — read from the reference's own module files.  One documented superset: DConv.forward also accepts
+    edge_weight = None (the reference's DCRNN passes it through, dcrnn.py:172-192)."""
+    import inspect
+
+    import pytorch_geometric_temporal_amd.nn.attention as A
+    import pytorch_geometric_temporal_amd.nn.recurrent as Rec
+    classes = {
+        "nn.recurrent.dcrnn": ["DConv", "DCRNN", "BatchedDConv", "BatchedDCRNN"],
+        "nn.recurrent.temporalgcn": ["TGCN", "TGCN2"],
+        "nn.recurrent.attentiontemporalgcn": ["A3TGCN", "A3TGCN2"],
+        "nn.recurrent.evolvegcnh": ["EvolveGCNH"],
+        "nn.recurrent.evolvegcno": ["EvolveGCNO", "GCNConv_Fixed_W"],
+        "nn.recurrent.gconv_gru": ["GConvGRU"],
+        "nn.recurrent.gconv_lstm": ["GConvLSTM"],
+        "nn.recurrent.gc_lstm": ["GCLSTM"],
+        "nn.attention.stgcn": ["TemporalConv", "STConv"],
+        "nn.attention.astgcn": ["ChebConvAttention", "SpatialAttention", "TemporalAttention", "ASTGCNBlock", "ASTGCN"],
+        "nn.attention.mstgcn": ["MSTGCNBlock", "MSTGCN"],
+    }
+
+    def params(fn):
+        return [(p.name, repr(p.default) if p.default is not inspect.Parameter.empty else "<required>")
+                for p in inspect.signature(fn).parameters.values()]
+    differences = []
+    for module, names in classes.items():
+        ref_mod = R.load(module)
+        for name in names:
+            ref_cls, ours = getattr(ref_mod, name), getattr(Rec, name, None) or getattr(A, name)
+            for method in ("__init__", "forward"):
+                if params(getattr(ref_cls, method)) != params(getattr(ours, method)):
+                    differences.append((name, method))
+    assert differences == [("DConv", "forward")], differences

@@ -37,7 +37,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 
 N_NODES, N_EDGES, SEQ = 207, 1515, 12
 PROPAGATES_PER_CELL = 12     # the reference's op count per DCRNN cell step: 6 (K - 1) propagate calls at K = 3
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
+                                                          "r02_pmc_traffic.json")]
+PMC_FILES_TGCN = [os.path.join(ROOT, "profiles", f) for f in ("r05_tgcn50k_pmc_traffic.json", "r04_tgcn50k_pmc_traffic.json")]
 
 
 _T0 = time.time()
@@ -72,15 +74,22 @@ def gemm_operand_bytes(shape):
     return 4.0 * M * (n_seg * seg_k + N)
 
 
-def pmc_traffic(kind):
+def pmc_traffic(kind, files=None):
     """HBM bytes per launch of the dominant kernel class from the rocprofv3 --pmc passes of THIS bench command
     (scripts/pmc_bench.sh: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, averaged over the kernel's dispatches),
-    committed under profiles/ — counters cannot be read from inside the process.  The newest round's file wins."""
-    for path in PMC_FILES:
+    committed under profiles/ — counters cannot be read from inside the process.  The newest round's file wins.  `kind` may be
+    a tuple of kernel entries of one class (forward + backward of the fused cell): their dispatch-weighted mean."""
+    for path in (files or PMC_FILES):
         try:
             with open(path) as fh:
                 d = json.load(fh)
-            e = d["kernels"][kind]
+            if isinstance(kind, (tuple, list)):
+                es = [d["kernels"][k] for k in kind]
+                n = sum(x["dispatches"] for x in es)
+                e = {"dispatches": n, **{f: sum(x[f] * x["dispatches"] for x in es) / n
+                                         for f in ("bytes_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch")}}
+            else:
+                e = d["kernels"][kind]
             return {"traffic": e["bytes_per_launch"], "traffic_measured_in_this_run": False,
                     "traffic_source": f"BUILDER-BOX PMC, not this run: profiles/{os.path.basename(path)} ({d.get('command', '')}): "
                     f"FETCH_SIZE x2 {e['fetch_bytes_per_launch']:.3e} + WRITE_SIZE {e['write_bytes_per_launch']:.3e} B per launch "
@@ -145,7 +154,9 @@ def all_kernel_classes(kernels, profile_steps):
     all_s = sum(v["total_ms"] for v in kernels.values()) * 1e-3
     return {"achieved_GBs": all_b / all_s / 1e9, "hbm_frac": all_b / all_s / 1e9 / HBM_PEAK_GBS,
             "ms_per_step_in_timed_kernels": 1e3 * all_s / profile_steps,
-            "classes": {k: round(v["total_ms"] / profile_steps, 4) for k, v in kernels.items()}}
+            "classes": {k: round(v["total_ms"] / profile_steps, 4) for k, v in kernels.items()},
+            "classes_ms_frac": {k: [round(v["total_ms"] / profile_steps, 3), round(v["hbm_frac"], 3)] for k, v in kernels.items()},
+            "note": "instrumented steps (HIP events around every launch) run slower than the timed ones: fractions are lower bounds"}
 
 
 MEAN, STD = 54.0, 19.5       # METR-LA-like speed statistics used to de-normalise inside the loss
@@ -259,7 +270,8 @@ def cpu_baseline(hidden, target_seconds=10.0):
     for i in range(reps):
         one_step(2 + i)
     dt = time.perf_counter() - t0
-    return {"value": reps * Bc * SEQ * N_EDGES / dt, "unit": "snapshot-edges/s", "cores": cores, "kind": "port",
+    return {"value": reps * Bc * SEQ * N_EDGES / dt, "unit": "snapshot-edges/s", "cores": cores, "threads_used": cores,
+            "host_threads": ncpu, "kind": "port",
             "thread_sweep_snapshot_edges_per_s": sweep, "thread_sweep_sample": "one step of 16 windows per thread count",
             "all_hardware_threads_snapshot_edges_per_s": all_threads, "host_hardware_threads": ncpu,
             "sample": f"{reps} training steps of the same model on {Bc} windows x {SEQ} steps (oracle/functional.py, "
@@ -817,7 +829,9 @@ def main():
             "roofline": roof, "kernels": kernels, "roofline_ns_spmm_N200k_F64": ns, "cpu_baseline": cpu,
             "variants": variants, "other_configs": extra,
         }
-        print(json.dumps(line))
+        import bench_line
+        text = bench_line.emit(line)                           # complete record -> gpurun_out/bench_full.json + stderr; ONE short line on stdout
+        log(f"headline: {head['ms_per_step']:.3f} ms/step; printed line {len(text)} bytes")
     if world > 1:
         dist.destroy_process_group()
 

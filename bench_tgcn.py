@@ -204,7 +204,10 @@ def measure(device, rank, world, batch, steps, warmup, profile_steps, series, ei
             dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
             k = kernels[dom]
             res["roofline"] = {"kernel_class": dom, "bound": "hbm", "achieved": k["achieved_GBs"], "peak": bench.HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": k["hbm_frac"], "traffic": None,
+                               "unit": "GB/s", "frac": k["hbm_frac"],
+                               # the committed PMC passes are of the default batch (8): bytes per launch scale with it
+                               **(bench.pmc_traffic(("tgcn_cell_fwd", "tgcn_cell_bwd") if dom == "tgcn_cell" else dom, bench.PMC_FILES_TGCN)
+                                  if batch == 8 else {"traffic": None}),
                                "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "avg_us_per_launch": k["avg_us"],
                                "share_of_step_ms": k["ms_per_step"],
                                "all_kernel_classes": bench.all_kernel_classes(kernels, profile_steps)}
@@ -278,4 +281,5 @@ def main(args, rank, local_rank, world, device, bench):
                     "dropin_blas_readout_graphed": None if dropin_blas is None else {
                         "ms_per_step": dropin_blas["ms_per_step"], "what": "the same with TGCN2.readout_interception = False (torch's BLAS product)"}},
                 "final_loss": res["final_loss"], "roofline": res.get("roofline"), "kernels": res.get("kernels"), "cpu_baseline": cpu}
-        print(json.dumps(line))
+        import bench_line
+        bench_line.emit(line, "bench_full_tgcn50k.json")

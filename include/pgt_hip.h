@@ -19,6 +19,8 @@
  *   pgt_gcn_prep          PyG gcn_norm as called from GCNConv: nn/recurrent/temporalgcn.py:38-70,
  *                         nn/recurrent/evolvegcno.py:88-90
  *   pgt_cheb_prep         PyG ChebConv.__norm__ / nn/attention/astgcn.py:82-110 (ChebConvAttention.__norm__)
+ *   pgt_cheb_prep_graphs  the same with one lambda_max per graph of a disjoint batch: astgcn.py:97-98
+ *                         (`lambda_max = lambda_max[batch[edge_index[0]]]`), exercised by test/attention_test.py:205-217
  *   pgt_spmm_csr_f32      MessagePassing.propagate(aggr="add") + message():
  *                         dcrnn.py:39-40,86-87,95-100,300-313; astgcn.py:169-175,185-190; evolvegcno.py:95-101
  *                         (index_select -> norm*x_j -> scatter_add, fused, with the 2*P*T - T0 epilogue of dcrnn.py:96,100)
@@ -47,7 +49,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 12
+#define PGT_ABI_VERSION 13
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -78,7 +80,7 @@ typedef struct pgt_sym_graph {
   pgt_csr fwd;      /* capacity E + 2N */
   pgt_csr bwd;      /* capacity E + 2N */
   float* deg;       /* [N] */
-  int32_t* info;    /* [4] info[2] = #edge endpoints outside [0,N) */
+  int32_t* info;    /* [4] info[2] = #edge endpoints outside [0,N), info[3] = #batch labels outside [0,n_graphs) (pgt_cheb_prep_graphs) */
 } pgt_sym_graph;
 
 /* Two-level row layout of an [M, W] operand: row m starts at base + (m / period) * stride_hi + (m % period) * ld floats,
@@ -136,6 +138,14 @@ int pgt_gcn_prep(const int64_t* edge_index, const float* edge_weight, int64_t E,
 int pgt_cheb_prep(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N,
                   int normalization, float lambda_max, int variant, const pgt_sym_graph* out, void* ws,
                   size_t ws_bytes, pgt_stream_t stream);
+
+/* pgt_cheb_prep for a disjoint batch of graphs with one lambda_max each (astgcn.py:97-98, PyG ChebConv.__norm__):
+ * batch [N] int64 = graph label of every node, lambda_max [n_graphs] fp32 (device); every entry of the Laplacian
+ * (edges and the appended diagonal) is scaled by 2 / lambda_max[batch[row]], row = edge_index[0] of that entry.
+ * Labels outside [0, n_graphs) are counted in out->info[3] and their entries become NaN. */
+int pgt_cheb_prep_graphs(const int64_t* edge_index, const float* edge_weight, int64_t E, int64_t N,
+                         int normalization, const int64_t* batch, const float* lambda_max, int64_t n_graphs,
+                         int variant, const pgt_sym_graph* out, void* ws, size_t ws_bytes, pgt_stream_t stream);
 
 /* ---------------------------------------------------------------- aggregation (the graded kernel) */
 

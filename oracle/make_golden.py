@@ -288,6 +288,95 @@ def chebconvattention_sensor():
                  {"K": 3, "lambda_rw": 2.3, "lambda_none": 3.1})
 
 
+def _two_graph_batch(seed):
+    """A disjoint batch of two sensor graphs (14 + 16 nodes) as one edge list with a `batch` label per node."""
+    ei_a, ew_a = syn.sensor_graph(14, 60, seed=seed, symmetric=False)
+    ei_b, ew_b = syn.sensor_graph(16, 80, seed=seed + 1, symmetric=False)
+    ei = np.concatenate([ei_a, ei_b + 14], axis=1)
+    ew = np.concatenate([ew_a, ew_b])
+    batch = torch.tensor([0] * 14 + [1] * 16)
+    return _t(ei), _t(ew), batch
+
+
+@case
+def chebconvattention_graphs():
+    """ChebConvAttention with `batch` and one lambda_max per graph (astgcn.py:97-98; test/attention_test.py:205-217 pins the
+    shapes only).  Also `batch` beside a single lambda_max / none: the labels change nothing there."""
+    m = R.load("nn.attention.astgcn")
+    ei, ew, batch = _two_graph_batch(140)
+    X = _rand((3, 30, 4), 141)
+    S = torch.softmax(_rand((3, 30, 30), 142, -2, 2), dim=1)
+    lam = torch.tensor([2.0, 3.0])
+    outs, layer = {}, None
+    for norm in ("sym", "rw", None):
+        layer_n = m.ChebConvAttention(4, 8, 3, normalization=norm)
+        if layer is None:
+            layer = layer_n
+            _randomise(layer, 143)
+        else:
+            layer_n.load_state_dict(layer.state_dict())
+        with torch.no_grad():
+            outs["out_graphs_" + str(norm)] = layer_n(X, ei, S, ew, batch, lam)
+            outs["out_graphs_noweight_" + str(norm)] = layer_n(X, ei, S, None, batch, lam)
+            outs["out_batch_scalar_" + str(norm)] = layer_n(X, ei, S, ew, batch, torch.tensor(2.5))
+    with torch.no_grad():
+        outs["out_batch_nolambda_sym"] = layer(X, ei, S, ew, batch)
+    # gradients of the per-graph form ("sym"): loss = sum(out * G)
+    G = _rand((3, 30, 8), 144)
+    Xg, Sg = X.clone().requires_grad_(True), S.clone().requires_grad_(True)
+    layer.zero_grad()
+    (layer(Xg, ei, Sg, ew, batch, lam) * G).sum().backward()
+    outs.update({"grad_X": Xg.grad, "grad_S": Sg.grad, "grad__weight": layer._weight.grad, "grad__bias": layer._bias.grad})
+    return _pack({"X": X, "S": S, "edge_index": ei, "edge_weight": ew, "batch": batch, "lambda_max": lam, "G": G}, layer, outs,
+                 {"K": 3, "lambda_scalar": 2.5})
+
+
+@case
+def chebconv_graphs():
+    """PyG ChebConv (restated, oracle/pyg_restated.py) with `batch` and one lambda_max per graph: the same selection rule
+    (`lambda_max[batch[edge_index[0]]]` over the Laplacian's entries, diagonal included)."""
+    from . import pyg_restated as P
+    ei, ew, batch = _two_graph_batch(150)
+    X = _rand((30, 5), 151)
+    lam = torch.tensor([1.7, 2.6])
+    outs, layer = {}, None
+    for norm in ("sym", "rw", None):
+        layer_n = P.ChebConv(5, 7, 3, normalization=norm)
+        if layer is None:
+            layer = layer_n
+            _randomise(layer, 152)
+        else:
+            layer_n.load_state_dict(layer.state_dict())
+        with torch.no_grad():
+            outs["out_graphs_" + str(norm)] = layer_n(X, ei, ew, batch, lam)
+            outs["out_batch_scalar_" + str(norm)] = layer_n(X, ei, ew, batch, 2.2)
+    return _pack({"X": X, "edge_index": ei, "edge_weight": ew, "batch": batch, "lambda_max": lam}, layer, outs,
+                 {"K": 3, "lambda_scalar": 2.2})
+
+
+@case
+def stconv_sensor_grads():
+    """STConv (stgcn.py:86-168) in TRAINING mode with every gradient: loss = sum(out * G); dX, the parameter gradients and the
+    updated BatchNorm running statistics, from the reference's own module file under torch autograd."""
+    m = R.load("nn.attention.stgcn")
+    ei, ew = syn.sensor_graph(30, 200, seed=12, symmetric=False)
+    X = _rand((2, 7, 30, 4), 160)
+    layer = m.STConv(30, 4, 8, 6, kernel_size=3, K=3, normalization="sym")
+    _randomise(layer, 161)
+    layer.train()
+    Xg = X.clone().requires_grad_(True)
+    out = layer(Xg, _t(ei), _t(ew))
+    G = _rand(tuple(out.shape), 162)
+    (out * G).sum().backward()
+    outs = {"out_train": out.detach(), "grad_X": Xg.grad}
+    for k, p in layer.named_parameters():
+        outs["grad_" + k] = p.grad
+    outs["running_mean"] = layer._batch_norm.running_mean.clone()
+    outs["running_var"] = layer._batch_norm.running_var.clone()
+    # parameters as they were when the forward ran (state_dict below holds the updated running statistics too)
+    return _pack({"X": X, "edge_index": _t(ei), "edge_weight": _t(ew), "G": G}, layer, outs, {"K": 3, "kernel_size": 3})
+
+
 # ------------------------------------------------------------------------------------------------ ASTGCN / MSTGCN
 
 @case

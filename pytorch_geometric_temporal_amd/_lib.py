@@ -67,6 +67,8 @@ PROTOTYPES = {
                              c_size, c_ptr]),
     "pgt_cheb_prep": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_f32, c_int, ctypes.POINTER(SymGraphStruct),
                               c_ptr, c_size, c_ptr]),
+    "pgt_cheb_prep_graphs": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_int,
+                                     ctypes.POINTER(SymGraphStruct), c_ptr, c_size, c_ptr]),
     "pgt_spmm_csr_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_f32,
                                  c_f32, c_i64, c_ptr]),
     "pgt_ellw_plan": (c_int, [c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
@@ -167,7 +169,7 @@ PROTOTYPES = {
                                       c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 12
+EXPECTED_ABI = 13
 
 
 class PgtLib:

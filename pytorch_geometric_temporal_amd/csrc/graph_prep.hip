@@ -350,13 +350,25 @@ __global__ __launch_bounds__(256) void k_set_scalar(float* scal, float v) {
   if (threadIdx.x == 0 && blockIdx.x == 0) scal[0] = v;
 }
 
-// (2 * v) / lambda, inf -> 0; variant 0: "-1" folded into the diagonal slots; variant 1: N extra "-1" slots
+// (2 * v) / lambda, inf -> 0; variant 0: "-1" folded into the diagonal slots; variant 1: N extra "-1" slots.
+// batch != nullptr: lambda of a slot = lam_vec[batch[row]] with row = edge_index[0] of the Laplacian's entry
+// (astgcn.py:97-98 / PyG ChebConv.__norm__: `lambda_max[batch[edge_index[0]]]` after get_laplacian appended the diagonal);
+// a label outside [0, G) is counted in info[3] and its slots become NaN.
 __global__ __launch_bounds__(256) void k_cheb_scale(int64_t E, int64_t N, const float* __restrict__ scal,
-                                                     int variant, int32_t* l_dst, int32_t* l_src, float* l_val) {
+                                                     int variant, int32_t* l_dst, int32_t* l_src, float* l_val,
+                                                     const int64_t* __restrict__ batch,
+                                                     const float* __restrict__ lam_vec, int64_t G, int32_t* info) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= E + 2 * N) return;
   if (q < E + N) {
-    float v = (2.0f * l_val[q]) / scal[0];
+    float lam = scal[0];
+    if (batch != nullptr && l_dst[q] < (int32_t)N) {
+      const int64_t row = (q >= E) ? (q - E) : (variant == 1 ? (int64_t)l_dst[q] : (int64_t)l_src[q]);
+      const int64_t b = batch[row];
+      if (b < 0 || b >= G) { atomicAdd(info + 3, 1); lam = NAN; }
+      else lam = lam_vec[b];
+    }
+    float v = (2.0f * l_val[q]) / lam;
     if (isinf(v) && v > 0.f) v = 0.f;  // masked_fill_(edge_weight == inf, 0)
     if (q >= E && variant == 0) v -= 1.0f;
     l_val[q] = v;
@@ -482,16 +494,15 @@ extern "C" int pgt_gcn_prep(const int64_t* ei, const float* ew, int64_t E, int64
   return pgt_check_launch("pgt_gcn_prep");
 }
 
-extern "C" int pgt_cheb_prep(const int64_t* ei, const float* ew, int64_t E, int64_t N, int normalization,
-                             float lambda_max, int variant, const pgt_sym_graph* out, void* ws, size_t ws_bytes,
-                             pgt_stream_t stream) {
+namespace {
+int cheb_prep_impl(const char* what, const int64_t* ei, const float* ew, int64_t E, int64_t N, int normalization,
+                   float lambda_max, const int64_t* batch, const float* lam_vec, int64_t G, int variant,
+                   const pgt_sym_graph* out, void* ws, size_t ws_bytes, pgt_stream_t stream) {
   Ws w;
-  if (int e = common_checks("pgt_cheb_prep", ei, E, N, ws, ws_bytes, &w)) return e;
-  PGT_REQUIRE(out && csr_ok(out->fwd) && csr_ok(out->bwd) && out->deg && out->info,
-              "pgt_cheb_prep: null output buffer");
-  PGT_REQUIRE(normalization >= 0 && normalization <= 2, "pgt_cheb_prep: normalization must be 0 (None), 1 (sym) or 2 (rw)");
-  PGT_REQUIRE(variant == 0 || variant == 1, "pgt_cheb_prep: variant must be 0 or 1");
-  PGT_REQUIRE(isnan(lambda_max) || lambda_max != 0.f, "pgt_cheb_prep: lambda_max must be non-zero");
+  if (int e = common_checks(what, ei, E, N, ws, ws_bytes, &w)) return e;
+  PGT_REQUIRE(out && csr_ok(out->fwd) && csr_ok(out->bwd) && out->deg && out->info, "%s: null output buffer", what);
+  PGT_REQUIRE(normalization >= 0 && normalization <= 2, "%s: normalization must be 0 (None), 1 (sym) or 2 (rw)", what);
+  PGT_REQUIRE(variant == 0 || variant == 1, "%s: variant must be 0 or 1", what);
   dim3 block(256);
   (void)hipMemsetAsync(out->info, 0, 4 * sizeof(int32_t), (hipStream_t)stream);
   PGT_LAUNCH(k_check_edges, g1(E), block, stream, ei, ew, E, N, out->info);
@@ -504,7 +515,9 @@ extern "C" int pgt_cheb_prep(const int64_t* ei, const float* ew, int64_t E, int6
   PGT_LAUNCH(k_cheb_edge_vals, g1(E), block, stream, ei, E, N, out->deg, normalization, variant, w.l_dst, w.l_src,
              w.l_val);
   PGT_LAUNCH(k_cheb_diag, g1(N), block, stream, E, N, out->deg, normalization, w.l_dst, w.l_src, w.l_val);
-  if (isnan(lambda_max)) {
+  if (batch != nullptr) {
+    PGT_LAUNCH(k_set_scalar, dim3(1), block, stream, w.scal, 1.0f);     // (unused: every live slot has a label)
+  } else if (isnan(lambda_max)) {
     if (normalization == 1) {
       PGT_LAUNCH(k_set_scalar, dim3(1), block, stream, w.scal, 2.0f);
     } else {
@@ -514,8 +527,27 @@ extern "C" int pgt_cheb_prep(const int64_t* ei, const float* ew, int64_t E, int6
     PGT_LAUNCH(k_set_scalar, dim3(1), block, stream, w.scal, lambda_max);
   }
   const int64_t L = E + 2 * N;
-  PGT_LAUNCH(k_cheb_scale, g1(L), block, stream, E, N, w.scal, variant, w.l_dst, w.l_src, w.l_val);
+  PGT_LAUNCH(k_cheb_scale, g1(L), block, stream, E, N, w.scal, variant, w.l_dst, w.l_src, w.l_val, batch, lam_vec, G,
+             out->info);
   if (int e = build_csr(w, L, N, out->fwd, stream)) return e;
   if (int e = transpose_csr(w, out->fwd, L, N, out->bwd, stream)) return e;
-  return pgt_check_launch("pgt_cheb_prep");
+  return pgt_check_launch(what);
+}
+}  // namespace
+
+extern "C" int pgt_cheb_prep(const int64_t* ei, const float* ew, int64_t E, int64_t N, int normalization,
+                             float lambda_max, int variant, const pgt_sym_graph* out, void* ws, size_t ws_bytes,
+                             pgt_stream_t stream) {
+  PGT_REQUIRE(isnan(lambda_max) || lambda_max != 0.f, "pgt_cheb_prep: lambda_max must be non-zero");
+  return cheb_prep_impl("pgt_cheb_prep", ei, ew, E, N, normalization, lambda_max, nullptr, nullptr, 0, variant, out, ws,
+                        ws_bytes, stream);
+}
+
+extern "C" int pgt_cheb_prep_graphs(const int64_t* ei, const float* ew, int64_t E, int64_t N, int normalization,
+                                    const int64_t* batch, const float* lambda_max, int64_t n_graphs, int variant,
+                                    const pgt_sym_graph* out, void* ws, size_t ws_bytes, pgt_stream_t stream) {
+  PGT_REQUIRE(n_graphs > 0 && lambda_max != nullptr, "pgt_cheb_prep_graphs: no lambda_max values");
+  PGT_REQUIRE(N == 0 || batch != nullptr, "pgt_cheb_prep_graphs: null batch vector");
+  return cheb_prep_impl("pgt_cheb_prep_graphs", ei, ew, E, N, normalization, NAN, batch, lambda_max, n_graphs, variant,
+                        out, ws, ws_bytes, stream);
 }

@@ -44,20 +44,15 @@ class ChebConvAttention(torch.nn.Module):
                 "You need to pass `lambda_max` to `forward() in`"
                 "case the normalization is non-symmetric."
             )
-        if lambda_max is None:
+        lam, lam_graphs = ops.cheb_lambda(lambda_max, batch)     # one lambda per graph through `batch` (astgcn.py:97-98)
+        if lam is None and lam_graphs is None:
             lam = 2.0
-        elif isinstance(lambda_max, torch.Tensor):
-            if lambda_max.numel() > 1:
-                # per-graph lambda_max with a `batch` vector (astgcn.py:97-98) only matters for PyG-style disjoint
-                # batches; on the [B, N, F] layout every batch entry shares the graph, so all entries must agree
-                if not bool((lambda_max == lambda_max.flatten()[0]).all()):
-                    raise NotImplementedError("ChebConvAttention: per-graph lambda_max values differ")
-            lam = float(lambda_max.flatten()[0])
-        else:
-            lam = float(lambda_max)
         if isinstance(edge_index, (list, tuple)):       # the reference accepts a list for edge_index (attention_test.py)
             edge_index = torch.as_tensor(edge_index, device=x.device)
-        g = ops.cheb_graph(edge_index, edge_weight, x.size(1), self._normalization, lam, variant=1)
+        if lam_graphs is not None:
+            g = ops.cheb_graph(edge_index, edge_weight, x.size(1), self._normalization, lam_graphs, variant=1, batch=batch)
+        else:
+            g = ops.cheb_graph(edge_index, edge_weight, x.size(1), self._normalization, lam, variant=1)
         return ops.ChebConvAttentionFunction.apply(x, spatial_attention, self._weight, self._bias, g,
                                                    self._weight.size(0))
 

@@ -151,12 +151,14 @@ class ChebConv(torch.nn.Module):
             torch.nn.init.zeros_(self.bias)
 
     def forward(self, x, edge_index, edge_weight=None, batch=None, lambda_max=None):
-        if batch is not None:
-            raise NotImplementedError("ChebConv: per-graph `batch` vectors are not used on the reference's hot path")
-        # lambda_max=None -> 2 * max(L), computed on the device (PyG ChebConv.__norm__)
-        lam = None if lambda_max is None else float(lambda_max)
+        # lambda_max=None -> 2 * max(L), computed on the device (PyG ChebConv.__norm__); a tensor of several values = one per
+        # graph of a disjoint batch, selected through `batch`
+        lam, lam_graphs = ops.cheb_lambda(lambda_max, batch)
         N = x.size(-2)
-        g = ops.cheb_graph(edge_index, edge_weight, N, self.normalization, lam, variant=0)
+        if lam_graphs is not None:
+            g = ops.cheb_graph(edge_index, edge_weight, N, self.normalization, lam_graphs, variant=0, batch=batch)
+        else:
+            g = ops.cheb_graph(edge_index, edge_weight, N, self.normalization, lam, variant=0)
         K = len(self.lins)
         Wst = torch.cat([lin.weight.t() for lin in self.lins], dim=0)          # [K*in, out]
         if x.dim() == 2:

@@ -272,7 +272,7 @@ class SymGraph:
     """GCN-normalised (gcn_norm) or scaled-Laplacian (ChebConv.__norm__) operator and its transpose."""
 
     def __init__(self, kind, edge_index, edge_weight, num_nodes, improved=False, add_self_loops=True,
-                 normalization="sym", lambda_max=None, variant=0, validate=True):
+                 normalization="sym", lambda_max=None, variant=0, validate=True, batch=None):
         lib = _lib.get_lib()
         ei, ew = _edge_inputs(lib, edge_index, edge_weight)
         dev = ei.device
@@ -290,16 +290,27 @@ class SymGraph:
                      ctypes.byref(st), ptr(ws), ws_bytes, stream_of(lib, ei))
         elif kind == "cheb":
             norm_code = {None: 0, "sym": 1, "rw": 2}[normalization]
-            lam = float("nan") if lambda_max is None else float(lambda_max)
-            lib.call("pgt_cheb_prep", ptr(ei), ptr(ew), E, N, norm_code, lam, int(variant), ctypes.byref(st),
-                     ptr(ws), ws_bytes, stream_of(lib, ei))
+            if batch is not None:
+                # one lambda_max per graph of a disjoint batch (astgcn.py:97-98): lambda_max [G] and batch [N] stay on the device
+                lam_vec = lambda_max.detach().to(device=dev, dtype=F32).contiguous().view(-1)
+                labels = batch.detach().to(device=dev, dtype=torch.int64).contiguous().view(-1)
+                if labels.numel() < N:
+                    raise IndexError(f"batch has {labels.numel()} labels for {N} nodes")
+                lib.call("pgt_cheb_prep_graphs", ptr(ei), ptr(ew), E, N, norm_code, ptr(labels), ptr(lam_vec), lam_vec.numel(),
+                         int(variant), ctypes.byref(st), ptr(ws), ws_bytes, stream_of(lib, ei))
+            else:
+                lam = float("nan") if lambda_max is None else float(lambda_max)
+                lib.call("pgt_cheb_prep", ptr(ei), ptr(ew), E, N, norm_code, lam, int(variant), ctypes.byref(st),
+                         ptr(ws), ws_bytes, stream_of(lib, ei))
         else:
             raise ValueError(kind)
         measure_locality((self.fwd, self.bwd))
         if validate:
-            oob = int(self.info[2])
-            if oob:
-                raise IndexError(f"edge_index has {oob} endpoint(s) outside [0, {N})")
+            info = self.info.tolist()
+            if info[2]:
+                raise IndexError(f"edge_index has {info[2]} endpoint(s) outside [0, {N})")
+            if info[3]:
+                raise IndexError(f"batch has {info[3]} label(s) outside [0, {lambda_max.numel()}) (one lambda_max per graph)")
 
 
 def tensor_version(t):
@@ -468,7 +479,23 @@ def gcn_small(x, W, edge_index, edge_weight, improved=False, add_self_loops=True
     return GcnSmallFunction.apply(x, W, small_edges(edge_index, edge_weight, x.size(0)), improved, add_self_loops, normalize)
 
 
-def cheb_graph(edge_index, edge_weight, num_nodes, normalization="sym", lambda_max=None, variant=0):
+def cheb_lambda(lambda_max, batch):
+    """ChebConv / ChebConvAttention's `lambda_max` argument as (scalar or None, per-graph tensor or None): a tensor with more
+    than one value selects one lambda per graph through `batch` (astgcn.py:97-98, PyG ChebConv.__norm__); `batch` beside a
+    single value (or none) changes nothing there either."""
+    if isinstance(lambda_max, torch.Tensor) and lambda_max.numel() > 1:
+        if batch is None:
+            # the reference divides the [E' + N] Laplacian entries by the tensor as it is: a size mismatch unless it is per entry
+            raise RuntimeError(f"lambda_max has {lambda_max.numel()} values: pass `batch` (one graph label per node) with it")
+        return None, lambda_max
+    return (None if lambda_max is None else float(lambda_max)), None
+
+
+def cheb_graph(edge_index, edge_weight, num_nodes, normalization="sym", lambda_max=None, variant=0, batch=None):
+    if batch is not None and isinstance(lambda_max, torch.Tensor) and lambda_max.numel() > 1:
+        # per-graph lambda_max: prepared on every call (keyed by four tensors' identity it would rarely hit)
+        return SymGraph("cheb", edge_index, edge_weight, num_nodes, normalization=normalization, lambda_max=lambda_max,
+                        variant=variant, batch=batch)
     lam = None if lambda_max is None else float(lambda_max)
     return GRAPH_CACHE.get("cheb", edge_index, edge_weight, (int(num_nodes), normalization, lam, int(variant)),
                            lambda: SymGraph("cheb", edge_index, edge_weight, num_nodes, normalization=normalization,

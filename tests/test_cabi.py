@@ -46,6 +46,18 @@ def test_emu_test_double_exports_the_same_abi():
     assert exported(build_emu_library()) == set(header_functions())
 
 
+def test_integration_notes_name_the_current_abi_and_every_entry_point():
+    """INTEGRATION.md is what a maintainer of the reference binds from: its ABI number is the header's, and every exported symbol
+    is named in its entry-point table."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    abi = int(re.search(r"#define\s+PGT_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert abi == _lib.EXPECTED_ABI
+    assert {int(n) for n in re.findall(r"PGT_ABI_VERSION (\d+)", doc)} == {abi}
+    assert {int(n) for n in re.findall(r"pgt_abi_version\(\) == (\d+)", doc)} == {abi}
+    missing = sorted(n for n in header_functions() if f"`{n}`" not in doc)
+    assert missing == [], missing
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_lib.PgtLibraryMissing, match="no CPU fallback"):
         _lib.PgtLib(str(tmp_path / "libpgt_hip.so"))

@@ -360,6 +360,50 @@ def test_chebconvattention_forward_matches_reference_fixture(backend):
         ChebConvAttention(4, 8, 2, normalization="rw").to(backend.device)(X, ei, S)
 
 
+def test_chebconvattention_one_lambda_max_per_graph_matches_reference_fixture(backend):
+    """`conv(x, edge_index, attention, edge_weight, batch, lambda_max=tensor([2., 3.]))` (test/attention_test.py:205-217): every
+    entry of the Laplacian scaled by 2 / lambda_max[batch[row]] (astgcn.py:97-98) — values and gradients from the reference's
+    own astgcn.py; `batch` beside a single lambda_max (or none) changes nothing."""
+    from pytorch_geometric_temporal_amd.nn.attention import ChebConvAttention
+    g = load_golden("chebconvattention_graphs")
+    X, S, ei, ew, batch, lam, G = (backend.t(g["in"][k]) for k in ("X", "S", "edge_index", "edge_weight", "batch", "lambda_max", "G"))
+    K = int(g["meta"]["K"])
+    for norm in ("sym", "rw", None):
+        m = _load(ChebConvAttention(4, 8, K, normalization=norm), g["param"], backend.device)
+        with torch.no_grad():
+            assert_close_with_nonfinite(m(X, ei, S, ew, batch, lam), g["out"]["out_graphs_" + str(norm)], 2e-5, 2e-5, f"graphs {norm}")
+            assert_close_with_nonfinite(m(X, ei, S, None, batch, lam), g["out"]["out_graphs_noweight_" + str(norm)], 2e-5, 2e-5,
+                                        f"graphs, no weight {norm}")
+            assert_close_with_nonfinite(m(X, ei, S, ew, batch, torch.tensor(float(g["meta"]["lambda_scalar"]))),
+                                        g["out"]["out_batch_scalar_" + str(norm)], 2e-5, 2e-5, f"batch + one lambda {norm}")
+    m = _load(ChebConvAttention(4, 8, K, normalization="sym"), g["param"], backend.device)
+    with torch.no_grad():
+        assert_close_with_nonfinite(m(X, ei, S, ew, batch), g["out"]["out_batch_nolambda_sym"], 2e-5, 2e-5, "batch, no lambda")
+    Xd, Sd = X.clone().requires_grad_(), S.clone().requires_grad_()
+    (m(Xd, ei, Sd, ew, batch, lam) * G).sum().backward()
+    assert_close_with_nonfinite(Xd.grad, g["out"]["grad_X"], 5e-5, 1e-4, "dX")
+    assert_close_with_nonfinite(Sd.grad, g["out"]["grad_S"], 5e-5, 1e-4, "dS")
+    assert_close_with_nonfinite(m._weight.grad, g["out"]["grad__weight"], 1e-4, 1e-4, "dW")
+    assert_close_with_nonfinite(m._bias.grad, g["out"]["grad__bias"], 1e-4, 1e-4, "db")
+    # a label outside the lambda_max vector is an index error in the reference too; several lambdas without labels cannot be applied
+    with pytest.raises(IndexError, match="label"):
+        m(X, ei, S, ew, batch + 1, lam)
+    with pytest.raises(RuntimeError, match="batch"):
+        m(X, ei, S, ew, None, lam)
+
+
+def test_chebconv_one_lambda_max_per_graph_matches_restated_pyg_fixture(backend):
+    """PyG ChebConv.forward(x, edge_index, edge_weight, batch, lambda_max) with a lambda per graph: the same selection rule."""
+    g = load_golden("chebconv_graphs")
+    X, ei, ew, batch, lam = (backend.t(g["in"][k]) for k in ("X", "edge_index", "edge_weight", "batch", "lambda_max"))
+    for norm in ("sym", "rw", None):
+        m = _load(ChebConv(5, 7, int(g["meta"]["K"]), normalization=norm), g["param"], backend.device)
+        with torch.no_grad():
+            assert_close_with_nonfinite(m(X, ei, ew, batch, lam), g["out"]["out_graphs_" + str(norm)], 2e-5, 2e-5, f"graphs {norm}")
+            assert_close_with_nonfinite(m(X, ei, ew, batch, float(g["meta"]["lambda_scalar"])), g["out"]["out_batch_scalar_" + str(norm)],
+                                        2e-5, 2e-5, f"batch + one lambda {norm}")
+
+
 @pytest.mark.parametrize("K,norm,lam", [(1, "sym", None), (2, "sym", None), (3, "rw", 2.2), (4, None, 2.9)])
 def test_chebconvattention_backward_matches_oracle_autograd(backend, K, norm, lam):
     from pytorch_geometric_temporal_amd.nn.attention import ChebConvAttention

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_close_with_nonfinite
+from conftest import assert_close_with_nonfinite, load_golden
 from oracle import ref_import as R
 from pytorch_geometric_temporal_amd import ops
 from pytorch_geometric_temporal_amd.dataset import synthetic as syn
@@ -214,6 +214,33 @@ def test_stconv_forward_and_every_gradient_at_the_reference_test_shape(emu_backe
     if train:
         assert_close_with_nonfinite(our._batch_norm.running_mean, ref_bn.running_mean, 1e-5, 1e-5, "running_mean")
         assert_close_with_nonfinite(our._batch_norm.running_var, ref_bn.running_var, 1e-5, 1e-4, "running_var")
+
+
+def test_stconv_training_step_matches_reference_fixture_with_every_gradient(backend):
+    """STConv in training mode against tests/golden/stconv_sensor_grads.npz (the reference's own stgcn.py under torch autograd,
+    oracle/make_golden.py): forward, dX, every parameter gradient and the updated batch-norm running statistics — on the
+    product library (`-m gpu`) as on the CPU double, no detour through either."""
+    g = load_golden("stconv_sensor_grads")
+    X, ei, ew, G = (backend.t(g["in"][k]) for k in ("X", "edge_index", "edge_weight", "G"))
+    m = STConv(30, 4, 8, 6, kernel_size=3, K=int(g["meta"]["K"]), normalization="sym")
+    m.load_state_dict(g["param"], strict=True)
+    with torch.no_grad():                                    # the fixture's state_dict was taken AFTER the step: back to a fresh module's
+        m._batch_norm.running_mean.zero_()
+        m._batch_norm.running_var.fill_(1.0)
+        m._batch_norm.num_batches_tracked.zero_()
+    m = m.to(backend.device).train()
+    Xd = X.clone().requires_grad_()
+    out = m(Xd, ei, ew)
+    assert_close_with_nonfinite(out, g["out"]["out_train"], 2e-5, 2e-5, "forward (train mode)")
+    (out * G).sum().backward()
+    assert_close_with_nonfinite(Xd.grad, g["out"]["grad_X"], 1e-4 * float(g["out"]["grad_X"].abs().max()), 1e-4, "dX")
+    for name, p in m.named_parameters():
+        ref = g["out"]["grad_" + name]
+        assert p.grad is not None, name
+        assert_close_with_nonfinite(p.grad, ref, 1e-4 * float(ref.abs().max()) + 1e-7, 1e-4, name)
+    assert_close_with_nonfinite(m._batch_norm.running_mean, g["out"]["running_mean"], 1e-5, 1e-5, "running_mean")
+    assert_close_with_nonfinite(m._batch_norm.running_var, g["out"]["running_var"], 1e-5, 1e-4, "running_var")
+    assert int(m._batch_norm.num_batches_tracked) == 1
 
 
 @pytest.mark.gpu

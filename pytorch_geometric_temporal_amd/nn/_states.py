@@ -67,35 +67,71 @@ def _plain(out):
 
 
 # ---- packed operands shared by the calls of one training step -------------------------------------------------------------------
+import threading
 import weakref
+
+from torch.nn.modules.module import register_module_forward_hook, register_module_forward_pre_hook
 
 _PACKED = weakref.WeakKeyDictionary()
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+_scope = threading.local()        # .depth: nn.Module calls in flight on this thread; .epoch: outermost calls finished so far
+
+
+def _enter_module(module, args):
+    _scope.depth = getattr(_scope, "depth", 0) + 1
+
+
+def _leave_module(module, args, output):
+    d = getattr(_scope, "depth", 1) - 1
+    _scope.depth = d
+    if d <= 0:
+        _scope.depth = 0
+        _scope.epoch = getattr(_scope, "epoch", 0) + 1
+
+
+# The scope of "the same operands" is one OUTERMOST module call (the user's model: its T-step loop over the cell runs inside it).
+# Two process-wide hooks count the nesting; they do nothing else.
+register_module_forward_pre_hook(_enter_module)
+register_module_forward_hook(_leave_module, always_call=True)
 
 
 def _in_backward():
     return _graph_task_id is not None and _graph_task_id() != -1
 
 
-def packed_once(module, params, build):
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def packed_once(module, params, build, repack=None):
     """`build()` = the stacked / folded operands of a gated cell from `params` (one launch, an autograd node).  A sequence loop
     calls the cell once per time step with the SAME parameters (examples/indexBatching/tgcn/metr_la_main.py:41-45, examples/
     recurrent/dcrnn_example.py:38-46): packing per call also means one adjoint launch and a dozen gradient-accumulation adds per
-    call (144 five-microsecond adds per T = 12 training step of config 4).  The packed operands are therefore kept until the
-    parameters change (`_version`) or a backward pass has run through them (a hook on the first operand: their
-    autograd node is spent after that), so a T-step loop packs once and autograd sums the T gradients at the packed level.  Only
-    while gradients are being recorded: an inference call packs for itself."""
+    call (144 five-microsecond adds per T = 12 training step of config 4).  The operands are therefore kept until the parameters
+    change (`_version`) or a backward pass has run through them (a hook on the first operand), so a T-step loop packs once and
+    autograd sums the T gradients at the packed level.
+
+    What keeps this from ever serving stale weights: (1) within one outermost module call the operands are reused as they are;
+    across outermost calls (a per-snapshot loop in a script, two forwards before a backward) the autograd node is reused but the
+    VALUES are written again by `repack(params, packed)` — one pack launch, so a write that leaves `_version` alone
+    (`p.data.copy_()`, an EMA swap) is picked up; (2) operands made outside a hipGraph capture are not used inside one and vice
+    versa (the capture must hold its own pack launch and its own buffers); (3) only while gradients are being recorded: an
+    inference call packs for itself."""
     if not (torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)) or _in_backward():
         # inference: one cheap launch per call and nothing to accumulate — and no way to go stale.  A forward that runs INSIDE a
         # backward pass (torch.utils.checkpoint re-running a segment) gets operands of its own: the cached ones belong to the graph
-        # being walked right now, and a second walk through their node would find it freed
+        # being walked right now
         return build()
-    key = tuple((p.data_ptr(), p._version) if p is not None else None for p in params)
+    key = (tuple((p.data_ptr(), p._version) if p is not None else None for p in params), _capturing())
+    epoch = (getattr(_scope, "epoch", 0), getattr(_scope, "depth", 0) > 0)
     hit = _PACKED.get(module)
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and (repack is not None or hit[2] == epoch):
+        if hit[2] != epoch or not epoch[1]:            # another outermost call (or no enclosing module at all): values anew
+            repack(params, hit[1])
+            _PACKED[module] = (key, hit[1], epoch)
         return hit[1]
     packed = build()
-    _PACKED[module] = (key, packed)
+    _PACKED[module] = (key, packed, epoch)
     first = packed[0]
     if first.requires_grad:
         ref = weakref.ref(module)

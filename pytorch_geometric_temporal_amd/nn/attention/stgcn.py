@@ -26,6 +26,12 @@ class TemporalConv(nn.Module):
         self.conv_3 = nn.Conv2d(in_channels, out_channels, (1, kernel_size))
 
     def forward(self, X):
+        if X.dtype != torch.float32 or self.conv_1.weight.dtype != torch.float32:
+            # a double / half module (`.double()`, `.half()`): the kernels are fp32 — torch's own convolutions on the SAME device,
+            # in the order of stgcn.py:36-44
+            Xp = X.permute(0, 3, 2, 1)
+            H = F.relu(self.conv_1(Xp) * torch.sigmoid(self.conv_2(Xp)) + self.conv_3(Xp))
+            return H.permute(0, 3, 2, 1)
         return ops.temporal_conv(X, self.conv_1, self.conv_2, self.conv_3)     # relu(P * sigmoid(Q) + R), stgcn.py:36-44
 
 
@@ -54,4 +60,9 @@ class STConv(nn.Module):
         T = self._graph_conv(T_0, edge_index, edge_weight)             # every (b, t) slice in one Chebyshev stack
         T = F.relu(T)
         T = self._temporal_conv2(T)
-        return ops.batch_norm_nodes(T, self._batch_norm, self.training)  # BatchNorm2d over the node axis, stgcn.py:156-159
+        bn = self._batch_norm
+        if T.dtype != torch.float32 or (bn.weight is not None and bn.weight.dtype != torch.float32):
+            return bn(T.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)         # non-fp32 module: torch's batch norm as stgcn.py:156-159 calls it
+        # BatchNorm2d over the node axis, stgcn.py:156-159; batch statistics follow the BATCH NORM's own mode (a frozen
+        # `model._batch_norm.eval()` inside a training block uses its running statistics, as in the reference)
+        return ops.batch_norm_nodes(T, bn, bn.training)

@@ -70,7 +70,7 @@ def _cell_weights(conv_z, conv_r, conv_h):
     (ops.CellWeightsFunction) instead of three weight re-stackings and two concatenations."""
     params = (conv_z.weight, conv_r.weight, conv_h.weight, conv_z.bias, conv_r.bias)
     # (a per-snapshot loop calls the cell with the same parameters every time: packed once per training step, nn/_states.py)
-    Wzr, bzr, Wh = packed_once(conv_z, params, lambda: ops.CellWeightsFunction.apply(*params))
+    Wzr, bzr, Wh = packed_once(conv_z, params, lambda: ops.CellWeightsFunction.apply(*params), ops.CellWeightsFunction.repack)
     return Wzr, bzr, Wh, conv_h.bias
 
 

@@ -19,7 +19,7 @@ def _cell(mod, X2, H2, g, Bt, batch_major=False):
     params = (cz.lin.weight, cr.lin.weight, ch.lin.weight, cz.bias, cr.bias, ch.bias,
               mod.linear_z.weight, mod.linear_r.weight, mod.linear_h.weight, mod.linear_z.bias, mod.linear_r.bias, mod.linear_h.bias)
     # (one packing per training step, not per time step of the caller's loop: nn/_states.py packed_once)
-    Wzr, bzr, Wh, bh = packed_once(mod, params, lambda: ops.TGCNWeightsFunction.apply(*params))
+    Wzr, bzr, Wh, bh = packed_once(mod, params, lambda: ops.TGCNWeightsFunction.apply(*params), ops.TGCNWeightsFunction.repack)
     return ops.TGCNCellFunction.apply(X2, H2, Wzr, bzr, Wh, bh, g, Bt, batch_major)
 
 

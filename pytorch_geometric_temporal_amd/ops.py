@@ -964,14 +964,23 @@ class CellWeightsFunction(torch.autograd.Function):
         Wzr = torch.empty(S * C, 2 * O, dtype=F32, device=dev)
         Whs = torch.empty(S * C, O, dtype=F32, device=dev)
         bzr = torch.empty(2 * O, dtype=F32, device=dev) if bz is not None else None
-        Wzc, Wrc, Whc = Wz.contiguous(), Wr.contiguous(), Wh.contiguous()
-        lib.call("pgt_dcrnn_pack_weights_f32", ptr(Wzc), ptr(Wrc), ptr(Whc), ptr(bz.contiguous() if bz is not None else None),
-                 ptr(br.contiguous() if br is not None else None), K, C, O, ptr(Wzr), ptr(bzr), ptr(Whs), stream_of(lib, Wzr))
+        CellWeightsFunction.repack((Wz, Wr, Wh, bz, br), (Wzr, bzr, Whs))
         ctx.dims = (K, C, O)
         ctx.has_bias = bz is not None
         if bzr is None:
             return Wzr, None, Whs
         return Wzr, bzr, Whs
+
+    @staticmethod
+    def repack(params, packed):
+        """The pack launch alone, into operands that already exist (nn/_states.py packed_once refreshes cached operands with it)."""
+        lib = _lib.get_lib()
+        Wz, Wr, Wh, bz, br = params
+        Wzr, bzr, Whs = packed
+        _, K, C, O = Wz.shape
+        Wzc, Wrc, Whc = Wz.contiguous(), Wr.contiguous(), Wh.contiguous()
+        lib.call("pgt_dcrnn_pack_weights_f32", ptr(Wzc), ptr(Wrc), ptr(Whc), ptr(bz.contiguous() if bz is not None else None),
+                 ptr(br.contiguous() if br is not None else None), K, C, O, ptr(Wzr), ptr(bzr), ptr(Whs), stream_of(lib, Wzr))
 
     @staticmethod
     def backward(ctx, dWzr, dbzr, dWhs):
@@ -1194,12 +1203,26 @@ class DCRNNSeqSmallFunction(torch.autograd.Function):
     def forward(ctx, X, H0, Wzr, bzr, Wh, bh, g, K):
         lib = _lib.get_lib()
         check_tensor(lib, X, "X")
+        if X.dim() != 4:
+            raise ValueError(f"DCRNNSeqSmallFunction: X must be [B, T, N, in], got {tuple(X.shape)}")
         B, T, N, Fin = X.shape
         O = Wh.size(1)
+        S, C = 2 * K - 1, Fin + O
+        # the C entry point only null-checks its pointers: a wrong width here would be an out-of-bounds device read
+        if N != g.N:
+            raise ValueError(f"X has {N} nodes, the graph {g.N}")
+        if Wzr.shape != (S * C, 2 * O) or Wh.shape != (S * C, O):
+            raise ValueError(f"DCRNNSeqSmallFunction: inconsistent operand shapes: X has {Fin} input channels, the stacked weights "
+                             f"{tuple(Wzr.shape)} / {tuple(Wh.shape)} expect in + out = {Wzr.size(0) // S if S else 0} with out = {O} "
+                             f"(K = {K})")
+        if (bzr is not None and bzr.shape != (2 * O,)) or (bh is not None and bh.shape != (O,)):
+            raise ValueError("DCRNNSeqSmallFunction: inconsistent bias shapes")
         Xc = X.contiguous()
         H0c = None
         if H0 is not None:
             check_tensor(lib, H0, "H")
+            if H0.shape != (B, N, O):
+                raise ValueError(f"H must be {(B, N, O) if B > 1 else (N, O)}, got {tuple(H0.shape[1:] if B == 1 and H0.dim() == 3 else H0.shape)}")
             H0c = H0.contiguous()
         dev = X.device
         Wzr_c, Wh_c = Wzr.contiguous(), Wh.contiguous()
@@ -1511,12 +1534,28 @@ class TGCNWeightsFunction(torch.autograd.Function):
     -> Wzr [Fin + O, 2O], bzr [2O], Wh [Fin + O, O], bh [O]; one launch forward, one backward."""
 
     @staticmethod
-    def forward(ctx, Wcz, Wcr, Wch, bcz, bcr, bch, Lz, Lr, Lh, lbz, lbr, lbh):
-        lib = _lib.get_lib()
+    def _operands(params):
+        Wcz, Wcr, Wch, bcz, bcr, bch, Lz, Lr, Lh, lbz, lbr, lbh = params
         Wc = [t.contiguous() for t in (Wcz, Wcr, Wch)]
         L = [t.contiguous() for t in (Lz, Lr, Lh)]
         bc = [None if t is None else t.contiguous() for t in (bcz, bcr, bch)]
         lb = [None if t is None else t.contiguous() for t in (lbz, lbr, lbh)]
+        return Wc, bc, L, lb
+
+    @staticmethod
+    def repack(params, packed):
+        """The pack launch alone, into operands that already exist (nn/_states.py packed_once refreshes cached operands with it)."""
+        lib = _lib.get_lib()
+        Wc, bc, L, lb = TGCNWeightsFunction._operands(params)
+        O, Fin = Wc[0].shape
+        Wzr, bzr, Wh, bh = packed
+        lib.call("pgt_tgcn_pack_weights_f32", _lib.ptr3(*Wc), _lib.ptr3(*bc), _lib.ptr3(*L), _lib.ptr3(*lb), Fin, O, ptr(Wzr),
+                 ptr(bzr), ptr(Wh), ptr(bh), stream_of(lib, Wzr))
+
+    @staticmethod
+    def forward(ctx, *params):
+        lib = _lib.get_lib()
+        Wc, bc, L, lb = TGCNWeightsFunction._operands(params)
         for t in Wc + L:
             check_tensor(lib, t, "T-GCN parameter")
         O, Fin = Wc[0].shape
@@ -1527,9 +1566,14 @@ class TGCNWeightsFunction(torch.autograd.Function):
         buf = torch.empty(C * 3 * O + 3 * O, dtype=F32, device=dev)
         Wzr, Wh = buf[:C * 2 * O].view(C, 2 * O), buf[C * 2 * O:C * 3 * O].view(C, O)
         bzr, bh = buf[C * 3 * O:C * 3 * O + 2 * O], buf[C * 3 * O + 2 * O:]
-        lib.call("pgt_tgcn_pack_weights_f32", _lib.ptr3(*Wc), _lib.ptr3(*bc), _lib.ptr3(*L), _lib.ptr3(*lb), Fin, O, ptr(Wzr),
-                 ptr(bzr), ptr(Wh), ptr(bh), stream_of(lib, buf))
-        ctx.save_for_backward(*Wc, *L, *[t for t in bc if t is not None])
+        TGCNWeightsFunction.repack(params, (Wzr, bzr, Wh, bh))
+        # The folded operands are products of two parameters each, so the adjoint needs the parameters.  They are kept as plain
+        # attributes, not through save_for_backward: the operands of one pack may feed several independent graphs (packed_once:
+        # o1 = m(x1); o2 = m(x2); o1.backward(); o2.backward()), and autograd frees saved tensors after the first walk.  Inputs
+        # held by their own node form no reference cycle; the in-place check save_for_backward would have made is done by hand.
+        ctx.kept = (Wc, L, bc)
+        ctx.versions = tuple(tensor_version(t) for t in params if t is not None)
+        ctx.kept_sources = tuple(t for t in params if t is not None)
         ctx.bias_mask = tuple(t is not None for t in bc)
         ctx.lb_mask = tuple(t is not None for t in lb)
         ctx.dims = (Fin, O)
@@ -1538,9 +1582,10 @@ class TGCNWeightsFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dWzr, dbzr, dWh, dbh):
         lib = _lib.get_lib()
-        saved = ctx.saved_tensors
-        Wc, L, rest = list(saved[:3]), list(saved[3:6]), list(saved[6:])
-        bc = [rest.pop(0) if m else None for m in ctx.bias_mask]
+        if tuple(tensor_version(t) for t in ctx.kept_sources) != ctx.versions:
+            raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                               "a T-GCN parameter changed between the forward pass and this backward pass")
+        Wc, L, bc = ctx.kept
         Fin, O = ctx.dims
         dev = Wc[0].device
         C = Fin + O
@@ -1584,6 +1629,10 @@ class TGCNCellFunction(torch.autograd.Function):
         N = g.N
         if M != N * Bt or H.shape != (M, O):
             raise ValueError(f"TGCN: X has {M} rows, H {tuple(H.shape)}, expected num_nodes*B = {N * Bt} rows of {O}")
+        if Wzr.shape != (C, 2 * O) or Wh.shape != (C, O) or (bzr is not None and bzr.shape != (2 * O,)) or \
+                (bh is not None and bh.shape != (O,)):
+            raise ValueError(f"TGCN: X has {Fin} input channels, the folded weights {tuple(Wzr.shape)} / {tuple(Wh.shape)} expect "
+                             f"{Wzr.size(0) - O} (in_channels of the module)")
         dev = Xc.device
         AX = TGCNCellFunction._aggregate(g.fwd, Xc, N, Bt, Fin, batch_major)
         ZR = torch.empty(M, 2 * O, dtype=F32, device=dev)

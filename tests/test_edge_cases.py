@@ -117,3 +117,35 @@ def test_wrong_dtype_device_and_index_range_fail_loudly(backend):
     if backend.name == "hip":
         with pytest.raises(_lib.PgtError, match="no CPU fallback"):
             m(torch.randn(n, 2), backend.t(ei))
+
+
+@pytest.mark.parametrize("K", [1, 2, 3])
+def test_operands_of_the_wrong_width_are_refused_before_any_launch(backend, K):
+    """The one-workgroup cell / sequence kernels read the stacked weights and the state by the sizes they are TOLD (the C entry
+    points only null-check pointers): X or H of another width than the module's must raise in Python, on every path — the
+    reference fails in its first matmul.  (Round 4's advisor: DCRNN(4, 8, K=2) on X [N, 6] returned garbage.)"""
+    from pytorch_geometric_temporal_amd.nn.recurrent import TGCN2
+    n = 12
+    ei_np, ew_np = syn.sensor_graph(n, 50, seed=2, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    cell = DCRNN(4, 8, K).to(backend.device)
+    good_x, good_h = backend.t(torch.randn(n, 4)), backend.t(torch.randn(n, 8))
+    assert cell(good_x, ei, ew, good_h).shape == (n, 8)
+    cases = [(torch.randn(n, 6), None), (torch.randn(n, 2), None), (torch.randn(n, 4), torch.randn(n, 5)),
+             (torch.randn(n, 4), torch.randn(n - 3, 8))]
+    if K > 1:                                                    # (K = 1 never touches the graph: fewer rows than nodes is legal there,
+        cases.append((torch.randn(n - 1, 4), None))              #  in the reference too, dcrnn.py:79-82)
+    for x, h in cases:
+        with pytest.raises((ValueError, IndexError)):
+            cell(backend.t(x), ei, ew, None if h is None else backend.t(h))
+    seq = BatchedDCRNN(2, 2, K=max(K, 2)).to(backend.device)           # hidden 2: the whole sequence in one workgroup
+    assert seq(backend.t(torch.randn(3, 4, n, 2)), ei, ew).shape == (3, 4, n, 2)
+    for x in (torch.randn(3, 4, n, 3), torch.randn(3, 4, n, 1)):       # (more nodes than the edge list names are isolated nodes: legal)
+        with pytest.raises((ValueError, IndexError)):
+            seq(backend.t(x), ei, ew)
+    for m, x, h in ((TGCN(4, 32).to(backend.device), torch.randn(n, 6), None),          # hidden 32: the one-launch cell
+                    (TGCN(4, 32).to(backend.device), torch.randn(n, 4), torch.randn(n, 16)),
+                    (TGCN2(4, 32, 1).to(backend.device), torch.randn(2, n, 3), None),
+                    (TGCN(4, 8).to(backend.device), torch.randn(n, 5), None)):
+        with pytest.raises((ValueError, IndexError)):
+            m(backend.t(x), ei, ew, None if h is None else backend.t(h))

@@ -1009,12 +1009,18 @@ def test_cell_operands_are_packed_once_per_training_step(backend):
             m = make().to(backend.device)
             xs = [backend.t(torch.randn(B, n, 2)) for _ in range(4)]
 
-            def loop():
-                h, tot = None, 0
-                for x in xs:
-                    h = run(m, x, h)
-                    tot = tot + h.square().mean()
-                return tot
+            class Seq(torch.nn.Module):                       # the user's model: its loop over the cell runs inside ONE module call
+                def __init__(self, cell):
+                    super().__init__()
+                    self.cell = cell
+
+                def forward(self):
+                    h, tot = None, 0
+                    for x in xs:
+                        h = run(self.cell, x, h)
+                        tot = tot + h.square().mean()
+                    return tot
+            loop = Seq(m)
             counts.clear()
             m.zero_grad()
             loop().backward()
@@ -1024,7 +1030,7 @@ def test_cell_operands_are_packed_once_per_training_step(backend):
             m.zero_grad()
             loop().backward()                                 # the backward pass spent the packed operands: packed again
             assert counts[pack] == 1
-            saved, _states.packed_once = _states.packed_once, (lambda module, params, build: build())
+            saved, _states.packed_once = _states.packed_once, (lambda module, params, build, repack=None: build())
             try:
                 import importlib
                 for modname in ("temporalgcn", "dcrnn"):
@@ -1050,8 +1056,64 @@ def test_cell_operands_are_packed_once_per_training_step(backend):
             with torch.no_grad():
                 run(m, xs[0], None); run(m, xs[0], None)
             assert counts[pack] == 2                          # inference packs per call
+            # the same loop at script level (every cell call an outermost module call, examples/recurrent/dcrnn_example.py:38-46):
+            # ONE autograd node — one adjoint launch — but the values are written again per call (a `.data` write is picked up)
+            m.zero_grad()
+            loop().backward()                                 # (the parameters moved above: the reference gradients anew)
+            g_once = {k: p.grad.clone() for k, p in m.named_parameters()}
+            counts.clear()
+            m.zero_grad()
+            h, tot = None, 0
+            for x in xs:
+                h = run(m, x, h)
+                tot = tot + h.square().mean()
+            tot.backward()
+            assert counts[pack] == 4 and counts[unpack] == 1, counts
+            for k, p in m.named_parameters():
+                assert_close_with_nonfinite(g_once[k], p.grad, 1e-6 + 2e-5 * float(p.grad.abs().max()), 1e-5, k + " (script-level loop)")
     finally:
         lib.call = orig
+
+
+@pytest.mark.parametrize("kind", ["tgcn", "tgcn2", "dcrnn"])
+def test_two_forwards_then_two_backwards_and_data_writes_between_forwards(backend, kind):
+    """Round 4's advisor cases on the shared pack: (a) o1 = m(x1); o2 = m(x2); o1.sum().backward(); o2.sum().backward() works as
+    in the reference and gives the sum of the two gradients; (b) a write through `p.data` (no `_version` bump) between two
+    grad-enabled forwards with no backward in between is seen by the second forward."""
+    from pytorch_geometric_temporal_amd.nn.recurrent import DCRNN
+    torch.manual_seed(11)
+    n = 13
+    ei_np, ew_np = syn.sensor_graph(n, 60, seed=5, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    m = {"tgcn": lambda: TGCN(3, 8), "tgcn2": lambda: TGCN2(3, 8, 1), "dcrnn": lambda: DCRNN(3, 8, 2)}[kind]().to(backend.device)
+    shape = (2, n, 3) if kind == "tgcn2" else (n, 3)
+    x1, x2 = backend.t(torch.randn(*shape)), backend.t(torch.randn(*shape))
+    # (a)
+    m.zero_grad()
+    o1 = m(x1, ei, ew)
+    o2 = m(x2, ei, ew)
+    o1.sum().backward()
+    o2.sum().backward()
+    both = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    (m(x1, ei, ew).sum() + m(x2, ei, ew).sum()).backward()
+    for k, p in m.named_parameters():
+        assert_close_with_nonfinite(both[k], p.grad, 1e-6 + 1e-5 * float(p.grad.abs().max()), 1e-5, k)
+    # (b)
+    o1 = m(x1, ei, ew).detach().clone()
+    for p in m.parameters():
+        p.data.zero_()
+    o2 = m(x1, ei, ew).detach()
+    with torch.no_grad():
+        fresh = m(x1, ei, ew)
+    assert torch.equal(o2, fresh) and float((o2 - o1).abs().max()) > 1e-3
+    # a parameter changed in place between a forward and its backward: an error, as with torch's own saved tensors
+    if kind != "dcrnn":                                       # (DCRNN's pack is linear in the parameters: nothing saved, nothing to check)
+        out = m(x1, ei, ew)
+        with torch.no_grad():
+            m.linear_z.weight.add_(1.0)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            out.sum().backward()
 
 
 def test_packed_operands_under_reentrant_checkpointing(backend):

@@ -282,3 +282,35 @@ def test_stconv_at_the_reference_test_shape_on_the_gpu_matches_the_cpu_double():
     for n in gp_c:
         assert_close_with_nonfinite(gp_g[n], gp_c[n], 1e-4 * float(gp_c[n].abs().max()) + 1e-7, 1e-4, n)
     assert_close_with_nonfinite(rv_g, rv_c, 1e-5, 1e-5, "running_var")
+
+
+def test_frozen_batch_norm_and_double_modules_follow_the_reference(emu_backend):
+    """(a) `model._batch_norm.eval()` inside a training STConv: running statistics are used and left alone, as torch's BatchNorm2d
+    does in the reference (round 4's advisor: the block's own flag was consulted).  (b) a `.double()` TemporalConv runs (torch's
+    convolutions, stgcn.py:36-44) and agrees with the fp32 kernel path."""
+    torch.manual_seed(3)
+    ei_np, ew_np = syn.sensor_graph(12, 50, seed=4, symmetric=False)
+    ei, ew = torch.from_numpy(ei_np), torch.from_numpy(ew_np)
+    X = torch.randn(2, 6, 12, 3)
+    m = STConv(12, 3, 4, 5, 3, 2)
+    with torch.no_grad():
+        m._batch_norm.running_mean.uniform_(-0.5, 0.5)
+        m._batch_norm.running_var.uniform_(0.5, 1.5)
+    rm, rv = m._batch_norm.running_mean.clone(), m._batch_norm.running_var.clone()
+    m.train()
+    m._batch_norm.eval()
+    out_frozen = m(X, ei, ew)
+    assert torch.equal(m._batch_norm.running_mean, rm) and torch.equal(m._batch_norm.running_var, rv)
+    assert int(m._batch_norm.num_batches_tracked) == 0
+    m.eval()
+    assert_close_with_nonfinite(out_frozen, m(X, ei, ew), 1e-6, 1e-6, "frozen batch norm = eval-mode statistics")
+    m.train()
+    out_train = m(X, ei, ew)
+    assert not torch.equal(m._batch_norm.running_mean, rm) and float((out_train - out_frozen).detach().abs().max()) > 1e-3
+    tc = TemporalConv(3, 4, 3)
+    ref32 = tc(X)
+    tc64 = TemporalConv(3, 4, 3).double()
+    tc64.load_state_dict({k: v.double() for k, v in tc.state_dict().items()})
+    out64 = tc64(X.double())
+    assert out64.dtype == torch.float64
+    assert_close_with_nonfinite(ref32, out64, 1e-5, 1e-5, "double TemporalConv vs the fp32 kernels")

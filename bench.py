@@ -555,6 +555,41 @@ def aux_worker(args):
         log(f"other config {name} done")
 
 
+def self_launch(argv, n):
+    """`python bench.py --gpus N` with no launcher in the environment (the reference starts its N workers from one command too,
+    examples/indexBatching/DCRNN/pems_ddp.py:198-207): re-run this script under torch.distributed.run, one rank per GPU, rendezvous
+    on 127.0.0.1; the ranks' output (rank 0's ONE JSON line on stdout, stage marks on stderr) passes straight through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL on hosts whose driver only has dmabuf IPC
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 1) // n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log(f"--gpus {n} without a launcher: " + " ".join(cmd[1:8]) + " ...")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_probe(rank, world):
+    """PGT_BENCH_LAUNCH_PROBE=1 (tests/test_distributed.py, CPU, gloo): the ranks meet, reduce once and rank 0 prints a line of the
+    printed format — everything of the N > 1 path that does not need a GPU."""
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t)
+    if rank == 0:
+        import bench_line
+        print(bench_line.compact({"metric": "snapshot-edges aggregated/sec", "value": 0.0, "unit": "snapshot-edges/s", "n_gpus": world,
+                                  "steps": 0, "warmup": 0, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak",
+                                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                  "config": {"workload": "launch probe (no GPU work)", "rank_sum": float(t)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def pin_host_threads(local_rank, world):
     """8 ranks x ~250 ctypes launches per step share one host: give every rank its own slice of the cores and keep
     the intra-op pools small (the step is launch-issue bound on the host side, not compute bound)."""
@@ -603,6 +638,8 @@ def main():
     if args.cpu_sweep_worker:                  # child of cpu_baseline's thread sweep: one thread count, CPU only, prints the rate
         print(cpu_sweep_point(args.hidden, args.cpu_sweep_worker))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # plain `python bench.py --gpus N`: start the ranks ourselves
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     t_start = time.time()
     if os.environ.get("PGT_BENCH_STACKS"):          # diagnostic: the Python stack on stderr every N seconds (where a slow box sits)
         import faulthandler
@@ -618,6 +655,9 @@ def main():
     # the one GPU of a test box so that the multi-rank code path (barrier, all-reduce, MAX-reduce, rank-0 printing) runs there.
     rank, local_rank, world = dp.init_from_env(os.environ.get("PGT_BENCH_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("PGT_BENCH_LAUNCH_PROBE") == "1":
+        launch_probe(rank, world)
+        return
     pin_host_threads(local_rank, world)
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)

@@ -148,3 +148,20 @@ def test_flat_parameters_adam_equals_per_parameter_adam():
     b.load_state_dict(a.state_dict())                      # copies into the views
     assert b[2].bias.data_ptr() == flat.data[-2:].data_ptr()
     torch.testing.assert_close(flat.data[-2:], a[2].bias.detach())
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_in_the_environment():
+    """`python bench.py --gpus 2` with no WORLD_SIZE set re-runs itself under torch.distributed.run (one process per GPU, rendezvous
+    on 127.0.0.1) and rank 0 prints ONE line of the printed format with n_gpus = 2.  PGT_BENCH_LAUNCH_PROBE=1 stops the ranks after
+    the rendezvous + one all-reduce (gloo, no GPU here); the same command without it is the 2-GPU bench."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PGT_BENCH_LAUNCH_PROBE="1", PGT_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rank_sum"] == 3.0        # ranks 0 and 1 met: 1 + 2
+    assert "torch.distributed.run" in r.stderr

@@ -542,6 +542,8 @@ def aux_worker(args):
         "config5_covid_evolvegcnh": lambda: BCfg.covid_epoch(device, cores),
     }
     assert tuple(blocks) == AUX_BLOCKS
+    if args.aux_only:
+        blocks = {k: v for k, v in blocks.items() if k in args.aux_only.split(",")}
     for name, fn in blocks.items():
         if time.time() - t_start > args.aux_seconds:
             res = {"skipped": f"--aux-seconds spent ({args.aux_seconds:g} s left for the auxiliary process)"}
@@ -628,6 +630,7 @@ def main():
                          "(per-GPU batches whose step is host-launch bound, e.g. --global-batch 1024 on 8 GPUs)")
     ap.add_argument("--cpu-sweep-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--aux-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--aux-only", default="", help=argparse.SUPPRESS)      # with --aux-worker: only these blocks (comma-separated)
     ap.add_argument("--aux-seconds", type=float, default=200.0,
                     help="wall-clock budget of the whole run after which the remaining AUXILIARY lines (variants, other configs) are "
                          "skipped and recorded as such: the default run has to finish within minutes on any box")

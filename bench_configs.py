@@ -225,15 +225,18 @@ def covid_epoch(device, cores):
             epoch()
         finally:
             snaps = keep
-    t_fresh = _time_gpu(fresh_epoch, 3, warm=1)
+    skip = os.environ.get("PGT_COVID_SKIP", "").split(",")      # diagnostic (scripts/covid_fault_hunt.sh): leave stages out
+    t_fresh = _time_gpu(fresh_epoch, 3, warm=1) if "fresh" not in skip else float("nan")
     fits = ops.gcn_small_fits
     try:
         ops.gcn_small_fits = lambda *a: False
-        t_fresh_prepared = _time_gpu(fresh_epoch, 3, warm=1)
+        t_fresh_prepared = _time_gpu(fresh_epoch, 3, warm=1) if "prepared" not in skip else float("nan")
     finally:
         ops.gcn_small_fits = fits
     t_graph = None
     try:
+        if "graphed" in skip:
+            raise RuntimeError("skipped")
         graphed = GraphedStep(epoch, [])
         t_graph = _time_gpu(lambda: graphed(), 20)
     except Exception as e:                          # an auxiliary line must never cost the bench line

@@ -84,6 +84,10 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_seq_set_vdot(value);
     return PGT_OK;
   }
+  if (strcmp(key, "tgcn_rows") == 0) {
+    pgt_tgcn_set_rows(value);
+    return PGT_OK;
+  }
   if (strcmp(key, "slab_gu") == 0) {
     pgt_slab_set_gu(value);
     return PGT_OK;

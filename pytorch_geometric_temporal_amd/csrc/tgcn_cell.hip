@@ -17,7 +17,11 @@
 //   d/dX (the transposed aggregation's operand) is not produced here: a caller that needs it runs the unfused adjoint.
 #include "pgt_common.h"
 
+#include <initializer_list>
+
 namespace {
+
+int g_tc_rows = 1;                  // pgt_tune("tgcn_rows", 0): the round-4 column-per-lane kernels for every shape
 
 constexpr int TC_O = 32;            // hidden width these kernels are built for
 constexpr int TC_LD = 33;           // LDS row pitch of a wavefront's strips (32 rows + 1: conflict-free both ways)
@@ -382,11 +386,315 @@ __global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __re
   else if (dbh) dbh[e - nWzr - 64 - nWh] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Row-per-lane forms (Fin <= 2, every operand 16-byte addressable): the products are computed TRANSPOSED — D^T = W^T X^T — so the
+// weights are the A operand (lane = output column, in registers for the whole launch) and a lane's B operand is ITS OWN ROW:
+// lane (lo, hi) holds columns 8q + 4hi + j (q, j = 0 .. 3) of row lo, exactly the four 16-byte pieces a global_load_dwordx4
+// brings in, and the accumulator comes back in the same layout (register r <-> column tc_row(r, hi), lane <-> row).  The
+// contraction index is visited in that permuted order (any order is a valid sum; the weights are fetched to match), so
+//   * every global access is a 16-byte row piece (the first forms moved 4 bytes per lane: 96 memory instructions per 32-row strip
+//     against 21 here),
+//   * H, Z | R, H * R, the candidate and the blend never leave the lane's registers: the forward kernel touches no LDS strip,
+//   * the adjoint needs LDS only where the contraction runs over ROWS (the weight gradients): three row-major [32][36] matrices
+//     per wavefront, written with ds_write_b128 and read column-wise, conflict-free both ways.
+// Rounds 4's kernels above stay as the path for 3 <= Fin <= 30 and for operands that are not 16-byte addressable.
+
+// bias: the accumulators start from it (12 broadcast ds_read_b128 per strip instead of 48 registers or three more MFMAs)
+__device__ __forceinline__ void tc_bias_init(pgt_f32x16& acc, const float* sb, int hi) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const pgt_f4 b = *reinterpret_cast<const pgt_f4*>(sb + 8 * q + 4 * hi);
+    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
+  __shared__ __attribute__((aligned(16))) float s_b[96];                   // bzr | bh
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+  const int Fin = g.Fin;
+  if (tid < 96) s_b[tid] = tid < 64 ? (g.bzr ? g.bzr[tid] : 0.f) : (g.bh ? g.bh[tid - 64] : 0.f);
+  // A operands: this lane's column `lo` of the three weight blocks, k in the order the row pieces arrive; step 16 = the inputs
+  float wz[17], wr[17], wh[17];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int64_t k = Fin + tc_row(s, hi);
+    wz[s] = g.Wzr[k * 64 + lo]; wr[s] = g.Wzr[k * 64 + 32 + lo]; wh[s] = g.Wh[k * 32 + lo];
+  }
+  {
+    const bool in = hi < Fin;
+    wz[16] = in ? g.Wzr[(int64_t)hi * 64 + lo] : 0.f; wr[16] = in ? g.Wzr[(int64_t)hi * 64 + 32 + lo] : 0.f;
+    wh[16] = in ? g.Wh[(int64_t)hi * 32 + lo] : 0.f;
+  }
+  __syncthreads();
+  const float* __restrict__ Hg = g.H;
+  const float* __restrict__ AXg = g.AX;
+  float* __restrict__ ZRg = g.ZR;
+  float* __restrict__ HTg = g.HT;
+  float* __restrict__ Hng = g.Hn;
+  // a strip's rows start at a wavefront-UNIFORM address (scalar registers); a lane adds a 32-bit offset of its own
+  const int64_t n_strips = ((int64_t)g.M + 31) >> 5, stride = (int64_t)gridDim.x * 4;
+  const int wave_u = PGT_UNIFORM(wave);
+  pgt_f4 hq[4];
+  float axv = 0.f;
+  auto fetch = [&](int64_t st) {
+    const int64_t r0 = st * 32, left = (int64_t)g.M - 1 - r0;
+    const int lr = lo < left ? lo : (int)left;                       // rows past the end re-read the last one (never stored)
+    const float* hp = Hg + r0 * g.ldh + (lr * (int)g.ldh + 4 * hi);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hq[q] = *reinterpret_cast<const pgt_f4*>(hp + 8 * q);
+    axv = hi < Fin ? AXg[r0 * g.ldax + (lr * (int)g.ldax + hi)] : 0.f;
+  };
+  int64_t st = (int64_t)blockIdx.x * 4 + wave_u;
+  if (st < n_strips) fetch(st);
+  for (; st < n_strips; st += stride) {
+    float h[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { h[4 * q] = hq[q].x; h[4 * q + 1] = hq[q].y; h[4 * q + 2] = hq[q].z; h[4 * q + 3] = hq[q].w; }
+    const float ax = axv;
+    if (st + stride < n_strips) fetch(st + stride);            // the next strip's pieces travel while this one is on the matrix cores
+    pgt_f32x16 az, ar, ah;
+    tc_bias_init(az, s_b, hi);
+    tc_bias_init(ar, s_b + 32, hi);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      az = PGT_MFMA_32x32x2(wz[s], h[s], az);
+      ar = PGT_MFMA_32x32x2(wr[s], h[s], ar);
+    }
+    az = PGT_MFMA_32x32x2(wz[16], ax, az);
+    ar = PGT_MFMA_32x32x2(wr[16], ax, ar);
+    const int64_t r0 = st * 32;
+    const bool ok = r0 + lo < g.M;
+    float z[16], hr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      z[r] = tc_sigmoidf(az[r]);
+      ar[r] = tc_sigmoidf(ar[r]);
+      hr[r] = h[r] * ar[r];
+    }
+    if (ok) {
+      float* zp = ZRg + r0 * 64 + (lo * 64 + 4 * hi);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<pgt_f4*>(zp + 8 * q) = pgt_mk4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+        *reinterpret_cast<pgt_f4*>(zp + 32 + 8 * q) = pgt_mk4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
+      }
+    }
+    tc_bias_init(ah, s_b + 64, hi);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) ah = PGT_MFMA_32x32x2(wh[s], hr[s], ah);
+    ah = PGT_MFMA_32x32x2(wh[16], ax, ah);
+    if (ok) {
+      float* tp = HTg + r0 * 32 + (lo * 32 + 4 * hi);
+      float* np = Hng + r0 * g.ldhn + (lo * (int)g.ldhn + 4 * hi);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t[4], n[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t[j] = tc_tanhf(ah[4 * q + j]); n[j] = pgt_gru_blend(z[4 * q + j], h[4 * q + j], t[j]); }
+        *reinterpret_cast<pgt_f4*>(tp + 8 * q) = pgt_mk4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<pgt_f4*>(np + 8 * q) = pgt_mk4(n[0], n[1], n[2], n[3]);
+      }
+    }
+  }
+}
+
+constexpr int TC_P = 36;            // row pitch of the adjoint's row-major LDS matrices (16-byte rows: ds_write_b128; 36 mod 32 = 4)
+
+__device__ __forceinline__ void tc_park_rows(float* mat, int lo, int hi, const float (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<pgt_f4*>(mat + lo * TC_P + 8 * q + 4 * hi) = pgt_mk4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+__global__ __launch_bounds__(256, 2) void tgcn_cell_bwd_rows_kernel(TcArgs g) {
+  __shared__ __attribute__((aligned(16))) float s_t[4][3 * 32 * TC_P];     // per wavefront: M0 | M1 | M2, each [32 rows][36]
+  __shared__ __attribute__((aligned(16))) float s_ax[4][32 * 2];            // per wavefront: the strip's input columns [row][2]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+  const int Fin = g.Fin, C = Fin + TC_O;
+  float* M0 = s_t[wave];
+  float* M1 = M0 + 32 * TC_P;
+  float* M2 = M1 + 32 * TC_P;
+  float* axs = s_ax[wave];
+  // A operands of the two "weights x d_pre^T" products: row Fin + lo of the hidden blocks, k in the order of the row pieces —
+  // [step][lane] in LDS (48 conflict-free reads per strip; as registers they pushed the kernel past 256)
+  __shared__ float s_w[48 * 64];
+  for (int e = tid; e < 48 * 64; e += 256) {
+    const int s = (e >> 6) & 15, blk = e >> 10, l = e & 63, c = tc_row(s, l >> 5);
+    const int64_t i = Fin + (l & 31);
+    s_w[e] = blk == 0 ? g.Wh[i * 32 + c] : g.Wzr[i * 64 + (blk - 1) * 32 + c];
+  }
+  const float* a1 = s_w + lane;
+  const float* a2z = s_w + 1024 + lane;
+  const float* a2r = s_w + 2048 + lane;
+  __syncthreads();
+  const float* __restrict__ dHg = g.dHn;
+  const float* __restrict__ ZRg = g.ZR;
+  const float* __restrict__ HTg = g.HT;
+  const float* __restrict__ Hg = g.H;
+  const float* __restrict__ AXg = g.AX;
+  pgt_f32x16 wz1a, wz1b, wh1;                          // H^T d_pre_z, H^T d_pre_r, (H R)^T d_pre_h
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { wz1a[r] = 0.f; wz1b[r] = 0.f; wh1[r] = 0.f; }
+  float tz[3] = {0.f, 0.f, 0.f}, th[3] = {0.f, 0.f, 0.f};   // [AX | 1]^T d: column `lane` of d_pre_z | d_pre_r; column lo of d_pre_h (half the rows per hi)
+  const int64_t n_strips = ((int64_t)g.M + 31) >> 5, stride = (int64_t)gridDim.x * 4;
+  const int wave_u = PGT_UNIFORM(wave);
+  for (int64_t st = (int64_t)blockIdx.x * 4 + wave_u; st < n_strips; st += stride) {
+    // a strip's rows start at a wavefront-UNIFORM address (scalar registers); a lane adds a 32-bit offset of its own
+    const int64_t r0 = st * 32, left = (int64_t)g.M - 1 - r0;
+    const bool ok = lo <= left;
+    const int lr = ok ? lo : (int)left;                              // rows past the end re-read the last one (their g is zeroed)
+    float gg[16], z[16], rr[16], t[16], h[16];
+    {
+      const float* gp = dHg + r0 * g.lddhn + (lr * (int)g.lddhn + 4 * hi);
+      const float* zp = ZRg + r0 * 64 + (lr * 64 + 4 * hi);
+      const float* tp = HTg + r0 * 32 + (lr * 32 + 4 * hi);
+      const float* hp = Hg + r0 * g.ldh + (lr * (int)g.ldh + 4 * hi);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const pgt_f4 a = *reinterpret_cast<const pgt_f4*>(gp + 8 * q), b = *reinterpret_cast<const pgt_f4*>(zp + 8 * q),
+                     c = *reinterpret_cast<const pgt_f4*>(zp + 32 + 8 * q), d = *reinterpret_cast<const pgt_f4*>(tp + 8 * q),
+                     e = *reinterpret_cast<const pgt_f4*>(hp + 8 * q);
+        gg[4 * q] = a.x; gg[4 * q + 1] = a.y; gg[4 * q + 2] = a.z; gg[4 * q + 3] = a.w;
+        z[4 * q] = b.x; z[4 * q + 1] = b.y; z[4 * q + 2] = b.z; z[4 * q + 3] = b.w;
+        rr[4 * q] = c.x; rr[4 * q + 1] = c.y; rr[4 * q + 2] = c.z; rr[4 * q + 3] = c.w;
+        t[4 * q] = d.x; t[4 * q + 1] = d.y; t[4 * q + 2] = d.z; t[4 * q + 3] = d.w;
+        h[4 * q] = e.x; h[4 * q + 1] = e.y; h[4 * q + 2] = e.z; h[4 * q + 3] = e.w;
+      }
+    }
+    const float ax = (ok && hi < Fin) ? AXg[r0 * g.ldax + (lr * (int)g.ldax + hi)] : 0.f;
+    // the row-contracting products need (row, column) transposed: H, d_pre_z, d_pre_r go row-major into the wavefront's strip
+    tc_park_rows(M0, lo, hi, h);
+    axs[lo * 2 + hi] = ax;
+    float dph[16], dz[16], gz[16], hr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float g1 = ok ? gg[r] : 0.f;                               // rows past the end contribute nothing anywhere
+      dph[r] = g1 * (1.f - z[r]) * (1.f - t[r] * t[r]);                // d_pre_h
+      dz[r] = g1 * (h[r] - t[r]) * z[r] * (1.f - z[r]);                // d_pre_z
+      gz[r] = g1 * z[r];
+      hr[r] = h[r] * rr[r];
+    }
+    tc_park_rows(M1, lo, hi, dz);
+    pgt_f32x16 p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) p = PGT_MFMA_32x32x2(a1[s * 64], dph[s], p);             // d(H R)^T = Wh_H d_pre_h^T
+    float dr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dr[r] = p[r] * hr[r] * (1.f - rr[r]);                            // d_pre_r
+      gz[r] = fmaf(p[r], rr[r], gz[r]);
+    }
+    tc_park_rows(M2, lo, hi, dr);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      p = PGT_MFMA_32x32x2(a2z[s * 64], dz[s], p);                     // d_pre_zr Wzr_H^T, transposed
+      p = PGT_MFMA_32x32x2(a2r[s * 64], dr[s], p);
+    }
+    if (ok) {
+      float* dp = g.dH + r0 * g.lddh + (lo * (int)g.lddh + 4 * hi);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<pgt_f4*>(dp + 8 * q) = pgt_mk4(gz[4 * q] + p[4 * q], gz[4 * q + 1] + p[4 * q + 1], gz[4 * q + 2] + p[4 * q + 2],
+                                                          gz[4 * q + 3] + p[4 * q + 3]);
+    }
+    PGT_WAVE_SYNC();
+    // dWzr (hidden rows) += H^T [d_pre_z | d_pre_r]: A[m = feature][k = row], B[k = row][n = column]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int rho = 2 * s + hi;
+      const float a = M0[rho * TC_P + lo], bz = M1[rho * TC_P + lo], br = M2[rho * TC_P + lo];
+      wz1a = PGT_MFMA_32x32x2(a, bz, wz1a);
+      wz1b = PGT_MFMA_32x32x2(a, br, wz1b);
+    }
+    // the input rows and the bias ([AX | 1]^T d) on the vector unit: three sums per column instead of a 32-row MFMA block of
+    // which three rows are alive (a third of the first form's matrix-core time)
+    {
+      const float* dcol = (hi ? M2 : M1) + lo;                         // lane = column `lane` of [d_pre_z | d_pre_r]
+#pragma unroll 4
+      for (int rho = 0; rho < 32; ++rho) {
+        const float d = dcol[rho * TC_P];
+        tz[0] = fmaf(axs[rho * 2], d, tz[0]);
+        tz[1] = fmaf(axs[rho * 2 + 1], d, tz[1]);
+        tz[2] += d;
+      }
+    }
+    PGT_WAVE_SYNC();
+    tc_park_rows(M0, lo, hi, hr);
+    tc_park_rows(M1, lo, hi, dph);
+    PGT_WAVE_SYNC();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int rho = 2 * s + hi;
+      const float d = M1[rho * TC_P + lo];
+      wh1 = PGT_MFMA_32x32x2(M0[rho * TC_P + lo], d, wh1);          // dWh (hidden rows) += (H R)^T d_pre_h
+      th[0] = fmaf(axs[rho * 2], d, th[0]);                            // (its input rows and bias: this lane's half of the rows)
+      th[1] = fmaf(axs[rho * 2 + 1], d, th[1]);
+      th[2] += d;
+    }
+    PGT_WAVE_SYNC();                                                   // the strip is rewritten by the next one
+  }
+  // ---- the four wavefronts' sums meet in LDS (the strips are dead), one partial per workgroup
+  __syncthreads();
+  float* red = &s_t[0][0];                                             // 4 x 3 x 1024 accumulator floats, then 4 x 384 thin sums
+  float* thin = red + 4 * 3 * 1024;
+  {
+    float* mine = red + wave * 3 * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = tc_row(r, hi);
+      mine[i * 32 + lo] = wz1a[r]; mine[1024 + i * 32 + lo] = wz1b[r]; mine[2048 + i * 32 + lo] = wh1[r];
+    }
+    float* tm = thin + wave * 384;                                     // [3][64] of d_pre_zr, then [3][2 halves][32] of d_pre_h
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { tm[k * 64 + lane] = tz[k]; tm[192 + k * 64 + hi * 32 + lo] = th[k]; }
+  }
+  __syncthreads();
+  float* part = g.part + (int64_t)blockIdx.x * tc_part_floats(Fin);
+  float* pWzr = part;
+  float* pbzr = part + (int64_t)C * 64;
+  float* pWh = pbzr + 64;
+  float* pbh = pWh + (int64_t)C * 32;
+  for (int e = tid; e < 3 * 1024; e += 256) {
+    const float v = ((red[e] + red[3 * 1024 + e]) + red[6 * 1024 + e]) + red[9 * 1024 + e];
+    const int blk = e >> 10, i = (e >> 5) & 31, j = e & 31;
+    if (blk < 2) pWzr[(int64_t)(Fin + i) * 64 + blk * 32 + j] = v;
+    else pWh[(int64_t)(Fin + i) * 32 + j] = v;
+  }
+  for (int e = tid; e < 192 + 96; e += 256) {
+    if (e < 192) {                                                     // k = 0, 1: input rows of dWzr; k = 2: dbzr
+      const int k = e >> 6, j = e & 63;
+      const float v = ((thin[e] + thin[384 + e]) + thin[768 + e]) + thin[1152 + e];
+      if (k < Fin) pWzr[(int64_t)k * 64 + j] = v; else if (k == 2) pbzr[j] = v;
+    } else {
+      const int k = (e - 192) >> 5, j = (e - 192) & 31;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += thin[w * 384 + 192 + k * 64 + j] + thin[w * 384 + 192 + k * 64 + 32 + j];
+      if (k < Fin) pWh[(int64_t)k * 32 + j] = v; else if (k == 2) pbh[j] = v;
+    }
+  }
+}
+
 #ifdef PGT_EMU
 constexpr int TC_WGS = 3;
+constexpr int TC_WGS_ROWS_FWD = 3, TC_WGS_ROWS_BWD = 3;
 #else
 constexpr int TC_WGS = 256;
+constexpr int TC_WGS_ROWS_FWD = 512;      // two 256-thread workgroups per CU (<= 256 registers), no LDS strips
+constexpr int TC_WGS_ROWS_BWD = 512;      // two per CU (<= 256 registers, 68 KB of LDS each)
 #endif
+
+// the row-per-lane kernels move 16-byte row pieces: every base pointer and row stride must allow it
+bool tc_rows_ok(int64_t Fin, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+  if (g_tc_rows == 0 || Fin > 2) return false;
+  for (const void* p : ptrs) if (!pgt_aligned(p, 16)) return false;
+  for (int64_t ld : lds) if (ld % 4) return false;
+  return true;
+}
 
 }  // namespace
 
@@ -394,8 +702,10 @@ extern "C" int pgt_tgcn_cell_fits(int64_t Fin, int64_t O) { return (O == TC_O &&
 
 extern "C" int64_t pgt_tgcn_cell_bwd_ws_floats(int64_t Fin, int64_t O) {
   if (!pgt_tgcn_cell_fits(Fin, O)) return 0;
-  return (int64_t)TC_WGS * ((Fin + TC_O) * 96 + 96);
+  return (int64_t)(TC_WGS_ROWS_BWD > TC_WGS ? TC_WGS_ROWS_BWD : TC_WGS) * ((Fin + TC_O) * 96 + 96);
 }
+
+void pgt_tgcn_set_rows(int v) { g_tc_rows = v ? 1 : 0; }
 
 extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, int64_t ldh, const float* Wzr, const float* bzr,
                                  const float* Wh, const float* bh, int64_t M, int64_t Fin, int64_t O, float* ZR, float* HT, float* Hn,
@@ -409,6 +719,11 @@ extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, 
   TcArgs g{};
   g.AX = AX; g.ldax = ldax; g.H = H; g.ldh = ldh; g.Wzr = Wzr; g.bzr = bzr; g.Wh = Wh; g.bh = bh;
   g.ZR = ZR; g.HT = HT; g.Hn = Hn; g.ldhn = ldhn; g.M = (int)M; g.Fin = (int)Fin; g.tiles = (int)pgt_cdiv(M, 128);
+  if (tc_rows_ok(Fin, {H, ZR, HT, Hn}, {ldh, ldhn})) {
+    const int64_t wg = g.tiles < TC_WGS_ROWS_FWD ? g.tiles : TC_WGS_ROWS_FWD;
+    PGT_LAUNCH(tgcn_cell_fwd_rows_kernel, dim3((unsigned)wg), dim3(256), stream, g);
+    return pgt_check_launch("pgt_tgcn_cell_f32");
+  }
   int64_t wgs = g.tiles < 4 * TC_WGS ? g.tiles : 4 * TC_WGS;
   if (Fin <= 2) PGT_LAUNCH((tgcn_cell_fwd_kernel<34>), dim3((unsigned)wgs), dim3(256), stream, g);
   else PGT_LAUNCH((tgcn_cell_fwd_kernel<0>), dim3((unsigned)wgs), dim3(256), stream, g);
@@ -440,9 +755,12 @@ extern "C" int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const floa
   g.AX = AX; g.ldax = ldax; g.H = H; g.ldh = ldh; g.Wzr = Wzr; g.Wh = Wh; g.ZR = const_cast<float*>(ZR); g.HT = const_cast<float*>(HT);
   g.dHn = dHn; g.lddhn = lddhn; g.dH = dH; g.lddh = lddh; g.part = ws;
   g.M = (int)M; g.Fin = (int)Fin; g.tiles = (int)pgt_cdiv(M, 128);
-  const int wgs = g.tiles < TC_WGS ? g.tiles : TC_WGS;
+  const bool rows = tc_rows_ok(Fin, {dHn, H, ZR, HT, dH}, {lddhn, ldh, lddh});
+  const int cap = rows ? TC_WGS_ROWS_BWD : TC_WGS;
+  const int wgs = g.tiles < cap ? g.tiles : cap;
   g.n_wg = wgs;
-  PGT_LAUNCH(tgcn_cell_bwd_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
+  if (rows) PGT_LAUNCH(tgcn_cell_bwd_rows_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
+  else PGT_LAUNCH(tgcn_cell_bwd_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
   PGT_LAUNCH(tgcn_cell_reduce_kernel, dim3((unsigned)pgt_cdiv(n, 64)), dim3(256), stream, ws, wgs, n, dWzr, dbzr, dWh, dbh, C);
   return pgt_check_launch("pgt_tgcn_cell_bwd_f32");
 }

@@ -915,9 +915,11 @@ def test_fused_tgcn_cell_at_hidden_32_equals_the_unfused_path(backend, n, B, Fin
         assert_close_with_nonfinite(res[True][3][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, k)
 
 
-def test_fused_tgcn_cell_against_the_oracle_and_strided_state(backend):
+@pytest.mark.parametrize("col0", [4, 3])
+def test_fused_tgcn_cell_against_the_oracle_and_strided_state(backend, col0):
     """TGCN(2, 32) (the cell of BASELINE configs[2] / [3]) on the fused kernels against the fp64 oracle, H handed in as a column
-    slice of a wider tensor (read in place), and the inference path."""
+    slice of a wider tensor (read in place), and the inference path.  Column offset 4: 16-byte row pieces, the row-per-lane
+    kernels on the strided state; offset 3: not 16-byte addressable, the column-per-lane kernels (csrc/tgcn_cell.hip)."""
     from pytorch_geometric_temporal_amd.nn.recurrent import TGCN
     torch.manual_seed(11)
     n = 70
@@ -929,22 +931,26 @@ def test_fused_tgcn_cell_against_the_oracle_and_strided_state(backend):
             p.uniform_(-0.5, 0.5)
     p64 = {k: v.detach().double().clone().requires_grad_() for k, v in m.state_dict().items()}
     X, Hbig = torch.randn(n, 2), torch.randn(n, 40)
-    H = Hbig[:, 3:35]
+    H = Hbig[:, col0:col0 + 32]
     H64 = H.double().requires_grad_()
     ref = F.tgcn_cell(X.double(), ei, ew.double(), H64, p64)
     ref.square().sum().backward()
     m = m.to(backend.device)
     Hd = backend.t(Hbig).requires_grad_()
-    out = m(backend.t(X), backend.t(ei), backend.t(ew), Hd[:, 3:35])
+    out = m(backend.t(X), backend.t(ei), backend.t(ew), Hd[:, col0:col0 + 32])
     assert_close_with_nonfinite(out, ref, 1e-5, 1e-5, "forward")
     out.square().sum().backward()
-    assert_close_with_nonfinite(Hd.grad[:, 3:35], H64.grad, 2e-5, 1e-4, "dH")
-    assert float(Hd.grad[:, :3].abs().sum()) == 0.0
+    assert_close_with_nonfinite(Hd.grad[:, col0:col0 + 32], H64.grad, 2e-5, 1e-4, "dH")
+    assert float(Hd.grad[:, :col0].abs().sum()) == 0.0 and float(Hd.grad[:, col0 + 32:].abs().sum()) == 0.0
     for name, p in m.named_parameters():
         gref = p64[name].grad
         assert_close_with_nonfinite(p.grad, gref, 2e-5 * float(gref.abs().max()) + 1e-7, 1e-4, name)
     with torch.no_grad():
-        assert torch.equal(m(backend.t(X), backend.t(ei), backend.t(ew), backend.t(H.contiguous())), out.detach())
+        again = m(backend.t(X), backend.t(ei), backend.t(ew), backend.t(H.contiguous()))
+    if col0 % 4 == 0:
+        assert torch.equal(again, out.detach())                    # the same kernel on the strided and on the contiguous state
+    else:                                                           # two kernels: the same sums in another order
+        assert_close_with_nonfinite(again, out.detach(), 2e-6, 2e-6, "contiguous vs strided state")
 
 
 def test_tgcn2_states_route_the_reference_examples_readout(backend):

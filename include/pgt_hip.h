@@ -109,7 +109,7 @@ const char* pgt_build_target(void);
  * 1 where it wins / 2 at any size / 0 never), "gemm_bx_sym" (0: short-K products on its K-split variant).  Diffusion
  * stack: "slab_pairs", "slab_split", "slab_wpc", "slab_threads" (pgt_dconv_stack_slab_plan), "slab_quad" (0: 64 / 66-column blocks on the pair-layout kernels), "slab_gu" (2 | 4 LDS reads in flight in their backward gathers).  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
  * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_ellw" (0: pgt_spmm_ellw_f32 runs
- * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan), "seq_vdot" (1: the gate products of the one-workgroup DCRNN sequences one thread per node; same sums; off until measured).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
+ * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan), "tgcn_rows" (0: the column-per-lane T-GCN cell kernels of round 4 for every shape).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
 int pgt_tune(const char* key, int value);
 
 /* ---------------------------------------------------------------- graph preparation */

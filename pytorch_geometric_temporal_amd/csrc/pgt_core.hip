@@ -80,10 +80,6 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_slab_set_sort(value);
     return PGT_OK;
   }
-  if (strcmp(key, "seq_vdot") == 0) {
-    pgt_seq_set_vdot(value);
-    return PGT_OK;
-  }
   if (strcmp(key, "tgcn_rows") == 0) {
     pgt_tgcn_set_rows(value);
     return PGT_OK;

@@ -197,44 +197,11 @@ __device__ __forceinline__ float sq_dot(const SeqArgs& a, const float* TS, const
   return acc;
 }
 
-// All LDW outputs of node n at once: acc[j] = sum_{s, c} TS[s][n][c] W[(s C + c) LDW + j], every output's terms in the order of
-// sq_dot (the same sums, bit for bit).  Why: the phase timeline (profiles/r04o_seq_small_phase_timeline.txt) puts the two products
-// of a forward step at 3.3 + 2.4 us of 14 — as long as the hops — because one thread per OUTPUT reads the node's stack row and a
-// weight column term by term (two LDS reads per multiply-add); per node the stack value is read once per term and the weight
-// row comes as one broadcast vector read: a quarter to a sixth of the LDS instructions.  Behind pgt_tune("seq_vdot", 1) until it
-// has been measured (builder's GPU budget of the round was spent); default off.
-template <int LDW>
-__device__ __forceinline__ void sq_dot_node(const SeqArgs& a, const float* TS, const float* __restrict__ W, int n, float (&acc)[LDW]) {
-  const int C = a.Fin + a.O, S = 2 * a.K - 1, NC = a.N * C;
-#pragma unroll
-  for (int j = 0; j < LDW; ++j) acc[j] = 0.f;
-  for (int sg = 0; sg < S; ++sg) {
-    const float* t = TS + (size_t)sg * NC + n * C;
-    const float* w = W + (size_t)sg * C * LDW;
-    for (int c = 0; c < C; ++c) {
-      const float tc = t[c];
-#pragma unroll
-      for (int j = 0; j < LDW; ++j) acc[j] = fmaf(tc, w[c * LDW + j], acc[j]);
-    }
-  }
-}
-// f(std::integral_constant<int, ldw>) for the widths the per-node products are instantiated for; false: not one of them
-template <class F>
-__device__ __forceinline__ bool sq_with_width(int ldw, F&& f) {
-  switch (ldw) {
-    case 2: f(std::integral_constant<int, 2>{}); return true;
-    case 4: f(std::integral_constant<int, 4>{}); return true;
-    case 8: f(std::integral_constant<int, 8>{}); return true;
-    case 16: f(std::integral_constant<int, 16>{}); return true;
-    default: return false;
-  }
-}
-__device__ __forceinline__ bool sq_width_ok(int ldw) { return ldw == 2 || ldw == 4 || ldw == 8 || ldw == 16; }
-
 // LDS_BYTES: the static LDS of the instantiation (three sizes: small samples leave room for 2 - 4 resident workgroups per CU)
-// VDOT: the per-node products (a kernel of its own: compiled into the default kernel the code costs it 30 VGPRs — and a resident
-// workgroup per CU — even when switched off at run time)
-template <int LDS_BYTES, bool VDOT>
+// (Round 4 also built "one thread per NODE" forms of the two products — a node's stack row read once, the weight rows as broadcast
+// vector reads.  Measured in round 5, they lose everywhere: B = 64 / 256 / 1024 at hidden 2: 0.565 / 0.596 / 1.480 ms per step
+// against 0.591 / 0.628 / 2.008 with them, profiles/r05a_seq_vdot_ab.txt — 207 busy threads of 512 and 30 more VGPRs.  Deleted.)
+template <int LDS_BYTES>
 __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
@@ -256,29 +223,11 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
       PGT_SEQ_MARK(t, 0);                                    // [X_t | H] staged
       sq_hops(a, s, tid);
       PGT_SEQ_MARK(t, 1);                                    // hops of the z | r stack
-      const bool per_node = VDOT && a.w_lds && sq_width_ok(2 * O) && sq_width_ok(O);
-      if constexpr (VDOT) if (per_node) {                    // Z | R = sigmoid(stack Wzr + bzr), a node's 2 O outputs per thread
-        sq_with_width(2 * O, [&](auto L) {
-          constexpr int LDW = decltype(L)::value;
-          for (int n = tid; n < a.N; n += SQ_THREADS) {
-            float acc[LDW];
-            sq_dot_node<LDW>(a, s.TS, s.Wzr, n, acc);
-#pragma unroll
-            for (int j = 0; j < LDW; ++j) {
-              const float v = pgt_sigmoidf(acc[j] + (a.bzr ? a.bzr[j] : 0.f));
-              s.ZR[n * LDW + j] = v;
-              if (sv) sv[(int64_t)2 * S * NC + n * LDW + j] = v;
-            }
-          }
-        });
-      }
-      if (!per_node) {
-        for (int e = tid; e < 2 * NO; e += SQ_THREADS) {     // Z | R = sigmoid(stack Wzr + bzr)
-          const int n = e / (2 * O), j = e - n * 2 * O;
-          const float v = pgt_sigmoidf(sq_dot(a, s.TS, s.Wzr, 2 * O, n, j) + (a.bzr ? a.bzr[j] : 0.f));
-          s.ZR[e] = v;
-          if (sv) sv[(int64_t)2 * S * NC + e] = v;
-        }
+      for (int e = tid; e < 2 * NO; e += SQ_THREADS) {       // Z | R = sigmoid(stack Wzr + bzr)
+        const int n = e / (2 * O), j = e - n * 2 * O;
+        const float v = pgt_sigmoidf(sq_dot(a, s.TS, s.Wzr, 2 * O, n, j) + (a.bzr ? a.bzr[j] : 0.f));
+        s.ZR[e] = v;
+        if (sv) sv[(int64_t)2 * S * NC + e] = v;
       }
       if (sv) for (int e = tid; e < S * NC; e += SQ_THREADS) sv[e] = s.TS[e];
       PGT_LDS_BARRIER();
@@ -291,33 +240,13 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_fwd_kernel(SeqArgs
       sq_hops(a, s, tid);
       PGT_SEQ_MARK(t, 3);                                    // H * R, hops of the candidate's stack
       float* o_t = a.out + b * a.o_sb + t * a.o_st;
-      if constexpr (VDOT) if (per_node) {                    // candidate, blend, H_t: a node's O outputs per thread
-        sq_with_width(O, [&](auto L) {
-          constexpr int LDW = decltype(L)::value;
-          for (int n = tid; n < a.N; n += SQ_THREADS) {
-            float acc[LDW];
-            sq_dot_node<LDW>(a, s.TS, s.Wh, n, acc);
-#pragma unroll
-            for (int o = 0; o < LDW; ++o) {
-              const int e = n * LDW + o;
-              const float ht = tanhf(acc[o] + (a.bh ? a.bh[o] : 0.f));
-              const float hn = pgt_gru_blend(s.ZR[n * 2 * LDW + o], s.H[e], ht);
-              if (sv) sv[(int64_t)2 * S * NC + 2 * NO + e] = ht;
-              o_t[e] = hn;
-              s.H[e] = hn;                                    // node n's state is read by this thread only in this phase
-            }
-          }
-        });
-      }
-      if (!per_node) {
-        for (int e = tid; e < NO; e += SQ_THREADS) {         // candidate, blend, H_t
-          const int n = e / O, o = e - n * O;
-          const float ht = tanhf(sq_dot(a, s.TS, s.Wh, O, n, o) + (a.bh ? a.bh[o] : 0.f));
-          const float hn = pgt_gru_blend(s.ZR[n * 2 * O + o], s.H[e], ht);
-          if (sv) sv[(int64_t)2 * S * NC + 2 * NO + e] = ht;
-          o_t[e] = hn;
-          s.H[e] = hn;                                        // (n, o) is read by this thread only in this phase
-        }
+      for (int e = tid; e < NO; e += SQ_THREADS) {           // candidate, blend, H_t
+        const int n = e / O, o = e - n * O;
+        const float ht = tanhf(sq_dot(a, s.TS, s.Wh, O, n, o) + (a.bh ? a.bh[o] : 0.f));
+        const float hn = pgt_gru_blend(s.ZR[n * 2 * O + o], s.H[e], ht);
+        if (sv) sv[(int64_t)2 * S * NC + 2 * NO + e] = ht;
+        o_t[e] = hn;
+        s.H[e] = hn;                                          // (n, o) is read by this thread only in this phase
       }
       if (sv) for (int e = tid; e < S * NC; e += SQ_THREADS) sv[(int64_t)S * NC + e] = s.TS[e];
       PGT_LDS_BARRIER();
@@ -376,7 +305,6 @@ __device__ __forceinline__ void sq_hops_adjoint(const SeqArgs& a, const SqLds& s
 
 // one gate product's adjoint: weight-gradient sums into the sample's buffer (dW[(s C + c) ldw + j] += sum_n TV[s][n][c] dP[n][j0 + j]),
 // bias sums, and the stack gradient G[s][n][c] = sum_j dP[n][j0 + j] W[(s C + c) ldw + j]
-template <bool VDOT>
 __device__ __forceinline__ void sq_product_adjoint(const SeqArgs& a, const SqLds& s, const float* __restrict__ W, int ldw, int j0,
                                                    float* dW, float* db, int tid) {
   const int C = a.Fin + a.O, O = a.O, S = 2 * a.K - 1, NC = a.N * C;
@@ -427,37 +355,18 @@ __device__ __forceinline__ void sq_product_adjoint(const SeqArgs& a, const SqLds
       db[j] += acc;
     }
   }
-  bool per_node = false;
-  if constexpr (VDOT) per_node = a.w_lds && sq_with_width(ldw, [&](auto L) {   // a node's S C stack gradients per thread
-    constexpr int LDW = decltype(L)::value;
-    for (int n = tid; n < a.N; n += SQ_THREADS) {
-      float g[LDW];
-#pragma unroll
-      for (int j = 0; j < LDW; ++j) g[j] = s.dP[n * 3 * O + j0 + j];
-      for (int sc = 0; sc < S * C; ++sc) {
-        const float* w = W + (size_t)sc * LDW;
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < LDW; ++j) acc = fmaf(g[j], w[j], acc);
-        const int sg = sc / C;
-        s.TS[(size_t)sg * NC + n * C + (sc - sg * C)] = acc;
-      }
-    }
-  });
-  if (!per_node) {
-    for (int e = tid; e < S * NC; e += SQ_THREADS) {
-      const int sg = e / NC, r = e - sg * NC, n = r / C, c = r - n * C;
-      const float* w = W + ((size_t)sg * C + c) * ldw;
-      const float* g = s.dP + n * 3 * O + j0;
-      float acc = 0.f;
+  for (int e = tid; e < S * NC; e += SQ_THREADS) {
+    const int sg = e / NC, r = e - sg * NC, n = r / C, c = r - n * C;
+    const float* w = W + ((size_t)sg * C + c) * ldw;
+    const float* g = s.dP + n * 3 * O + j0;
+    float acc = 0.f;
 #pragma unroll 4
-      for (int j = 0; j < ldw; ++j) acc = fmaf(g[j], w[j], acc);
-      s.TS[e] = acc;
-    }
+    for (int j = 0; j < ldw; ++j) acc = fmaf(g[j], w[j], acc);
+    s.TS[e] = acc;
   }
 }
 
-template <int LDS_BYTES, bool VDOT>
+template <int LDS_BYTES>
 __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
@@ -492,7 +401,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
       for (int e = tid; e < S * NC; e += SQ_THREADS) s.TV[e] = sv[(int64_t)S * NC + e];
       PGT_LDS_BARRIER();
       PGT_SEQ_MARK(a.T - 1 - t, 0);                          // gate adjoints, the candidate's saved stack in LDS
-      sq_product_adjoint<VDOT>(a, s, s.Wh, O, 2 * O, dWh, dbh, tid);
+      sq_product_adjoint(a, s, s.Wh, O, 2 * O, dWh, dbh, tid);
       PGT_LDS_BARRIER();
       PGT_SEQ_MARK(a.T - 1 - t, 1);                          // candidate product adjoint (weight sums + stack gradient)
       sq_hops_adjoint(a, s, s.TS, tid);
@@ -509,7 +418,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq_small_bwd_kernel(SeqArgs
       for (int e = tid; e < S * NC; e += SQ_THREADS) s.TV[e] = sv[e];
       PGT_LDS_BARRIER();
       PGT_SEQ_MARK(a.T - 1 - t, 3);                          // d(H R), the z | r stack in LDS
-      sq_product_adjoint<VDOT>(a, s, s.Wzr, 2 * O, 0, dWzr, dbzr, tid);
+      sq_product_adjoint(a, s, s.Wzr, 2 * O, 0, dWzr, dbzr, tid);
       PGT_LDS_BARRIER();
       PGT_SEQ_MARK(a.T - 1 - t, 4);                          // z | r product adjoint
       sq_hops_adjoint(a, s, s.TS, tid);
@@ -537,11 +446,7 @@ static int sq_take(const char* who, const pgt_csr* op_o, const pgt_csr* op_i, in
   return PGT_OK;
 }
 
-int g_seq_vdot = 0;   // pgt_tune("seq_vdot"): 1 = the products of the one-workgroup sequences one thread per node (unmeasured: off)
-
 }  // namespace
-
-void pgt_seq_set_vdot(int v) { g_seq_vdot = v; }
 
 extern "C" int pgt_dcrnn_seq_small_fits(int64_t N, int64_t E_o, int64_t E_i, int64_t Fin, int64_t O, int64_t K) {
   if (N < 1 || Fin < 0 || O < 1 || K < 1 || E_o < 0 || E_i < 0 || N > 65535) return 0;
@@ -567,11 +472,7 @@ extern "C" int pgt_dcrnn_seq_small_f32(const pgt_csr* op_o, const pgt_csr* op_i,
   const int64_t wgs = B < 2048 ? B : 2048;
   a.w_lds = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, false, true) <= (size_t)SQ_LDS ? 1 : 0;
   const size_t need = sq_lds_bytes(N, E_o, E_i, Fin + O, O, K, false, a.w_lds != 0);
-#define SQ_GO(KERN, BYTES)                                                                                      \
-  do {                                                                                                          \
-    if (g_seq_vdot) PGT_LAUNCH((KERN<BYTES, true>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);          \
-    else PGT_LAUNCH((KERN<BYTES, false>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a);                    \
-  } while (0)
+#define SQ_GO(KERN, BYTES) PGT_LAUNCH((KERN<BYTES>), dim3((unsigned)wgs), dim3(SQ_THREADS), stream, a)
   if (need <= 38 * 1024) SQ_GO(dcrnn_seq_small_fwd_kernel, 38 * 1024);
   else if (need <= 78 * 1024) SQ_GO(dcrnn_seq_small_fwd_kernel, 78 * 1024);
   else SQ_GO(dcrnn_seq_small_fwd_kernel, SQ_LDS);

@@ -1,9 +1,7 @@
 #!/bin/bash
 # One gpurun call, stages chosen on the command line (in the order given); everything lands under gpurun_out/.
-#   scripts/gpu_trip.sh tests smoke bench tgcn vdot covid:20 stats pmc stats_tgcn pmc_tgcn
 # tests      pytest -m gpu (tail of the log)                smoke    __graft_entry__.smoke()
 # bench      python bench.py (default run, clocked)          tgcn     python bench.py --config tgcn50k
-# vdot       A/B of pgt_tune(seq_vdot) at B = 64/256/1024    covid:N  scripts/covid_fault_hunt.sh N
 # stats/pmc  rocprofv3 --stats / --pmc passes of the headline command (TAG=${TAG:-r05}); *_tgcn: of --config tgcn50k
 # x:<cmd>    any other command, quoted
 export TMPDIR=/tmp
@@ -19,7 +17,6 @@ for stage in "$@"; do
     bench) (timeout 600 python bench.py ${BENCH_ARGS:-}) > $O/bench.json 2> $O/bench.err; echo "bench rc=$? line bytes=$(wc -c < $O/bench.json)"
            cat $O/bench.json; grep "^\[bench \|(aux)" $O/bench.err | tail -40 ;;
     tgcn)  (timeout 400 python bench.py --config tgcn50k ${TGCN_ARGS:-}) > $O/bench_tgcn.json 2> $O/bench_tgcn.err; echo "tgcn rc=$?"; cat $O/bench_tgcn.json ;;
-    vdot)  for B in 64 256 1024; do for V in 0 1; do echo -n "B=$B seq_vdot=$V "; PGT_TUNE=seq_vdot=$V timeout 100 python scripts/small_batch_probe.py $B 2 100 2>&1 | tail -1; done; done ;;
     covid:*) bash scripts/covid_fault_hunt.sh "${stage#covid:}" ${COVID_ENV:-} ;;
     stats) (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof/${TAG}_stats -- python $OLDPWD/bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-extra) > $O/prof/${TAG}_stats.log 2>&1; echo "stats rc=$?"
            find $O/prof -name "*kernel_trace.csv" -size +8M -delete ;;

@@ -533,21 +533,6 @@ def test_one_workgroup_sequence_kernels_equal_the_general_path(backend, Fin, O, 
         finally:
             ops.USE_SEQ_SMALL = True
     assert ops.seq_small_fits(ops.dconv_graph(ei, ew, n), Fin, O, K)
-    # pgt_tune("seq_vdot", 1): the gate products (and the stack gradients of their adjoints) one thread per NODE — every output
-    # of a node from one pass over its stack row and broadcast weight rows; the same sums in the same order, bit for bit
-    from pytorch_geometric_temporal_amd import _lib
-    lib = _lib.get_lib()
-    lib.tune("seq_vdot", 1)
-    try:
-        m.zero_grad()
-        Xd = backend.t(X).requires_grad_()
-        out = m(Xd, ei, ew)
-        (out * w).sum().backward()
-        assert torch.equal(out.detach(), res[True][0]) and torch.equal(Xd.grad, res[True][1])
-        for k, p in m.named_parameters():
-            assert torch.equal(p.grad, res[True][2][k]), k
-    finally:
-        lib.tune("seq_vdot", 0)
     assert_close_with_nonfinite(res[True][0], res[False][0], 2e-6, 1e-5, "states")
     assert_close_with_nonfinite(res[True][1], res[False][1], 1e-5, 1e-4, "dX")
     for k in res[True][2]:

@@ -257,7 +257,15 @@ def covid_epoch(device, cores):
             finally:
                 snaps = keep
         flat_edges = [t for (_, e, w, _) in snaps for t in (e, w)]
-        graphed_e = GraphedStep(epoch_on, flat_edges, warmup=2)
+        mode = os.environ.get("PGT_COVID_MODE", "")           # diagnostic (scripts/covid_bisect.sh)
+        if mode == "drop_outputs" and t_graph is not None:
+            graphed.static_outputs = None                      # the first capture's loss (and the autograd graph behind it)
+        if mode == "del_graphed" and t_graph is not None:
+            del graphed
+        if mode == "sync_gc":
+            import gc
+            torch.cuda.synchronize(); gc.collect()
+        graphed_e = GraphedStep(epoch_on if mode != "plain_second" else (lambda *a: epoch()), flat_edges, warmup=2)
         fresh = [t.clone() for t in flat_edges]
         t_graph_fresh = _time_gpu(lambda: graphed_e(*fresh), 20)
         # (the parameters move with every replay, so there is no eager figure to compare a replayed cost with: finite is the check)

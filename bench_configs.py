@@ -225,27 +225,24 @@ def covid_epoch(device, cores):
             epoch()
         finally:
             snaps = keep
-    skip = os.environ.get("PGT_COVID_SKIP", "").split(",")      # diagnostic (scripts/covid_fault_hunt.sh): leave stages out
-    t_fresh = _time_gpu(fresh_epoch, 3, warm=1) if "fresh" not in skip else float("nan")
+    t_fresh = _time_gpu(fresh_epoch, 3, warm=1)
     fits = ops.gcn_small_fits
     try:
         ops.gcn_small_fits = lambda *a: False
-        t_fresh_prepared = _time_gpu(fresh_epoch, 3, warm=1) if "prepared" not in skip else float("nan")
+        t_fresh_prepared = _time_gpu(fresh_epoch, 3, warm=1)
     finally:
         ops.gcn_small_fits = fits
     t_graph = None
     try:
-        if "graphed" in skip:
-            raise RuntimeError("skipped")
         graphed = GraphedStep(epoch, [])
         t_graph = _time_gpu(lambda: graphed(), 20)
     except Exception as e:                          # an auxiliary line must never cost the bench line
         t_graph_err = repr(e)
     # the same epoch captured with the 53 edge lists (index + weight tensors) as GRAPH INPUTS and replayed on fresh copies of
     # them every epoch: what a stream of new graphs of these sizes costs as one hipGraph (the GCN layer reads the RAW edge list
-    # inside its kernel, so nothing is prepared on the host per new list).  This block ended ONE builder run of round 4 with a GPU
-    # memory access fault (then in the main process, after the headline's captures and empty_cache() calls); scripts/
-    # covid_fault_hunt.sh runs it over and over in this child process, in this order (DESIGN.md records the outcome).
+    # inside its kernel, so nothing is prepared on the host per new list).  (The memory access fault of round 4 at this point was
+    # the SECOND capture of a process whose first GraphedStep still held its loss and, through it, the parameters' AccumulateGrad
+    # nodes on another stream: graphed.py now hands out detached outputs.  scripts/covid_fault_hunt.sh repeats this block.)
     t_graph_fresh = None
     try:
         def epoch_on(*edges):
@@ -257,15 +254,7 @@ def covid_epoch(device, cores):
             finally:
                 snaps = keep
         flat_edges = [t for (_, e, w, _) in snaps for t in (e, w)]
-        mode = os.environ.get("PGT_COVID_MODE", "")           # diagnostic (scripts/covid_bisect.sh)
-        if mode == "drop_outputs" and t_graph is not None:
-            graphed.static_outputs = None                      # the first capture's loss (and the autograd graph behind it)
-        if mode == "del_graphed" and t_graph is not None:
-            del graphed
-        if mode == "sync_gc":
-            import gc
-            torch.cuda.synchronize(); gc.collect()
-        graphed_e = GraphedStep(epoch_on if mode != "plain_second" else (lambda *a: epoch()), flat_edges, warmup=2)
+        graphed_e = GraphedStep(epoch_on, flat_edges, warmup=2)
         fresh = [t.clone() for t in flat_edges]
         t_graph_fresh = _time_gpu(lambda: graphed_e(*fresh), 20)
         # (the parameters move with every replay, so there is no eager figure to compare a replayed cost with: finite is the check)

@@ -18,6 +18,7 @@
 #include "pgt_common.h"
 
 #include <initializer_list>
+#include <type_traits>
 
 namespace {
 
@@ -399,6 +400,21 @@ __global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __re
 //     per wavefront, written with ds_write_b128 and read column-wise, conflict-free both ways.
 // Rounds 4's kernels above stay as the path for 3 <= Fin <= 30 and for operands that are not 16-byte addressable.
 
+// The forward kernel's prefetch: 16-byte loads the compiler cannot see, released by a hand-counted wait.  vmcnt is ONE in-order
+// counter for loads and stores; the compiler's own wait for a prefetched register at a loop head merges the first-entry path (no
+// stores pending) with the back edge (sixteen pending) and takes the smaller count — the whole store queue drained once per strip
+// (measured: the first row-per-lane form gained only 15 % over the column form).  Here the wait says what is true: the prefetch is
+// older than exactly the sixteen stores of the strip, which stay in flight.  (Same device as csrc/gemm_bx.hip's platform layer.)
+#ifdef PGT_EMU
+#define TC_LOAD4(dst, p, OFF) ((dst) = *reinterpret_cast<const pgt_f4*>((p) + (OFF) / 4))
+#define TC_LOAD1(dst, p) ((dst) = *(p))
+#define TC_WAIT5(n, a, b, c, d, e) ((void)0)
+#else
+#define TC_LOAD4(dst, p, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(p) : "memory")
+#define TC_LOAD1(dst, p) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory")
+#define TC_WAIT5(n, a, b, c, d, e) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(n))
+#endif
+
 // bias: the accumulators start from it (12 broadcast ds_read_b128 per strip instead of 48 registers or three more MFMAs)
 __device__ __forceinline__ void tc_bias_init(pgt_f32x16& acc, const float* sb, int hi) {
 #pragma unroll
@@ -432,26 +448,29 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
   float* __restrict__ HTg = g.HT;
   float* __restrict__ Hng = g.Hn;
   // a strip's rows start at a wavefront-UNIFORM address (scalar registers); a lane adds a 32-bit offset of its own
-  const int64_t n_strips = ((int64_t)g.M + 31) >> 5, stride = (int64_t)gridDim.x * 4;
+  const int64_t n_strips = ((int64_t)g.M + 31) >> 5, n_full = (int64_t)g.M >> 5, stride = (int64_t)gridDim.x * 4;
   const int wave_u = PGT_UNIFORM(wave);
   pgt_f4 hq[4];
   float axv = 0.f;
+  const int axc = hi < Fin ? hi : Fin - 1;                          // every lane loads (an unconditional instruction: the wait counts it)
   auto fetch = [&](int64_t st) {
     const int64_t r0 = st * 32, left = (int64_t)g.M - 1 - r0;
     const int lr = lo < left ? lo : (int)left;                       // rows past the end re-read the last one (never stored)
     const float* hp = Hg + r0 * g.ldh + (lr * (int)g.ldh + 4 * hi);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) hq[q] = *reinterpret_cast<const pgt_f4*>(hp + 8 * q);
-    axv = hi < Fin ? AXg[r0 * g.ldax + (lr * (int)g.ldax + hi)] : 0.f;
+    const float* ap = AXg + r0 * g.ldax + (lr * (int)g.ldax + axc);
+    TC_LOAD4(hq[0], hp, 0); TC_LOAD4(hq[1], hp, 32); TC_LOAD4(hq[2], hp, 64); TC_LOAD4(hq[3], hp, 96);
+    TC_LOAD1(axv, ap);
   };
-  int64_t st = (int64_t)blockIdx.x * 4 + wave_u;
-  if (st < n_strips) fetch(st);
-  for (; st < n_strips; st += stride) {
+  // One strip.  FULL strips store without a branch, so that exactly sixteen stores follow the prefetch and TC_WAIT5(16, ...) at
+  // the end of the strip releases the prefetched registers with those stores still in flight.  The one partial strip (stores
+  // behind `row < M`) runs after the loop and drains instead.
+  auto strip = [&](int64_t st, auto full_c, bool prefetch) {
+    constexpr bool FULL = decltype(full_c)::value;
     float h[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { h[4 * q] = hq[q].x; h[4 * q + 1] = hq[q].y; h[4 * q + 2] = hq[q].z; h[4 * q + 3] = hq[q].w; }
-    const float ax = axv;
-    if (st + stride < n_strips) fetch(st + stride);            // the next strip's pieces travel while this one is on the matrix cores
+    const float ax = hi < Fin ? axv : 0.f;
+    if (prefetch) fetch(st + stride);                          // the next strip's pieces travel while this one is on the matrix cores
     pgt_f32x16 az, ar, ah;
     tc_bias_init(az, s_b, hi);
     tc_bias_init(ar, s_b + 32, hi);
@@ -463,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
     az = PGT_MFMA_32x32x2(wz[16], ax, az);
     ar = PGT_MFMA_32x32x2(wr[16], ax, ar);
     const int64_t r0 = st * 32;
-    const bool ok = r0 + lo < g.M;
+    const bool ok = FULL || r0 + lo < g.M;
     float z[16], hr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -495,7 +514,23 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
         *reinterpret_cast<pgt_f4*>(np + 8 * q) = pgt_mk4(n[0], n[1], n[2], n[3]);
       }
     }
+    if (prefetch) {
+      if constexpr (FULL) TC_WAIT5(16, hq[0], hq[1], hq[2], hq[3], axv);     // the prefetch is older than this strip's 16 stores
+      else TC_WAIT5(0, hq[0], hq[1], hq[2], hq[3], axv);
+    }
+  };
+  int64_t st = (int64_t)blockIdx.x * 4 + wave_u;
+  if (st < n_strips) {
+    fetch(st);
+    TC_WAIT5(0, hq[0], hq[1], hq[2], hq[3], axv);
   }
+  for (; st + stride < n_full; st += stride) strip(st, std::true_type{}, true);    // (the prefetched strip is a full one too)
+  if (st < n_full) {                                                                // this wavefront's last full strip; a partial one may follow
+    const bool more = st + stride < n_strips;
+    strip(st, std::true_type{}, more);
+    st += stride;
+  }
+  if (st < n_strips) strip(st, std::false_type{}, false);                           // the partial strip, if this wavefront owns it
 }
 
 constexpr int TC_P = 36;            // row pitch of the adjoint's row-major LDS matrices (16-byte rows: ds_write_b128; 36 mod 32 = 4)
@@ -684,7 +719,7 @@ constexpr int TC_WGS = 3;
 constexpr int TC_WGS_ROWS_FWD = 3, TC_WGS_ROWS_BWD = 3;
 #else
 constexpr int TC_WGS = 256;
-constexpr int TC_WGS_ROWS_FWD = 512;      // two 256-thread workgroups per CU (<= 256 registers), no LDS strips
+constexpr int TC_WGS_ROWS_FWD = 768;      // three 256-thread workgroups per CU (168 registers), no LDS strips
 constexpr int TC_WGS_ROWS_BWD = 512;      // two per CU (<= 256 registers, 68 KB of LDS each)
 #endif
 

@@ -409,10 +409,17 @@ __global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __re
 #define TC_LOAD4(dst, p, OFF) ((dst) = *reinterpret_cast<const pgt_f4*>((p) + (OFF) / 4))
 #define TC_LOAD1(dst, p) ((dst) = *(p))
 #define TC_WAIT5(n, a, b, c, d, e) ((void)0)
+#define TC_WAIT21(g, z, r, t, h, ax) ((void)0)
 #else
 #define TC_LOAD4(dst, p, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(p) : "memory")
 #define TC_LOAD1(dst, p) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory")
 #define TC_WAIT5(n, a, b, c, d, e) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(n))
+// vmcnt(0) tied to the adjoint kernel's five prefetched row sets + the input column
+#define TC_WAIT21(g, z, r, t, h, ax)                                                                                              \
+  asm volatile("s_waitcnt vmcnt(0)"                                                                                               \
+               : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(r[0]),      \
+                 "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(h[0]), "+v"(h[1]),      \
+                 "+v"(h[2]), "+v"(h[3]), "+v"(ax))
 #endif
 
 // bias: the accumulators start from it (12 broadcast ds_read_b128 per strip instead of 48 registers or three more MFMAs)
@@ -550,6 +557,10 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_bwd_rows_kernel(TcArgs g) {
   float* M1 = M0 + 32 * TC_P;
   float* M2 = M1 + 32 * TC_P;
   float* axs = s_ax[wave];
+  const float* m0l = M0 + hi * TC_P + lo;      // this lane's MFMA operand columns: row 2 s + hi of a matrix = base + 2 s TC_P
+  const float* m1l = M1 + hi * TC_P + lo;
+  const float* m2l = M2 + hi * TC_P + lo;
+  const float* axl = axs + hi * 2;              // the input columns of row 2 s + hi = base + 4 s
   // A operands of the two "weights x d_pre^T" products: row Fin + lo of the hidden blocks, k in the order of the row pieces —
   // [step][lane] in LDS (48 conflict-free reads per strip; as registers they pushed the kernel past 256)
   __shared__ float s_w[48 * 64];
@@ -573,33 +584,43 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_bwd_rows_kernel(TcArgs g) {
   float tz[3] = {0.f, 0.f, 0.f}, th[3] = {0.f, 0.f, 0.f};   // [AX | 1]^T d: column `lane` of d_pre_z | d_pre_r; column lo of d_pre_h (half the rows per hi)
   const int64_t n_strips = ((int64_t)g.M + 31) >> 5, stride = (int64_t)gridDim.x * 4;
   const int wave_u = PGT_UNIFORM(wave);
-  for (int64_t st = (int64_t)blockIdx.x * 4 + wave_u; st < n_strips; st += stride) {
-    // a strip's rows start at a wavefront-UNIFORM address (scalar registers); a lane adds a 32-bit offset of its own
+  const int axc = hi < Fin ? hi : Fin - 1;
+  // The next strip's twenty row pieces are requested when this strip's operands have moved to LDS (the 48 weight-gradient MFMAs
+  // that follow run from there, and eighty registers are free): invisible to the compiler (TC_LOAD4), released by one hand-placed
+  // wait at the top of the next round.  Loaded the plain way, each strip opened with ~2 us of HBM latency nothing covered.
+  pgt_f4 pg[4], pz[4], pr[4], pt[4], ph[4];
+  float pax = 0.f;
+  auto fetch = [&](int64_t st) {
+    const int64_t r0 = st * 32, left = (int64_t)g.M - 1 - r0;
+    const int lr = lo < left ? lo : (int)left;                       // rows past the end re-read the last one (their g is zeroed)
+    const float* gp = dHg + r0 * g.lddhn + (lr * (int)g.lddhn + 4 * hi);
+    const float* zp = ZRg + r0 * 64 + (lr * 64 + 4 * hi);
+    const float* tp = HTg + r0 * 32 + (lr * 32 + 4 * hi);
+    const float* hp = Hg + r0 * g.ldh + (lr * (int)g.ldh + 4 * hi);
+    const float* ap = AXg + r0 * g.ldax + (lr * (int)g.ldax + axc);
+    TC_LOAD4(pg[0], gp, 0); TC_LOAD4(pg[1], gp, 32); TC_LOAD4(pg[2], gp, 64); TC_LOAD4(pg[3], gp, 96);
+    TC_LOAD4(pz[0], zp, 0); TC_LOAD4(pz[1], zp, 32); TC_LOAD4(pz[2], zp, 64); TC_LOAD4(pz[3], zp, 96);
+    TC_LOAD4(pr[0], zp, 128); TC_LOAD4(pr[1], zp, 160); TC_LOAD4(pr[2], zp, 192); TC_LOAD4(pr[3], zp, 224);
+    TC_LOAD4(pt[0], tp, 0); TC_LOAD4(pt[1], tp, 32); TC_LOAD4(pt[2], tp, 64); TC_LOAD4(pt[3], tp, 96);
+    TC_LOAD4(ph[0], hp, 0); TC_LOAD4(ph[1], hp, 32); TC_LOAD4(ph[2], hp, 64); TC_LOAD4(ph[3], hp, 96);
+    TC_LOAD1(pax, ap);
+  };
+  int64_t st = (int64_t)blockIdx.x * 4 + wave_u;
+  if (st < n_strips) fetch(st);
+  for (; st < n_strips; st += stride) {
     const int64_t r0 = st * 32, left = (int64_t)g.M - 1 - r0;
     const bool ok = lo <= left;
-    const int lr = ok ? lo : (int)left;                              // rows past the end re-read the last one (their g is zeroed)
+    TC_WAIT21(pg, pz, pr, pt, ph, pax);                                // nothing younger than the prefetch is in flight
     float gg[16], z[16], rr[16], t[16], h[16];
-    {
-      const float* gp = dHg + r0 * g.lddhn + (lr * (int)g.lddhn + 4 * hi);
-      const float* zp = ZRg + r0 * 64 + (lr * 64 + 4 * hi);
-      const float* tp = HTg + r0 * 32 + (lr * 32 + 4 * hi);
-      const float* hp = Hg + r0 * g.ldh + (lr * (int)g.ldh + 4 * hi);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const pgt_f4 a = *reinterpret_cast<const pgt_f4*>(gp + 8 * q), b = *reinterpret_cast<const pgt_f4*>(zp + 8 * q),
-                     c = *reinterpret_cast<const pgt_f4*>(zp + 32 + 8 * q), d = *reinterpret_cast<const pgt_f4*>(tp + 8 * q),
-                     e = *reinterpret_cast<const pgt_f4*>(hp + 8 * q);
-        gg[4 * q] = a.x; gg[4 * q + 1] = a.y; gg[4 * q + 2] = a.z; gg[4 * q + 3] = a.w;
-        z[4 * q] = b.x; z[4 * q + 1] = b.y; z[4 * q + 2] = b.z; z[4 * q + 3] = b.w;
-        rr[4 * q] = c.x; rr[4 * q + 1] = c.y; rr[4 * q + 2] = c.z; rr[4 * q + 3] = c.w;
-        t[4 * q] = d.x; t[4 * q + 1] = d.y; t[4 * q + 2] = d.z; t[4 * q + 3] = d.w;
-        h[4 * q] = e.x; h[4 * q + 1] = e.y; h[4 * q + 2] = e.z; h[4 * q + 3] = e.w;
-      }
+    for (int q = 0; q < 4; ++q) {
+      gg[4 * q] = pg[q].x; gg[4 * q + 1] = pg[q].y; gg[4 * q + 2] = pg[q].z; gg[4 * q + 3] = pg[q].w;
+      z[4 * q] = pz[q].x; z[4 * q + 1] = pz[q].y; z[4 * q + 2] = pz[q].z; z[4 * q + 3] = pz[q].w;
+      rr[4 * q] = pr[q].x; rr[4 * q + 1] = pr[q].y; rr[4 * q + 2] = pr[q].z; rr[4 * q + 3] = pr[q].w;
+      t[4 * q] = pt[q].x; t[4 * q + 1] = pt[q].y; t[4 * q + 2] = pt[q].z; t[4 * q + 3] = pt[q].w;
+      h[4 * q] = ph[q].x; h[4 * q + 1] = ph[q].y; h[4 * q + 2] = ph[q].z; h[4 * q + 3] = ph[q].w;
     }
-    const float ax = (ok && hi < Fin) ? AXg[r0 * g.ldax + (lr * (int)g.ldax + hi)] : 0.f;
-    // the row-contracting products need (row, column) transposed: H, d_pre_z, d_pre_r go row-major into the wavefront's strip
-    tc_park_rows(M0, lo, hi, h);
-    axs[lo * 2 + hi] = ax;
+    const float ax = (ok && hi < Fin) ? pax : 0.f;
     float dph[16], dz[16], gz[16], hr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -609,7 +630,11 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_bwd_rows_kernel(TcArgs g) {
       gz[r] = g1 * z[r];
       hr[r] = h[r] * rr[r];
     }
-    tc_park_rows(M1, lo, hi, dz);
+    // the row-contracting products need (row, column) transposed: their operands go row-major into the wavefront's strip.
+    // First H R and d_pre_h (the candidate's weight gradient), so that H, d_pre_z, d_pre_r can stay in registers meanwhile.
+    tc_park_rows(M0, lo, hi, hr);
+    tc_park_rows(M1, lo, hi, dph);
+    axs[lo * 2 + hi] = ax;
     pgt_f32x16 p;
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = 0.f;
@@ -621,7 +646,6 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_bwd_rows_kernel(TcArgs g) {
       dr[r] = p[r] * hr[r] * (1.f - rr[r]);                            // d_pre_r
       gz[r] = fmaf(p[r], rr[r], gz[r]);
     }
-    tc_park_rows(M2, lo, hi, dr);
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = 0.f;
 #pragma unroll
@@ -637,16 +661,29 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_bwd_rows_kernel(TcArgs g) {
                                                           gz[4 * q + 3] + p[4 * q + 3]);
     }
     PGT_WAVE_SYNC();
-    // dWzr (hidden rows) += H^T [d_pre_z | d_pre_r]: A[m = feature][k = row], B[k = row][n = column]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {                                     // (lane bases + compile-time offsets: rows 2 s + hi)
+      const float d = m1l[2 * s * TC_P];
+      wh1 = PGT_MFMA_32x32x2(m0l[2 * s * TC_P], d, wh1);            // dWh (hidden rows) += (H R)^T d_pre_h: A[m = feature][k = row]
+      // its input rows and bias ([AX | 1]^T d) on the vector unit: three sums per column instead of a 32-row MFMA block of which
+      // three rows are alive (a third of the first form's matrix-core time); this lane's half of the rows
+      th[0] = fmaf(axl[4 * s], d, th[0]);
+      th[1] = fmaf(axl[4 * s + 1], d, th[1]);
+      th[2] += d;
+    }
+    PGT_WAVE_SYNC();
+    tc_park_rows(M0, lo, hi, h);
+    tc_park_rows(M1, lo, hi, dz);
+    tc_park_rows(M2, lo, hi, dr);
+    if (st + stride < n_strips) fetch(st + stride);                    // (every operand of what follows is in LDS now)
+    PGT_WAVE_SYNC();
+    // dWzr (hidden rows) += H^T [d_pre_z | d_pre_r]
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int rho = 2 * s + hi;
-      const float a = M0[rho * TC_P + lo], bz = M1[rho * TC_P + lo], br = M2[rho * TC_P + lo];
+      const float a = m0l[2 * s * TC_P], bz = m1l[2 * s * TC_P], br = m2l[2 * s * TC_P];
       wz1a = PGT_MFMA_32x32x2(a, bz, wz1a);
       wz1b = PGT_MFMA_32x32x2(a, br, wz1b);
     }
-    // the input rows and the bias ([AX | 1]^T d) on the vector unit: three sums per column instead of a 32-row MFMA block of
-    // which three rows are alive (a third of the first form's matrix-core time)
     {
       const float* dcol = (hi ? M2 : M1) + lo;                         // lane = column `lane` of [d_pre_z | d_pre_r]
 #pragma unroll 4
@@ -656,19 +693,6 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_bwd_rows_kernel(TcArgs g) {
         tz[1] = fmaf(axs[rho * 2 + 1], d, tz[1]);
         tz[2] += d;
       }
-    }
-    PGT_WAVE_SYNC();
-    tc_park_rows(M0, lo, hi, hr);
-    tc_park_rows(M1, lo, hi, dph);
-    PGT_WAVE_SYNC();
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int rho = 2 * s + hi;
-      const float d = M1[rho * TC_P + lo];
-      wh1 = PGT_MFMA_32x32x2(M0[rho * TC_P + lo], d, wh1);          // dWh (hidden rows) += (H R)^T d_pre_h
-      th[0] = fmaf(axs[rho * 2], d, th[0]);                            // (its input rows and bias: this lane's half of the rows)
-      th[1] = fmaf(axs[rho * 2 + 1], d, th[1]);
-      th[2] += d;
     }
     PGT_WAVE_SYNC();                                                   // the strip is rewritten by the next one
   }

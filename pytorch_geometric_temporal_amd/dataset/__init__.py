@@ -6,8 +6,6 @@ path's examples use:
 
     ChickenpoxDatasetLoader      dataset/chickenpox.py:10-128      static graph, vendored JSON
     EnglandCovidDatasetLoader    dataset/encovid.py:8-75           dynamic graph, vendored JSON
-    PedalMeDatasetLoader         dataset/pedalme.py:8-66           static weighted graph, vendored JSON
-    MontevideoBusDatasetLoader   dataset/montevideo_bus.py:9-118   static weighted graph, per-node variables, JSON
     METRLADatasetLoader          dataset/metr_la.py:15-262         adj_mat.npy + node_values.npy
     PemsBayDatasetLoader         dataset/pems_bay.py:14-250        pems_adj_mat.npy + pems_node_values.npy
 
@@ -29,7 +27,7 @@ from torch.utils.data.distributed import DistributedSampler
 from ..signal import DynamicGraphTemporalSignal, IndexDataset, StaticGraphTemporalSignal
 from .cache import TemporalGraphCache, csr_by_destination, load_cache, save_cache
 
-__all__ = ["ChickenpoxDatasetLoader", "EnglandCovidDatasetLoader", "PedalMeDatasetLoader", "MontevideoBusDatasetLoader",
+__all__ = ["ChickenpoxDatasetLoader", "EnglandCovidDatasetLoader",
            "METRLADatasetLoader", "PemsBayDatasetLoader", "PemsDatasetLoader",
            "TemporalGraphCache", "load_cache", "save_cache", "csr_by_destination", "dense_to_sparse_numpy"]
 
@@ -165,105 +163,6 @@ class EnglandCovidDatasetLoader(object):
         self.features = [z[i:i + lags, :].T for i in range(n)]
         self.targets = [z[i + lags, :].T for i in range(n)]
         return DynamicGraphTemporalSignal(self._edges, self._edge_weights, self.features, self.targets)
-
-
-# ------------------------------------------------------------------------------------------------ PedalMe / Montevideo
-
-def _compact(a):
-    """Integer arrays in the narrowest integer dtype that holds them (the loaders widen back before any arithmetic)."""
-    a = np.asarray(a)
-    if a.dtype.kind not in "iu" or a.size == 0:
-        return a
-    lo, hi = int(a.min()), int(a.max())
-    for dt in (np.int16, np.int32):
-        if np.iinfo(dt).min <= lo and hi <= np.iinfo(dt).max:
-            return a.astype(dt)
-    return a
-
-
-def _widen(a):
-    a = np.array(a)
-    return a.astype(np.int64) if a.dtype.kind in "iu" else a
-
-
-def _pedalme_from_json(d):
-    x = np.array(d["X"])
-    edges = np.array(d["edges"]).T.astype(np.int64)
-    w = np.array(d["weights"]).T
-    rp, col, val = csr_by_destination(edges, w, x.shape[1])
-    arrays = {"series": x[:, :, None], "edge_index": edges, "edge_weight": w, "csr_rowptr": rp, "csr_col": col,
-              "csr_val": val}
-    return TemporalGraphCache("pedalme_london", {"nodes": int(x.shape[1]), "steps": int(x.shape[0])}, arrays, None)
-
-
-class PedalMeDatasetLoader(object):
-    """Weekly bicycle-delivery demand of PedalMe in 15 London localities, 2020-2021 (reference: dataset/pedalme.py:8-66):
-    15 nodes, 225 weighted directed edges, 35 weeks."""
-
-    def __init__(self, path=None):
-        self._cache = _read(path, "pedalme_london.pgtc", _pedalme_from_json)
-
-    def get_dataset(self, lags: int = 4) -> StaticGraphTemporalSignal:
-        self.lags = lags
-        x = np.array(self._cache.series)[:, :, 0]
-        self._edges = np.array(self._cache.edge_index)
-        self._edge_weights = np.array(self._cache.edge_weight)
-        n = x.shape[0] - lags
-        self.features = [x[i:i + lags, :].T for i in range(n)]
-        self.targets = [x[i + lags, :].T for i in range(n)]
-        return StaticGraphTemporalSignal(self._edges, self._edge_weights, self.features, self.targets)
-
-
-def _montevideo_from_json(d):
-    ids = [n.get("bus_stop") for n in d["nodes"]]
-    pos = dict(zip(ids, range(len(ids))))
-    edges = np.array([(pos[e["source"]], pos[e["target"]]) for e in d["links"]]).T.astype(np.int64)
-    w = np.array([e["weight"] for e in d["links"]]).T
-    arrays = {"edge_index": edges, "edge_weight": w,
-              "var:y": _compact(np.stack([np.array(n.get("y")) for n in d["nodes"]]).T)}
-    names = []
-    for key in d["nodes"][0].get("X", {}):                 # the feature variables every node carries
-        arrays["X:" + key] = _compact(np.stack([np.array(n["X"][key]) for n in d["nodes"]]).T)
-        names.append(key)
-    rp, col, val = csr_by_destination(edges, w, len(ids))
-    arrays.update(csr_rowptr=rp, csr_col=col, csr_val=val)
-    steps = int(arrays["var:y"].shape[0])
-    return TemporalGraphCache("montevideo_bus", {"nodes": len(ids), "steps": steps, "feature_vars": names}, arrays, None)
-
-
-class MontevideoBusDatasetLoader(object):
-    """Hourly passenger inflow at 675 bus stops of 11 lines in Montevideo, October 2020 (reference:
-    dataset/montevideo_bus.py:9-118): 690 weighted edges (road distance), 744 hours."""
-
-    def __init__(self, path=None):
-        self._cache = _read(path, "montevideo_bus.pgtc", _montevideo_from_json)
-
-    @staticmethod
-    def _standardize(a):
-        return (a - np.mean(a, axis=0)) / np.std(a, axis=0)
-
-    def get_dataset(self, lags: int = 4, target_var: str = "y", feature_vars=["y"]) -> StaticGraphTemporalSignal:
-        """features [N * len(feature_vars), lags] (variables interleaved per node, as the reference stacks them),
-        target [N]; both standardised per column."""
-        self.lags = lags
-        c = self._cache
-        self._edges = np.array(c.edge_index)
-        self._edge_weights = np.array(c.edge_weight)
-        for v in list(feature_vars):
-            if "X:" + v not in c:
-                raise KeyError(f"feature variable {v!r} is not in the dataset (has {c.meta.get('feature_vars')})")
-        if "var:" + target_var not in c:
-            raise KeyError(f"target variable {target_var!r} is not in the dataset")
-        per_var = [_widen(c.arrays["X:" + v]) for v in feature_vars]                        # each [T, N]
-        stacked = np.stack(per_var, axis=2).reshape(per_var[0].shape[0], -1)              # node-major, variable-minor
-        # the reference standardises TRANSPOSED VIEWS of [N, T] arrays (np.stack(...).T): numpy's pairwise summation
-        # order follows the memory layout, so the same layout is needed to get the same last bit
-        zf = self._standardize(np.ascontiguousarray(stacked.T).T)
-        zt = self._standardize(np.ascontiguousarray(_widen(c.arrays["var:" + target_var]).T).T)
-        n = zf.shape[0] - lags
-        self.features = [zf[i:i + lags, :].T for i in range(n)]
-        self.targets = [zt[i + lags, :].T for i in range(len(zt) - lags)]
-        return StaticGraphTemporalSignal(self._edges, self._edge_weights, self.features, self.targets)
 
 
 # ------------------------------------------------------------------------------------------------ METR-LA / PeMS-BAY

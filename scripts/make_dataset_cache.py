@@ -1,7 +1,6 @@
 #!/usr/bin/env python
-"""Convert the datasets the reference vendors as JSON (dataset/chickenpox.json, england_covid.json, pedalme_london.json,
-montevideo_bus.json) into the
-package's binary cache format (pytorch_geometric_temporal_amd/dataset/cache.py) so that the loaders work without a
+"""Convert the in-scope datasets the reference vendors as JSON (dataset/chickenpox.json, england_covid.json: BASELINE configs[0]
+and [4]) into the package's binary cache format (pytorch_geometric_temporal_amd/dataset/cache.py) so that the loaders work without a
 network.  Run in the build container (reads /root/reference, writes pytorch_geometric_temporal_amd/dataset/data/).
 
     python scripts/make_dataset_cache.py [/path/to/reference/dataset]
@@ -14,8 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pytorch_geometric_temporal_amd.dataset import (_chickenpox_from_json, _covid_from_json,  # noqa: E402
-                                                    _montevideo_from_json, _pedalme_from_json)
+from pytorch_geometric_temporal_amd.dataset import _chickenpox_from_json, _covid_from_json  # noqa: E402
 from pytorch_geometric_temporal_amd.dataset.cache import load_cache, save_cache  # noqa: E402
 
 
@@ -24,9 +22,7 @@ def main():
     out = os.path.join(ROOT, "pytorch_geometric_temporal_amd", "dataset", "data")
     os.makedirs(out, exist_ok=True)
     for fname, conv, cname in (("chickenpox.json", _chickenpox_from_json, "chickenpox.pgtc"),
-                               ("england_covid.json", _covid_from_json, "england_covid.pgtc"),
-                               ("pedalme_london.json", _pedalme_from_json, "pedalme_london.pgtc"),
-                               ("montevideo_bus.json", _montevideo_from_json, "montevideo_bus.pgtc")):
+                               ("england_covid.json", _covid_from_json, "england_covid.pgtc")):
         with open(os.path.join(src, fname)) as f:
             c = conv(json.load(f))
         meta = dict(c.meta, source=f"benedekrozemberczki/pytorch_geometric_temporal dataset/{fname}")

@@ -80,6 +80,10 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_slab_set_sort(value);
     return PGT_OK;
   }
+  if (strcmp(key, "tgcn_probe") == 0) {
+    pgt_tgcn_set_probe(value);
+    return PGT_OK;
+  }
   if (strcmp(key, "tgcn_rows") == 0) {
     pgt_tgcn_set_rows(value);
     return PGT_OK;

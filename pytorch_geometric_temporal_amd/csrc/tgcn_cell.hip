@@ -23,6 +23,8 @@
 namespace {
 
 int g_tc_rows = 1;                  // pgt_tune("tgcn_rows", 0): the round-4 column-per-lane kernels for every shape
+int g_tc_wgs = 0;                   // pgt_tune("tgcn_wgs", n): workgroups of the row-per-lane forward kernel (0 = default), lab use
+int g_tc_probe = 0;                 // pgt_tune("tgcn_probe", n): lab variants of the forward kernel (wrong results), see PROBE
 
 constexpr int TC_O = 32;            // hidden width these kernels are built for
 constexpr int TC_LD = 33;           // LDS row pitch of a wavefront's strips (32 rows + 1: conflict-free both ways)
@@ -431,12 +433,32 @@ __device__ __forceinline__ void tc_bias_init(pgt_f32x16& acc, const float* sb, i
   }
 }
 
+constexpr int TC_P = 36;            // row pitch of the adjoint's row-major LDS matrices (16-byte rows: ds_write_b128; 36 mod 32 = 4)
+
+__device__ __forceinline__ void tc_park_rows(float* mat, int lo, int hi, const float (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<pgt_f4*>(mat + lo * TC_P + 8 * q + 4 * hi) = pgt_mk4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// PROBE (pgt_tune("tgcn_probe"), lab use only): 1 = no MFMAs, 2 = no Z | R / candidate stores, 3 = neither — what the memory system
+// alone makes of this access pattern.  0 is the kernel.
+template <int PROBE>
 __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
   __shared__ __attribute__((aligned(16))) float s_b[96];                   // bzr | bh
+  // per wavefront: one [32 rows][36] matrix through which every result goes from "lane = row, 32-byte pieces" (the accumulator
+  // layout) to whole 128-byte rows per eight lanes.  A store instruction in the accumulator layout writes 32 pieces of 32 bytes
+  // (32 L2 requests: PMC TCP_TCC_WRITE_REQ = 32 per instruction) and the CU's store path, not HBM, set the kernel's time (no MFMAs:
+  // 75 of 87 us; outputs cut to H' alone: 51 us); staged, an instruction writes eight complete rows.
+  __shared__ __attribute__((aligned(16))) float s_o[4][32 * TC_P];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
   const int Fin = g.Fin;
+  float* mat = s_o[wave];
+  const int srow = lane >> 3, spc = (lane & 7) * 4;                 // store role of the lane: rows srow + 8 j, floats spc .. spc + 3
   if (tid < 96) s_b[tid] = tid < 64 ? (g.bzr ? g.bzr[tid] : 0.f) : (g.bh ? g.bh[tid - 64] : 0.f);
   // A operands: this lane's column `lo` of the three weight blocks, k in the order the row pieces arrive; step 16 = the inputs
+  // (coalesced loads staged through LDS once per workgroup, and H fetched as whole rows through the staging matrix, were tried
+  // and measured: 64 -> 69 us; the L1 serves the repeated row pieces of the layout below well enough)
   float wz[17], wr[17], wh[17];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
@@ -481,13 +503,18 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
     pgt_f32x16 az, ar, ah;
     tc_bias_init(az, s_b, hi);
     tc_bias_init(ar, s_b + 32, hi);
+    if constexpr ((PROBE & 1) == 0) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      az = PGT_MFMA_32x32x2(wz[s], h[s], az);
-      ar = PGT_MFMA_32x32x2(wr[s], h[s], ar);
+      for (int s = 0; s < 16; ++s) {
+        az = PGT_MFMA_32x32x2(wz[s], h[s], az);
+        ar = PGT_MFMA_32x32x2(wr[s], h[s], ar);
+      }
+      az = PGT_MFMA_32x32x2(wz[16], ax, az);
+      ar = PGT_MFMA_32x32x2(wr[16], ax, ar);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { az[r] += h[r] * wz[r]; ar[r] += h[r] * wr[r] + ax; }
     }
-    az = PGT_MFMA_32x32x2(wz[16], ax, az);
-    ar = PGT_MFMA_32x32x2(wr[16], ax, ar);
     const int64_t r0 = st * 32;
     const bool ok = FULL || r0 + lo < g.M;
     float z[16], hr[16];
@@ -497,32 +524,43 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
       ar[r] = tc_sigmoidf(ar[r]);
       hr[r] = h[r] * ar[r];
     }
-    if (ok) {
-      float* zp = ZRg + r0 * 64 + (lo * 64 + 4 * hi);
+    auto put = [&](const float (&v)[16], float* dst, int ld) {      // v: this lane's 16 columns of its row -> dst[row][0 .. 31]
+      tc_park_rows(mat, lo, hi, v);
+      PGT_WAVE_SYNC();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<pgt_f4*>(zp + 8 * q) = pgt_mk4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
-        *reinterpret_cast<pgt_f4*>(zp + 32 + 8 * q) = pgt_mk4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
+      for (int j = 0; j < 4; ++j) {
+        const int row = srow + 8 * j;
+        const pgt_f4 t4 = *reinterpret_cast<const pgt_f4*>(mat + row * TC_P + spc);
+        if (FULL || r0 + row < g.M) *reinterpret_cast<pgt_f4*>(dst + (row * ld + spc)) = t4;
       }
+      PGT_WAVE_SYNC();
+    };
+    (void)ok;
+    if constexpr ((PROBE & 2) == 0) {
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = ar[r];
+      put(z, ZRg + r0 * 64, 64);
+      put(rv, ZRg + r0 * 64 + 32, 64);
     }
     tc_bias_init(ah, s_b + 64, hi);
+    if constexpr ((PROBE & 1) == 0) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) ah = PGT_MFMA_32x32x2(wh[s], hr[s], ah);
-    ah = PGT_MFMA_32x32x2(wh[16], ax, ah);
-    if (ok) {
-      float* tp = HTg + r0 * 32 + (lo * 32 + 4 * hi);
-      float* np = Hng + r0 * g.ldhn + (lo * (int)g.ldhn + 4 * hi);
+      for (int s = 0; s < 16; ++s) ah = PGT_MFMA_32x32x2(wh[s], hr[s], ah);
+      ah = PGT_MFMA_32x32x2(wh[16], ax, ah);
+    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t[4], n[4];
+      for (int r = 0; r < 16; ++r) ah[r] += hr[r] * wh[r] + ax;
+    }
+    {
+      float tv[16], nv[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { t[j] = tc_tanhf(ah[4 * q + j]); n[j] = pgt_gru_blend(z[4 * q + j], h[4 * q + j], t[j]); }
-        *reinterpret_cast<pgt_f4*>(tp + 8 * q) = pgt_mk4(t[0], t[1], t[2], t[3]);
-        *reinterpret_cast<pgt_f4*>(np + 8 * q) = pgt_mk4(n[0], n[1], n[2], n[3]);
-      }
+      for (int r = 0; r < 16; ++r) { tv[r] = tc_tanhf(ah[r]); nv[r] = pgt_gru_blend(z[r], h[r], tv[r]); }
+      if constexpr ((PROBE & 2) == 0) put(tv, HTg + r0 * 32, 32);
+      put(nv, Hng + r0 * g.ldhn, (int)g.ldhn);
     }
     if (prefetch) {
-      if constexpr (FULL) TC_WAIT5(16, hq[0], hq[1], hq[2], hq[3], axv);     // the prefetch is older than this strip's 16 stores
+      if constexpr (FULL) TC_WAIT5((PROBE & 2) ? 4 : 16, hq[0], hq[1], hq[2], hq[3], axv);   // the prefetch is older than this strip's 16 stores
       else TC_WAIT5(0, hq[0], hq[1], hq[2], hq[3], axv);
     }
   };
@@ -538,14 +576,6 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
     st += stride;
   }
   if (st < n_strips) strip(st, std::false_type{}, false);                           // the partial strip, if this wavefront owns it
-}
-
-constexpr int TC_P = 36;            // row pitch of the adjoint's row-major LDS matrices (16-byte rows: ds_write_b128; 36 mod 32 = 4)
-
-__device__ __forceinline__ void tc_park_rows(float* mat, int lo, int hi, const float (&v)[16]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    *reinterpret_cast<pgt_f4*>(mat + lo * TC_P + 8 * q + 4 * hi) = pgt_mk4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
 __global__ __launch_bounds__(256, 2) void tgcn_cell_bwd_rows_kernel(TcArgs g) {
@@ -765,6 +795,7 @@ extern "C" int64_t pgt_tgcn_cell_bwd_ws_floats(int64_t Fin, int64_t O) {
 }
 
 void pgt_tgcn_set_rows(int v) { g_tc_rows = v ? 1 : 0; }
+void pgt_tgcn_set_probe(int v) { if (v >= 1000) g_tc_wgs = v - 1000; else g_tc_probe = v; }   // (1000 + n: workgroup cap n)
 
 extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, int64_t ldh, const float* Wzr, const float* bzr,
                                  const float* Wh, const float* bh, int64_t M, int64_t Fin, int64_t O, float* ZR, float* HT, float* Hn,
@@ -779,8 +810,14 @@ extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, 
   g.AX = AX; g.ldax = ldax; g.H = H; g.ldh = ldh; g.Wzr = Wzr; g.bzr = bzr; g.Wh = Wh; g.bh = bh;
   g.ZR = ZR; g.HT = HT; g.Hn = Hn; g.ldhn = ldhn; g.M = (int)M; g.Fin = (int)Fin; g.tiles = (int)pgt_cdiv(M, 128);
   if (tc_rows_ok(Fin, {H, ZR, HT, Hn}, {ldh, ldhn})) {
-    const int64_t wg = g.tiles < TC_WGS_ROWS_FWD ? g.tiles : TC_WGS_ROWS_FWD;
-    PGT_LAUNCH(tgcn_cell_fwd_rows_kernel, dim3((unsigned)wg), dim3(256), stream, g);
+    const int64_t cap = g_tc_wgs > 0 ? g_tc_wgs : TC_WGS_ROWS_FWD;
+    const int64_t wg = g.tiles < cap ? g.tiles : cap;
+    switch (g_tc_probe) {
+      case 1: PGT_LAUNCH(tgcn_cell_fwd_rows_kernel<1>, dim3((unsigned)wg), dim3(256), stream, g); break;
+      case 2: PGT_LAUNCH(tgcn_cell_fwd_rows_kernel<2>, dim3((unsigned)wg), dim3(256), stream, g); break;
+      case 3: PGT_LAUNCH(tgcn_cell_fwd_rows_kernel<3>, dim3((unsigned)wg), dim3(256), stream, g); break;
+      default: PGT_LAUNCH(tgcn_cell_fwd_rows_kernel<0>, dim3((unsigned)wg), dim3(256), stream, g);
+    }
     return pgt_check_launch("pgt_tgcn_cell_f32");
   }
   int64_t wgs = g.tiles < 4 * TC_WGS ? g.tiles : 4 * TC_WGS;

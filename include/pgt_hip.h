@@ -31,6 +31,8 @@
  *   pgt_gemm_tn_acc_f32   autograd of the above w.r.t. the weights (torch autograd in the reference)
  *   pgt_att_*             SpatialAttention / TemporalAttention of ASTGCN: nn/attention/astgcn.py:226-262, :291-328
  *   pgt_window_gather_f32 signal/index_dataset.py:32-57 (the index-batch windows of a resident series)
+ *   pgt_relu_linear_*     the per-node read-out of the reference's models, `self.linear(F.relu(h))` with a torch.nn.Linear(hidden,
+ *                         1 .. 4): examples/indexBatching/tgcn/metr_la_main.py:43-45, examples/recurrent/dcrnn_example.py:27-31
  *   pgt_gru_*             the GRU gate chains: dcrnn.py:172-192,406-427; temporalgcn.py:82-102
  *   pgt_lstm_gates*       the LSTM gate chains: gconv_lstm.py:138-172 (peepholes), gc_lstm.py:138-169
  */
@@ -49,7 +51,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 13
+#define PGT_ABI_VERSION 14
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -608,6 +610,22 @@ int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const float* AX, int6
                           const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin, int64_t O,
                           float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, float* ws, int64_t ws_floats,
                           pgt_stream_t stream);
+
+/* The read-out behind a recurrent layer (examples/indexBatching/tgcn/metr_la_main.py:43-45: `self.linear(F.relu(h))`, torch.nn.Linear
+ * with 1 .. 4 outputs) as one streaming pass each way over the states X [M, K] (row stride ldx, 16-byte addressable), csrc/readout.hip:
+ *   forward   Y[m, n] = sum_k act(X[m, k]) W[n, k] + b[n],  act = relu when `relu` != 0, identity otherwise;  W [N, K] row-major
+ *             (torch.nn.Linear.weight), b [N] | NULL, Y [M, N] row stride ldy
+ *   adjoint   dX[m, k] = act'(X[m, k]) sum_n dY[m, n] W[n, k]  (dX NULL: not wanted),  dW [N, K] = dY^T act(X),  db [N] = column sums
+ *             of dY (either NULL: not wanted) — STORED, deterministic: per-workgroup partial sums in ws
+ *             (pgt_relu_linear_bwd_ws_floats floats) added in index order.
+ * pgt_relu_linear_fits: 4 <= K <= 64, K % 4 == 0, 1 <= N <= 4. */
+int pgt_relu_linear_fits(int64_t K, int64_t N);
+int64_t pgt_relu_linear_bwd_ws_floats(int64_t K, int64_t N);
+int pgt_relu_linear_f32(const float* X, int64_t ldx, const float* W, const float* b, int64_t M, int64_t K, int64_t N, int relu,
+                        float* Y, int64_t ldy, pgt_stream_t stream);
+int pgt_relu_linear_bwd_f32(const float* X, int64_t ldx, const float* dY, int64_t lddy, const float* W, int64_t M, int64_t K,
+                            int64_t N, int relu, float* dX, int64_t lddx, float* dW, float* db, float* ws, int64_t ws_floats,
+                            pgt_stream_t stream);
 
 /* Index-batch window gather (signal/index_dataset.py:32-57; examples/indexBatching: "GPU-index-batching"): for every
  * sample b, X[b] = data[idx[b] : idx[b] + h], Y[b] = data[idx[b] + h : idx[b] + 2 h] from the resident series

@@ -50,7 +50,59 @@ static void run(const char* name, char* buf, size_t total, size_t window, float*
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps, mb = (double)(R + W) * per / 1e6;
   printf("{\"mix\": \"%s\", \"read_MB\": %.1f, \"write_MB\": %.1f, \"us\": %.1f, \"TBs\": %.3f}\n", name, R * per / 1e6, W * per / 1e6, us,
-         mb / us / 1e6 * 1e6 / 1e6);
+         mb / us);
+}
+
+// Write-only, three store patterns over [rows][64] fp32 tiles of 32 rows (what an MFMA epilogue has to choose between):
+//   0: whole rows, 16 bytes per lane (an instruction = 4 complete 256-byte rows) — what staging through LDS buys
+//   1: the accumulator layout as it is, 4 bytes per lane (an instruction = two 128-byte row pieces, rows 4 apart; csrc/gemm_bx.hip)
+//   2: lane = row, 16 bytes per lane (an instruction = 32 pieces of 32 bytes; the first row-per-lane T-GCN forward kernel)
+template <int PAT>
+__global__ __launch_bounds__(256) void store_pattern_kernel(float* __restrict__ dst, int64_t n_tiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 31, hi = lane >> 5;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+    float* tile = dst + t * 32 * 64;
+    if (PAT == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f4 v = {(float)j, 1.f, 2.f, (float)lane};
+        *reinterpret_cast<f4*>(tile + (4 * j + (lane >> 4)) * 64 + (lane & 15) * 4) = v;
+      }
+    } else if (PAT == 1) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + half * 32 + lo] = (float)(r + lane);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        f4 v = {(float)q, 1.f, 2.f, (float)lane};
+        *reinterpret_cast<f4*>(tile + lo * 64 + 8 * q + 4 * hi) = v;
+      }
+    }
+  }
+}
+
+template <int PAT>
+static void run_pattern(const char* name, char* buf, size_t total, size_t window) {
+  const int64_t n_tiles = (int64_t)(window / (32 * 64 * 4));
+  const int n_win = (int)(total / window);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto launch = [&](int w) {
+    hipLaunchKernelGGL((store_pattern_kernel<PAT>), dim3(1024), dim3(256), 0, 0, (float*)(buf + (size_t)(w % n_win) * window), n_tiles);
+  };
+  for (int w = 0; w < n_win; ++w) launch(w);
+  CK(hipDeviceSynchronize());
+  const int reps = 3 * n_win;
+  CK(hipEventRecord(e0));
+  for (int w = 0; w < reps; ++w) launch(w);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps;
+  printf("{\"store_pattern\": \"%s\", \"write_MB\": %.1f, \"us\": %.1f, \"TBs\": %.3f}\n", name, window / 1e6, us, window / us / 1e6);
 }
 
 int main(int argc, char** argv) {
@@ -70,5 +122,8 @@ int main(int argc, char** argv) {
   run<4, 1>("4:1 (the adjoint cell: 259 MB in, 51 MB out)", buf, total, window, sink);
   run<2, 1>("2:1", buf, total, window, sink);
   run<1, 2>("1:2", buf, total, window, sink);
+  run_pattern<0>("whole rows, 16 B per lane", buf, total, window);
+  run_pattern<1>("accumulator layout, 4 B per lane (two 128-byte pieces per instruction)", buf, total, window);
+  run_pattern<2>("lane = row, 16 B per lane (32 pieces of 32 bytes per instruction)", buf, total, window);
   return 0;
 }

@@ -31,6 +31,14 @@ class _StatesTensor(torch.Tensor):
                     x.device == w.device and (b is None or (type(b) in (torch.Tensor, torch.nn.Parameter) and
                                                             b.dtype == torch.float32 and b.device == w.device))):
                 from .conv import _rows_in_memory_order
+                pre = getattr(x, "_pgt_pre", None)
+                if pre is not None and pre[0]._version == pre[1] and ops.readout_fits(x, w, b):
+                    # linear(relu(states)): one pass each way over the PRE-relu states (csrc/readout.hip) — relu, the product, and in
+                    # the adjoint relu's mask, the input gradient and the weight gradient together.  The relu tensor itself exists
+                    # (it was computed when the caller asked for it) and is an ordinary operand for anything else done with it.
+                    x2, restore = _rows_in_memory_order(pre[0].as_subclass(torch.Tensor))
+                    if x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0:
+                        return restore(ops.ReadoutFunction.apply(x2, w, b, True))
                 x2, restore = _rows_in_memory_order(x.as_subclass(torch.Tensor))
                 return restore(ops.linear(x2, w.t(), b))
         with torch._C.DisableTorchFunctionSubclass():
@@ -40,7 +48,12 @@ class _StatesTensor(torch.Tensor):
         # one purpose of this class, so the read-out that follows is routed as well
         if func in cls._RELUS and not kwargs.get("inplace", False) and isinstance(out, torch.Tensor) and \
                 type(args[0]) is _StatesTensor:
-            return out.as_subclass(_StatesTensor)
+            res = out.as_subclass(_StatesTensor)
+            if getattr(args[0], "_pgt_pre", None) is None:        # (relu of a relu: the inner one stays the reference point)
+                res._pgt_pre = (args[0], args[0]._version)          # the states this is the relu of, and their version then
+            else:
+                res._pgt_pre = args[0]._pgt_pre
+            return res
         return _plain(out)
 
     def __reduce_ex__(self, proto):

@@ -1526,6 +1526,72 @@ def linear(X2d, W_kn, bias=None):
     return LinearFunction.apply(X2d, W_kn, bias)
 
 
+class ReadoutFunction(torch.autograd.Function):
+    """The read-out the reference's models apply to the states of a recurrent layer — `linear(relu(h))` or `linear(h)` with a
+    torch.nn.Linear of 1 .. 4 outputs (examples/indexBatching/tgcn/metr_la_main.py:43-45, examples/recurrent/dcrnn_example.py:27-31)
+    — as one streaming pass each way (csrc/readout.hip): X [M, K] rows (the PRE-relu states), weight [N, K] as torch.nn.Linear
+    holds it, bias [N] | None -> Y [M, N]; the adjoint reads X once and writes dX once (relu's mask applied in the same pass),
+    weight / bias gradients from per-workgroup partial sums added in index order (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, X, weight, bias, relu):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        check_tensor(lib, weight, "weight")
+        M, K = X.shape
+        N = weight.size(0)
+        if weight.shape != (N, K) or (bias is not None and bias.shape != (N,)):
+            raise ValueError(f"read-out: weight must be [out, {K}] and bias [out], got {tuple(weight.shape)}")
+        xp, ldx = _rows(X, "X")
+        W = weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        Y = torch.empty(M, N, dtype=F32, device=X.device)
+        _timed("readout", 4.0 * M * (K + N) if KERNEL_TIMER else 0, lambda: lib.call(
+            "pgt_relu_linear_f32", xp, ldx, ptr(W), ptr(b), M, K, N, int(bool(relu)), ptr(Y), N, stream_of(lib, Y)), tag=("fwd", M, K, N))
+        ctx.save_for_backward(X, W)
+        ctx.relu, ctx.has_bias = bool(relu), bias is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = _lib.get_lib()
+        X, W = ctx.saved_tensors
+        M, K = X.shape
+        N = W.size(0)
+        dYc = dY.contiguous()
+        xp, ldx = _rows(X, "X")
+        need = ctx.needs_input_grad
+        dX = torch.empty(M, K, dtype=F32, device=X.device) if need[0] else None
+        dW = torch.empty(N, K, dtype=F32, device=X.device) if need[1] else None
+        db = torch.empty(N, dtype=F32, device=X.device) if (ctx.has_bias and need[2]) else None
+        nws = int(lib._pgt_relu_linear_bwd_ws_floats(K, N))
+        ws = _det_workspace(X.device, nws)
+        _timed("readout", 4.0 * M * (2 * K + N) if KERNEL_TIMER else 0, lambda: lib.call(
+            "pgt_relu_linear_bwd_f32", xp, ldx, ptr(dYc), N, ptr(W), M, K, N, int(ctx.relu), ptr(dX), K, ptr(dW), ptr(db), ptr(ws), nws,
+            stream_of(lib, X)), tag=("bwd", M, K, N))
+        return dX, dW, db, None
+
+
+def readout_fits(x, weight, bias):
+    """Whether the streaming read-out kernels take this call: fp32 rows of 4 .. 64 (a multiple of 4) floats that are 16-byte
+    addressable, 1 .. 4 outputs."""
+    if x.dim() < 2 or weight.dim() != 2 or x.size(-1) != weight.size(1):
+        return False
+    K, N = weight.size(1), weight.size(0)
+    return bool(_lib.get_lib()._pgt_relu_linear_fits(int(K), int(N)))
+
+
+def readout(x, weight, bias, relu):
+    """linear(relu(x)) / linear(x) over the last dimension of x through ReadoutFunction (rows in memory order, no copy when x is
+    contiguous)."""
+    lead = x.shape[:-1]
+    K = x.size(-1)
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    return ReadoutFunction.apply(x2, weight, bias, relu).view(*lead, weight.size(0))
+
+
 # --------------------------------------------------------------------------------------------- T-GCN cell
 
 class TGCNWeightsFunction(torch.autograd.Function):

@@ -972,8 +972,8 @@ def test_tgcn2_states_route_the_reference_examples_readout(backend):
     for routed in (True, False):
         TGCN2.readout_interception = routed
         calls = []
-        orig = ops.linear
-        ops.linear = lambda *a: (calls.append(1), orig(*a))[1]
+        orig = ops.ReadoutFunction.apply       # relu -> Linear: ONE pass each way over the pre-relu states (csrc/readout.hip)
+        ops.ReadoutFunction.apply = lambda *a: (calls.append(a[3]), orig(*a))[1]
         try:
             cell.zero_grad(); head.zero_grad()
             h, outs = None, []
@@ -982,14 +982,59 @@ def test_tgcn2_states_route_the_reference_examples_readout(backend):
                 assert (type(h) is _StatesTensor) == routed and h.shape == (B, n, O)
                 outs.append(head(TF.relu(h)).unsqueeze(1))
             y = torch.cat(outs, 1)
-            assert type(y) is torch.Tensor and len(calls) == (3 if routed else 0)
+            assert type(y) is torch.Tensor and calls == ([True] * 3 if routed else [])
             y.square().mean().backward()
-            res[routed] = (y.detach().clone(), head.weight.grad.clone(), cell.linear_z.weight.grad.clone())
+            res[routed] = (y.detach().clone(), head.weight.grad.clone(), cell.linear_z.weight.grad.clone(), head.bias.grad.clone())
         finally:
-            ops.linear = orig
+            ops.ReadoutFunction.apply = orig
             TGCN2.readout_interception = True
-    for a, b, what in zip(res[True], res[False], ("outputs", "d/d read-out weight", "d/d linear_z.weight")):
+    for a, b, what in zip(res[True], res[False], ("outputs", "d/d read-out weight", "d/d linear_z.weight", "d/d read-out bias")):
         assert_close_with_nonfinite(a, b, 1e-6 + 1e-5 * float(b.abs().max()), 1e-5, what)
+    # the relu tensor is an ordinary operand for anything else (its own gradient path through torch's relu); states edited in place
+    # between the relu and the read-out are not taken for what the relu saw
+    h = cell(xs[0], ei, ew, None)
+    r = TF.relu(h)
+    y = head(r) .sum() + (r * 2.0).sum()
+    h2 = cell(xs[0], ei, ew, None).as_subclass(torch.Tensor)
+    r2 = torch.relu(h2)
+    y2 = TF.linear(r2, head.weight, head.bias).sum() + (r2 * 2.0).sum()
+    cell.zero_grad(); y.backward(); g1 = cell.linear_h.weight.grad.clone()
+    cell.zero_grad(); y2.backward(); g2 = cell.linear_h.weight.grad.clone()
+    assert_close_with_nonfinite(y, y2, 1e-4, 1e-5, "relu used twice")
+    assert_close_with_nonfinite(g1, g2, 1e-6 + 1e-5 * float(g2.abs().max()), 1e-5, "relu used twice: gradient")
+    with torch.no_grad():
+        h = cell(xs[0], ei, ew, None)
+        r = TF.relu(h)
+        want = TF.linear(r.as_subclass(torch.Tensor), head.weight, head.bias)
+        h.mul_(-1.0)                                            # the states change after the relu was taken
+        assert_close_with_nonfinite(head(r), want, 1e-6, 1e-5, "in-place edit of the states after relu")
+
+
+@pytest.mark.parametrize("M,K,N,relu,ld", [(1, 4, 1, True, 4), (37, 8, 2, True, 8), (130, 32, 2, True, 32), (130, 32, 2, False, 40),
+                                           (257, 64, 4, True, 64), (64, 20, 3, True, 20), (1000, 32, 1, True, 32)])
+def test_readout_kernels_match_torch(backend, M, K, N, relu, ld):
+    """csrc/readout.hip: y = linear(relu(x)) (or linear(x)) and every gradient against torch in fp64, rows inside a wider buffer
+    (row stride ld), row counts that do not fill a pass."""
+    from pytorch_geometric_temporal_amd import ops
+    torch.manual_seed(M + K)
+    buf = torch.randn(M, ld)
+    x = buf[:, :K]
+    W, b, gy = torch.randn(N, K) * 0.3, torch.randn(N), torch.randn(M, N)
+    x64, W64, b64 = x.double().requires_grad_(), W.double().requires_grad_(), b.double().requires_grad_()
+    ref = torch.nn.functional.linear(torch.relu(x64) if relu else x64, W64, b64)
+    (ref * gy.double()).sum().backward()
+    bd = backend.t(buf).requires_grad_()
+    Wd, bdev = backend.t(W).requires_grad_(), backend.t(b).requires_grad_()
+    assert ops.readout_fits(bd[:, :K], Wd, bdev)
+    y = ops.ReadoutFunction.apply(bd[:, :K], Wd, bdev, relu)
+    assert_close_with_nonfinite(y, ref, 2e-5, 2e-5, "forward")
+    (y * backend.t(gy)).sum().backward()
+    assert_close_with_nonfinite(bd.grad[:, :K], x64.grad, 2e-5, 1e-5, "dX")
+    assert float(bd.grad[:, K:].abs().sum()) == 0.0
+    assert_close_with_nonfinite(Wd.grad, W64.grad, 2e-5 * float(W64.grad.abs().max()) + 1e-6, 1e-5, "dW")
+    assert_close_with_nonfinite(bdev.grad, b64.grad, 2e-5 * float(b64.grad.abs().max()) + 1e-6, 1e-5, "db")
+    y_nb = ops.ReadoutFunction.apply(bd[:, :K].detach(), Wd.detach(), None, relu)
+    assert_close_with_nonfinite(y_nb, ref - b64, 2e-5, 2e-5, "no bias")
 
 
 def test_cell_operands_are_packed_once_per_training_step(backend):

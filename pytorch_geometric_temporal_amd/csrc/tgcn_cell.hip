@@ -402,11 +402,13 @@ __global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __re
 //     per wavefront, written with ds_write_b128 and read column-wise, conflict-free both ways.
 // Rounds 4's kernels above stay as the path for 3 <= Fin <= 30 and for operands that are not 16-byte addressable.
 
-// The forward kernel's prefetch: 16-byte loads the compiler cannot see, released by a hand-counted wait.  vmcnt is ONE in-order
-// counter for loads and stores; the compiler's own wait for a prefetched register at a loop head merges the first-entry path (no
-// stores pending) with the back edge (sixteen pending) and takes the smaller count — the whole store queue drained once per strip
-// (measured: the first row-per-lane form gained only 15 % over the column form).  Here the wait says what is true: the prefetch is
-// older than exactly the sixteen stores of the strip, which stay in flight.  (Same device as csrc/gemm_bx.hip's platform layer.)
+// Prefetches as 16-byte loads the compiler cannot see, released by a hand-placed wait.  Why not leave it to the compiler: its wait
+// for a prefetched register sits wherever the register is first read, which for a loop-carried prefetch is the loop head, behind
+// whatever the scheduler moved there.  Why the wait is vmcnt(0) and not "all but this strip's sixteen stores": vmcnt is ONE counter
+// for loads and stores, loads retire in order among themselves but a younger store may be acknowledged BEFORE an older load lands,
+// so a count that leaves the stores outstanding can pass with a load still in flight (csrc/gemm_bx.hip found this the hard way:
+// four stale rows in 200 000, scripts/bx_sym_race_probe.py).  Measured, the exact-count form bought nothing anyway (76.6 vs
+// 81.5 us): the kernel's time was in the CU's store path, not in this wait.
 #ifdef PGT_EMU
 #define TC_LOAD4(dst, p, OFF) ((dst) = *reinterpret_cast<const pgt_f4*>((p) + (OFF) / 4))
 #define TC_LOAD1(dst, p) ((dst) = *(p))
@@ -490,9 +492,7 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
     TC_LOAD4(hq[0], hp, 0); TC_LOAD4(hq[1], hp, 32); TC_LOAD4(hq[2], hp, 64); TC_LOAD4(hq[3], hp, 96);
     TC_LOAD1(axv, ap);
   };
-  // One strip.  FULL strips store without a branch, so that exactly sixteen stores follow the prefetch and TC_WAIT5(16, ...) at
-  // the end of the strip releases the prefetched registers with those stores still in flight.  The one partial strip (stores
-  // behind `row < M`) runs after the loop and drains instead.
+  // One strip.  FULL strips store without a branch; the one partial strip (stores behind `row < M`) runs after the loop.
   auto strip = [&](int64_t st, auto full_c, bool prefetch) {
     constexpr bool FULL = decltype(full_c)::value;
     float h[16];
@@ -560,8 +560,7 @@ __global__ __launch_bounds__(256, 2) void tgcn_cell_fwd_rows_kernel(TcArgs g) {
       put(nv, Hng + r0 * g.ldhn, (int)g.ldhn);
     }
     if (prefetch) {
-      if constexpr (FULL) TC_WAIT5((PROBE & 2) ? 4 : 16, hq[0], hq[1], hq[2], hq[3], axv);   // the prefetch is older than this strip's 16 stores
-      else TC_WAIT5(0, hq[0], hq[1], hq[2], hq[3], axv);
+      TC_WAIT5(0, hq[0], hq[1], hq[2], hq[3], axv);              // (everything: see TC_LOAD4)
     }
   };
   int64_t st = (int64_t)blockIdx.x * 4 + wave_u;

@@ -42,6 +42,9 @@ class Linear(torch.nn.Linear):
     the rows once."""
 
     def forward(self, x):
+        if getattr(x, "_pgt_pre", None) is not None:
+            # relu(states) of a recurrent layer (nn/_states.py): relu and this product as one pass over the states
+            return torch.nn.functional.linear(x, self.weight, self.bias)
         x2, restore = _rows_in_memory_order(x)
         return restore(ops.linear(x2, self.weight.t(), self.bias))
 

@@ -254,6 +254,56 @@ def _batched_tgcn_against_oracle(device, ei, ew, X, y, hidden, atol_fwd, grad_to
         assert_close_with_nonfinite(p.grad, g64, grad_tol * float(g64.abs().max()) + 1e-9, grad_tol, name)
 
 
+@pytest.mark.gpu
+def test_config4_cell_kernels_row_and_column_forms_agree_on_every_row_repeatedly():
+    """The fused T-GCN cell at config 4's size (400 000 rows): the row-per-lane kernels (hand-issued prefetches, hand-placed waits)
+    against the column-per-lane kernels of round 4 (compiler-placed waits), EVERY element, five launches of each — a prefetched
+    register consumed before its load landed shows up as a handful of rows far off (csrc/gemm_bx.hip's round-2 race was four rows in
+    200 000) — and bit-identical results from launch to launch."""
+    from pytorch_geometric_temporal_amd import _lib
+    from pytorch_geometric_temporal_amd.ops import ptr, stream_of
+    dev = torch.device("cuda:0")
+    lib = _lib.get_lib()
+    M, Fin, O = 400_000, 2, 32
+    C = Fin + O
+    torch.manual_seed(5)
+    AX, H, dHn = (torch.randn(M, Fin, device=dev), torch.randn(M, O, device=dev), torch.randn(M, O, device=dev))
+    Wzr, bzr = torch.randn(C, 2 * O, device=dev) * 0.2, torch.randn(2 * O, device=dev) * 0.1
+    Wh, bh = torch.randn(C, O, device=dev) * 0.2, torch.randn(O, device=dev) * 0.1
+    nws = int(lib._pgt_tgcn_cell_bwd_ws_floats(Fin, O))
+
+    def run():
+        ZR, HT, Hn, dH = (torch.empty(M, 2 * O, device=dev), torch.empty(M, O, device=dev), torch.empty(M, O, device=dev),
+                          torch.empty(M, O, device=dev))
+        dW, ws = torch.empty(C * 3 * O + 3 * O, device=dev), torch.empty(nws, device=dev)
+        lib.call("pgt_tgcn_cell_f32", ptr(AX), Fin, ptr(H), O, ptr(Wzr), ptr(bzr), ptr(Wh), ptr(bh), M, Fin, O, ptr(ZR), ptr(HT), ptr(Hn), O,
+                 stream_of(lib, H))
+        lib.call("pgt_tgcn_cell_bwd_f32", ptr(dHn), O, ptr(AX), Fin, ptr(H), O, ptr(ZR), ptr(HT), ptr(Wzr), ptr(Wh), M, Fin, O, ptr(dH), O,
+                 ptr(dW[:C * 2 * O]), ptr(dW[C * 3 * O:C * 3 * O + 2 * O]), ptr(dW[C * 2 * O:C * 3 * O]), ptr(dW[C * 3 * O + 2 * O:]),
+                 ptr(ws), nws, stream_of(lib, H))
+        torch.cuda.synchronize()
+        return ZR, HT, Hn, dH, dW
+    try:
+        lib.tune("tgcn_rows", 0)
+        ref = run()
+    finally:
+        lib.tune("tgcn_rows", 1)
+    first = None
+    for it in range(5):
+        got = run()
+        for a, b, what, tol in zip(got, ref, ("Z|R", "candidate", "H'", "dH", "weight gradients"), (2e-6, 2e-6, 2e-6, 2e-5, 0.0)):
+            if what == "weight gradients":
+                assert_close_with_nonfinite(a, b, 2e-5 * float(b.abs().max()), 1e-5, f"{what}, launch {it}")
+            else:
+                d = (a - b).abs()
+                assert float(d.max()) <= tol + 1e-5 * float(b.abs().max()), f"{what}, launch {it}: {int((d > tol).sum())} elements off, max {float(d.max()):.3e}"
+        if first is None:
+            first = got
+        else:
+            for a, b, what in zip(got, first, ("Z|R", "candidate", "H'", "dH", "weight gradients")):
+                assert torch.equal(a, b), f"{what}: launch {it} differs from launch 0"
+
+
 def test_config4_batched_tgcn_training_loop_small(backend):
     """The T-step BatchedTGCN loop (TGCN2 -> relu -> Linear per step, hidden state carried, masked-MAE) at a size the CPU
     double runs in seconds: 60 nodes, B = 3, T = 5."""

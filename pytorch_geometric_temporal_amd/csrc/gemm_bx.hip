@@ -33,7 +33,6 @@ namespace {
 
 int g_bx = 1;   // pgt_tune("gemm_bx"): 1 = where it applies (>= 8192 rows), 2 = at any size (tests), 0 = never
 int g_bx_sym = 1;   // pgt_tune("gemm_bx_sym"): 0 = short-K products on the K-split kernel instead of the symmetric one (A/B)
-int g_bx_stage = 1; // pgt_tune("gemm_bx_stage"): 0 = the symmetric kernel stores straight from the accumulator layout (A/B)
 
 // ---- platform layer: the handful of operations below are hand-written gfx950 instructions.  The CPU test double compiles
 // the SAME kernel bodies against tests/hipemu/pgt_bx_platform_emu.h, which spells these operations in plain C++ (fibers,
@@ -63,7 +62,6 @@ __device__ __forceinline__ BxRsrc bx_make_rsrc(const void* p, int64_t bytes) {
 // (a store of more than 8 bytes reads its data registers over several cycles: a VALU write to them in the next two issue
 // slots corrupts the stored value — the compiler pads its own stores for this hazard and cannot see into the asm)
 #define BX_STORE4(val, voff, rs) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" :: "v"(val), "v"(voff), "s"(rs) : "memory")
-#define BX_STORE4S(val, voff, rs, soff) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(val), "v"(voff), "s"(rs), "s"(soff) : "memory")
 // hand-counted waits, tied to the registers they release so that the consumer cannot be scheduled above them
 #define BX_WAIT(n, reg) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n))
 #define BX_WAIT2(n, r0, r1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(n))
@@ -846,16 +844,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
 // EPT - 1 loads + the 16 stores of the previous block.  Column blocks 8 and 9 (N = 320 = five 64-wide stack segments:
 // one product reads dP once instead of a 256-column product plus a 64-column remainder) go to wavefronts 0 and 1 as a
 // second block whose B fragments wait in LDS in operand order.
-// STAGED: a wavefront's 32 x 32 result tile goes through LDS so that a store instruction writes eight whole 128-byte row pieces
-// (16 bytes per lane, four instructions per tile) instead of two (4 bytes per lane, sixteen instructions): the T-GCN cell's forward
-// kernel gained 26 % from that alone in round 5 (the CU's store path, not HBM, was its bound).  Needs 16-byte addressable rows.
-template <int KSTEPS, bool STAGED>
+template <int KSTEPS>
 __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int n_blocks) {
   constexpr int BM = 32, KP = KSTEPS * 16, SROW = KP * 2 + 16, PLANE = BM * SROW, BUF = 3 * PLANE;
   constexpr int EPT = (KP / 2) / 16;                      // float pairs per thread and block (16 threads per row)
   constexpr int B2 = KSTEPS * 3 * 64 * 16;                // one extra column block's B fragments, operand order
-  constexpr int STG = STAGED ? 8 * 32 * 36 * 4 : 0;       // per wavefront: one [32 rows][36] fp32 tile
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 2 * B2 + STG];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 2 * B2];
   const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
   const int wave = BX_SGPR(tid >> 6);
   const int nwg = gridDim.x;
@@ -968,30 +962,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   int cur = 0;
   const int arow = lo * SROW + 16 * hi;
   const uint32_t ldc4 = (uint32_t)(g.ldc * 4);
-  float* const stg = reinterpret_cast<float*>(lds + 2 * BUF + 2 * B2) + (STAGED ? wave * (32 * 36) : 0);
-  const int srow = lane >> 3, spc = (lane & 7) * 4;       // staged store role: rows srow + 8 j, floats spc .. spc + 3 of the tile
-  const uint32_t svoff = (uint32_t)((srow * g.ldc + spc) * 4);
-  auto store_tile = [&](const float (&v)[16], uint32_t voff_cols, const BxRsrc& rc) {
-    if constexpr (STAGED) {
-      (void)voff_cols;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + lo] = v[r];
-      PGT_WAVE_SYNC();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bx_u32x4 t4 = *reinterpret_cast<const bx_u32x4*>(stg + (srow + 8 * j) * 36 + spc);
-        const uint32_t soff = (uint32_t)BX_SGPR((int)(8 * j * ldc4));
-        BX_STORE4S(t4, svoff, rc, soff);
-      }
-      PGT_WAVE_SYNC();
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
-        BX_STORE1S(v[r], voff_cols, rc, soff);
-      }
-    }
-  };
   for (; rb < n_blocks; rb += nwg) {
     unsigned char* bcur = lds + cur * BUF;
     unsigned char* bnxt = lds + (cur ^ 1) * BUF;
@@ -1036,7 +1006,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
         BX_DRAIN();
         bx_exact_tile(g, a_rsrc(rb), col, hi, bias_r, v);
       }
-      store_tile(v, cvoff, rc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
+        BX_STORE1S(v[r], cvoff, rc, soff);
+      }
       if (two) {
         const BxRsrc rc2 = c_rsrc(cbase2, rb);
 #pragma unroll
@@ -1045,7 +1019,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
           BX_DRAIN();
           bx_exact_tile(g, a_rsrc(rb), col2, hi, bias_r2, v);
         }
-        store_tile(v, cvoff2, rc2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
+          BX_STORE1S(v[r], cvoff2, rc2, soff);
+        }
       }
     }
     bx_barrier();
@@ -1073,7 +1051,6 @@ int bx_device_cus() {
 
 void pgt_gemm_bx_set(int v) { g_bx = v; }
 void pgt_gemm_bx_sym_set(int v) { g_bx_sym = v; }
-void pgt_gemm_bx_stage_set(int v) { g_bx_stage = v; }
 
 int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (!g_bx) return 0;
@@ -1127,15 +1104,8 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   dim3 grid((unsigned)wgs), block(512);
 #define PGT_BX_GO(KS_, WN_, EPI_, Q4_) PGT_LAUNCH((gemm_bx_kernel<KS_, WN_, EPI_, Q4_>), grid, block, stream, g, n_blocks)
   if (sym_ok) {
-    // whole-row stores through LDS when every output row piece is 16-byte addressable and the column blocks are whole
-    const bool staged = g_bx_stage && g.N % 32 == 0 && g.ldc % 4 == 0 && g.c_seg_stride % 4 == 0 && pgt_aligned(g.C, 16);
-    if (K > 64) {
-      if (staged) PGT_LAUNCH((gemm_bx_sym_kernel<8, true>), grid, block, stream, g, n_blocks);
-      else PGT_LAUNCH((gemm_bx_sym_kernel<8, false>), grid, block, stream, g, n_blocks);
-    } else {
-      if (staged) PGT_LAUNCH((gemm_bx_sym_kernel<4, true>), grid, block, stream, g, n_blocks);
-      else PGT_LAUNCH((gemm_bx_sym_kernel<4, false>), grid, block, stream, g, n_blocks);
-    }
+    if (K > 64) PGT_LAUNCH((gemm_bx_sym_kernel<8>), grid, block, stream, g, n_blocks);
+    else PGT_LAUNCH((gemm_bx_sym_kernel<4>), grid, block, stream, g, n_blocks);
   } else if (K > 128 && g.N <= 64) {                         // two column blocks: K cut four ways
     if (g.epi == 1) PGT_BX_GO(21, 1, 1, true);
     else if (g.epi == 2) PGT_BX_GO(21, 1, 2, true);

@@ -15,7 +15,6 @@ static inline bool bx_in_range(const BxRsrc& r, uint64_t off, unsigned size) { r
 #define BX_STORE1S(val, voff, rs, soff) do { uint64_t o_ = (uint64_t)(uint32_t)(voff) + (uint32_t)(soff); float v_ = (val); if (bx_in_range(rs, o_, 4)) memcpy(const_cast<unsigned char*>((rs).base) + o_, &v_, 4); } while (0)
 #define BX_LOAD4(dst, voff, rs) do { uint64_t o_ = (uint32_t)(voff); if (bx_in_range(rs, o_, 16)) memcpy(&(dst), (rs).base + o_, 16); else memset(&(dst), 0, 16); } while (0)
 #define BX_STORE4(val, voff, rs) do { uint64_t o_ = (uint32_t)(voff); bx_u32x4 v_ = (val); if (bx_in_range(rs, o_, 16)) memcpy(const_cast<unsigned char*>((rs).base) + o_, &v_, 16); } while (0)
-#define BX_STORE4S(val, voff, rs, soff) do { uint64_t o_ = (uint64_t)(uint32_t)(voff) + (uint32_t)(soff); bx_u32x4 v_ = (val); if (bx_in_range(rs, o_, 16)) memcpy(const_cast<unsigned char*>((rs).base) + o_, &v_, 16); } while (0)
 #define BX_WAIT(n, reg) ((void)0)
 #define BX_WAIT2(n, r0, r1) ((void)0)
 #define BX_WAIT_PLAIN(n) ((void)0)

@@ -51,7 +51,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 14
+#define PGT_ABI_VERSION 15
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -610,6 +610,12 @@ int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const float* AX, int6
                           const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin, int64_t O,
                           float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, float* ws, int64_t ws_floats,
                           pgt_stream_t stream);
+/* The same adjoint with the four weight / bias gradients ADDED to what dWzr / dbzr / dWh / dbh hold (dH is stored): the cells of a
+ * T-step loop (examples/indexBatching/tgcn/metr_la_main.py:41-45) share their folded operands and sum their gradients in one buffer. */
+int pgt_tgcn_cell_bwd_acc_f32(const float* dHn, int64_t lddhn, const float* AX, int64_t ldax, const float* H, int64_t ldh,
+                              const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin, int64_t O,
+                              float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, float* ws, int64_t ws_floats,
+                              pgt_stream_t stream);
 
 /* The read-out behind a recurrent layer (examples/indexBatching/tgcn/metr_la_main.py:43-45: `self.linear(F.relu(h))`, torch.nn.Linear
  * with 1 .. 4 outputs) as one streaming pass each way over the states X [M, K] (row stride ldx, 16-byte addressable), csrc/readout.hip:

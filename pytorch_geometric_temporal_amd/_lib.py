@@ -172,9 +172,11 @@ PROTOTYPES = {
                                   c_i64, c_ptr]),
     "pgt_tgcn_cell_bwd_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
                                       c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "pgt_tgcn_cell_bwd_acc_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64,
+                                          c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 14
+EXPECTED_ABI = 15
 
 
 class PgtLib:

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
 // element walking all 256 partials in turn was a 61 us launch - a third of the adjoint kernel it follows.)
 __global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __restrict__ part, int n_wg, int n, float* __restrict__ dWzr,
                                                                float* __restrict__ dbzr, float* __restrict__ dWh, float* __restrict__ dbh,
-                                                               int C) {
+                                                               int C, int accumulate) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
@@ -383,10 +383,9 @@ __global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __re
   if (q != 0 || e >= n) return;
   acc = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
   const int nWzr = C * 64, nWh = C * 32;
-  if (e < nWzr) dWzr[e] = acc;
-  else if (e < nWzr + 64) { if (dbzr) dbzr[e - nWzr] = acc; }
-  else if (e < nWzr + 64 + nWh) dWh[e - nWzr - 64] = acc;
-  else if (dbh) dbh[e - nWzr - 64 - nWh] = acc;
+  float* dst = e < nWzr ? dWzr + e : e < nWzr + 64 ? (dbzr ? dbzr + (e - nWzr) : nullptr)
+               : e < nWzr + 64 + nWh ? dWh + (e - nWzr - 64) : (dbh ? dbh + (e - nWzr - 64 - nWh) : nullptr);
+  if (dst) *dst = accumulate ? *dst + acc : acc;           // (accumulate: a T-step loop's cells sum into one buffer, ops.py)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -825,15 +824,16 @@ extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, 
   return pgt_check_launch("pgt_tgcn_cell_f32");
 }
 
-extern "C" int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const float* AX, int64_t ldax, const float* H, int64_t ldh,
-                                     const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin,
-                                     int64_t O, float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, float* ws,
-                                     int64_t ws_floats, pgt_stream_t stream) {
+static int tc_bwd_impl(const float* dHn, int64_t lddhn, const float* AX, int64_t ldax, const float* H, int64_t ldh,
+                       const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin,
+                       int64_t O, float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, int accumulate, float* ws,
+                       int64_t ws_floats, pgt_stream_t stream) {
   PGT_REQUIRE(M >= 0, "pgt_tgcn_cell_bwd_f32: negative size");
   PGT_REQUIRE(pgt_tgcn_cell_fits(Fin, O), "pgt_tgcn_cell_bwd_f32: built for hidden width 32 and 1 .. 30 input columns");
   PGT_REQUIRE(dWzr && dWh, "pgt_tgcn_cell_bwd_f32: null weight gradient");
   const int C = (int)Fin + TC_O, n = C * 96 + 96;
   if (M == 0) {
+    if (accumulate) return PGT_OK;
     if (hipMemsetAsync(dWzr, 0, (size_t)C * 64 * 4, (hipStream_t)stream) != hipSuccess ||
         hipMemsetAsync(dWh, 0, (size_t)C * 32 * 4, (hipStream_t)stream) != hipSuccess ||
         (dbzr && hipMemsetAsync(dbzr, 0, 64 * 4, (hipStream_t)stream) != hipSuccess) ||
@@ -856,6 +856,21 @@ extern "C" int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const floa
   g.n_wg = wgs;
   if (rows) PGT_LAUNCH(tgcn_cell_bwd_rows_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
   else PGT_LAUNCH(tgcn_cell_bwd_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
-  PGT_LAUNCH(tgcn_cell_reduce_kernel, dim3((unsigned)pgt_cdiv(n, 64)), dim3(256), stream, ws, wgs, n, dWzr, dbzr, dWh, dbh, C);
+  PGT_LAUNCH(tgcn_cell_reduce_kernel, dim3((unsigned)pgt_cdiv(n, 64)), dim3(256), stream, ws, wgs, n, dWzr, dbzr, dWh, dbh, C,
+             accumulate);
   return pgt_check_launch("pgt_tgcn_cell_bwd_f32");
+}
+
+extern "C" int pgt_tgcn_cell_bwd_f32(const float* dHn, int64_t lddhn, const float* AX, int64_t ldax, const float* H, int64_t ldh,
+                                     const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin,
+                                     int64_t O, float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, float* ws,
+                                     int64_t ws_floats, pgt_stream_t stream) {
+  return tc_bwd_impl(dHn, lddhn, AX, ldax, H, ldh, ZR, HT, Wzr, Wh, M, Fin, O, dH, lddh, dWzr, dbzr, dWh, dbh, 0, ws, ws_floats, stream);
+}
+
+extern "C" int pgt_tgcn_cell_bwd_acc_f32(const float* dHn, int64_t lddhn, const float* AX, int64_t ldax, const float* H, int64_t ldh,
+                                         const float* ZR, const float* HT, const float* Wzr, const float* Wh, int64_t M, int64_t Fin,
+                                         int64_t O, float* dH, int64_t lddh, float* dWzr, float* dbzr, float* dWh, float* dbh, float* ws,
+                                         int64_t ws_floats, pgt_stream_t stream) {
+  return tc_bwd_impl(dHn, lddhn, AX, ldax, H, ldh, ZR, HT, Wzr, Wh, M, Fin, O, dH, lddh, dWzr, dbzr, dWh, dbh, 1, ws, ws_floats, stream);
 }

@@ -1594,6 +1594,31 @@ def readout(x, weight, bias, relu):
 
 # --------------------------------------------------------------------------------------------- T-GCN cell
 
+class _PackDeposit:
+    """Where the fused T-GCN cells that share one set of folded operands (nn/_states.py packed_once) sum their weight / bias
+    gradients: one [dWzr | dWh | dbzr | dbh] buffer the adjoint kernels ACCUMULATE into (pgt_tgcn_cell_bwd_acc_f32).  Every cell
+    returns None for the four operands to autograd — except the first one to run, which hands out the buffer's dbh slice: one
+    defined gradient is what makes the engine call TGCNWeightsFunction.backward once all the cells have run, and that is where the
+    sums are taken from (`take`).  Cells that did not run (a loss that does not reach them) simply never deposited."""
+
+    def __init__(self):
+        self.buf, self.views = None, None
+
+    def slot(self, C, O, device):
+        """(views dWzr, dbzr, dWh, dbh of the buffer, first): `first` = nothing deposited yet (the kernel stores)."""
+        first = self.buf is None
+        if first:
+            self.buf = torch.empty(C * 3 * O + 3 * O, dtype=F32, device=device)
+            b = self.buf
+            self.views = (b[:C * 2 * O].view(C, 2 * O), b[C * 3 * O:C * 3 * O + 2 * O], b[C * 2 * O:C * 3 * O].view(C, O),
+                          b[C * 3 * O + 2 * O:])
+        return self.views, first
+
+    def take(self):
+        v, self.buf, self.views = self.views, None, None
+        return v
+
+
 class TGCNWeightsFunction(torch.autograd.Function):
     """The module's parameters -> the operands of the two gate products of the fused cell (csrc/tgcn.hip):
     conv_{z,r,h}.lin.weight [O, Fin], conv_{z,r,h}.bias, linear_{z,r,h}.weight [O, 2O], linear_{z,r,h}.bias
@@ -1638,6 +1663,11 @@ class TGCNWeightsFunction(torch.autograd.Function):
         # o1 = m(x1); o2 = m(x2); o1.backward(); o2.backward()), and autograd frees saved tensors after the first walk.  Inputs
         # held by their own node form no reference cycle; the in-place check save_for_backward would have made is done by hand.
         ctx.kept = (Wc, L, bc)
+        # the cells fed by these operands sum their weight / bias gradients into ONE buffer (TGCNCellFunction.backward) instead of
+        # handing autograd four small tensors per cell to add up (44 five-microsecond adds per T = 12 step): see _PackDeposit
+        ctx.deposit = _PackDeposit()
+        Wzr._pgt_deposit = ctx.deposit
+        ctx.set_materialize_grads(False)
         ctx.versions = tuple(tensor_version(t) for t in params if t is not None)
         ctx.kept_sources = tuple(t for t in params if t is not None)
         ctx.bias_mask = tuple(t is not None for t in bc)
@@ -1652,6 +1682,14 @@ class TGCNWeightsFunction(torch.autograd.Function):
             raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
                                "a T-GCN parameter changed between the forward pass and this backward pass")
         Wc, L, bc = ctx.kept
+        dep = ctx.deposit.take()
+        if dep is not None:                                   # what the fused cells summed among themselves (+ anything autograd brought)
+            dWzr = dep[0] if dWzr is None else dWzr + dep[0]
+            dbzr = dep[1] if dbzr is None else dbzr + dep[1]
+            dWh = dep[2] if dWh is None else dWh + dep[2]
+            dbh = dep[3]                                      # (the incoming dbh IS the deposit's slice: the first cell handed it out)
+        if dWzr is None and dbzr is None and dWh is None and dbh is None:
+            return (None,) * 12
         Fin, O = ctx.dims
         dev = Wc[0].device
         C = Fin + O
@@ -1714,6 +1752,7 @@ class TGCNCellFunction(torch.autograd.Function):
                 "pgt_tgcn_cell_f32", ptr(AX), Fin, hp, ldh, ptr(Wzr_c), ptr(bzr), ptr(Wh_c), ptr(bh), M, Fin, O, ptr(ZR), ptr(HT),
                 ptr(Hn), O, stream_of(lib, Hn)), tag=("fwd", M, Fin, O))
             ctx.fused = True
+            ctx.deposit = getattr(Wzr, "_pgt_deposit", None) if (Wzr.requires_grad and bzr is not None and bh is not None) else None
             ctx.save_for_backward(AX, Hs, ZR, HT, Wzr_c, Wh_c)
             return Hn
         XH = torch.empty(M, C, dtype=F32, device=dev)          # [AX | H]
@@ -1765,14 +1804,24 @@ class TGCNCellFunction(torch.autograd.Function):
                 gp, ldg = _rows(dHn, "dHn")
                 hp, ldh = _rows(Hs, "H")
                 dH = torch.empty(M, O, dtype=F32, device=dev)
-                buf = torch.empty(C * 3 * O + 3 * O, dtype=F32, device=dev)
-                dWzr, dWh = buf[:C * 2 * O].view(C, 2 * O), buf[C * 2 * O:C * 3 * O].view(C, O)
-                dbzr, dbh = buf[C * 3 * O:C * 3 * O + 2 * O], buf[C * 3 * O + 2 * O:]
+                dep = ctx.deposit if all(need[2:6]) else None
+                if dep is not None:
+                    (dWzr, dbzr, dWh, dbh), first = dep.slot(C, O, dev)
+                    entry = "pgt_tgcn_cell_bwd_f32" if first else "pgt_tgcn_cell_bwd_acc_f32"
+                else:
+                    buf = torch.empty(C * 3 * O + 3 * O, dtype=F32, device=dev)
+                    dWzr, dWh = buf[:C * 2 * O].view(C, 2 * O), buf[C * 2 * O:C * 3 * O].view(C, O)
+                    dbzr, dbh = buf[C * 3 * O:C * 3 * O + 2 * O], buf[C * 3 * O + 2 * O:]
+                    entry, first = "pgt_tgcn_cell_bwd_f32", True
                 nws = int(lib._pgt_tgcn_cell_bwd_ws_floats(Fin, O))
                 ws = _det_workspace(dev, nws)
                 _timed("tgcn_cell", 4.0 * M * (Fin + 6 * O) if KERNEL_TIMER else 0, lambda: lib.call(
-                    "pgt_tgcn_cell_bwd_f32", gp, ldg, ptr(AX), Fin, hp, ldh, ptr(ZR), ptr(HT), ptr(Wzr_c), ptr(Wh_c), M, Fin, O,
+                    entry, gp, ldg, ptr(AX), Fin, hp, ldh, ptr(ZR), ptr(HT), ptr(Wzr_c), ptr(Wh_c), M, Fin, O,
                     ptr(dH), O, ptr(dWzr), ptr(dbzr), ptr(dWh), ptr(dbh), ptr(ws), nws, stream_of(lib, dH)), tag=("bwd", M, Fin, O))
+                if dep is not None:
+                    # summed in the deposit; the first cell's dbh (a slice of it) is the one defined gradient that brings autograd to
+                    # TGCNWeightsFunction.backward, which reads the deposit
+                    return None, (dH if need[1] else None), None, None, None, (dbh if first else None), None, None, None
                 return None, (dH if need[1] else None), dWzr, dbzr, dWh, dbh, None, None, None
             # the input gradient is wanted: rebuild the unfused operands ([AX | H], [AX | H * R]) and run the general adjoint
             XH = torch.empty(M, C, dtype=F32, device=dev)

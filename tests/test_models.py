@@ -1126,6 +1126,68 @@ def test_cell_operands_are_packed_once_per_training_step(backend):
         lib.call = orig
 
 
+def test_cells_of_one_loop_sum_their_weight_gradients_in_one_buffer(backend):
+    """A T-step loop over the fused T-GCN cell (hidden 32): the cells hand autograd no weight gradients of their own — they
+    accumulate into one deposit that TGCNWeightsFunction.backward reads (ops._PackDeposit).  Equal to per-cell packing: with every
+    cell in the loss, with a loss that reaches only the first two states (the later cells never run backward), and twice through
+    one graph (retain_graph)."""
+    from pytorch_geometric_temporal_amd import _lib
+    from pytorch_geometric_temporal_amd.nn import _states
+    import importlib
+    torch.manual_seed(21)
+    n, B = 19, 2
+    ei_np, ew_np = syn.sensor_graph(n, 90, seed=4, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    cell = TGCN2(2, 32, 1).to(backend.device)
+    xs = [backend.t(torch.randn(B, n, 2)) for _ in range(4)]
+
+    class Seq(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cell = cell
+
+        def forward(self, upto):
+            h, tot = None, 0
+            for t, x in enumerate(xs):
+                h = self.cell(x, ei, ew, h)
+                if t < upto:
+                    tot = tot + h.square().mean() * (t + 1)
+            return tot
+    model = Seq()
+    lib = _lib.get_lib()
+    counts = {}
+    orig = lib.call
+    lib.call = lambda name, *a: (counts.__setitem__(name, counts.get(name, 0) + 1), orig(name, *a))[1]
+    try:
+        res = {}
+        for upto in (4, 2):
+            counts.clear()
+            model.zero_grad()
+            loss = model(upto)
+            loss.backward(retain_graph=True)
+            got = {k: p.grad.clone() for k, p in model.named_parameters()}
+            assert counts["pgt_tgcn_cell_bwd_f32"] == 1 and counts.get("pgt_tgcn_cell_bwd_acc_f32", 0) == upto - 1, counts
+            model.zero_grad()
+            loss.backward()                                    # the same graph again: deposited and taken again
+            for k, p in model.named_parameters():
+                assert_close_with_nonfinite(p.grad, got[k], 1e-6 + 1e-6 * float(got[k].abs().max()), 1e-6, f"second walk {k}")
+            res[upto] = got
+        saved = _states.packed_once
+        per_call = lambda module, params, build, repack=None: build()
+        mod = importlib.import_module("pytorch_geometric_temporal_amd.nn.recurrent.temporalgcn")
+        mod.packed_once = per_call
+        try:
+            for upto in (4, 2):
+                model.zero_grad()
+                model(upto).backward()
+                for k, p in model.named_parameters():
+                    assert_close_with_nonfinite(res[upto][k], p.grad, 1e-6 + 2e-5 * float(p.grad.abs().max()), 1e-5, f"{k}, loss on {upto} states")
+        finally:
+            mod.packed_once = saved
+    finally:
+        lib.call = orig
+
+
 @pytest.mark.parametrize("kind", ["tgcn", "tgcn2", "dcrnn"])
 def test_two_forwards_then_two_backwards_and_data_writes_between_forwards(backend, kind):
     """Round 4's advisor cases on the shared pack: (a) o1 = m(x1); o2 = m(x2); o1.sum().backward(); o2.sum().backward() works as

@@ -160,6 +160,8 @@ def compact_other(extra):
         for name in ("batch_per_gpu",):
             if name in v:
                 e[name] = v[name]
+        if isinstance(v.get("graphed"), dict) and "ms_per_step" in v["graphed"]:
+            e["graphed_ms"] = _r(v["graphed"]["ms_per_step"], 4)      # the same step as two hipGraphs (eager is host-launch bound)
         for name, sub in v.items():                       # nested measurements of the same block at another batch size
             if isinstance(sub, dict) and "batch_per_gpu" in sub and "ms_per_step" in sub:
                 e[_s(name, 28)] = {"batch_per_gpu": sub["batch_per_gpu"], "ms": _r(sub["ms_per_step"], 4)}

@@ -31,6 +31,8 @@ def klass(name):
         return "tgcn_cell_fwd"
     if "tgcn_cell_bwd" in name:
         return "tgcn_cell_bwd"
+    if "relu_linear" in name:
+        return "readout"
     if "tconv_glu" in name:
         return "tconv"
     if "seq_small" in name:

@@ -13,6 +13,7 @@ from hypothesis import HealthCheck, given, settings, strategies as hst     # noq
 
 pytestmark = pytest.mark.skipif(not R.reference_available(), reason="reference checkout not mounted")
 FUZZ = settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+FUZZ_HEAVY = settings(max_examples=24, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)   # five models per example
 TOL = dict(atol=3e-5, rtol=3e-5)
 
 
@@ -218,7 +219,7 @@ def test_gradients_of_cells_against_reference_autograd(emu_backend, data, K, wei
             _grads_match(ref, our, name)
 
 
-@FUZZ
+@FUZZ_HEAVY
 @given(data=hst.data(), K=hst.integers(1, 3), B=hst.integers(1, 3))
 def test_gradients_of_batched_models_against_reference_autograd(emu_backend, data, K, B):
     """BatchedDCRNN (hand-written BPTT over T steps), TGCN2, A3TGCN2, STConv and ASTGCN: parameter and input gradients

@@ -1,7 +1,17 @@
-# same-box A/B of the split-bf16 kernels inside the bench (PGT_TUNE switches, see include/pgt_hip.h: pgt_tune)
-for t in ${BX_AB:-"gemm_bx=1" "gemm_bx=0" "gemm_bx=1"}; do
-  PGT_TUNE="$t" python bench.py --no-extra --no-cpu-baseline > gpurun_out/ab.json 2>gpurun_out/ab.err || tail -3 gpurun_out/ab.err
-  python -c "
-import json;d=json.load(open('gpurun_out/ab.json'));k=d['kernels']
-print('$t', round(d['ms_per_step'],3), 'gemm', round(k['gemm']['total_ms'],2), 'tn', round(k['gemm_tn']['total_ms'],2), 'stack', round(k['stack']['total_ms'],2), ' '.join(s['shape'][0]+str(s['shape'][2])+'/'+str(s['shape'][4])+':'+str(round(s['avg_us'],1)) for s in k['gemm']['by_shape'][:6]))"
+#!/bin/bash
+# A/B of a pgt_tune switch inside the headline step: alternating runs on one box, per-shape product times.
+#   scripts/bx_ab.sh gemm_bx_sym2 "1 0 1 0"
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"
+KEY=${1:-gemm_bx_sym2}
+for v in ${2:-1 0 1 0}; do
+  echo "$KEY=$v"
+  PGT_TUNE=$KEY=$v python bench.py --no-extra --no-cpu-baseline --no-ns 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  ms_per_step', d['ms_per_step'], d['roofline']['all_kernel_classes']['classes_ms_frac'])"
+  python - <<'P'
+import json
+d=json.load(open('gpurun_out/bench_full.json'))
+for s in d['kernels']['gemm']['by_shape']: print('   ', s['shape'], round(s['avg_us'],1), round(s['hbm_frac'],3))
+P
 done

@@ -33,7 +33,6 @@ namespace {
 
 int g_bx = 1;   // pgt_tune("gemm_bx"): 1 = where it applies (>= 8192 rows), 2 = at any size (tests), 0 = never
 int g_bx_sym = 1;   // pgt_tune("gemm_bx_sym"): 0 = short-K products on the K-split kernel instead of the symmetric one (A/B)
-int g_bx_sym2 = 1;  // pgt_tune("gemm_bx_sym2"): 0 = the symmetric kernel as ONE 512-thread workgroup per CU (A/B); 2 = split at any size (tests)
 
 // ---- platform layer: the handful of operations below are hand-written gfx950 instructions.  The CPU test double compiles
 // the SAME kernel bodies against tests/hipemu/pgt_bx_platform_emu.h, which spells these operations in plain C++ (fibers,
@@ -845,34 +844,21 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
 // EPT - 1 loads + the 16 stores of the previous block.  Column blocks 8 and 9 (N = 320 = five 64-wide stack segments:
 // one product reads dP once instead of a 256-column product plus a 64-column remainder) go to wavefronts 0 and 1 as a
 // second block whose B fragments wait in LDS in operand order.
-//
-// NW = 8: one 512-thread workgroup per CU owns all the column blocks (round 2).  NW = 4 (round 5): TWO 256-thread workgroups per CU,
-// each with half of the column blocks (five of ten at 320 columns: wavefront 0 takes the fifth as its second block) and its own
-// A buffers — a workgroup's load / convert, MFMA and store phases run in turn behind its one barrier per block (4.9 us per block
-// against 1.9 us of MFMAs on the busiest SIMD + 2.3 us of traffic, notebook 5.5); two independent workgroups overlap them.  The two
-// halves of a row block are workgroups b and b + 8 (the same XCD: the second read of the block's A rows is an L2 hit).
-template <int KSTEPS, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_bx_sym_kernel(PgtGemmArgs g, int n_blocks) {
-  constexpr int THREADS = 64 * NW, TPR = THREADS / 32;    // threads per row of the A block
+template <int KSTEPS>
+__global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int n_blocks) {
   constexpr int BM = 32, KP = KSTEPS * 16, SROW = KP * 2 + 16, PLANE = BM * SROW, BUF = 3 * PLANE;
-  constexpr int EPT = (KP / 2) / TPR;                     // float pairs per thread and block
+  constexpr int EPT = (KP / 2) / 16;                      // float pairs per thread and block (16 threads per row)
   constexpr int B2 = KSTEPS * 3 * 64 * 16;                // one extra column block's B fragments, operand order
-  constexpr int NB2 = NW == 8 ? 2 : 1;                    // wavefronts with a second block
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + NB2 * B2];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 2 * B2];
   const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
   const int wave = BX_SGPR(tid >> 6);
+  const int nwg = gridDim.x;
   const int Ktot = g.n_seg * g.seg_k;
-  // column blocks of this workgroup: [cb0, cb1); NW = 4: workgroup = (row stream, column half), halves on blockIdx bit 3
-  const int n_cb = (g.N + 31) >> 5, cb_half = (n_cb + 1) >> 1;
-  const int half_id = NW == 8 ? 0 : (((int)blockIdx.x >> 3) & 1);
-  const int cb0 = NW == 8 ? 0 : half_id * cb_half, cb1 = NW == 8 ? n_cb : (half_id ? n_cb : cb_half);
-  const int nwg = NW == 8 ? (int)gridDim.x : (int)gridDim.x >> 1;                                     // row streams
-  const int stream_id = NW == 8 ? (int)blockIdx.x : (((int)blockIdx.x & 7) | (((int)blockIdx.x >> 4) << 3));
-  const int col = (cb0 + wave) * 32 + lo;
-  const bool live = cb0 + wave < cb1;
-  const bool two = wave < NB2 && cb0 + NW + wave < cb1;    // this wavefront owns a second column block
-  const int col2 = (cb0 + NW + wave) * 32 + lo;
-  bx_u32x4* const b2 = reinterpret_cast<bx_u32x4*>(lds + 2 * BUF + (wave < NB2 ? wave : 0) * B2);
+  const int col = wave * 32 + lo;
+  const bool live = wave * 32 < g.N;
+  const bool two = (wave + 8) * 32 < g.N;                  // this wavefront owns a second column block (wave + 8)
+  const int col2 = (wave + 8) * 32 + lo;
+  bx_u32x4* const b2 = reinterpret_cast<bx_u32x4*>(lds + 2 * BUF + (wave & 1) * B2);
   bx_u32x4 bf[KSTEPS][3];
 #pragma unroll
   for (int i = 0; i < KSTEPS; ++i) {
@@ -881,7 +867,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_bx_sym_kernel(P
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int k = k0 + t;
-      v[t] = (k < Ktot && live && col < g.N) ? g.Bw[(int64_t)k * g.sbk + (int64_t)col * g.sbn] : 0.f;
+      v[t] = (k < Ktot && col < g.N) ? g.Bw[(int64_t)k * g.sbk + (int64_t)col * g.sbn] : 0.f;
     }
     uint32_t p[3][4];
 #pragma unroll
@@ -889,7 +875,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_bx_sym_kernel(P
 #pragma unroll
     for (int q = 0; q < 3; ++q) { bx_u32x4 f = {p[q][0], p[q][1], p[q][2], p[q][3]}; bf[i][q] = f; }
   }
-  for (int i = tid; i < 2 * BUF / 16; i += THREADS) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 2 * BUF / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
   if (two) {
 #pragma unroll
     for (int i = 0; i < KSTEPS; ++i) {
@@ -907,16 +893,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_bx_sym_kernel(P
       for (int q = 0; q < 3; ++q) { bx_u32x4 f = {p[q][0], p[q][1], p[q][2], p[q][3]}; b2[(i * 3 + q) * 64 + lane] = f; }
     }
   }
-  int rb = stream_id;
+  int rb = blockIdx.x;
   if (rb >= n_blocks) return;
   __syncthreads();
-  // ---- element map: row = tid / TPR, pairs (tid % TPR) + TPR t
-  const int erow = tid / TPR, el = tid % TPR;
+  // ---- element map: row = tid / 16, pairs (tid % 16) + 16 t
+  const int erow = tid >> 4, el = tid & 15;
   const int half = g.seg_k >> 1, rpairs = g.n_seg * half;
   uint32_t goff[EPT];
 #pragma unroll
   for (int t = 0; t < EPT; ++t) {
-    const int pi = el + TPR * t, seg = pi / half, pp = pi - seg * half;
+    const int pi = el + 16 * t, seg = pi / half, pp = pi - seg * half;
     goff[t] = pi < rpairs ? (uint32_t)((seg * g.a_seg_stride + erow * g.lda + 2 * pp) * 4) : 0xfffffff0u;
   }
   const uint32_t lbase = (uint32_t)(erow * SROW + el * 4);
@@ -930,13 +916,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_bx_sym_kernel(P
     return rsrc(g.A + (int64_t)(rows_left > 0 ? b : 0) * BM * g.lda, rows_left > 0 ? span_last + (rows - 1) * g.lda * 4 + (int64_t)g.seg_k * 4 : 0);
   };
   // the wavefront's output block: column segment js of C (c_seg_n is a multiple of 32), rows of block b
-  const int c0 = (cb0 + wave) * 32, c2 = (cb0 + NW + wave) * 32;
-  const int js = c0 / g.c_seg_n;
-  const float* cbase = g.C + (int64_t)js * g.c_seg_stride + (c0 - js * g.c_seg_n);
-  const uint32_t cvoff = (live && col < g.N) ? (uint32_t)((4 * hi * g.ldc + lo) * 4) : 0xfffffff0u;
-  const int js2 = c2 / g.c_seg_n;
-  const float* cbase2 = g.C + (int64_t)js2 * g.c_seg_stride + (c2 - js2 * g.c_seg_n);
-  const uint32_t cvoff2 = (two && col2 < g.N) ? (uint32_t)((4 * hi * g.ldc + lo) * 4) : 0xfffffff0u;
+  const int js = (wave * 32) / g.c_seg_n;
+  const float* cbase = g.C + (int64_t)js * g.c_seg_stride + (wave * 32 - js * g.c_seg_n);
+  const uint32_t cvoff = col < g.N ? (uint32_t)((4 * hi * g.ldc + lo) * 4) : 0xfffffff0u;
+  const int js2 = ((wave + 8) * 32) / g.c_seg_n;
+  const float* cbase2 = g.C + (int64_t)js2 * g.c_seg_stride + ((wave + 8) * 32 - js2 * g.c_seg_n);
+  const uint32_t cvoff2 = col2 < g.N ? (uint32_t)((4 * hi * g.ldc + lo) * 4) : 0xfffffff0u;
   auto c_rsrc = [&](const float* cb_, int b) {
     const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
     const int64_t rows = rows_left < BM ? rows_left : BM;
@@ -955,7 +940,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_bx_sym_kernel(P
     BX_WAIT(EPT - 1, raw[t]);
     uint32_t p1, p2, p3;
     bx_split2_fast(bx_as_float(raw[t][0]), bx_as_float(raw[t][1]), p1, p2, p3);
-    unsigned char* d = buf + lbase + 4 * TPR * t;
+    unsigned char* d = buf + lbase + 64 * t;
     *reinterpret_cast<uint32_t*>(d) = p1;
     *reinterpret_cast<uint32_t*>(d + PLANE) = p2;
     *reinterpret_cast<uint32_t*>(d + 2 * PLANE) = p3;
@@ -970,8 +955,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gemm_bx_sym_kernel(P
       issue_load(t, r1);
     }
   }
-  const float bias_r = (g.bias && live && col < g.N) ? g.bias[col] : 0.f;
-  const float bias_r2 = (g.bias && two && col2 < g.N) ? g.bias[col2] : 0.f;
+  const float bias_r = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+  const float bias_r2 = (g.bias && col2 < g.N) ? g.bias[col2] : 0.f;
   BX_WAIT_PLAIN(EPT);      // the B / bias loads above are older than the EPT block loads
   bx_barrier();
   int cur = 0;
@@ -1066,7 +1051,6 @@ int bx_device_cus() {
 
 void pgt_gemm_bx_set(int v) { g_bx = v; }
 void pgt_gemm_bx_sym_set(int v) { g_bx_sym = v; }
-void pgt_gemm_bx_sym2_set(int v) { g_bx_sym2 = v; }
 
 int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (!g_bx) return 0;
@@ -1120,18 +1104,8 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   dim3 grid((unsigned)wgs), block(512);
 #define PGT_BX_GO(KS_, WN_, EPI_, Q4_) PGT_LAUNCH((gemm_bx_kernel<KS_, WN_, EPI_, Q4_>), grid, block, stream, g, n_blocks)
   if (sym_ok) {
-    // two 256-thread workgroups per CU (column halves) when there are row blocks enough for every stream; pgt_tune("gemm_bx_sym2", 0):
-    // the one 512-thread workgroup of round 2
-    const bool split = g_bx_sym2 == 2 || (g_bx_sym2 && g.N > 128 && n_blocks >= 2 * wgs && wgs % 8 == 0);
-    if (split) {
-      const int streams = g_bx_sym2 == 2 ? 8 : wgs;        // (2: tests — eight row streams whatever the size)
-      dim3 grid2((unsigned)(2 * streams)), block2(256);
-      if (K > 64) PGT_LAUNCH((gemm_bx_sym_kernel<8, 4>), grid2, block2, stream, g, n_blocks);
-      else PGT_LAUNCH((gemm_bx_sym_kernel<4, 4>), grid2, block2, stream, g, n_blocks);
-    } else {
-      if (K > 64) PGT_LAUNCH((gemm_bx_sym_kernel<8, 8>), grid, block, stream, g, n_blocks);
-      else PGT_LAUNCH((gemm_bx_sym_kernel<4, 8>), grid, block, stream, g, n_blocks);
-    }
+    if (K > 64) PGT_LAUNCH((gemm_bx_sym_kernel<8>), grid, block, stream, g, n_blocks);
+    else PGT_LAUNCH((gemm_bx_sym_kernel<4>), grid, block, stream, g, n_blocks);
   } else if (K > 128 && g.N <= 64) {                         // two column blocks: K cut four ways
     if (g.epi == 1) PGT_BX_GO(21, 1, 1, true);
     else if (g.epi == 2) PGT_BX_GO(21, 1, 2, true);

@@ -1366,31 +1366,6 @@ def test_gemm_split_bf16_gate_epilogues_and_weight_gradient_with_non_finite_oper
         assert_close_with_nonfinite(a, b, tol, tol, name)
 
 
-@pytest.mark.parametrize("M,segk,N", [(6100, 128, 320), (2049, 64, 320), (7000, 128, 256), (2500, 64, 256), (900, 100, 192),
-                                      (333, 128, 192), (70, 64, 320), (1, 128, 320)])
-def test_gemm_split_bf16_symmetric_kernel_as_two_workgroups_per_cu(backend, M, segk, N):
-    """gemm_bx_sym_kernel<K, 4> (two 256-thread workgroups per CU, each with half of the column blocks and its own A buffers;
-    pgt_tune("gemm_bx_sym2")) computes every element with the same operations in the same order as the one-workgroup form: bit
-    for bit the same result — odd column-block counts, second blocks, ragged row blocks, row streams without a block."""
-    lib = _lib.get_lib()
-    dev = backend.device
-    if backend.name == "emu":
-        M = min(M, 70 + M % 97)
-    A, B, bias, ref = _bx_case(M, 1, segk, N, True, seed=M + N)
-    try:
-        lib.tune("gemm_bx", 2)
-        lib.tune("gemm_bx_sym2", 0)
-        C_one = _bx_run(A, B, bias, M, 1, segk, N, True, dev).cpu()
-        lib.tune("gemm_bx_sym2", 2)
-        C_two = _bx_run(A, B, bias, M, 1, segk, N, True, dev).cpu()
-    finally:
-        lib.tune("gemm_bx", 1)
-        lib.tune("gemm_bx_sym2", 1)
-    assert torch.isfinite(C_two).all()
-    assert torch.equal(C_one, C_two)
-    assert float((C_two.double() - ref).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1.0)
-
-
 def test_gemm_split_bf16_fuzz_shapes_on_the_test_double(emu_backend):
     """Seeded sweep over shapes around every routing boundary of gemm_bx.hip (K buckets 64 / 128 / 336, one / two / three
     column-block layouts, 256 / 320 columns, odd row counts, segmented inputs and outputs, with and without bias), the

@@ -356,16 +356,16 @@ __global__ __launch_bounds__(256) void tgcn_cell_bwd_kernel(TcArgs g) {
   }
 }
 
-// out[e] = sum over the workgroups' partials, in a FIXED order: a workgroup owns 64 elements, its four wavefronts each add a
-// contiguous quarter of the partials (eight loads in flight per lane), the quarters meet in LDS in index order.  (One thread per
-// element walking all 256 partials in turn was a 61 us launch - a third of the adjoint kernel it follows.)
-__global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __restrict__ part, int n_wg, int n, float* __restrict__ dWzr,
+// out[e] = sum over the workgroups' partials, in a FIXED order: a workgroup of sixteen wavefronts owns 64 elements, every wavefront
+// adds a contiguous sixteenth of the partials (eight loads in flight per lane), the sixteenths meet in LDS in index order.  (One
+// thread per element walking all 256 partials in turn was a 61 us launch; four wavefronts per 64 elements 8.6 us at 512 partials.)
+__global__ __launch_bounds__(1024) void tgcn_cell_reduce_kernel(const float* __restrict__ part, int n_wg, int n, float* __restrict__ dWzr,
                                                                float* __restrict__ dbzr, float* __restrict__ dWh, float* __restrict__ dbh,
                                                                int C, int accumulate) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][64];        // sixteen wavefronts, a contiguous sixteenth of the partials each
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
-  const int per = (n_wg + 3) / 4, w0 = q * per, w1 = (w0 + per < n_wg) ? w0 + per : n_wg;
+  const int per = (n_wg + 15) / 16, w0 = q * per, w1 = (w0 + per < n_wg) ? w0 + per : n_wg;
   float acc = 0.f;
   if (e < n) {
     int w = w0;
@@ -381,7 +381,9 @@ __global__ __launch_bounds__(256) void tgcn_cell_reduce_kernel(const float* __re
   red[q][lane] = acc;
   __syncthreads();
   if (q != 0 || e >= n) return;
-  acc = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  acc = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) acc += red[w][lane];          // in index order: the same sum launch after launch
   const int nWzr = C * 64, nWh = C * 32;
   float* dst = e < nWzr ? dWzr + e : e < nWzr + 64 ? (dbzr ? dbzr + (e - nWzr) : nullptr)
                : e < nWzr + 64 + nWh ? dWh + (e - nWzr - 64) : (dbh ? dbh + (e - nWzr - 64 - nWh) : nullptr);
@@ -856,7 +858,7 @@ static int tc_bwd_impl(const float* dHn, int64_t lddhn, const float* AX, int64_t
   g.n_wg = wgs;
   if (rows) PGT_LAUNCH(tgcn_cell_bwd_rows_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
   else PGT_LAUNCH(tgcn_cell_bwd_kernel, dim3((unsigned)wgs), dim3(256), stream, g);
-  PGT_LAUNCH(tgcn_cell_reduce_kernel, dim3((unsigned)pgt_cdiv(n, 64)), dim3(256), stream, ws, wgs, n, dWzr, dbzr, dWh, dbh, C,
+  PGT_LAUNCH(tgcn_cell_reduce_kernel, dim3((unsigned)pgt_cdiv(n, 64)), dim3(1024), stream, ws, wgs, n, dWzr, dbzr, dWh, dbh, C,
              accumulate);
   return pgt_check_launch("pgt_tgcn_cell_bwd_f32");
 }

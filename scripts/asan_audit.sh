@@ -14,10 +14,11 @@ set -e
 cd "$(dirname "$0")/.."
 MODE=${1:-asan}
 case "$MODE" in asan|ubsan|order) shift || true ;; *) MODE=asan ;; esac
+if [ $# -gt 0 ]; then ARGS=("$@"); else ARGS=(tests/test_kernels.py tests/test_dcrnn.py tests/test_models.py tests/test_edge_cases.py); fi
 if [ "$MODE" = order ]; then
   for o in reverse rotate; do
     echo "== wavefront order: $o"
-    PGT_EMU_ORDER=$o python -m pytest ${@:-tests/test_kernels.py tests/test_dcrnn.py tests/test_models.py tests/test_edge_cases.py} -x -q -m "not gpu"
+    PGT_EMU_ORDER=$o python -m pytest "${ARGS[@]}" -x -q -m "not gpu"
   done
   exit 0
 fi
@@ -34,4 +35,4 @@ g++ -std=c++17 -O1 -g $SAN -fno-omit-frame-pointer -fPIC -shared -x c++ -DPGT_EM
     -I tests/hipemu -I include -I pytorch_geometric_temporal_amd/csrc pytorch_geometric_temporal_amd/csrc/*.hip \
     -o "$OUT/libpgt_emu.so"
 LD_PRELOAD=$RT PGT_EMU_LIB="$OUT/libpgt_emu.so" \
-python -m pytest ${@:-tests/test_kernels.py tests/test_dcrnn.py tests/test_models.py tests/test_edge_cases.py} -x -q -m "not gpu"
+python -m pytest "${ARGS[@]}" -x -q -m "not gpu"

@@ -25,9 +25,10 @@ root, tag = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(f"{root}/{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
-        if "tgcn" not in k and "spmm" not in k and "gemm" not in k and "dconv" not in k:
+        name = r["Kernel_Name"]
+        if not any(t in name for t in ("tgcn", "spmm", "gemm", "dconv", "relu_linear", "gru_")):
             continue
+        k = name.replace("(anonymous namespace)::", "").replace("void ", "")[:70]
         a = acc[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 out = open(f"{root}/{tag}_pmc_summary.csv", "w")

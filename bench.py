@@ -138,13 +138,23 @@ def kernel_class_rooflines(kernels, shapes):
                               "algorithmic_MB": gemm_operand_bytes(r["tag"][1:]) / 1e6,
                               "achieved_GBs": gemm_operand_bytes(r["tag"][1:]) / (r["avg_us"] * 1e-6) / 1e9,
                               "hbm_frac": gemm_operand_bytes(r["tag"][1:]) / (r["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              "fp32_product_TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12}
+                              "fp32_product_TFLOPs": r["work_per_launch"] / (r["avg_us"] * 1e-6) / 1e12,
+                              **({"set_aside_launches": r["set_aside_launches"], "set_aside_ms": r["set_aside_ms"]}
+                                 if "set_aside_launches" in r else {})}
                              for r in recs]
         else:
             v["algorithmic_bytes_per_launch"] = v["work_per_launch"]
             v["achieved_GBs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
             v["hbm_frac"] = v["achieved_GBs"] / HBM_PEAK_GBS
     return kernels
+
+
+def set_aside(roof, kernels):
+    """Launches KernelTimer set aside as host stalls (ops.KernelTimer: more than 10x the median of their shape), said on the line."""
+    n = sum(v.get("set_aside_launches", 0) for v in kernels.values())
+    if n:
+        roof["set_aside"] = {"launches": n, "ms": sum(v.get("set_aside_ms", 0.0) for v in kernels.values()),
+                             "rule": "event-pair time over 10x the median of the same shape = a host stall inside the pair; not in any average"}
 
 
 def all_kernel_classes(kernels, profile_steps):
@@ -724,6 +734,7 @@ def main():
                 "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
                 "avg_us_per_launch": k["avg_us"], "launches_per_step": k["launches"] / args.profile_steps,
                 "share_of_step_ms": k["total_ms"] / args.profile_steps}
+        set_aside(roof, kernels)
         if dom in ("gemm", "gemm_tn"):
             roof["bf16_pipe_frac"] = k["bf16_pipe_frac"]
             roof["fp32_product_TFLOPs"] = k["fp32_product_TFLOPs"]
@@ -873,7 +884,8 @@ def main():
             "variants": variants, "other_configs": extra,
         }
         import bench_line
-        text = bench_line.emit(line)                           # complete record -> gpurun_out/bench_full.json + stderr; ONE short line on stdout
+        partial = args.no_extra or args.no_cpu_baseline or args.profile_steps == 0      # a profiler pass must not overwrite the clocked run's record
+        text = bench_line.emit(line, "bench_partial.json" if partial else "bench_full.json")   # complete record -> gpurun_out/ + stderr; ONE short line on stdout
         log(f"headline: {head['ms_per_step']:.3f} ms/step; printed line {len(text)} bytes")
     if world > 1:
         dist.destroy_process_group()

@@ -74,6 +74,9 @@ def compact_roofline(roof):
     for k in ("bf16_pipe_frac", "fp32_product_TFLOPs"):
         if roof.get(k) is not None:
             out[k] = _r(roof[k])
+    if isinstance(roof.get("set_aside"), dict):
+        out["set_aside"] = {"launches": roof["set_aside"].get("launches"), "ms": _r(roof["set_aside"].get("ms"), 4),
+                            "rule": "over 10x the median of its shape (host stall inside the event pair)"}
     ak = roof.get("all_kernel_classes")
     if isinstance(ak, dict):
         out["all_kernel_classes"] = {"frac": _r(ak.get("hbm_frac")), "ms_per_step_in_timed_kernels": _r(ak.get("ms_per_step_in_timed_kernels")),

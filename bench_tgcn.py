@@ -211,8 +211,9 @@ def measure(device, rank, world, batch, steps, warmup, profile_steps, series, ei
                                "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "avg_us_per_launch": k["avg_us"],
                                "share_of_step_ms": k["ms_per_step"],
                                "all_kernel_classes": bench.all_kernel_classes(kernels, profile_steps)}
+            bench.set_aside(res["roofline"], kernels)
             res["kernels"] = {kk: {f: v[f] for f in ("launches_per_step", "ms_per_step", "avg_us", "algorithmic_bytes_per_launch",
-                                                      "achieved_GBs", "hbm_frac") if f in v} | (
+                                                      "achieved_GBs", "hbm_frac", "set_aside_launches", "set_aside_ms") if f in v} | (
                                    {"by_shape": v["by_shape"]} if "by_shape" in v else {}) for kk, v in kernels.items()}
     del step, model
     torch.cuda.empty_cache()
@@ -282,4 +283,5 @@ def main(args, rank, local_rank, world, device, bench):
                         "ms_per_step": dropin_blas["ms_per_step"], "what": "the same with TGCN2.readout_interception = False (torch's BLAS product)"}},
                 "final_loss": res["final_loss"], "roofline": res.get("roofline"), "kernels": res.get("kernels"), "cpu_baseline": cpu}
         import bench_line
-        bench_line.emit(line, "bench_full_tgcn50k.json")
+        partial = args.no_extra or args.no_cpu_baseline or args.profile_steps == 0      # (a profiler pass keeps its own file)
+        bench_line.emit(line, "bench_partial_tgcn50k.json" if partial else "bench_full_tgcn50k.json")

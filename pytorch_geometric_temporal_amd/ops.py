@@ -507,10 +507,17 @@ def cheb_graph(edge_index, edge_weight, num_nodes, normalization="sym", lambda_m
 class KernelTimer:
     """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on (torch's
     current stream is the stream handed to the C ABI).  Used by bench.py for the live roofline figures; disabled
-    (None) on the timed path."""
+    (None) on the timed path.
+
+    An event pair brackets the host call that issues the kernel, so a host stall between the first record and the launch (the
+    allocator, the interpreter's collector, a descheduled process) lands in that launch's time.  One such stall of 72 ms made a
+    119 us product read 3 012 us on average over 24 launches (round 5, profiles/r05f_bench_full.json).  A launch that took more
+    than STALL_FACTOR times the MEDIAN of the launches of the same shape is therefore set aside and REPORTED
+    (`set_aside_launches`, `set_aside_ms`), never silently dropped; averages are over the others."""
+    STALL_FACTOR = 10.0
 
     def __init__(self):
-        self.records = {}   # kind -> list of (start_event, end_event, work) ; work = algorithmic bytes or flops
+        self.records = {}   # kind -> list of (start_event, end_event, work, group) ; work = algorithmic bytes or flops
         self.tagged = {}
 
     def launch(self, kind, work, fn, tag=None):
@@ -519,27 +526,51 @@ class KernelTimer:
         e0.record()
         fn()
         e1.record()
-        self.records.setdefault(kind, []).append((e0, e1, work))
+        group = (kind,) + tuple(tag) if tag is not None else (kind, work)
+        rec = (e0, e1, work, group)
+        self.records.setdefault(kind, []).append(rec)
         if tag is not None:
-            self.tagged.setdefault((kind,) + tuple(tag), []).append((e0, e1, work))
+            self.tagged.setdefault(group, []).append(rec)
+
+    def _times(self):
+        """{id(record): (ms, kept)} with the per-shape stall rule applied."""
+        torch.cuda.synchronize()
+        groups = {}
+        for recs in self.records.values():
+            for r in recs:
+                groups.setdefault(r[3], []).append(r)
+        out = {}
+        for recs in groups.values():
+            ms = [r[0].elapsed_time(r[1]) for r in recs]
+            med = sorted(ms)[len(ms) // 2]
+            for r, t in zip(recs, ms):
+                out[id(r)] = (t, t <= self.STALL_FACTOR * med or len(ms) < 3)
+        return out
+
+    @staticmethod
+    def _stats(recs, times):
+        kept = [times[id(r)][0] for r in recs if times[id(r)][1]]
+        aside = [times[id(r)][0] for r in recs if not times[id(r)][1]]
+        d = {"launches": len(kept), "avg_us": 1e3 * sum(kept) / max(len(kept), 1), "total_ms": sum(kept)}
+        if aside:
+            d["set_aside_launches"] = len(aside)
+            d["set_aside_ms"] = sum(aside)
+        return d
 
     def by_tag(self):
         """Per (kind, shape...) mean launch time; the shape tags are the C-ABI size arguments."""
-        torch.cuda.synchronize()
+        times = self._times()
         out = []
         for tag, recs in self.tagged.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            out.append({"tag": list(tag), "launches": len(recs), "avg_us": 1e3 * sum(ms) / len(ms),
-                        "total_ms": sum(ms), "work_per_launch": recs[0][2]})
+            out.append({"tag": list(tag), **self._stats(recs, times), "work_per_launch": recs[0][2]})
         return sorted(out, key=lambda r: -r["total_ms"])
 
     def summary(self):
-        torch.cuda.synchronize()
+        times = self._times()
         out = {}
         for kind, recs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            out[kind] = {"launches": len(recs), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms),
-                         "work_per_launch": sum(w for _, _, w in recs) / len(recs)}
+            kept = [r for r in recs if times[id(r)][1]]
+            out[kind] = {**self._stats(recs, times), "work_per_launch": sum(r[2] for r in kept) / max(len(kept), 1)}
         return out
 
 

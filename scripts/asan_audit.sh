@@ -23,6 +23,7 @@ if [ "$MODE" = order ]; then
   exit 0
 fi
 OUT=${TMPDIR:-/tmp}/pgt_${MODE}_emu
+export PGT_EMU_SANITIZER=$MODE      # tests skip checks that need a C++ exception to cross torch's autograd engine
 mkdir -p "$OUT"
 if [ "$MODE" = asan ]; then
   SAN="-fsanitize=address"; RT=$(gcc -print-file-name=libasan.so)

@@ -84,3 +84,50 @@ def test_unforeseen_record_still_gives_a_whole_line():
     assert len(text.encode()) < bench_line.LINE_LIMIT
     line = json.loads(text)
     assert "dropped" in line["other_configs"] and line["roofline"] is not None and line["cpu_baseline"] is not None
+
+
+def test_kernel_timer_sets_a_stalled_launch_aside_and_says_so(monkeypatch):
+    """A host stall between the first event and the launch (72 ms inside one of 24 launches of a 119 us product in the round-5
+    evidence run) must not become the kernel's average: the launch is set aside by the 10x-the-median-of-its-shape rule, counted
+    and reported; fewer than three launches of a shape are never judged."""
+    import torch
+    from pytorch_geometric_temporal_amd import ops
+
+    clock = {"t": 0.0}
+
+    class FakeEvent:
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            self.t = clock["t"]
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    kt = ops.KernelTimer()
+
+    def kernel(ms):
+        def fn():
+            clock["t"] += ms
+        return fn
+
+    for i in range(24):
+        kt.launch("gemm", 100.0, kernel(72.0 if i == 5 else 0.119), tag=("NT", 211968, 320))
+    for i in range(2):
+        kt.launch("gemm", 10.0, kernel(50.0 if i else 0.1), tag=("NN", 8, 8))       # two launches: no median to judge by
+    for i in range(10):
+        kt.launch("stack", 7.0, kernel(0.08))
+    s = kt.summary()
+    assert s["gemm"]["launches"] == 25 and s["gemm"]["set_aside_launches"] == 1 and abs(s["gemm"]["set_aside_ms"] - 72.0) < 1e-9
+    assert "set_aside_launches" not in s["stack"] and abs(s["stack"]["avg_us"] - 80.0) < 1e-6
+    tags = {tuple(r["tag"]): r for r in kt.by_tag()}
+    nt = tags[("gemm", "NT", 211968, 320)]
+    assert nt["launches"] == 23 and abs(nt["avg_us"] - 119.0) < 1e-6 and nt["set_aside_launches"] == 1
+    assert tags[("gemm", "NN", 8, 8)]["launches"] == 2 and "set_aside_launches" not in tags[("gemm", "NN", 8, 8)]
+    # the printed line carries the count
+    import bench_line
+    line = json.loads(bench_line.compact({"roofline": {"kernel": "k", "frac": 0.4, "set_aside": {"launches": 1, "ms": 72.0, "rule": "x"}}}))
+    assert line["roofline"]["set_aside"]["launches"] == 1

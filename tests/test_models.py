@@ -1,6 +1,7 @@
 """T-GCN / A3T-GCN / STConv (ChebConv) / EvolveGCN families through the drop-in modules:
 forward parity against the fixtures produced by the reference's own module files (tests/golden, tolerance 1e-5 as
 north_star states), forward + backward parity against the fp64 CPU oracle, state_dict compatibility."""
+import os
 import pytest
 import torch
 
@@ -1221,7 +1222,9 @@ def test_two_forwards_then_two_backwards_and_data_writes_between_forwards(backen
         fresh = m(x1, ei, ew)
     assert torch.equal(o2, fresh) and float((o2 - o1).abs().max()) > 1e-3
     # a parameter changed in place between a forward and its backward: an error, as with torch's own saved tensors
-    if kind != "dcrnn":                                       # (DCRNN's pack is linear in the parameters: nothing saved, nothing to check)
+    # (not under scripts/asan_audit.sh: an exception crossing autograd's C++ engine aborts a preloaded ASAN run time, which has
+    #  no __cxa_throw to forward to)
+    if kind != "dcrnn" and not os.environ.get("PGT_EMU_SANITIZER"):       # (DCRNN's pack is linear in the parameters: nothing saved)
         out = m(x1, ei, ew)
         with torch.no_grad():
             m.linear_z.weight.add_(1.0)

@@ -885,8 +885,8 @@ def main():
         }
         import bench_line
         partial = args.no_extra or args.no_cpu_baseline or args.profile_steps == 0      # a profiler pass must not overwrite the clocked run's record
-        text = bench_line.emit(line, "bench_partial.json" if partial else "bench_full.json")   # complete record -> gpurun_out/ + stderr; ONE short line on stdout
-        log(f"headline: {head['ms_per_step']:.3f} ms/step; printed line {len(text)} bytes")
+        bench_line.emit(line, "bench_partial.json" if partial else "bench_full.json",       # complete record -> gpurun_out/ + stderr; ONE short
+                        before=lambda text: log(f"headline: {head['ms_per_step']:.3f} ms/step; printed line {len(text)} bytes"))   # line on stdout, last
     if world > 1:
         dist.destroy_process_group()
 

@@ -206,8 +206,10 @@ def compact(full, full_path=None):
     return text
 
 
-def emit(full, name="bench_full.json"):
-    """Write the complete record under gpurun_out/ (merged back from a GPU box) and to stderr, print the compact line on stdout."""
+def emit(full, name="bench_full.json", before=None):
+    """Write the complete record under gpurun_out/ (merged back from a GPU box) and to stderr, then print the compact line on stdout
+    as the LAST thing the process writes (`before(text)`: the caller's closing stage mark, ahead of it) — a tail of the merged
+    streams ends with the line."""
     path = None
     try:
         d = os.path.join(ROOT, "gpurun_out")
@@ -219,5 +221,8 @@ def emit(full, name="bench_full.json"):
         pass
     print("[bench-full] " + json.dumps(full), file=sys.stderr, flush=True)
     text = compact(full, path)
+    if before is not None:
+        before(text)
+    sys.stderr.flush()
     print(text, flush=True)
     return text

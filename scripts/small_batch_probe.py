@@ -13,6 +13,10 @@ from pytorch_geometric_temporal_amd.dataset import synthetic as syn
 from pytorch_geometric_temporal_amd.graphed import GraphedStep
 
 dev = torch.device("cuda:0")
+for kv in [a for a in sys.argv[1:] if "=" in a]:          # pgt_tune switches: key=value (after the positional arguments)
+    from pytorch_geometric_temporal_amd import _lib
+    _lib.get_lib().tune(kv.split("=")[0], int(kv.split("=")[1]))
+sys.argv = [a for a in sys.argv if "=" not in a]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hidden = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50

@@ -34,7 +34,12 @@ def regs(tok):
 
 
 def main():
-    with tempfile.TemporaryDirectory() as tmp:
+    if len(sys.argv) > 1:                         # an ISA listing made elsewhere (a kernel kept for the record, a lab variant)
+        text = open(sys.argv[1]).read()
+        if ".Lfunc_end" not in text:
+            text += "\n.Lfunc_end:\n"
+    else:
+      with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "gemm_bx.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                         "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(SRC), "-S", "--cuda-device-only", SRC,
@@ -81,38 +86,58 @@ def main():
                 out.append(i + 1)
             succ.append(out)
 
+        # The in-flight state is the ORDERED list of hand-issued loads (oldest first, one register set each): a hand-written
+        # `s_waitcnt vmcnt(N)` retires all but the N youngest — not everything.  (Until round 5 any hand-written wait cleared the
+        # whole set, and a kernel whose compiler-made register copies at the loop's back edge read loads issued a few
+        # instructions earlier passed the audit; it failed on the GPU.)  States meeting at a block are merged position by
+        # position from the youngest end.
         def transfer(b, pend, report):
-            pend = set(pend)
+            pend = [set(x) for x in pend]
             found = []
             for op, rest, in_asm, s in b["ins"]:
                 if op == "s_waitcnt" and "vmcnt" in rest:
-                    if in_asm or "vmcnt(0)" in rest:
-                        pend.clear()
+                    n = int(re.search(r"vmcnt\((\d+)\)", rest).group(1))
+                    if n == 0:
+                        pend = []
+                    elif in_asm:
+                        pend = pend[len(pend) - n:] if n < len(pend) else pend
                     continue
                 operands = rest.split(",")
                 if in_asm and op.startswith("buffer_load"):
-                    pend |= regs(operands[0])
+                    pend.append(set(regs(operands[0])))
                     continue
+                if op.startswith(("buffer_store", "global_store", "global_atomic", "buffer_atomic", "global_load", "buffer_load")):
+                    pend.append(set())              # any other vector-memory instruction counts in vmcnt as well
                 start = 0 if op.startswith(("buffer_store", "global_store", "ds_write", "global_atomic", "v_cmp", "s_")) else 1
                 srcs = set()
                 for tok in operands[start:]:
                     srcs |= regs(tok)
-                hit = srcs & pend
+                flying = set().union(*pend) if pend else set()
+                hit = srcs & flying
                 if hit and report:
                     found.append((sorted(hit), s))
                 if start == 1:                      # an overwritten register is no longer the load's
-                    pend -= regs(operands[0])
-            return pend, found
+                    dst = regs(operands[0])
+                    for x in pend:
+                        x -= dst
+            return tuple(frozenset(x) for x in pend), found
 
-        ins = [set() for _ in blocks]
-        changed = True
-        while changed:
-            changed = False
+        def merge(a, b):
+            n = max(len(a), len(b))
+            pa, pb = (frozenset(),) * (n - len(a)) + tuple(a), (frozenset(),) * (n - len(b)) + tuple(b)
+            return tuple(x | y for x, y in zip(pa, pb))
+
+        ins = [() for _ in blocks]
+        changed, rounds = True, 0
+        while changed and rounds < 200:
+            changed, rounds = False, rounds + 1
             for i, b in enumerate(blocks):
                 out, _ = transfer(b, ins[i], False)
+                out = out[-64:]                     # (vmcnt is six bits: nothing older than 64 instructions is in flight)
                 for j in succ[i]:
-                    if not out <= ins[j]:
-                        ins[j] |= out
+                    m = merge(ins[j], out)
+                    if m != ins[j]:
+                        ins[j] = m
                         changed = True
         violations, n_loads, n_waits, scratch = 0, 0, 0, 0
         for b in blocks:                            # rule 3

@@ -21,3 +21,43 @@ def test_split_bf16_kernels_pass_the_isa_audit():
     assert res.returncode == 0, res.stdout[-3000:]
     for ln in lines:
         assert "early reads 0  scratch 0" in ln, ln
+
+
+LISTING = """
+_ZN4test12gemm_bx_fakeEv: ; a two-deep software pipeline: two loads in flight over the back edge
+	;;#ASMSTART
+	buffer_load_dword v10, v1, s[0:3], 0 offen
+	;;#ASMEND
+	;;#ASMSTART
+	buffer_load_dword v11, v1, s[0:3], 0 offen
+	;;#ASMEND
+.LBB0_1:
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_add_f32_e32 v20, v20, v10
+	;;#ASMSTART
+	buffer_load_dword v12, v1, s[0:3], 0 offen
+	;;#ASMEND
+	s_cmp_lt_i32 s4, s5
+	s_cbranch_scc0 .LBB0_3
+%COPY%
+	s_branch .LBB0_1
+.LBB0_3:
+	s_waitcnt vmcnt(0)
+	v_add_f32_e32 v20, v20, v11
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+@pytest.mark.parametrize("copy,bad", [("\tv_mov_b32_e32 v13, v10", False), ("\tv_mov_b32_e32 v13, v12", True)])
+def test_audit_models_vmcnt_exactly(tmp_path, copy, bad):
+    """`s_waitcnt vmcnt(1)` retires all but the YOUNGEST load: a copy of the register it released is fine, a copy of the load
+    issued a moment ago is a read of a register still in flight — the case that reached the GPU in round 5 (compiler-made copies
+    at a loop's back edge) and that the audit used to wave through because any hand-written wait cleared its whole set."""
+    f = tmp_path / "listing.s"
+    f.write_text(LISTING.replace("%COPY%", copy))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bx_isa_audit.py"), str(f)], capture_output=True, text=True, timeout=60)
+    assert (res.returncode != 0) == bad, res.stdout + res.stderr
+    assert ("reads in-flight" in res.stdout) == bad, res.stdout

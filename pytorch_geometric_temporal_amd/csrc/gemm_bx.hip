@@ -33,6 +33,7 @@ namespace {
 
 int g_bx = 1;   // pgt_tune("gemm_bx"): 1 = where it applies (>= 8192 rows), 2 = at any size (tests), 0 = never
 int g_bx_sym = 1;   // pgt_tune("gemm_bx_sym"): 0 = short-K products on the K-split kernel instead of the symmetric one (A/B)
+int g_bx_tn_pc = 1;   // pgt_tune("gemm_bx_tn_pc"): 1 = the weight gradient on specialised wavefronts (gemm_bx_tn_pc_kernel), 0 = all alike
 
 // ---- platform layer: the handful of operations below are hand-written gfx950 instructions.  The CPU test double compiles
 // the SAME kernel bodies against tests/hipemu/pgt_bx_platform_emu.h, which spells these operations in plain C++ (fibers,
@@ -54,7 +55,14 @@ __device__ __forceinline__ BxRsrc bx_make_rsrc(const void* p, int64_t bytes) {
                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bytes), 0x00020000u};
   return r;
 }
+// one of two descriptors by a wave-uniform condition, the result in scalar registers
+__device__ __forceinline__ BxRsrc bx_select_rsrc(bool c, const BxRsrc& a, const BxRsrc& b) {
+  bx_u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(c ? a[0] : b[0])), (uint32_t)__builtin_amdgcn_readfirstlane((int)(c ? a[1] : b[1])),
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(c ? a[2] : b[2])), (uint32_t)__builtin_amdgcn_readfirstlane((int)(c ? a[3] : b[3]))};
+  return r;
+}
 #define BX_LOAD2(dst, voff, rs) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory")
+#define BX_LOAD2S(dst, voff, rs, soff) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory")
 #define BX_LOAD1(dst, voff, rs) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory")
 #define BX_LOAD1S(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory")
 #define BX_STORE1S(val, voff, rs, soff) asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(val), "v"(voff), "s"(rs), "s"(soff) : "memory")
@@ -65,6 +73,7 @@ __device__ __forceinline__ BxRsrc bx_make_rsrc(const void* p, int64_t bytes) {
 // hand-counted waits, tied to the registers they release so that the consumer cannot be scheduled above them
 #define BX_WAIT(n, reg) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n))
 #define BX_WAIT2(n, r0, r1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(n))
+#define BX_WAIT8(n, a0, a1, a2, a3, a4, a5, a6, a7) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "n"(n))
 #define BX_WAIT_PLAIN(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 #define BX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define BX_FENCE() asm volatile("" ::: "memory")
@@ -836,6 +845,251 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The weight gradient with the wavefronts SPECIALISED (round 5; pgt_tune("gemm_bx_tn_pc", 1)).  In gemm_bx_tn_kernel all eight
+// wavefronts are alike — matrix products, then conversion of the next stage, then a barrier — and a stage costs the SUM of those
+// phases: matrix pipe 52 % busy, LDS 50 %, HBM 3.7 TB/s, nothing saturated (notebook 5.7).  Here
+//   * wavefronts 0 .. 3 ("consumers", one per SIMD) do nothing but LDS fragment reads and MFMAs: wavefront w owns column block w
+//     of G and ALL eleven 32-row blocks of dW (NCB = 4; 176 accumulator registers), or column block w & 1 and every second row
+//     block (NCB = 2) — 66 back-to-back MFMAs per stage and SIMD, 2 112 cycles: the floor of the matrix pipe;
+//   * wavefronts 4 .. 7 ("producers", one per SIMD) never issue an MFMA: they stream both operands (hand-issued 4-byte loads,
+//     lanes along the columns, 32 in flight per thread), cut them into three bf16 planes and write the transposed LDS image of
+//     the NEXT stage — their VALU / LDS / VMEM instructions issue in the shadow of the consumers' MFMAs.
+// A producer's unit is (column, EIGHT rows): the four dwords of a plane leave as one ds_write_b128 at c * 48 + 16 q, which is
+// conflict-free (sixteen consecutive columns x four dwords = the 64 banks once), where one-dword writes meet four ways — with the
+// LDS pipe now shared by four writers and four readers at full rate that is the difference between 1 500 and 2 600 LDS cycles per
+// stage.  Same planes, same six piece products per block in the same order as gemm_bx_tn_kernel: the same sums bit for bit.
+// One LDS-only barrier per stage, double-buffered stages, the non-finite redo and the flush on the consumers.
+template <int NCB, bool DET>
+__global__ __launch_bounds__(512, 1) void gemm_bx_tn_pc_kernel(PgtTnArgs g, int n_stages, int slab_base) {
+  constexpr int RB = 11, ROWB = 48, APL = RB * 32 * ROWB, GPL = NCB * 32 * ROWB, BUF = 3 * (APL + GPL);
+  constexpr int RSTEP = 4 / NCB, MAXB = (RB + RSTEP - 1) / RSTEP;      // row blocks of a consumer: every RSTEP-th
+  constexpr int UPT = 2;                                               // (column pair, eight rows) units per producer thread and stage
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = BX_SGPR(tid >> 6);
+  const bool producer = wave >= 4;
+  const int nwg = gridDim.x;
+  const int K = g.n_seg * g.seg_k;
+  for (int i = tid; i < 2 * BUF / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (tid < 16) reinterpret_cast<uint32_t*>(lds + (tid >> 3) * BUF + K * ROWB)[tid & 7] = 0x3f803f80u;   // the row of ones (bias gradient)
+  __syncthreads();
+  int st = blockIdx.x;
+  if (producer) {
+    // ---- unit map (256 threads).  A unit = (column PAIR, eight rows): eight 8-byte loads (a wavefront's instruction reads 512
+    // contiguous bytes of a row), two columns x four row pairs -> two quads per plane.  Unit 0 of thread p: A unit p; unit 1: A
+    // unit 256 + p on producer wavefronts 0, 1, G unit p - 128 on wavefronts 2, 3 (uniform per wavefront: descriptor and row
+    // pitch of a hand-issued load are scalar).  K and N even, operands 8-byte aligned (the host side checks).
+    const int p = tid - 256, pw = wave - 4;
+    const int KH = K >> 1;
+    uint32_t ug[UPT], ul[UPT];          // byte offset of the unit's first element in its operand's stage; of its first quad in a buffer
+    const bool g1 = pw >= 2;            // unit 1 of this wavefront is a G unit
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+      if (j == 1 && g1) {
+        const int w = p - 128;
+        const int q = w / (NCB * 16), c = 2 * (w - q * (NCB * 16));
+        const bool unit = w < NCB * 32;
+        ug[j] = unit && c < g.N ? (uint32_t)((8 * q * g.ldg + c) * 4) : 0xfffffff0u;
+        ul[j] = unit ? (uint32_t)(3 * APL + c * ROWB + 16 * q) : (uint32_t)((RB * 32 - 2) * ROWB + 32);
+      } else {
+        const int v = 256 * j + p;
+        const int q = v / KH, c = 2 * (v - q * KH), seg = c / g.seg_k, cc = c - seg * g.seg_k;
+        const bool unit = v < K;
+        ug[j] = unit ? (uint32_t)((seg * g.a_seg_stride + 8 * q * g.lda + cc) * 4) : 0xfffffff0u;
+        ul[j] = unit ? (uint32_t)(c * ROWB + 16 * q) : (uint32_t)((RB * 32 - 2) * ROWB + 32);      // (no unit: the padding of the last two rows)
+      }
+    }
+    const uint32_t lda4 = (uint32_t)(g.lda * 4), ldg4 = (uint32_t)(g.ldg * 4);
+    const int64_t span_last = (int64_t)(g.n_seg - 1) * g.a_seg_stride * 4;
+    auto a_rsrc = [&](int s) {
+      const int64_t rows_left = (int64_t)g.M - (int64_t)s * 16;
+      const int64_t rows = rows_left < 16 ? rows_left : 16;
+      return bx_make_rsrc(g.A + (int64_t)(rows_left > 0 ? s : 0) * 16 * g.lda,
+                          rows_left > 0 ? span_last + (rows - 1) * g.lda * 4 + (int64_t)g.seg_k * 4 : 0);
+    };
+    auto g_rsrc = [&](int s) {
+      const int64_t rows_left = (int64_t)g.M - (int64_t)s * 16;
+      const int64_t rows = rows_left < 16 ? rows_left : 16;
+      return bx_make_rsrc(g.G + (int64_t)(rows_left > 0 ? s : 0) * 16 * g.ldg, rows_left > 0 ? (rows - 1) * g.ldg * 4 + (int64_t)g.N * 4 : 0);
+    };
+    // TWO stages of loads in flight per thread (2 x 16 loads of 8 bytes = 64 KB per CU): with one (32 KB) the stream is bound by
+    // latency x bytes in flight at ~4 TB/s whatever the wavefronts do meanwhile (the first form of this kernel: 1 353 us against
+    // 1 433 for the kernel it replaces — and the reason that one never passed 3.7 TB/s).  The two register sets take turns: the
+    // loop below is unrolled by two, so every register has one name.
+    bx_u32x2 raw[2][UPT][8];
+    auto issue_unit = [&](int set, int j, const BxRsrc& ra, const BxRsrc& rg) {
+      const bool gu = j == 1 && g1;
+      const BxRsrc ru = bx_select_rsrc(gu, rg, ra);
+      const uint32_t ld = (uint32_t)BX_SGPR((int)(gu ? ldg4 : lda4));
+      BX_LOAD2(raw[set][j][0], ug[j], ru);
+#pragma unroll
+      for (int r = 1; r < 8; ++r) {
+        const uint32_t so = (uint32_t)BX_SGPR((int)(r * ld));
+        BX_LOAD2S(raw[set][j][r], ug[j], ru, so);
+      }
+    };
+    // unit j of `set`, whose eight loads are the OLDEST in flight: 8 (2 UPT - 1) younger ones behind them
+    auto convert_unit = [&](int set, int j, unsigned char* buf, int rows_left) {
+      BX_WAIT8(8 * (2 * UPT - 1), raw[set][j][0], raw[set][j][1], raw[set][j][2], raw[set][j][3], raw[set][j][4], raw[set][j][5],
+               raw[set][j][6], raw[set][j][7]);
+      const int q8 = 8 * (int)((ul[j] % ROWB) >> 4);          // first row of the unit inside the stage
+      const int pl = (j == 1 && g1) ? GPL : APL;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                           // the unit's two columns
+        uint32_t hold[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = bx_as_float(raw[set][j][2 * i][h]), y = bx_as_float(raw[set][j][2 * i + 1][h]);
+          if (rows_left < 16) {                                // (rows past M: other data in A's earlier segments)
+            x = q8 + 2 * i < rows_left ? x : 0.f;
+            y = q8 + 2 * i + 1 < rows_left ? y : 0.f;
+          }
+          bx_split2_fast(x, y, hold[0][i], hold[1][i], hold[2][i]);
+        }
+        unsigned char* d = buf + ul[j] + h * ROWB;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const bx_u32x4 v4 = {hold[q][0], hold[q][1], hold[q][2], hold[q][3]};
+          *reinterpret_cast<bx_u32x4*>(d + q * pl) = v4;
+        }
+      }
+    };
+    // stage s of this workgroup's sequence: st + s * nwg
+    {
+      const BxRsrc ra0 = a_rsrc(st), rg0 = g_rsrc(st), ra1 = a_rsrc(st + nwg), rg1 = g_rsrc(st + nwg);
+      const BxRsrc ra2 = a_rsrc(st + 2 * nwg), rg2 = g_rsrc(st + 2 * nwg);
+#pragma unroll
+      for (int j = 0; j < UPT; ++j) issue_unit(0, j, ra0, rg0);
+#pragma unroll
+      for (int j = 0; j < UPT; ++j) issue_unit(1, j, ra1, rg1);
+#pragma unroll
+      for (int j = 0; j < UPT; ++j) {
+        convert_unit(0, j, lds, g.M - st * 16);
+        issue_unit(0, j, ra2, rg2);
+      }
+    }
+    bx_barrier();
+    // iteration i consumes stage i out of buffer i & 1; the producers meanwhile convert stage i + 1 (register set (i + 1) & 1) into
+    // the other buffer and request stage i + 3 into the same set
+    // S stages for this workgroup (>= 1: the grid never has more workgroups than stages), i.e. S more barriers: whole rounds of
+    // two, then the odd one BEHIND the loop — the loop has one exit and one back edge, so the two halves' in-flight orders never
+    // meet at its header (scripts/bx_isa_audit.py follows the control-flow graph, not the values of the exit tests).
+    const int S = (n_stages - st + nwg - 1) / nwg;
+    auto half = [&](int set, unsigned char* buf, int stage_conv, int stage_load) {
+      const BxRsrc ran = a_rsrc(stage_load), rgn = g_rsrc(stage_load);
+#pragma unroll
+      for (int j = 0; j < UPT; ++j) {
+        convert_unit(set, j, buf, g.M - stage_conv * 16);
+        issue_unit(set, j, ran, rgn);
+      }
+      bx_barrier();
+    };
+    for (int r = 0; r < (S >> 1); ++r) {
+      half(1, lds + BUF, st + nwg, st + 3 * nwg);
+      half(0, lds, st + 2 * nwg, st + 4 * nwg);
+      st += 2 * nwg;
+    }
+    if (S & 1) half(1, lds + BUF, st + nwg, st + 3 * nwg);
+    BX_DRAIN();
+    return;
+  }
+  // ---- consumers
+  const int cb = NCB == 4 ? wave : (wave & 1), r0 = NCB == 4 ? 0 : (wave >> 1);
+  pgt_f32x16 acc[MAXB];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int n = cb * 32 + lo;
+  auto flush_block = [&](int rb, const auto& v) {
+    const int slab = slab_base + (int)blockIdx.x;
+    float* const wbase = (DET ? g.part + (int64_t)slab * g.part_stride : g.dW) + n;
+    float* const bbase = g.db == nullptr ? nullptr : (DET ? g.dbpart + (int64_t)slab * g.N : g.db) + n;
+    const uint32_t ld = (uint32_t)g.lddw;
+    if (rb >= RB || n >= g.N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (k < K) {
+        if constexpr (DET) wbase[(uint32_t)k * ld] = v[r];
+        else atomicAdd(wbase + (uint32_t)k * ld, v[r]);
+      } else if (k == K && bbase != nullptr) {
+        if constexpr (DET) *bbase = v[r];
+        else atomicAdd(bbase, v[r]);
+      }
+    }
+  };
+  bx_barrier();                                           // stage 0 is in buffer 0
+  int cur = 0;
+  const int afrag = (lane & 31) * ROWB + 16 * (lane >> 5);
+  for (; st < n_stages; st += nwg) {
+    unsigned char* bcur = lds + cur * BUF;
+    bx_u32x4 fb[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bx_u32x4*>(bcur + 3 * APL + q * GPL + cb * 32 * ROWB + afrag);
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+      const int rb = r0 + RSTEP * b;
+      if (rb < RB) {
+        bx_u32x4 fa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * APL + rb * 32 * ROWB + afrag);
+        acc[b] = bx_mfma(fa[2], fb[0], acc[b]);      // small piece products first (the order of gemm_bx_tn_kernel)
+        acc[b] = bx_mfma(fa[0], fb[2], acc[b]);
+        acc[b] = bx_mfma(fa[1], fb[1], acc[b]);
+        acc[b] = bx_mfma(fa[1], fb[0], acc[b]);
+        acc[b] = bx_mfma(fa[0], fb[1], acc[b]);
+        acc[b] = bx_mfma(fa[0], fb[0], acc[b]);
+      }
+    }
+    bx_barrier();
+    cur ^= 1;
+  }
+  // ---- non-finite operands: as in gemm_bx_tn_kernel (a nan among this wavefront's sums -> its blocks again as an fp32 fmaf chain)
+  {
+    bool bad = false;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bad |= acc[b][r] != acc[b][r];
+    if (__ballot(bad) != 0) {
+      for (int b = 0; b < MAXB; ++b) {
+        const int rb = r0 + RSTEP * b;
+        if (rb >= RB) continue;
+        int koff[16];
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int seg = k / g.seg_k;
+          koff[r] = k > K ? -2 : k == K ? -1 : (int)(seg * g.a_seg_stride + (k - seg * g.seg_k));
+          t[r] = 0.f;
+        }
+        for (int s2 = blockIdx.x; s2 < n_stages; s2 += nwg)
+          for (int i = 0; i < 16; ++i) {
+            const int64_t m = (int64_t)s2 * 16 + i;
+            if (m >= g.M) break;
+            const float gv = n < g.N ? g.G[m * g.ldg + n] : 0.f;
+            const float* ar = g.A + m * g.lda;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int o = koff[r];
+              const float a = o >= 0 ? ar[o] : (o == -1 ? 1.f : 0.f);
+              t[r] = fmaf(a, gv, t[r]);
+            }
+          }
+        flush_block(rb, t);
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) flush_block(r0 + RSTEP * b, acc[b]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Short K (<= 128) into up to 320 columns — the feature-gradient products dP W^T of the training step: nothing to split
 // along K, so all eight wavefronts are alike: wavefront w owns the 32-column block w for the whole K (B slice: KSTEPS x 3
 // fragments in registers), every thread converts its share of the next 32-row block of A, no partial sums, no flag,
@@ -1051,6 +1305,7 @@ int bx_device_cus() {
 
 void pgt_gemm_bx_set(int v) { g_bx = v; }
 void pgt_gemm_bx_sym_set(int v) { g_bx_sym = v; }
+void pgt_gemm_bx_tn_pc_set(int v) { g_bx_tn_pc = v; }
 
 int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (!g_bx) return 0;
@@ -1167,13 +1422,20 @@ int pgt_gemm_bx_tn_launch(const PgtTnArgs& t, pgt_stream_t stream) {
     const int n_stages = (int)pgt_cdiv(u.M, 16);
     dim3 grid((unsigned)wgs), block(512);                  // every workgroup writes its slab, also when it has no stage
     const int slab_base = c * wgs;
+    // the specialised kernel reads column PAIRS with 8-byte loads: even widths and pitches, 8-byte aligned operands
+    const bool pc_ok = g_bx_tn_pc && t.seg_k % 2 == 0 && t.lda % 2 == 0 && t.a_seg_stride % 2 == 0 && t.N % 2 == 0 && t.ldg % 2 == 0 &&
+                       pgt_aligned(u.A, 8) && pgt_aligned(u.G, 8);
+#define PGT_BX_TN_GO(NCB_, DET_)                                                                                       \
+    do {                                                                                                                \
+      if (pc_ok) PGT_LAUNCH((gemm_bx_tn_pc_kernel<NCB_, DET_>), grid, block, stream, u, n_stages, slab_base);           \
+      else PGT_LAUNCH((gemm_bx_tn_kernel<NCB_, DET_>), grid, block, stream, u, n_stages, slab_base);                    \
+    } while (0)
     if (t.part != nullptr) {
-      if (t.N > 64) PGT_LAUNCH((gemm_bx_tn_kernel<4, true>), grid, block, stream, u, n_stages, slab_base);
-      else PGT_LAUNCH((gemm_bx_tn_kernel<2, true>), grid, block, stream, u, n_stages, slab_base);
+      if (t.N > 64) PGT_BX_TN_GO(4, true); else PGT_BX_TN_GO(2, true);
     } else {
-      if (t.N > 64) PGT_LAUNCH((gemm_bx_tn_kernel<4, false>), grid, block, stream, u, n_stages, slab_base);
-      else PGT_LAUNCH((gemm_bx_tn_kernel<2, false>), grid, block, stream, u, n_stages, slab_base);
+      if (t.N > 64) PGT_BX_TN_GO(4, false); else PGT_BX_TN_GO(2, false);
     }
+#undef PGT_BX_TN_GO
   }
   return pgt_check_launch("pgt_gemm_tn_acc_f32 (split-bf16)");
 }

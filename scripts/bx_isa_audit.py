@@ -7,8 +7,8 @@ hold in the emitted code, in program order, for every kernel:
   1. on EVERY control-flow path between an asm load and an instruction that READS one of its destination registers there
      is a hand-written `s_waitcnt vmcnt` (or a compiler `s_waitcnt vmcnt(0)`) — the in-flight set is propagated over the
      basic-block graph to a fixed point;
-  2. no scratch (spill) instruction exists — a spilled in-flight register would be stored before it has landed, and
-     scratch accesses would change the vmcnt arithmetic;
+  2. no scratch (spill) instruction exists where a hand-issued load can be in flight — a spilled in-flight register would be
+     stored before it has landed, and scratch accesses would change the vmcnt arithmetic;
   3. every hand-issued store of more than 8 bytes is followed, inside its asm statement, by `s_nop` (the store reads its
      data registers over several cycles; the compiler pads its own wide stores against a VALU write in the next two issue
      slots and cannot see into the asm — round 3 shipped corrupted quads to the GPU tests before this rule).
@@ -156,7 +156,18 @@ def main():
             for op, rest, in_asm, s in b["ins"]:
                 n_loads += in_asm and op.startswith("buffer_load")
                 n_waits += in_asm and op == "s_waitcnt" and "vmcnt" in rest
-                scratch += "scratch_" in op
+            # rule 2, exactly: a scratch access is a violation where a hand-issued load can be in flight (it would change the
+            # vmcnt arithmetic, or store a register that has not landed).  Spills on paths that never issue such a load — the
+            # consumer wavefronts' epilogue of gemm_bx_tn_pc_kernel — are slow, not wrong.
+            pend = [set(x) for x in ins[i]]
+            for op, rest, in_asm, s in b["ins"]:
+                if "scratch_" in op and any(pend):
+                    scratch += 1
+                if op == "s_waitcnt" and "vmcnt" in rest:
+                    n = int(re.search(r"vmcnt\((\d+)\)", rest).group(1))
+                    pend = [] if n == 0 else (pend[len(pend) - n:] if in_asm and n < len(pend) else pend)
+                elif in_asm and op.startswith("buffer_load"):
+                    pend.append(set(regs(rest.split(",")[0])))
         print(f"{name[22:72]:52s} asm loads {n_loads:3d}  hand waits {n_waits:3d}  early reads {violations}  scratch {scratch}")
         bad += violations + scratch
     return 1 if bad else 0

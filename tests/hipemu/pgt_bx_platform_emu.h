@@ -8,8 +8,10 @@ typedef uint32_t bx_u32x4 __attribute__((vector_size(16)));
 typedef uint32_t bx_u32x2 __attribute__((vector_size(8)));
 struct BxRsrc { const unsigned char* base; uint32_t bytes; };
 static inline BxRsrc bx_make_rsrc(const void* p, int64_t bytes) { return BxRsrc{static_cast<const unsigned char*>(p), (uint32_t)bytes}; }
+static inline BxRsrc bx_select_rsrc(bool c, const BxRsrc& a, const BxRsrc& b) { return c ? a : b; }
 static inline bool bx_in_range(const BxRsrc& r, uint64_t off, unsigned size) { return off + size <= r.bytes; }   // raw buffer rule
 #define BX_LOAD2(dst, voff, rs) do { uint64_t o_ = (voff); if (bx_in_range(rs, o_, 8)) memcpy(&(dst), (rs).base + o_, 8); else memset(&(dst), 0, 8); } while (0)
+#define BX_LOAD2S(dst, voff, rs, soff) do { uint64_t o_ = (uint64_t)(uint32_t)(voff) + (uint32_t)(soff); if (bx_in_range(rs, o_, 8)) memcpy(&(dst), (rs).base + o_, 8); else memset(&(dst), 0, 8); } while (0)
 #define BX_LOAD1(dst, voff, rs) do { uint64_t o_ = (voff); if (bx_in_range(rs, o_, 4)) memcpy(&(dst), (rs).base + o_, 4); else memset(&(dst), 0, 4); } while (0)
 #define BX_LOAD1S(dst, voff, rs, soff) do { uint64_t o_ = (uint64_t)(uint32_t)(voff) + (uint32_t)(soff); if (bx_in_range(rs, o_, 4)) memcpy(&(dst), (rs).base + o_, 4); else memset(&(dst), 0, 4); } while (0)
 #define BX_STORE1S(val, voff, rs, soff) do { uint64_t o_ = (uint64_t)(uint32_t)(voff) + (uint32_t)(soff); float v_ = (val); if (bx_in_range(rs, o_, 4)) memcpy(const_cast<unsigned char*>((rs).base) + o_, &v_, 4); } while (0)
@@ -17,6 +19,7 @@ static inline bool bx_in_range(const BxRsrc& r, uint64_t off, unsigned size) { r
 #define BX_STORE4(val, voff, rs) do { uint64_t o_ = (uint32_t)(voff); bx_u32x4 v_ = (val); if (bx_in_range(rs, o_, 16)) memcpy(const_cast<unsigned char*>((rs).base) + o_, &v_, 16); } while (0)
 #define BX_WAIT(n, reg) ((void)0)
 #define BX_WAIT2(n, r0, r1) ((void)0)
+#define BX_WAIT8(n, a0, a1, a2, a3, a4, a5, a6, a7) ((void)0)
 #define BX_WAIT_PLAIN(n) ((void)0)
 #define BX_DRAIN() ((void)0)
 #define BX_FENCE() ((void)0)

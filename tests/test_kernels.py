@@ -1263,6 +1263,9 @@ def test_gemm_split_bf16_fused_gru_epilogues(backend, M, O, fin):
     assert float((res[2][3].cpu().double() - (z * H.cpu().double() + (1 - z) * ht64)).abs().max()) <= 4e-6
 
 
+TN_PC_DEFAULT = 1      # csrc/gemm_bx.hip: g_bx_tn_pc
+
+
 @pytest.mark.parametrize("M,segs,segk,N,force", [(20000, 5, 66, 128, False), (17001, 5, 66, 64, False), (3000, 3, 60, 100, True),
                                                  (1000, 5, 66, 128, True), (517, 2, 66, 33, True), (40, 5, 70, 128, True),
                                                  (2048, 3, 61, 50, True)])
@@ -1301,8 +1304,18 @@ def test_gemm_tn_split_bf16_weight_and_bias_gradient(backend, M, segs, segk, N, 
                 dW, db = dW0.clone().to(dev), db0.clone().to(dev)
                 ops.gemm_tn_acc(Ad, segk, M * segk, segs, segk, Gd, N, dW, N, db, M, N)
                 det.append((dW, db))
+            # the other wavefront organisation (all alike <-> producers / consumers): the same planes and the same six piece
+            # products per block in the same order — the same bits
+            lib.tune("gemm_bx_tn_pc", 1 - TN_PC_DEFAULT)
+            dW, db = dW0.clone().to(dev), db0.clone().to(dev)
+            ops.gemm_tn_acc(Ad, segk, M * segk, segs, segk, Gd, N, dW, N, db, M, N)
+            other = (dW, db)
+            dWo = dW0.clone().to(dev)
+            ops.DETERMINISTIC_WEIGHT_GRADIENTS = old
+            ops.gemm_tn_acc(Ad, segk, M * segk, segs, segk, Gd, N, dWo, N, None, M, N)         # its atomics form, no bias gradient
         finally:
             ops.DETERMINISTIC_WEIGHT_GRADIENTS = old
+            lib.tune("gemm_bx_tn_pc", TN_PC_DEFAULT)
     finally:
         lib.tune("gemm_bx", 1)
     sw, sb = float(refW.abs().max()), float(refb.abs().max())
@@ -1311,6 +1324,8 @@ def test_gemm_tn_split_bf16_weight_and_bias_gradient(backend, M, segs, segk, N, 
         assert float((db.cpu().double() - refb).abs().max()) <= 3e-6 * sb + 1e-5, name
     assert float((dWn.cpu().double() - refW).abs().max()) <= 3e-6 * sw
     assert torch.equal(det[0][0], det[1][0]) and torch.equal(det[0][1], det[1][1])
+    assert torch.equal(det[0][0], other[0]) and torch.equal(det[0][1], other[1])
+    assert float((dWo.cpu().double() - refW).abs().max()) <= 3e-6 * sw
     e_bx, e_32 = float((out[bx][0].cpu().double() - refW).abs().mean()), float((out[0][0].cpu().double() - refW).abs().mean())
     if backend.name == "hip":          # at a few hundred rows (test double) both errors are a handful of roundings
         assert e_bx <= 1.5 * e_32 + 1e-9, (e_bx, e_32)

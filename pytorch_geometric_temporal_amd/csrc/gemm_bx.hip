@@ -33,6 +33,7 @@ namespace {
 
 int g_bx = 1;   // pgt_tune("gemm_bx"): 1 = where it applies (>= 8192 rows), 2 = at any size (tests), 0 = never
 int g_bx_sym = 1;   // pgt_tune("gemm_bx_sym"): 0 = short-K products on the K-split kernel instead of the symmetric one (A/B)
+int g_bx_sym_pc = 1;   // pgt_tune("gemm_bx_sym_pc"): 1 = K <= 64 products on specialised wavefronts (gemm_bx_sym_pc_kernel), 0 = all alike
 int g_bx_tn_pc = 1;   // pgt_tune("gemm_bx_tn_pc"): 1 = the weight gradient on specialised wavefronts (gemm_bx_tn_pc_kernel), 0 = all alike
 
 // ---- platform layer: the handful of operations below are hand-written gfx950 instructions.  The CPU test double compiles
@@ -1286,6 +1287,187 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_sym_kernel(PgtGemmArgs g, int 
   BX_DRAIN();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The short-K product with the wavefronts SPECIALISED (round 5; pgt_tune("gemm_bx_sym_pc", 1)): twelve wavefronts,
+//   * ten "consumers" — wavefront w owns the 32-column block w for the whole K (B fragments in registers), reads the A planes of
+//     the current block out of LDS, issues its MFMAs and STORES its 32 x 32 tile; it never loads from global memory, so it never
+//     waits on vmcnt: the stores of one block drain while the next block's MFMAs run;
+//   * two "producers" — they issue no store and no MFMA: 8-byte loads of the next blocks' rows of A (TWO blocks in flight),
+//     three bf16 planes into the other LDS buffer.
+// In gemm_bx_sym_kernel every wavefront does all of that, and because vmcnt is ONE counter for loads and stores (unordered
+// against each other) its wait for a load of the next block is also a wait for the acknowledgement of the previous block's 16 - 32
+// stores — every block pays a store round trip.  Here loads and stores are counted by different wavefronts.  Same planes, same
+// products in the same order per accumulator (the big term and the corrections apart): the same bits.
+// One LDS-only barrier per block; registers: 96 (B) + 32 (accumulators) + fragments — three wavefronts per SIMD.
+template <int KSTEPS>
+__global__ __launch_bounds__(768, 1) void gemm_bx_sym_pc_kernel(PgtGemmArgs g, int n_blocks) {
+  constexpr int BM = 32, KP = KSTEPS * 16, SROW = KP * 2 + 16, PLANE = BM * SROW, BUF = 3 * PLANE;
+  constexpr int NCONS = 10, NPROD = 2, NPT = NPROD * 64;
+  constexpr int EPT = (BM * KP / 2) / NPT;                 // float pairs per producer thread and block
+  static_assert(2 * EPT - 1 < 64, "vmcnt is six bits");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+  const int wave = BX_SGPR(tid >> 6);
+  const bool producer = wave >= NCONS;
+  const int nwg = gridDim.x;
+  const int Ktot = g.n_seg * g.seg_k;
+  for (int i = tid; i < 2 * BUF / 16; i += 768) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  int rb = blockIdx.x;
+  if (rb >= n_blocks) return;
+  __syncthreads();
+  const int64_t span_last = (int64_t)(g.n_seg - 1) * g.a_seg_stride * 4;
+  auto a_rsrc = [&](int b) {
+    const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
+    const int64_t rows = rows_left < BM ? rows_left : BM;
+    return bx_make_rsrc(g.A + (int64_t)(rows_left > 0 ? b : 0) * BM * g.lda,
+                        rows_left > 0 ? span_last + (rows - 1) * g.lda * 4 + (int64_t)g.seg_k * 4 : 0);
+  };
+  // blocks of this workgroup: rb, rb + nwg, ...  S of them (>= 1)
+  const int S = (n_blocks - rb + nwg - 1) / nwg;
+  if (producer) {
+    // ---- element map: 16 threads per row (pairs el + 16 t of a row), 8 rows per pass of the 128 producer threads
+    const int ptid = tid - NCONS * 64;
+    const int prow = ptid >> 4, el = ptid & 15;
+    constexpr int PPR = KP / 32;                           // pairs per thread and row (16 threads per row)
+    constexpr int PASSES = BM / (NPT / 16);
+    static_assert(PPR * PASSES == EPT, "element map");
+    const int half = g.seg_k >> 1, rpairs = g.n_seg * half;
+    uint32_t goff[EPT], loff[EPT];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u)
+#pragma unroll
+      for (int t = 0; t < PPR; ++t) {
+        const int row = prow + (NPT / 16) * u, pi = el + 16 * t, seg = pi / half, pp = pi - seg * half;
+        goff[u * PPR + t] = pi < rpairs ? (uint32_t)((seg * g.a_seg_stride + row * g.lda + 2 * pp) * 4) : 0xfffffff0u;
+        loff[u * PPR + t] = (uint32_t)(row * SROW + el * 4 + 64 * t);
+      }
+    bx_u32x2 raw[2][EPT];
+    auto issue_set = [&](int set, const BxRsrc& r) {
+#pragma unroll
+      for (int t = 0; t < EPT; ++t) BX_LOAD2(raw[set][t], goff[t], r);
+    };
+    // the set's EPT loads are the oldest in flight, the other set's EPT the younger ones: element t has EPT - 1 - t of its own
+    // set and EPT of the other behind it
+    auto convert_one = [&](int set, int t, unsigned char* buf, auto NY) {
+      BX_WAIT(decltype(NY)::value, raw[set][t]);
+      uint32_t p1, p2, p3;
+      bx_split2_fast(bx_as_float(raw[set][t][0]), bx_as_float(raw[set][t][1]), p1, p2, p3);
+      unsigned char* d = buf + loff[t];
+      *reinterpret_cast<uint32_t*>(d) = p1;
+      *reinterpret_cast<uint32_t*>(d + PLANE) = p2;
+      *reinterpret_cast<uint32_t*>(d + 2 * PLANE) = p3;
+    };
+    // convert element t of `set`, then request the same element of the block two ahead: the count behind element t stays 2 EPT - 1
+    auto half_step = [&](int set, unsigned char* buf, int block_load) {
+      const BxRsrc rn = a_rsrc(block_load);
+#pragma unroll
+      for (int t = 0; t < EPT; ++t) {
+        convert_one(set, t, buf, BxInt<2 * EPT - 1>());
+        BX_LOAD2(raw[set][t], goff[t], rn);
+      }
+      bx_barrier();
+    };
+    issue_set(0, a_rsrc(rb));
+    issue_set(1, a_rsrc(rb + nwg));
+    {
+      const BxRsrc rn = a_rsrc(rb + 2 * nwg);
+#pragma unroll
+      for (int t = 0; t < EPT; ++t) {
+        convert_one(0, t, lds, BxInt<2 * EPT - 1>());
+        BX_LOAD2(raw[0][t], goff[t], rn);
+      }
+    }
+    bx_barrier();                                          // block 0 is in buffer 0
+    for (int r = 0; r < (S >> 1); ++r) {
+      half_step(1, lds + BUF, rb + 3 * nwg);
+      half_step(0, lds, rb + 4 * nwg);
+      rb += 2 * nwg;
+    }
+    if (S & 1) half_step(1, lds + BUF, rb + 3 * nwg);
+    BX_DRAIN();
+    return;
+  }
+  // ---- consumers
+  const int col = wave * 32 + lo;
+  const bool live = wave * 32 < g.N;
+  bx_u32x4 bf[KSTEPS][3];
+#pragma unroll
+  for (int i = 0; i < KSTEPS; ++i) {
+    const int k0 = i * 16 + 8 * hi;
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = k0 + t;
+      v[t] = (k < Ktot && col < g.N) ? g.Bw[(int64_t)k * g.sbk + (int64_t)col * g.sbn] : 0.f;
+    }
+    uint32_t p[3][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bx_split2(v[2 * t], v[2 * t + 1], p[0][t], p[1][t], p[2][t]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { bx_u32x4 f = {p[q][0], p[q][1], p[q][2], p[q][3]}; bf[i][q] = f; }
+  }
+  const int js = (wave * 32) / g.c_seg_n;
+  const float* cbase = g.C + (int64_t)js * g.c_seg_stride + (wave * 32 - js * g.c_seg_n);
+  const uint32_t cvoff = col < g.N ? (uint32_t)((4 * hi * g.ldc + lo) * 4) : 0xfffffff0u;
+  auto c_rsrc = [&](int b) {
+    const int64_t rows_left = (int64_t)g.M - (int64_t)b * BM;
+    const int64_t rows = rows_left < BM ? rows_left : BM;
+    return bx_make_rsrc(cbase + (int64_t)b * BM * g.ldc, ((rows - 1) * g.ldc + 32) * 4);
+  };
+  const float bias_r = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+  BX_DRAIN();                                              // the B / bias loads (compiler-issued) have landed; from here on only stores
+  bx_barrier();                                            // block 0 is in buffer 0
+  int cur = 0;
+  const int arow = lo * SROW + 16 * hi;
+  const uint32_t ldc4 = (uint32_t)(g.ldc * 4);
+  for (int it = 0; it < S; ++it, rb += nwg) {
+    unsigned char* bcur = lds + cur * BUF;
+    pgt_f32x16 am, ac;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { am[r] = 0.f; ac[r] = 0.f; }
+    if (live) {
+      // the fragments of k-step i + 1 are requested BEFORE the six products of k-step i are issued (pinned: left alone the
+      // compiler reuses one set of fragment registers and every k-step waits out an LDS round trip in front of its MFMAs)
+      bx_u32x4 fa[3], fn[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow);
+#pragma unroll
+      for (int i = 0; i < KSTEPS; ++i) {
+        if (i + 1 < KSTEPS) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fn[q] = *reinterpret_cast<const bx_u32x4*>(bcur + q * PLANE + arow + (i + 1) * 32);
+        }
+        PGT_SCHED_FENCE();
+        am = bx_mfma(fa[0], bf[i][0], am);
+        ac = bx_mfma(fa[0], bf[i][1], ac);
+        ac = bx_mfma(fa[1], bf[i][0], ac);
+        ac = bx_mfma(fa[1], bf[i][1], ac);
+        ac = bx_mfma(fa[0], bf[i][2], ac);
+        ac = bx_mfma(fa[2], bf[i][0], ac);
+        PGT_SCHED_FENCE();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[q] = fn[q];
+      }
+      const BxRsrc rc = c_rsrc(rb);
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = am[r] + ac[r] + bias_r;
+      if (bx_tile_has_nan(v)) {                              // non-finite operand: exact fp32 tile (rare)
+        BX_DRAIN();
+        bx_exact_tile(g, a_rsrc(rb), col, hi, bias_r, v);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t soff = (uint32_t)BX_SGPR((int)(((r & 3) + 8 * (r >> 2)) * ldc4));
+        BX_STORE1S(v[r], cvoff, rc, soff);
+      }
+    }
+    bx_barrier();
+    cur ^= 1;
+  }
+  BX_DRAIN();
+}
+
 int bx_device_cus() {
 #ifdef PGT_EMU
   return 4;
@@ -1306,6 +1488,7 @@ int bx_device_cus() {
 void pgt_gemm_bx_set(int v) { g_bx = v; }
 void pgt_gemm_bx_sym_set(int v) { g_bx_sym = v; }
 void pgt_gemm_bx_tn_pc_set(int v) { g_bx_tn_pc = v; }
+void pgt_gemm_bx_sym_pc_set(int v) { g_bx_sym_pc = v; }
 
 int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (!g_bx) return 0;
@@ -1358,7 +1541,12 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   if (wgs > n_blocks) wgs = n_blocks;
   dim3 grid((unsigned)wgs), block(512);
 #define PGT_BX_GO(KS_, WN_, EPI_, Q4_) PGT_LAUNCH((gemm_bx_kernel<KS_, WN_, EPI_, Q4_>), grid, block, stream, g, n_blocks)
-  if (sym_ok) {
+  // K <= 64: specialised wavefronts (83 -> 73 - 76 us at the step's 64 -> 320 product).  At K = 128 that form measures the SAME
+  // as the all-alike kernel (123 vs 122 us): both are paced by the two SIMDs that carry three of the ten column blocks (4 608 MFMA
+  // cycles per 32-row block; block time = 2 300 + 945 cycles per k-step in either form), so the longer K stays where it was.
+  if (sym_ok && g_bx_sym_pc && K <= 64 && g.N <= 320 && g.seg_k % 2 == 0) {
+    PGT_LAUNCH((gemm_bx_sym_pc_kernel<4>), grid, dim3(768), stream, g, n_blocks);
+  } else if (sym_ok) {
     if (K > 64) PGT_LAUNCH((gemm_bx_sym_kernel<8>), grid, block, stream, g, n_blocks);
     else PGT_LAUNCH((gemm_bx_sym_kernel<4>), grid, block, stream, g, n_blocks);
   } else if (K > 128 && g.N <= 64) {                         // two column blocks: K cut four ways

@@ -162,6 +162,7 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream);
 void pgt_gemm_bx_set(int v);
 void pgt_gemm_bx_sym_set(int v);
 void pgt_gemm_bx_tn_pc_set(int v);
+void pgt_gemm_bx_sym_pc_set(int v);
 
 // V-float (4 / 8 / 16-byte) global accesses; V is chosen by the host from pointer and stride alignment.
 template <int VEC>

@@ -44,6 +44,10 @@ extern "C" int pgt_tune(const char* key, int value) {
     pgt_gemm_bx_tn_pc_set(value);
     return PGT_OK;
   }
+  if (strcmp(key, "gemm_bx_sym_pc") == 0) {
+    pgt_gemm_bx_sym_pc_set(value);
+    return PGT_OK;
+  }
   if (strcmp(key, "gemm_tn_fullk") == 0) {
     pgt_gemm_set_tn_fullk(value);
     return PGT_OK;

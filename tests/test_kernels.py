@@ -1069,6 +1069,9 @@ def _bx_run(A, B, bias, M, segs, segk, N, nt, dev):
     return C
 
 
+SYM_PC_DEFAULT = 1      # csrc/gemm_bx.hip: g_bx_sym_pc
+
+
 @pytest.mark.parametrize("M,segs,segk,N,nt", [(5000, 5, 66, 128, False), (4131, 5, 66, 64, False), (3000, 3, 34, 96, False),
                                               (7000, 1, 128, 256, True), (2500, 1, 64, 256, True), (3333, 1, 128, 64, True),
                                               (6100, 1, 128, 320, True), (2049, 1, 64, 320, True), (900, 1, 100, 192, True),
@@ -1092,6 +1095,15 @@ def test_gemm_split_bf16_is_at_least_as_accurate_as_the_fp32_kernels(backend, M,
         C_32 = _bx_run(A, B, bias, M, segs, segk, N, nt, dev).cpu().double()
     finally:
         lib.tune("gemm_bx", 1)
+    if nt and N > 128:       # the short-K kernel in its other wavefront organisation (all alike <-> producers / consumers): the same bits
+        try:
+            lib.tune("gemm_bx", 2)
+            lib.tune("gemm_bx_sym_pc", 1 - SYM_PC_DEFAULT)
+            C_other = _bx_run(A, B, bias, M, segs, segk, N, nt, dev).cpu().double()
+        finally:
+            lib.tune("gemm_bx_sym_pc", SYM_PC_DEFAULT)
+            lib.tune("gemm_bx", 1)
+        assert torch.equal(C_bx, C_other)
     assert torch.isfinite(C_bx).all()
     e_bx, e_32 = (C_bx - ref).abs(), (C_32 - ref).abs()
     scale = float(ref.abs().max())

@@ -791,6 +791,14 @@ def main():
             variant("exact_fp32", "pgt_tune(gemm_bx, 0): every dense product on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain)")
         finally:
             lib.tune("gemm_bx", 1)
+        lib.tune("gemm_bx_tn_pc", 0)
+        lib.tune("gemm_bx_sym_pc", 0)
+        try:
+            variant("wavefronts_all_alike", "pgt_tune(gemm_bx_tn_pc, 0) + (gemm_bx_sym_pc, 0): the weight-gradient and 64 -> 320 products on round 4's "
+                    "kernels (every wavefront converts, multiplies and stores) instead of producers / consumers — the same bits, the same box")
+        finally:
+            lib.tune("gemm_bx_tn_pc", 1)
+            lib.tune("gemm_bx_sym_pc", 1)
         ops.DETERMINISTIC_WEIGHT_GRADIENTS = True
         try:
             variant("deterministic", "PGT_DETERMINISTIC=1: weight gradients without float atomics (per-slab partial sums added in order)")

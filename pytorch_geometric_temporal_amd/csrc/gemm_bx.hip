@@ -1542,8 +1542,8 @@ int pgt_gemm_bx_launch(const PgtGemmArgs& g, pgt_stream_t stream) {
   dim3 grid((unsigned)wgs), block(512);
 #define PGT_BX_GO(KS_, WN_, EPI_, Q4_) PGT_LAUNCH((gemm_bx_kernel<KS_, WN_, EPI_, Q4_>), grid, block, stream, g, n_blocks)
   // K <= 64: specialised wavefronts (83 -> 73 - 76 us at the step's 64 -> 320 product).  At K = 128 that form measures the SAME
-  // as the all-alike kernel (123 vs 122 us): both are paced by the two SIMDs that carry three of the ten column blocks (4 608 MFMA
-  // cycles per 32-row block; block time = 2 300 + 945 cycles per k-step in either form), so the longer K stays where it was.
+  // as the all-alike kernel (123 vs 122 us), and balancing the ten column blocks over the SIMDs measured 3 % slower: that launch is
+  // matrix-pipe bound at the clock its power draw allows (docs/LAB_NOTEBOOK.md 5.8), so the longer K stays where it was.
   if (sym_ok && g_bx_sym_pc && K <= 64 && g.N <= 320 && g.seg_k % 2 == 0) {
     PGT_LAUNCH((gemm_bx_sym_pc_kernel<4>), grid, dim3(768), stream, g, n_blocks);
   } else if (sym_ok) {

@@ -34,7 +34,7 @@ namespace {
 int g_bx = 1;   // pgt_tune("gemm_bx"): 1 = where it applies (>= 8192 rows), 2 = at any size (tests), 0 = never
 int g_bx_sym = 1;   // pgt_tune("gemm_bx_sym"): 0 = short-K products on the K-split kernel instead of the symmetric one (A/B)
 int g_bx_sym_pc = 1;   // pgt_tune("gemm_bx_sym_pc"): 1 = K <= 64 products on specialised wavefronts (gemm_bx_sym_pc_kernel), 0 = all alike
-int g_bx_tn_pc = 1;   // pgt_tune("gemm_bx_tn_pc"): 1 = the weight gradient on specialised wavefronts (gemm_bx_tn_pc_kernel), 0 = all alike
+int g_bx_tn_pc = 1;   // pgt_tune("gemm_bx_tn_pc"): 1 = the weight gradient on specialised wavefronts (gemm_bx_tn_pc_kernel), 0 = all alike, 2 = twelve wavefronts at N = 128 too
 
 // ---- platform layer: the handful of operations below are hand-written gfx950 instructions.  The CPU test double compiles
 // the SAME kernel bodies against tests/hipemu/pgt_bx_platform_emu.h, which spells these operations in plain C++ (fibers,
@@ -860,18 +860,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_kernel(PgtTnArgs g, int n_s
 // LDS pipe now shared by four writers and four readers at full rate that is the difference between 1 500 and 2 600 LDS cycles per
 // stage.  Same planes, same six piece products per block in the same order as gemm_bx_tn_kernel: the same sums bit for bit.
 // One LDS-only barrier per stage, double-buffered stages, the non-finite redo and the flush on the consumers.
-template <int NCB, bool DET>
-__global__ __launch_bounds__(512, 1) void gemm_bx_tn_pc_kernel(PgtTnArgs g, int n_stages, int slab_base) {
+// NCW consumer + NPW producer wavefronts.  4 + 4 is the form described above.  Twelve wavefronts (168 registers) put the extra four
+// where a shape is short: N <= 64 has half the MFMAs per stage, so its stage is paced by ONE producer wavefront per SIMD walking
+// its dependent convert chains — 4 + 8 (one unit per producer thread); N = 128 is paced by the matrix pipe with one consumer per
+// SIMD waiting out its fragment reads — 8 + 4 (two consumers per SIMD, half the row blocks each).
+template <int NCB, bool DET, int NCW, int NPW>
+__global__ __launch_bounds__(64 * (NCW + NPW), 1) void gemm_bx_tn_pc_kernel(PgtTnArgs g, int n_stages, int slab_base) {
   constexpr int RB = 11, ROWB = 48, APL = RB * 32 * ROWB, GPL = NCB * 32 * ROWB, BUF = 3 * (APL + GPL);
-  constexpr int RSTEP = 4 / NCB, MAXB = (RB + RSTEP - 1) / RSTEP;      // row blocks of a consumer: every RSTEP-th
-  constexpr int UPT = 2;                                               // (column pair, eight rows) units per producer thread and stage
+  constexpr int NT = 64 * (NCW + NPW);
+  constexpr int RSTEP = NCW / NCB, MAXB = (RB + RSTEP - 1) / RSTEP;      // row blocks of a consumer: every RSTEP-th
+  constexpr int UPT = NPW == 4 ? 2 : 1;                                // (column pair, eight rows) units per producer thread and stage
+  static_assert((NPW == 4 || NPW == 8) && NCW % NCB == 0, "wavefront roles");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = BX_SGPR(tid >> 6);
-  const bool producer = wave >= 4;
+  const bool producer = wave >= NCW;
   const int nwg = gridDim.x;
   const int K = g.n_seg * g.seg_k;
-  for (int i = tid; i < 2 * BUF / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 2 * BUF / 16; i += NT) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (tid < 16) reinterpret_cast<uint32_t*>(lds + (tid >> 3) * BUF + K * ROWB)[tid & 7] = 0x3f803f80u;   // the row of ones (bias gradient)
   __syncthreads();
@@ -881,14 +887,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_pc_kernel(PgtTnArgs g, int 
     // contiguous bytes of a row), two columns x four row pairs -> two quads per plane.  Unit 0 of thread p: A unit p; unit 1: A
     // unit 256 + p on producer wavefronts 0, 1, G unit p - 128 on wavefronts 2, 3 (uniform per wavefront: descriptor and row
     // pitch of a hand-issued load are scalar).  K and N even, operands 8-byte aligned (the host side checks).
-    const int p = tid - 256, pw = wave - 4;
+    // (eight producer wavefronts: ONE unit per thread — A unit p on wavefronts 0 - 5, G unit p - 384 on wavefronts 6, 7)
+    const int p = tid - 64 * NCW, pw = wave - NCW;
     const int KH = K >> 1;
     uint32_t ug[UPT], ul[UPT];          // byte offset of the unit's first element in its operand's stage; of its first quad in a buffer
-    const bool g1 = pw >= 2;            // unit 1 of this wavefront is a G unit
+    const bool g1 = NPW == 4 ? pw >= 2 : pw >= 6;      // the LAST unit of this wavefront is a G unit
 #pragma unroll
     for (int j = 0; j < UPT; ++j) {
-      if (j == 1 && g1) {
-        const int w = p - 128;
+      if (j == UPT - 1 && g1) {
+        const int w = NPW == 4 ? p - 128 : p - 384;
         const int q = w / (NCB * 16), c = 2 * (w - q * (NCB * 16));
         const bool unit = w < NCB * 32;
         ug[j] = unit && c < g.N ? (uint32_t)((8 * q * g.ldg + c) * 4) : 0xfffffff0u;
@@ -920,7 +927,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_pc_kernel(PgtTnArgs g, int 
     // loop below is unrolled by two, so every register has one name.
     bx_u32x2 raw[2][UPT][8];
     auto issue_unit = [&](int set, int j, const BxRsrc& ra, const BxRsrc& rg) {
-      const bool gu = j == 1 && g1;
+      const bool gu = j == UPT - 1 && g1;
       const BxRsrc ru = bx_select_rsrc(gu, rg, ra);
       const uint32_t ld = (uint32_t)BX_SGPR((int)(gu ? ldg4 : lda4));
       BX_LOAD2(raw[set][j][0], ug[j], ru);
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_pc_kernel(PgtTnArgs g, int 
       BX_WAIT8(8 * (2 * UPT - 1), raw[set][j][0], raw[set][j][1], raw[set][j][2], raw[set][j][3], raw[set][j][4], raw[set][j][5],
                raw[set][j][6], raw[set][j][7]);
       const int q8 = 8 * (int)((ul[j] % ROWB) >> 4);          // first row of the unit inside the stage
-      const int pl = (j == 1 && g1) ? GPL : APL;
+      const int pl = (j == UPT - 1 && g1) ? GPL : APL;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {                           // the unit's two columns
         uint32_t hold[3][4];
@@ -996,7 +1003,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bx_tn_pc_kernel(PgtTnArgs g, int 
     return;
   }
   // ---- consumers
-  const int cb = NCB == 4 ? wave : (wave & 1), r0 = NCB == 4 ? 0 : (wave >> 1);
+  const int cb = wave % NCB, r0 = wave / NCB;
   pgt_f32x16 acc[MAXB];
 #pragma unroll
   for (int b = 0; b < MAXB; ++b)
@@ -1613,15 +1620,20 @@ int pgt_gemm_bx_tn_launch(const PgtTnArgs& t, pgt_stream_t stream) {
     // the specialised kernel reads column PAIRS with 8-byte loads: even widths and pitches, 8-byte aligned operands
     const bool pc_ok = g_bx_tn_pc && t.seg_k % 2 == 0 && t.lda % 2 == 0 && t.a_seg_stride % 2 == 0 && t.N % 2 == 0 && t.ldg % 2 == 0 &&
                        pgt_aligned(u.A, 8) && pgt_aligned(u.G, 8);
-#define PGT_BX_TN_GO(NCB_, DET_)                                                                                       \
+#define PGT_BX_TN_GO(NCB_, DET_, CW_, PW_)                                                                             \
     do {                                                                                                                \
-      if (pc_ok) PGT_LAUNCH((gemm_bx_tn_pc_kernel<NCB_, DET_>), grid, block, stream, u, n_stages, slab_base);           \
+      if (pc_ok && (g_bx_tn_pc == 2 || NCB_ == 2))                                                                      \
+        PGT_LAUNCH((gemm_bx_tn_pc_kernel<NCB_, DET_, CW_, PW_>), grid, dim3(64 * (CW_ + PW_)), stream, u, n_stages, slab_base); \
+      else if (pc_ok) PGT_LAUNCH((gemm_bx_tn_pc_kernel<NCB_, DET_, 4, 4>), grid, block, stream, u, n_stages, slab_base); \
       else PGT_LAUNCH((gemm_bx_tn_kernel<NCB_, DET_>), grid, block, stream, u, n_stages, slab_base);                    \
     } while (0)
+    // N <= 64: twelve wavefronts, four consumers + eight producers (885 us per call at the step's shape against 933 for four +
+    // four and 980 all alike); N = 128: four + four (1 246 us; eight consumers + four producers measure the same, 1 230 - 1 240:
+    // pgt_tune("gemm_bx_tn_pc", 2) launches that form) — profiles/r05v_tn_twelve_wavefronts_ab.jsonl
     if (t.part != nullptr) {
-      if (t.N > 64) PGT_BX_TN_GO(4, true); else PGT_BX_TN_GO(2, true);
+      if (t.N > 64) PGT_BX_TN_GO(4, true, 8, 4); else PGT_BX_TN_GO(2, true, 4, 8);
     } else {
-      if (t.N > 64) PGT_BX_TN_GO(4, false); else PGT_BX_TN_GO(2, false);
+      if (t.N > 64) PGT_BX_TN_GO(4, false, 8, 4); else PGT_BX_TN_GO(2, false, 4, 8);
     }
 #undef PGT_BX_TN_GO
   }

@@ -108,7 +108,9 @@ const char* pgt_build_target(void);
  * (streaming kernels for an extent <= 4: 1 from 1024 rows / 2 always / 0), "gemm_small_tiles", "gemm_tn_pipe",
  * "gemm_tn_fullk", "gemm_small_fill", "gemm_bx" (split-bf16 kernel on the bf16 matrix pipe — fp32 operands as three
  * bf16 pieces, six piece products, fp32 accumulation; at least as close to the exact product as the fp32 kernels:
- * 1 where it wins / 2 at any size / 0 never), "gemm_bx_sym" (0: short-K products on its K-split variant).  Diffusion
+ * 1 where it wins / 2 at any size / 0 never), "gemm_bx_sym" (0: short-K products on its K-split variant), "gemm_bx_tn_pc" / "gemm_bx_sym_pc" (0: the
+ * weight-gradient / K <= 64 short products on the kernels whose wavefronts are all alike instead of producers and consumers; the
+ * same bits).  Diffusion
  * stack: "slab_pairs", "slab_split", "slab_wpc", "slab_threads" (pgt_dconv_stack_slab_plan), "slab_quad" (0: 64 / 66-column blocks on the pair-layout kernels), "slab_gu" (2 | 4 LDS reads in flight in their backward gathers).  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
  * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_ellw" (0: pgt_spmm_ellw_f32 runs
  * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan), "tgcn_rows" (0: the column-per-lane T-GCN cell kernels of round 4 for every shape).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */

@@ -51,7 +51,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 15
+#define PGT_ABI_VERSION 16
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -73,7 +73,8 @@ typedef struct pgt_dconv_graph {
   float* deg_out;   /* [N]  scatter_add(edge_weight, row)  (dcrnn.py:61-64 / :279) */
   float* deg_in;    /* [N]  scatter_add(edge_weight, col)  (dcrnn.py:65-68 / :280) */
   int32_t* info;    /* [4]  info[0] = #duplicate (row,col) pairs, info[1] = #zero weights,
-                            info[2] = #edge endpoints outside [0,N), info[3] = reserved */
+                            info[2] = #edge endpoints outside [0,N), info[3] = #slots of P_o / P_i with a
+                            non-finite coefficient (1 / deg of a node without out- / in-edges) */
 } pgt_dconv_graph;
 
 /* GCN / Chebyshev operators: one CSR for propagate, one transposed CSR for the feature gradient.
@@ -594,6 +595,29 @@ int pgt_dcrnn_seq_small_bwd_f32(const pgt_csr* tp_o, const pgt_csr* tp_i, int64_
                                 int64_t out_stride_t, const float* H0, const float* save, const float* Wzr, const float* Wh,
                                 int64_t B, int64_t T, int64_t Fin, int64_t O, int64_t K, float* dX, int64_t x_stride_b,
                                 int64_t x_stride_t, float* dH0, float* dWpart, pgt_stream_t stream);
+
+/* Whole DCRNN sequences at hidden width 64, one workgroup per sample (csrc/seq64.hip): BatchedDCRNN.forward (nn/recurrent/dcrnn.py:
+ * 429-475; cell :194-219, gates :172-192, diffusion :85-106) of the benchmarked model BatchedDCRNN(2, 64, K) on graphs whose block
+ * and operators fit a CU's LDS (pgt_dcrnn_seq64_fits: O == 64, Fin == 2, K = 2 | 3, N <= 208, two [N, 68] blocks + a 24 KB weight
+ * ring + 6 bytes per slot within 160 KB: METR-LA at 1 515 and at 1 722 edges).  ONE launch runs all T steps of every sample: the
+ * hops are gathered out of LDS (the diffusion terms are bit-identical to pgt_dconv_stack_slab_f32's), every term meets its weight
+ * block while it is in LDS (split-bf16 products on v_mfma_f32_16x16x32_bf16, fp32 accumulation: the arithmetic of
+ * pgt_gemm_gru_zr_f32 / pgt_gemm_gru_h_f32 above 8 192 rows), the gate chains run on the accumulators.
+ *   Wp: pgt_dcrnn_seq64_pack_floats(K) floats, 16-byte aligned, written by pgt_dcrnn_seq64_pack_f32 from the stacked operands
+ *   Wzr [(2K - 1)(Fin + 64), 128], Wh [(2K - 1)(Fin + 64), 64] (pgt_dcrnn_pack_weights_f32) whenever they change;
+ *   X[b, t] = X + b * x_stride_b + t * x_stride_t: [N, Fin] rows; out likewise [N, 64] rows; H0 [B, N, 64] or NULL (zeros);
+ *   saved for the adjoint (all required; batch-major rows m = b N + n, M = B N): TSzr / TSh = the two diffusion stacks, segment s
+ *   of step t at s * seg_stride + t * t_stride + m * (Fin + 64) ([T0 | T1o T1i | T2o T2i], 8-byte aligned, even strides),
+ *   ZR [T, M, 128] = Z | R, HT [T, M, 64] = the candidate — the layout pgt_gru_*_bwd_f32 / pgt_dconv_stack_slab_bwd_f32 /
+ *   pgt_gemm_tn_acc_f32 take. */
+int pgt_dcrnn_seq64_fits(int64_t N, int64_t E_o, int64_t E_i, int64_t Fin, int64_t O, int64_t K);
+int64_t pgt_dcrnn_seq64_pack_floats(int64_t K);
+int pgt_dcrnn_seq64_pack_f32(const float* Wzr, const float* Wh, int64_t Fin, int64_t K, float* Wp, pgt_stream_t stream);
+int pgt_dcrnn_seq64_f32(const pgt_csr* op_o, const pgt_csr* op_i, int64_t E_o, int64_t E_i, int64_t N, const float* X,
+                        int64_t x_stride_b, int64_t x_stride_t, const float* H0, const float* Wp, const float* Wzr,
+                        const float* bzr, const float* Wh, const float* bh, int64_t B, int64_t T, int64_t Fin, int64_t K,
+                        float* out, int64_t out_stride_b, int64_t out_stride_t, float* TSzr, float* TSh,
+                        int64_t seg_stride, int64_t t_stride, float* ZR, float* HT, pgt_stream_t stream);
 
 /* Fused T-GCN cell for hidden width 32 (nn/recurrent/temporalgcn.py:82-130; csrc/tgcn_cell.hip): with AX = A_hat X [M, Fin] and
  * the folded operands of pgt_tgcn_pack_weights_f32,

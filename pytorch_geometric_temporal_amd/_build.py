@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libpgt_hip.so")
 INCLUDE = os.path.join(ROOT, "include")
 
 SOURCES = ["pgt_core.hip", "spmm.hip", "dconv_slab.hip", "gemm.hip", "gemm_bx.hip", "elementwise.hip",
-           "graph_prep.hip", "attention.hip", "evolve.hip", "small_cell.hip", "small_gcn.hip", "tconv.hip", "tgcn.hip", "seq_small.hip", "tgcn_cell.hip", "tile_order.hip", "readout.hip"]
+           "graph_prep.hip", "attention.hip", "evolve.hip", "small_cell.hip", "small_gcn.hip", "tconv.hip", "tgcn.hip", "seq_small.hip", "tgcn_cell.hip", "tile_order.hip", "readout.hip", "seq64.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                "-Wall", "-Wno-unused-function"]
 

@@ -166,6 +166,12 @@ PROTOTYPES = {
     "pgt_dcrnn_seq_small_bwd_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64, c_ptr, c_i64,
                                             c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64,
                                             c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "pgt_dcrnn_seq64_fits": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "pgt_dcrnn_seq64_pack_floats": (c_i64, [c_i64]),
+    "pgt_dcrnn_seq64_pack_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "pgt_dcrnn_seq64_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64,
+                                    c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64,
+                                    c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "pgt_tgcn_cell_fits": (c_int, [c_i64, c_i64]),
     "pgt_tgcn_cell_bwd_ws_floats": (c_i64, [c_i64, c_i64]),
     "pgt_tgcn_cell_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr,
@@ -176,7 +182,7 @@ PROTOTYPES = {
                                           c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 15
+EXPECTED_ABI = 16
 
 
 class PgtLib:

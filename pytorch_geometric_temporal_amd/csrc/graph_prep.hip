@@ -193,6 +193,13 @@ __global__ __launch_bounds__(256) void k_dconv_val_by_row(const int32_t* __restr
   for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) val[q] = v;
 }
 
+// info[3] += the slots of an operator whose coefficient is not finite (1 / deg of a node without out- / in-edges, dcrnn.py:71-77)
+__global__ __launch_bounds__(256) void k_count_nonfinite(const float* __restrict__ val, int64_t L, int32_t* info) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= L) return;
+  if (!(fabsf(val[q]) <= 3.0e38f)) atomicAdd(info + 3, 1);
+}
+
 __global__ __launch_bounds__(256) void k_dconv_sigma_keys(const int64_t* __restrict__ ei, int64_t E, int64_t N,
                                                            uint64_t* k_in, int32_t* v_in) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -462,6 +469,11 @@ extern "C" int pgt_dconv_prep(const int64_t* ei, const float* ew, int64_t E, int
   PGT_LAUNCH(k_dconv_stage_reverse, g1(E), block, stream, ei, w.sigma, E, N, out->deg_in, 1, w.l_dst, w.l_src,
              w.l_val);
   if (int e = build_csr(w, E, N, out->bwd_i, stream)) return e;
+  // (P_o and P_i hold every coefficient of the four operators: the transposes carry the same values)
+  if (E > 0) {
+    PGT_LAUNCH(k_count_nonfinite, g1(E), block, stream, out->fwd_o.val, E, out->info);
+    PGT_LAUNCH(k_count_nonfinite, g1(E), block, stream, out->fwd_i.val, E, out->info);
+  }
   return pgt_check_launch("pgt_dconv_prep");
 }
 

@@ -1,0 +1,642 @@
+// Whole DCRNN sequences at hidden width 64, one workgroup per sample: BatchedDCRNN.forward (nn/recurrent/dcrnn.py:429-475; cell
+// :194-219, gates :172-192, diffusion convolution :85-106) for graphs of up to ~220 nodes (METR-LA: 207) — the benchmarked
+// model BatchedDCRNN(2, 64, K = 3).
+//
+// The general path runs four launches per cell step (two LDS-resident diffusion stacks, two gate-fused split-bf16 products): at
+// the reference's default batch (64 windows, pems_ddp.py:31) every one of them is a latency-bound chain of a few 32-row blocks per
+// CU, and at B = 1024 every diffusion term crosses HBM twice (the stack kernel writes it, the product reads it back).  Here a
+// 1024-thread workgroup owns a sample for the WHOLE T-step sequence:
+//   * the sample's [N, 64 + Fin] block lives in LDS (two blocks, 272-byte rows: sixteen hidden quads + one quad of input columns)
+//     next to both CSR operators (16-bit sources, fp32 coefficients); the hops are gathered out of LDS exactly as in
+//     csrc/dconv_slab.hip (one ds_read_b128 per slot, fmaf chain in slot order: the diffusion terms are bit-identical to that path);
+//   * every diffusion term is multiplied by its weight block WHILE it sits in LDS: split-bf16 products (three bf16 pieces per fp32
+//     operand, the six largest piece products, fp32 accumulation: csrc/gemm_bx.hip) on v_mfma_f32_16x16x32_bf16 — wavefront w owns
+//     rows 16 w .. 16 w + 15 and ALL output columns, so its A fragment (its own rows, converted in registers) is built once per 32
+//     columns of a term; the weights arrive pre-split in fragment order (pgt_dcrnn_seq64_pack_f32, once per optimizer step) and
+//     stream through a two-slot LDS ring (12 KB chunks) filled by the last two wavefronts, one LDS-only barrier per chunk;
+//   * the two input columns of a term (+ the bias) are a rank-2 update on the VALU; the gate chains run on the accumulators:
+//     Z stays in registers from the update / reset epilogue to the blend, H_{t-1} in the accumulator layout across steps, H * R and
+//     the new state go straight back into the LDS block as the next T_0;
+//   * what the adjoint needs (both stacks, Z | R, the candidate, the states) is stored once, in the layout of the general path
+//     (ops.DCRNNSeqFunction), so the general backward and the weight-gradient product run unchanged on it.
+// Two blocks are enough for K = 3 because T_1^i = P_i T_0 is gathered together with T_1^o and waits in registers:
+//   A = T0 | B = T1o, regs = T1i | MFMA T0, T1o | A = T2o = 2 P_o B - T0 | MFMA T2o | B = T1i | A = T2i = 2 P_i B - T0 | MFMA T1i, T2i.
+#include "pgt_common.h"
+
+namespace {
+
+// ---- platform layer (tests/hipemu/pgt_sq_platform_emu.h spells the same operations in plain C++ for the CPU test double)
+#ifdef PGT_EMU
+#include "pgt_sq_platform_emu.h"
+constexpr int SQ_CUS = 4;
+#else
+constexpr int SQ_CUS = 256;
+typedef __bf16 sq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sq_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float sq_f32x2 __attribute__((ext_vector_type(2)));
+typedef float sq_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t sq_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float sq_as_float(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t sq_as_uint(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ uint32_t sq_pack(float x, float y) {     // v_cvt_pk_bf16_f32: round to nearest even
+  sq_f32x2 v = {x, y};
+  sq_bf16x2 r = __builtin_convertvector(v, sq_bf16x2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t sq_perm_hi16(uint32_t y, uint32_t x) { return __builtin_amdgcn_perm(y, x, 0x07060302u); }
+__device__ __forceinline__ float sq_rcp(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float sq_exp(float x) { return __expf(x); }
+__device__ __forceinline__ void sq_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ sq_f32x4 sq_mfma16(sq_u32x4 a, sq_u32x4 b, sq_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sq_bf16x8, a), __builtin_bit_cast(sq_bf16x8, b), c, 0, 0, 0);
+}
+// exact fp32 products (v_mfma_f32_16x16x4_f32): the rank-Fin update of the input columns
+__device__ __forceinline__ sq_f32x4 sq_mfma4(float a, float b, sq_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
+
+// (x, y) -> three packed bf16 pairs (low half = x's piece), every piece rounded to nearest: the packed weights
+__device__ __forceinline__ void sq_split2(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = sq_pack(x, y);
+  float rx = x - sq_as_float(p1 << 16), ry = y - sq_as_float(p1 & 0xffff0000u);
+  rx = (fabsf(rx) <= 3.0e38f) ? rx : 0.f;      // inf / nan: the first piece carries it, the others are zero
+  ry = (fabsf(ry) <= 3.0e38f) ? ry : 0.f;
+  p2 = sq_pack(rx, ry);
+  rx -= sq_as_float(p2 << 16);
+  ry -= sq_as_float(p2 & 0xffff0000u);
+  p3 = sq_pack(rx, ry);
+}
+// the streaming operand: first piece rounded to nearest, the other two cut off (csrc/gemm_bx.hip bx_split2_fast)
+__device__ __forceinline__ void sq_split2_fast(float x, float y, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  p1 = sq_pack(x, y);
+  float rx = x - sq_as_float(p1 << 16), ry = y - sq_as_float(p1 & 0xffff0000u);
+  p2 = sq_perm_hi16(sq_as_uint(ry), sq_as_uint(rx));
+  rx -= sq_as_float(p2 << 16);
+  ry -= sq_as_float(p2 & 0xffff0000u);
+  p3 = sq_perm_hi16(sq_as_uint(ry), sq_as_uint(rx));
+}
+__device__ __forceinline__ float sq_sigmoidf(float x) { return sq_rcp(1.f + sq_exp(-x)); }
+__device__ __forceinline__ float sq_tanhf(float x) {             // csrc/gemm_bx.hip bx_tanhf
+  const float x2 = x * x;
+  const float small = x * fmaf(x2, fmaf(x2, 0.13333334f, -0.33333334f), 1.f);
+  const float big = 1.f - 2.f * sq_rcp(1.f + sq_exp(2.f * x));
+  return fabsf(x) < 0.04f ? small : big;
+}
+__device__ __forceinline__ pgt_f4 sq_fma4(float w, pgt_f4 x, pgt_f4 acc) {
+  return pgt_mk4(fmaf(w, x.x, acc.x), fmaf(w, x.y, acc.y), fmaf(w, x.z, acc.z), fmaf(w, x.w, acc.w));
+}
+// 2 g - t with the rounding of csrc/dconv_slab.hip's axpby4 (2.0f * g + (-1.0f) * t)
+__device__ __forceinline__ pgt_f4 sq_two_minus(pgt_f4 g, pgt_f4 t) {
+  return pgt_mk4(2.0f * g.x + -1.0f * t.x, 2.0f * g.y + -1.0f * t.y, 2.0f * g.z + -1.0f * t.z, 2.0f * g.w + -1.0f * t.w);
+}
+
+constexpr int SQ_THREADS = 1024;
+constexpr int SQ_O = 64;             // hidden width
+constexpr int SQ_PITCH = 68;         // floats per LDS row: 16 hidden quads + the quad of input columns
+constexpr int SQ_MAXT = 4;           // gather tasks (row, quad) per thread: 17 N <= 4096
+constexpr int SQ_CHUNK_DW = 3072;    // one ring slot: 4 column tiles x 3 planes x 64 lanes x 4 dwords = 12 KB
+constexpr int SQ_LOADER0 = 13;       // wavefronts 13 .. 15 fill the ring (192 lanes x 4 x 16 bytes = one chunk)
+constexpr int SQ_LDS = 160 * 1024;
+
+struct Seq64Args {
+  const int32_t* rp_o; const int32_t* col_o; const float* val_o;
+  const int32_t* rp_i; const int32_t* col_i; const float* val_i;
+  int N, Fin, K, T, B, nnz_o, nnz_i;
+  const float* X; int64_t xs_b, xs_t;     // X[b, t] = X + b xs_b + t xs_t: [N, Fin] rows
+  const float* H0;                         // [B, N, 64] | null (zeros)
+  const uint32_t* Wp;                      // the packed weights: chunks in consumption order (pgt_dcrnn_seq64_pack_f32)
+  const float* Wzr; const float* Wh;       // the stacked fp32 operands [(2K-1)(Fin+64), 128 | 64]: the input-column rows are read in place
+  const float* bzr; const float* bh;       // [128] | null, [64] | null
+  float* out; int64_t os_b, os_t;          // out[b, t] = out + b os_b + t os_t: [N, 64] rows
+  float* TSzr; float* TSh;                 // saved stacks: segment s, step t, row m = b N + n at s seg_stride + t t_stride + m C
+  int64_t seg_stride, t_stride;
+  float* ZR; float* HT;                    // [T, B N, 128], [T, B N, 64]
+};
+
+__host__ __device__ inline int sq_nseg(int K) { return 2 * K - 1; }
+__host__ __device__ inline int sq_nchunks(int K) { return sq_nseg(K) * 6; }   // per cell step: 4 per segment (z | r) + 2 (candidate)
+// position in the consumption order -> stack segment ([T0 | T1o T1i | T2o T2i]): K = 3: T0 T1o T2o T1i T2i; K = 2: T0 T1o T1i
+__host__ __device__ inline int sq_seg_at(int K, int pos) {
+  if (K >= 3) { const int order[5] = {0, 1, 3, 2, 4}; return order[pos]; }
+  return pos;
+}
+
+// slots of an operator in LDS, padding included (rows start at even positions; an even count keeps the next array 4-byte aligned)
+__host__ __device__ inline size_t sq_slot_cap(int64_t nnz, int64_t N) { return (size_t)((nnz + N + 2) & ~(int64_t)1); }
+// two blocks, the ring, fp32 coefficients + 16-bit sources per slot, 16-bit row pointers
+static size_t sq_lds_bytes(int64_t N, int64_t nnz_o, int64_t nnz_i) {
+  return 2 * (size_t)N * SQ_PITCH * 4 + 2 * (size_t)SQ_CHUNK_DW * 4 + (sq_slot_cap(nnz_o, N) + sq_slot_cap(nnz_i, N)) * 6 +
+         2 * (size_t)(N + 2) * 2;
+}
+
+struct SqLds {
+  float* bufA; float* bufB;
+  uint32_t* ring;
+  const float* val_o; const float* val_i;
+  const uint16_t* col_o; const uint16_t* col_i;
+  const uint16_t* rp_o; const uint16_t* rp_i;
+};
+
+// Slot lists in LDS: 16-bit sources and fp32 coefficients in two arrays, row r's slots from the EVEN position
+// sq_row_start(rp[r], r) on (room for one padding slot per row), so that two slots are one 4-byte + one 8-byte read — the same two
+// LDS instructions per slot pair + two quad reads as the packed (col, val) slots of csrc/dconv_slab.hip, at 6 instead of 8 bytes per slot.
+__host__ __device__ inline int sq_row_start(int rp_r, int r) { return (rp_r + r + 1) & ~1; }
+// row sum over the slots of row r (csrc/dconv_slab.hip gather_q: the same fmaf chain in slot order), four slots in flight
+__device__ __forceinline__ pgt_f4 sq_gather(const uint16_t* __restrict__ rp, const uint16_t* __restrict__ col,
+                                            const float* __restrict__ val, const float* __restrict__ blk, int r, int qoff) {
+  pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+  const int b0 = rp[r];
+  int q = sq_row_start(b0, r);
+  const int e = q + ((int)rp[r + 1] - b0);
+  for (; q + 4 <= e; q += 4) {
+    const uint32_t c01 = *reinterpret_cast<const uint32_t*>(col + q), c23 = *reinterpret_cast<const uint32_t*>(col + q + 2);
+    const float2 v01 = *reinterpret_cast<const float2*>(val + q), v23 = *reinterpret_cast<const float2*>(val + q + 2);
+    const pgt_f4 x0 = *reinterpret_cast<const pgt_f4*>(blk + qoff + (int)(c01 & 0xffffu) * SQ_PITCH);
+    const pgt_f4 x1 = *reinterpret_cast<const pgt_f4*>(blk + qoff + (int)(c01 >> 16) * SQ_PITCH);
+    const pgt_f4 x2 = *reinterpret_cast<const pgt_f4*>(blk + qoff + (int)(c23 & 0xffffu) * SQ_PITCH);
+    const pgt_f4 x3 = *reinterpret_cast<const pgt_f4*>(blk + qoff + (int)(c23 >> 16) * SQ_PITCH);
+    acc = sq_fma4(v01.x, x0, acc);
+    acc = sq_fma4(v01.y, x1, acc);
+    acc = sq_fma4(v23.x, x2, acc);
+    acc = sq_fma4(v23.y, x3, acc);
+  }
+  if (q + 2 <= e) {
+    const uint32_t c01 = *reinterpret_cast<const uint32_t*>(col + q);
+    const float2 v01 = *reinterpret_cast<const float2*>(val + q);
+    const pgt_f4 x0 = *reinterpret_cast<const pgt_f4*>(blk + qoff + (int)(c01 & 0xffffu) * SQ_PITCH);
+    const pgt_f4 x1 = *reinterpret_cast<const pgt_f4*>(blk + qoff + (int)(c01 >> 16) * SQ_PITCH);
+    acc = sq_fma4(v01.x, x0, acc);
+    acc = sq_fma4(v01.y, x1, acc);
+    q += 2;
+  }
+  if (q < e) acc = sq_fma4(val[q], *reinterpret_cast<const pgt_f4*>(blk + qoff + (int)col[q] * SQ_PITCH), acc);
+  return acc;
+}
+
+// ---- packed weights.  Chunk c of a cell step (consumption order): c < 4 S: the update / reset product, segment sq_seg_at(c / 4),
+// hidden columns 32 kk .. + 31 (kk = (c / 2) % 2), output columns 64 half .. + 63 (half = c % 2); then 2 S chunks of the candidate
+// product (segment, kk).  Inside a chunk: [column tile ct (4)][plane (3)][lane (64)][4 dwords] — lane l of v_mfma_f32_16x16x32_bf16
+// holds B[k = 8 (l / 16) + j][n = l % 16], j = 0 .. 7, two bf16 per dword.
+__global__ __launch_bounds__(256) void seq64_pack_kernel(const float* __restrict__ Wzr, const float* __restrict__ Wh, int Fin, int K,
+                                                         uint32_t* __restrict__ Wp) {
+  const int S = sq_nseg(K), C = Fin + SQ_O;
+  const int total = sq_nchunks(K) * 4 * 64 * 4;
+  const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (idx >= total) return;
+  const int d = idx & 3, l = (idx >> 2) & 63, ct = (idx >> 8) & 3, c = idx >> 10;
+  const float* W;
+  int ld, seg, kk, n;
+  if (c < 4 * S) {
+    W = Wzr; ld = 2 * SQ_O; seg = sq_seg_at(K, c >> 2); kk = (c >> 1) & 1; n = 64 * (c & 1) + 16 * ct + (l & 15);
+  } else {
+    const int ch = c - 4 * S;
+    W = Wh; ld = SQ_O; seg = sq_seg_at(K, ch >> 1); kk = ch & 1; n = 16 * ct + (l & 15);
+  }
+  const int h0 = 32 * kk + 8 * (l >> 4) + 2 * d;
+  const float x = W[(int64_t)(seg * C + Fin + h0) * ld + n], y = W[(int64_t)(seg * C + Fin + h0 + 1) * ld + n];
+  uint32_t p1, p2, p3;
+  sq_split2(x, y, p1, p2, p3);
+  uint32_t* dst = Wp + (int64_t)c * SQ_CHUNK_DW + ((ct * 3) * 64 + l) * 4 + d;
+  dst[0] = p1;
+  dst[256] = p2;
+  dst[512] = p3;
+}
+
+// one 16-byte store / load of a hidden quad at 8-byte alignment (a row of 66 floats starts every 264 bytes; csrc/dconv_slab.hip
+// stQ / ldQ), a float2 for the quad of input columns
+__device__ __forceinline__ void sq_store_quad(float* p, bool hidden, pgt_f4 v) {
+  if (hidden) __builtin_memcpy(__builtin_assume_aligned(p, 8), &v, 16);
+  else *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
+}
+__device__ __forceinline__ pgt_f4 sq_load_quad(const float* p, bool hidden) {
+  pgt_f4 v;
+  if (hidden) {
+    __builtin_memcpy(&v, __builtin_assume_aligned(p, 8), 16);
+  } else {
+    const float2 a = *reinterpret_cast<const float2*>(p);
+    v = pgt_mk4(a.x, a.y, 0.f, 0.f);
+  }
+  return v;
+}
+__device__ __forceinline__ int sq_min(int a, int b) { return a < b ? a : b; }
+
+// gather task j of a thread: idx = tid + 1024 j; idx < 16 N: (row idx / 16, hidden quad idx % 16); then the N quads of input columns
+struct SqTask {
+  int row, quad;
+  bool live;
+  __device__ __forceinline__ bool hidden() const { return quad < 16; }
+  __device__ __forceinline__ int loff() const { return row * SQ_PITCH + 4 * quad; }                 // inside an LDS block
+  __device__ __forceinline__ int goff(int C, int Fin) const { return row * C + (quad < 16 ? Fin + 4 * quad : 0); }   // inside [N, C]
+};
+__device__ __forceinline__ SqTask sq_task(int tid, int j, int N) {
+  const int idx = tid + j * SQ_THREADS;
+  SqTask k;
+  k.live = idx < 17 * N;
+  const int ic = k.live ? idx : 0;
+  k.row = ic < 16 * N ? (ic >> 4) : ic - 16 * N;
+  k.quad = ic < 16 * N ? (ic & 15) : 16;
+  return k;
+}
+
+// lab/seq64_lab.hip defines this to record the phase timeline of workgroup 0 (wall_clock64 ticks); a no-op in the library
+#ifndef SQ_MARK
+#define SQ_MARK(t, G, slot) do { } while (0)
+#endif
+// a value the compiler must treat as unknown: address arithmetic that depends on it is recomputed where it is used instead of being
+// hoisted out of the time loop and spilled (the first build of this kernel carried 444 spilled registers of loop-invariant addresses)
+#ifdef PGT_EMU
+#define SQ_OPAQUE(x) ((void)0)
+#else
+#define SQ_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+template <int V> struct SqInt { static constexpr int value = V; };
+
+// The whole kernel for one kind of wavefront.  LOADER = the three wavefronts that stream the packed weights into the ring: they run
+// the same loop nest and meet the same barriers as everybody else (and take their share of the gathers), but their product phases
+// move chunks instead of issuing MFMAs — as a separate instantiation, so that the chunk registers are not live in the MFMA
+// wavefronts' code and the accumulators not in theirs (one body for both carried 530 spilled registers).
+template <bool LOADER>
+__device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, Fin = a.Fin, K = a.K, C = Fin + SQ_O;
+  // ---- LDS carve-up: two blocks, the ring, both operators
+  SqLds s;
+  {
+    char* p = smem;
+    s.bufA = reinterpret_cast<float*>(p); p += (size_t)N * SQ_PITCH * 4;
+    s.bufB = reinterpret_cast<float*>(p); p += (size_t)N * SQ_PITCH * 4;
+    s.ring = reinterpret_cast<uint32_t*>(p); p += 2 * (size_t)SQ_CHUNK_DW * 4;
+    const size_t cap_o = sq_slot_cap(a.nnz_o, N), cap_i = sq_slot_cap(a.nnz_i, N);
+    float* vo = reinterpret_cast<float*>(p); p += cap_o * 4;
+    float* vi = reinterpret_cast<float*>(p); p += cap_i * 4;
+    uint16_t* co = reinterpret_cast<uint16_t*>(p); p += cap_o * 2;
+    uint16_t* ci = reinterpret_cast<uint16_t*>(p); p += cap_i * 2;
+    uint16_t* ro = reinterpret_cast<uint16_t*>(p); p += (size_t)(N + 2) * 2;
+    uint16_t* ri = reinterpret_cast<uint16_t*>(p);
+    for (int i = tid; i <= N; i += SQ_THREADS) { ro[i] = (uint16_t)a.rp_o[i]; ri[i] = (uint16_t)a.rp_i[i]; }
+    for (int r = tid; r < 2 * N; r += SQ_THREADS) {           // one thread per (operator, row): its slots to the row's even start
+      const bool second = r >= N;
+      const int row = second ? r - N : r;
+      const int32_t* rp = second ? a.rp_i : a.rp_o;
+      const int32_t* gc_ = second ? a.col_i : a.col_o;
+      const float* gv = second ? a.val_i : a.val_o;
+      uint16_t* dc = second ? ci : co;
+      float* dv = second ? vi : vo;
+      const int b0 = rp[row], e0 = rp[row + 1], st = sq_row_start(b0, row);
+      for (int q = b0; q < e0; ++q) { dc[st + q - b0] = (uint16_t)gc_[q]; dv[st + q - b0] = gv[q]; }
+    }
+    s.val_o = vo; s.val_i = vi; s.col_o = co; s.col_i = ci; s.rp_o = ro; s.rp_i = ri;
+  }
+  // ---- roles
+  const int NRT = (N + 15) >> 4;                 // row tiles = MFMA wavefronts
+  const bool consumer = !LOADER && wave < NRT;
+  constexpr bool loader = LOADER;
+  const int ll = tid - SQ_LOADER0 * 64;          // loader lane 0 .. 191
+  const int NCH = sq_nchunks(K);
+  // MFMA lane map: A row (clamped: the sums of rows past N are never used), D rows 4 (lane / 16) + i, D column lane % 16
+  const int aoff = sq_min(16 * wave + (lane & 15), N - 1) * SQ_PITCH + 8 * (lane >> 4);
+  const int dcol = lane & 15;
+  const int drow0 = 16 * wave + 4 * (lane >> 4);
+  // ---- the ring: chunk gc of the kernel's stream sits in slot gc & 1; the loaders hold chunks gc + 1 .. gc + 3 in registers (an
+  // L2 round trip is longer than a chunk's products: one chunk of look-ahead made every barrier wait for the loaders)
+  constexpr int DEPTH = LOADER ? 3 : 1;
+  sq_u32x4 pre[DEPTH][4];
+  int gc = 0, lc = 0;                // chunks consumed so far; the chunk of the cell step (0 .. NCH - 1) the loaders fetch next
+  auto load_chunk = [&](int set) {
+    const sq_u32x4* src = reinterpret_cast<const sq_u32x4*>(a.Wp + lc * SQ_CHUNK_DW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[set][i] = src[ll + 192 * i];
+    lc = lc + 1 == NCH ? 0 : lc + 1;
+  };
+  auto write_chunk = [&](int slot, int set) {
+    sq_u32x4* dst = reinterpret_cast<sq_u32x4*>(s.ring + slot * SQ_CHUNK_DW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[ll + 192 * i] = pre[set][i];
+  };
+  // one loader turn, while the MFMA wavefronts work on chunk gc: the oldest register set -> slot (gc + 1) & 1, the sets move up, a
+  // new chunk is requested into the youngest
+  auto loader_turn = [&]() {
+    write_chunk((gc + 1) & 1, 0);
+#pragma unroll
+    for (int d = 0; d + 1 < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[d][i] = pre[d + 1][i];
+    load_chunk(DEPTH - 1);
+  };
+  if constexpr (LOADER) {
+    load_chunk(0);
+    write_chunk(0, 0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_chunk(d);
+  }
+  float hprev[4][4];                 // H_{t-1} in the accumulator layout: [column tile][row i]
+  sq_f32x4 acc[8];
+
+  for (int b = (int)blockIdx.x; b < a.B; b += (int)gridDim.x) {
+    const int64_t m0 = (int64_t)b * N;
+    // ---- H_0 and X_0 into block A
+    sq_barrier();                    // (every lane is done with the blocks of the previous sample; first pass: operators staged)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = drow0 + i;
+        float h = 0.f;
+        if (consumer && r < N) {
+          if (a.H0) h = a.H0[(m0 + r) * SQ_O + 16 * ct + dcol];
+          s.bufA[r * SQ_PITCH + 16 * ct + dcol] = h;
+        }
+        hprev[ct][i] = h;
+      }
+    float2 xt = make_float2(0.f, 0.f), xn = make_float2(0.f, 0.f);
+    if (tid < N) {
+      const float* xp = a.X + (int64_t)b * a.xs_b + (int64_t)tid * Fin;
+      xt.x = xp[0];
+      if (Fin > 1) xt.y = xp[1];
+      *reinterpret_cast<pgt_f4*>(s.bufA + tid * SQ_PITCH + 64) = pgt_mk4(xt.x, xt.y, 0.f, 0.f);
+    }
+#pragma unroll 1
+    for (int t = 0; t < a.T; ++t) {
+      if (tid < N && t + 1 < a.T) {   // next step's input columns: requested a whole step ahead
+        const float* xp = a.X + (int64_t)b * a.xs_b + (int64_t)(t + 1) * a.xs_t + (int64_t)tid * Fin;
+        xn.x = xp[0];
+        if (Fin > 1) xn.y = xp[1];
+      }
+      // rows of this (sample, step) in the saved tensors: wave-uniform bases, 32-bit lane offsets
+      float* const zr_rows = a.ZR + ((int64_t)t * a.B * N + m0) * (2 * SQ_O);
+      float* const ht_rows = a.HT + ((int64_t)t * a.B * N + m0) * SQ_O;
+      float* const out_rows = a.out + (int64_t)b * a.os_b + (int64_t)t * a.os_t;
+
+      // ================================================================ one diffusion convolution + its gate chain
+      auto gate = [&](auto gtag) {
+        constexpr int G = decltype(gtag)::value;          // 0: update | reset gates (128 columns), 1: candidate (64 columns)
+        constexpr int NOUT = G == 0 ? 2 * SQ_O : SQ_O, NCT = NOUT / 16;
+        const float* const Wg = G == 0 ? a.Wzr : a.Wh;
+        const float* const bg = G == 0 ? a.bzr : a.bh;
+        float* const ts0 = (G == 0 ? a.TSzr : a.TSh) + (int64_t)t * a.t_stride + m0 * C;
+        sq_barrier();                // block A = T_0 of this convolution, complete
+        SQ_MARK(t, G, 0);
+        if (consumer) {              // the sums start from the bias (requested here, needed after the first hop)
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const float bias = bg ? bg[16 * ct + dcol] : 0.f;
+            acc[ct] = sq_f32x4{bias, bias, bias, bias};
+          }
+        }
+
+        // ---- products of one stack segment sitting in `buf` with its weight block (position `pos` of the consumption order)
+        auto mfma_seg = [&](const float* buf, int pos) {
+          // the segment's input columns: a rank-Fin update as ONE exact-fp32 MFMA per column tile — lane l supplies B[k = l / 16]
+          // [n = l % 16] = the weight row of input column k (zero for k >= Fin), requested here and used behind the first chunk
+          float xw[NCT];
+          int ol = lane;
+          SQ_OPAQUE(ol);             // (the lane's part of these addresses is recomputed here, not kept per segment across the time loop)
+          if (consumer) {
+            const float* const wx = Wg + (int64_t)(sq_seg_at(K, pos) * C) * NOUT;
+            const int xo = sq_min(ol >> 4, Fin - 1) * NOUT + (ol & 15);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) xw[ct] = (ol >> 4) < Fin ? wx[xo + 16 * ct] : 0.f;
+          }
+#pragma unroll 1
+          for (int kk = 0; kk < 2; ++kk) {
+            sq_u32x4 a1, a2, a3;
+            if (consumer) {
+              const pgt_f4 f0 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk);
+              const pgt_f4 f1 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk + 4);
+              uint32_t p1, p2, p3;
+              sq_split2_fast(f0.x, f0.y, p1, p2, p3); a1[0] = p1; a2[0] = p2; a3[0] = p3;
+              sq_split2_fast(f0.z, f0.w, p1, p2, p3); a1[1] = p1; a2[1] = p2; a3[1] = p3;
+              sq_split2_fast(f1.x, f1.y, p1, p2, p3); a1[2] = p1; a2[2] = p2; a3[2] = p3;
+              sq_split2_fast(f1.z, f1.w, p1, p2, p3); a1[3] = p1; a2[3] = p2; a3[3] = p3;
+              if (kk == 1) {
+                // (before the segment's last barrier, so that whoever rewrites the block afterwards cannot race with this read)
+                const float xa = (lane >> 4) < Fin ? buf[(aoff - 8 * (lane >> 4)) + 64 + (lane >> 4)] : 0.f;   // A[row][k = lane / 16]
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = sq_mfma4(xa, xw[ct], acc[ct]);
+              }
+            }
+#pragma unroll
+            for (int half = 0; half < NCT / 4; ++half) {
+              if (consumer) {
+                // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four)
+                const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (gc & 1) * SQ_CHUNK_DW) + lane;
+                sq_u32x4 bq[2][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                  if (ct < 3) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bq[(ct + 1) & 1][pl] = slot[((ct + 1) * 3 + pl) * 64];
+                  }
+                  const sq_u32x4 b1 = bq[ct & 1][0], b2 = bq[ct & 1][1], b3 = bq[ct & 1][2];
+                  sq_f32x4 c = acc[4 * half + ct];
+                  c = sq_mfma16(a3, b1, c);
+                  c = sq_mfma16(a1, b3, c);
+                  c = sq_mfma16(a2, b2, c);
+                  c = sq_mfma16(a2, b1, c);
+                  c = sq_mfma16(a1, b2, c);
+                  c = sq_mfma16(a1, b1, c);
+                  acc[4 * half + ct] = c;
+                  PGT_SCHED_FENCE();
+                }
+              }
+              if constexpr (LOADER) loader_turn();
+              ++gc;
+              sq_barrier();
+            }
+          }
+        };
+
+        // ---- hop 1: T1o = P_o T0 -> block B; T1i = P_i T0 and T0 itself wait in the saved stack (this thread's own stores,
+        // read back by the same thread) while block A is still being read by the products
+        int ot = tid;
+        SQ_OPAQUE(ot);
+#pragma unroll
+        for (int j = 0; j < SQ_MAXT; ++j) {
+          const SqTask k = sq_task(ot, j, N);
+          if (k.live) {
+            const int go = k.goff(C, Fin);
+            sq_store_quad(ts0 + go, k.hidden(), *reinterpret_cast<const pgt_f4*>(s.bufA + k.loff()));
+            const pgt_f4 o1 = sq_gather(s.rp_o, s.col_o, s.val_o, s.bufA, k.row, 4 * k.quad);
+            const pgt_f4 i1 = sq_gather(s.rp_i, s.col_i, s.val_i, s.bufA, k.row, 4 * k.quad);
+            *reinterpret_cast<pgt_f4*>(s.bufB + k.loff()) = o1;
+            sq_store_quad(ts0 + a.seg_stride + go, k.hidden(), o1);
+            sq_store_quad(ts0 + 2 * a.seg_stride + go, k.hidden(), i1);
+          }
+        }
+        sq_barrier();
+        SQ_MARK(t, G, 1);
+        mfma_seg(s.bufA, 0);
+        mfma_seg(s.bufB, 1);
+        SQ_MARK(t, G, 2);
+        if (K >= 3) {
+          // ---- hop 2, first direction: T2o = 2 P_o T1o - T0 -> block A (T_0 is dead in LDS)
+          ot = tid;
+          SQ_OPAQUE(ot);
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N);
+            if (k.live) {
+              const int go = k.goff(C, Fin);
+              const pgt_f4 t0 = sq_load_quad(ts0 + go, k.hidden());
+              const pgt_f4 o2 = sq_two_minus(sq_gather(s.rp_o, s.col_o, s.val_o, s.bufB, k.row, 4 * k.quad), t0);
+              *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = o2;
+              sq_store_quad(ts0 + 3 * a.seg_stride + go, k.hidden(), o2);
+            }
+          }
+          // T1i comes back from the saved stack: requested here, a product phase ahead of its use
+          pgt_f4 i1[SQ_MAXT];
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N);
+            i1[j] = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+            if (k.live) i1[j] = sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
+          }
+          sq_barrier();
+          SQ_MARK(t, G, 3);
+          mfma_seg(s.bufA, 2);
+          SQ_MARK(t, G, 4);
+          ot = tid;
+          SQ_OPAQUE(ot);
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N);
+            if (k.live) *reinterpret_cast<pgt_f4*>(s.bufB + k.loff()) = i1[j];
+          }
+          sq_barrier();
+          SQ_MARK(t, G, 5);
+          // ---- hop 2, second direction: T2i = 2 P_i T1i - T0 -> block A
+          ot = tid;
+          SQ_OPAQUE(ot);
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N);
+            if (k.live) {
+              const int go = k.goff(C, Fin);
+              const pgt_f4 t0 = sq_load_quad(ts0 + go, k.hidden());
+              const pgt_f4 i2 = sq_two_minus(sq_gather(s.rp_i, s.col_i, s.val_i, s.bufB, k.row, 4 * k.quad), t0);
+              *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = i2;
+              sq_store_quad(ts0 + 4 * a.seg_stride + go, k.hidden(), i2);
+            }
+          }
+          sq_barrier();
+          SQ_MARK(t, G, 6);
+          mfma_seg(s.bufB, 3);
+          mfma_seg(s.bufA, 4);
+        } else {
+          ot = tid;
+          SQ_OPAQUE(ot);
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N);
+            if (k.live) *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
+          }
+          sq_barrier();
+          mfma_seg(s.bufA, 2);
+        }
+        SQ_MARK(t, G, 7);
+        // ---- gate chain on the accumulators (every product of this convolution is behind a barrier: both blocks are free)
+        int orow = drow0;
+        SQ_OPAQUE(orow);
+        if (G == 0) {
+          if (consumer) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int r = orow + i;
+                const float g = sq_sigmoidf(acc[ct][i]);
+                if (r < N) {
+                  if (ct >= 4) s.bufA[r * SQ_PITCH + 16 * (ct & 3) + dcol] = hprev[ct & 3][i] * g;     // H * R: the candidate's T_0
+                  zr_rows[r * (2 * SQ_O) + 16 * ct + dcol] = g;
+                }
+              }
+            }
+          }
+          if (tid < N) *reinterpret_cast<pgt_f4*>(s.bufA + tid * SQ_PITCH + 64) = pgt_mk4(xt.x, xt.y, 0.f, 0.f);
+        } else {
+          if (consumer) {
+            float z[4][4];           // Z of this step: stored by this very lane in the update / reset epilogue, read back instead of held
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) z[ct][i] = zr_rows[sq_min(orow + i, N - 1) * (2 * SQ_O) + 16 * ct + dcol];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int r = orow + i;
+                const float ht = sq_tanhf(acc[ct][i]);
+                const float hn = pgt_gru_blend(z[ct][i], hprev[ct][i], ht);
+                hprev[ct][i] = hn;
+                if (r < N) {
+                  s.bufA[r * SQ_PITCH + 16 * ct + dcol] = hn;                                 // the next step's T_0
+                  out_rows[r * SQ_O + 16 * ct + dcol] = hn;
+                  ht_rows[r * SQ_O + 16 * ct + dcol] = ht;
+                }
+              }
+            }
+          }
+          xt = xn;
+          if (tid < N) *reinterpret_cast<pgt_f4*>(s.bufA + tid * SQ_PITCH + 64) = pgt_mk4(xt.x, xt.y, 0.f, 0.f);
+        }
+        SQ_MARK(t, G, 8);
+      };
+      gate(SqInt<0>{});
+      gate(SqInt<1>{});
+    }
+  }
+}
+
+__global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq64_fwd_kernel(Seq64Args a) {
+  __shared__ __attribute__((aligned(16))) char smem[SQ_LDS];
+  if ((int)(threadIdx.x >> 6) >= SQ_LOADER0) sq_fwd_body<true>(a, smem);
+  else sq_fwd_body<false>(a, smem);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------- C ABI
+extern "C" int pgt_dcrnn_seq64_fits(int64_t N, int64_t E_o, int64_t E_i, int64_t Fin, int64_t O, int64_t K) {
+  if (O != SQ_O || Fin != 2 || (K != 2 && K != 3) || N < 1 || E_o < 0 || E_i < 0) return 0;
+  if ((N + 15) / 16 > SQ_LOADER0 || 17 * N > SQ_MAXT * SQ_THREADS) return 0;
+  if (E_o > 65535 || E_i > 65535) return 0;
+  return sq_lds_bytes(N, E_o, E_i) <= (size_t)SQ_LDS ? 1 : 0;
+}
+
+extern "C" int64_t pgt_dcrnn_seq64_pack_floats(int64_t K) { return (int64_t)sq_nchunks((int)K) * SQ_CHUNK_DW; }
+
+extern "C" int pgt_dcrnn_seq64_pack_f32(const float* Wzr, const float* Wh, int64_t Fin, int64_t K, float* Wp, pgt_stream_t stream) {
+  PGT_REQUIRE(Wzr && Wh && Wp, "pgt_dcrnn_seq64_pack_f32: null pointer");
+  PGT_REQUIRE(Fin == 2 && (K == 2 || K == 3), "pgt_dcrnn_seq64_pack_f32: Fin = 2 and K = 2 | 3 only");
+  const int total = sq_nchunks((int)K) * 4 * 64 * 4;
+  PGT_LAUNCH(seq64_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, Wzr, Wh, (int)Fin, (int)K,
+             reinterpret_cast<uint32_t*>(Wp));
+  return pgt_check_launch("pgt_dcrnn_seq64_pack_f32");
+}
+
+extern "C" int pgt_dcrnn_seq64_f32(const pgt_csr* op_o, const pgt_csr* op_i, int64_t E_o, int64_t E_i, int64_t N, const float* X,
+                                   int64_t x_stride_b, int64_t x_stride_t, const float* H0, const float* Wp, const float* Wzr,
+                                   const float* bzr, const float* Wh, const float* bh, int64_t B, int64_t T, int64_t Fin, int64_t K,
+                                   float* out, int64_t out_stride_b, int64_t out_stride_t, float* TSzr, float* TSh,
+                                   int64_t seg_stride, int64_t t_stride, float* ZR, float* HT, pgt_stream_t stream) {
+  PGT_REQUIRE(op_o && op_i && X && Wp && Wzr && Wh && out, "pgt_dcrnn_seq64_f32: null pointer");
+  PGT_REQUIRE(pgt_dcrnn_seq64_fits(N, E_o, E_i, Fin, SQ_O, K), "pgt_dcrnn_seq64_f32: shape not covered (pgt_dcrnn_seq64_fits)");
+  PGT_REQUIRE(B >= 0 && T >= 0, "pgt_dcrnn_seq64_f32: negative extent");
+  PGT_REQUIRE(TSzr && TSh && ZR && HT, "pgt_dcrnn_seq64_f32: the saved tensors double as the kernel's own parking space (T_0, T_1^i, Z)");
+  PGT_REQUIRE(pgt_aligned(Wp, 16), "pgt_dcrnn_seq64_f32: the packed weights must be 16-byte aligned");
+  PGT_REQUIRE(pgt_aligned(TSzr, 8) && pgt_aligned(TSh, 8) && seg_stride % 2 == 0 && t_stride % 2 == 0,
+              "pgt_dcrnn_seq64_f32: the saved stacks must be 8-byte aligned with even strides");
+  if (B == 0 || T == 0) return PGT_OK;
+  Seq64Args a;
+  a.rp_o = op_o->rowptr; a.col_o = op_o->col; a.val_o = op_o->val;
+  a.rp_i = op_i->rowptr; a.col_i = op_i->col; a.val_i = op_i->val;
+  a.N = (int)N; a.Fin = (int)Fin; a.K = (int)K; a.T = (int)T; a.B = (int)B; a.nnz_o = (int)E_o; a.nnz_i = (int)E_i;
+  a.X = X; a.xs_b = x_stride_b; a.xs_t = x_stride_t; a.H0 = H0;
+  a.Wp = reinterpret_cast<const uint32_t*>(Wp); a.Wzr = Wzr; a.Wh = Wh; a.bzr = bzr; a.bh = bh;
+  a.out = out; a.os_b = out_stride_b; a.os_t = out_stride_t;
+  a.TSzr = TSzr; a.TSh = TSh; a.seg_stride = seg_stride; a.t_stride = t_stride; a.ZR = ZR; a.HT = HT;
+  const int nblk = (int)(B < SQ_CUS ? B : SQ_CUS);
+  PGT_LAUNCH(dcrnn_seq64_fwd_kernel, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
+  return pgt_check_launch("pgt_dcrnn_seq64_f32");
+}

@@ -32,7 +32,9 @@ class _StatesTensor(torch.Tensor):
                                                             b.dtype == torch.float32 and b.device == w.device))):
                 from .conv import _rows_in_memory_order
                 pre = getattr(x, "_pgt_pre", None)
-                if pre is not None and pre[0]._version == pre[1] and ops.readout_fits(x, w, b):
+                # (the fused pass recomputes the relu from the states: only while neither the states nor the relu's own result —
+                # h.mul_(2), F.dropout(h, inplace=True) — were written since)
+                if pre is not None and pre[0]._version == pre[1] and x._version == pre[2] and ops.readout_fits(x, w, b):
                     # linear(relu(states)): one pass each way over the PRE-relu states (csrc/readout.hip) — relu, the product, and in
                     # the adjoint relu's mask, the input gradient and the weight gradient together.  The relu tensor itself exists
                     # (it was computed when the caller asked for it) and is an ordinary operand for anything else done with it.
@@ -49,10 +51,13 @@ class _StatesTensor(torch.Tensor):
         if func in cls._RELUS and not kwargs.get("inplace", False) and isinstance(out, torch.Tensor) and \
                 type(args[0]) is _StatesTensor:
             res = out.as_subclass(_StatesTensor)
-            if getattr(args[0], "_pgt_pre", None) is None:        # (relu of a relu: the inner one stays the reference point)
-                res._pgt_pre = (args[0], args[0]._version)          # the states this is the relu of, and their version then
-            else:
-                res._pgt_pre = args[0]._pgt_pre
+            inner = getattr(args[0], "_pgt_pre", None)
+            if inner is None:
+                # the states this is the relu of, their version then, and the version of the relu's own result
+                res._pgt_pre = (args[0], args[0]._version, res._version)
+            elif inner[0]._version == inner[1] and args[0]._version == inner[2]:
+                # relu of an untouched relu: the inner states stay the reference point (relu is idempotent)
+                res._pgt_pre = (inner[0], inner[1], res._version)
             return res
         return _plain(out)
 

@@ -159,6 +159,11 @@ class BatchedDCRNN(torch.nn.Module):
             # narrow states on a small graph (the reference's own BatchedDCRNN(2, 2, K = 3), pems_ddp.py:80): the whole 12-step
             # sequence of a sample in one workgroup, ONE launch forward and one backward (csrc/seq_small.hip)
             return self._states(ops.DCRNNSeqSmallFunction.apply(X, None, Wzr, bzr, Wh, bh, g, self.K))
+        if ops.USE_SEQ64 and B >= ops.SEQ64_MIN_BATCH and X.dtype == torch.float32 and ops.seq64_fits(g, Fin, O, self.K):
+            # hidden width 64 on a graph whose block fits a CU's LDS (the benchmarked BatchedDCRNN(2, 64, K = 3) on METR-LA's 207
+            # sensors): all T steps of every sample in ONE launch, the diffusion terms and the products never leave the CU
+            # (csrc/seq64.hip); the backward pass is the general path's BPTT on what the launch saved
+            return self._states(ops.DCRNNSeq64Function.apply(X, None, Wzr, bzr, Wh, bh, g, self.K))
         if ops.slab_fits(g, Fin + O, self.K):
             # small graph: batch-major rows m = b*N + n; every diffusion stack is ONE LDS-resident launch.
             # [B][T][N*F] -> [T][B][N*F]

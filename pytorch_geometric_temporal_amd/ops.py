@@ -257,7 +257,8 @@ class DConvGraph:
         lib.call("pgt_dconv_prep", ptr(ei), ptr(ew), E, N, ctypes.byref(st), ptr(ws), ws_bytes, stream_of(lib, ei))
         measure_locality((self.fwd_o, self.fwd_i, self.bwd_o, self.bwd_i))
         if validate:
-            dup, zero, oob, _ = self.info.tolist()  # one host sync per *new* graph
+            dup, zero, oob, nonfinite = self.info.tolist()  # one host sync per *new* graph
+            self.finite = nonfinite == 0          # every coefficient of both operators is finite (no node without in- / out-edges)
             if oob:
                 raise IndexError(f"edge_index has {oob} endpoint(s) outside [0, {N})")
             if strict_dense and (dup or zero):
@@ -1494,6 +1495,87 @@ class DCRNNSeqFunction(torch.autograd.Function):
         return dX, dH0, dWzr, dbzr, dWh, dbh, None, None, None, None, None
 
 
+# hidden width 64 on a graph whose block fits a CU's LDS: the whole T-step forward of every sample in ONE launch (csrc/seq64.hip);
+# PGT_SEQ64=0 = the per-step launches of DCRNNSeqFunction (A/B)
+USE_SEQ64 = os.environ.get("PGT_SEQ64", "1") != "0"
+# smallest batch that takes it: a sample occupies ONE CU for the whole sequence, so below ~100 samples the per-step launches —
+# which spread every step over all 256 CUs — are faster (B = 64: 0.82 ms against 0.98 ms forward; B = 256: 1.68 against 1.11)
+SEQ64_MIN_BATCH = int(os.environ.get("PGT_SEQ64_MIN_B", "96"))
+
+
+def seq64_fits(g, Fin, O, K):
+    """Whether pgt_dcrnn_seq64_f32 takes this graph / width: hidden 64, two input channels, K = 2 | 3, the sample's block + both
+    operators + the weight ring within a CU's LDS — and finite operator coefficients (a node without incoming edges makes
+    DConv's 1 / deg infinite, dcrnn.py:71-77: inf / nan placement is the general path's speciality, csrc/gemm_bx.hip)."""
+    return bool(getattr(g, "finite", False)) and bool(_lib.get_lib()._pgt_dcrnn_seq64_fits(g.N, g.E, g.E, int(Fin), int(O), int(K)))
+
+
+class DCRNNSeq64Function(torch.autograd.Function):
+    """BatchedDCRNN.forward at hidden width 64 (dcrnn.py:429-475): X [B, T, N, Fin], H0 [B * N, O] | None -> [B, T, N, O] in ONE
+    launch for all T steps (csrc/seq64.hip: one workgroup per sample, diffusion terms and products never leave the CU); the
+    launch leaves behind exactly what DCRNNSeqFunction.forward saves (both stacks, Z | R, the candidates, the states in the
+    reference's layout), so the hand-written BPTT of DCRNNSeqFunction.backward runs on it unchanged."""
+
+    @staticmethod
+    def forward(ctx, X, H0, Wzr, bzr, Wh, bh, g, K):
+        lib = _lib.get_lib()
+        check_tensor(lib, X, "X")
+        if X.dim() != 4:
+            raise ValueError(f"DCRNNSeq64Function: X must be [B, T, N, in], got {tuple(X.shape)}")
+        B, T, N, Fin = X.shape
+        O = Wh.size(1)
+        S, C = 2 * K - 1, Fin + O
+        M = B * N
+        if N != g.N:
+            raise ValueError(f"X has {N} nodes, the graph {g.N}")
+        if Wzr.shape != (S * C, 2 * O) or Wh.shape != (S * C, O):
+            raise ValueError(f"DCRNNSeq64Function: inconsistent operand shapes: X has {Fin} input channels, the stacked weights "
+                             f"{tuple(Wzr.shape)} / {tuple(Wh.shape)} (K = {K})")
+        if (bzr is not None and bzr.shape != (2 * O,)) or (bh is not None and bh.shape != (O,)):
+            raise ValueError("DCRNNSeq64Function: inconsistent bias shapes")
+        if not lib._pgt_dcrnn_seq64_fits(N, g.E, g.E, Fin, O, K):
+            raise ValueError("DCRNNSeq64Function: shape not covered (seq64_fits)")
+        dev = X.device
+        Xc = X.contiguous()
+        H0c = None
+        if H0 is not None:
+            check_tensor(lib, H0, "H0")
+            if H0.shape != (M, O):
+                raise ValueError(f"H0 must be {(M, O)}, got {tuple(H0.shape)}")
+            H0c = H0.contiguous()
+        Wzr_c, Wh_c = Wzr.contiguous(), Wh.contiguous()
+        Wp = torch.empty(int(lib._pgt_dcrnn_seq64_pack_floats(K)), dtype=F32, device=dev)
+        lib.call("pgt_dcrnn_seq64_pack_f32", ptr(Wzr_c), ptr(Wh_c), Fin, K, ptr(Wp), stream_of(lib, Wp))
+        TSzr = torch.empty(S, T, M, C, dtype=F32, device=dev)
+        TSh = torch.empty(S, T, M, C, dtype=F32, device=dev)
+        ZR = torch.empty(T, M, 2 * O, dtype=F32, device=dev)
+        HT = torch.empty(T, M, O, dtype=F32, device=dev)
+        Hout = torch.empty(B, T, N, O, dtype=F32, device=dev)
+        so, si = g.fwd_o.struct(), g.fwd_i.struct()
+        work = 4.0 * (Xc.numel() + Hout.numel() + TSzr.numel() + TSh.numel() + ZR.numel() + HT.numel()) if KERNEL_TIMER else 0
+        _timed("seq64", work, lambda: lib.call(
+            "pgt_dcrnn_seq64_f32", ctypes.byref(so), ctypes.byref(si), g.E, g.E, N, ptr(Xc), T * N * Fin, N * Fin, ptr(H0c), ptr(Wp),
+            ptr(Wzr_c), ptr(bzr), ptr(Wh_c), ptr(bh), B, T, Fin, K, ptr(Hout), T * N * O, N * O, ptr(TSzr), ptr(TSh), T * M * C, M * C,
+            ptr(ZR), ptr(HT), stream_of(lib, Hout)), tag=("fwd", B, T, N))
+        if any(ctx.needs_input_grad):
+            if H0c is None:
+                H0c = torch.zeros(M, O, dtype=F32, device=dev)
+            ctx.g, ctx.K, ctx.B, ctx.Fin, ctx.slab = g, K, B, Fin, True
+            ctx.btno, ctx.batch_major = True, True
+            ctx.has_bias = (bzr is not None, bh is not None)
+            ctx.dims = (B, T, N, Fin)
+            ctx.save_for_backward(TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c)
+        return Hout
+
+    @staticmethod
+    def backward(ctx, dOut):
+        dX, dH0, dWzr, dbzr, dWh, dbh = DCRNNSeqFunction.backward(ctx, dOut)[:6]
+        if dX is not None:                                     # [T, B N, Fin] (time-major steps of batch-major rows) -> X's layout
+            B, T, N, Fin = ctx.dims
+            dX = dX.view(T, B, N, Fin).permute(1, 0, 2, 3).contiguous()
+        return dX, dH0, dWzr, dbzr, dWh, dbh, None, None
+
+
 # --------------------------------------------------------------------------------------------- generic building blocks
 
 class SpmmFunction(torch.autograd.Function):
@@ -1625,29 +1707,42 @@ def readout(x, weight, bias, relu):
 
 # --------------------------------------------------------------------------------------------- T-GCN cell
 
+def _graph_task():
+    """Identity of the backward walk in flight (-1 outside one): what a deposit is stamped with."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
+
+
 class _PackDeposit:
     """Where the fused T-GCN cells that share one set of folded operands (nn/_states.py packed_once) sum their weight / bias
     gradients: one [dWzr | dWh | dbzr | dbh] buffer the adjoint kernels ACCUMULATE into (pgt_tgcn_cell_bwd_acc_f32).  Every cell
-    returns None for the four operands to autograd — except the first one to run, which hands out the buffer's dbh slice: one
-    defined gradient is what makes the engine call TGCNWeightsFunction.backward once all the cells have run, and that is where the
-    sums are taken from (`take`).  Cells that did not run (a loss that does not reach them) simply never deposited."""
+    returns None for the four operands to autograd — except the first one to run in a backward walk, which hands out a ZERO dbh of
+    its own: one defined gradient is what makes the engine call TGCNWeightsFunction.backward once all the cells of that walk have
+    run, and that is where the sums are taken from (`take`) and ADDED to whatever autograd itself brought (cells of the same pack
+    on the non-deposit path).  The buffer belongs to ONE walk: it is stamped with the engine's graph-task id, and a deposit that
+    meets another walk's buffer (torch.autograd.grad w.r.t. H0 never reaches the weights node; a backward that raised half way)
+    starts over instead of accumulating onto it.  Cells that did not run (a loss that does not reach them) never deposited."""
 
     def __init__(self):
-        self.buf, self.views = None, None
+        self.buf, self.views, self.task = None, None, None
 
     def slot(self, C, O, device):
-        """(views dWzr, dbzr, dWh, dbh of the buffer, first): `first` = nothing deposited yet (the kernel stores)."""
-        first = self.buf is None
+        """(views dWzr, dbzr, dWh, dbh of the buffer, first): `first` = nothing deposited in THIS walk yet (the kernel stores)."""
+        task = _graph_task()
+        first = self.buf is None or self.task != task
         if first:
             self.buf = torch.empty(C * 3 * O + 3 * O, dtype=F32, device=device)
             b = self.buf
             self.views = (b[:C * 2 * O].view(C, 2 * O), b[C * 3 * O:C * 3 * O + 2 * O], b[C * 2 * O:C * 3 * O].view(C, O),
                           b[C * 3 * O + 2 * O:])
+            self.task = task
         return self.views, first
 
     def take(self):
-        v, self.buf, self.views = self.views, None, None
-        return v
+        """The sums of the walk in flight (None if its cells deposited nothing; another walk's leftovers are dropped)."""
+        v, stale = self.views, self.task != _graph_task()
+        self.buf, self.views, self.task = None, None, None
+        return None if stale else v
 
 
 class TGCNWeightsFunction(torch.autograd.Function):
@@ -1718,7 +1813,9 @@ class TGCNWeightsFunction(torch.autograd.Function):
             dWzr = dep[0] if dWzr is None else dWzr + dep[0]
             dbzr = dep[1] if dbzr is None else dbzr + dep[1]
             dWh = dep[2] if dWh is None else dWh + dep[2]
-            dbh = dep[3]                                      # (the incoming dbh IS the deposit's slice: the first cell handed it out)
+            # the incoming dbh = the first cell's zero trigger + whatever cells on the non-deposit path returned (autograd sums
+            # them out of place): the deposit is added to it, never substituted for it
+            dbh = dep[3] if dbh is None else dbh + dep[3]
         if dWzr is None and dbzr is None and dWh is None and dbh is None:
             return (None,) * 12
         Fin, O = ctx.dims
@@ -1850,9 +1947,10 @@ class TGCNCellFunction(torch.autograd.Function):
                     entry, gp, ldg, ptr(AX), Fin, hp, ldh, ptr(ZR), ptr(HT), ptr(Wzr_c), ptr(Wh_c), M, Fin, O,
                     ptr(dH), O, ptr(dWzr), ptr(dbzr), ptr(dWh), ptr(dbh), ptr(ws), nws, stream_of(lib, dH)), tag=("bwd", M, Fin, O))
                 if dep is not None:
-                    # summed in the deposit; the first cell's dbh (a slice of it) is the one defined gradient that brings autograd to
-                    # TGCNWeightsFunction.backward, which reads the deposit
-                    return None, (dH if need[1] else None), None, None, None, (dbh if first else None), None, None, None
+                    # summed in the deposit; the first cell's zero dbh is the one defined gradient that brings autograd to
+                    # TGCNWeightsFunction.backward, which reads the deposit (never a slice of the deposit itself: autograd may add
+                    # other cells' gradients to it out of place)
+                    return None, (dH if need[1] else None), None, None, None, (torch.zeros_like(dbh) if first else None), None, None, None
                 return None, (dH if need[1] else None), dWzr, dbzr, dWh, dbh, None, None, None
             # the input gradient is wanted: rebuild the unfused operands ([AX | H], [AX | H * R]) and run the general adjoint
             XH = torch.empty(M, C, dtype=F32, device=dev)

@@ -1,0 +1,5 @@
+#!/bin/bash
+# build products are shipped; this runs the seq64 probe + phase trace on the GPU box
+cd "${GRAFT_REPO_ROOT:-.}"
+python scripts/seq64_probe.py ${PROBE_B:-64 256 1024} 2>&1 | grep -v amdgpu.ids
+python scripts/seq64_trace.py ${TRACE_B:-256} 2>&1 | grep -v amdgpu.ids

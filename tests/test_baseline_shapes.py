@@ -41,11 +41,22 @@ def _params64(g):
 
 # ------------------------------------------------------------------------------------------------ config 2
 
+@pytest.fixture(params=["per_step_launches", "one_launch_sequences"])
+def dcrnn64_path(request):
+    """Both forward paths of the hidden-64 model at B = 64: the per-step launches (the default below SEQ64_MIN_BATCH samples) and
+    the one-launch sequence kernel (csrc/seq64.hip, the default from there on: what bench.py's B = 1024 runs)."""
+    from pytorch_geometric_temporal_amd import ops
+    keep = (ops.USE_SEQ64, ops.SEQ64_MIN_BATCH)
+    ops.USE_SEQ64, ops.SEQ64_MIN_BATCH = request.param == "one_launch_sequences", 1
+    yield request.param
+    ops.USE_SEQ64, ops.SEQ64_MIN_BATCH = keep
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("E", [1515, 1722])
-def test_config2_benchmarked_dcrnn_forward_matches_reference_fixture(E):
+def test_config2_benchmarked_dcrnn_forward_matches_reference_fixture(E, dcrnn64_path):
     """BatchedDCRNN(2, 64, K=3), 207 nodes, B = 64 x 12 steps: the model bench.py times, through the slab kernels at
-    C = 66 and the gate-fused GEMMs, against the reference module's output."""
+    C = 66 and the gate-fused GEMMs — and through the one-launch sequence kernel —, against the reference module's output."""
     dev = torch.device("cuda:0")
     g = load_golden("baseline_c2_batched_dcrnn64")
     ei, ew, X = BC.metrla(E)
@@ -62,7 +73,7 @@ def test_config2_benchmarked_dcrnn_forward_matches_reference_fixture(E):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("E", [1515, 1722])
-def test_config2_benchmarked_dcrnn_gradients_match_fp64_oracle(E):
+def test_config2_benchmarked_dcrnn_gradients_match_fp64_oracle(E, dcrnn64_path):
     """Every parameter gradient of the benchmarked model (hidden 64, B = 64) against autograd through the fp64 oracle
     (op for op the reference).  dW comes from fp32 atomics: tolerance 2e-4 of the gradient's scale."""
     dev = torch.device("cuda:0")

@@ -547,6 +547,85 @@ def test_one_workgroup_sequence_kernels_equal_the_general_path(backend, Fin, O, 
         assert_close_with_nonfinite(res[True][2][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, k)
 
 
+@pytest.mark.parametrize("n,E,K,B,T,bias,x_grad", [(37, 251, 3, 3, 3, True, False),     # ragged last row tile, odd slot counts
+                                                     (48, 300, 2, 2, 2, True, False),     # K = 2: three segments
+                                                     (21, 120, 3, 5, 2, False, True)])    # no bias; the input wants a gradient
+def test_hidden_64_sequences_in_one_launch_equal_the_per_step_launches(backend, n, E, K, B, T, bias, x_grad):
+    """csrc/seq64.hip (all T steps of a sample in one workgroup: hops out of LDS, split-bf16 products on the terms while they
+    are there, gate chains on the accumulators) against the per-step launches of ops.DCRNNSeqFunction: the states, and — through
+    the general backward on what the launch saved — dX and every parameter gradient.  The diffusion terms it saves must be the
+    per-step path's bit for bit (the same fmaf chain in slot order)."""
+    from pytorch_geometric_temporal_amd import ops
+    torch.manual_seed(n + K)
+    ei_np, ew_np = syn.sensor_graph(n, E, seed=2, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    m = BatchedDCRNN(2, 64, K, bias=bias).to(backend.device)
+    m.readout_interception = False                 # plain tensors: the result's grad_fn is the sequence function itself
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.2, 0.2)
+    X = torch.randn(B, T, n, 2)
+    w = backend.t(torch.randn(B, T, n, 64))
+    g = ops.dconv_graph(ei, ew, n)
+    assert ops.seq64_fits(g, 2, 64, K)
+    res, saved = {}, {}
+    keep = (ops.USE_SEQ64, ops.SEQ64_MIN_BATCH)
+    try:
+        for one_launch in (True, False):
+            ops.USE_SEQ64, ops.SEQ64_MIN_BATCH = one_launch, 1
+            m.zero_grad()
+            Xd = backend.t(X).requires_grad_(x_grad)
+            out = m(Xd, ei, ew)
+            saved[one_launch] = [t.clone() for t in out.grad_fn.saved_tensors[:4]]   # both stacks, Z | R, the candidates
+            (out * w).sum().backward()
+            res[one_launch] = (out.detach().clone(), Xd.grad.clone() if x_grad else None,
+                               {k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        ops.USE_SEQ64, ops.SEQ64_MIN_BATCH = keep
+    assert_close_with_nonfinite(res[True][0], res[False][0], 3e-6, 1e-5, "states")
+    # segment 0 of step 0 of the gate stack = [X_0 | H_0]: identical inputs -> every term of that step identical
+    assert torch.equal(saved[True][0][:, 0], saved[False][0][:, 0]), "diffusion terms of the first step"
+    for a, b, what in zip(saved[True], saved[False], ("gate stack", "candidate stack", "Z | R", "candidates")):
+        assert_close_with_nonfinite(a, b, 5e-6, 1e-5, what)
+    if x_grad:
+        assert_close_with_nonfinite(res[True][1], res[False][1], 1e-5, 1e-4, "dX")
+    for k in res[True][2]:
+        ref = res[False][2][k]
+        assert_close_with_nonfinite(res[True][2][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, k)
+
+
+def test_hidden_64_one_launch_path_is_taken_only_where_it_applies(backend):
+    """Dispatch: hidden width 64 with two input channels on a graph with finite coefficients from SEQ64_MIN_BATCH samples on; a node
+    without incoming edges (infinite 1 / deg, dcrnn.py:71-77) keeps the per-step launches, whose products place inf / nan like the
+    reference's."""
+    from pytorch_geometric_temporal_amd import ops
+    ei_np, ew_np = syn.sensor_graph(30, 170, seed=1, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    g = ops.dconv_graph(ei, ew, 30)
+    assert g.finite and ops.seq64_fits(g, 2, 64, 3) and ops.seq64_fits(g, 2, 64, 2)
+    assert not ops.seq64_fits(g, 2, 32, 3) and not ops.seq64_fits(g, 3, 64, 3) and not ops.seq64_fits(g, 2, 64, 4)
+    src = torch.tensor([0, 1, 2, 3, 4, 5]); dst = torch.tensor([1, 2, 3, 4, 5, 1])          # node 0 has no incoming edge
+    g2 = ops.dconv_graph(backend.t(torch.stack([src, dst])), None, 6)
+    assert not g2.finite and not ops.seq64_fits(g2, 2, 64, 3)
+    calls = []
+    orig = ops.DCRNNSeq64Function.apply
+    try:
+        ops.DCRNNSeq64Function.apply = staticmethod(lambda *a: calls.append(1) or orig(*a))
+        m = BatchedDCRNN(2, 64, 3).to(backend.device)
+        keep = ops.SEQ64_MIN_BATCH
+        ops.SEQ64_MIN_BATCH = 3
+        try:
+            with torch.no_grad():
+                m(backend.t(torch.randn(2, 2, 30, 2)), ei, ew)
+                assert not calls
+                m(backend.t(torch.randn(3, 2, 30, 2)), ei, ew)
+                assert len(calls) == 1
+        finally:
+            ops.SEQ64_MIN_BATCH = keep
+    finally:
+        ops.DCRNNSeq64Function.apply = orig
+
+
 @pytest.mark.parametrize("K,hidden", [(2, True), (3, True), (3, False)])
 def test_dcrnn_cell_with_hops_on_a_small_graph_is_one_launch_each_way(backend, K, hidden):
     """DCRNN(in, out, K > 1) on a graph of tens of nodes (Chickenpox; test/recurrent_test.py:274-315 uses K = 2, 3): one

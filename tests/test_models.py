@@ -1011,6 +1011,82 @@ def test_tgcn2_states_route_the_reference_examples_readout(backend):
         assert_close_with_nonfinite(head(r), want, 1e-6, 1e-5, "in-place edit of the states after relu")
 
 
+def test_readout_after_an_in_place_edit_of_the_relu_is_not_fused(backend):
+    """`r = relu(h); r.mul_(2); linear(r)` (or an in-place dropout of r): the fused read-out recomputes the relu from the states,
+    so it may only run while the relu's OWN result is untouched as well (its version is recorded with the states')."""
+    import torch.nn.functional as TF
+    torch.manual_seed(4)
+    n, B, O = 13, 2, 32
+    ei_np, ew_np = syn.sensor_graph(n, 60, seed=1, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    cell = TGCN2(2, O, 1).to(backend.device)
+    head = torch.nn.Linear(O, 2).to(backend.device)
+    x = backend.t(torch.randn(B, n, 2))
+    with torch.no_grad():
+        h = cell(x, ei, ew, None)
+        for edit in (lambda r: r.mul_(2.0), lambda r: r[..., :16].zero_(), lambda r: TF.dropout(r, 0.5, True, inplace=True)):
+            r = TF.relu(h)
+            edit(r)
+            want = TF.linear(r.as_subclass(torch.Tensor).clone(), head.weight, head.bias)
+            assert_close_with_nonfinite(head(r), want, 1e-6, 1e-5, "read-out of an edited relu")
+        r = TF.relu(TF.relu(h))                       # relu of an untouched relu: still the fused pass, same values
+        assert_close_with_nonfinite(head(r), TF.linear(torch.relu(h.as_subclass(torch.Tensor)), head.weight, head.bias), 1e-6, 1e-5, "relu twice")
+
+
+def test_tgcn_weight_gradients_survive_a_walk_that_never_reaches_the_weights(backend):
+    """The fused cells of one pack sum their weight gradients in a side buffer that TGCNWeightsFunction.backward collects.  A
+    backward walk that stops short of the weights (torch.autograd.grad w.r.t. H0) must not leave its sums behind for the next
+    walk to build on, and a cell of the same pack on the non-deposit path (its input wants a gradient) must not lose its bias
+    gradient to the deposit's."""
+    from pytorch_geometric_temporal_amd import ops
+    torch.manual_seed(5)
+    n, O = 19, 32
+    ei_np, ew_np = syn.sensor_graph(n, 90, seed=3, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    m = TGCN(2, O).to(backend.device)
+    x, x2 = backend.t(torch.randn(n, 2)), backend.t(torch.randn(n, 2))
+    h0 = backend.t(torch.randn(n, O)).requires_grad_()
+
+    def grads(fused, first_walk):
+        ops.USE_TGCN_FUSED = fused
+        try:
+            m.zero_grad()
+            out = m(x, ei, ew, m(x, ei, ew, h0))
+            if first_walk:
+                torch.autograd.grad(out.sum(), h0, retain_graph=True)
+            out.sum().backward()
+            return {k: p.grad.clone() for k, p in m.named_parameters()}
+        finally:
+            ops.USE_TGCN_FUSED = True
+
+    ref = grads(False, False)
+    for first_walk in (False, True):
+        got = grads(True, first_walk)
+        for k in ref:
+            assert_close_with_nonfinite(got[k], ref[k], 2e-5 * float(ref[k].abs().max()) + 1e-7, 1e-4, f"{k} (walk to H0 first: {first_walk})")
+
+    class Loop(torch.nn.Module):                      # one outermost call -> one pack for the three cells
+        def __init__(self):
+            super().__init__()
+            self.cell = m
+
+        def forward(self, xa, xb):
+            return self.cell(xa, ei, ew, None) + self.cell(xa, ei, ew, None) + self.cell(xb, ei, ew, None)
+
+    loop = Loop()
+    res = {}
+    for fused in (True, False):
+        ops.USE_TGCN_FUSED = fused
+        try:
+            m.zero_grad()
+            loop(x, x2.clone().requires_grad_()).sum().backward()
+            res[fused] = {k: p.grad.clone() for k, p in m.named_parameters()}
+        finally:
+            ops.USE_TGCN_FUSED = True
+    for k in res[False]:
+        assert_close_with_nonfinite(res[True][k], res[False][k], 2e-5 * float(res[False][k].abs().max()) + 1e-7, 1e-4, f"{k} (mixed deposit / non-deposit cells)")
+
+
 @pytest.mark.parametrize("M,K,N,relu,ld", [(1, 4, 1, True, 4), (37, 8, 2, True, 8), (130, 32, 2, True, 32), (130, 32, 2, False, 40),
                                            (257, 64, 4, True, 64), (64, 20, 3, True, 20), (1000, 32, 1, True, 32)])
 def test_readout_kernels_match_torch(backend, M, K, N, relu, ld):

@@ -619,6 +619,21 @@ int pgt_dcrnn_seq64_f32(const pgt_csr* op_o, const pgt_csr* op_i, int64_t E_o, i
                         float* out, int64_t out_stride_b, int64_t out_stride_t, float* TSzr, float* TSh,
                         int64_t seg_stride, int64_t t_stride, float* ZR, float* HT, pgt_stream_t stream);
 
+/* The adjoint of the same sequences in one launch (hand-written BPTT; replaces per cell step pgt_gru_h_bwd_f32, two feature-gradient
+ * pgt_gemm_f32, two pgt_dconv_stack_slab_bwd_f32 and pgt_gru_zr_bwd_f32), the input being data (no d/dX):
+ *   tp_o / tp_i: the TRANSPOSED operators; dOut[b, t] = dOut + b * g_stride_b + t * g_stride_t: [N, 64] rows (the gradient of
+ *   out); out / ZR / HT: what pgt_dcrnn_seq64_f32 wrote; Wp: pgt_dcrnn_seq64_pack_floats(K) floats written by
+ *   pgt_dcrnn_seq64_pack_bwd_f32 (the weights transposed, segment 0 folded as ops.fold_backward_weight does);
+ *   -> dPzr [T, M, 128], dPh [T, M, 64]: the gradients of the gates' pre-activations, STORED — the weight gradients are
+ *   pgt_gemm_tn_acc_f32(saved stack, dP) over all T M rows; dH0 [B, N, 64] or NULL; ws: pgt_dcrnn_seq64_bwd_ws_floats(N, B) floats
+ *   of scratch.  All operands 16-byte addressable. */
+int pgt_dcrnn_seq64_pack_bwd_f32(const float* Wzr, const float* Wh, int64_t Fin, int64_t K, float* Wp, pgt_stream_t stream);
+int64_t pgt_dcrnn_seq64_bwd_ws_floats(int64_t N, int64_t B);
+int pgt_dcrnn_seq64_bwd_f32(const pgt_csr* tp_o, const pgt_csr* tp_i, int64_t E_o, int64_t E_i, int64_t N, const float* dOut,
+                            int64_t g_stride_b, int64_t g_stride_t, const float* out, int64_t out_stride_b, int64_t out_stride_t,
+                            const float* H0, const float* ZR, const float* HT, const float* Wp, int64_t B, int64_t T, int64_t Fin,
+                            int64_t K, float* dPzr, float* dPh, float* dH0, float* ws, int64_t ws_floats, pgt_stream_t stream);
+
 /* Fused T-GCN cell for hidden width 32 (nn/recurrent/temporalgcn.py:82-130; csrc/tgcn_cell.hip): with AX = A_hat X [M, Fin] and
  * the folded operands of pgt_tgcn_pack_weights_f32,
  *   Z | R = sigmoid([AX | H] Wzr + bzr),  H' = Z H + (1 - Z) tanh([AX | H * R] Wh + bh)

@@ -172,6 +172,11 @@ PROTOTYPES = {
     "pgt_dcrnn_seq64_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64,
                                     c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64,
                                     c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "pgt_dcrnn_seq64_pack_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "pgt_dcrnn_seq64_bwd_ws_floats": (c_i64, [c_i64, c_i64]),
+    "pgt_dcrnn_seq64_bwd_f32": (c_int, [ctypes.POINTER(CsrStruct), ctypes.POINTER(CsrStruct), c_i64, c_i64, c_i64, c_ptr, c_i64, c_i64,
+                                        c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr,
+                                        c_ptr, c_i64, c_ptr]),
     "pgt_tgcn_cell_fits": (c_int, [c_i64, c_i64]),
     "pgt_tgcn_cell_bwd_ws_floats": (c_i64, [c_i64, c_i64]),
     "pgt_tgcn_cell_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr,

@@ -172,6 +172,38 @@ __device__ __forceinline__ pgt_f4 sq_gather(const uint16_t* __restrict__ rp, con
   return acc;
 }
 
+// LDS carve-up (two blocks, the ring, both operators) and the staging of the operators: every thread of the workgroup calls it
+__device__ __forceinline__ SqLds sq_setup(char* smem, int N, const int32_t* rp_o, const int32_t* col_o, const float* val_o, int nnz_o,
+                                          const int32_t* rp_i, const int32_t* col_i, const float* val_i, int nnz_i) {
+  const int tid = threadIdx.x;
+  SqLds s;
+  char* p = smem;
+  s.bufA = reinterpret_cast<float*>(p); p += (size_t)N * SQ_PITCH * 4;
+  s.bufB = reinterpret_cast<float*>(p); p += (size_t)N * SQ_PITCH * 4;
+  s.ring = reinterpret_cast<uint32_t*>(p); p += 2 * (size_t)SQ_CHUNK_DW * 4;
+  const size_t cap_o = sq_slot_cap(nnz_o, N), cap_i = sq_slot_cap(nnz_i, N);
+  float* vo = reinterpret_cast<float*>(p); p += cap_o * 4;
+  float* vi = reinterpret_cast<float*>(p); p += cap_i * 4;
+  uint16_t* co = reinterpret_cast<uint16_t*>(p); p += cap_o * 2;
+  uint16_t* ci = reinterpret_cast<uint16_t*>(p); p += cap_i * 2;
+  uint16_t* ro = reinterpret_cast<uint16_t*>(p); p += (size_t)(N + 2) * 2;
+  uint16_t* ri = reinterpret_cast<uint16_t*>(p);
+  for (int i = tid; i <= N; i += SQ_THREADS) { ro[i] = (uint16_t)rp_o[i]; ri[i] = (uint16_t)rp_i[i]; }
+  for (int r = tid; r < 2 * N; r += SQ_THREADS) {           // one thread per (operator, row): its slots to the row's even start
+    const bool second = r >= N;
+    const int row = second ? r - N : r;
+    const int32_t* rp = second ? rp_i : rp_o;
+    const int32_t* gcol = second ? col_i : col_o;
+    const float* gval = second ? val_i : val_o;
+    uint16_t* dc = second ? ci : co;
+    float* dv = second ? vi : vo;
+    const int b0 = rp[row], e0 = rp[row + 1], st = sq_row_start(b0, row);
+    for (int q = b0; q < e0; ++q) { dc[st + q - b0] = (uint16_t)gcol[q]; dv[st + q - b0] = gval[q]; }
+  }
+  s.val_o = vo; s.val_i = vi; s.col_o = co; s.col_i = ci; s.rp_o = ro; s.rp_i = ri;
+  return s;
+}
+
 // ---- packed weights.  Chunk c of a cell step (consumption order): c < 4 S: the update / reset product, segment sq_seg_at(c / 4),
 // hidden columns 32 kk .. + 31 (kk = (c / 2) % 2), output columns 64 half .. + 63 (half = c % 2); then 2 S chunks of the candidate
 // product (segment, kk).  Inside a chunk: [column tile ct (4)][plane (3)][lane (64)][4 dwords] — lane l of v_mfma_f32_16x16x32_bf16
@@ -259,33 +291,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = a.N, Fin = a.Fin, K = a.K, C = Fin + SQ_O;
   // ---- LDS carve-up: two blocks, the ring, both operators
-  SqLds s;
-  {
-    char* p = smem;
-    s.bufA = reinterpret_cast<float*>(p); p += (size_t)N * SQ_PITCH * 4;
-    s.bufB = reinterpret_cast<float*>(p); p += (size_t)N * SQ_PITCH * 4;
-    s.ring = reinterpret_cast<uint32_t*>(p); p += 2 * (size_t)SQ_CHUNK_DW * 4;
-    const size_t cap_o = sq_slot_cap(a.nnz_o, N), cap_i = sq_slot_cap(a.nnz_i, N);
-    float* vo = reinterpret_cast<float*>(p); p += cap_o * 4;
-    float* vi = reinterpret_cast<float*>(p); p += cap_i * 4;
-    uint16_t* co = reinterpret_cast<uint16_t*>(p); p += cap_o * 2;
-    uint16_t* ci = reinterpret_cast<uint16_t*>(p); p += cap_i * 2;
-    uint16_t* ro = reinterpret_cast<uint16_t*>(p); p += (size_t)(N + 2) * 2;
-    uint16_t* ri = reinterpret_cast<uint16_t*>(p);
-    for (int i = tid; i <= N; i += SQ_THREADS) { ro[i] = (uint16_t)a.rp_o[i]; ri[i] = (uint16_t)a.rp_i[i]; }
-    for (int r = tid; r < 2 * N; r += SQ_THREADS) {           // one thread per (operator, row): its slots to the row's even start
-      const bool second = r >= N;
-      const int row = second ? r - N : r;
-      const int32_t* rp = second ? a.rp_i : a.rp_o;
-      const int32_t* gc_ = second ? a.col_i : a.col_o;
-      const float* gv = second ? a.val_i : a.val_o;
-      uint16_t* dc = second ? ci : co;
-      float* dv = second ? vi : vo;
-      const int b0 = rp[row], e0 = rp[row + 1], st = sq_row_start(b0, row);
-      for (int q = b0; q < e0; ++q) { dc[st + q - b0] = (uint16_t)gc_[q]; dv[st + q - b0] = gv[q]; }
-    }
-    s.val_o = vo; s.val_i = vi; s.col_o = co; s.col_i = ci; s.rp_o = ro; s.rp_i = ri;
-  }
+  const SqLds s = sq_setup(smem, N, a.rp_o, a.col_o, a.val_o, a.nnz_o, a.rp_i, a.col_i, a.val_i, a.nnz_i);
   // ---- roles
   const int NRT = (N + 15) >> 4;                 // row tiles = MFMA wavefronts
   const bool consumer = !LOADER && wave < NRT;
@@ -594,6 +600,363 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq64_fwd_kernel(Seq64Args a
   else sq_fwd_body<false>(a, smem);
 }
 
+
+// ================================================================================================================ adjoint
+// Hand-written BPTT of the same sequences (ops.DCRNNSeqFunction.backward: gate adjoints pgt_gru_h_bwd_f32 / pgt_gru_zr_bwd_f32,
+// feature-gradient products dP W^T, stack adjoints pgt_dconv_stack_slab_bwd_f32 — six launches per cell step) as ONE launch for
+// all T steps of every sample, the input being data (no d/dX): only the 64 hidden columns of a stack gradient exist.
+//   * wavefront w owns rows 16 w .. 16 w + 15 in the MFMA A-operand layout (lane = row l % 16, columns 8 (l / 16) .. + 7 of every
+//     32): the gate adjoints are computed in that layout, so dP IS the A operand of the feature-gradient products and the running
+//     d/dH_t never leaves the registers; dPh / dP(z | r) are stored once (the weight-gradient product over all T steps reads them);
+//   * G_s = dP W_s^T per stack segment (split-bf16, weights transposed + pre-split by pgt_dcrnn_seq64_pack_bwd_f32, the "- T_0" of
+//     the second hop folded into segment 0: ops.fold_backward_weight) leaves the accumulators straight into an LDS block;
+//   * the stack adjoint runs on the two blocks with the TRANSPOSED operators:
+//       A = G2o, B = G1o | B += 2 P_o^T A | park = P_o^T B | A = G2i, B = G1i | B += 2 P_i^T A | A = G0' | A += P_i^T B + park
+//     (`park`: one [N, 64] slice of global scratch per workgroup, written and read back by the same threads);
+//   * d/dT_0 comes back out of block A in the A-operand layout for the next gate adjoint.
+struct Seq64BwdArgs {
+  const int32_t* rp_o; const int32_t* col_o; const float* val_o;    // P_o^T
+  const int32_t* rp_i; const int32_t* col_i; const float* val_i;    // P_i^T
+  int N, Fin, K, T, B, nnz_o, nnz_i;
+  const float* dOut; int64_t gs_b, gs_t;   // incoming gradient of out[b, t]: [N, 64] rows
+  const float* out; int64_t os_b, os_t;    // the states
+  const float* H0;                         // [B, N, 64] | null (zeros)
+  const float* ZR; const float* HT;        // saved by the forward launch
+  const uint32_t* Wp;                      // pgt_dcrnn_seq64_pack_bwd_f32
+  float* dPzr; float* dPh;                 // [T, B N, 128], [T, B N, 64]
+  float* dH0;                              // [B, N, 64] | null
+  float* park;                             // [gridDim.x][N][64]
+};
+
+// position in the adjoint's consumption order -> stack segment: K = 3: G2o G1o G2i G1i G0; K = 2: G1o G1i G0
+__host__ __device__ inline int sq_bwd_seg_at(int K, int pos) {
+  if (K >= 3) { const int order[5] = {3, 1, 4, 2, 0}; return order[pos]; }
+  const int order2[3] = {1, 2, 0};
+  return order2[pos];
+}
+
+// Packed weights of the adjoint.  Chunk c of a cell step: c < 2 S: the candidate's product (segment sq_bwd_seg_at(c / 2), columns
+// 32 kk .. + 31 of dPh, kk = c % 2); then 4 S chunks of the z | r product (segment, kk = c % 4 over the 128 columns of dP(z | r)).
+// Inside a chunk [column tile ct][plane][lane][4 dwords]: B[k = 8 (l / 16) + j][n = 16 ct + l % 16] = W'[(seg C + Fin + n), 32 kk + k]
+// with W' = the stacked operand, segment 0 folded for K = 3 (W_0 - W_3 - W_4: ops.fold_backward_weight).
+__global__ __launch_bounds__(256) void seq64_pack_bwd_kernel(const float* __restrict__ Wzr, const float* __restrict__ Wh, int Fin, int K,
+                                                             uint32_t* __restrict__ Wp) {
+  const int S = sq_nseg(K), C = Fin + SQ_O;
+  const int total = sq_nchunks(K) * 4 * 64 * 4;
+  const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (idx >= total) return;
+  const int d = idx & 3, l = (idx >> 2) & 63, ct = (idx >> 8) & 3, c = idx >> 10;
+  const float* W;
+  int ld, seg, kk;
+  if (c < 2 * S) {
+    W = Wh; ld = SQ_O; seg = sq_bwd_seg_at(K, c >> 1); kk = c & 1;
+  } else {
+    const int ch = c - 2 * S;
+    W = Wzr; ld = 2 * SQ_O; seg = sq_bwd_seg_at(K, ch >> 2); kk = ch & 3;
+  }
+  const int n = 16 * ct + (l & 15), k0 = 32 * kk + 8 * (l >> 4) + 2 * d;
+  const float* row = W + (int64_t)(seg * C + Fin + n) * ld;
+  float x = row[k0], y = row[k0 + 1];
+  if (seg == 0 && K == 3) {
+    const float* r3 = W + (int64_t)(3 * C + Fin + n) * ld;
+    const float* r4 = W + (int64_t)(4 * C + Fin + n) * ld;
+    x = (x - r3[k0]) - r4[k0];                       // the order of ops.fold_backward_weight (k = 2: d = 0, then d = 1)
+    y = (y - r3[k0 + 1]) - r4[k0 + 1];
+  }
+  uint32_t p1, p2, p3;
+  sq_split2(x, y, p1, p2, p3);
+  uint32_t* dst = Wp + (int64_t)c * SQ_CHUNK_DW + ((ct * 3) * 64 + l) * 4 + d;
+  dst[0] = p1;
+  dst[256] = p2;
+  dst[512] = p3;
+}
+
+template <bool LOADER>
+__device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N, K = a.K;
+  const SqLds s = sq_setup(smem, N, a.rp_o, a.col_o, a.val_o, a.nnz_o, a.rp_i, a.col_i, a.val_i, a.nnz_i);
+  const int NRT = (N + 15) >> 4;
+  const bool consumer = !LOADER && wave < NRT;
+  const int ll = tid - SQ_LOADER0 * 64;
+  const int NCH = sq_nchunks(K);
+  // A-operand layout: this lane's row (clamped; `rvalid`: it exists) and its first column of every 32
+  const int arow_raw = 16 * wave + (lane & 15);
+  const bool rvalid = consumer && arow_raw < N;
+  const int arow = sq_min(arow_raw, N - 1);
+  const int acol = 8 * (lane >> 4);
+  const int dcol = lane & 15;
+  const int drow0 = 16 * wave + 4 * (lane >> 4);
+  // ---- the ring (as in the forward kernel)
+  constexpr int DEPTH = LOADER ? 3 : 1;
+  sq_u32x4 pre[DEPTH][4];
+  int gc = 0, lc = 0;
+  auto load_chunk = [&](int set) {
+    const sq_u32x4* src = reinterpret_cast<const sq_u32x4*>(a.Wp + lc * SQ_CHUNK_DW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[set][i] = src[ll + 192 * i];
+    lc = lc + 1 == NCH ? 0 : lc + 1;
+  };
+  auto write_chunk = [&](int slot, int set) {
+    sq_u32x4* dst = reinterpret_cast<sq_u32x4*>(s.ring + slot * SQ_CHUNK_DW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[ll + 192 * i] = pre[set][i];
+  };
+  auto loader_turn = [&]() {
+    write_chunk((gc + 1) & 1, 0);
+#pragma unroll
+    for (int d = 0; d + 1 < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[d][i] = pre[d + 1][i];
+    load_chunk(DEPTH - 1);
+  };
+  if constexpr (LOADER) {
+    load_chunk(0);
+    write_chunk(0, 0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_chunk(d);
+  }
+  float* const park = a.park + (int64_t)blockIdx.x * N * SQ_O;
+
+  // G = dP W_seg^T for one stack segment: KK chunks (32 columns of dP each), the 64 columns of G leave the accumulators into `dst`
+  // (accumulator layout: rows 4 (l / 16) + i, column 16 ct + l % 16) before the segment's last barrier
+  auto mfma_to = [&](float* dst, const float* dp, auto kktag) {
+    constexpr int KK = decltype(kktag)::value;
+    sq_f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = sq_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (consumer) {
+        sq_u32x4 a1, a2, a3;
+        uint32_t p1, p2, p3;
+        sq_split2_fast(dp[8 * kk + 0], dp[8 * kk + 1], p1, p2, p3); a1[0] = p1; a2[0] = p2; a3[0] = p3;
+        sq_split2_fast(dp[8 * kk + 2], dp[8 * kk + 3], p1, p2, p3); a1[1] = p1; a2[1] = p2; a3[1] = p3;
+        sq_split2_fast(dp[8 * kk + 4], dp[8 * kk + 5], p1, p2, p3); a1[2] = p1; a2[2] = p2; a3[2] = p3;
+        sq_split2_fast(dp[8 * kk + 6], dp[8 * kk + 7], p1, p2, p3); a1[3] = p1; a2[3] = p2; a3[3] = p3;
+        const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (gc & 1) * SQ_CHUNK_DW) + lane;
+        sq_u32x4 bq[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          if (ct < 3) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bq[(ct + 1) & 1][pl] = slot[((ct + 1) * 3 + pl) * 64];
+          }
+          const sq_u32x4 b1 = bq[ct & 1][0], b2 = bq[ct & 1][1], b3 = bq[ct & 1][2];
+          sq_f32x4 c = acc[ct];
+          c = sq_mfma16(a3, b1, c);
+          c = sq_mfma16(a1, b3, c);
+          c = sq_mfma16(a2, b2, c);
+          c = sq_mfma16(a2, b1, c);
+          c = sq_mfma16(a1, b2, c);
+          c = sq_mfma16(a1, b1, c);
+          acc[ct] = c;
+          PGT_SCHED_FENCE();
+        }
+        if (kk == KK - 1) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (drow0 + i < N) dst[(drow0 + i) * SQ_PITCH + 16 * ct + dcol] = acc[ct][i];
+        }
+      }
+      if constexpr (LOADER) loader_turn();
+      ++gc;
+      sq_barrier();
+    }
+  };
+
+  // adjoint of one diffusion convolution: dp = this lane's KK * 8 columns of dP; on exit block A holds d/dT_0 (hidden columns),
+  // NOT yet behind a barrier
+  auto conv_adjoint = [&](const float* dp, auto kktag) {
+    auto own = [&](int j, int& off, bool& live) {          // hidden quad j of this thread: tasks tid + 1024 j < 16 N
+      int ot = tid;
+      SQ_OPAQUE(ot);
+      const int idx = ot + j * SQ_THREADS;
+      live = idx < 16 * N;
+      off = live ? (idx >> 4) * SQ_PITCH + 4 * (idx & 15) : 0;
+    };
+    auto addq = [](pgt_f4 x, pgt_f4 y) { return pgt_mk4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
+    if (K >= 3) {
+      mfma_to(s.bufA, dp, kktag);          // G2o
+      mfma_to(s.bufB, dp, kktag);          // G1o
+#pragma unroll
+      for (int j = 0; j < SQ_MAXT; ++j) {  // B += 2 P_o^T A
+        int off; bool live;
+        own(j, off, live);
+        if (live) {
+          const pgt_f4 g = sq_gather(s.rp_o, s.col_o, s.val_o, s.bufA, off / SQ_PITCH, off % SQ_PITCH);
+          const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufB + off);
+          *reinterpret_cast<pgt_f4*>(s.bufB + off) = pgt_mk4(2.0f * g.x + 1.0f * t.x, 2.0f * g.y + 1.0f * t.y, 2.0f * g.z + 1.0f * t.z, 2.0f * g.w + 1.0f * t.w);
+        }
+      }
+      sq_barrier();
+#pragma unroll
+      for (int j = 0; j < SQ_MAXT; ++j) {  // park = P_o^T B
+        int off; bool live;
+        own(j, off, live);
+        if (live) {
+          const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
+          *reinterpret_cast<pgt_f4*>(park + r * SQ_O + q4) = sq_gather(s.rp_o, s.col_o, s.val_o, s.bufB, r, q4);
+        }
+      }
+      sq_barrier();
+      mfma_to(s.bufA, dp, kktag);          // G2i
+      mfma_to(s.bufB, dp, kktag);          // G1i
+#pragma unroll
+      for (int j = 0; j < SQ_MAXT; ++j) {  // B += 2 P_i^T A
+        int off; bool live;
+        own(j, off, live);
+        if (live) {
+          const pgt_f4 g = sq_gather(s.rp_i, s.col_i, s.val_i, s.bufA, off / SQ_PITCH, off % SQ_PITCH);
+          const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufB + off);
+          *reinterpret_cast<pgt_f4*>(s.bufB + off) = pgt_mk4(2.0f * g.x + 1.0f * t.x, 2.0f * g.y + 1.0f * t.y, 2.0f * g.z + 1.0f * t.z, 2.0f * g.w + 1.0f * t.w);
+        }
+      }
+      sq_barrier();
+      mfma_to(s.bufA, dp, kktag);          // G0 (the "- T_0" of the second hop folded in)
+#pragma unroll
+      for (int j = 0; j < SQ_MAXT; ++j) {  // A += park + P_i^T B
+        int off; bool live;
+        own(j, off, live);
+        if (live) {
+          const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
+          const pgt_f4 pk = *reinterpret_cast<const pgt_f4*>(park + r * SQ_O + q4);
+          const pgt_f4 g = sq_gather(s.rp_i, s.col_i, s.val_i, s.bufB, r, q4);
+          const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufA + off);
+          *reinterpret_cast<pgt_f4*>(s.bufA + off) = addq(addq(t, pk), g);
+        }
+      }
+    } else {
+      mfma_to(s.bufA, dp, kktag);          // G1o
+      mfma_to(s.bufB, dp, kktag);          // G1i
+#pragma unroll
+      for (int j = 0; j < SQ_MAXT; ++j) {  // park = P_o^T A + P_i^T B
+        int off; bool live;
+        own(j, off, live);
+        if (live) {
+          const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
+          const pgt_f4 go = sq_gather(s.rp_o, s.col_o, s.val_o, s.bufA, r, q4);
+          const pgt_f4 gi = sq_gather(s.rp_i, s.col_i, s.val_i, s.bufB, r, q4);
+          *reinterpret_cast<pgt_f4*>(park + r * SQ_O + q4) = addq(go, gi);
+        }
+      }
+      sq_barrier();
+      mfma_to(s.bufA, dp, kktag);          // G0
+#pragma unroll
+      for (int j = 0; j < SQ_MAXT; ++j) {
+        int off; bool live;
+        own(j, off, live);
+        if (live) {
+          const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
+          const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufA + off);
+          *reinterpret_cast<pgt_f4*>(s.bufA + off) = addq(t, *reinterpret_cast<const pgt_f4*>(park + r * SQ_O + q4));
+        }
+      }
+    }
+  };
+
+  // 8 floats of this lane's row at columns c0 + acol .. + 7 of a [rows, ld] global array
+  auto ld8 = [&](const float* rows, int ld, int c0, float* v) {
+    const pgt_f4 x = *reinterpret_cast<const pgt_f4*>(rows + arow * ld + c0 + acol);
+    const pgt_f4 y = *reinterpret_cast<const pgt_f4*>(rows + arow * ld + c0 + acol + 4);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+  };
+  auto st8 = [&](float* rows, int ld, int c0, const float* v) {
+    if (!rvalid) return;
+    *reinterpret_cast<pgt_f4*>(rows + arow * ld + c0 + acol) = pgt_mk4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<pgt_f4*>(rows + arow * ld + c0 + acol + 4) = pgt_mk4(v[4], v[5], v[6], v[7]);
+  };
+
+  for (int b = (int)blockIdx.x; b < a.B; b += (int)gridDim.x) {
+    const int64_t m0 = (int64_t)b * N;
+    float dh[16];                      // running d/dH_t, A-operand layout: [kk][8]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dh[i] = 0.f;
+    sq_barrier();
+#pragma unroll 1
+    for (int t = a.T - 1; t >= 0; --t) {
+      const float* const zr_rows = a.ZR + ((int64_t)t * a.B * N + m0) * (2 * SQ_O);
+      const float* const ht_rows = a.HT + ((int64_t)t * a.B * N + m0) * SQ_O;
+      const float* const g_rows = a.dOut + (int64_t)b * a.gs_b + (int64_t)t * a.gs_t;
+      const float* const hp_rows = t > 0 ? a.out + (int64_t)b * a.os_b + (int64_t)(t - 1) * a.os_t : (a.H0 ? a.H0 + m0 * SQ_O : nullptr);
+      float* const dpzr_rows = a.dPzr + ((int64_t)t * a.B * N + m0) * (2 * SQ_O);
+      float* const dph_rows = a.dPh + ((int64_t)t * a.B * N + m0) * SQ_O;
+      // ---- adjoint of the blend and of the candidate's tanh (pgt_gru_h_bwd_f32): dPh, dP(z), d/dH_{t-1} (the Z H part)
+      float dp[32];
+      if (consumer) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float g[8], z[8], h[8], c[8], dpz[8];
+          ld8(g_rows, SQ_O, 32 * kk, g);
+          ld8(zr_rows, 2 * SQ_O, 32 * kk, z);
+          ld8(ht_rows, SQ_O, 32 * kk, c);
+          if (hp_rows) ld8(hp_rows, SQ_O, 32 * kk, h);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (!hp_rows) h[i] = 0.f;
+            const float gi = g[i] + dh[8 * kk + i];
+            dp[8 * kk + i] = gi * (1.f - z[i]) * (1.f - c[i] * c[i]);
+            dpz[i] = gi * (h[i] - c[i]) * z[i] * (1.f - z[i]);
+            dh[8 * kk + i] = gi * z[i];
+          }
+          st8(dph_rows, SQ_O, 32 * kk, dp + 8 * kk);
+          st8(dpzr_rows, 2 * SQ_O, 32 * kk, dpz);
+        }
+      }
+      conv_adjoint(dp, SqInt<2>{});
+      sq_barrier();
+      // ---- adjoint of H * R and of the reset gate (pgt_gru_zr_bwd_f32); dP(z) comes back from this lane's own store
+      if (consumer) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float r[8], h[8];
+          ld8(zr_rows, 2 * SQ_O, SQ_O + 32 * kk, r);
+          if (hp_rows) ld8(hp_rows, SQ_O, 32 * kk, h);
+          ld8(dpzr_rows, 2 * SQ_O, 32 * kk, dp + 8 * kk);
+          const pgt_f4 x = *reinterpret_cast<const pgt_f4*>(s.bufA + arow * SQ_PITCH + 32 * kk + acol);
+          const pgt_f4 y = *reinterpret_cast<const pgt_f4*>(s.bufA + arow * SQ_PITCH + 32 * kk + acol + 4);
+          const float d0[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (!hp_rows) h[i] = 0.f;
+            dp[16 + 8 * kk + i] = d0[i] * h[i] * r[i] * (1.f - r[i]);
+            dh[8 * kk + i] += d0[i] * r[i];
+          }
+          st8(dpzr_rows, 2 * SQ_O, SQ_O + 32 * kk, dp + 16 + 8 * kk);
+        }
+      }
+      sq_barrier();                    // block A has been read: the next products may overwrite it
+      conv_adjoint(dp, SqInt<4>{});
+      sq_barrier();
+      if (consumer) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const pgt_f4 x = *reinterpret_cast<const pgt_f4*>(s.bufA + arow * SQ_PITCH + 32 * kk + acol);
+          const pgt_f4 y = *reinterpret_cast<const pgt_f4*>(s.bufA + arow * SQ_PITCH + 32 * kk + acol + 4);
+          dh[8 * kk + 0] += x.x; dh[8 * kk + 1] += x.y; dh[8 * kk + 2] += x.z; dh[8 * kk + 3] += x.w;
+          dh[8 * kk + 4] += y.x; dh[8 * kk + 5] += y.y; dh[8 * kk + 6] += y.z; dh[8 * kk + 7] += y.w;
+        }
+      }
+      sq_barrier();                    // (block A read before the next step's products write it)
+    }
+    if (a.dH0 && consumer) {
+      float* rows = a.dH0 + m0 * SQ_O;
+      st8(rows, SQ_O, 0, dh);
+      st8(rows, SQ_O, 32, dh + 8);
+    }
+  }
+}
+
+__global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq64_bwd_kernel(Seq64BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[SQ_LDS];
+  if ((int)(threadIdx.x >> 6) >= SQ_LOADER0) sq_bwd_body<true>(a, smem);
+  else sq_bwd_body<false>(a, smem);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------- C ABI
@@ -639,4 +1002,42 @@ extern "C" int pgt_dcrnn_seq64_f32(const pgt_csr* op_o, const pgt_csr* op_i, int
   const int nblk = (int)(B < SQ_CUS ? B : SQ_CUS);
   PGT_LAUNCH(dcrnn_seq64_fwd_kernel, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
   return pgt_check_launch("pgt_dcrnn_seq64_f32");
+}
+
+extern "C" int pgt_dcrnn_seq64_pack_bwd_f32(const float* Wzr, const float* Wh, int64_t Fin, int64_t K, float* Wp, pgt_stream_t stream) {
+  PGT_REQUIRE(Wzr && Wh && Wp, "pgt_dcrnn_seq64_pack_bwd_f32: null pointer");
+  PGT_REQUIRE(Fin == 2 && (K == 2 || K == 3), "pgt_dcrnn_seq64_pack_bwd_f32: Fin = 2 and K = 2 | 3 only");
+  const int total = sq_nchunks((int)K) * 4 * 64 * 4;
+  PGT_LAUNCH(seq64_pack_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, Wzr, Wh, (int)Fin, (int)K,
+             reinterpret_cast<uint32_t*>(Wp));
+  return pgt_check_launch("pgt_dcrnn_seq64_pack_bwd_f32");
+}
+
+extern "C" int64_t pgt_dcrnn_seq64_bwd_ws_floats(int64_t N, int64_t B) { return (B < SQ_CUS ? B : SQ_CUS) * N * SQ_O; }
+
+extern "C" int pgt_dcrnn_seq64_bwd_f32(const pgt_csr* tp_o, const pgt_csr* tp_i, int64_t E_o, int64_t E_i, int64_t N, const float* dOut,
+                                       int64_t g_stride_b, int64_t g_stride_t, const float* out, int64_t out_stride_b,
+                                       int64_t out_stride_t, const float* H0, const float* ZR, const float* HT, const float* Wp,
+                                       int64_t B, int64_t T, int64_t Fin, int64_t K, float* dPzr, float* dPh, float* dH0, float* ws,
+                                       int64_t ws_floats, pgt_stream_t stream) {
+  PGT_REQUIRE(tp_o && tp_i && dOut && out && ZR && HT && Wp && dPzr && dPh && ws, "pgt_dcrnn_seq64_bwd_f32: null pointer");
+  PGT_REQUIRE(pgt_dcrnn_seq64_fits(N, E_o, E_i, Fin, SQ_O, K), "pgt_dcrnn_seq64_bwd_f32: shape not covered (pgt_dcrnn_seq64_fits)");
+  PGT_REQUIRE(B >= 0 && T >= 0, "pgt_dcrnn_seq64_bwd_f32: negative extent");
+  PGT_REQUIRE(ws_floats >= pgt_dcrnn_seq64_bwd_ws_floats(N, B), "pgt_dcrnn_seq64_bwd_f32: scratch too small (pgt_dcrnn_seq64_bwd_ws_floats)");
+  PGT_REQUIRE(pgt_aligned(Wp, 16) && pgt_aligned(dOut, 16) && pgt_aligned(out, 16) && pgt_aligned(ZR, 16) && pgt_aligned(HT, 16) &&
+                  pgt_aligned(dPzr, 16) && pgt_aligned(dPh, 16) && pgt_aligned(ws, 16) && (!H0 || pgt_aligned(H0, 16)) &&
+                  (!dH0 || pgt_aligned(dH0, 16)) && g_stride_b % 4 == 0 && g_stride_t % 4 == 0 && out_stride_b % 4 == 0 &&
+                  out_stride_t % 4 == 0,
+              "pgt_dcrnn_seq64_bwd_f32: operands must be 16-byte addressable");
+  if (B == 0 || T == 0) return PGT_OK;
+  Seq64BwdArgs a;
+  a.rp_o = tp_o->rowptr; a.col_o = tp_o->col; a.val_o = tp_o->val;
+  a.rp_i = tp_i->rowptr; a.col_i = tp_i->col; a.val_i = tp_i->val;
+  a.N = (int)N; a.Fin = (int)Fin; a.K = (int)K; a.T = (int)T; a.B = (int)B; a.nnz_o = (int)E_o; a.nnz_i = (int)E_i;
+  a.dOut = dOut; a.gs_b = g_stride_b; a.gs_t = g_stride_t; a.out = out; a.os_b = out_stride_b; a.os_t = out_stride_t;
+  a.H0 = H0; a.ZR = ZR; a.HT = HT; a.Wp = reinterpret_cast<const uint32_t*>(Wp);
+  a.dPzr = dPzr; a.dPh = dPh; a.dH0 = dH0; a.park = ws;
+  const int nblk = (int)(B < SQ_CUS ? B : SQ_CUS);
+  PGT_LAUNCH(dcrnn_seq64_bwd_kernel, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
+  return pgt_check_launch("pgt_dcrnn_seq64_bwd_f32");
 }

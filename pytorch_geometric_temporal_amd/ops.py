@@ -1382,6 +1382,10 @@ class DCRNNSeqFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dOut):
+        if _seq64_adjoint_applies(ctx):
+            # hidden 64, the input is data: all T steps of the adjoint in ONE launch (csrc/seq64.hip) — faster than the six
+            # launches per step at every batch size (B = 64: 1.32 -> 1.11 ms, B = 1024: 8.8 -> 6.9 ms)
+            return (None,) + _seq64_adjoint(ctx, dOut) + (None,) * 5
         TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c = ctx.saved_tensors
         g, K, Fin = ctx.g, ctx.K, ctx.Fin
         S, T, M, C = TSzr.shape
@@ -1501,6 +1505,7 @@ USE_SEQ64 = os.environ.get("PGT_SEQ64", "1") != "0"
 # smallest batch that takes it: a sample occupies ONE CU for the whole sequence, so below ~100 samples the per-step launches —
 # which spread every step over all 256 CUs — are faster (B = 64: 0.82 ms against 0.98 ms forward; B = 256: 1.68 against 1.11)
 SEQ64_MIN_BATCH = int(os.environ.get("PGT_SEQ64_MIN_B", "96"))
+USE_SEQ64_BWD = os.environ.get("PGT_SEQ64_BWD", "1") != "0"      # 0: the per-step adjoint launches behind the one-launch forward (A/B)
 
 
 def seq64_fits(g, Fin, O, K):
@@ -1508,6 +1513,55 @@ def seq64_fits(g, Fin, O, K):
     operators + the weight ring within a CU's LDS — and finite operator coefficients (a node without incoming edges makes
     DConv's 1 / deg infinite, dcrnn.py:71-77: inf / nan placement is the general path's speciality, csrc/gemm_bx.hip)."""
     return bool(getattr(g, "finite", False)) and bool(_lib.get_lib()._pgt_dcrnn_seq64_fits(g.N, g.E, g.E, int(Fin), int(O), int(K)))
+
+
+def _seq64_adjoint(ctx, dOut):
+    """(dH0, dWzr, dbzr, dWh, dbh) of a hidden-64 sequence whose input is data: the whole BPTT in ONE launch (csrc/seq64.hip) on
+    what either forward path saved (both stacks, Z | R, the candidates, the states in the reference's [B, T, N, O] layout,
+    batch-major rows) + the two weight-gradient products over all T steps."""
+    lib = _lib.get_lib()
+    TSzr, TSh, ZR, HT, H0c, Hout, Wzr_c, Wh_c = ctx.saved_tensors
+    g, K = ctx.g, ctx.K
+    S, T, M, C = TSzr.shape
+    O = HT.size(2)
+    N = g.N
+    B, Fin = M // N, C - O
+    dev = dOut.device
+    dOc = dOut.contiguous()
+    need = ctx.needs_input_grad
+    dPzr = torch.empty(T, M, 2 * O, dtype=F32, device=dev)
+    dPh = torch.empty(T, M, O, dtype=F32, device=dev)
+    dH0 = torch.empty(M, O, dtype=F32, device=dev) if need[1] else None
+    Wp = torch.empty(int(lib._pgt_dcrnn_seq64_pack_floats(K)), dtype=F32, device=dev)
+    lib.call("pgt_dcrnn_seq64_pack_bwd_f32", ptr(Wzr_c), ptr(Wh_c), Fin, K, ptr(Wp), stream_of(lib, Wp))
+    nws = int(lib._pgt_dcrnn_seq64_bwd_ws_floats(N, B))
+    ws = torch.empty(nws, dtype=F32, device=dev)
+    to, ti = g.bwd_o.struct(), g.bwd_i.struct()
+    work = 4.0 * (dOc.numel() + Hout.numel() + ZR.numel() + HT.numel() + dPzr.numel() + dPh.numel()) if KERNEL_TIMER else 0
+    _timed("seq64", work, lambda: lib.call(
+        "pgt_dcrnn_seq64_bwd_f32", ctypes.byref(to), ctypes.byref(ti), g.E, g.E, N, ptr(dOc), T * N * O, N * O, ptr(Hout), T * N * O,
+        N * O, ptr(H0c), ptr(ZR), ptr(HT), ptr(Wp), B, T, Fin, K, ptr(dPzr), ptr(dPh), ptr(dH0), ptr(ws), nws,
+        stream_of(lib, dPh)), tag=("bwd", B, T, N))
+    seg = T * M * C
+    dWzr = dbzr = dWh = dbh = None
+    if need[2] or need[3]:
+        dWzr = torch.zeros_like(Wzr_c)
+        dbzr = torch.zeros(2 * O, dtype=F32, device=dev) if ctx.has_bias[0] else None
+        gemm_tn_acc(TSzr, C, seg, S, C, dPzr, 2 * O, dWzr, 2 * O, dbzr, T * M, 2 * O)
+    if need[4] or need[5]:
+        dWh = torch.zeros_like(Wh_c)
+        dbh = torch.zeros(O, dtype=F32, device=dev) if ctx.has_bias[1] else None
+        gemm_tn_acc(TSh, C, seg, S, C, dPh, O, dWh, O, dbh, T * M, O)
+    return dH0, dWzr, dbzr, dWh, dbh
+
+
+def _seq64_adjoint_applies(ctx):
+    """The one-launch adjoint takes a DCRNNSeqFunction / DCRNNSeq64Function context: hidden 64 with two input channels on a graph
+    pgt_dcrnn_seq64_fits covers, batch-major rows with the states in the reference's layout, the input being data."""
+    if not (USE_SEQ64 and USE_SEQ64_BWD) or ctx.needs_input_grad[0] or not (ctx.btno and ctx.batch_major and ctx.slab):
+        return False
+    TSzr, _, _, HT = ctx.saved_tensors[:4]
+    return seq64_fits(ctx.g, TSzr.size(3) - HT.size(2), HT.size(2), ctx.K)
 
 
 class DCRNNSeq64Function(torch.autograd.Function):
@@ -1569,11 +1623,14 @@ class DCRNNSeq64Function(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dOut):
-        dX, dH0, dWzr, dbzr, dWh, dbh = DCRNNSeqFunction.backward(ctx, dOut)[:6]
-        if dX is not None:                                     # [T, B N, Fin] (time-major steps of batch-major rows) -> X's layout
-            B, T, N, Fin = ctx.dims
-            dX = dX.view(T, B, N, Fin).permute(1, 0, 2, 3).contiguous()
-        return dX, dH0, dWzr, dbzr, dWh, dbh, None, None
+        if not _seq64_adjoint_applies(ctx):
+            # the input wants a gradient (or the A/B switch is off): the per-step adjoint launches on what the forward saved
+            dX, dH0, dWzr, dbzr, dWh, dbh = DCRNNSeqFunction.backward(ctx, dOut)[:6]
+            if dX is not None:                                 # [T, B N, Fin] (time-major steps of batch-major rows) -> X's layout
+                B, T, N, Fin = ctx.dims
+                dX = dX.view(T, B, N, Fin).permute(1, 0, 2, 3).contiguous()
+            return dX, dH0, dWzr, dbzr, dWh, dbh, None, None
+        return (None,) + _seq64_adjoint(ctx, dOut) + (None, None)
 
 
 # --------------------------------------------------------------------------------------------- generic building blocks

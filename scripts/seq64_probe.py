@@ -22,8 +22,12 @@ with torch.no_grad():
         p.mul_(0.5)
 
 
-def run(flag, X, w, reps, backward):
-    ops.USE_SEQ64 = flag
+MODES = {"per-step": (False, False), "adjoint only": (False, True), "forward only": (True, False), "one-launch": (True, True)}
+
+
+def run(mode, X, w, reps, backward):
+    fwd, bwd = MODES[mode]
+    ops.USE_SEQ64, ops.SEQ64_MIN_BATCH, ops.USE_SEQ64_BWD = fwd or bwd, (1 if fwd else 1 << 30), bwd
     for _ in range(2):
         model.zero_grad()
         out = model(X, ei, ew)
@@ -44,11 +48,14 @@ for B in batches:
     X = torch.randn(B, 12, 207, 2, device=dev)
     w = torch.randn(B, 12, 207, 64, device=dev)
     reps = 20 if B <= 256 else 5
-    t_old, o_old, g_old = run(False, X, w, reps, True)
-    t_new, o_new, g_new = run(True, X, w, reps, True)
-    f_old = run(False, X, w, reps, False)[0]
-    f_new = run(True, X, w, reps, False)[0]
-    gerr = max(float((a - b).abs().max() / (a.abs().max() + 1e-12)) for a, b in zip(g_old, g_new))
-    print(f"B = {B} ({edges} edges): forward {f_old:.3f} -> {f_new:.3f} ms, forward + backward {t_old:.3f} -> {t_new:.3f} ms; "
-          f"max |out diff| {float((o_old - o_new).abs().max()):.2e} (scale {float(o_old.abs().max()):.2f}), worst relative gradient diff {gerr:.2e}",
-          flush=True)
+    res = {m: run(m, X, w, reps, True) for m in MODES}
+    f_old = run("per-step", X, w, reps, False)[0]
+    f_new = run("one-launch", X, w, reps, False)[0]
+    o_old, g_old = res["per-step"][1:]
+    worst = 0.0
+    for m in MODES:
+        worst = max(worst, float((res[m][1] - o_old).abs().max()))
+    gerr = max(float((a - b).abs().max() / (a.abs().max() + 1e-12)) for m in MODES for a, b in zip(g_old, res[m][2]))
+    print(f"B = {B} ({edges} edges): forward {f_old:.3f} -> {f_new:.3f} ms; forward + backward: " +
+          ", ".join(f"{m} {res[m][0]:.3f}" for m in MODES) +
+          f" ms; max |out diff| {worst:.2e} (scale {float(o_old.abs().max()):.2f}), worst relative gradient diff {gerr:.2e}", flush=True)

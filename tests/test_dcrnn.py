@@ -570,28 +570,34 @@ def test_hidden_64_sequences_in_one_launch_equal_the_per_step_launches(backend, 
     assert ops.seq64_fits(g, 2, 64, K)
     res, saved = {}, {}
     keep = (ops.USE_SEQ64, ops.SEQ64_MIN_BATCH)
+    # "one_launch": csrc/seq64.hip both ways; "adjoint_only": the per-step forward with the one-launch adjoint (what batches
+    # below SEQ64_MIN_BATCH run); "per_step": neither
+    modes = {"one_launch": (True, 1), "adjoint_only": (True, 1 << 30), "per_step": (False, 1)}
     try:
-        for one_launch in (True, False):
-            ops.USE_SEQ64, ops.SEQ64_MIN_BATCH = one_launch, 1
+        for mode, (use, min_b) in modes.items():
+            ops.USE_SEQ64, ops.SEQ64_MIN_BATCH = use, min_b
             m.zero_grad()
             Xd = backend.t(X).requires_grad_(x_grad)
             out = m(Xd, ei, ew)
-            saved[one_launch] = [t.clone() for t in out.grad_fn.saved_tensors[:4]]   # both stacks, Z | R, the candidates
+            assert (type(out.grad_fn).__name__ == "DCRNNSeq64FunctionBackward") == (mode == "one_launch")
+            saved[mode] = [t.clone() for t in out.grad_fn.saved_tensors[:4]]   # both stacks, Z | R, the candidates
             (out * w).sum().backward()
-            res[one_launch] = (out.detach().clone(), Xd.grad.clone() if x_grad else None,
-                               {k: p.grad.clone() for k, p in m.named_parameters()})
+            res[mode] = (out.detach().clone(), Xd.grad.clone() if x_grad else None,
+                         {k: p.grad.clone() for k, p in m.named_parameters()})
     finally:
         ops.USE_SEQ64, ops.SEQ64_MIN_BATCH = keep
-    assert_close_with_nonfinite(res[True][0], res[False][0], 3e-6, 1e-5, "states")
+    assert torch.equal(res["adjoint_only"][0], res["per_step"][0])
+    assert_close_with_nonfinite(res["one_launch"][0], res["per_step"][0], 3e-6, 1e-5, "states")
     # segment 0 of step 0 of the gate stack = [X_0 | H_0]: identical inputs -> every term of that step identical
-    assert torch.equal(saved[True][0][:, 0], saved[False][0][:, 0]), "diffusion terms of the first step"
-    for a, b, what in zip(saved[True], saved[False], ("gate stack", "candidate stack", "Z | R", "candidates")):
+    assert torch.equal(saved["one_launch"][0][:, 0], saved["per_step"][0][:, 0]), "diffusion terms of the first step"
+    for a, b, what in zip(saved["one_launch"], saved["per_step"], ("gate stack", "candidate stack", "Z | R", "candidates")):
         assert_close_with_nonfinite(a, b, 5e-6, 1e-5, what)
-    if x_grad:
-        assert_close_with_nonfinite(res[True][1], res[False][1], 1e-5, 1e-4, "dX")
-    for k in res[True][2]:
-        ref = res[False][2][k]
-        assert_close_with_nonfinite(res[True][2][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, k)
+    for mode in ("one_launch", "adjoint_only"):
+        if x_grad:
+            assert_close_with_nonfinite(res[mode][1], res["per_step"][1], 1e-5, 1e-4, f"dX ({mode})")
+        for k in res[mode][2]:
+            ref = res["per_step"][2][k]
+            assert_close_with_nonfinite(res[mode][2][k], ref, 2e-5 * float(ref.abs().max()) + 1e-7, 1e-4, f"{k} ({mode})")
 
 
 def test_hidden_64_one_launch_path_is_taken_only_where_it_applies(backend):

@@ -15,6 +15,10 @@ constexpr int SQ_TR_STEPS = 12, SQ_TR_SLOTS = 9;
       g_sq_trace[((t) * 2 + (G)) * SQ_TR_SLOTS + (slot)] = (long long)wall_clock64();                                 \
   } while (0)
 
+#ifdef SQ_SKIP
+#define SQ_LAB_SKIP(bit) (((SQ_SKIP) & (bit)) != 0)
+#endif
+
 static char g_err[512];
 void pgt_set_error(const char* fmt, ...) {
   va_list ap;
@@ -25,6 +29,24 @@ void pgt_set_error(const char* fmt, ...) {
 extern "C" const char* sq_lab_last_error() { return g_err; }
 
 #include "../pytorch_geometric_temporal_amd/csrc/seq64.hip"
+
+// the loader wavefront's path alone, compile-only: `hipcc -Rpass-analysis=kernel-resource-usage` must report ScratchSize 0 for these
+namespace {
+template <int K>
+__global__ __launch_bounds__(SQ_THREADS) void sq_lab_fwd_loader_only(Seq64Args a) {
+  __shared__ __attribute__((aligned(16))) char smem[SQ_LDS];
+  sq_fwd_body<true, K>(a, smem);
+}
+template <int K>
+__global__ __launch_bounds__(SQ_THREADS) void sq_lab_bwd_loader_only(Seq64BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[SQ_LDS];
+  sq_bwd_body<true, K>(a, smem);
+}
+template __global__ void sq_lab_fwd_loader_only<3>(Seq64Args);
+template __global__ void sq_lab_fwd_loader_only<2>(Seq64Args);
+template __global__ void sq_lab_bwd_loader_only<3>(Seq64BwdArgs);
+template __global__ void sq_lab_bwd_loader_only<2>(Seq64BwdArgs);
+}  // namespace
 
 extern "C" int sq_lab_set_trace(long long* buf) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sq_trace), &buf, sizeof(buf));

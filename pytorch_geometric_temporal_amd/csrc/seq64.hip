@@ -50,6 +50,16 @@ __device__ __forceinline__ void sq_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ sq_f32x4 sq_mfma16(sq_u32x4 a, sq_u32x4 b, sq_f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sq_bf16x8, a), __builtin_bit_cast(sq_bf16x8, b), c, 0, 0, 0);
 }
+// the loaders' weight stream: loads the compiler does not track (its counter insertion waits for vmcnt(0) before every ring write and
+// at every loop back-edge, which made each chunk cost a full L2 round trip) and hand-counted waits tied to the registers they
+// release.  Loads return in order, so "at most n younger LOADS outstanding" is safe whatever stores are in flight beside them.
+__device__ __forceinline__ uint64_t sq_uniform64(uint64_t x) {      // a wave-uniform value, provably so: both halves through v_readfirstlane
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
+// (uniform 64-bit base in scalar registers + 32-bit lane offset + immediate: no 64-bit address per load for the compiler to hoist and spill)
+#define SQ_GLOAD4(dst, voff, sbase, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
+#define SQ_VMWAIT4(n, r0, r1, r2, r3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(n))
+#define SQ_VMWAIT6(n, r) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(n))
 // exact fp32 products (v_mfma_f32_16x16x4_f32): the rank-Fin update of the input columns
 __device__ __forceinline__ sq_f32x4 sq_mfma4(float a, float b, sq_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 #endif
@@ -89,12 +99,19 @@ __device__ __forceinline__ pgt_f4 sq_two_minus(pgt_f4 g, pgt_f4 t) {
   return pgt_mk4(2.0f * g.x + -1.0f * t.x, 2.0f * g.y + -1.0f * t.y, 2.0f * g.z + -1.0f * t.z, 2.0f * g.w + -1.0f * t.w);
 }
 
+// lab/seq64_lab.hip defines this to take the kernels apart (1: no MFMAs, 2: the B fragments of a chunk read once, 4: no ring
+// writes, 8: no gathers, 16: no stores of the saved stacks); compile-time constants in the library
+#ifndef SQ_LAB_SKIP
+#define SQ_LAB_SKIP(bit) false
+#endif
+
 constexpr int SQ_THREADS = 1024;
 constexpr int SQ_O = 64;             // hidden width
 constexpr int SQ_PITCH = 68;         // floats per LDS row: 16 hidden quads + the quad of input columns
-constexpr int SQ_MAXT = 4;           // gather tasks (row, quad) per thread: 17 N <= 4096
+constexpr int SQ_MAXT = 4;           // gather tasks (row, quad) per thread: 17 N <= 4 * 896
 constexpr int SQ_CHUNK_DW = 3072;    // one ring slot: 4 column tiles x 3 planes x 64 lanes x 4 dwords = 12 KB
-constexpr int SQ_LOADER0 = 13;       // wavefronts 13 .. 15 fill the ring (192 lanes x 4 x 16 bytes = one chunk)
+constexpr int SQ_LOADER0 = 14;       // the last two wavefronts fill the ring (128 lanes x 6 x 16 bytes = one chunk) and do nothing else
+constexpr int SQ_GTHREADS = 896;     // threads that take gather tasks: every wavefront but the loaders
 constexpr int SQ_LDS = 160 * 1024;
 
 struct Seq64Args {
@@ -144,6 +161,7 @@ __host__ __device__ inline int sq_row_start(int rp_r, int r) { return (rp_r + r 
 __device__ __forceinline__ pgt_f4 sq_gather(const uint16_t* __restrict__ rp, const uint16_t* __restrict__ col,
                                             const float* __restrict__ val, const float* __restrict__ blk, int r, int qoff) {
   pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+  if (SQ_LAB_SKIP(8)) return *reinterpret_cast<const pgt_f4*>(blk + qoff + r * SQ_PITCH);
   const int b0 = rp[r];
   int q = sq_row_start(b0, r);
   const int e = q + ((int)rp[r + 1] - b0);
@@ -236,6 +254,7 @@ __global__ __launch_bounds__(256) void seq64_pack_kernel(const float* __restrict
 // one 16-byte store / load of a hidden quad at 8-byte alignment (a row of 66 floats starts every 264 bytes; csrc/dconv_slab.hip
 // stQ / ldQ), a float2 for the quad of input columns
 __device__ __forceinline__ void sq_store_quad(float* p, bool hidden, pgt_f4 v) {
+  if (SQ_LAB_SKIP(16)) return;
   if (hidden) __builtin_memcpy(__builtin_assume_aligned(p, 8), &v, 16);
   else *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
 }
@@ -251,7 +270,7 @@ __device__ __forceinline__ pgt_f4 sq_load_quad(const float* p, bool hidden) {
 }
 __device__ __forceinline__ int sq_min(int a, int b) { return a < b ? a : b; }
 
-// gather task j of a thread: idx = tid + 1024 j; idx < 16 N: (row idx / 16, hidden quad idx % 16); then the N quads of input columns
+// gather task j of a thread (the loader wavefront takes none): idx = tid + 896 j; idx < 16 N: (row idx / 16, hidden quad idx % 16); then the N quads of input columns
 struct SqTask {
   int row, quad;
   bool live;
@@ -260,7 +279,7 @@ struct SqTask {
   __device__ __forceinline__ int goff(int C, int Fin) const { return row * C + (quad < 16 ? Fin + 4 * quad : 0); }   // inside [N, C]
 };
 __device__ __forceinline__ SqTask sq_task(int tid, int j, int N) {
-  const int idx = tid + j * SQ_THREADS;
+  const int idx = tid + j * SQ_GTHREADS;
   SqTask k;
   k.live = idx < 17 * N;
   const int ic = k.live ? idx : 0;
@@ -273,6 +292,7 @@ __device__ __forceinline__ SqTask sq_task(int tid, int j, int N) {
 #ifndef SQ_MARK
 #define SQ_MARK(t, G, slot) do { } while (0)
 #endif
+
 // a value the compiler must treat as unknown: address arithmetic that depends on it is recomputed where it is used instead of being
 // hoisted out of the time loop and spilled (the first build of this kernel carried 444 spilled registers of loop-invariant addresses)
 #ifdef PGT_EMU
@@ -282,57 +302,77 @@ __device__ __forceinline__ SqTask sq_task(int tid, int j, int N) {
 #endif
 template <int V> struct SqInt { static constexpr int value = V; };
 
+// ---- the loaders' side of the ring.  The last TWO wavefronts stream the packed weights and do nothing else: they issue no store
+// and no other load, so their vmcnt counts exactly their own chunk loads, which return in order (wavefronts that take part in the
+// gathers carry the stores of the saved stacks on the same counter: every wait for a chunk then also waited for write
+// acknowledgements, 1 - 2.5 us per product phase).  Chunk c of the cell step (0 .. NCH - 1, NCH even) sits in ring slot c & 1 and
+// travels through register set c & 1 (6 x 16 bytes per lane: 24 registers a set — with twelve pieces per lane in ONE wavefront
+// the compiler spilled a set right behind its loads, i.e. before the data had landed).  Turn C (the MFMA wavefronts work on
+// chunk C): chunk C + 1 has landed once at most the six loads of chunk C + 2 are outstanding; it goes to slot (C + 1) & 1 and
+// its set is requested again for chunk C + 3 — two chunks of look-ahead, kept up across the gather phases.
+struct SqLoader {
+  sq_u32x4 pre0[6], pre1[6];
+  const uint32_t* Wp;
+  uint32_t* ring;
+  int ll;                           // loader lane 0 .. 127
+  uint32_t voff[3];                 // byte offsets of this lane's pieces 0 - 1, 2 - 3, 4 - 5 of a chunk (2 KB apart within a pair)
+  __device__ __forceinline__ void init(const uint32_t* w, uint32_t* r, int l) {
+    Wp = w; ring = r; ll = l;
+    voff[0] = 16u * (uint32_t)l; voff[1] = voff[0] + 4096u; voff[2] = voff[0] + 8192u;
+  }
+  template <int CHUNK>
+  __device__ __forceinline__ void issue() {
+    const uint64_t base = sq_uniform64(reinterpret_cast<uint64_t>(Wp + CHUNK * SQ_CHUNK_DW));
+    sq_u32x4(&st)[6] = (CHUNK & 1) ? pre1 : pre0;
+    SQ_GLOAD4(st[0], voff[0], base, 0); SQ_GLOAD4(st[1], voff[0], base, 2048);
+    SQ_GLOAD4(st[2], voff[1], base, 0); SQ_GLOAD4(st[3], voff[1], base, 2048);
+    SQ_GLOAD4(st[4], voff[2], base, 0); SQ_GLOAD4(st[5], voff[2], base, 2048);
+  }
+  template <int CHUNK, int YOUNGER>
+  __device__ __forceinline__ void write() {
+    sq_u32x4(&st)[6] = (CHUNK & 1) ? pre1 : pre0;
+    SQ_VMWAIT6(YOUNGER, st);
+    sq_u32x4* dst = reinterpret_cast<sq_u32x4*>(ring + (CHUNK & 1) * SQ_CHUNK_DW) + ll;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (!SQ_LAB_SKIP(4) || i == 0) dst[128 * i] = st[i];
+  }
+  __device__ __forceinline__ void start() {       // kernel start: chunk 0 into slot 0; chunks 1 and 2 requested
+    issue<0>();
+    write<0, 0>();
+    issue<1>();
+    issue<2>();
+  }
+  template <int C, int NCH>
+  __device__ __forceinline__ void turn() {
+    write<(C + 1) % NCH, 6>();
+    issue<(C + 3) % NCH>();
+  }
+};
+
 // The whole kernel for one kind of wavefront.  LOADER = the three wavefronts that stream the packed weights into the ring: they run
 // the same loop nest and meet the same barriers as everybody else (and take their share of the gathers), but their product phases
 // move chunks instead of issuing MFMAs — as a separate instantiation, so that the chunk registers are not live in the MFMA
 // wavefronts' code and the accumulators not in theirs (one body for both carried 530 spilled registers).
-template <bool LOADER>
+template <bool LOADER, int K>
 __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, Fin = a.Fin, K = a.K, C = Fin + SQ_O;
+  const int N = a.N, Fin = a.Fin, C = Fin + SQ_O;
+  constexpr int S = 2 * K - 1, NCH = 6 * S;
   // ---- LDS carve-up: two blocks, the ring, both operators
   const SqLds s = sq_setup(smem, N, a.rp_o, a.col_o, a.val_o, a.nnz_o, a.rp_i, a.col_i, a.val_i, a.nnz_i);
   // ---- roles
   const int NRT = (N + 15) >> 4;                 // row tiles = MFMA wavefronts
   const bool consumer = !LOADER && wave < NRT;
   constexpr bool loader = LOADER;
-  const int ll = tid - SQ_LOADER0 * 64;          // loader lane 0 .. 191
-  const int NCH = sq_nchunks(K);
   // MFMA lane map: A row (clamped: the sums of rows past N are never used), D rows 4 (lane / 16) + i, D column lane % 16
   const int aoff = sq_min(16 * wave + (lane & 15), N - 1) * SQ_PITCH + 8 * (lane >> 4);
   const int dcol = lane & 15;
   const int drow0 = 16 * wave + 4 * (lane >> 4);
-  // ---- the ring: chunk gc of the kernel's stream sits in slot gc & 1; the loaders hold chunks gc + 1 .. gc + 3 in registers (an
-  // L2 round trip is longer than a chunk's products: one chunk of look-ahead made every barrier wait for the loaders)
-  constexpr int DEPTH = LOADER ? 3 : 1;
-  sq_u32x4 pre[DEPTH][4];
-  int gc = 0, lc = 0;                // chunks consumed so far; the chunk of the cell step (0 .. NCH - 1) the loaders fetch next
-  auto load_chunk = [&](int set) {
-    const sq_u32x4* src = reinterpret_cast<const sq_u32x4*>(a.Wp + lc * SQ_CHUNK_DW);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pre[set][i] = src[ll + 192 * i];
-    lc = lc + 1 == NCH ? 0 : lc + 1;
-  };
-  auto write_chunk = [&](int slot, int set) {
-    sq_u32x4* dst = reinterpret_cast<sq_u32x4*>(s.ring + slot * SQ_CHUNK_DW);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dst[ll + 192 * i] = pre[set][i];
-  };
-  // one loader turn, while the MFMA wavefronts work on chunk gc: the oldest register set -> slot (gc + 1) & 1, the sets move up, a
-  // new chunk is requested into the youngest
-  auto loader_turn = [&]() {
-    write_chunk((gc + 1) & 1, 0);
-#pragma unroll
-    for (int d = 0; d + 1 < DEPTH; ++d)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pre[d][i] = pre[d + 1][i];
-    load_chunk(DEPTH - 1);
-  };
+  SqLoader ld;
   if constexpr (LOADER) {
-    load_chunk(0);
-    write_chunk(0, 0);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_chunk(d);
+    ld.init(a.Wp, s.ring, tid - SQ_LOADER0 * 64);
+    ld.start();
   }
   float hprev[4][4];                 // H_{t-1} in the accumulator layout: [column tile][row i]
   sq_f32x4 acc[8];
@@ -341,6 +381,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
     const int64_t m0 = (int64_t)b * N;
     // ---- H_0 and X_0 into block A
     sq_barrier();                    // (every lane is done with the blocks of the previous sample; first pass: operators staged)
+    if constexpr (!LOADER)
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -354,7 +395,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
         hprev[ct][i] = h;
       }
     float2 xt = make_float2(0.f, 0.f), xn = make_float2(0.f, 0.f);
-    if (tid < N) {
+    if (!LOADER && tid < N) {
       const float* xp = a.X + (int64_t)b * a.xs_b + (int64_t)tid * Fin;
       xt.x = xp[0];
       if (Fin > 1) xt.y = xp[1];
@@ -362,7 +403,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
     }
 #pragma unroll 1
     for (int t = 0; t < a.T; ++t) {
-      if (tid < N && t + 1 < a.T) {   // next step's input columns: requested a whole step ahead
+      if (!LOADER && tid < N && t + 1 < a.T) {   // next step's input columns: requested a whole step ahead
         const float* xp = a.X + (int64_t)b * a.xs_b + (int64_t)(t + 1) * a.xs_t + (int64_t)tid * Fin;
         xn.x = xp[0];
         if (Fin > 1) xn.y = xp[1];
@@ -389,67 +430,79 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           }
         }
 
-        // ---- products of one stack segment sitting in `buf` with its weight block (position `pos` of the consumption order)
-        auto mfma_seg = [&](const float* buf, int pos) {
+        // ---- products of one stack segment sitting in `buf` with its weight block (position POS of the consumption order): NSEG
+        // chunks, (32 hidden columns kk, 64 output columns half) each; chunk index of the step C0 + j
+        auto mfma_seg = [&](const float* buf, auto postag) {
+          constexpr int POS = decltype(postag)::value;
+          constexpr int NSEG = NCT / 2;
+          constexpr int C0 = (G == 0 ? 0 : 4 * S) + POS * NSEG;
           // the segment's input columns: a rank-Fin update as ONE exact-fp32 MFMA per column tile — lane l supplies B[k = l / 16]
           // [n = l % 16] = the weight row of input column k (zero for k >= Fin), requested here and used behind the first chunk
           float xw[NCT];
           int ol = lane;
           SQ_OPAQUE(ol);             // (the lane's part of these addresses is recomputed here, not kept per segment across the time loop)
           if (consumer) {
-            const float* const wx = Wg + (int64_t)(sq_seg_at(K, pos) * C) * NOUT;
+            const float* const wx = Wg + (int64_t)(sq_seg_at(K, POS) * C) * NOUT;
             const int xo = sq_min(ol >> 4, Fin - 1) * NOUT + (ol & 15);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) xw[ct] = (ol >> 4) < Fin ? wx[xo + 16 * ct] : 0.f;
           }
-#pragma unroll 1
-          for (int kk = 0; kk < 2; ++kk) {
-            sq_u32x4 a1, a2, a3;
+          sq_u32x4 a1, a2, a3;
+          auto chunk = [&](auto jtag) {
+            constexpr int J = decltype(jtag)::value;
+            constexpr int kk = NSEG == 4 ? J / 2 : J, half = NSEG == 4 ? J % 2 : 0, CH = C0 + J;
             if (consumer) {
-              const pgt_f4 f0 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk);
-              const pgt_f4 f1 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk + 4);
-              uint32_t p1, p2, p3;
-              sq_split2_fast(f0.x, f0.y, p1, p2, p3); a1[0] = p1; a2[0] = p2; a3[0] = p3;
-              sq_split2_fast(f0.z, f0.w, p1, p2, p3); a1[1] = p1; a2[1] = p2; a3[1] = p3;
-              sq_split2_fast(f1.x, f1.y, p1, p2, p3); a1[2] = p1; a2[2] = p2; a3[2] = p3;
-              sq_split2_fast(f1.z, f1.w, p1, p2, p3); a1[3] = p1; a2[3] = p2; a3[3] = p3;
-              if (kk == 1) {
-                // (before the segment's last barrier, so that whoever rewrites the block afterwards cannot race with this read)
-                const float xa = (lane >> 4) < Fin ? buf[(aoff - 8 * (lane >> 4)) + 64 + (lane >> 4)] : 0.f;   // A[row][k = lane / 16]
+              if (half == 0) {
+                const pgt_f4 f0 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk);
+                const pgt_f4 f1 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk + 4);
+                uint32_t p1, p2, p3;
+                sq_split2_fast(f0.x, f0.y, p1, p2, p3); a1[0] = p1; a2[0] = p2; a3[0] = p3;
+                sq_split2_fast(f0.z, f0.w, p1, p2, p3); a1[1] = p1; a2[1] = p2; a3[1] = p3;
+                sq_split2_fast(f1.x, f1.y, p1, p2, p3); a1[2] = p1; a2[2] = p2; a3[2] = p3;
+                sq_split2_fast(f1.z, f1.w, p1, p2, p3); a1[3] = p1; a2[3] = p2; a3[3] = p3;
+                if (kk == 1) {
+                  // (before the segment's last barrier, so that whoever rewrites the block afterwards cannot race with this read)
+                  const float xa = (lane >> 4) < Fin ? buf[(aoff - 8 * (lane >> 4)) + 64 + (lane >> 4)] : 0.f;   // A[row][k = lane / 16]
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) acc[ct] = sq_mfma4(xa, xw[ct], acc[ct]);
+                  for (int ct = 0; ct < NCT; ++ct) acc[ct] = sq_mfma4(xa, xw[ct], acc[ct]);
+                }
               }
-            }
+              // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four)
+              const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (CH & 1) * SQ_CHUNK_DW) + lane;
+              sq_u32x4 bq[2][3];
 #pragma unroll
-            for (int half = 0; half < NCT / 4; ++half) {
-              if (consumer) {
-                // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four)
-                const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (gc & 1) * SQ_CHUNK_DW) + lane;
-                sq_u32x4 bq[2][3];
+              for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+              for (int ct = 0; ct < 4; ++ct) {
+                if (ct < 3 && !SQ_LAB_SKIP(2)) {
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                  if (ct < 3) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bq[(ct + 1) & 1][pl] = slot[((ct + 1) * 3 + pl) * 64];
-                  }
-                  const sq_u32x4 b1 = bq[ct & 1][0], b2 = bq[ct & 1][1], b3 = bq[ct & 1][2];
-                  sq_f32x4 c = acc[4 * half + ct];
+                  for (int pl = 0; pl < 3; ++pl) bq[(ct + 1) & 1][pl] = slot[((ct + 1) * 3 + pl) * 64];
+                }
+                const sq_u32x4 b1 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][0], b2 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][1], b3 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][2];
+                sq_f32x4 c = acc[4 * half + ct];
+                if (!SQ_LAB_SKIP(1)) {
+                  // (one chain of six on the running sum: two chains of three, added at the end, measured 12 % SLOWER per phase)
                   c = sq_mfma16(a3, b1, c);
                   c = sq_mfma16(a1, b3, c);
                   c = sq_mfma16(a2, b2, c);
                   c = sq_mfma16(a2, b1, c);
                   c = sq_mfma16(a1, b2, c);
                   c = sq_mfma16(a1, b1, c);
-                  acc[4 * half + ct] = c;
-                  PGT_SCHED_FENCE();
+                } else {
+                  c[0] += sq_as_float(a1[0] ^ b1[0] ^ a2[1] ^ b2[1] ^ a3[2] ^ b3[2]);
                 }
+                acc[4 * half + ct] = c;
+                PGT_SCHED_FENCE();
               }
-              if constexpr (LOADER) loader_turn();
-              ++gc;
-              sq_barrier();
             }
+            if constexpr (LOADER) ld.template turn<CH, NCH>();
+            sq_barrier();
+          };
+          chunk(SqInt<0>{});
+          chunk(SqInt<1>{});
+          if constexpr (NSEG == 4) {
+            chunk(SqInt<2>{});
+            chunk(SqInt<3>{});
           }
         };
 
@@ -457,6 +510,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
         // read back by the same thread) while block A is still being read by the products
         int ot = tid;
         SQ_OPAQUE(ot);
+if constexpr (!LOADER)
 #pragma unroll
         for (int j = 0; j < SQ_MAXT; ++j) {
           const SqTask k = sq_task(ot, j, N);
@@ -472,13 +526,14 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
         }
         sq_barrier();
         SQ_MARK(t, G, 1);
-        mfma_seg(s.bufA, 0);
-        mfma_seg(s.bufB, 1);
+        mfma_seg(s.bufA, SqInt<0>{});
+        mfma_seg(s.bufB, SqInt<1>{});
         SQ_MARK(t, G, 2);
-        if (K >= 3) {
+        if constexpr (K >= 3) {
           // ---- hop 2, first direction: T2o = 2 P_o T1o - T0 -> block A (T_0 is dead in LDS)
           ot = tid;
           SQ_OPAQUE(ot);
+if constexpr (!LOADER)
 #pragma unroll
           for (int j = 0; j < SQ_MAXT; ++j) {
             const SqTask k = sq_task(ot, j, N);
@@ -492,6 +547,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           }
           // T1i comes back from the saved stack: requested here, a product phase ahead of its use
           pgt_f4 i1[SQ_MAXT];
+if constexpr (!LOADER)
 #pragma unroll
           for (int j = 0; j < SQ_MAXT; ++j) {
             const SqTask k = sq_task(ot, j, N);
@@ -500,10 +556,11 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           }
           sq_barrier();
           SQ_MARK(t, G, 3);
-          mfma_seg(s.bufA, 2);
+          mfma_seg(s.bufA, SqInt<2>{});
           SQ_MARK(t, G, 4);
           ot = tid;
           SQ_OPAQUE(ot);
+if constexpr (!LOADER)
 #pragma unroll
           for (int j = 0; j < SQ_MAXT; ++j) {
             const SqTask k = sq_task(ot, j, N);
@@ -514,6 +571,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           // ---- hop 2, second direction: T2i = 2 P_i T1i - T0 -> block A
           ot = tid;
           SQ_OPAQUE(ot);
+if constexpr (!LOADER)
 #pragma unroll
           for (int j = 0; j < SQ_MAXT; ++j) {
             const SqTask k = sq_task(ot, j, N);
@@ -527,18 +585,19 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           }
           sq_barrier();
           SQ_MARK(t, G, 6);
-          mfma_seg(s.bufB, 3);
-          mfma_seg(s.bufA, 4);
+          mfma_seg(s.bufB, SqInt<3>{});
+          mfma_seg(s.bufA, SqInt<4>{});
         } else {
           ot = tid;
           SQ_OPAQUE(ot);
+if constexpr (!LOADER)
 #pragma unroll
           for (int j = 0; j < SQ_MAXT; ++j) {
             const SqTask k = sq_task(ot, j, N);
             if (k.live) *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
           }
           sq_barrier();
-          mfma_seg(s.bufA, 2);
+          mfma_seg(s.bufA, SqInt<2>{});
         }
         SQ_MARK(t, G, 7);
         // ---- gate chain on the accumulators (every product of this convolution is behind a barrier: both blocks are free)
@@ -559,7 +618,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
               }
             }
           }
-          if (tid < N) *reinterpret_cast<pgt_f4*>(s.bufA + tid * SQ_PITCH + 64) = pgt_mk4(xt.x, xt.y, 0.f, 0.f);
+          if (!LOADER && tid < N) *reinterpret_cast<pgt_f4*>(s.bufA + tid * SQ_PITCH + 64) = pgt_mk4(xt.x, xt.y, 0.f, 0.f);
         } else {
           if (consumer) {
             float z[4][4];           // Z of this step: stored by this very lane in the update / reset epilogue, read back instead of held
@@ -584,7 +643,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
             }
           }
           xt = xn;
-          if (tid < N) *reinterpret_cast<pgt_f4*>(s.bufA + tid * SQ_PITCH + 64) = pgt_mk4(xt.x, xt.y, 0.f, 0.f);
+          if (!LOADER && tid < N) *reinterpret_cast<pgt_f4*>(s.bufA + tid * SQ_PITCH + 64) = pgt_mk4(xt.x, xt.y, 0.f, 0.f);
         }
         SQ_MARK(t, G, 8);
       };
@@ -594,10 +653,13 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
   }
 }
 
+// (lab/seq64_lab.hip instantiates the loader wavefront's path as a kernel of its own: its register report must show NO scratch — a
+// register spilled while a hand-issued load is pending on it would be saved before the data lands)
+template <int K>
 __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq64_fwd_kernel(Seq64Args a) {
   __shared__ __attribute__((aligned(16))) char smem[SQ_LDS];
-  if ((int)(threadIdx.x >> 6) >= SQ_LOADER0) sq_fwd_body<true>(a, smem);
-  else sq_fwd_body<false>(a, smem);
+  if ((int)(threadIdx.x >> 6) >= SQ_LOADER0) sq_fwd_body<true, K>(a, smem);
+  else sq_fwd_body<false, K>(a, smem);
 }
 
 
@@ -671,15 +733,14 @@ __global__ __launch_bounds__(256) void seq64_pack_bwd_kernel(const float* __rest
   dst[512] = p3;
 }
 
-template <bool LOADER>
+template <bool LOADER, int K>
 __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, K = a.K;
+  const int N = a.N;
+  constexpr int S = 2 * K - 1, NCH = 6 * S;
   const SqLds s = sq_setup(smem, N, a.rp_o, a.col_o, a.val_o, a.nnz_o, a.rp_i, a.col_i, a.val_i, a.nnz_i);
   const int NRT = (N + 15) >> 4;
   const bool consumer = !LOADER && wave < NRT;
-  const int ll = tid - SQ_LOADER0 * 64;
-  const int NCH = sq_nchunks(K);
   // A-operand layout: this lane's row (clamped; `rvalid`: it exists) and its first column of every 32
   const int arow_raw = 16 * wave + (lane & 15);
   const bool rvalid = consumer && arow_raw < N;
@@ -687,46 +748,24 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
   const int acol = 8 * (lane >> 4);
   const int dcol = lane & 15;
   const int drow0 = 16 * wave + 4 * (lane >> 4);
-  // ---- the ring (as in the forward kernel)
-  constexpr int DEPTH = LOADER ? 3 : 1;
-  sq_u32x4 pre[DEPTH][4];
-  int gc = 0, lc = 0;
-  auto load_chunk = [&](int set) {
-    const sq_u32x4* src = reinterpret_cast<const sq_u32x4*>(a.Wp + lc * SQ_CHUNK_DW);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pre[set][i] = src[ll + 192 * i];
-    lc = lc + 1 == NCH ? 0 : lc + 1;
-  };
-  auto write_chunk = [&](int slot, int set) {
-    sq_u32x4* dst = reinterpret_cast<sq_u32x4*>(s.ring + slot * SQ_CHUNK_DW);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dst[ll + 192 * i] = pre[set][i];
-  };
-  auto loader_turn = [&]() {
-    write_chunk((gc + 1) & 1, 0);
-#pragma unroll
-    for (int d = 0; d + 1 < DEPTH; ++d)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pre[d][i] = pre[d + 1][i];
-    load_chunk(DEPTH - 1);
-  };
+  SqLoader ld;
   if constexpr (LOADER) {
-    load_chunk(0);
-    write_chunk(0, 0);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_chunk(d);
+    ld.init(a.Wp, s.ring, tid - SQ_LOADER0 * 64);
+    ld.start();
   }
   float* const park = a.park + (int64_t)blockIdx.x * N * SQ_O;
 
-  // G = dP W_seg^T for one stack segment: KK chunks (32 columns of dP each), the 64 columns of G leave the accumulators into `dst`
-  // (accumulator layout: rows 4 (l / 16) + i, column 16 ct + l % 16) before the segment's last barrier
-  auto mfma_to = [&](float* dst, const float* dp, auto kktag) {
-    constexpr int KK = decltype(kktag)::value;
+  // G = dP W_seg^T for one stack segment (position POS of the adjoint's consumption order): KK chunks (32 columns of dP each), the
+  // 64 columns of G leave the accumulators into `dst` (accumulator layout: rows 4 (l / 16) + i, column 16 ct + l % 16) before the
+  // segment's last barrier.  Chunk index of the step: the candidate's 2 S chunks come first, then the 4 S of z | r
+  auto mfma_to = [&](float* dst, const float* dp, auto kktag, auto postag) {
+    constexpr int KK = decltype(kktag)::value, POS = decltype(postag)::value;
+    constexpr int C0 = (KK == 2 ? 0 : 2 * S) + POS * KK;
     sq_f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = sq_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
+    auto chunk = [&](auto jtag) {
+      constexpr int kk = decltype(jtag)::value, CH = C0 + kk;
       if (consumer) {
         sq_u32x4 a1, a2, a3;
         uint32_t p1, p2, p3;
@@ -734,7 +773,7 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
         sq_split2_fast(dp[8 * kk + 2], dp[8 * kk + 3], p1, p2, p3); a1[1] = p1; a2[1] = p2; a3[1] = p3;
         sq_split2_fast(dp[8 * kk + 4], dp[8 * kk + 5], p1, p2, p3); a1[2] = p1; a2[2] = p2; a3[2] = p3;
         sq_split2_fast(dp[8 * kk + 6], dp[8 * kk + 7], p1, p2, p3); a1[3] = p1; a2[3] = p2; a3[3] = p3;
-        const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (gc & 1) * SQ_CHUNK_DW) + lane;
+        const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (CH & 1) * SQ_CHUNK_DW) + lane;
         sq_u32x4 bq[2][3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
@@ -763,26 +802,32 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
               if (drow0 + i < N) dst[(drow0 + i) * SQ_PITCH + 16 * ct + dcol] = acc[ct][i];
         }
       }
-      if constexpr (LOADER) loader_turn();
-      ++gc;
+      if constexpr (LOADER) ld.template turn<CH, NCH>();
       sq_barrier();
+    };
+    chunk(SqInt<0>{});
+    chunk(SqInt<1>{});
+    if constexpr (KK == 4) {
+      chunk(SqInt<2>{});
+      chunk(SqInt<3>{});
     }
   };
 
   // adjoint of one diffusion convolution: dp = this lane's KK * 8 columns of dP; on exit block A holds d/dT_0 (hidden columns),
   // NOT yet behind a barrier
   auto conv_adjoint = [&](const float* dp, auto kktag) {
-    auto own = [&](int j, int& off, bool& live) {          // hidden quad j of this thread: tasks tid + 1024 j < 16 N
+    auto own = [&](int j, int& off, bool& live) {          // hidden quad j of this thread: tasks tid + 896 j < 16 N
       int ot = tid;
       SQ_OPAQUE(ot);
-      const int idx = ot + j * SQ_THREADS;
+      const int idx = ot + j * SQ_GTHREADS;
       live = idx < 16 * N;
       off = live ? (idx >> 4) * SQ_PITCH + 4 * (idx & 15) : 0;
     };
     auto addq = [](pgt_f4 x, pgt_f4 y) { return pgt_mk4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
-    if (K >= 3) {
-      mfma_to(s.bufA, dp, kktag);          // G2o
-      mfma_to(s.bufB, dp, kktag);          // G1o
+    if constexpr (K >= 3) {
+      mfma_to(s.bufA, dp, kktag, SqInt<0>{});          // G2o
+      mfma_to(s.bufB, dp, kktag, SqInt<1>{});          // G1o
+if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // B += 2 P_o^T A
         int off; bool live;
@@ -794,6 +839,7 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
         }
       }
       sq_barrier();
+if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // park = P_o^T B
         int off; bool live;
@@ -804,8 +850,9 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
         }
       }
       sq_barrier();
-      mfma_to(s.bufA, dp, kktag);          // G2i
-      mfma_to(s.bufB, dp, kktag);          // G1i
+      mfma_to(s.bufA, dp, kktag, SqInt<2>{});          // G2i
+      mfma_to(s.bufB, dp, kktag, SqInt<3>{});          // G1i
+if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // B += 2 P_i^T A
         int off; bool live;
@@ -817,7 +864,8 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
         }
       }
       sq_barrier();
-      mfma_to(s.bufA, dp, kktag);          // G0 (the "- T_0" of the second hop folded in)
+      mfma_to(s.bufA, dp, kktag, SqInt<4>{});          // G0 (the "- T_0" of the second hop folded in)
+if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // A += park + P_i^T B
         int off; bool live;
@@ -831,8 +879,9 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
         }
       }
     } else {
-      mfma_to(s.bufA, dp, kktag);          // G1o
-      mfma_to(s.bufB, dp, kktag);          // G1i
+      mfma_to(s.bufA, dp, kktag, SqInt<0>{});          // G1o
+      mfma_to(s.bufB, dp, kktag, SqInt<1>{});          // G1i
+if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // park = P_o^T A + P_i^T B
         int off; bool live;
@@ -845,7 +894,8 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
         }
       }
       sq_barrier();
-      mfma_to(s.bufA, dp, kktag);          // G0
+      mfma_to(s.bufA, dp, kktag, SqInt<2>{});          // G0
+if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {
         int off; bool live;
@@ -951,10 +1001,11 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
   }
 }
 
+template <int K>
 __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq64_bwd_kernel(Seq64BwdArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[SQ_LDS];
-  if ((int)(threadIdx.x >> 6) >= SQ_LOADER0) sq_bwd_body<true>(a, smem);
-  else sq_bwd_body<false>(a, smem);
+  if ((int)(threadIdx.x >> 6) >= SQ_LOADER0) sq_bwd_body<true, K>(a, smem);
+  else sq_bwd_body<false, K>(a, smem);
 }
 
 }  // namespace
@@ -962,7 +1013,7 @@ __global__ __launch_bounds__(SQ_THREADS) void dcrnn_seq64_bwd_kernel(Seq64BwdArg
 // ---------------------------------------------------------------------------------------------------------------- C ABI
 extern "C" int pgt_dcrnn_seq64_fits(int64_t N, int64_t E_o, int64_t E_i, int64_t Fin, int64_t O, int64_t K) {
   if (O != SQ_O || Fin != 2 || (K != 2 && K != 3) || N < 1 || E_o < 0 || E_i < 0) return 0;
-  if ((N + 15) / 16 > SQ_LOADER0 || 17 * N > SQ_MAXT * SQ_THREADS) return 0;
+  if ((N + 15) / 16 > SQ_LOADER0 || 17 * N > SQ_MAXT * SQ_GTHREADS) return 0;
   if (E_o > 65535 || E_i > 65535) return 0;
   return sq_lds_bytes(N, E_o, E_i) <= (size_t)SQ_LDS ? 1 : 0;
 }
@@ -1000,7 +1051,8 @@ extern "C" int pgt_dcrnn_seq64_f32(const pgt_csr* op_o, const pgt_csr* op_i, int
   a.out = out; a.os_b = out_stride_b; a.os_t = out_stride_t;
   a.TSzr = TSzr; a.TSh = TSh; a.seg_stride = seg_stride; a.t_stride = t_stride; a.ZR = ZR; a.HT = HT;
   const int nblk = (int)(B < SQ_CUS ? B : SQ_CUS);
-  PGT_LAUNCH(dcrnn_seq64_fwd_kernel, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
+  if (K == 3) PGT_LAUNCH(dcrnn_seq64_fwd_kernel<3>, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
+  else PGT_LAUNCH(dcrnn_seq64_fwd_kernel<2>, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
   return pgt_check_launch("pgt_dcrnn_seq64_f32");
 }
 
@@ -1038,6 +1090,7 @@ extern "C" int pgt_dcrnn_seq64_bwd_f32(const pgt_csr* tp_o, const pgt_csr* tp_i,
   a.H0 = H0; a.ZR = ZR; a.HT = HT; a.Wp = reinterpret_cast<const uint32_t*>(Wp);
   a.dPzr = dPzr; a.dPh = dPh; a.dH0 = dH0; a.park = ws;
   const int nblk = (int)(B < SQ_CUS ? B : SQ_CUS);
-  PGT_LAUNCH(dcrnn_seq64_bwd_kernel, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
+  if (K == 3) PGT_LAUNCH(dcrnn_seq64_bwd_kernel<3>, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
+  else PGT_LAUNCH(dcrnn_seq64_bwd_kernel<2>, dim3((unsigned)nblk), dim3(SQ_THREADS), stream, a);
   return pgt_check_launch("pgt_dcrnn_seq64_bwd_f32");
 }

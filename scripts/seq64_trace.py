@@ -16,7 +16,8 @@ from pytorch_geometric_temporal_amd.nn.recurrent.dcrnn import _cell_weights
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 1515
 dev = torch.device("cuda:0")
-lab = ctypes.CDLL(os.path.join(ROOT, "lab", "libseq64_lab.so"))
+lab = ctypes.CDLL(os.path.join(ROOT, "lab", f"libseq64_lab{sys.argv[3] if len(sys.argv) > 3 else ''}.so"))
+print(f"== {os.path.basename(lab._name)}")
 N, T, Fin, O, K = 207, 12, 2, 64, 3
 S, C, M = 2 * K - 1, Fin + O, B * N
 ei_np, ew_np = syn.sensor_graph(N, E, seed=0, symmetric=False)

@@ -146,6 +146,23 @@ def kernel_class_rooflines(kernels, shapes):
             v["algorithmic_bytes_per_launch"] = v["work_per_launch"]
             v["achieved_GBs"] = v["work_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
             v["hbm_frac"] = v["achieved_GBs"] / HBM_PEAK_GBS
+            if kk == "seq64":
+                # the one-launch sequence kernels (csrc/seq64.hip): forward = every diffusion term x its weight block (330 -> 192
+                # columns per row and step), adjoint = dP x W^T (192 -> 320); six bf16 MFMAs per fp32 product.  Bytes = inputs read
+                # once + saved tensors / pre-activation gradients written once (no term crosses HBM between aggregation and product)
+                v["by_direction"] = []
+                tot_f = tot_s = 0.0
+                for r in recs:
+                    d, B, T, Nn = r["tag"][1:5]
+                    flops = 2.0 * B * T * Nn * (330 * 192 if d == "fwd" else 192 * 320)
+                    sec = r["avg_us"] * 1e-6
+                    tot_f += flops * r["launches"]
+                    tot_s += r["total_ms"] * 1e-3
+                    v["by_direction"].append({"direction": d, "launches": r["launches"], "avg_us": r["avg_us"],
+                                              "algorithmic_MB": r["work_per_launch"] / 1e6,
+                                              "hbm_frac": r["work_per_launch"] / sec / 1e9 / HBM_PEAK_GBS,
+                                              "bf16_pipe_frac": 6.0 * flops / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS})
+                v["bf16_pipe_frac"] = 6.0 * tot_f / tot_s / 1e12 / MFMA_BF16_PEAK_TFLOPS if tot_s > 0 else None
     return kernels
 
 
@@ -728,7 +745,10 @@ def main():
                  "gemm": "gemm_bx_kernel / gemm_bx_sym_kernel (split-bf16 on the bf16 matrix pipe: 330->128 + z|r gates, 330->64 + candidate "
                          "gate, 128->320 and 64->320 feature gradients) + the streaming read-out kernels, behind pgt_gemm_f32 / "
                          "pgt_gemm_gru_zr/h_f32; every launch of the entry points; bytes = operands once + results once",
-                 "gemm_tn": "gemm_bx_tn_kernel (pgt_gemm_tn_acc_f32, split-bf16)"}
+                 "gemm_tn": "gemm_bx_tn_kernel (pgt_gemm_tn_acc_f32, split-bf16)",
+                 "seq64": "dcrnn_seq64_fwd/bwd_kernel (pgt_dcrnn_seq64_f32 / _bwd_f32): all T cell steps of a sample in one workgroup — hops "
+                          "gathered out of LDS, split-bf16 products on the terms while they are there, gate chains on the accumulators; "
+                          "bytes = inputs once + what the adjoint / the weight gradient needs, written once"}
         roof = {"kernel": names.get(dom, dom), "bound": "hbm", "achieved": k["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": k["hbm_frac"], "traffic": None,
                 "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
@@ -738,6 +758,11 @@ def main():
         if dom in ("gemm", "gemm_tn"):
             roof["bf16_pipe_frac"] = k["bf16_pipe_frac"]
             roof["fp32_product_TFLOPs"] = k["fp32_product_TFLOPs"]
+        if dom == "seq64":
+            roof["bf16_pipe_frac"] = k["bf16_pipe_frac"]
+            roof["by_direction"] = k["by_direction"]
+            roof["why_hbm"] = ("a fused kernel: its HBM traffic is the saved activations (written once) — at 2 TB/s it is bound by neither "
+                               "HBM nor the matrix pipe but by the LDS gathers and the per-chunk hand-overs inside a CU (DESIGN.md 3.2)")
         roof.update(pmc_traffic(dom))
         roof["all_kernel_classes"] = all_kernel_classes(kernels, args.profile_steps)
     del step

@@ -767,6 +767,45 @@ def main():
         roof["all_kernel_classes"] = all_kernel_classes(kernels, args.profile_steps)
     del step
 
+    # ---- more than one GPU: the exchange on its own, and the same 1 024-window step split over the ranks (strong scaling) beside
+    # the weak-scaling headline — every rank runs both (they contain collectives), rank 0 reports
+    multi = None
+    if world > 1:
+        assert dist.is_initialized() and dist.get_world_size() == args.gpus, \
+            f"--gpus {args.gpus} but the process group has {dist.get_world_size() if dist.is_initialized() else 0} rank(s)"
+        multi = {"world_size": dist.get_world_size(), "backend": dist.get_backend()}
+        try:
+            n_par = sum(p.numel() for p in Model(args.hidden).parameters())
+            buf = torch.zeros(n_par, device=device)
+            for _ in range(5):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            multi["allreduce_us_per_step"] = 1e6 * (time.perf_counter() - t0) / 50
+            multi["allreduce_bytes"] = 4 * n_par
+            multi["allreduce_what"] = "50 back-to-back all-reduces of the flat gradient buffer, wall clock / 50 (launch + ring latency; nothing overlaps it in the step)"
+            del buf
+        except Exception as e:
+            multi["allreduce_error"] = repr(e)
+        if scaling == "weak" and 1024 % world == 0 and not args.no_extra:
+            try:
+                torch.cuda.empty_cache()
+                ds, _, st, _ = train_run(device, rank, world, series, args.edges, 1024 // world, args.hidden, args.steps, args.warmup, graph=True)
+                del st
+                multi["strong_scaling_global_batch_1024"] = {
+                    "batch_per_gpu": 1024 // world, "ms_per_step": 1e3 * ds / args.steps, "graphed": True,
+                    "value": 1024 * SEQ * args.edges * args.steps / ds,
+                    "what": "the fixed 1 024-window step split over the ranks (forward + backward and the update as hipGraphs, the "
+                            "all-reduce between them eager); compare with the 1-GPU line's ms_per_step"}
+                log(f"strong scaling, {1024 // world} windows per GPU: {1e3 * ds / args.steps:.3f} ms/step")
+            except Exception as e:
+                multi["strong_scaling_global_batch_1024"] = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline ...")
@@ -811,11 +850,17 @@ def main():
                 "the torch.nn.Linear read-out (dcrnn_example.py:27-28, tgcn/metr_la_main.py:43-44): relu(states) keeps the routing, the "
                 "relu itself is torch's", dropin=True, relu=True)
         variant("edges_1722", "1 722-edge graph (the reference's METR-LA data)", edges=1722)
-        lib.tune("gemm_bx", 0)
+        ops.USE_SEQ64 = False
         try:
-            variant("exact_fp32", "pgt_tune(gemm_bx, 0): every dense product on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain)")
+            variant("per_step_launches", "PGT_SEQ64=0: round 5's path — four launches per cell step forward (two LDS-resident stacks, two "
+                    "gate-fused split-bf16 products), six backward — instead of the one-launch sequence kernels (csrc/seq64.hip)")
+            lib.tune("gemm_bx", 0)
+            try:
+                variant("exact_fp32", "PGT_SEQ64=0 + pgt_tune(gemm_bx, 0): every dense product on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain)")
+            finally:
+                lib.tune("gemm_bx", 1)
         finally:
-            lib.tune("gemm_bx", 1)
+            ops.USE_SEQ64 = True
         lib.tune("gemm_bx_tn_pc", 0)
         lib.tune("gemm_bx_sym_pc", 0)
         try:
@@ -906,7 +951,8 @@ def main():
             "config": {"workload": f"METR-LA-shaped synthetic (207 nodes, {args.edges} edges, 12-step) BatchedDCRNN(2,{args.hidden},K=3)"
                                    + ("" if args.hidden == 2 else "+Linear") + " training step (fwd+bwd+allreduce+Adam)",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "seq_len": SEQ,
-                       "parallelism": f"dp{world}", "hidden": args.hidden, "K": 3, "init_passes": 1,
+                       "parallelism": f"dp{world}", "ranks": (dist.get_world_size() if world > 1 else 1),
+                       "backend": (dist.get_backend() if world > 1 else None), "hidden": args.hidden, "K": 3, "init_passes": 1,
                        "graphed": bool(args.graph),
                        "output_layout": "BatchedDCRNN default (contiguous [B,T,N,O], stored by the gate epilogues) + this package's Linear "
                                         "read-out; torch.nn.Linear read-out = variants.dropin_default (routed to the same kernels) / dropin_blas_readout (torch's BLAS)"},
@@ -914,7 +960,7 @@ def main():
             "epoch_time_s_23974_windows": 23974.0 / (world * args.batch) * dt / args.steps,
             "final_loss": final_loss,
             "roofline": roof, "kernels": kernels, "roofline_ns_spmm_N200k_F64": ns, "cpu_baseline": cpu,
-            "variants": variants, "other_configs": extra,
+            "multi_gpu": multi, "variants": variants, "other_configs": extra,
         }
         import bench_line
         partial = args.no_extra or args.no_cpu_baseline or args.profile_steps == 0      # a profiler pass must not overwrite the clocked run's record

@@ -74,6 +74,11 @@ def compact_roofline(roof):
     for k in ("bf16_pipe_frac", "fp32_product_TFLOPs"):
         if roof.get(k) is not None:
             out[k] = _r(roof[k])
+    if roof.get("why_hbm"):
+        out["why_hbm"] = _s(roof["why_hbm"], 240)
+    if isinstance(roof.get("by_direction"), list):
+        out["by_direction"] = [{"dir": d.get("direction"), "us": _r(d.get("avg_us")), "hbm_frac": _r(d.get("hbm_frac"), 3),
+                                "bf16_pipe_frac": _r(d.get("bf16_pipe_frac"), 3)} for d in roof["by_direction"][:2]]
     if isinstance(roof.get("set_aside"), dict):
         out["set_aside"] = {"launches": roof["set_aside"].get("launches"), "ms": _r(roof["set_aside"].get("ms"), 4),
                             "rule": "over 10x the median of its shape (host stall inside the event pair)"}
@@ -189,6 +194,15 @@ def compact(full, full_path=None):
     line["cpu_baseline"] = compact_cpu(full.get("cpu_baseline"))
     if full.get("roofline_ns_spmm_N200k_F64") is not None:
         line["roofline_ns_spmm_N200k_F64"] = compact_ns(full["roofline_ns_spmm_N200k_F64"])
+    if isinstance(full.get("multi_gpu"), dict):
+        m = full["multi_gpu"]
+        line["multi_gpu"] = {"world_size": m.get("world_size"), "backend": m.get("backend"), "allreduce_us_per_step": _r(m.get("allreduce_us_per_step")),
+                             "allreduce_bytes": m.get("allreduce_bytes"),
+                             "strong_scaling_global_batch_1024": (_problem(m.get("strong_scaling_global_batch_1024")) or
+                                                                  {k: _r(v) if isinstance(v, float) else v
+                                                                   for k, v in (m.get("strong_scaling_global_batch_1024") or {}).items() if k != "what"})
+                             if m.get("strong_scaling_global_batch_1024") is not None else None,
+                             **({"allreduce_error": _s(m["allreduce_error"], 120)} if m.get("allreduce_error") else {})}
     if full.get("variants") is not None:
         line["variants_ms_per_step"] = compact_variants(full["variants"])
     if full.get("other_configs") is not None:

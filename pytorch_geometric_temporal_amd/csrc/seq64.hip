@@ -448,6 +448,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
             for (int ct = 0; ct < NCT; ++ct) xw[ct] = (ol >> 4) < Fin ? wx[xo + 16 * ct] : 0.f;
           }
           sq_u32x4 a1, a2, a3;
+          sq_u32x4 bq[2][3];
           auto chunk = [&](auto jtag) {
             constexpr int J = decltype(jtag)::value;
             constexpr int kk = NSEG == 4 ? J / 2 : J, half = NSEG == 4 ? J % 2 : 0, CH = C0 + J;
@@ -467,16 +468,28 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
                   for (int ct = 0; ct < NCT; ++ct) acc[ct] = sq_mfma4(xa, xw[ct], acc[ct]);
                 }
               }
-              // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four)
+              // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four).  The
+              // chunk's barrier stands BEFORE the products of its last tile — every read of this slot is behind it, the loaders have
+              // written the next chunk into the other slot — and the first fragments of the next chunk are requested right behind
+              // it: their LDS latency and the barrier's skew hide under six MFMAs instead of idling the matrix pipe at every chunk
               const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (CH & 1) * SQ_CHUNK_DW) + lane;
-              sq_u32x4 bq[2][3];
+              if (J == 0) {
 #pragma unroll
-              for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+                for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+              }
 #pragma unroll
               for (int ct = 0; ct < 4; ++ct) {
                 if (ct < 3 && !SQ_LAB_SKIP(2)) {
 #pragma unroll
                   for (int pl = 0; pl < 3; ++pl) bq[(ct + 1) & 1][pl] = slot[((ct + 1) * 3 + pl) * 64];
+                }
+                if (ct == 3) {
+                  sq_barrier();
+                  if (J < NSEG - 1) {
+                    const sq_u32x4* nslot = reinterpret_cast<const sq_u32x4*>(s.ring + ((CH + 1) & 1) * SQ_CHUNK_DW) + lane;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bq[0][pl] = nslot[pl * 64];
+                  }
                 }
                 const sq_u32x4 b1 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][0], b2 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][1], b3 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][2];
                 sq_f32x4 c = acc[4 * half + ct];
@@ -494,9 +507,10 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
                 acc[4 * half + ct] = c;
                 PGT_SCHED_FENCE();
               }
+            } else {
+              if constexpr (LOADER) ld.template turn<CH, NCH>();
+              sq_barrier();
             }
-            if constexpr (LOADER) ld.template turn<CH, NCH>();
-            sq_barrier();
           };
           chunk(SqInt<0>{});
           chunk(SqInt<1>{});
@@ -764,8 +778,10 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
     sq_f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = sq_f32x4{0.f, 0.f, 0.f, 0.f};
+    sq_u32x4 bq[2][3];
     auto chunk = [&](auto jtag) {
       constexpr int kk = decltype(jtag)::value, CH = C0 + kk;
+      constexpr bool LAST = kk == KK - 1;       // the segment's last chunk keeps its barrier at the end: G must be in `dst` behind it
       if (consumer) {
         sq_u32x4 a1, a2, a3;
         uint32_t p1, p2, p3;
@@ -774,14 +790,21 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
         sq_split2_fast(dp[8 * kk + 4], dp[8 * kk + 5], p1, p2, p3); a1[2] = p1; a2[2] = p2; a3[2] = p3;
         sq_split2_fast(dp[8 * kk + 6], dp[8 * kk + 7], p1, p2, p3); a1[3] = p1; a2[3] = p2; a3[3] = p3;
         const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (CH & 1) * SQ_CHUNK_DW) + lane;
-        sq_u32x4 bq[2][3];
+        if (kk == 0) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+          for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+        }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
           if (ct < 3) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bq[(ct + 1) & 1][pl] = slot[((ct + 1) * 3 + pl) * 64];
+          }
+          if (ct == 3 && !LAST) {              // (see the forward kernel: the barrier before the last tile's products, the next chunk's
+            sq_barrier();                      // first fragments requested right behind it)
+            const sq_u32x4* nslot = reinterpret_cast<const sq_u32x4*>(s.ring + ((CH + 1) & 1) * SQ_CHUNK_DW) + lane;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bq[0][pl] = nslot[pl * 64];
           }
           const sq_u32x4 b1 = bq[ct & 1][0], b2 = bq[ct & 1][1], b3 = bq[ct & 1][2];
           sq_f32x4 c = acc[ct];
@@ -794,16 +817,18 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
           acc[ct] = c;
           PGT_SCHED_FENCE();
         }
-        if (kk == KK - 1) {
+        if (LAST) {
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               if (drow0 + i < N) dst[(drow0 + i) * SQ_PITCH + 16 * ct + dcol] = acc[ct][i];
+          sq_barrier();
         }
+      } else {
+        if constexpr (LOADER) ld.template turn<CH, NCH>();
+        sq_barrier();
       }
-      if constexpr (LOADER) ld.template turn<CH, NCH>();
-      sq_barrier();
     };
     chunk(SqInt<0>{});
     chunk(SqInt<1>{});

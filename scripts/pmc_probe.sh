@@ -26,7 +26,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(f"{root}/{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if not any(t in name for t in ("tgcn", "spmm", "gemm", "dconv", "relu_linear", "gru_")):
+        if not any(t in name for t in ("tgcn", "spmm", "gemm", "dconv", "relu_linear", "gru_", "seq64")):
             continue
         k = name.replace("(anonymous namespace)::", "").replace("void ", "")[:70]
         a = acc[k][r["Counter_Name"]]

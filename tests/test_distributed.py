@@ -165,3 +165,37 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_in_the_environment():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["rank_sum"] == 3.0        # ranks 0 and 1 met: 1 + 2
     assert "torch.distributed.run" in r.stderr
+
+
+@pytest.mark.gpu
+def test_rccl_carries_the_flat_gradient_all_reduce_on_one_rank():
+    """What one GPU can show of the RCCL path (8-GPU runs are the driver's): a world-1 "nccl" process group comes up on cuda:0, the
+    flat gradient buffer of the benchmarked model goes through all_reduce_mean / reduce_scalars / timed_steps' MAX-reduce, and comes
+    back unchanged — in a child process, so that the group's lifetime is the test's."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pytorch_geometric_temporal_amd import dp
+from pytorch_geometric_temporal_amd.nn.recurrent import BatchedDCRNN
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+m = torch.nn.Sequential(BatchedDCRNN(2, 64, 3), torch.nn.Linear(64, 2)).cuda()
+flat = dp.FlatParameters(m.parameters())
+flat.flat.copy_(torch.randn_like(flat.flat))
+want = flat.flat.clone()
+dist.all_reduce(flat.flat)                      # SUM over one rank
+flat.all_reduce_mean(world=1)                   # (a no-op by construction at world 1)
+torch.cuda.synchronize()
+assert torch.equal(flat.flat, want)
+assert float(dp.reduce_scalars([1.5, 2.0])[1]) == 2.0
+dt, out = dp.timed_steps(lambda i: i, 0, 3, device="cuda:0")
+assert out == 2 and dt >= 0.0
+dist.barrier()
+dist.destroy_process_group()
+print("rccl world-1 ok", flat.flat.numel())
+'''
+    r = subprocess.run([sys.executable, "-c", code, ROOT, str(_free_port())], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -60,6 +60,11 @@ __device__ __forceinline__ uint64_t sq_uniform64(uint64_t x) {      // a wave-un
 #define SQ_GLOAD4(dst, voff, sbase, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
 #define SQ_VMWAIT4(n, r0, r1, r2, r3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(n))
 #define SQ_VMWAIT6(n, r) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(n))
+// one discarded dword: brings its cache line towards this CU ahead of the load proper
+// (`sink` must stay allocated until the data has landed — the compiler cannot see the pending write to it: SQ_TOUCH_DONE(sink) stands
+// where the loads proper have been waited for, which are younger and return in order)
+#define SQ_TOUCH(sink, ptr) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(ptr) : "memory")
+#define SQ_TOUCH_DONE(sink) asm volatile("" :: "v"(sink))
 // exact fp32 products (v_mfma_f32_16x16x4_f32): the rank-Fin update of the input columns
 __device__ __forceinline__ sq_f32x4 sq_mfma4(float a, float b, sq_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 #endif
@@ -840,7 +845,10 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
 
   // adjoint of one diffusion convolution: dp = this lane's KK * 8 columns of dP; on exit block A holds d/dT_0 (hidden columns),
   // NOT yet behind a barrier
-  auto conv_adjoint = [&](const float* dp, auto kktag) {
+  int mark_t = 0;                     // (lab timeline only)
+  // `after_products`: the caller's cache-line touches for the next gate adjoint, run two gather phases before the convolution ends
+  auto conv_adjoint = [&](const float* dp, auto kktag, auto&& after_products) {
+    constexpr int MG = decltype(kktag)::value == 2 ? 0 : 1;
     auto own = [&](int j, int& off, bool& live) {          // hidden quad j of this thread: tasks tid + 896 j < 16 N
       int ot = tid;
       SQ_OPAQUE(ot);
@@ -852,6 +860,7 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
     if constexpr (K >= 3) {
       mfma_to(s.bufA, dp, kktag, SqInt<0>{});          // G2o
       mfma_to(s.bufB, dp, kktag, SqInt<1>{});          // G1o
+      SQ_MARK(mark_t, MG, 1);
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // B += 2 P_o^T A
@@ -864,6 +873,7 @@ if constexpr (!LOADER)
         }
       }
       sq_barrier();
+      SQ_MARK(mark_t, MG, 2);
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // park = P_o^T B
@@ -875,8 +885,11 @@ if constexpr (!LOADER)
         }
       }
       sq_barrier();
+      SQ_MARK(mark_t, MG, 3);
       mfma_to(s.bufA, dp, kktag, SqInt<2>{});          // G2i
       mfma_to(s.bufB, dp, kktag, SqInt<3>{});          // G1i
+      SQ_MARK(mark_t, MG, 4);
+      after_products();                    // (ahead of a gather phase without global loads: nothing queues behind what it requests)
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // B += 2 P_i^T A
@@ -889,7 +902,9 @@ if constexpr (!LOADER)
         }
       }
       sq_barrier();
+      SQ_MARK(mark_t, MG, 5);
       mfma_to(s.bufA, dp, kktag, SqInt<4>{});          // G0 (the "- T_0" of the second hop folded in)
+      SQ_MARK(mark_t, MG, 6);
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // A += park + P_i^T B
@@ -920,6 +935,7 @@ if constexpr (!LOADER)
       }
       sq_barrier();
       mfma_to(s.bufA, dp, kktag, SqInt<2>{});          // G0
+      after_products();
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {
@@ -951,13 +967,34 @@ if constexpr (!LOADER)
     float dh[16];                      // running d/dH_t, A-operand layout: [kk][8]
 #pragma unroll
     for (int i = 0; i < 16; ++i) dh[i] = 0.f;
+    // The gate adjoints read four [N, 64] operands per step from HBM in this lane's own layout; requested right before use, their
+    // latency is 17 of a step's 75 us.  (Requested a gather phase ahead into 48 - 64 registers they were spilled on the spot:
+    // 75 -> 95 us per step.)  Instead their cache lines are TOUCHED a gather phase ahead — one discarded dword per 32-byte piece —
+    // so that the loads proper find them in L2.
+    uint32_t sink = 0;
+    auto rows_of = [&](int t, const float*& zr_rows, const float*& ht_rows, const float*& g_rows, const float*& hp_rows) {
+      zr_rows = a.ZR + ((int64_t)t * a.B * N + m0) * (2 * SQ_O);
+      ht_rows = a.HT + ((int64_t)t * a.B * N + m0) * SQ_O;
+      g_rows = a.dOut + (int64_t)b * a.gs_b + (int64_t)t * a.gs_t;
+      hp_rows = t > 0 ? a.out + (int64_t)b * a.os_b + (int64_t)(t - 1) * a.os_t : (a.H0 ? a.H0 + m0 * SQ_O : nullptr);
+    };
+    auto touch_blend_operands = [&](int t) {
+      const float *zr_rows, *ht_rows, *g_rows, *hp_rows;
+      rows_of(t, zr_rows, ht_rows, g_rows, hp_rows);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        SQ_TOUCH(sink, g_rows + arow * SQ_O + 32 * kk + acol);
+        SQ_TOUCH(sink, zr_rows + arow * (2 * SQ_O) + 32 * kk + acol);
+        SQ_TOUCH(sink, ht_rows + arow * SQ_O + 32 * kk + acol);
+        if (hp_rows) SQ_TOUCH(sink, hp_rows + arow * SQ_O + 32 * kk + acol);
+      }
+    };
+    if (consumer) touch_blend_operands(a.T - 1);
     sq_barrier();
 #pragma unroll 1
     for (int t = a.T - 1; t >= 0; --t) {
-      const float* const zr_rows = a.ZR + ((int64_t)t * a.B * N + m0) * (2 * SQ_O);
-      const float* const ht_rows = a.HT + ((int64_t)t * a.B * N + m0) * SQ_O;
-      const float* const g_rows = a.dOut + (int64_t)b * a.gs_b + (int64_t)t * a.gs_t;
-      const float* const hp_rows = t > 0 ? a.out + (int64_t)b * a.os_b + (int64_t)(t - 1) * a.os_t : (a.H0 ? a.H0 + m0 * SQ_O : nullptr);
+      const float *zr_rows, *ht_rows, *g_rows, *hp_rows;
+      rows_of(t, zr_rows, ht_rows, g_rows, hp_rows);
       float* const dpzr_rows = a.dPzr + ((int64_t)t * a.B * N + m0) * (2 * SQ_O);
       float* const dph_rows = a.dPh + ((int64_t)t * a.B * N + m0) * SQ_O;
       // ---- adjoint of the blend and of the candidate's tanh (pgt_gru_h_bwd_f32): dPh, dP(z), d/dH_{t-1} (the Z H part)
@@ -981,9 +1018,18 @@ if constexpr (!LOADER)
           st8(dph_rows, SQ_O, 32 * kk, dp + 8 * kk);
           st8(dpzr_rows, 2 * SQ_O, 32 * kk, dpz);
         }
+        SQ_TOUCH_DONE(sink);
       }
-      conv_adjoint(dp, SqInt<2>{});
+      mark_t = t;
+      SQ_MARK(t, 0, 0);
+      conv_adjoint(dp, SqInt<2>{}, [&]() {
+        if (consumer) {                // the reset-gate adjoint's R (H_{t-1} and this lane's own dP(z) were just here)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) SQ_TOUCH(sink, zr_rows + arow * (2 * SQ_O) + SQ_O + 32 * kk + acol);
+        }
+      });
       sq_barrier();
+      SQ_MARK(t, 0, 7);
       // ---- adjoint of H * R and of the reset gate (pgt_gru_zr_bwd_f32); dP(z) comes back from this lane's own store
       if (consumer) {
 #pragma unroll
@@ -1003,10 +1049,15 @@ if constexpr (!LOADER)
           }
           st8(dpzr_rows, 2 * SQ_O, SQ_O + 32 * kk, dp + 16 + 8 * kk);
         }
+        SQ_TOUCH_DONE(sink);
       }
       sq_barrier();                    // block A has been read: the next products may overwrite it
-      conv_adjoint(dp, SqInt<4>{});
+      SQ_MARK(t, 1, 0);
+      conv_adjoint(dp, SqInt<4>{}, [&]() {
+        if (consumer && t > 0) touch_blend_operands(t - 1);
+      });
       sq_barrier();
+      SQ_MARK(t, 1, 7);
       if (consumer) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1017,6 +1068,7 @@ if constexpr (!LOADER)
         }
       }
       sq_barrier();                    // (block A read before the next step's products write it)
+      SQ_MARK(t, 1, 8);
     }
     if (a.dH0 && consumer) {
       float* rows = a.dH0 + m0 * SQ_O;

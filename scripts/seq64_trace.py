@@ -74,3 +74,48 @@ for t in (1, 5, 11):
             d.append(float(tr[t, G, sl] - prev))
             prev = tr[t, G, sl]
         print(f"  step {t:2d} {'z|r ' if G == 0 else 'cand'}: " + " ".join(f"{x:6.2f}" for x in d) + f"   = {sum(d):6.2f} us")
+
+
+# ---- the adjoint kernel: marks per (step, gate: 0 candidate, 1 z | r): 0 gate adjoint done | 1 G2o, G1o | 2 B += 2 Po^T A | 3 park |
+# 4 G2i, G1i | 5 B += 2 Pi^T A | 6 G0 | 7 A += park + Pi^T B | 8 state gradient folded
+dOut = torch.randn(B, T, N, O, **f32)
+dPzr, dPh = torch.empty(T, M, 2 * O, **f32), torch.empty(T, M, O, **f32)
+lab.pgt_dcrnn_seq64_bwd_ws_floats.restype = ctypes.c_int64
+nws = lab.pgt_dcrnn_seq64_bwd_ws_floats(I(N), I(B))
+ws = torch.empty(nws, **f32)
+Wpb = torch.empty_like(Wp)
+assert lab.pgt_dcrnn_seq64_pack_bwd_f32(p(Wzr), p(Wh), I(Fin), I(K), p(Wpb), stream) == 0
+to, ti = g.bwd_o.struct(), g.bwd_i.struct()
+
+
+def launch_bwd():
+    rc = lab.pgt_dcrnn_seq64_bwd_f32(ctypes.byref(to), ctypes.byref(ti), I(g.E), I(g.E), I(N), p(dOut), I(T * N * O), I(N * O), p(out),
+                                     I(T * N * O), I(N * O), P(None), p(ZR), p(HT), p(Wpb), I(B), I(T), I(Fin), I(K), p(dPzr), p(dPh),
+                                     P(None), p(ws), I(nws), stream)
+    assert rc == 0, ctypes.c_char_p(lab.sq_lab_last_error()).value
+
+
+for _ in range(3):
+    launch_bwd()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(10):
+    launch_bwd()
+e1.record()
+torch.cuda.synchronize()
+print(f"adjoint, B = {B}: {e0.elapsed_time(e1) * 100:.1f} us per launch = {e0.elapsed_time(e1) * 100 / T:.1f} us per cell step")
+tr = torch.zeros(T * 2 * SLOTS, dtype=torch.int64, device=dev)
+assert lab.sq_lab_set_trace(p(tr)) == 0
+launch_bwd()
+torch.cuda.synchronize()
+lab.sq_lab_set_trace(P(None))
+tr = tr.cpu().view(T, 2, SLOTS).double() / 100.0
+print("marks: gate adj | G2o,G1o | B+=2PoA | park | G2i,G1i | B+=2PiA | G0 | A+=park+PiB | fold")
+for t in (10, 5, 1):
+    for G in (0, 1):
+        prev = tr[t + 1, 1, 8] if G == 0 else tr[t, 0, 7]
+        d = []
+        for sl in range(SLOTS if G == 1 else 8):
+            d.append(float(tr[t, G, sl] - prev))
+            prev = tr[t, G, sl]
+        print(f"  adjoint step {t:2d} {'cand' if G == 0 else 'z|r '}: " + " ".join(f"{x:6.2f}" for x in d) + f"   = {sum(d):6.2f} us")

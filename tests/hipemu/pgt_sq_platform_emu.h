@@ -24,6 +24,8 @@ static inline void sq_barrier() { __syncthreads(); }
 static inline uint64_t sq_uniform64(uint64_t x) { return x; }
 #define SQ_VMWAIT4(n, r0, r1, r2, r3) ((void)0)
 #define SQ_VMWAIT6(n, r) ((void)0)
+#define SQ_TOUCH(sink, ptr) ((void)(ptr))
+#define SQ_TOUCH_DONE(sink) ((void)(sink))
 // v_mfma_f32_16x16x32_bf16 on fibers: lane l holds A[i = l % 16][k = 8 (l / 16) .. + 7] and B[k = 8 (l / 16) .. + 7][j = l % 16];
 // D: col = l % 16, row = 4 (l / 16) + reg
 static uint32_t sq_emu_a[16][64][4], sq_emu_b[16][64][4];

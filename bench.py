@@ -469,7 +469,7 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
 
 
 def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup, profile_steps=0, dropin=False, graph=False,
-              relu=False):
+              relu=False, torch_adam=False):
     """Build the model on the `n_edges`-edge METR-LA-shaped graph, run one initialisation pass, `warmup` untimed steps,
     then EXACTLY `steps` timed steps bracketed by barrier + synchronize; MAX over ranks.  `dropin`: torch.nn.Linear as the
     read-out (what swapping the import alone gives) instead of this package's Linear.  `graph`: forward + loss + backward
@@ -481,8 +481,11 @@ def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup
     torch.manual_seed(0)
     model = Model(hidden, dropin=dropin, relu=relu).to(device)
     flat = dp.FlatParameters(model.parameters())   # one gradient buffer, one parameter buffer
+    # Adam over the flat parameter buffer: the library's elementwise kernel (dp.FlatAdam, the step count on the device: capturable
+    # as it is) — or, `torch_adam`, torch.optim.Adam(fused) over the same buffer (96 us per step: one tensor = two workgroups)
     opt_kw = {"capturable": True} if graph else {}
-    opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)  # Adam over the flat parameter: one (fused) update per step
+    make_opt = (lambda: flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)) if torch_adam else (lambda: flat.adam(lr=1e-3))
+    opt = make_opt()
     n_total = warmup + steps + profile_steps
     batches = make_batches(series, batch, n_total, seed=1000 + rank, device=device)
 
@@ -513,16 +516,19 @@ def train_run(device, rank, world, series, n_edges, batch, hidden, steps, warmup
         torch.cuda.synchronize()
         log("initialisation pass done")
     flat.data.copy_(snapshot)
-    opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)
+    opt = make_opt()
     if graph:
         from pytorch_geometric_temporal_amd.graphed import GraphedStep
         g_fb = GraphedStep(forward_backward, list(batches[0]), warmup=1)
         g_opt = GraphedStep(lambda: opt.step(), [], warmup=1)      # its eager warm-up call moved the parameters ...
         flat.data.copy_(snapshot)                                  # ... back to the start, moments and step count too
-        for st in opt.state.values():                              # (in place: the captured update holds their addresses)
-            for v in st.values():
-                if isinstance(v, torch.Tensor):
-                    v.zero_()
+        if torch_adam:
+            for st in opt.state.values():                          # (in place: the captured update holds their addresses)
+                for v in st.values():
+                    if isinstance(v, torch.Tensor):
+                        v.zero_()
+        else:
+            opt.reset()
 
         def step(i):                                               # noqa: F811  (the graphed step replaces the eager one)
             loss = g_fb(*batches[i])
@@ -850,6 +856,7 @@ def main():
                 "the torch.nn.Linear read-out (dcrnn_example.py:27-28, tgcn/metr_la_main.py:43-44): relu(states) keeps the routing, the "
                 "relu itself is torch's", dropin=True, relu=True)
         variant("edges_1722", "1 722-edge graph (the reference's METR-LA data)", edges=1722)
+        variant("torch_adam", "torch.optim.Adam(fused=True) over the flat parameter buffer instead of dp.FlatAdam (pgt_adam_f32)", torch_adam=True)
         ops.USE_SEQ64 = False
         try:
             variant("per_step_launches", "PGT_SEQ64=0: round 5's path — four launches per cell step forward (two LDS-resident stacks, two "

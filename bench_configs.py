@@ -52,7 +52,7 @@ def small_batch(device, make_model, masked_mae_loss, series, ei, ew, n_edges, se
         torch.manual_seed(0)
         model = make_model(hidden).to(device)
         flat = dp.FlatParameters(model.parameters())
-        opt = flat.optimizer(torch.optim.Adam, lr=1e-3, capturable=True)
+        opt = flat.adam(lr=1e-3)
 
         def step(xi, yi):
             X, y = series[xi], series[yi]

@@ -89,10 +89,7 @@ def training_step_fn(model, flat, opt, series, ei, ew, world, seq=SEQ, graph=Fal
         g_fb = GraphedStep(forward_backward, [torch.zeros(model.batch_hint, dtype=torch.long, device=series.device)], warmup=1)
         g_opt = GraphedStep(lambda: opt.step(), [], warmup=1)
         flat.data.copy_(snapshot)
-        for st in opt.state.values():
-            for v in st.values():
-                if isinstance(v, torch.Tensor):
-                    v.zero_()
+        opt.reset()
 
         def step(idx):
             loss = g_fb(idx)
@@ -115,7 +112,7 @@ def train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile
     model.batch_hint = batch
     flat = dp.FlatParameters(model.parameters())
     opt_kw = {"capturable": True} if graph else {}
-    opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)
+    opt = flat.adam(lr=1e-3)
     rng = np.random.default_rng(1000 + rank)
     n_total = warmup + steps + profile_steps
     T_total = series.shape[0]
@@ -124,7 +121,7 @@ def train_run(device, rank, world, series, ei, ew, batch, steps, warmup, profile
     snapshot = flat.data.clone()
     run(batches[n_total])                                   # initialisation pass (graph preparation, code objects, allocator)
     flat.data.copy_(snapshot)
-    opt = flat.optimizer(torch.optim.Adam, lr=1e-3, **opt_kw)
+    opt = flat.adam(lr=1e-3)
     run = training_step_fn(model, flat, opt, series, ei, ew, world, graph=graph)
     step = lambda i: run(batches[i])                        # noqa: E731
     for i in range(warmup):

@@ -674,6 +674,13 @@ int pgt_relu_linear_bwd_f32(const float* X, int64_t ldx, const float* dY, int64_
                             int64_t N, int relu, float* dX, int64_t lddx, float* dW, float* db, float* ws, int64_t ws_floats,
                             pgt_stream_t stream);
 
+/* torch.optim.Adam's update (no amsgrad; weight_decay = L2 added to the gradient) over one flat buffer of n parameters — the
+ * optimizer step of the reference's training loops (examples/indexBatching/DCRNN/pems_ddp.py:86,118-120) on the concatenation of all
+ * parameters (every tensor of these models is small: 150 - 76 000 floats in total).  p / m / v updated in place, g read; `step`:
+ * one device float, the number of updates so far — advanced by this call, so the whole update is graph-capturable. */
+int pgt_adam_f32(float* p, const float* g, float* m, float* v, float* step, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, pgt_stream_t stream);
+
 /* Index-batch window gather (signal/index_dataset.py:32-57; examples/indexBatching: "GPU-index-batching"): for every
  * sample b, X[b] = data[idx[b] : idx[b] + h], Y[b] = data[idx[b] + h : idx[b] + 2 h] from the resident series
  * data [T_total, W] (W = nodes * features), both windows of all B samples in one launch.  time_major != 0 writes

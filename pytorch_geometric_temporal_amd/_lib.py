@@ -119,6 +119,7 @@ PROTOTYPES = {
     "pgt_att_softmax_rows_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "pgt_att_sigmoid_bwd_f32": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "pgt_window_gather_f32": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
+    "pgt_adam_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr]),
     "pgt_relu_linear_fits": (c_int, [c_i64, c_i64]),
     "pgt_relu_linear_bwd_ws_floats": (c_i64, [c_i64, c_i64]),
     "pgt_relu_linear_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr]),

@@ -607,3 +607,40 @@ extern "C" int pgt_window_gather_f32(const float* data, int64_t T_total, int64_t
   PGT_VDISPATCH(pick.v, window_gather_kernel, grid, block, stream, data, idx, B, h, W, T_total, X, Y, time_major ? 1 : 0);
   return pgt_check_launch("pgt_window_gather_f32");
 }
+
+// ---- Adam over one flat parameter buffer (torch.optim.Adam's update, examples/indexBatching/DCRNN/pems_ddp.py:86, on the
+// concatenation of all parameters: dp.FlatParameters).  torch's fused / foreach Adam hands a single 76 k-element tensor to TWO
+// workgroups (96 us per step, whatever the batch); this is one thread per element.  The step count lives on the device so that the
+// update can be captured in a hipGraph: a one-thread launch advances it, the update launch reads it.
+namespace {
+__global__ void adam_tick_kernel(float* step) { *step += 1.f; }
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* __restrict__ step, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float t = *step;
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  float gi = g[i];
+  const float pi = p[i];
+  if (wd != 0.f) gi = fmaf(wd, pi, gi);
+  const float mi = m[i] + (gi - m[i]) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = fmaf(1.f - b2, gi * gi, b2 * v[i]);           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+}  // namespace
+
+extern "C" int pgt_adam_f32(float* p, const float* g, float* m, float* v, float* step, int64_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, pgt_stream_t stream) {
+  PGT_REQUIRE(n >= 0, "pgt_adam_f32: negative size");
+  if (n == 0) return PGT_OK;
+  PGT_REQUIRE(p && g && m && v && step, "pgt_adam_f32: null pointer");
+  PGT_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), stream, step);
+  dim3 grid, block(256);
+  if (int e = grid_for(n, "pgt_adam_f32", &grid)) return e;
+  PGT_LAUNCH(adam_kernel, grid, block, stream, p, g, m, v, step, n, lr, beta1, beta2, eps, weight_decay);
+  return pgt_check_launch("pgt_adam_f32");
+}

@@ -124,6 +124,39 @@ class FlatParameters(FlatGradients):
                 pass
         return cls([self.master], **kwargs)
 
+    def adam(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """torch.optim.Adam's update over the flat buffer on the library's own kernel (FlatAdam)."""
+        return FlatAdam(self, lr, betas, eps, weight_decay)
+
+
+class FlatAdam:
+    """torch.optim.Adam's update (amsgrad off) over a FlatParameters buffer through ONE elementwise launch of the library
+    (pgt_adam_f32; + a one-thread launch that advances the device-side step count, so `step()` is hipGraph-capturable as it is).
+    torch's fused Adam gives a single 76 k-element tensor to two workgroups: 96 us per step at every batch size."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if flat.data.dtype != torch.float32:
+            raise TypeError("FlatAdam: fp32 parameters only")
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.steps = torch.zeros(1, dtype=torch.float32, device=flat.data.device)
+
+    def reset(self):
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.steps.zero_()
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero()                 # (the gradients are views of one buffer: never set to None)
+
+    def step(self):
+        from . import _lib
+        lib = _lib.get_lib()
+        f = self.flat
+        lib.call("pgt_adam_f32", _lib.ptr(f.data), _lib.ptr(f.flat), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), _lib.ptr(self.steps),
+                 f.data.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, _lib.stream_of(lib, f.data))
+
 
 def broadcast_parameters(module, src=0):
     """Make every rank start from rank `src`'s weights (what DDP does at construction)."""

@@ -26,7 +26,7 @@ series = torch.randn(4000, 207, 2, device=dev)
 torch.manual_seed(0)
 model = bench.Model(hidden).to(dev)
 flat = dp.FlatParameters(model.parameters())
-opt = flat.optimizer(torch.optim.Adam, lr=1e-3, capturable=True)
+opt = flat.adam(lr=1e-3)
 ar = torch.arange(12, device=dev)
 
 

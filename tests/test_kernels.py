@@ -2238,3 +2238,31 @@ try:
             lib.tune("spmm_ellw_cus", 0)
 except ImportError:      # hypothesis is optional
     pass
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_flat_adam_kernel_equals_torch_adam(backend, wd):
+    """dp.FlatAdam (pgt_adam_f32: one elementwise launch over the flat parameter buffer, the step count on the device) against
+    torch.optim.Adam over the individual parameters: eight updates, with and without weight decay."""
+    from pytorch_geometric_temporal_amd import dp
+    torch.manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 3))
+    mod = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 3))
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(backend.device)
+    opt_r = torch.optim.Adam(ref.parameters(), lr=3e-3, betas=(0.8, 0.95), eps=1e-6, weight_decay=wd)
+    flat = dp.FlatParameters(mod.parameters())
+    opt_m = flat.adam(lr=3e-3, betas=(0.8, 0.95), eps=1e-6, weight_decay=wd)
+    x, y = torch.randn(12, 6), torch.randn(12, 3)
+    for _ in range(8):
+        opt_r.zero_grad()
+        (ref(x) - y).pow(2).mean().backward()
+        opt_r.step()
+        opt_m.zero_grad()
+        (mod(backend.t(x)) - backend.t(y)).pow(2).mean().backward()
+        opt_m.step()
+    assert float(opt_m.steps) == 8.0
+    for pr, pm in zip(ref.parameters(), mod.parameters()):
+        assert_close_with_nonfinite(pm.detach(), pr.detach(), 2e-6, 2e-5, "parameters after eight updates")
+    opt_m.reset()
+    assert float(opt_m.steps) == 0.0 and float(opt_m.exp_avg.abs().sum()) == 0.0

@@ -322,17 +322,35 @@ def tensor_version(t):
 
 class _GraphCache:
     """Identity-keyed cache (data_ptr + in-place version counter), never torch.equal (no host sync per forward;
-    the reference compares with torch.equal twice per BatchedDCRNN forward, dcrnn.py:446-447)."""
+    the reference compares with torch.equal twice per BatchedDCRNN forward, dcrnn.py:446-447).
+
+    What identity cannot see: a write that leaves `_version` alone — `edge_weight.data.mul_(2)`, `edge_weight.data.copy_(...)`, a
+    kernel of the caller's own writing through the pointer.  Two ways to have it seen: `GRAPH_CACHE.forget(edge_index, edge_weight)`
+    after such a write, or `verify = True` (PGT_GRAPH_VERIFY=1): every hit then compares a checksum of the VALUES with the one taken
+    when the operators were built — one host synchronisation per forward, which is what the reference's own `torch.equal` costs."""
 
     def __init__(self, capacity=128):      # a dynamic-graph signal holds one edge list per snapshot (England-Covid: 53)
         self.capacity = capacity
         self._d = OrderedDict()
+        self.verify = os.environ.get("PGT_GRAPH_VERIFY", "0") == "1"
 
     @staticmethod
     def _tkey(t):
         if t is None:
             return None
         return (t.data_ptr(), tensor_version(t), tuple(t.shape), tuple(t.stride()), str(t.device), t.dtype)
+
+    @staticmethod
+    def _checksum(edge_index, edge_weight):
+        """Two device scalars that change with (almost) any change of the values: position-weighted sums of the endpoints and of
+        the weights' bit patterns."""
+        ei = edge_index.reshape(-1).to(torch.int64)
+        pos = torch.arange(1, ei.numel() + 1, device=ei.device, dtype=torch.int64)
+        c = [(ei * pos).sum()]
+        if edge_weight is not None:
+            w = edge_weight.detach().reshape(-1).contiguous().to(torch.float32).view(torch.int32).to(torch.int64)
+            c.append((w * pos[:w.numel()]).sum())
+        return torch.stack(c)
 
     def get(self, tag, edge_index, edge_weight, extra, builder):
         # inference tensors carry no version counter, so an in-place edit under torch.inference_mode() would go unnoticed:
@@ -342,14 +360,23 @@ class _GraphCache:
         key = (tag, self._tkey(edge_index), self._tkey(edge_weight), extra)
         hit = self._d.get(key)
         if hit is not None:
-            self._d.move_to_end(key)
-            return hit[0]
+            if self.verify and not bool(torch.equal(hit[3], self._checksum(edge_index, edge_weight))):
+                del self._d[key]           # same tensors, other values: a write that did not bump the version counter
+            else:
+                self._d.move_to_end(key)
+                return hit[0]
         g = builder()
         # keep the key tensors alive so their storage (data_ptr) cannot be recycled while the entry lives
-        self._d[key] = (g, edge_index, edge_weight)
+        self._d[key] = (g, edge_index, edge_weight, self._checksum(edge_index, edge_weight) if self.verify else None)
         if len(self._d) > self.capacity:
             self._d.popitem(last=False)
         return g
+
+    def forget(self, edge_index, edge_weight=None):
+        """Drop every entry built from these tensors (after a write through `.data` that the version counter did not record)."""
+        ki, kw = self._tkey(edge_index), self._tkey(edge_weight)
+        for key in [k for k in self._d if k[1] == ki and (edge_weight is None or k[2] == kw)]:
+            del self._d[key]
 
     def clear(self):
         self._d.clear()

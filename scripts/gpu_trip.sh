@@ -2,13 +2,13 @@
 # One gpurun call, stages chosen on the command line (in the order given); everything lands under gpurun_out/.
 # tests      pytest -m gpu (tail of the log)                smoke    __graft_entry__.smoke()
 # bench      python bench.py (default run, clocked)          tgcn     python bench.py --config tgcn50k
-# stats/pmc  rocprofv3 --stats / --pmc passes of the headline command (TAG=${TAG:-r05}); *_tgcn: of --config tgcn50k
+# stats/pmc  rocprofv3 --stats / --pmc passes of the headline command (TAG=${TAG:-r06}); *_tgcn: of --config tgcn50k
 # x:<cmd>    any other command, quoted
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out
 mkdir -p $O/prof
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 for stage in "$@"; do
   SECONDS=0
   case "$stage" in

@@ -35,6 +35,8 @@ def klass(name):
         return "readout"
     if "tconv_glu" in name:
         return "tconv"
+    if "seq64" in name:
+        return "seq64"
     if "seq_small" in name:
         return "seq_small"
     if "gemm_tn" in name or "gemm_bx_tn" in name:

@@ -248,6 +248,38 @@ def test_graph_prep_is_cached_by_identity_not_by_value(backend):
     assert ops.dconv_graph(ei, ew, 12) is not g1
 
 
+def test_graph_cache_and_writes_the_version_counter_does_not_record(backend):
+    """`edge_weight.data.mul_()` leaves `_version` alone, so the identity-keyed cache keeps the old operators (documented on
+    ops._GraphCache; the reference compares VALUES with torch.equal, dcrnn.py:446-447, one host sync each).  `forget` after such a
+    write, or verify mode (PGT_GRAPH_VERIFY=1: a value checksum per hit, one sync per forward), brings the new values in."""
+    from pytorch_geometric_temporal_amd import ops
+    ei_np, ew_np = syn.sensor_graph(12, 60, seed=2)
+    ei, ew = backend.t(ei_np), backend.t(ew_np)
+    m = DCRNN(3, 5, 2).to(backend.device)
+    X = backend.t(torch.randn(12, 3))
+    with torch.no_grad():
+        before = m(X, ei, ew)
+        g1 = ops.dconv_graph(ei, ew, 12, strict_dense=True)
+        ew.data[::2] *= 3.0                                     # (slice assignment through .data: no version bump)
+        assert ops.dconv_graph(ei, ew, 12, strict_dense=True) is g1 and torch.equal(m(X, ei, ew), before)   # the documented hazard
+        ops.GRAPH_CACHE.forget(ei, ew)
+        after = m(X, ei, ew)
+        assert not torch.equal(after, before)
+        want = m(X, ei.clone(), ew.clone())
+        assert torch.equal(after, want)
+        keep = ops.GRAPH_CACHE.verify
+        ops.GRAPH_CACHE.verify = True
+        try:
+            ops.GRAPH_CACHE.clear()
+            a = m(X, ei, ew)
+            assert torch.equal(a, want) and torch.equal(m(X, ei, ew), want)      # a hit: checksums agree
+            ew.data[::3] *= 0.5
+            assert torch.equal(m(X, ei, ew), m(X, ei.clone(), ew.clone()))       # the write is seen
+        finally:
+            ops.GRAPH_CACHE.verify = keep
+            ops.GRAPH_CACHE.clear()
+
+
 def test_no_cpu_fallback():
     """A CPU tensor handed to the product path must raise, not silently compute somewhere else."""
     from pytorch_geometric_temporal_amd import _lib

@@ -28,7 +28,11 @@ void pgt_set_error(const char* fmt, ...) {
 }
 extern "C" const char* sq_lab_last_error() { return g_err; }
 
+#ifdef SQ_SERIAL_RECORD          // round 6's first form (one phase at a time): lab/seq64_serial_record.hip, kept for same-box A/Bs
+#include "seq64_serial_record.hip"
+#else
 #include "../pytorch_geometric_temporal_amd/csrc/seq64.hip"
+#endif
 
 // the loader wavefront's path alone, compile-only: `hipcc -Rpass-analysis=kernel-resource-usage` must report ScratchSize 0 for these
 namespace {

@@ -11,3 +11,6 @@ done
 for m in 0 1 4 8 16 20 21 28 9 29 32; do
   /opt/rocm/bin/hipcc $FLAGS -DBX_SKIP=$m lab/gemm_bx_trace_lab.hip -o lab/gemm_bx_trace_lab_$m || exit 1
 done
+# csrc/seq64.hip with the phase timeline of workgroup 0 (scripts/seq64_trace.py); "_serial": round 6's first form of it
+/opt/rocm/bin/hipcc $FLAGS -shared -fPIC lab/seq64_lab.hip -o lab/libseq64_lab.so || exit 1
+/opt/rocm/bin/hipcc $FLAGS -shared -fPIC -DSQ_SERIAL_RECORD lab/seq64_lab.hip -o lab/libseq64_lab_serial.so || exit 1

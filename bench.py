@@ -876,11 +876,16 @@ def main():
         finally:
             lib.tune("gemm_bx_tn_pc", 1)
             lib.tune("gemm_bx_sym_pc", 1)
-        ops.DETERMINISTIC_WEIGHT_GRADIENTS = True
+        keep_det = ops.DETERMINISTIC_WEIGHT_GRADIENTS
+        ops.DETERMINISTIC_WEIGHT_GRADIENTS = not keep_det
         try:
-            variant("deterministic", "PGT_DETERMINISTIC=1: weight gradients without float atomics (per-slab partial sums added in order)")
+            if keep_det:
+                variant("atomic_weight_gradients", "PGT_DETERMINISTIC=0: weight gradients through fp32 atomics into dW (the default adds per-slab "
+                        "partial sums in a fixed order: bitwise reproducible)")
+            else:
+                variant("deterministic", "PGT_DETERMINISTIC=1: weight gradients without float atomics (per-slab partial sums added in order)")
         finally:
-            ops.DETERMINISTIC_WEIGHT_GRADIENTS = False
+            ops.DETERMINISTIC_WEIGHT_GRADIENTS = keep_det
         if not args.graph:
             variant("hipgraph_step", "--graph: forward+backward and the update as two hipGraphs, the all-reduce between them eager",
                     graph=True)

@@ -1631,7 +1631,8 @@ int pgt_gemm_bx_tn_launch(const PgtTnArgs& t, pgt_stream_t stream) {
     // four and 980 all alike); N = 128: four + four (1 246 us; eight consumers + four producers measure the same, 1 230 - 1 240:
     // pgt_tune("gemm_bx_tn_pc", 2) launches that form) — profiles/r05v_tn_twelve_wavefronts_ab.jsonl
     if (t.part != nullptr) {
-      if (t.N > 64) PGT_BX_TN_GO(4, true, 8, 4); else PGT_BX_TN_GO(2, true, 4, 8);
+      // (the atomics-free epilogue on twelve wavefronts spills 80 registers — 603 against 454 us per launch at the step's shape: four + four)
+      if (t.N > 64) PGT_BX_TN_GO(4, true, 8, 4); else PGT_BX_TN_GO(2, true, 4, 4);
     } else {
       if (t.N > 64) PGT_BX_TN_GO(4, false, 8, 4); else PGT_BX_TN_GO(2, false, 4, 8);
     }

@@ -720,10 +720,11 @@ ONE_FEATURE_GRADIENT = os.environ.get("PGT_ONE_FG", "1") != "0"
 # = a separate accumulation pass per time step)
 FOLD_STATE_GRADIENT = os.environ.get("PGT_FOLD_DH", "1") != "0"
 ONE_FEATURE_GRADIENT_MIN_ROWS = int(os.environ.get("PGT_ONE_FG_MIN_ROWS", "8192"))   # tests lower it to drive the 320-column product at small sizes
-# weight / bias gradients without float atomics (pgt_gemm_tn_det_f32): bitwise reproducible run to run, one extra pass
-# over the per-slab partial sums.  Off by default (the atomics are ~2 % faster at the benchmark shape); PGT_DETERMINISTIC=1
-# or ops.DETERMINISTIC_WEIGHT_GRADIENTS = True turns it on.
-DETERMINISTIC_WEIGHT_GRADIENTS = os.environ.get("PGT_DETERMINISTIC", "0") == "1"
+# weight / bias gradients without float atomics (pgt_gemm_tn_det_f32): per-slab partial sums + one pass that adds them in a fixed
+# order — bitwise reproducible run to run, like the reference's CPU path.  The default since round 6 (the second pass takes 15 us
+# per product, the products themselves the same time either way: 2.32 against 2.2 - 2.4 ms per training step at the benchmark
+# shape); PGT_DETERMINISTIC=0 or ops.DETERMINISTIC_WEIGHT_GRADIENTS = False returns to fp32 atomics into dW.
+DETERMINISTIC_WEIGHT_GRADIENTS = os.environ.get("PGT_DETERMINISTIC", "1") != "0"
 
 
 def gemm_gru_zr(A, lda, a_seg_stride, n_seg, seg_k, Bw, sbk, sbn, bias, zr, H, xhr, f_in):

@@ -1,5 +1,5 @@
-"""The weight-gradient product over the saved stacks in the two row layouts: contiguous rows of 66 floats (the per-step launches')
-and the one-launch forward's rows of 68 (hidden columns first).  usage: tn_layout_probe.py [B = 1024]"""
+"""The weight-gradient product over the saved stacks (all T steps of B windows): fp32 atomics against the deterministic two-pass form,
+and rows of 66 floats (what the forward saves) against rows padded to 68 (16-byte aligned).  usage: tn_layout_probe.py [B = 1024]"""
 import sys
 import torch
 
@@ -10,7 +10,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dev = torch.device("cuda:0")
 S, T, N, O, Fin = 5, 12, 207, 64, 2
 M, C = B * N, Fin + O
-for ld in (66, 68):
+for ld, det in ((66, False), (66, True), (68, False), (66, False), (66, True), (68, False)):
+    ops.DETERMINISTIC_WEIGHT_GRADIENTS = det
     TS = torch.randn(S, T, M, ld, device=dev)
     for NO in (128, 64):
         G = torch.randn(T, M, NO, device=dev)
@@ -21,9 +22,9 @@ for ld in (66, 68):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(20):
             ops.gemm_tn_acc(TS, ld, T * M * ld, S, C, G, NO, dW, NO, db, T * M, NO)
         e1.record()
         torch.cuda.synchronize()
-        print(f"B = {B}: rows of {ld} floats, N = {NO}: {e0.elapsed_time(e1) / 5:.3f} ms", flush=True)
+        print(f"B = {B}: rows of {ld} floats, N = {NO}, {'deterministic' if det else 'atomics'}: {e0.elapsed_time(e1) / 20:.3f} ms", flush=True)
     del TS

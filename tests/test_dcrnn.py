@@ -743,3 +743,30 @@ def test_dconv_on_a_graph_whose_numbering_hides_its_locality(backend):
         ops.ELLW_MIN_ROWS = min_rows
     for a, b, what in zip(outs[0], outs[1], ("H", "dX", "dW")):
         assert_close_with_nonfinite(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, what)
+
+
+def test_training_step_gradients_are_bitwise_reproducible_by_default(backend):
+    """The reference's CPU path gives the same gradients run after run; so does this one with its default settings: the weight
+    gradients are per-slab partial sums added in a fixed order (ops.DETERMINISTIC_WEIGHT_GRADIENTS, on by default), the sequence
+    kernels and the read-out use no float atomics.  On the GPU the batch is large enough for the split-bf16 weight-gradient kernel
+    (>= 16 384 rows over all steps), whose workgroups retire in a different order every run."""
+    from pytorch_geometric_temporal_amd import ops
+    assert ops.DETERMINISTIC_WEIGHT_GRADIENTS
+    n, E, B, T = (207, 1515, 8, 12) if backend.name == "hip" else (23, 140, 2, 3)
+    ei_np, ew_np = syn.sensor_graph(n, E, seed=3, symmetric=False)
+    ei, ew = backend.t(torch.from_numpy(ei_np)), backend.t(torch.from_numpy(ew_np))
+    torch.manual_seed(5)
+    m = BatchedDCRNN(2, 64, 3).to(backend.device)
+    lin = torch.nn.Linear(64, 1).to(backend.device)
+    X = backend.t(torch.randn(B, T, n, 2))
+    y = backend.t(torch.randn(B, T, n, 1))
+    runs = []
+    for _ in range(3):
+        m.zero_grad()
+        lin.zero_grad()
+        loss = ((lin(torch.relu(m(X, ei, ew))) - y) ** 2).mean()
+        loss.backward()
+        runs.append([p.grad.clone() for p in list(m.parameters()) + list(lin.parameters())] + [loss.detach().clone()])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)

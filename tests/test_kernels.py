@@ -1298,6 +1298,8 @@ def test_gemm_tn_split_bf16_weight_and_bias_gradient(backend, M, segs, segk, N, 
     refW, refb = dW0.double() + A2.t() @ G.double(), db0.double() + G.double().sum(0)
     Ad, Gd = A.to(dev), G.to(dev)
     out = {}
+    keep_det = ops.DETERMINISTIC_WEIGHT_GRADIENTS
+    ops.DETERMINISTIC_WEIGHT_GRADIENTS = False           # first the fp32-atomics form of every kernel (the library's default is the other)
     try:
         for bx in ((2 if force else 1), 0):
             lib.tune("gemm_bx", bx)
@@ -1333,6 +1335,7 @@ def test_gemm_tn_split_bf16_weight_and_bias_gradient(backend, M, segs, segk, N, 
             lib.tune("gemm_bx_tn_pc", TN_PC_DEFAULT)
     finally:
         lib.tune("gemm_bx", 1)
+        ops.DETERMINISTIC_WEIGHT_GRADIENTS = keep_det
     sw, sb = float(refW.abs().max()), float(refb.abs().max())
     for name, (dW, db) in (("split-bf16", out[bx]), ("fp32", out[0]), ("deterministic", det[0])):
         assert float((dW.cpu().double() - refW).abs().max()) <= 3e-6 * sw, name
@@ -1954,6 +1957,7 @@ def test_deterministic_weight_gradient_matches_and_is_reproducible(backend, M, s
     db0 = torch.randn(N, generator=g)
     for k, v in knobs.items():
         lib.tune(k, v)
+    keep_det = ops.DETERMINISTIC_WEIGHT_GRADIENTS
     try:
         outs = []
         ops.DETERMINISTIC_WEIGHT_GRADIENTS = True
@@ -1965,7 +1969,7 @@ def test_deterministic_weight_gradient_matches_and_is_reproducible(backend, M, s
         dWa, dba = dW0.clone().to(backend.device), db0.clone().to(backend.device)
         ops.gemm_tn_acc(A, segk, M * segk, segs, segk, G, N, dWa, N, dba, M, N)
     finally:
-        ops.DETERMINISTIC_WEIGHT_GRADIENTS = False
+        ops.DETERMINISTIC_WEIGHT_GRADIENTS = keep_det
         for k in knobs:
             lib.tune(k, defaults[k])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # reproducible
@@ -2074,6 +2078,7 @@ def test_split_bf16_kernels_reproduce_their_output_bit_for_bit_at_benchmark_size
         ref = dP[idx].double() @ WH.double().t()
         assert float((outs[0].permute(1, 0, 2).reshape(M, 320)[idx].double() - ref).abs().max()) < 2e-5
     Gm = torch.randn(M, 2 * O, generator=g).to(dev)
+    keep_det = ops.DETERMINISTIC_WEIGHT_GRADIENTS
     ops.DETERMINISTIC_WEIGHT_GRADIENTS = True
     try:
         outs = []
@@ -2083,7 +2088,7 @@ def test_split_bf16_kernels_reproduce_their_output_bit_for_bit_at_benchmark_size
             outs.append(torch.cat([dW, db[None]], 0))
         same(outs, "deterministic weight gradient")
     finally:
-        ops.DETERMINISTIC_WEIGHT_GRADIENTS = False
+        ops.DETERMINISTIC_WEIGHT_GRADIENTS = keep_det
 
 
 @pytest.mark.parametrize("cap,cus", [(0, 0), (48, 3)])

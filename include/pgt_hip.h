@@ -114,7 +114,7 @@ const char* pgt_build_target(void);
  * same bits).  Diffusion
  * stack: "slab_pairs", "slab_split", "slab_wpc", "slab_threads" (pgt_dconv_stack_slab_plan), "slab_quad" (0: 64 / 66-column blocks on the pair-layout kernels), "slab_gu" (2 | 4 LDS reads in flight in their backward gathers).  Aggregation: "spmm_tile_rows", "spmm_unroll", "spmm_tile_xcd",
  * "spmm_tile_nt" (streaming stores: 1 = for outputs >= 32 MiB / 2 always / 0), "spmm_ellw" (0: pgt_spmm_ellw_f32 runs
- * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan), "tgcn_rows" (0: the column-per-lane T-GCN cell kernels of round 4 for every shape).  Returns PGT_ERR_INVALID for an unknown key.  Not thread-safe: call between launches. */
+ * the CSR kernels), "spmm_ellw_rows" / "spmm_ellw_cus" / "spmm_ellw_cfg" (test hooks of pgt_ellw_plan), "tgcn_rows" (0: the column-per-lane T-GCN cell kernels of round 4 for every shape), "tgcn_wgs" (n > 0: at most n workgroups per T-GCN cell launch).  Returns PGT_ERR_INVALID for an unknown key — and for "tgcn_probe" (forward-kernel variants with parts switched off, WRONG results by design) unless the library was built with -DPGT_LAB_PROBES.  Not thread-safe: call between launches. */
 int pgt_tune(const char* key, int value);
 
 /* ---------------------------------------------------------------- graph preparation */

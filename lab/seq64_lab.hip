@@ -28,8 +28,8 @@ void pgt_set_error(const char* fmt, ...) {
 }
 extern "C" const char* sq_lab_last_error() { return g_err; }
 
-#ifdef SQ_SERIAL_RECORD          // round 6's first form (one phase at a time): lab/seq64_serial_record.hip, kept for same-box A/Bs
-#include "seq64_serial_record.hip"
+#ifdef SQ_STAGGER_RECORD         // the forward with a gather phase and the products independent of it in one run of chunk barriers, the
+#include "seq64_stagger_record.hip"   // wavefront pairs of a SIMD in opposite orders (measured, withdrawn: notebook 7.10): kept for same-box A/Bs
 #else
 #include "../pytorch_geometric_temporal_amd/csrc/seq64.hip"
 #endif

@@ -19,9 +19,11 @@
 //     the new state go straight back into the LDS block as the next T_0;
 //   * what the adjoint needs (both stacks, Z | R, the candidate, the states) is stored once, in the layout of the general path
 //     (ops.DCRNNSeqFunction), so the general backward and the weight-gradient product run unchanged on it.
-// Two blocks are enough for K = 3 because T_1^i = P_i T_0 is gathered together with T_1^o and waits in registers:
-//   A = T0 | B = T1o, regs = T1i | MFMA T0, T1o | A = T2o = 2 P_o B - T0 | MFMA T2o | B = T1i | A = T2i = 2 P_i B - T0 | MFMA T1i, T2i.
+// Two blocks are enough for K = 3 because T_1^i = P_i T_0 is gathered together with T_1^o and waits in its place in the saved stack,
+// as does T_0.  A gather phase and the products that do not depend on it share one run of chunk barriers (`||`):
+//   A = T0 | MFMA T0 || B = T1o, T1i -> stack | MFMA T1o || A = T2o = 2 P_o B - T0 | MFMA T2o || B = T1i | MFMA T1i || A = T2i = 2 P_i B - T0 | MFMA T2i.
 #include "pgt_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -105,7 +107,8 @@ __device__ __forceinline__ pgt_f4 sq_two_minus(pgt_f4 g, pgt_f4 t) {
 }
 
 // lab/seq64_lab.hip defines this to take the kernels apart (1: no MFMAs, 2: the B fragments of a chunk read once, 4: no ring
-// writes, 8: no gathers, 16: no stores of the saved stacks); compile-time constants in the library
+// writes, 8: no gathers, 16: no stores of the saved stacks, 32: no T_0 read back in the second hops, 64: no T_1^i read back);
+// compile-time constants in the library
 #ifndef SQ_LAB_SKIP
 #define SQ_LAB_SKIP(bit) false
 #endif
@@ -144,10 +147,11 @@ __host__ __device__ inline int sq_seg_at(int K, int pos) {
 
 // slots of an operator in LDS, padding included (rows start at even positions; an even count keeps the next array 4-byte aligned)
 __host__ __device__ inline size_t sq_slot_cap(int64_t nnz, int64_t N) { return (size_t)((nnz + N + 2) & ~(int64_t)1); }
-// two blocks, the ring, fp32 coefficients + 16-bit sources per slot, 16-bit row pointers
+// two blocks, the ring, fp32 coefficients + 16-bit sources per slot, one 32-bit row descriptor per operator and task row, the
+// 16-bit row of a task row
 static size_t sq_lds_bytes(int64_t N, int64_t nnz_o, int64_t nnz_i) {
   return 2 * (size_t)N * SQ_PITCH * 4 + 2 * (size_t)SQ_CHUNK_DW * 4 + (sq_slot_cap(nnz_o, N) + sq_slot_cap(nnz_i, N)) * 6 +
-         2 * (size_t)(N + 2) * 2;
+         2 * (size_t)N * 4 + (size_t)(N + 2) * 2;
 }
 
 struct SqLds {
@@ -155,21 +159,26 @@ struct SqLds {
   uint32_t* ring;
   const float* val_o; const float* val_i;
   const uint16_t* col_o; const uint16_t* col_i;
-  const uint16_t* rp_o; const uint16_t* rp_i;
+  const uint32_t* desc_o; const uint32_t* desc_i;    // task row p -> first slot (even) | slot count << 16 of row prow[p]
+  const uint16_t* prow;                              // task row p -> row: by falling slot count (both operators together)
 };
 
 // Slot lists in LDS: 16-bit sources and fp32 coefficients in two arrays, row r's slots from the EVEN position
 // sq_row_start(rp[r], r) on (room for one padding slot per row), so that two slots are one 4-byte + one 8-byte read — the same two
 // LDS instructions per slot pair + two quad reads as the packed (col, val) slots of csrc/dconv_slab.hip, at 6 instead of 8 bytes per slot.
 __host__ __device__ inline int sq_row_start(int rp_r, int r) { return (rp_r + r + 1) & ~1; }
-// row sum over the slots of row r (csrc/dconv_slab.hip gather_q: the same fmaf chain in slot order), four slots in flight
-__device__ __forceinline__ pgt_f4 sq_gather(const uint16_t* __restrict__ rp, const uint16_t* __restrict__ col,
-                                            const float* __restrict__ val, const float* __restrict__ blk, int r, int qoff) {
+// The gather tasks walk the rows in the order of FALLING slot count (sq_setup: `prow`, one order for both operators and both
+// directions — the counts of a row in P_o and P_i go together on road graphs: 0.93 correlation on the benchmark's), so that the four
+// rows a wavefront gathers at a time are equally long give or take a slot: in row order the longest of four has 10.3 slots against
+// a mean of 7.3 on the METR-LA-shaped graph, and the wavefront walks the longest (gather phases 3.5 -> 3.1 us).
+// Row sum over the slots of one row, `desc` = its first slot | slot count << 16 (csrc/dconv_slab.hip gather_q: the same fmaf chain
+// in slot order), four slots in flight
+__device__ __forceinline__ pgt_f4 sq_gather(uint32_t desc, const uint16_t* __restrict__ col, const float* __restrict__ val,
+                                            const float* __restrict__ blk, int qoff) {
   pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-  if (SQ_LAB_SKIP(8)) return *reinterpret_cast<const pgt_f4*>(blk + qoff + r * SQ_PITCH);
-  const int b0 = rp[r];
-  int q = sq_row_start(b0, r);
-  const int e = q + ((int)rp[r + 1] - b0);
+  int q = (int)(desc & 0xffffu);
+  const int e = q + (int)(desc >> 16);
+  if (SQ_LAB_SKIP(8)) return *reinterpret_cast<const pgt_f4*>(blk + qoff + (int)col[q] * SQ_PITCH);
   for (; q + 4 <= e; q += 4) {
     const uint32_t c01 = *reinterpret_cast<const uint32_t*>(col + q), c23 = *reinterpret_cast<const uint32_t*>(col + q + 2);
     const float2 v01 = *reinterpret_cast<const float2*>(val + q), v23 = *reinterpret_cast<const float2*>(val + q + 2);
@@ -209,9 +218,22 @@ __device__ __forceinline__ SqLds sq_setup(char* smem, int N, const int32_t* rp_o
   float* vi = reinterpret_cast<float*>(p); p += cap_i * 4;
   uint16_t* co = reinterpret_cast<uint16_t*>(p); p += cap_o * 2;
   uint16_t* ci = reinterpret_cast<uint16_t*>(p); p += cap_i * 2;
-  uint16_t* ro = reinterpret_cast<uint16_t*>(p); p += (size_t)(N + 2) * 2;
-  uint16_t* ri = reinterpret_cast<uint16_t*>(p);
-  for (int i = tid; i <= N; i += SQ_THREADS) { ro[i] = (uint16_t)rp_o[i]; ri[i] = (uint16_t)rp_i[i]; }
+  uint32_t* dso = reinterpret_cast<uint32_t*>(p); p += (size_t)N * 4;
+  uint32_t* dsi = reinterpret_cast<uint32_t*>(p); p += (size_t)N * 4;
+  uint16_t* pr = reinterpret_cast<uint16_t*>(p);
+  // task order: rows by falling slot count (P_o's + P_i's), ties in row order — every row counts the rows ahead of it (block A is
+  // free at this point: the keys wait there)
+  uint32_t* key = reinterpret_cast<uint32_t*>(s.bufA);
+  for (int r = tid; r < N; r += SQ_THREADS) key[r] = (uint32_t)((rp_o[r + 1] - rp_o[r]) + (rp_i[r + 1] - rp_i[r]));
+  __syncthreads();
+  for (int r = tid; r < N; r += SQ_THREADS) {
+    const uint32_t k = key[r];
+    int ahead = 0;
+    for (int o = 0; o < N; ++o) ahead += (key[o] > k || (key[o] == k && o < r)) ? 1 : 0;
+    pr[ahead] = (uint16_t)r;
+    dso[ahead] = (uint32_t)sq_row_start(rp_o[r], r) | ((uint32_t)(rp_o[r + 1] - rp_o[r]) << 16);
+    dsi[ahead] = (uint32_t)sq_row_start(rp_i[r], r) | ((uint32_t)(rp_i[r + 1] - rp_i[r]) << 16);
+  }
   for (int r = tid; r < 2 * N; r += SQ_THREADS) {           // one thread per (operator, row): its slots to the row's even start
     const bool second = r >= N;
     const int row = second ? r - N : r;
@@ -223,7 +245,7 @@ __device__ __forceinline__ SqLds sq_setup(char* smem, int N, const int32_t* rp_o
     const int b0 = rp[row], e0 = rp[row + 1], st = sq_row_start(b0, row);
     for (int q = b0; q < e0; ++q) { dc[st + q - b0] = (uint16_t)gcol[q]; dv[st + q - b0] = gval[q]; }
   }
-  s.val_o = vo; s.val_i = vi; s.col_o = co; s.col_i = ci; s.rp_o = ro; s.rp_i = ri;
+  s.val_o = vo; s.val_i = vi; s.col_o = co; s.col_i = ci; s.desc_o = dso; s.desc_i = dsi; s.prow = pr;
   return s;
 }
 
@@ -275,21 +297,23 @@ __device__ __forceinline__ pgt_f4 sq_load_quad(const float* p, bool hidden) {
 }
 __device__ __forceinline__ int sq_min(int a, int b) { return a < b ? a : b; }
 
-// gather task j of a thread (the loader wavefront takes none): idx = tid + 896 j; idx < 16 N: (row idx / 16, hidden quad idx % 16); then the N quads of input columns
+// gather task j of a thread (the loader wavefronts take none): idx = tid + 896 j; idx < 16 N: (task row idx / 16, hidden quad idx % 16);
+// then the N quads of input columns.  Task row p stands for row prow[p] (sq_setup: rows by falling slot count)
 struct SqTask {
-  int row, quad;
+  int pos, row, quad;
   bool live;
   __device__ __forceinline__ bool hidden() const { return quad < 16; }
   __device__ __forceinline__ int loff() const { return row * SQ_PITCH + 4 * quad; }                 // inside an LDS block
   __device__ __forceinline__ int goff(int C, int Fin) const { return row * C + (quad < 16 ? Fin + 4 * quad : 0); }   // inside [N, C]
 };
-__device__ __forceinline__ SqTask sq_task(int tid, int j, int N) {
+__device__ __forceinline__ SqTask sq_task(int tid, int j, int N, const uint16_t* __restrict__ prow) {
   const int idx = tid + j * SQ_GTHREADS;
   SqTask k;
   k.live = idx < 17 * N;
   const int ic = k.live ? idx : 0;
-  k.row = ic < 16 * N ? (ic >> 4) : ic - 16 * N;
+  k.pos = ic < 16 * N ? (ic >> 4) : ic - 16 * N;
   k.quad = ic < 16 * N ? (ic & 15) : 16;
+  k.row = (int)prow[k.pos];
   return k;
 }
 
@@ -306,6 +330,7 @@ __device__ __forceinline__ SqTask sq_task(int tid, int j, int N) {
 #define SQ_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 template <int V> struct SqInt { static constexpr int value = V; };
+struct SqNoWork {};            // "no gather work rides with this segment's products"
 
 // ---- the loaders' side of the ring.  The last TWO wavefronts stream the packed weights and do nothing else: they issue no store
 // and no other load, so their vmcnt counts exactly their own chunk loads, which return in order (wavefronts that take part in the
@@ -370,6 +395,8 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
   const int NRT = (N + 15) >> 4;                 // row tiles = MFMA wavefronts
   const bool consumer = !LOADER && wave < NRT;
   constexpr bool loader = LOADER;
+  // wavefronts w and w + 4 sit on one SIMD: of a SIMD's four, two gather first and multiply second, two the other way round
+  const bool gfirst = ((wave >> 2) & 1) != 0;
   // MFMA lane map: A row (clamped: the sums of rows past N are never used), D rows 4 (lane / 16) + i, D column lane % 16
   const int aoff = sq_min(16 * wave + (lane & 15), N - 1) * SQ_PITCH + 8 * (lane >> 4);
   const int dcol = lane & 15;
@@ -436,11 +463,17 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
         }
 
         // ---- products of one stack segment sitting in `buf` with its weight block (position POS of the consumption order): NSEG
-        // chunks, (32 hidden columns kk, 64 output columns half) each; chunk index of the step C0 + j
-        auto mfma_seg = [&](const float* buf, auto postag) {
+        // chunks, (32 hidden columns kk, 64 output columns half) each; chunk index of the step C0 + j.  `work(thread, task)` = the
+        // gather phase that is independent of these products (none: SqNoWork), a share per chunk: one of a thread's four tasks
+        // with each of four chunks, two with each of two.  Of the four wavefronts of a SIMD two gather first and multiply second,
+        // two the other way round, so that one pair's LDS round trips run under the other pair's MFMAs; a chunk's barrier stands
+        // at its end — everything a wavefront reads of the chunk's ring slot lies between the previous chunk's barrier (the loaders
+        // had written the slot by then) and this one (they overwrite it behind it) — and doubles as the phase barrier.
+        auto mfma_seg = [&](const float* buf, auto postag, auto&& work) {
           constexpr int POS = decltype(postag)::value;
           constexpr int NSEG = NCT / 2;
           constexpr int C0 = (G == 0 ? 0 : 4 * S) + POS * NSEG;
+          constexpr bool HAS_WORK = !std::is_same<std::decay_t<decltype(work)>, SqNoWork>::value;
           // the segment's input columns: a rank-Fin update as ONE exact-fp32 MFMA per column tile — lane l supplies B[k = l / 16]
           // [n = l % 16] = the weight row of input column k (zero for k >= Fin), requested here and used behind the first chunk
           float xw[NCT];
@@ -457,7 +490,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           auto chunk = [&](auto jtag) {
             constexpr int J = decltype(jtag)::value;
             constexpr int kk = NSEG == 4 ? J / 2 : J, half = NSEG == 4 ? J % 2 : 0, CH = C0 + J;
-            if (consumer) {
+            auto products = [&]() {
               if (half == 0) {
                 const pgt_f4 f0 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk);
                 const pgt_f4 f1 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk + 4);
@@ -473,28 +506,15 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
                   for (int ct = 0; ct < NCT; ++ct) acc[ct] = sq_mfma4(xa, xw[ct], acc[ct]);
                 }
               }
-              // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four).  The
-              // chunk's barrier stands BEFORE the products of its last tile — every read of this slot is behind it, the loaders have
-              // written the next chunk into the other slot — and the first fragments of the next chunk are requested right behind
-              // it: their LDS latency and the barrier's skew hide under six MFMAs instead of idling the matrix pipe at every chunk
+              // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four)
               const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (CH & 1) * SQ_CHUNK_DW) + lane;
-              if (J == 0) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
-              }
+              for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
 #pragma unroll
               for (int ct = 0; ct < 4; ++ct) {
                 if (ct < 3 && !SQ_LAB_SKIP(2)) {
 #pragma unroll
                   for (int pl = 0; pl < 3; ++pl) bq[(ct + 1) & 1][pl] = slot[((ct + 1) * 3 + pl) * 64];
-                }
-                if (ct == 3) {
-                  sq_barrier();
-                  if (J < NSEG - 1) {
-                    const sq_u32x4* nslot = reinterpret_cast<const sq_u32x4*>(s.ring + ((CH + 1) & 1) * SQ_CHUNK_DW) + lane;
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bq[0][pl] = nslot[pl * 64];
-                  }
                 }
                 const sq_u32x4 b1 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][0], b2 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][1], b3 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][2];
                 sq_f32x4 c = acc[4 * half + ct];
@@ -512,10 +532,32 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
                 acc[4 * half + ct] = c;
                 PGT_SCHED_FENCE();
               }
-            } else {
-              if constexpr (LOADER) ld.template turn<CH, NCH>();
-              sq_barrier();
+            };
+            auto gathers = [&]() {
+              if constexpr (HAS_WORK && !LOADER) {
+                int ot = tid;
+                SQ_OPAQUE(ot);
+                if constexpr (NSEG == 4) {
+                  work(ot, J);
+                } else {
+                  work(ot, 2 * J);
+                  work(ot, 2 * J + 1);
+                }
+                PGT_SCHED_FENCE();
+              }
+            };
+            if constexpr (LOADER) {
+              ld.template turn<CH, NCH>();
+            } else if constexpr (HAS_WORK) {
+#pragma unroll 1
+              for (int ph = 0; ph < 2; ++ph) {
+                if ((ph == 0) == gfirst) gathers();
+                else if (consumer) products();
+              }
+            } else if (consumer) {
+              products();
             }
+            sq_barrier();
           };
           chunk(SqInt<0>{});
           chunk(SqInt<1>{});
@@ -525,98 +567,58 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           }
         };
 
-        // ---- hop 1: T1o = P_o T0 -> block B; T1i = P_i T0 and T0 itself wait in the saved stack (this thread's own stores,
-        // read back by the same thread) while block A is still being read by the products
-        int ot = tid;
-        SQ_OPAQUE(ot);
-if constexpr (!LOADER)
-#pragma unroll
-        for (int j = 0; j < SQ_MAXT; ++j) {
-          const SqTask k = sq_task(ot, j, N);
+        // ---- the gather tasks (j = 0 .. SQ_MAXT - 1 of thread `ot`)
+        // hop 1: T1o = P_o T0 -> block B; T1i = P_i T0 and T0 itself wait in the saved stack (this thread's own stores, read back
+        // by the same thread) while block A is still being read by the products
+        auto hop1 = [&](int ot, int j) {
+          const SqTask k = sq_task(ot, j, N, s.prow);
           if (k.live) {
             const int go = k.goff(C, Fin);
             sq_store_quad(ts0 + go, k.hidden(), *reinterpret_cast<const pgt_f4*>(s.bufA + k.loff()));
-            const pgt_f4 o1 = sq_gather(s.rp_o, s.col_o, s.val_o, s.bufA, k.row, 4 * k.quad);
-            const pgt_f4 i1 = sq_gather(s.rp_i, s.col_i, s.val_i, s.bufA, k.row, 4 * k.quad);
+            const pgt_f4 o1 = sq_gather(s.desc_o[k.pos], s.col_o, s.val_o, s.bufA, 4 * k.quad);
+            const pgt_f4 i1 = sq_gather(s.desc_i[k.pos], s.col_i, s.val_i, s.bufA, 4 * k.quad);
             *reinterpret_cast<pgt_f4*>(s.bufB + k.loff()) = o1;
             sq_store_quad(ts0 + a.seg_stride + go, k.hidden(), o1);
             sq_store_quad(ts0 + 2 * a.seg_stride + go, k.hidden(), i1);
           }
-        }
-        sq_barrier();
+        };
+        // hop 2: T2 = 2 P T1 - T0, T1 in block B -> block A (T_0 is dead in LDS: it comes back from the saved stack)
+        auto hop2 = [&](int ot, int j, auto dirtag) {
+          constexpr int DIR = decltype(dirtag)::value;            // 0: P_o, segment 3; 1: P_i, segment 4
+          const SqTask k = sq_task(ot, j, N, s.prow);
+          if (k.live) {
+            const int go = k.goff(C, Fin);
+            const pgt_f4 t0 = SQ_LAB_SKIP(32) ? pgt_mk4(0.f, 0.f, 0.f, 0.f) : sq_load_quad(ts0 + go, k.hidden());
+            const pgt_f4 g = DIR == 0 ? sq_gather(s.desc_o[k.pos], s.col_o, s.val_o, s.bufB, 4 * k.quad)
+                                      : sq_gather(s.desc_i[k.pos], s.col_i, s.val_i, s.bufB, 4 * k.quad);
+            const pgt_f4 t2 = sq_two_minus(g, t0);
+            *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = t2;
+            sq_store_quad(ts0 + (3 + DIR) * a.seg_stride + go, k.hidden(), t2);
+          }
+        };
+        // T1i back from the saved stack into block `dst`
+        auto t1i_back = [&](float* dst, int ot, int j) {
+          const SqTask k = sq_task(ot, j, N, s.prow);
+          if (k.live) *reinterpret_cast<pgt_f4*>(dst + k.loff()) = SQ_LAB_SKIP(64) ? pgt_mk4(0.f, 0.f, 0.f, 0.f) : sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
+        };
+
+        // A = T0 | products T0 || hop 1 (B = T1o; T1i, T0 -> saved stack) | products T1o || A = T2o = 2 P_o B - T0 |
+        // products T2o || B = T1i | products T1i || A = T2i = 2 P_i B - T0 | products T2i
+        mfma_seg(s.bufA, SqInt<0>{}, [&](int ot, int j) { hop1(ot, j); });
         SQ_MARK(t, G, 1);
-        mfma_seg(s.bufA, SqInt<0>{});
-        mfma_seg(s.bufB, SqInt<1>{});
-        SQ_MARK(t, G, 2);
         if constexpr (K >= 3) {
-          // ---- hop 2, first direction: T2o = 2 P_o T1o - T0 -> block A (T_0 is dead in LDS)
-          ot = tid;
-          SQ_OPAQUE(ot);
-if constexpr (!LOADER)
-#pragma unroll
-          for (int j = 0; j < SQ_MAXT; ++j) {
-            const SqTask k = sq_task(ot, j, N);
-            if (k.live) {
-              const int go = k.goff(C, Fin);
-              const pgt_f4 t0 = sq_load_quad(ts0 + go, k.hidden());
-              const pgt_f4 o2 = sq_two_minus(sq_gather(s.rp_o, s.col_o, s.val_o, s.bufB, k.row, 4 * k.quad), t0);
-              *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = o2;
-              sq_store_quad(ts0 + 3 * a.seg_stride + go, k.hidden(), o2);
-            }
-          }
-          // T1i comes back from the saved stack: requested here, a product phase ahead of its use
-          pgt_f4 i1[SQ_MAXT];
-if constexpr (!LOADER)
-#pragma unroll
-          for (int j = 0; j < SQ_MAXT; ++j) {
-            const SqTask k = sq_task(ot, j, N);
-            i1[j] = pgt_mk4(0.f, 0.f, 0.f, 0.f);
-            if (k.live) i1[j] = sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
-          }
-          sq_barrier();
+          mfma_seg(s.bufB, SqInt<1>{}, [&](int ot, int j) { hop2(ot, j, SqInt<0>{}); });
+          SQ_MARK(t, G, 2);
           SQ_MARK(t, G, 3);
-          mfma_seg(s.bufA, SqInt<2>{});
+          mfma_seg(s.bufA, SqInt<2>{}, [&](int ot, int j) { t1i_back(s.bufB, ot, j); });
           SQ_MARK(t, G, 4);
-          ot = tid;
-          SQ_OPAQUE(ot);
-if constexpr (!LOADER)
-#pragma unroll
-          for (int j = 0; j < SQ_MAXT; ++j) {
-            const SqTask k = sq_task(ot, j, N);
-            if (k.live) *reinterpret_cast<pgt_f4*>(s.bufB + k.loff()) = i1[j];
-          }
-          sq_barrier();
           SQ_MARK(t, G, 5);
-          // ---- hop 2, second direction: T2i = 2 P_i T1i - T0 -> block A
-          ot = tid;
-          SQ_OPAQUE(ot);
-if constexpr (!LOADER)
-#pragma unroll
-          for (int j = 0; j < SQ_MAXT; ++j) {
-            const SqTask k = sq_task(ot, j, N);
-            if (k.live) {
-              const int go = k.goff(C, Fin);
-              const pgt_f4 t0 = sq_load_quad(ts0 + go, k.hidden());
-              const pgt_f4 i2 = sq_two_minus(sq_gather(s.rp_i, s.col_i, s.val_i, s.bufB, k.row, 4 * k.quad), t0);
-              *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = i2;
-              sq_store_quad(ts0 + 4 * a.seg_stride + go, k.hidden(), i2);
-            }
-          }
-          sq_barrier();
+          mfma_seg(s.bufB, SqInt<3>{}, [&](int ot, int j) { hop2(ot, j, SqInt<1>{}); });
           SQ_MARK(t, G, 6);
-          mfma_seg(s.bufB, SqInt<3>{});
-          mfma_seg(s.bufA, SqInt<4>{});
+          mfma_seg(s.bufA, SqInt<4>{}, SqNoWork{});
         } else {
-          ot = tid;
-          SQ_OPAQUE(ot);
-if constexpr (!LOADER)
-#pragma unroll
-          for (int j = 0; j < SQ_MAXT; ++j) {
-            const SqTask k = sq_task(ot, j, N);
-            if (k.live) *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
-          }
-          sq_barrier();
-          mfma_seg(s.bufA, SqInt<2>{});
+          mfma_seg(s.bufB, SqInt<1>{}, [&](int ot, int j) { t1i_back(s.bufA, ot, j); });
+          mfma_seg(s.bufA, SqInt<2>{}, SqNoWork{});
         }
         SQ_MARK(t, G, 7);
         // ---- gate chain on the accumulators (every product of this convolution is behind a barrier: both blocks are free)
@@ -849,12 +851,14 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
   // `after_products`: the caller's cache-line touches for the next gate adjoint, run two gather phases before the convolution ends
   auto conv_adjoint = [&](const float* dp, auto kktag, auto&& after_products) {
     constexpr int MG = decltype(kktag)::value == 2 ? 0 : 1;
-    auto own = [&](int j, int& off, bool& live) {          // hidden quad j of this thread: tasks tid + 896 j < 16 N
+    // hidden quad j of this thread: tasks tid + 896 j < 16 N, task row `pos` = row prow[pos] (sq_setup), `off` inside an LDS block
+    auto own = [&](int j, int& pos, int& off, bool& live) {
       int ot = tid;
       SQ_OPAQUE(ot);
       const int idx = ot + j * SQ_GTHREADS;
       live = idx < 16 * N;
-      off = live ? (idx >> 4) * SQ_PITCH + 4 * (idx & 15) : 0;
+      pos = live ? idx >> 4 : 0;
+      off = (int)s.prow[pos] * SQ_PITCH + 4 * (idx & 15);
     };
     auto addq = [](pgt_f4 x, pgt_f4 y) { return pgt_mk4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
     if constexpr (K >= 3) {
@@ -864,10 +868,10 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // B += 2 P_o^T A
-        int off; bool live;
-        own(j, off, live);
+        int pos, off; bool live;
+        own(j, pos, off, live);
         if (live) {
-          const pgt_f4 g = sq_gather(s.rp_o, s.col_o, s.val_o, s.bufA, off / SQ_PITCH, off % SQ_PITCH);
+          const pgt_f4 g = sq_gather(s.desc_o[pos], s.col_o, s.val_o, s.bufA, off % SQ_PITCH);
           const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufB + off);
           *reinterpret_cast<pgt_f4*>(s.bufB + off) = pgt_mk4(2.0f * g.x + 1.0f * t.x, 2.0f * g.y + 1.0f * t.y, 2.0f * g.z + 1.0f * t.z, 2.0f * g.w + 1.0f * t.w);
         }
@@ -877,11 +881,11 @@ if constexpr (!LOADER)
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // park = P_o^T B
-        int off; bool live;
-        own(j, off, live);
+        int pos, off; bool live;
+        own(j, pos, off, live);
         if (live) {
           const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
-          *reinterpret_cast<pgt_f4*>(park + r * SQ_O + q4) = sq_gather(s.rp_o, s.col_o, s.val_o, s.bufB, r, q4);
+          *reinterpret_cast<pgt_f4*>(park + r * SQ_O + q4) = sq_gather(s.desc_o[pos], s.col_o, s.val_o, s.bufB, q4);
         }
       }
       sq_barrier();
@@ -893,10 +897,10 @@ if constexpr (!LOADER)
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // B += 2 P_i^T A
-        int off; bool live;
-        own(j, off, live);
+        int pos, off; bool live;
+        own(j, pos, off, live);
         if (live) {
-          const pgt_f4 g = sq_gather(s.rp_i, s.col_i, s.val_i, s.bufA, off / SQ_PITCH, off % SQ_PITCH);
+          const pgt_f4 g = sq_gather(s.desc_i[pos], s.col_i, s.val_i, s.bufA, off % SQ_PITCH);
           const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufB + off);
           *reinterpret_cast<pgt_f4*>(s.bufB + off) = pgt_mk4(2.0f * g.x + 1.0f * t.x, 2.0f * g.y + 1.0f * t.y, 2.0f * g.z + 1.0f * t.z, 2.0f * g.w + 1.0f * t.w);
         }
@@ -908,12 +912,12 @@ if constexpr (!LOADER)
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // A += park + P_i^T B
-        int off; bool live;
-        own(j, off, live);
+        int pos, off; bool live;
+        own(j, pos, off, live);
         if (live) {
           const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
           const pgt_f4 pk = *reinterpret_cast<const pgt_f4*>(park + r * SQ_O + q4);
-          const pgt_f4 g = sq_gather(s.rp_i, s.col_i, s.val_i, s.bufB, r, q4);
+          const pgt_f4 g = sq_gather(s.desc_i[pos], s.col_i, s.val_i, s.bufB, q4);
           const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufA + off);
           *reinterpret_cast<pgt_f4*>(s.bufA + off) = addq(addq(t, pk), g);
         }
@@ -924,12 +928,12 @@ if constexpr (!LOADER)
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {  // park = P_o^T A + P_i^T B
-        int off; bool live;
-        own(j, off, live);
+        int pos, off; bool live;
+        own(j, pos, off, live);
         if (live) {
           const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
-          const pgt_f4 go = sq_gather(s.rp_o, s.col_o, s.val_o, s.bufA, r, q4);
-          const pgt_f4 gi = sq_gather(s.rp_i, s.col_i, s.val_i, s.bufB, r, q4);
+          const pgt_f4 go = sq_gather(s.desc_o[pos], s.col_o, s.val_o, s.bufA, q4);
+          const pgt_f4 gi = sq_gather(s.desc_i[pos], s.col_i, s.val_i, s.bufB, q4);
           *reinterpret_cast<pgt_f4*>(park + r * SQ_O + q4) = addq(go, gi);
         }
       }
@@ -939,8 +943,8 @@ if constexpr (!LOADER)
 if constexpr (!LOADER)
 #pragma unroll
       for (int j = 0; j < SQ_MAXT; ++j) {
-        int off; bool live;
-        own(j, off, live);
+        int pos, off; bool live;
+        own(j, pos, off, live);
         if (live) {
           const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
           const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufA + off);

@@ -96,7 +96,8 @@ void pgt_slab_set_quad(int v);
 void pgt_slab_set_gu(int v);
 void pgt_slab_set_sort(int v);
 void pgt_tgcn_set_rows(int v);
-void pgt_tgcn_set_probe(int v);
+int pgt_tgcn_set_probe(int v);    // 0: not compiled in (product library)
+void pgt_tgcn_set_wgs(int v);
 void pgt_gemm_set_tn_pipe(int v);
 void pgt_gemm_set_skinny(int v);
 void pgt_gemm_set_dbp(int v);

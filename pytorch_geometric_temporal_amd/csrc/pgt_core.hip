@@ -89,7 +89,11 @@ extern "C" int pgt_tune(const char* key, int value) {
     return PGT_OK;
   }
   if (strcmp(key, "tgcn_probe") == 0) {
-    pgt_tgcn_set_probe(value);
+    PGT_REQUIRE(pgt_tgcn_set_probe(value), "pgt_tune: \"tgcn_probe\" selects kernels that compute wrong results on purpose; this library was built without -DPGT_LAB_PROBES");
+    return PGT_OK;
+  }
+  if (strcmp(key, "tgcn_wgs") == 0) {
+    pgt_tgcn_set_wgs(value);
     return PGT_OK;
   }
   if (strcmp(key, "tgcn_rows") == 0) {

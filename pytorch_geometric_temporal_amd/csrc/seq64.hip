@@ -19,11 +19,9 @@
 //     the new state go straight back into the LDS block as the next T_0;
 //   * what the adjoint needs (both stacks, Z | R, the candidate, the states) is stored once, in the layout of the general path
 //     (ops.DCRNNSeqFunction), so the general backward and the weight-gradient product run unchanged on it.
-// Two blocks are enough for K = 3 because T_1^i = P_i T_0 is gathered together with T_1^o and waits in its place in the saved stack,
-// as does T_0.  A gather phase and the products that do not depend on it share one run of chunk barriers (`||`):
-//   A = T0 | MFMA T0 || B = T1o, T1i -> stack | MFMA T1o || A = T2o = 2 P_o B - T0 | MFMA T2o || B = T1i | MFMA T1i || A = T2i = 2 P_i B - T0 | MFMA T2i.
+// Two blocks are enough for K = 3 because T_1^i = P_i T_0 is gathered together with T_1^o and waits in registers:
+//   A = T0 | B = T1o, regs = T1i | MFMA T0, T1o | A = T2o = 2 P_o B - T0 | MFMA T2o | B = T1i | A = T2i = 2 P_i B - T0 | MFMA T1i, T2i.
 #include "pgt_common.h"
-#include <type_traits>
 
 namespace {
 
@@ -170,7 +168,8 @@ __host__ __device__ inline int sq_row_start(int rp_r, int r) { return (rp_r + r 
 // The gather tasks walk the rows in the order of FALLING slot count (sq_setup: `prow`, one order for both operators and both
 // directions — the counts of a row in P_o and P_i go together on road graphs: 0.93 correlation on the benchmark's), so that the four
 // rows a wavefront gathers at a time are equally long give or take a slot: in row order the longest of four has 10.3 slots against
-// a mean of 7.3 on the METR-LA-shaped graph, and the wavefront walks the longest (gather phases 3.5 -> 3.1 us).
+// a mean of 7.3 on the METR-LA-shaped graph, and the wavefront walks the longest (the adjoint's gather phases 3.5 -> 3.1 us, its
+// launch - 3.4 %; the forward's, which also carry the stores of the saved stacks, measure the same either way).
 // Row sum over the slots of one row, `desc` = its first slot | slot count << 16 (csrc/dconv_slab.hip gather_q: the same fmaf chain
 // in slot order), four slots in flight
 __device__ __forceinline__ pgt_f4 sq_gather(uint32_t desc, const uint16_t* __restrict__ col, const float* __restrict__ val,
@@ -330,7 +329,6 @@ __device__ __forceinline__ SqTask sq_task(int tid, int j, int N, const uint16_t*
 #define SQ_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 template <int V> struct SqInt { static constexpr int value = V; };
-struct SqNoWork {};            // "no gather work rides with this segment's products"
 
 // ---- the loaders' side of the ring.  The last TWO wavefronts stream the packed weights and do nothing else: they issue no store
 // and no other load, so their vmcnt counts exactly their own chunk loads, which return in order (wavefronts that take part in the
@@ -395,8 +393,6 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
   const int NRT = (N + 15) >> 4;                 // row tiles = MFMA wavefronts
   const bool consumer = !LOADER && wave < NRT;
   constexpr bool loader = LOADER;
-  // wavefronts w and w + 4 sit on one SIMD: of a SIMD's four, two gather first and multiply second, two the other way round
-  const bool gfirst = ((wave >> 2) & 1) != 0;
   // MFMA lane map: A row (clamped: the sums of rows past N are never used), D rows 4 (lane / 16) + i, D column lane % 16
   const int aoff = sq_min(16 * wave + (lane & 15), N - 1) * SQ_PITCH + 8 * (lane >> 4);
   const int dcol = lane & 15;
@@ -463,17 +459,11 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
         }
 
         // ---- products of one stack segment sitting in `buf` with its weight block (position POS of the consumption order): NSEG
-        // chunks, (32 hidden columns kk, 64 output columns half) each; chunk index of the step C0 + j.  `work(thread, task)` = the
-        // gather phase that is independent of these products (none: SqNoWork), a share per chunk: one of a thread's four tasks
-        // with each of four chunks, two with each of two.  Of the four wavefronts of a SIMD two gather first and multiply second,
-        // two the other way round, so that one pair's LDS round trips run under the other pair's MFMAs; a chunk's barrier stands
-        // at its end — everything a wavefront reads of the chunk's ring slot lies between the previous chunk's barrier (the loaders
-        // had written the slot by then) and this one (they overwrite it behind it) — and doubles as the phase barrier.
-        auto mfma_seg = [&](const float* buf, auto postag, auto&& work) {
+        // chunks, (32 hidden columns kk, 64 output columns half) each; chunk index of the step C0 + j
+        auto mfma_seg = [&](const float* buf, auto postag) {
           constexpr int POS = decltype(postag)::value;
           constexpr int NSEG = NCT / 2;
           constexpr int C0 = (G == 0 ? 0 : 4 * S) + POS * NSEG;
-          constexpr bool HAS_WORK = !std::is_same<std::decay_t<decltype(work)>, SqNoWork>::value;
           // the segment's input columns: a rank-Fin update as ONE exact-fp32 MFMA per column tile — lane l supplies B[k = l / 16]
           // [n = l % 16] = the weight row of input column k (zero for k >= Fin), requested here and used behind the first chunk
           float xw[NCT];
@@ -490,7 +480,7 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           auto chunk = [&](auto jtag) {
             constexpr int J = decltype(jtag)::value;
             constexpr int kk = NSEG == 4 ? J / 2 : J, half = NSEG == 4 ? J % 2 : 0, CH = C0 + J;
-            auto products = [&]() {
+            if (consumer) {
               if (half == 0) {
                 const pgt_f4 f0 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk);
                 const pgt_f4 f1 = *reinterpret_cast<const pgt_f4*>(buf + aoff + 32 * kk + 4);
@@ -506,15 +496,28 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
                   for (int ct = 0; ct < NCT; ++ct) acc[ct] = sq_mfma4(xa, xw[ct], acc[ct]);
                 }
               }
-              // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four)
+              // B fragments of column tile ct + 1 are read while the six products of tile ct issue (two sets, not all four).  The
+              // chunk's barrier stands BEFORE the products of its last tile — every read of this slot is behind it, the loaders have
+              // written the next chunk into the other slot — and the first fragments of the next chunk are requested right behind
+              // it: their LDS latency and the barrier's skew hide under six MFMAs instead of idling the matrix pipe at every chunk
               const sq_u32x4* slot = reinterpret_cast<const sq_u32x4*>(s.ring + (CH & 1) * SQ_CHUNK_DW) + lane;
+              if (J == 0) {
 #pragma unroll
-              for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+                for (int pl = 0; pl < 3; ++pl) bq[0][pl] = slot[pl * 64];
+              }
 #pragma unroll
               for (int ct = 0; ct < 4; ++ct) {
                 if (ct < 3 && !SQ_LAB_SKIP(2)) {
 #pragma unroll
                   for (int pl = 0; pl < 3; ++pl) bq[(ct + 1) & 1][pl] = slot[((ct + 1) * 3 + pl) * 64];
+                }
+                if (ct == 3) {
+                  sq_barrier();
+                  if (J < NSEG - 1) {
+                    const sq_u32x4* nslot = reinterpret_cast<const sq_u32x4*>(s.ring + ((CH + 1) & 1) * SQ_CHUNK_DW) + lane;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bq[0][pl] = nslot[pl * 64];
+                  }
                 }
                 const sq_u32x4 b1 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][0], b2 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][1], b3 = bq[SQ_LAB_SKIP(2) ? 0 : ct & 1][2];
                 sq_f32x4 c = acc[4 * half + ct];
@@ -532,32 +535,10 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
                 acc[4 * half + ct] = c;
                 PGT_SCHED_FENCE();
               }
-            };
-            auto gathers = [&]() {
-              if constexpr (HAS_WORK && !LOADER) {
-                int ot = tid;
-                SQ_OPAQUE(ot);
-                if constexpr (NSEG == 4) {
-                  work(ot, J);
-                } else {
-                  work(ot, 2 * J);
-                  work(ot, 2 * J + 1);
-                }
-                PGT_SCHED_FENCE();
-              }
-            };
-            if constexpr (LOADER) {
-              ld.template turn<CH, NCH>();
-            } else if constexpr (HAS_WORK) {
-#pragma unroll 1
-              for (int ph = 0; ph < 2; ++ph) {
-                if ((ph == 0) == gfirst) gathers();
-                else if (consumer) products();
-              }
-            } else if (consumer) {
-              products();
+            } else {
+              if constexpr (LOADER) ld.template turn<CH, NCH>();
+              sq_barrier();
             }
-            sq_barrier();
           };
           chunk(SqInt<0>{});
           chunk(SqInt<1>{});
@@ -567,10 +548,13 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
           }
         };
 
-        // ---- the gather tasks (j = 0 .. SQ_MAXT - 1 of thread `ot`)
-        // hop 1: T1o = P_o T0 -> block B; T1i = P_i T0 and T0 itself wait in the saved stack (this thread's own stores, read back
-        // by the same thread) while block A is still being read by the products
-        auto hop1 = [&](int ot, int j) {
+        // ---- hop 1: T1o = P_o T0 -> block B; T1i = P_i T0 and T0 itself wait in the saved stack (this thread's own stores,
+        // read back by the same thread) while block A is still being read by the products
+        int ot = tid;
+        SQ_OPAQUE(ot);
+if constexpr (!LOADER)
+#pragma unroll
+        for (int j = 0; j < SQ_MAXT; ++j) {
           const SqTask k = sq_task(ot, j, N, s.prow);
           if (k.live) {
             const int go = k.goff(C, Fin);
@@ -581,44 +565,81 @@ __device__ __forceinline__ void sq_fwd_body(const Seq64Args& a, char* smem) {
             sq_store_quad(ts0 + a.seg_stride + go, k.hidden(), o1);
             sq_store_quad(ts0 + 2 * a.seg_stride + go, k.hidden(), i1);
           }
-        };
-        // hop 2: T2 = 2 P T1 - T0, T1 in block B -> block A (T_0 is dead in LDS: it comes back from the saved stack)
-        auto hop2 = [&](int ot, int j, auto dirtag) {
-          constexpr int DIR = decltype(dirtag)::value;            // 0: P_o, segment 3; 1: P_i, segment 4
-          const SqTask k = sq_task(ot, j, N, s.prow);
-          if (k.live) {
-            const int go = k.goff(C, Fin);
-            const pgt_f4 t0 = SQ_LAB_SKIP(32) ? pgt_mk4(0.f, 0.f, 0.f, 0.f) : sq_load_quad(ts0 + go, k.hidden());
-            const pgt_f4 g = DIR == 0 ? sq_gather(s.desc_o[k.pos], s.col_o, s.val_o, s.bufB, 4 * k.quad)
-                                      : sq_gather(s.desc_i[k.pos], s.col_i, s.val_i, s.bufB, 4 * k.quad);
-            const pgt_f4 t2 = sq_two_minus(g, t0);
-            *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = t2;
-            sq_store_quad(ts0 + (3 + DIR) * a.seg_stride + go, k.hidden(), t2);
-          }
-        };
-        // T1i back from the saved stack into block `dst`
-        auto t1i_back = [&](float* dst, int ot, int j) {
-          const SqTask k = sq_task(ot, j, N, s.prow);
-          if (k.live) *reinterpret_cast<pgt_f4*>(dst + k.loff()) = SQ_LAB_SKIP(64) ? pgt_mk4(0.f, 0.f, 0.f, 0.f) : sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
-        };
-
-        // A = T0 | products T0 || hop 1 (B = T1o; T1i, T0 -> saved stack) | products T1o || A = T2o = 2 P_o B - T0 |
-        // products T2o || B = T1i | products T1i || A = T2i = 2 P_i B - T0 | products T2i
-        mfma_seg(s.bufA, SqInt<0>{}, [&](int ot, int j) { hop1(ot, j); });
+        }
+        sq_barrier();
         SQ_MARK(t, G, 1);
+        mfma_seg(s.bufA, SqInt<0>{});
+        mfma_seg(s.bufB, SqInt<1>{});
+        SQ_MARK(t, G, 2);
         if constexpr (K >= 3) {
-          mfma_seg(s.bufB, SqInt<1>{}, [&](int ot, int j) { hop2(ot, j, SqInt<0>{}); });
-          SQ_MARK(t, G, 2);
+          // ---- hop 2, first direction: T2o = 2 P_o T1o - T0 -> block A (T_0 is dead in LDS)
+          ot = tid;
+          SQ_OPAQUE(ot);
+if constexpr (!LOADER)
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N, s.prow);
+            if (k.live) {
+              const int go = k.goff(C, Fin);
+              const pgt_f4 t0 = SQ_LAB_SKIP(32) ? pgt_mk4(0.f, 0.f, 0.f, 0.f) : sq_load_quad(ts0 + go, k.hidden());
+              const pgt_f4 o2 = sq_two_minus(sq_gather(s.desc_o[k.pos], s.col_o, s.val_o, s.bufB, 4 * k.quad), t0);
+              *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = o2;
+              sq_store_quad(ts0 + 3 * a.seg_stride + go, k.hidden(), o2);
+            }
+          }
+          // T1i comes back from the saved stack: requested here, a product phase ahead of its use
+          pgt_f4 i1[SQ_MAXT];
+if constexpr (!LOADER)
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N, s.prow);
+            i1[j] = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+            if (k.live && !SQ_LAB_SKIP(64)) i1[j] = sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
+          }
+          sq_barrier();
           SQ_MARK(t, G, 3);
-          mfma_seg(s.bufA, SqInt<2>{}, [&](int ot, int j) { t1i_back(s.bufB, ot, j); });
+          mfma_seg(s.bufA, SqInt<2>{});
           SQ_MARK(t, G, 4);
+          ot = tid;
+          SQ_OPAQUE(ot);
+if constexpr (!LOADER)
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N, s.prow);
+            if (k.live) *reinterpret_cast<pgt_f4*>(s.bufB + k.loff()) = i1[j];
+          }
+          sq_barrier();
           SQ_MARK(t, G, 5);
-          mfma_seg(s.bufB, SqInt<3>{}, [&](int ot, int j) { hop2(ot, j, SqInt<1>{}); });
+          // ---- hop 2, second direction: T2i = 2 P_i T1i - T0 -> block A
+          ot = tid;
+          SQ_OPAQUE(ot);
+if constexpr (!LOADER)
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N, s.prow);
+            if (k.live) {
+              const int go = k.goff(C, Fin);
+              const pgt_f4 t0 = SQ_LAB_SKIP(32) ? pgt_mk4(0.f, 0.f, 0.f, 0.f) : sq_load_quad(ts0 + go, k.hidden());
+              const pgt_f4 i2 = sq_two_minus(sq_gather(s.desc_i[k.pos], s.col_i, s.val_i, s.bufB, 4 * k.quad), t0);
+              *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = i2;
+              sq_store_quad(ts0 + 4 * a.seg_stride + go, k.hidden(), i2);
+            }
+          }
+          sq_barrier();
           SQ_MARK(t, G, 6);
-          mfma_seg(s.bufA, SqInt<4>{}, SqNoWork{});
+          mfma_seg(s.bufB, SqInt<3>{});
+          mfma_seg(s.bufA, SqInt<4>{});
         } else {
-          mfma_seg(s.bufB, SqInt<1>{}, [&](int ot, int j) { t1i_back(s.bufA, ot, j); });
-          mfma_seg(s.bufA, SqInt<2>{}, SqNoWork{});
+          ot = tid;
+          SQ_OPAQUE(ot);
+if constexpr (!LOADER)
+#pragma unroll
+          for (int j = 0; j < SQ_MAXT; ++j) {
+            const SqTask k = sq_task(ot, j, N, s.prow);
+            if (k.live) *reinterpret_cast<pgt_f4*>(s.bufA + k.loff()) = sq_load_quad(ts0 + 2 * a.seg_stride + k.goff(C, Fin), k.hidden());
+          }
+          sq_barrier();
+          mfma_seg(s.bufA, SqInt<2>{});
         }
         SQ_MARK(t, G, 7);
         // ---- gate chain on the accumulators (every product of this convolution is behind a barrier: both blocks are free)

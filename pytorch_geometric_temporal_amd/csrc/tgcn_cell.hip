@@ -24,7 +24,7 @@ namespace {
 
 int g_tc_rows = 1;                  // pgt_tune("tgcn_rows", 0): the round-4 column-per-lane kernels for every shape
 int g_tc_wgs = 0;                   // pgt_tune("tgcn_wgs", n): workgroups of the row-per-lane forward kernel (0 = default), lab use
-int g_tc_probe = 0;                 // pgt_tune("tgcn_probe", n): lab variants of the forward kernel (wrong results), see PROBE
+int g_tc_probe = 0;                 // lab variants of the forward kernel (wrong results; -DPGT_LAB_PROBES builds only), see PROBE
 
 constexpr int TC_O = 32;            // hidden width these kernels are built for
 constexpr int TC_LD = 33;           // LDS row pitch of a wavefront's strips (32 rows + 1: conflict-free both ways)
@@ -795,7 +795,18 @@ extern "C" int64_t pgt_tgcn_cell_bwd_ws_floats(int64_t Fin, int64_t O) {
 }
 
 void pgt_tgcn_set_rows(int v) { g_tc_rows = v ? 1 : 0; }
-void pgt_tgcn_set_probe(int v) { if (v >= 1000) g_tc_wgs = v - 1000; else g_tc_probe = v; }   // (1000 + n: workgroup cap n)
+void pgt_tgcn_set_wgs(int v) { g_tc_wgs = v > 0 ? v : 0; }          // pgt_tune("tgcn_wgs", n): at most n workgroups per launch (0: the default)
+// pgt_tune("tgcn_probe", n): forward-kernel variants with parts switched off (WRONG results: what a phase costs) — compiled only
+// into a library built with -DPGT_LAB_PROBES; the product library rejects the key
+int pgt_tgcn_set_probe(int v) {
+#ifdef PGT_LAB_PROBES
+  g_tc_probe = v;
+  return 1;
+#else
+  (void)v;
+  return 0;
+#endif
+}
 
 extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, int64_t ldh, const float* Wzr, const float* bzr,
                                  const float* Wh, const float* bh, int64_t M, int64_t Fin, int64_t O, float* ZR, float* HT, float* Hn,
@@ -813,9 +824,11 @@ extern "C" int pgt_tgcn_cell_f32(const float* AX, int64_t ldax, const float* H, 
     const int64_t cap = g_tc_wgs > 0 ? g_tc_wgs : TC_WGS_ROWS_FWD;
     const int64_t wg = g.tiles < cap ? g.tiles : cap;
     switch (g_tc_probe) {
+#ifdef PGT_LAB_PROBES
       case 1: PGT_LAUNCH(tgcn_cell_fwd_rows_kernel<1>, dim3((unsigned)wg), dim3(256), stream, g); break;
       case 2: PGT_LAUNCH(tgcn_cell_fwd_rows_kernel<2>, dim3((unsigned)wg), dim3(256), stream, g); break;
       case 3: PGT_LAUNCH(tgcn_cell_fwd_rows_kernel<3>, dim3((unsigned)wg), dim3(256), stream, g); break;
+#endif
       default: PGT_LAUNCH(tgcn_cell_fwd_rows_kernel<0>, dim3((unsigned)wg), dim3(256), stream, g);
     }
     return pgt_check_launch("pgt_tgcn_cell_f32");

@@ -95,11 +95,18 @@ _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
 _scope = threading.local()        # .depth: nn.Module calls in flight on this thread; .epoch: outermost calls finished so far
 
 
+_compiling = getattr(getattr(torch, "compiler", None), "is_compiling", lambda: False)
+
+
 def _enter_module(module, args):
+    if _compiling():                  # (a tracer sees no mutation of the thread-local: compiled code does not come through packed_once)
+        return
     _scope.depth = getattr(_scope, "depth", 0) + 1
 
 
 def _leave_module(module, args, output):
+    if _compiling():
+        return
     d = getattr(_scope, "depth", 1) - 1
     _scope.depth = d
     if d <= 0:
@@ -108,9 +115,26 @@ def _leave_module(module, args, output):
 
 
 # The scope of "the same operands" is one OUTERMOST module call (the user's model: its T-step loop over the cell runs inside it).
-# Two process-wide hooks count the nesting; they do nothing else.
-register_module_forward_pre_hook(_enter_module)
-register_module_forward_hook(_leave_module, always_call=True)
+# Two process-wide hooks count the nesting; they do nothing else — and they are installed by the first call of packed_once, i.e.
+# only in a process that actually runs one of this package's gated cells (importing the package leaves torch.nn.Module's
+# hook-free call path alone).  The outermost call during which they appear is seen as "no enclosing module": its cells write
+# their operands' values per call, which is always correct.
+_hooks = []
+
+
+def _install_scope_hooks():
+    if not _hooks:
+        _hooks.append(register_module_forward_pre_hook(_enter_module))
+        _hooks.append(register_module_forward_hook(_leave_module, always_call=True))
+
+
+def reset_call_scope():
+    """Forget the nesting count of this thread.  A module call abandoned by a BaseException that is not an Exception
+    (KeyboardInterrupt in a notebook) never runs its forward hook: the count then stays above zero and the cells keep treating
+    later calls as part of that one — correct for parameters changed in the ordinary ways (`_version`), blind to `p.data` writes.
+    Call this after such an interrupt."""
+    _scope.depth = 0
+    _scope.epoch = getattr(_scope, "epoch", 0) + 1
 
 
 def _in_backward():
@@ -135,6 +159,7 @@ def packed_once(module, params, build, repack=None):
     (`p.data.copy_()`, an EMA swap) is picked up; (2) operands made outside a hipGraph capture are not used inside one and vice
     versa (the capture must hold its own pack launch and its own buffers); (3) only while gradients are being recorded: an
     inference call packs for itself."""
+    _install_scope_hooks()
     if not (torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)) or _in_backward():
         # inference: one cheap launch per call and nothing to accumulate — and no way to go stale.  A forward that runs INSIDE a
         # backward pass (torch.utils.checkpoint re-running a segment) gets operands of its own: the cached ones belong to the graph

@@ -11,6 +11,8 @@ done
 for m in 0 1 4 8 16 20 21 28 9 29 32; do
   /opt/rocm/bin/hipcc $FLAGS -DBX_SKIP=$m lab/gemm_bx_trace_lab.hip -o lab/gemm_bx_trace_lab_$m || exit 1
 done
-# csrc/seq64.hip with the phase timeline of workgroup 0 (scripts/seq64_trace.py); "_serial": round 6's first form of it
+# csrc/seq64.hip with the phase timeline of workgroup 0 (scripts/seq64_trace.py); "_stagger": the withdrawn overlapped forward;
+# "_skipN": parts switched off (SQ_LAB_SKIP bits in csrc/seq64.hip)
 /opt/rocm/bin/hipcc $FLAGS -shared -fPIC lab/seq64_lab.hip -o lab/libseq64_lab.so || exit 1
-/opt/rocm/bin/hipcc $FLAGS -shared -fPIC -DSQ_SERIAL_RECORD lab/seq64_lab.hip -o lab/libseq64_lab_serial.so || exit 1
+/opt/rocm/bin/hipcc $FLAGS -shared -fPIC -DSQ_STAGGER_RECORD lab/seq64_lab.hip -o lab/libseq64_lab_stagger.so || exit 1
+for m in ${SQ_SKIPS:-}; do /opt/rocm/bin/hipcc $FLAGS -shared -fPIC -DSQ_SKIP=$m lab/seq64_lab.hip -o lab/libseq64_lab_skip$m.so || exit 1; done

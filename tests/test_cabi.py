@@ -151,8 +151,12 @@ def test_bad_arguments_return_error_codes_not_crashes():
     assert {"gemm_bx", "gemm_bx_sym", "gemm_db", "spmm_ellw", "slab_pairs"} <= keys
     defaults = {"gemm_small_fill": 256, "gemm_small_tiles": 0, "spmm_tile_rows": 32, "spmm_unroll": 8, "spmm_ellw_rows": 0,
                 "spmm_ellw_cus": 0, "spmm_ellw_cfg": 0, "slab_pairs": 2, "slab_wpc": 0, "slab_threads": 0, "slab_gu": 2}   # every other switch defaults to 1
-    for k in sorted(keys):
+    defaults["tgcn_wgs"] = 0
+    for k in sorted(keys - {"tgcn_probe"}):
         lib.tune(k, defaults.get(k, 1))
+    # ... except the one that selects kernels which compute wrong results on purpose: compiled only into lab builds
+    with pytest.raises(_lib.PgtError, match="PGT_LAB_PROBES"):
+        lib.tune("tgcn_probe", 1)
     assert lib.prep_workspace_bytes(2, 2) > 8
     ok = [
         ("pgt_gemm_f32", (p, 4, 0, 1, 4, p, 4, 1, p, 4, 0, 4, null, 0, 4, 0, null)),             # M = 0

@@ -1332,3 +1332,17 @@ def test_packed_operands_under_reentrant_checkpointing(backend):
         grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
     for k in grads[0]:
         assert_close_with_nonfinite(grads[1][k], grads[0][k], 1e-6 + 2e-5 * float(grads[0][k].abs().max()), 1e-5, k)
+
+
+def test_importing_the_package_installs_no_process_wide_module_hooks():
+    """The nesting counter behind packed_once lives in two global nn.Module hooks; they appear with the first gated cell that runs,
+    not with `import`: a process that only imports the package (or runs other models) keeps torch's hook-free module call path."""
+    import subprocess
+    import sys
+    code = ("import torch, pytorch_geometric_temporal_amd.nn.recurrent as r\n"
+            "from torch.nn.modules import module as m\n"
+            "print(len(m._global_forward_hooks) + len(m._global_forward_pre_hooks))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "0"

@@ -105,8 +105,8 @@ __device__ __forceinline__ pgt_f4 sq_two_minus(pgt_f4 g, pgt_f4 t) {
 }
 
 // lab/seq64_lab.hip defines this to take the kernels apart (1: no MFMAs, 2: the B fragments of a chunk read once, 4: no ring
-// writes, 8: no gathers, 16: no stores of the saved stacks, 32: no T_0 read back in the second hops, 64: no T_1^i read back);
-// compile-time constants in the library
+// writes, 8: no gathers, 16: no stores of the saved stacks / of dP, 32: no T_0 read back in the second hops / no parked slice in the
+// adjoint, 64: no T_1^i read back, 128: no operand loads of the gate adjoints); compile-time constants in the library
 #ifndef SQ_LAB_SKIP
 #define SQ_LAB_SKIP(bit) false
 #endif
@@ -836,12 +836,16 @@ __device__ __forceinline__ void sq_bwd_body(const Seq64BwdArgs& a, char* smem) {
           }
           const sq_u32x4 b1 = bq[ct & 1][0], b2 = bq[ct & 1][1], b3 = bq[ct & 1][2];
           sq_f32x4 c = acc[ct];
-          c = sq_mfma16(a3, b1, c);
-          c = sq_mfma16(a1, b3, c);
-          c = sq_mfma16(a2, b2, c);
-          c = sq_mfma16(a2, b1, c);
-          c = sq_mfma16(a1, b2, c);
-          c = sq_mfma16(a1, b1, c);
+          if (!SQ_LAB_SKIP(1)) {
+            c = sq_mfma16(a3, b1, c);
+            c = sq_mfma16(a1, b3, c);
+            c = sq_mfma16(a2, b2, c);
+            c = sq_mfma16(a2, b1, c);
+            c = sq_mfma16(a1, b2, c);
+            c = sq_mfma16(a1, b1, c);
+          } else {
+            c[0] += sq_as_float(a1[0] ^ b1[0] ^ a2[1] ^ b2[1] ^ a3[2] ^ b3[2]);
+          }
           acc[ct] = c;
           PGT_SCHED_FENCE();
         }
@@ -906,7 +910,8 @@ if constexpr (!LOADER)
         own(j, pos, off, live);
         if (live) {
           const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
-          *reinterpret_cast<pgt_f4*>(park + r * SQ_O + q4) = sq_gather(s.desc_o[pos], s.col_o, s.val_o, s.bufB, q4);
+          const pgt_f4 pk = sq_gather(s.desc_o[pos], s.col_o, s.val_o, s.bufB, q4);
+          if (!SQ_LAB_SKIP(32)) *reinterpret_cast<pgt_f4*>(park + r * SQ_O + q4) = pk;
         }
       }
       sq_barrier();
@@ -937,7 +942,7 @@ if constexpr (!LOADER)
         own(j, pos, off, live);
         if (live) {
           const int r = off / SQ_PITCH, q4 = off % SQ_PITCH;
-          const pgt_f4 pk = *reinterpret_cast<const pgt_f4*>(park + r * SQ_O + q4);
+          const pgt_f4 pk = SQ_LAB_SKIP(32) ? pgt_mk4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const pgt_f4*>(park + r * SQ_O + q4);
           const pgt_f4 g = sq_gather(s.desc_i[pos], s.col_i, s.val_i, s.bufB, q4);
           const pgt_f4 t = *reinterpret_cast<const pgt_f4*>(s.bufA + off);
           *reinterpret_cast<pgt_f4*>(s.bufA + off) = addq(addq(t, pk), g);
@@ -977,12 +982,17 @@ if constexpr (!LOADER)
 
   // 8 floats of this lane's row at columns c0 + acol .. + 7 of a [rows, ld] global array
   auto ld8 = [&](const float* rows, int ld, int c0, float* v) {
+    if (SQ_LAB_SKIP(128)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.25f;
+      return;
+    }
     const pgt_f4 x = *reinterpret_cast<const pgt_f4*>(rows + arow * ld + c0 + acol);
     const pgt_f4 y = *reinterpret_cast<const pgt_f4*>(rows + arow * ld + c0 + acol + 4);
     v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
   };
   auto st8 = [&](float* rows, int ld, int c0, const float* v) {
-    if (!rvalid) return;
+    if (!rvalid || SQ_LAB_SKIP(16)) return;
     *reinterpret_cast<pgt_f4*>(rows + arow * ld + c0 + acol) = pgt_mk4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<pgt_f4*>(rows + arow * ld + c0 + acol + 4) = pgt_mk4(v[4], v[5], v[6], v[7]);
   };

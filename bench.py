@@ -161,6 +161,9 @@ def kernel_class_rooflines(kernels, shapes):
                     v["by_direction"].append({"direction": d, "launches": r["launches"], "avg_us": r["avg_us"],
                                               "algorithmic_MB": r["work_per_launch"] / 1e6,
                                               "hbm_frac": r["work_per_launch"] / sec / 1e9 / HBM_PEAK_GBS,
+                                              # what a plain stream of this launch's read : write mix reaches on this part (lab/hbm_rw_lab,
+                                              # fresh windows: write-only 4.4 - 4.7 TB/s, mixed 5.05 - 5.4): the forward only writes
+                                              "stream_ceiling_frac": r["work_per_launch"] / sec / 1e9 / (4500.0 if d == "fwd" else 5200.0),
                                               "bf16_pipe_frac": 6.0 * flops / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS})
                 v["bf16_pipe_frac"] = 6.0 * tot_f / tot_s / 1e12 / MFMA_BF16_PEAK_TFLOPS if tot_s > 0 else None
     return kernels
@@ -768,7 +771,9 @@ def main():
             roof["bf16_pipe_frac"] = k["bf16_pipe_frac"]
             roof["by_direction"] = k["by_direction"]
             roof["why_hbm"] = ("a fused kernel: its HBM traffic is the saved activations (written once) — at 2 TB/s it is bound by neither "
-                               "HBM nor the matrix pipe but by the LDS gathers and the per-chunk hand-overs inside a CU (DESIGN.md 3.2)")
+                               "spec roofline but by the LDS gathers, the per-chunk hand-overs and the stores of the saved stacks inside a "
+                               "CU (a fifth of the forward); the forward is a pure write stream: stream_ceiling_frac prices it against "
+                               "the 4.5 TB/s a write-only stream reaches on this part (DESIGN.md 3.2)")
         roof.update(pmc_traffic(dom))
         roof["all_kernel_classes"] = all_kernel_classes(kernels, args.profile_steps)
     del step

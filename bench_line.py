@@ -78,6 +78,7 @@ def compact_roofline(roof):
         out["why_hbm"] = _s(roof["why_hbm"], 240)
     if isinstance(roof.get("by_direction"), list):
         out["by_direction"] = [{"dir": d.get("direction"), "us": _r(d.get("avg_us")), "hbm_frac": _r(d.get("hbm_frac"), 3),
+                                "stream_ceiling_frac": _r(d.get("stream_ceiling_frac"), 3),
                                 "bf16_pipe_frac": _r(d.get("bf16_pipe_frac"), 3)} for d in roof["by_direction"][:2]]
     if isinstance(roof.get("set_aside"), dict):
         out["set_aside"] = {"launches": roof["set_aside"].get("launches"), "ms": _r(roof["set_aside"].get("ms"), 4),

@@ -366,7 +366,7 @@ def cpu_spmm_ns(cores, seconds=2.0):
             "achieved_GBs": nbytes / us / 1e3, "cores": cores, "reps": reps}
 
 
-def spmm_roofline_ns(device, pairs=6, launches=60):
+def spmm_roofline_ns(device, pairs=6, launches=60, only=None):
     """North-star micro-benchmark: one diffusion-conv aggregation Y = P_o X at N = 200 000, F = 64, in-degree 8 (and 16).
     The launches rotate through `pairs` distinct (X, Y) buffer pairs (6 x 102 MB) so the 256 MiB Infinity Cache
     cannot keep X resident between launches: X really comes from HBM every time."""
@@ -377,6 +377,8 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
                            ("grid2d_hilbert", lambda n_, d_, seed: syn.grid2d_graph(447, "hilbert", seed), 8),
                            ("grid2d_rowmajor", lambda n_, d_, seed: syn.grid2d_graph(447, "rowmajor", seed), 8),
                            ("grid2d_shuffled", lambda n_, d_, seed: syn.grid2d_graph(447, "shuffled", seed), 8)):
+        if only is not None and name not in only:
+            continue
         n = 447 * 447 if name.startswith("grid2d") else 200_000      # a 447 x 447 mesh: 199 809 nodes
         ei_np, ew_np = gen(n, deg, seed=0)
         g = ops.DConvGraph(torch.from_numpy(ei_np).to(device), torch.from_numpy(ew_np).to(device), n)
@@ -426,7 +428,8 @@ def spmm_roofline_ns(device, pairs=6, launches=60):
                                 f"spmm_ellw64_kernel<{0 if e.scale is not None else 1}{', EllwCfgC, renumbered' if e.order is not None else ''}> (pgt_spmm_ellw_f32: "
                                 f"{e.n_tiles} tiles of {e.tile_rows} rows x {e.width} slots, halo {e.halo}, "
                                 f"{'per-source scale table' if e.scale is not None else 'per-slot coefficients'}, "
-                                f"{e.far} out-of-window slots)"),
+                                f"{e.far} out-of-window slots)" + (f" + spmm_long_rows_kernel (pgt_spmm_csr_rows_f32: the {e.left_out} rows longer "
+                                f"than {ops.LONG_ROW} slots the layout leaves out, one workgroup each; longest {g.fwd_o.max_len})" if e.left_out else "")),
                      "buffers": f"{pairs} rotating (X,Y) pairs", "launch": f"{launches} launches replayed as one hipGraph, mean of 3 replays"}
         if e is not None and e.order is not None:
             # the library laid the operator out in a numbering of its own (no permutation pass: X / Y rows go through the

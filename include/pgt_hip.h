@@ -51,7 +51,7 @@ extern "C" {
 #define PGT_ERR_LAUNCH (-2)    /* HIP reported an error at launch */
 #define PGT_ERR_WORKSPACE (-3) /* scratch buffer too small */
 
-#define PGT_ABI_VERSION 16
+#define PGT_ABI_VERSION 17
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
@@ -207,7 +207,8 @@ int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, int32_t sou
  * op->far_rows must be the per-slot plan's).  `far_col` (int32 [n_tiles * op->far_rows]) / `far_cnt` (int32 [n_tiles],
  * scratch: the number of distinct outside sources that got a row) receive the out-of-window table; both NULL: no table.  info (int32 [4], device): [0] = slots outside their
  * window, [1] = slots whose val differs bitwise from scale[col] (0 = the source-scale mode applies; otherwise rebuild
- * with scale = NULL and the per-slot plan), [2] = rows longer than `width` (must be 0: their tail is not represented),
+ * with scale = NULL and the per-slot plan), [2] = rows longer than `width`: LEFT OUT of the layout (pgt_spmm_ellw_f32 neither reads
+ * nor writes their rows of Y; the caller either produces exactly those rows with pgt_spmm_csr_rows_f32 — hubs — or drops the layout),
  * [3] = out-of-window slots that did not fit their tile's table (0xFFFF: served through the CSR at run time — correct,
  * slower). */
 int pgt_ellw_build(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t nnz,
@@ -251,6 +252,14 @@ int pgt_spmm_csr_long_f32(const int32_t* rowptr, const int32_t* col, const float
                           const int32_t* long_rows, int64_t n_long, int32_t long_len, const float* X, int64_t ldx,
                           float* Y, int64_t ldy, const float* T, int64_t ldt, float alpha, float beta, int64_t F,
                           pgt_stream_t stream);
+
+/* Only the n_listed rows of Y named in `rows` (int32, device; each row once), under pgt_spmm_csr_f32's contract for those rows: one
+ * 1024-thread workgroup per row, as in pgt_spmm_csr_long_f32 (the same kernel: the same sums).  The second launch of an operator
+ * whose ELLW layout leaves its hub rows out (pgt_ellw_build info[2]): the window kernel for the ordinary rows + this for the hubs.
+ * F / (widest vector the operands allow) must not exceed 64 lanes. */
+int pgt_spmm_csr_rows_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const int32_t* rows,
+                          int64_t n_listed, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* T, int64_t ldt,
+                          float alpha, float beta, int64_t F, pgt_stream_t stream);
 
 /* Same with a per-batch dense attention multiplier (ChebConvAttention hop 1, astgcn.py:157,169-171):
  * rows are node-major [N][B][C]; the coefficient of slot q of row i for batch b is val[q] * S[b, i, col[q]]

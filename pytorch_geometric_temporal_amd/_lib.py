@@ -82,6 +82,8 @@ PROTOTYPES = {
     "pgt_csr_locality": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, ctypes.c_int32, c_ptr]),
     "pgt_spmm_csr_long_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, ctypes.c_int32, c_ptr, c_i64, c_ptr, c_i64,
                                       c_ptr, c_i64, c_f32, c_f32, c_i64, c_ptr]),
+    "pgt_spmm_csr_rows_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64,
+                                      c_ptr, c_i64, c_f32, c_f32, c_i64, c_ptr]),
     "pgt_spmm_csr_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_int, c_ptr]),
     "pgt_sddmm_att_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgt_dconv_stack_slab_fits": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64]),
@@ -188,7 +190,7 @@ PROTOTYPES = {
                                           c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
-EXPECTED_ABI = 16
+EXPECTED_ABI = 17
 
 
 class PgtLib:

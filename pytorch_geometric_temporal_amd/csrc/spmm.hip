@@ -228,6 +228,7 @@ struct EllwCfgA { static constexpr int THREADS = 1024, WRMAX = 456, SLOTS = 392 
 struct EllwCfgB { static constexpr int THREADS = 512, WRMAX = 240, SLOTS = 176 * 16, FAR0 = 48, FAR1 = 12, HMIN = 1; };
 struct EllwCfgC { static constexpr int THREADS = 1024, WRMAX = 400, SLOTS = 400 * 8, FAR0 = 208, FAR1 = 160, HMIN = 0; };
 constexpr int ELLW_WMAX = 32;
+constexpr unsigned ELLW_ROW_LEFT_OUT = 0xfffeu;   // first slot of a row the layout leaves out (longer than its width)
 
 int g_ellw = 1;        // pgt_tune("spmm_ellw"): 0 = pgt_spmm_ellw_f32 runs the CSR kernels instead (A/B)
 int g_ellw_rows = 0;   // pgt_tune("spmm_ellw_rows"): test hook, caps the planned tile height (0 = no cap)
@@ -356,6 +357,10 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   auto do_row = [&](const int r, pgt_f4& tc, const int yr, const int yr_next) {
     pgt_f4 tnext = pgt_mk4(0.f, 0.f, 0.f, 0.f);
     if (T != nullptr && r + G < nr) tnext = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(yr_next * ldt) + l16 * 4);
+    if ((s_slots[r * W8].x & 0xffffu) == ELLW_ROW_LEFT_OUT) {   // a hub: not this launch's row (Y and an aliased T stay untouched)
+      tc = tnext;
+      return;
+    }
     pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
     auto chunk = [&](const int c8) {
       const pgt_u4 s4 = s_slots[r * W8 + c8];
@@ -466,8 +471,11 @@ __global__ __launch_bounds__(256) void ellw_build_kernel(const int32_t* __restri
   float v = 0.f;
   if (row < n_rows) {
     const int a = rowptr[row], len = rowptr[row + 1] - a;
-    if (j == 0 && len > W) atomicAdd(&info[2], 1);
-    if (j < len) {
+    if (len > W) {
+      // a row the layout cannot hold is LEFT OUT: its first slot says so (ELLW_ROW_LEFT_OUT) and the window kernel neither
+      // gathers nor stores it — the caller produces it some other way (a hub: pgt_spmm_csr_rows_f32) or rejects the layout
+      if (j == 0) { atomicAdd(&info[2], 1); d = ELLW_ROW_LEFT_OUT; }
+    } else if (j < len) {
       const int c = col[a + j];
       v = val[a + j];
       if (c >= w0 && c < w0 + WR && c >= 0 && c < n_rows) d = (unsigned)(c - w0);
@@ -1015,6 +1023,28 @@ extern "C" int pgt_spmm_csr_long_f32(const int32_t* rowptr, const int32_t* col, 
   else if (vp.v == 2) PGT_LAUNCH((spmm_long_rows_kernel<2>), grid, block, stream, rowptr, col, val, long_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, (int)F, lpr);
   else PGT_LAUNCH((spmm_long_rows_kernel<1>), grid, block, stream, rowptr, col, val, long_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, (int)F, lpr);
   return pgt_check_launch("pgt_spmm_csr_long_f32");
+}
+
+extern "C" int pgt_spmm_csr_rows_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                     const int32_t* rows, int64_t n_listed, const float* X, int64_t ldx, float* Y,
+                                     int64_t ldy, const float* T, int64_t ldt, float alpha, float beta, int64_t F,
+                                     pgt_stream_t stream) {
+  PGT_REQUIRE(n_rows >= 0 && F >= 0 && n_listed >= 0, "pgt_spmm_csr_rows_f32: negative size");
+  if (n_rows == 0 || F == 0 || n_listed == 0) return PGT_OK;
+  if (int rc = spmm_validate("pgt_spmm_csr_rows_f32", rowptr, n_rows, X, ldx, Y, ldy, T, ldt, F)) return rc;
+  PGT_REQUIRE(rows != nullptr && col != nullptr && val != nullptr, "pgt_spmm_csr_rows_f32: null pointer");
+  PGT_REQUIRE(n_listed < ((int64_t)1 << 31), "pgt_spmm_csr_rows_f32: too many rows");
+  PgtVecPick vp;
+  vp.width(F); vp.operand(X, ldx); vp.operand(Y, ldy); vp.operand(T, ldt);
+  PGT_REQUIRE(F / vp.v <= 64, "pgt_spmm_csr_rows_f32: rows of %lld floats exceed the kernel's 64 lanes x %d floats (node-major batches "
+              "spread a row over many wavefronts already: pgt_spmm_csr_f32)", (long long)F, vp.v);
+  int lpr = 4;
+  while (lpr < F / vp.v) lpr <<= 1;
+  dim3 grid((unsigned)n_listed), block(1024);
+  if (vp.v == 4) PGT_LAUNCH((spmm_long_rows_kernel<4>), grid, block, stream, rowptr, col, val, rows, X, ldx, Y, ldy, T, ldt, alpha, beta, (int)F, lpr);
+  else if (vp.v == 2) PGT_LAUNCH((spmm_long_rows_kernel<2>), grid, block, stream, rowptr, col, val, rows, X, ldx, Y, ldy, T, ldt, alpha, beta, (int)F, lpr);
+  else PGT_LAUNCH((spmm_long_rows_kernel<1>), grid, block, stream, rowptr, col, val, rows, X, ldx, Y, ldy, T, ldt, alpha, beta, (int)F, lpr);
+  return pgt_check_launch("pgt_spmm_csr_rows_f32");
 }
 
 extern "C" int pgt_spmm_csr_att_f32(const int32_t* rowptr, const int32_t* col, const float* val,

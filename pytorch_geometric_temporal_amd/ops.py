@@ -24,7 +24,7 @@ class Csr:
     """CSR operator by destination row.  `halo` is the operator's measured locality: 32 / 96 when at least 95 % of the
     slots have |col - row| within that distance (locality-ordered node numbering), else 0; `max_len` the longest row.
     `ellw` caches the ELLW layout (pgt_ellw) built for the F = 64 LDS-window kernel on first use."""
-    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows", "family")   # ellw: None | Ellw | False
+    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows", "family", "short_len")   # ellw: None | Ellw | False
 
     def __init__(self, n_rows, cap, device):
         self.n_rows = n_rows
@@ -33,6 +33,7 @@ class Csr:
         self.nnz = -1
         self.ellw = None
         self.long_rows = None      # int32 device list of the rows longer than LONG_ROW slots (hubs), or None
+        self.short_len = -1        # the longest row among the others (what an ELLW layout that leaves the hubs out is planned for)
         self.family = None         # dict shared by the operators of one graph (forward / transposed, both directions): what one of
         #                            them learned about a renumbering serves the others (same undirected neighbourhoods)
         self.rowptr = torch.zeros(n_rows + 1, dtype=I32, device=device)
@@ -85,6 +86,13 @@ def measure_locality(csrs):
         c.halo = 32 if 20 * n32 >= 19 * nnz > 0 else (96 if 20 * n96 >= 19 * nnz > 0 else 0)
         c.max_len, c.nnz = max_len, nnz
         c.long_rows = lst[:n_long] if 0 < n_long <= LONG_ROW_CAP else None
+        c.short_len = max_len
+    hubs = [c for c in todo if c.long_rows is not None]
+    if hubs:                             # (graph preparation of an operator with hubs: one more read, for all of them)
+        lens = [c.rowptr[1:c.n_rows + 1] - c.rowptr[:c.n_rows] for c in hubs]
+        short = torch.stack([torch.where(ln <= LONG_ROW, ln, torch.zeros_like(ln)).max() for ln in lens]).tolist()
+        for c, m in zip(hubs, short):
+            c.short_len = int(m)
 
 
 class Ellw:
@@ -95,6 +103,11 @@ class Ellw:
         lib = _lib.get_lib()
         dev = csr.rowptr.device
         self.halo = int(halo)
+        # hubs (rows longer than LONG_ROW slots, listed in csr.long_rows) are left out of the layout: the window kernel skips them
+        # and pgt_spmm_csr_rows_f32 produces them (ops.spmm); the layout is planned for the longest of the OTHER rows
+        lr = getattr(csr, "long_rows", None)
+        self.left_out = 0 if lr is None else int(lr.numel())
+        self.plan_len = int(csr.max_len) if lr is None else int(csr.short_len)
         # first as a source-scaled operator (P_o of DConv); the build verifies that and reports the slots outside
         # their window — if it is not, lay it out again with per-slot coefficients (whose plan leaves fewer far rows)
         mismatch = self._build(lib, csr, dev, True)
@@ -103,7 +116,7 @@ class Ellw:
 
     def _build(self, lib, csr, dev, source_scaled):
         tr, w, cfg, nt, fr = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
-        lib.call("pgt_ellw_plan", csr.n_rows, self.halo, int(csr.max_len), 1 if source_scaled else 0, ctypes.byref(tr),
+        lib.call("pgt_ellw_plan", csr.n_rows, self.halo, self.plan_len, 1 if source_scaled else 0, ctypes.byref(tr),
                  ctypes.byref(w), ctypes.byref(cfg), ctypes.byref(nt), ctypes.byref(fr))
         self.tile_rows, self.width, self.n_tiles, self.config = tr.value, w.value, nt.value, cfg.value
         self.far_rows = fr.value
@@ -121,13 +134,14 @@ class Ellw:
                  stream_of(lib, csr.rowptr))
         # far = slots outside their window, far_csr = those that did not fit the tile's table (served through the CSR)
         self.far, mismatch, overflow, self.far_csr = info.tolist()        # one host sync per new operator
-        if overflow:
-            raise PgtError(f"ELLW: {overflow} row(s) longer than the planned width {self.width}")
+        if overflow != self.left_out:
+            raise PgtError(f"ELLW: {overflow} row(s) longer than the planned width {self.width}, {self.left_out} listed as hubs")
         self.scale, self.vals = scale, vals
         self.far_col = far_col if self.far else None                   # no table: the kernel skips its loads
         return mismatch if source_scaled else 0
 
     order = None      # int32 [n_rows] of a renumbered layout (RenumberedEllw), None: the caller's numbering
+    left_out = 0      # hub rows the layout leaves out (csr.long_rows): ops.spmm produces them with pgt_spmm_csr_rows_f32
     csr = None        # the operator in LAYOUT numbering (RenumberedEllw); None: the caller's own CSR serves the layout
 
     def struct(self):
@@ -187,9 +201,13 @@ def ellw_of(csr):
     e = getattr(csr, "ellw", None)
     if e is False:                     # tried and rejected
         return None
-    if e is None and 0 <= getattr(csr, "max_len", -1) <= 32 and getattr(csr, "nnz", 0) > 0:
+    hubs = getattr(csr, "long_rows", None) is not None
+    plan_len = getattr(csr, "short_len", -1) if hubs else getattr(csr, "max_len", -1)
+    if e is None and 0 <= plan_len <= 32 and getattr(csr, "nnz", 0) > 0:
         if getattr(csr, "halo", 0) > 0:
             e = csr.ellw = Ellw(csr, csr.halo)
+        elif hubs:
+            csr.ellw = False               # (compact-tile and renumbered layouts are not built around hubs)
         elif csr.n_rows >= ELLW_MIN_ROWS:
             cand = Ellw(csr, 32)
             fam = getattr(csr, "family", None)
@@ -644,16 +662,22 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
         if ellw and not getattr(csr, "ellw", None):
             _force_ellw(csr)
         op = ellw_of(csr)
-        if op is not None and op.order is not None and not (
+        if op is not None and (op.order is not None or op.left_out) and not (
                 _window_kernel_covers(X, Y, T) and (csr.n_rows + 456) * max(ldx, ldy, ldt) < 2 ** 31):
-            op = None
+            op = None                  # (the C entry point's own fallback is the CSR row tiles on ALL rows: not for these two)
     work = spmm_algorithmic_bytes(csr.n_rows, csr.col.numel(), X.size(1), T is not None) if KERNEL_TIMER else 0
     if op is not None:
         es = op.struct()
         lay = op.csr or csr
-        _timed("spmm", work, lambda: lib.call(
-            "pgt_spmm_ellw_f32", ctypes.byref(es), ptr(lay.rowptr), ptr(lay.col), ptr(lay.val), csr.n_rows, xp, ldx,
-            yp, ldy, tp, ldt, float(alpha), float(beta), X.size(1), st))
+        hubs = csr.long_rows if op.left_out else None
+
+        def window_then_hubs():
+            lib.call("pgt_spmm_ellw_f32", ctypes.byref(es), ptr(lay.rowptr), ptr(lay.col), ptr(lay.val), csr.n_rows, xp, ldx,
+                     yp, ldy, tp, ldt, float(alpha), float(beta), X.size(1), st)
+            if hubs is not None:       # the rows the layout leaves out: one workgroup each (the window kernel did not touch them)
+                lib.call("pgt_spmm_csr_rows_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.n_rows, ptr(hubs), hubs.numel(),
+                         xp, ldx, yp, ldy, tp, ldt, float(alpha), float(beta), X.size(1), st)
+        _timed("spmm", work, window_then_hubs)
         return Y
     lr = getattr(csr, "long_rows", None)
     if lr is not None:       # hubs: the row tiles skip them, one workgroup per long row produces them
@@ -674,7 +698,8 @@ def _force_ellw(csr, halo=None):
         rp = csr.rowptr[:csr.n_rows + 1]
         csr.nnz = int(rp[csr.n_rows])
         csr.max_len = int((rp[1:] - rp[:-1]).max()) if csr.n_rows else 0
-    if csr.max_len > 32 or csr.nnz <= 0:
+    plan_len = csr.short_len if getattr(csr, "long_rows", None) is not None else csr.max_len     # hubs are left out of the layout
+    if plan_len > 32 or csr.nnz <= 0:
         return None
     csr.ellw = Ellw(csr, halo or csr.halo or 32)
     return csr.ellw

@@ -38,7 +38,9 @@ class CsrStruct(ctypes.Structure):
 class EllwStruct(ctypes.Structure):
     _fields_ = [("slots", c_ptr), ("vals", c_ptr), ("scale", c_ptr), ("tile_rows", ctypes.c_int32),
                 ("halo", ctypes.c_int32), ("width", ctypes.c_int32), ("config", ctypes.c_int32), ("n_tiles", c_i64),
-                ("far_col", c_ptr), ("far_rows", ctypes.c_int32), ("order", c_ptr)]
+                ("far_col", c_ptr), ("far_rows", ctypes.c_int32), ("order", c_ptr),
+                ("hub_col", c_ptr), ("hub_val", c_ptr), ("hub_rows", c_ptr), ("hub_partial", c_ptr),
+                ("n_hub", ctypes.c_int32), ("hub_split", ctypes.c_int32)]
 
 
 class DConvGraphStruct(ctypes.Structure):

@@ -239,12 +239,26 @@ int g_ellw_cfg = 0;    // pgt_tune("spmm_ellw_cfg"): launch shape pgt_ellw_plan 
 // PERM: the layout lives in a renumbered row space — layout row p is row order[p] of X / Y / T (slots, scale, far_col,
 // rowptr / col are all in layout numbering); every X row is still one coalesced 256-byte read and every Y row one
 // 256-byte streaming store, just not at consecutive addresses
-template <int MODE, class CFG, int W8C, bool PERM = false>
+// HUB: the operator has a few rows of thousands of slots (hubs) that the layout leaves out (ELLW_ROW_LEFT_OUT).  Their slots
+// are cut into pieces of at most 2 G = 128 (64) (source, coefficient) pairs, piece t rides with tile t: the pairs are addressable
+// from blockIdx like the table of outside rows, their X rows are requested behind them in the shadow of the window loads, every
+// lane group multiplies its one or two rows, the four groups of a wavefront add up through the lanes and each wavefront leaves ONE
+// partial row in the workspace; ellw_hub_combine_kernel (a second, tiny launch) adds a hub's partial rows in a fixed order.  A hub
+// on a workgroup of its own is a chain of ten dependent round trips (10.7 us per launch); here the chain hides in a memory phase
+// that is waited for anyway.
+struct EllwHub {
+  const int32_t* col;    // [pieces * 2 G] source row, -1 = unused entry
+  const float* val;      // [pieces * 2 G]
+  float* partial;        // [pieces * (THREADS / 64) * 64]
+  int pieces;            // tiles [0, pieces) carry one piece each
+};
+
+template <int MODE, class CFG, int W8C, bool PERM = false, bool HUB = false>
 __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     const uint16_t* __restrict__ slots, const float* __restrict__ vals, const float* __restrict__ scale,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
     int TR, int H, int W, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt, float alpha,
-    float beta, int flags, const int32_t* __restrict__ far_col, const int32_t* __restrict__ order) {
+    float beta, int flags, const int32_t* __restrict__ far_col, const int32_t* __restrict__ order, EllwHub hub) {
   constexpr int THREADS = CFG::THREADS, WRMAX = CFG::WRMAX, SLOTS = CFG::SLOTS;
   constexpr int FARMAX = MODE == 0 ? CFG::FAR0 : CFG::FAR1;   // LDS rows behind the zero row for out-of-window sources
   constexpr int G = THREADS / 16;                      // row groups of 16 lanes: one 256-byte row each
@@ -277,6 +291,20 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   for (int i = 0; i < FPT; ++i) {
     const int k = rg + G * i;
     fc[i] = (far_col != nullptr && k < FARMAX) ? far_col[(size_t)tile * FARMAX + k] : -1;
+  }
+  constexpr int HU = 2;                                // hub pairs per lane group
+  int hc[HUB ? HU : 1];
+  float hv[HUB ? HU : 1];
+  const bool hub_tile = HUB && tile < hub.pieces;
+  if constexpr (HUB) {
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      hc[u] = -1; hv[u] = 0.f;
+      if (hub_tile) {
+        const size_t e = (size_t)tile * (G * HU) + rg + G * u;
+        hc[u] = hub.col[e]; hv[u] = hub.val[e];
+      }
+    }
   }
   pgt_f4 xw[XPT];
   float sc[XPT];
@@ -324,6 +352,14 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
       if constexpr (MODE == 0) sfar[i] = scale[fc[i]];
     }
   }
+  pgt_f4 xh[HUB ? HU : 1];
+  if constexpr (HUB) {
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      xh[u] = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+      if (hc[u] >= 0) xh[u] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(hc[u] * ldx));
+    }
+  }
   pgt_f4 tcur = pgt_mk4(0.f, 0.f, 0.f, 0.f);
   if (T != nullptr && rg < nr) tcur = *reinterpret_cast<const pgt_f4*>(T + (unsigned)((PERM ? yrow[0] : r0 + rg) * ldt) + l16 * 4);
   // ---- window -> LDS.  MODE 0: scaled on the way in (the product is rounded once, like norm * x_j in the reference)
@@ -351,6 +387,19 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   if constexpr (MODE == 1) {
 #pragma unroll
     for (int i = 0; i < 2 * NSV; ++i) { const int v = tid + THREADS * i; if (v < 2 * nvec) s_vals[v] = va[i]; }
+  }
+  if constexpr (HUB) {
+    if (hub_tile) {                                      // (uniform)
+      pgt_f4 hacc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < HU; ++u)                       // select, not multiply-by-zero: an unused entry must not inject NaN
+        if (hc[u] >= 0) hacc = pgt_mk4(fmaf(hv[u], xh[u].x, hacc.x), fmaf(hv[u], xh[u].y, hacc.y), fmaf(hv[u], xh[u].z, hacc.z), fmaf(hv[u], xh[u].w, hacc.w));
+#pragma unroll
+      for (int m = 16; m < 64; m <<= 1)                  // the four lane groups of the wavefront: (g0 + g1) + (g2 + g3)
+        hacc = pgt_mk4(hacc.x + __shfl_xor(hacc.x, m), hacc.y + __shfl_xor(hacc.y, m), hacc.z + __shfl_xor(hacc.z, m), hacc.w + __shfl_xor(hacc.w, m));
+      if ((tid & 63) < 16)
+        *reinterpret_cast<pgt_f4*>(hub.partial + ((size_t)tile * (THREADS / 64) + (tid >> 6)) * 64 + l16 * 4) = hacc;
+    }
   }
   __syncthreads();
   // ---- gather out of the window: rows rg, rg + G, ... ; sequential chain in slot order
@@ -442,6 +491,49 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     }
   } else {
     for (int r = rg; r < nr; r += G) do_row(r, tcur, r0 + r, r0 + r + G);
+  }
+}
+
+// Y[hub row] from the partial rows its pieces left (spmm_ellw64_kernel<..., HUB>): one workgroup per hub, 64 lane groups take
+// the partial rows round-robin in rising order (eight loads in flight each: a loop of one load and one add per trip was 25
+// dependent round trips = 8 us), the group sums meet in LDS in group order — a fixed order: deterministic.
+__global__ __launch_bounds__(1024) void ellw_hub_combine_kernel(const int32_t* __restrict__ hub_rows, int rows_per_hub,
+                                                                const float* __restrict__ partial, float* Y, int ldy,
+                                                                const float* T, int ldt, float alpha, float beta) {
+  __shared__ pgt_f4 s_sum[64 * 16];
+  const int tid = threadIdx.x, l16 = tid & 15, g = tid >> 4;
+  const int hub = (int)blockIdx.x;
+  const int row = hub_rows[hub];
+  const float* p = partial + (size_t)hub * rows_per_hub * 64 + l16 * 4;
+  pgt_f4 acc = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+  constexpr int U = 8;
+  for (int r0 = g; r0 < rows_per_hub; r0 += 64 * U) {
+    pgt_f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + 64 * u;
+      v[u] = *reinterpret_cast<const pgt_f4*>(p + (size_t)(r < rows_per_hub ? r : r0) * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (r0 + 64 * u < rows_per_hub) acc = pgt_mk4(acc.x + v[u].x, acc.y + v[u].y, acc.z + v[u].z, acc.w + v[u].w);
+  }
+  s_sum[g * 16 + l16] = acc;
+  __syncthreads();
+  if (g == 0) {
+    pgt_f4 tt = pgt_mk4(0.f, 0.f, 0.f, 0.f);
+    if (T != nullptr) tt = *reinterpret_cast<const pgt_f4*>(T + (unsigned)(row * ldt) + l16 * 4);
+    pgt_f4 out = s_sum[l16];
+#pragma unroll 8
+    for (int gg = 1; gg < 64; ++gg) {
+      const pgt_f4 v = s_sum[gg * 16 + l16];
+      out = pgt_mk4(out.x + v.x, out.y + v.y, out.z + v.z, out.w + v.w);
+    }
+    float o[4] = {alpha * out.x, alpha * out.y, alpha * out.z, alpha * out.w};
+    if (T != nullptr) {
+      o[0] = alpha * out.x + beta * tt.x; o[1] = alpha * out.y + beta * tt.y; o[2] = alpha * out.z + beta * tt.z; o[3] = alpha * out.w + beta * tt.w;
+    }
+    stv<4>(Y + (unsigned)(row * ldy) + l16 * 4, o);
   }
 }
 
@@ -890,6 +982,11 @@ static int ellw_check(const char* who, const pgt_ellw* op, int64_t n_rows) {
               (long long)op->n_tiles, (long long)n_rows);
   PGT_REQUIRE(op->n_tiles < ((int64_t)1 << 31) && op->n_tiles * op->tile_rows * op->width < ((int64_t)1 << 40),
               "%s: operator too large", who);
+  PGT_REQUIRE(op->hub_col == nullptr ||
+                  (op->hub_val != nullptr && op->hub_rows != nullptr && op->hub_partial != nullptr && op->n_hub >= 1 &&
+                   op->hub_split >= 1 && (int64_t)op->n_hub * op->hub_split <= op->n_tiles && op->order == nullptr && op->config != 3),
+              "%s: hub tables need hub_val, hub_rows, hub_partial, n_hub >= 1 and n_hub * hub_split <= n_tiles on a layout in the "
+              "caller's numbering", who);
   PGT_REQUIRE(op->far_col == nullptr || op->far_rows == ellw_far_rows(op->config, op->scale != nullptr),
               "%s: far_rows %d does not match the kernel's table for this config / mode (see pgt_ellw_plan)", who,
               (int)op->far_rows);
@@ -961,10 +1058,18 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
     return pgt_spmm_csr_f32(rowptr, col, val, n_rows, X, ldx, Y, ldy, T, ldt, alpha, beta, F, stream);
   const int flags = (g_tile_xcd ? 1 : 0) | (g_tile_nt ? 2 : 0);
   dim3 grid((unsigned)op->n_tiles, (unsigned)(F / 64));   // y: 64-float column chunks (1 for the F = 64 north-star shape)
-#define PGT_ELLW_GO(MODE_, CFG_, W8C_)                                                                                \
-  PGT_LAUNCH((spmm_ellw64_kernel<MODE_, CFG_, W8C_, std::is_same<CFG_, EllwCfgC>::value>), grid, dim3(CFG_::THREADS), stream, \
+  // the hubs' pieces ride with the tiles at F = 64 (one column chunk); otherwise the caller produces the hub rows (pgt_spmm_csr_rows_f32)
+  const bool fold = op->hub_col != nullptr && F == 64;
+  EllwHub hub = {op->hub_col, op->hub_val, op->hub_partial, fold ? (int)(op->n_hub * op->hub_split) : 0};
+#define PGT_ELLW_GO_(MODE_, CFG_, W8C_, HUB_)                                                                         \
+  PGT_LAUNCH((spmm_ellw64_kernel<MODE_, CFG_, W8C_, std::is_same<CFG_, EllwCfgC>::value, HUB_>), grid, dim3(CFG_::THREADS), stream, \
              op->slots, op->vals, op->scale, rowptr, col, val, (int)n_rows, (int)op->tile_rows, (int)op->halo,            \
-             (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha, beta, flags, op->far_col, op->order)
+             (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha, beta, flags, op->far_col, op->order, hub)
+#define PGT_ELLW_GO(MODE_, CFG_, W8C_)                                                   \
+  do {                                                                                   \
+    if (fold) PGT_ELLW_GO_(MODE_, CFG_, W8C_, (!std::is_same<CFG_, EllwCfgC>::value));    \
+    else PGT_ELLW_GO_(MODE_, CFG_, W8C_, false);                                         \
+  } while (0)
 #define PGT_ELLW_W(MODE_, CFG_)                                  \
   do {                                                           \
     if (op->width == 8) PGT_ELLW_GO(MODE_, CFG_, 1);             \
@@ -978,6 +1083,13 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
   }
 #undef PGT_ELLW_W
 #undef PGT_ELLW_GO
+#undef PGT_ELLW_GO_
+  if (fold) {
+    if (int rc = pgt_check_launch("pgt_spmm_ellw_f32")) return rc;
+    const int waves = (op->config == 2 ? EllwCfgB::THREADS : EllwCfgA::THREADS) / 64;
+    PGT_LAUNCH(ellw_hub_combine_kernel, dim3((unsigned)op->n_hub), dim3(1024), stream, op->hub_rows, (int)op->hub_split * waves,
+               (const float*)op->hub_partial, Y, (int)ldy, T, (int)ldt, alpha, beta);
+  }
   return pgt_check_launch("pgt_spmm_ellw_f32");
 }
 

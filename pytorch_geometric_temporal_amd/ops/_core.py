@@ -136,7 +136,7 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
     if op is not None:
         es = op.struct()
         lay = op.csr or csr
-        hubs = csr.long_rows if op.left_out else None
+        hubs = csr.long_rows if op.left_out and not (op.hub_col is not None and X.size(1) == 64) else None    # (folded at F = 64)
 
         def window_then_hubs():
             lib.call("pgt_spmm_ellw_f32", ctypes.byref(es), ptr(lay.rowptr), ptr(lay.col), ptr(lay.val), csr.n_rows, xp, ldx,

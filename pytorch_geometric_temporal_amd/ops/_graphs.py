@@ -49,6 +49,9 @@ ELLW_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; 
 # layout at F = 64: 21 us against 33 us for the CSR row tiles at N = 200 000, in-degree 8.
 # PGT_ELLW=0 keeps every operator on the CSR kernels (A/B).
 USE_ELLW = os.environ.get("PGT_ELLW", "1") != "0"
+# hubs of an ELLW operator: their slots ride with the tiles of the window kernel (pgt_ellw.hub_*) instead of a workgroup per hub
+# behind it (pgt_spmm_csr_rows_f32).  PGT_HUB_FOLD=0: the second form (A/B)
+USE_HUB_FOLD = os.environ.get("PGT_HUB_FOLD", "1") != "0"
 
 
 def measure_locality(csrs):
@@ -99,6 +102,35 @@ class Ellw:
         mismatch = self._build(lib, csr, dev, True)
         if mismatch:
             self._build(lib, csr, dev, False)
+        if self.left_out and USE_HUB_FOLD:
+            self._hub_tables(csr, dev)
+
+    def _hub_tables(self, csr, dev):
+        """The hubs' slots cut into pieces that ride with the tiles (pgt_ellw.hub_*): piece s of hub h = its slots
+        [s C_h, (s + 1) C_h), C_h = ceil(len_h / split), at most P = 2 lane groups' worth per tile.  Graph preparation: torch
+        indexing, one host read (the hubs' lengths)."""
+        hubs = csr.long_rows
+        n_hub = int(hubs.numel())
+        split = int(self.n_tiles // n_hub)
+        lanes, waves = (64, 16) if self.config == 1 else (32, 8)
+        P = 2 * lanes
+        if split < 1:
+            return
+        a = csr.rowptr[hubs.long()].long()
+        lens = csr.rowptr[hubs.long() + 1].long() - a
+        C = (lens + split - 1) // split
+        if int(C.max()) > P:                                   # (a hub too long for its pieces: pgt_spmm_csr_rows_f32 keeps it)
+            return
+        j = torch.arange(P, device=dev).view(1, 1, P)
+        s_ = torch.arange(split, device=dev).view(1, split, 1)
+        off = s_ * C.view(-1, 1, 1) + j
+        live = (j < C.view(-1, 1, 1)) & (off < lens.view(-1, 1, 1))
+        q = (a.view(-1, 1, 1) + off).clamp_(max=max(int(csr.nnz) - 1, 0))
+        self.hub_col = torch.where(live, csr.col[q], torch.full_like(csr.col[q], -1)).contiguous().view(-1)
+        self.hub_val = torch.where(live, csr.val[q], torch.zeros_like(csr.val[q])).contiguous().view(-1)
+        self.hub_rows = hubs.contiguous()
+        self.hub_partial = torch.empty(n_hub * split * waves * 64, dtype=F32, device=dev)
+        self.hub_split = split
 
     def _build(self, lib, csr, dev, source_scaled):
         tr, w, cfg, nt, fr = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
@@ -127,12 +159,16 @@ class Ellw:
         return mismatch if source_scaled else 0
 
     order = None      # int32 [n_rows] of a renumbered layout (RenumberedEllw), None: the caller's numbering
-    left_out = 0      # hub rows the layout leaves out (csr.long_rows): ops.spmm produces them with pgt_spmm_csr_rows_f32
+    left_out = 0      # hub rows the layout leaves out (csr.long_rows): ops.spmm produces them with pgt_spmm_csr_rows_f32 ...
+    hub_col = hub_val = hub_rows = hub_partial = None       # ... unless their pieces ride with the tiles (F = 64: _hub_tables)
+    hub_split = 0
     csr = None        # the operator in LAYOUT numbering (RenumberedEllw); None: the caller's own CSR serves the layout
 
     def struct(self):
         return EllwStruct(ptr(self.slots), ptr(self.vals), ptr(self.scale), self.tile_rows, self.halo, self.width,
-                          self.config, self.n_tiles, ptr(self.far_col), self.far_rows, ptr(self.order))
+                          self.config, self.n_tiles, ptr(self.far_col), self.far_rows, ptr(self.order),
+                          ptr(self.hub_col), ptr(self.hub_val), ptr(self.hub_rows), ptr(self.hub_partial),
+                          0 if self.hub_col is None else int(self.hub_rows.numel()), self.hub_split)
 
 
 class _LayoutCsr:

@@ -2026,11 +2026,14 @@ def test_long_rows_are_listed_at_graph_preparation(backend):
     assert_close_with_nonfinite(Y, spmm_reference(g.fwd_o, X, None, 1.0, 0.0), 5e-5, 1e-5, "hub graph")
 
 
-def test_spmm_ellw_leaves_hub_rows_to_the_long_row_kernel(backend):
+@pytest.mark.parametrize("fold", [True, False])
+def test_spmm_ellw_leaves_hub_rows_out_of_the_layout(backend, fold):
     """A locality-ordered operator with a few hubs (rows of hundreds of slots) keeps the ELLW window kernel for its ordinary rows:
-    the layout is planned for the longest ORDINARY row, leaves the hubs out (first slot = 0xFFFE: the kernel neither gathers nor
-    stores them) and pgt_spmm_csr_rows_f32 produces exactly those rows — ordinary rows bit for bit the reference's roundings, hub
-    rows bit for bit the long-row kernel's, with the epilogue and an aliased T (the window kernel must not touch a hub's T row)."""
+    the layout is planned for the longest ORDINARY row and leaves the hubs out (first slot = 0xFFFE: the kernel neither gathers nor
+    stores them).  fold: the hubs' slots ride with the tiles as pieces (pgt_ellw.hub_*: one partial row per wavefront, a combine
+    launch adds them in a fixed order) at F = 64; otherwise — and at other widths — pgt_spmm_csr_rows_f32 produces exactly those rows
+    behind the window kernel.  Ordinary rows bit for bit the reference's roundings, hub rows against fp64 and reproducible, with the
+    epilogue and an aliased T (the window kernel must not touch a hub's T row)."""
     n = 5000
     ei, ew = syn.local_graph(n, 4, window=64, seed=0)
     rng = np.random.default_rng(1)
@@ -2039,30 +2042,46 @@ def test_spmm_ellw_leaves_hub_rows_to_the_long_row_kernel(backend):
     e2 = np.concatenate([ei, np.stack([src, np.repeat(hubs, 400)])], axis=1)
     w2 = np.concatenate([ew, (0.5 + rng.random(src.size)).astype(np.float32)])
     key = np.unique(e2[0].astype(np.int64) * n + e2[1], return_index=True)[1]
-    g = ops.DConvGraph(backend.t(e2[:, key]), backend.t(w2[key]), n)
-    csr = g.fwd_o
-    assert csr.long_rows is not None and csr.max_len >= 400 and 4 <= csr.short_len <= 8 and csr.halo == 32
-    e = ops.ellw_of(csr)
-    assert e is not None and e.left_out == 2 and e.width == 8 and e.scale is not None        # P_o: source-scaled
-    gen = torch.Generator().manual_seed(5)
-    X, T = torch.randn(n, 64, generator=gen).to(backend.device), torch.randn(n, 64, generator=gen).to(backend.device)
-    Y = torch.full((n, 64), float("nan"), device=backend.device)
-    ops.spmm(csr, X, Y)
-    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "window kernel + hubs")
-    ordinary = torch.ones(n, dtype=torch.bool)
-    ordinary[torch.from_numpy(hubs)] = False
-    assert torch.equal(Y.cpu()[ordinary], source_scaled_reference(csr, X)[ordinary])
-    Yc = torch.empty_like(Y)
-    ops.spmm(csr, X, Yc, ellw=False)                                       # CSR row tiles + the same long-row kernel
-    assert torch.equal(Y.cpu()[~ordinary], Yc.cpu()[~ordinary])
-    ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0)
-    assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "epilogue")
-    Tc = T.clone()
-    ops.spmm(csr, X, Tc, T=Tc, alpha=2.0, beta=1.0)
-    assert_close_with_nonfinite(Tc, spmm_reference(csr, X, T, 2.0, 1.0), 5e-5, 1e-5, "aliased T")
-    # the transposed operator has hub COLUMNS, no hub rows: an ordinary layout (or none), nothing left out
-    et = ops.ellw_of(g.bwd_o)
-    assert g.bwd_o.long_rows is None and (et is None or et.left_out == 0)
+    old = ops.USE_HUB_FOLD
+    ops.USE_HUB_FOLD = fold
+    try:
+        g = ops.DConvGraph(backend.t(e2[:, key]), backend.t(w2[key]), n)
+        csr = g.fwd_o
+        assert csr.long_rows is not None and csr.max_len >= 400 and 4 <= csr.short_len <= 8 and csr.halo == 32
+        e = ops.ellw_of(csr)
+        assert e is not None and e.left_out == 2 and e.width == 8 and e.scale is not None        # P_o: source-scaled
+        assert (e.hub_col is not None) == fold and (not fold or e.hub_split * 2 <= e.n_tiles)
+        gen = torch.Generator().manual_seed(5)
+        X, T = torch.randn(n, 64, generator=gen).to(backend.device), torch.randn(n, 64, generator=gen).to(backend.device)
+        X[3, 5] = float("inf")                                   # (row 0 is what an unused piece entry reads; row 3 a real source)
+        Y = torch.full((n, 64), float("nan"), device=backend.device)
+        ops.spmm(csr, X, Y)
+        assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "window kernel + hubs")
+        ordinary = torch.ones(n, dtype=torch.bool)
+        ordinary[torch.from_numpy(hubs)] = False
+        assert torch.equal(Y.cpu()[ordinary].nan_to_num(7.0, 8.0, 9.0), source_scaled_reference(csr, X)[ordinary].nan_to_num(7.0, 8.0, 9.0))
+        Y2 = torch.full_like(Y, float("nan"))
+        ops.spmm(csr, X, Y2)
+        assert torch.equal(Y.nan_to_num(7.0, 8.0, 9.0), Y2.nan_to_num(7.0, 8.0, 9.0))           # a fixed order of adds: reproducible
+        if not fold:
+            Yc = torch.empty_like(Y)
+            ops.spmm(csr, X, Yc, ellw=False)                                   # CSR row tiles + the same long-row kernel
+            assert torch.equal(Y.cpu()[~ordinary].nan_to_num(7.0, 8.0, 9.0), Yc.cpu()[~ordinary].nan_to_num(7.0, 8.0, 9.0))
+        ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0)
+        assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "epilogue")
+        Tc = T.clone()
+        ops.spmm(csr, X, Tc, T=Tc, alpha=2.0, beta=1.0)
+        assert_close_with_nonfinite(Tc, spmm_reference(csr, X, T, 2.0, 1.0), 5e-5, 1e-5, "aliased T")
+        # two column chunks: the pieces are for F = 64, the hub rows come from pgt_spmm_csr_rows_f32
+        Xw = torch.randn(n, 128, generator=gen).to(backend.device)
+        Yw = torch.full((n, 128), float("nan"), device=backend.device)
+        ops.spmm(csr, Xw, Yw)
+        assert_close_with_nonfinite(Yw, spmm_reference(csr, Xw, None, 1.0, 0.0), 5e-5, 1e-5, "F = 128")
+        # the transposed operator has hub COLUMNS, no hub rows: an ordinary layout (or none), nothing left out
+        et = ops.ellw_of(g.bwd_o)
+        assert g.bwd_o.long_rows is None and (et is None or et.left_out == 0)
+    finally:
+        ops.USE_HUB_FOLD = old
     # a row between the layout's 32 slots and the long-row threshold: neither fits — the operator stays on the CSR kernels
     mid = banded_csr(n, 0, 6, 30, seed=6, device=backend.device, heavy_row=40)
     mid.long_rows, mid.short_len = None, -1

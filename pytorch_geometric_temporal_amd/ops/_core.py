@@ -132,6 +132,8 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
         if op is not None and (op.order is not None or op.left_out) and not (
                 _window_kernel_covers(X, Y, T) and (csr.n_rows + 456) * max(ldx, ldy, ldt) < 2 ** 31):
             op = None                  # (the C entry point's own fallback is the CSR row tiles on ALL rows: not for these two)
+        if op is not None and op.left_out and X.size(1) > 256:
+            op = None                  # (node-major batches: the hub kernel covers 64 lanes x 4 floats; the wide CSR kernel spreads a row anyway)
     work = spmm_algorithmic_bytes(csr.n_rows, csr.col.numel(), X.size(1), T is not None) if KERNEL_TIMER else 0
     if op is not None:
         es = op.struct()

@@ -2077,6 +2077,10 @@ def test_spmm_ellw_leaves_hub_rows_out_of_the_layout(backend, fold):
         Yw = torch.full((n, 128), float("nan"), device=backend.device)
         ops.spmm(csr, Xw, Yw)
         assert_close_with_nonfinite(Yw, spmm_reference(csr, Xw, None, 1.0, 0.0), 5e-5, 1e-5, "F = 128")
+        Xw = torch.randn(n, 320, generator=gen).to(backend.device)             # wider than the hub kernel: the CSR kernels take it
+        Yw = torch.full((n, 320), float("nan"), device=backend.device)
+        ops.spmm(csr, Xw, Yw)
+        assert_close_with_nonfinite(Yw, spmm_reference(csr, Xw, None, 1.0, 0.0), 5e-5, 1e-5, "F = 320")
         # the transposed operator has hub COLUMNS, no hub rows: an ordinary layout (or none), nothing left out
         et = ops.ellw_of(g.bwd_o)
         assert g.bwd_o.long_rows is None and (et is None or et.left_out == 0)

@@ -37,9 +37,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 
 N_NODES, N_EDGES, SEQ = 207, 1515, 12
 PROPAGATES_PER_CELL = 12     # the reference's op count per DCRNN cell step: 6 (K - 1) propagate calls at K = 3
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r06e_pmc_traffic.json", "r06d_pmc_traffic.json", "r05w_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r06h_pmc_traffic.json", "r06e_pmc_traffic.json", "r06d_pmc_traffic.json", "r05w_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
                                                           "r02_pmc_traffic.json")]
-PMC_FILES_TGCN = [os.path.join(ROOT, "profiles", f) for f in ("r05w_tgcn50k_pmc_traffic.json", "r05_tgcn50k_pmc_traffic.json", "r04_tgcn50k_pmc_traffic.json")]
+PMC_FILES_TGCN = [os.path.join(ROOT, "profiles", f) for f in ("r06h_tgcn50k_pmc_traffic.json", "r05w_tgcn50k_pmc_traffic.json", "r05_tgcn50k_pmc_traffic.json", "r04_tgcn50k_pmc_traffic.json")]
 
 
 _T0 = time.time()

@@ -1614,6 +1614,58 @@ def test_gemm_persistent_deferred_store_schedule(backend, M, segs, segk, N):
 
 
 @pytest.mark.gpu
+def test_aggregation_with_hubs_at_north_star_size():
+    """The bench line's skewed graph (the band graph of the north-star shape + 20 rows of 2 000 more slots) on the product library:
+    the window kernel keeps the 199 980 ordinary rows (bit for bit the reference's roundings), the hubs' slots ride with its tiles
+    in 25 pieces per row and the combine launch adds them in a fixed order (against fp64, reproducible); the same rows from a
+    workgroup per hub behind the window kernel (PGT_HUB_FOLD=0's form) and from the CSR kernels agree to rounding."""
+    lib = _lib.get_lib()
+    if lib.target != "gfx950":
+        pytest.skip("product library only")
+    dev = torch.device("cuda:0")
+    n, F_ = 200_000, 64
+    ei, ew = syn.hub_graph(n, 8, seed=0)
+    gen = torch.Generator(device="cpu").manual_seed(12)
+    X, T = torch.randn(n, F_, generator=gen).to(dev), torch.randn(n, F_, generator=gen).to(dev)
+    outs = {}
+    for fold in (True, False):
+        old = ops.USE_HUB_FOLD
+        ops.USE_HUB_FOLD = fold
+        try:
+            G = ops.DConvGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(ew).to(dev), n)
+            csr = G.fwd_o
+            Y = torch.full((n, F_), float("nan"), device=dev)
+            ops.spmm(csr, X, Y)
+            e = csr.ellw
+            assert e and e.left_out == 20 and (e.tile_rows, e.width, e.config) == (392, 8, 1) and e.scale is not None
+            assert (e.hub_col is not None) == fold and (not fold or e.hub_split == 25)
+            Y2 = torch.full_like(Y, float("nan"))
+            ops.spmm(csr, X, Y2)
+            assert torch.equal(Y, Y2)
+            Z = torch.full_like(Y, float("nan"))
+            ops.spmm(csr, X, Z, T=T, alpha=2.0, beta=-1.0)
+            outs[fold] = (Y, Z)
+        finally:
+            ops.USE_HUB_FOLD = old
+    nnz = int(csr.rowptr[-1])
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (csr.rowptr[1:] - csr.rowptr[:-1]).long())
+    ref = torch.zeros(n, F_, dtype=torch.float64, device=dev).index_add_(0, rows, X.double()[csr.col[:nnz].long()] * csr.val[:nnz].double()[:, None])
+    hubs = csr.long_rows.long()
+    ordinary = torch.ones(n, dtype=torch.bool, device=dev)
+    ordinary[hubs] = False
+    for fold, (Y, Z) in outs.items():
+        assert_close_with_nonfinite(Y, ref.cpu(), 2e-5, 1e-5, f"fold={fold}: aggregation vs fp64")
+        assert_close_with_nonfinite(Z, (2.0 * ref - T.double()).cpu(), 4e-5, 1e-5, f"fold={fold}: Chebyshev epilogue")
+    assert torch.equal(outs[True][0][ordinary], outs[False][0][ordinary])                    # the same window kernel rows
+    assert torch.equal(outs[True][0][ordinary].cpu(), source_scaled_reference(csr, X)[ordinary.cpu()])
+    assert torch.allclose(outs[True][0][hubs], outs[False][0][hubs], atol=2e-5, rtol=1e-5)  # two orders of 2 000 adds
+    Yc = torch.full((n, F_), float("nan"), device=dev)
+    ops.spmm(csr, X, Yc, ellw=False)                                                         # CSR row tiles + a workgroup per hub
+    assert torch.equal(Yc[hubs], outs[False][0][hubs])                                       # (the same hub kernel)
+    assert_close_with_nonfinite(Yc, outs[True][0].cpu(), 2e-5, 1e-5, "CSR kernels vs window kernel + hubs")
+
+
+@pytest.mark.gpu
 def test_aggregation_at_north_star_size():
     """BASELINE.json's north-star shape (N = 200 000 nodes, F = 64, in-degree 8; 1.6 M edges) on the product library:
     the shipped kernel (ELLW layout, source-scale mode: P_o = A D_out^-1) against an fp64 gather / index_add of the same

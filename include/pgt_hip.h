@@ -201,6 +201,9 @@ typedef struct pgt_ellw {
   float* hub_partial;      /* [n_hub * hub_split * (threads / 64) * 64] workspace written by every launch: launches that share a
                               layout must be ordered (one stream / one hipGraph) */
   int32_t n_hub, hub_split; /* n_hub * hub_split <= n_tiles */
+  const int32_t* far_src; /* [n_tiles * far_rows] or NULL; a renumbered layout only: far_src[e] = order[far_col[e]] (-1 where
+                             far_col is) — the outside rows' X rows by the CALLER's numbering, so that the kernel reaches them in
+                             two dependent loads like its window rows instead of three (far_col -> order -> X) */
 } pgt_ellw;
 
 /* Host-only: tile height / slot width / tile count for an operator with `n_rows` rows whose longest row has

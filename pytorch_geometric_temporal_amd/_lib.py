@@ -40,7 +40,7 @@ class EllwStruct(ctypes.Structure):
                 ("halo", ctypes.c_int32), ("width", ctypes.c_int32), ("config", ctypes.c_int32), ("n_tiles", c_i64),
                 ("far_col", c_ptr), ("far_rows", ctypes.c_int32), ("order", c_ptr),
                 ("hub_col", c_ptr), ("hub_val", c_ptr), ("hub_rows", c_ptr), ("hub_partial", c_ptr),
-                ("n_hub", ctypes.c_int32), ("hub_split", ctypes.c_int32)]
+                ("n_hub", ctypes.c_int32), ("hub_split", ctypes.c_int32), ("far_src", c_ptr)]
 
 
 class DConvGraphStruct(ctypes.Structure):

@@ -258,7 +258,8 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     const uint16_t* __restrict__ slots, const float* __restrict__ vals, const float* __restrict__ scale,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int n_rows,
     int TR, int H, int W, const float* __restrict__ X, int ldx, float* Y, int ldy, const float* T, int ldt, float alpha,
-    float beta, int flags, const int32_t* __restrict__ far_col, const int32_t* __restrict__ order, EllwHub hub) {
+    float beta, int flags, const int32_t* __restrict__ far_col, const int32_t* __restrict__ order, EllwHub hub,
+    const int32_t* __restrict__ far_src) {
   constexpr int THREADS = CFG::THREADS, WRMAX = CFG::WRMAX, SLOTS = CFG::SLOTS;
   constexpr int FARMAX = MODE == 0 ? CFG::FAR0 : CFG::FAR1;   // LDS rows behind the zero row for out-of-window sources
   constexpr int G = THREADS / 16;                      // row groups of 16 lanes: one 256-byte row each
@@ -287,10 +288,12 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   // nothing younger) and the far rows ride in the shadow of the window loads.
   constexpr int FPT = (FARMAX + G - 1) / G;            // far rows per lane group
   int fc[FPT];
+  int fx[PERM ? FPT : 1];                              // PERM: the outside rows' X rows (the caller's numbering), straight from the layout
 #pragma unroll
   for (int i = 0; i < FPT; ++i) {
     const int k = rg + G * i;
     fc[i] = (far_col != nullptr && k < FARMAX) ? far_col[(size_t)tile * FARMAX + k] : -1;
+    if constexpr (PERM) fx[i] = (far_src != nullptr && k < FARMAX) ? far_src[(size_t)tile * FARMAX + k] : -1;
   }
   constexpr int HU = 2;                                // hub pairs per lane group
   int hc[HUB ? HU : 1];
@@ -347,7 +350,8 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
     sfar[i] = 1.f;
     if (fc[i] >= 0 && fc[i] < n_rows) {
       int fr = fc[i];
-      if constexpr (PERM) fr = order[fr];
+      // (far_col -> order -> X row is a chain of three round trips where the window's own is two: with far_src it is two as well)
+      if constexpr (PERM) fr = far_src != nullptr ? fx[i] : order[fr];
       xfar[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(fr * ldx));
       if constexpr (MODE == 0) sfar[i] = scale[fc[i]];
     }
@@ -987,6 +991,8 @@ static int ellw_check(const char* who, const pgt_ellw* op, int64_t n_rows) {
                    op->hub_split >= 1 && (int64_t)op->n_hub * op->hub_split <= op->n_tiles && op->order == nullptr && op->config != 3),
               "%s: hub tables need hub_val, hub_rows, hub_partial, n_hub >= 1 and n_hub * hub_split <= n_tiles on a layout in the "
               "caller's numbering", who);
+  PGT_REQUIRE(op->far_src == nullptr || (op->far_col != nullptr && op->order != nullptr),
+              "%s: far_src restates far_col through order: both must be set", who);
   PGT_REQUIRE(op->far_col == nullptr || op->far_rows == ellw_far_rows(op->config, op->scale != nullptr),
               "%s: far_rows %d does not match the kernel's table for this config / mode (see pgt_ellw_plan)", who,
               (int)op->far_rows);
@@ -1064,7 +1070,7 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
 #define PGT_ELLW_GO_(MODE_, CFG_, W8C_, HUB_)                                                                         \
   PGT_LAUNCH((spmm_ellw64_kernel<MODE_, CFG_, W8C_, std::is_same<CFG_, EllwCfgC>::value, HUB_>), grid, dim3(CFG_::THREADS), stream, \
              op->slots, op->vals, op->scale, rowptr, col, val, (int)n_rows, (int)op->tile_rows, (int)op->halo,            \
-             (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha, beta, flags, op->far_col, op->order, hub)
+             (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha, beta, flags, op->far_col, op->order, hub, op->far_src)
 #define PGT_ELLW_GO(MODE_, CFG_, W8C_)                                                   \
   do {                                                                                   \
     if (fold) PGT_ELLW_GO_(MODE_, CFG_, W8C_, (!std::is_same<CFG_, EllwCfgC>::value));    \

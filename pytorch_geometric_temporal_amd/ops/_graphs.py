@@ -52,6 +52,8 @@ USE_ELLW = os.environ.get("PGT_ELLW", "1") != "0"
 # hubs of an ELLW operator: their slots ride with the tiles of the window kernel (pgt_ellw.hub_*) instead of a workgroup per hub
 # behind it (pgt_spmm_csr_rows_f32).  PGT_HUB_FOLD=0: the second form (A/B)
 USE_HUB_FOLD = os.environ.get("PGT_HUB_FOLD", "1") != "0"
+# a renumbered layout hands the kernel its outside rows' X rows directly (pgt_ellw.far_src).  PGT_FAR_SRC=0: through `order` (A/B)
+USE_FAR_SRC = os.environ.get("PGT_FAR_SRC", "1") != "0"
 
 
 def measure_locality(csrs):
@@ -162,13 +164,14 @@ class Ellw:
     left_out = 0      # hub rows the layout leaves out (csr.long_rows): ops.spmm produces them with pgt_spmm_csr_rows_f32 ...
     hub_col = hub_val = hub_rows = hub_partial = None       # ... unless their pieces ride with the tiles (F = 64: _hub_tables)
     hub_split = 0
+    far_src = None    # a renumbered layout: order[far_col], the outside rows' X rows in the caller's numbering
     csr = None        # the operator in LAYOUT numbering (RenumberedEllw); None: the caller's own CSR serves the layout
 
     def struct(self):
         return EllwStruct(ptr(self.slots), ptr(self.vals), ptr(self.scale), self.tile_rows, self.halo, self.width,
                           self.config, self.n_tiles, ptr(self.far_col), self.far_rows, ptr(self.order),
                           ptr(self.hub_col), ptr(self.hub_val), ptr(self.hub_rows), ptr(self.hub_partial),
-                          0 if self.hub_col is None else int(self.hub_rows.numel()), self.hub_split)
+                          0 if self.hub_col is None else int(self.hub_rows.numel()), self.hub_split, ptr(self.far_src))
 
 
 class _LayoutCsr:
@@ -207,6 +210,9 @@ class RenumberedEllw(Ellw):
         lay.n_rows, lay.max_len, lay.nnz = n, csr.max_len, nnz
         self.csr, self.order = lay, order_h.to(dev)
         super().__init__(lay, 0)
+        if self.far_col is not None and USE_FAR_SRC:
+            fc = self.far_col.long()
+            self.far_src = torch.where(fc >= 0, self.order[fc.clamp(min=0)], torch.full_like(self.far_col, -1)).contiguous()
 
 
 # an operator that is NOT a band (fewer than 95 % of the slots within +-96 rows) may still have compact tiles — a mesh

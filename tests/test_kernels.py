@@ -2239,6 +2239,17 @@ def test_spmm_ellw_renumbered_layout_answers_in_the_callers_numbering(backend, c
             assert e.far_csr == 0 and (e.far > 0 or e.n_tiles == 1)          # a patch's ring fits its table
             Y = torch.full((n, 64), float("nan"), device=backend.device)
             ops.spmm(csr, X, Y)
+            if e.far:
+                # the outside rows' X rows handed to the kernel in the caller's numbering (pgt_ellw.far_src = order[far_col]):
+                # two dependent loads like the window rows instead of three — the same rows, the same bits as through `order`
+                fc = e.far_col.long()
+                assert e.far_src is not None and torch.equal(e.far_src[fc >= 0].long(), e.order[fc[fc >= 0]].long())
+                assert bool((e.far_src[fc < 0] == -1).all())
+                kept, e.far_src = e.far_src, None
+                Yo = torch.full_like(Y, float("nan"))
+                ops.spmm(csr, X, Yo)
+                e.far_src = kept
+                assert torch.equal(Y, Yo)
             Yc = torch.empty_like(Y)
             ops.spmm(csr, X, Yc, ellw=False)
             if scaled:

@@ -20,6 +20,8 @@ import time
 
 import numpy as np
 import torch
+
+import bench_line
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -625,11 +627,10 @@ def launch_probe(rank, world):
         dist.barrier()
         dist.all_reduce(t)
     if rank == 0:
-        import bench_line
-        print(bench_line.compact({"metric": "snapshot-edges aggregated/sec", "value": 0.0, "unit": "snapshot-edges/s", "n_gpus": world,
-                                  "steps": 0, "warmup": 0, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak",
-                                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                                  "config": {"workload": "launch probe (no GPU work)", "rank_sum": float(t)}}), flush=True)
+        bench_line.write_line(bench_line.compact({"metric": "snapshot-edges aggregated/sec", "value": 0.0, "unit": "snapshot-edges/s", "n_gpus": world,
+                                                  "steps": 0, "warmup": 0, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak",
+                                                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                                  "config": {"workload": "launch probe (no GPU work)", "rank_sum": float(t)}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -686,6 +687,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # plain `python bench.py --gpus N`: start the ranks ourselves
         sys.exit(self_launch(sys.argv[1:], args.gpus))
     t_start = time.time()
+    bench_line.capture_stdout()                     # (nothing but the result line reaches this rank's stdout)
     if os.environ.get("PGT_BENCH_STACKS"):          # diagnostic: the Python stack on stderr every N seconds (where a slow box sits)
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["PGT_BENCH_STACKS"]), repeat=True, file=sys.stderr)
@@ -985,7 +987,6 @@ def main():
             "roofline": roof, "kernels": kernels, "roofline_ns_spmm_N200k_F64": ns, "cpu_baseline": cpu,
             "multi_gpu": multi, "variants": variants, "other_configs": extra,
         }
-        import bench_line
         partial = args.no_extra or args.no_cpu_baseline or args.profile_steps == 0      # a profiler pass must not overwrite the clocked run's record
         bench_line.emit(line, "bench_partial.json" if partial else "bench_full.json",       # complete record -> gpurun_out/ + stderr; ONE short
                         before=lambda text: log(f"headline: {head['ms_per_step']:.3f} ms/step; printed line {len(text)} bytes"))   # line on stdout, last

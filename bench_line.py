@@ -239,5 +239,27 @@ def emit(full, name="bench_full.json", before=None):
     if before is not None:
         before(text)
     sys.stderr.flush()
-    print(text, flush=True)
+    write_line(text)
     return text
+
+
+_REAL_STDOUT = None
+
+
+def capture_stdout():
+    """A rank's stdout carries ONE line (rank 0's result).  Libraries under the script write there too — gloo announces its
+    connections on stdout from C++, RCCL its version when NCCL_DEBUG is set — so fd 1 is pointed at stderr for the run and the line
+    goes out through a duplicate of the real one (`write_line`)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def write_line(text):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(text, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (text + "\n").encode())

@@ -324,8 +324,10 @@ __global__ __launch_bounds__(CFG::THREADS) void spmm_ellw64_kernel(
   }
   int yrow[PERM ? RPG : 1];                            // PERM: where this lane group's output rows go
   if constexpr (PERM) {
+    // (a renumbered layout has no halo: the window rows ARE the tile's rows, output row k of this lane group is its window row k)
+    static_assert(!PERM || RPG <= XPT, "one order entry per window row serves the output row too");
 #pragma unroll
-    for (int k = 0; k < RPG; ++k) { const int r = rg + G * k; yrow[k] = order[r0 + (r < nr ? r : 0)]; }
+    for (int k = 0; k < RPG; ++k) yrow[k] = xrow[k < XPT ? k : 0];
   }
 #pragma unroll
   for (int i = 0; i < XPT; ++i) xw[i] = *reinterpret_cast<const pgt_f4*>(Xl + (unsigned)(xrow[i] * ldx));

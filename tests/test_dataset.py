@@ -306,3 +306,12 @@ def test_pems_california_loader_pkl_h5_and_cache(tmp_path, monkeypatch):
     L2 = PemsDatasetLoader(raw_data_dir=d, index=True)
     x2, y2 = next(iter(L2.get_index_dataset(lags=4, batch_size=6)[0]))
     assert torch.equal(x2, x) and torch.equal(y2, y)
+
+
+def test_out_of_scope_loaders_import_and_say_why_they_do_not_load():
+    """PedalMe / Montevideo-bus (reference dataset/pedalme.py, montevideo_bus.py) are outside SURVEY §8: the names import (an
+    import-swapped script does not die on its import line), the call explains."""
+    from pytorch_geometric_temporal_amd.dataset import MontevideoBusDatasetLoader, PedalMeDatasetLoader
+    for cls in (PedalMeDatasetLoader, MontevideoBusDatasetLoader):
+        with pytest.raises(NotImplementedError, match="outside this package's scope"):
+            cls()

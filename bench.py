@@ -430,10 +430,10 @@ def spmm_roofline_ns(device, pairs=6, launches=60, only=None):
                                 f"spmm_ellw64_kernel<{0 if e.scale is not None else 1}{', EllwCfgC, renumbered' if e.order is not None else ''}> (pgt_spmm_ellw_f32: "
                                 f"{e.n_tiles} tiles of {e.tile_rows} rows x {e.width} slots, halo {e.halo}, "
                                 f"{'per-source scale table' if e.scale is not None else 'per-slot coefficients'}, "
-                                f"{e.far} out-of-window slots)" + ((f" + ellw_hub_combine_kernel: the {e.left_out} rows longer than {ops.LONG_ROW} slots (longest {g.fwd_o.max_len}) are left out of "
+                                f"{e.far} out-of-window slots)" + ((f" + ellw_hub_combine_kernel: the {e.left_out} rows longer than {ops.ELLW_MAX_SLOTS} slots (longest {g.fwd_o.max_len}) are left out of "
                                  f"the layout, their slots ride with the tiles in {e.hub_split} pieces per row, a second launch adds the partial rows"
                                  if e.hub_col is not None else
-                                 f" + spmm_long_rows_kernel (pgt_spmm_csr_rows_f32: the {e.left_out} rows longer than {ops.LONG_ROW} slots the layout "
+                                 f" + spmm_long_rows_kernel (pgt_spmm_csr_rows_f32: the {e.left_out} rows longer than {ops.ELLW_MAX_SLOTS} slots the layout "
                                  f"leaves out, one workgroup each; longest {g.fwd_o.max_len})") if e.left_out else "")),
                      "buffers": f"{pairs} rotating (X,Y) pairs", "launch": f"{launches} launches replayed as one hipGraph, mean of 3 replays"}
         if e is not None and e.order is not None:

@@ -138,7 +138,7 @@ def spmm(csr, X, Y, T=None, alpha=1.0, beta=0.0, ellw=None):
     if op is not None:
         es = op.struct()
         lay = op.csr or csr
-        hubs = csr.long_rows if op.left_out and not (op.hub_col is not None and X.size(1) == 64) else None    # (folded at F = 64)
+        hubs = csr.left_rows if op.left_out and not (op.hub_col is not None and X.size(1) == 64) else None    # (folded at F = 64)
 
         def window_then_hubs():
             lib.call("pgt_spmm_ellw_f32", ctypes.byref(es), ptr(lay.rowptr), ptr(lay.col), ptr(lay.val), csr.n_rows, xp, ldx,
@@ -167,7 +167,7 @@ def _force_ellw(csr, halo=None):
         rp = csr.rowptr[:csr.n_rows + 1]
         csr.nnz = int(rp[csr.n_rows])
         csr.max_len = int((rp[1:] - rp[:-1]).max()) if csr.n_rows else 0
-    plan_len = csr.short_len if getattr(csr, "long_rows", None) is not None else csr.max_len     # hubs are left out of the layout
+    plan_len = csr.short_len if getattr(csr, "left_rows", None) is not None else csr.max_len     # left-out rows (hubs)
     if plan_len > 32 or csr.nnz <= 0:
         return None
     csr.ellw = Ellw(csr, halo or csr.halo or 32)

@@ -22,7 +22,7 @@ class Csr:
     """CSR operator by destination row.  `halo` is the operator's measured locality: 32 / 96 when at least 95 % of the
     slots have |col - row| within that distance (locality-ordered node numbering), else 0; `max_len` the longest row.
     `ellw` caches the ELLW layout (pgt_ellw) built for the F = 64 LDS-window kernel on first use."""
-    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows", "family", "short_len")   # ellw: None | Ellw | False
+    __slots__ = ("rowptr", "col", "val", "n_rows", "halo", "max_len", "nnz", "ellw", "long_rows", "family", "short_len", "left_rows")   # ellw: None | Ellw | False
 
     def __init__(self, n_rows, cap, device):
         self.n_rows = n_rows
@@ -31,7 +31,9 @@ class Csr:
         self.nnz = -1
         self.ellw = None
         self.long_rows = None      # int32 device list of the rows longer than LONG_ROW slots (hubs), or None
-        self.short_len = -1        # the longest row among the others (what an ELLW layout that leaves the hubs out is planned for)
+        self.left_rows = None      # int32 device list of the rows an ELLW layout leaves out (longer than its 32 slots: hubs and the odd
+        #                            junction), when they are few (ELLW_LEFT_MAX_FRACTION); None: no such rows, or too many for the layout
+        self.short_len = -1        # the longest row among the others (what that layout is planned for)
         self.family = None         # dict shared by the operators of one graph (forward / transposed, both directions): what one of
         #                            them learned about a renumbering serves the others (same undirected neighbourhoods)
         self.rowptr = torch.zeros(n_rows + 1, dtype=I32, device=device)
@@ -44,6 +46,8 @@ class Csr:
 
 LONG_ROW = 128         # rows with more slots go to the long-row kernel (one workgroup per row: pgt_spmm_csr_long_f32)
 LONG_ROW_CAP = 4096    # at most this many long rows are listed; an operator with more keeps the plain row tiles
+ELLW_MAX_SLOTS = 32    # the widest row of an ELLW layout (pgt_ellw_plan); longer rows are left out of it when they are few:
+ELLW_LEFT_MIN, ELLW_LEFT_MAX_FRACTION = 64, 1.0 / 256      # at most max(64, n_rows / 256) of them, else the operator keeps the CSR kernels
 ELLW_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; keep the CSR row tiles
 # Locality-ordered operators (>= 95 % of the slots within +-32 / +-96 rows, rows of at most 32 slots) take the ELLW
 # layout at F = 64: 21 us against 33 us for the CSR row tiles at N = 200 000, in-degree 8.
@@ -77,13 +81,20 @@ def measure_locality(csrs):
         c.halo = 32 if 20 * n32 >= 19 * nnz > 0 else (96 if 20 * n96 >= 19 * nnz > 0 else 0)
         c.max_len, c.nnz = max_len, nnz
         c.long_rows = lst[:n_long] if 0 < n_long <= LONG_ROW_CAP else None
-        c.short_len = max_len
-    hubs = [c for c in todo if c.long_rows is not None]
-    if hubs:                             # (graph preparation of an operator with hubs: one more read, for all of them)
-        lens = [c.rowptr[1:c.n_rows + 1] - c.rowptr[:c.n_rows] for c in hubs]
-        short = torch.stack([torch.where(ln <= LONG_ROW, ln, torch.zeros_like(ln)).max() for ln in lens]).tolist()
-        for c, m in zip(hubs, short):
-            c.short_len = int(m)
+        c.short_len, c.left_rows = max_len, None
+    # an operator whose rows fit the ELLW layout but for a few (a hub, the odd junction with 40 in-edges) keeps the layout: those
+    # rows are left out of it and produced separately (Ellw.left_out).  Graph preparation: one more host read, for all of them.
+    wide = [c for c in todo if c.max_len > ELLW_MAX_SLOTS and c.halo > 0]
+    if wide:
+        found = []
+        for c in wide:
+            ln = c.rowptr[1:c.n_rows + 1] - c.rowptr[:c.n_rows]
+            over = ln > ELLW_MAX_SLOTS
+            found.append((torch.nonzero(over).flatten().to(I32), torch.where(over, torch.zeros_like(ln), ln).max()))
+        short = torch.stack([f[1] for f in found]).tolist()
+        for c, (rows, _), m in zip(wide, found, short):
+            if 0 < rows.numel() <= max(ELLW_LEFT_MIN, int(c.n_rows * ELLW_LEFT_MAX_FRACTION)):
+                c.left_rows, c.short_len = rows.contiguous(), int(m)
 
 
 class Ellw:
@@ -94,9 +105,9 @@ class Ellw:
         lib = _lib.get_lib()
         dev = csr.rowptr.device
         self.halo = int(halo)
-        # hubs (rows longer than LONG_ROW slots, listed in csr.long_rows) are left out of the layout: the window kernel skips them
+        # rows longer than the layout's 32 slots (csr.left_rows: hubs, the odd junction) are left out of it: the window kernel skips them
         # and pgt_spmm_csr_rows_f32 produces them (ops.spmm); the layout is planned for the longest of the OTHER rows
-        lr = getattr(csr, "long_rows", None)
+        lr = getattr(csr, "left_rows", None)
         self.left_out = 0 if lr is None else int(lr.numel())
         self.plan_len = int(csr.max_len) if lr is None else int(csr.short_len)
         # first as a source-scaled operator (P_o of DConv); the build verifies that and reports the slots outside
@@ -111,7 +122,7 @@ class Ellw:
         """The hubs' slots cut into pieces that ride with the tiles (pgt_ellw.hub_*): piece s of hub h = its slots
         [s C_h, (s + 1) C_h), C_h = ceil(len_h / split), at most P = 2 lane groups' worth per tile.  Graph preparation: torch
         indexing, one host read (the hubs' lengths)."""
-        hubs = csr.long_rows
+        hubs = csr.left_rows
         n_hub = int(hubs.numel())
         split = int(self.n_tiles // n_hub)
         lanes, waves = (64, 16) if self.config == 1 else (32, 8)
@@ -161,7 +172,7 @@ class Ellw:
         return mismatch if source_scaled else 0
 
     order = None      # int32 [n_rows] of a renumbered layout (RenumberedEllw), None: the caller's numbering
-    left_out = 0      # hub rows the layout leaves out (csr.long_rows): ops.spmm produces them with pgt_spmm_csr_rows_f32 ...
+    left_out = 0      # rows the layout leaves out (csr.left_rows): ops.spmm produces them with pgt_spmm_csr_rows_f32 ...
     hub_col = hub_val = hub_rows = hub_partial = None       # ... unless their pieces ride with the tiles (F = 64: _hub_tables)
     hub_split = 0
     far_src = None    # a renumbered layout: order[far_col], the outside rows' X rows in the caller's numbering
@@ -229,7 +240,7 @@ def ellw_of(csr):
     e = getattr(csr, "ellw", None)
     if e is False:                     # tried and rejected
         return None
-    hubs = getattr(csr, "long_rows", None) is not None
+    hubs = getattr(csr, "left_rows", None) is not None
     plan_len = getattr(csr, "short_len", -1) if hubs else getattr(csr, "max_len", -1)
     if e is None and 0 <= plan_len <= 32 and getattr(csr, "nnz", 0) > 0:
         if getattr(csr, "halo", 0) > 0:

@@ -2080,18 +2080,18 @@ def test_long_rows_are_listed_at_graph_preparation(backend):
 
 @pytest.mark.parametrize("fold", [True, False])
 def test_spmm_ellw_leaves_hub_rows_out_of_the_layout(backend, fold):
-    """A locality-ordered operator with a few hubs (rows of hundreds of slots) keeps the ELLW window kernel for its ordinary rows:
-    the layout is planned for the longest ORDINARY row and leaves the hubs out (first slot = 0xFFFE: the kernel neither gathers nor
-    stores them).  fold: the hubs' slots ride with the tiles as pieces (pgt_ellw.hub_*: one partial row per wavefront, a combine
+    """A locality-ordered operator with a few rows wider than the layout's 32 slots (a hub of hundreds, a junction of 49) keeps the
+    ELLW window kernel for its ordinary rows: the layout is planned for the longest ORDINARY row and leaves the others out (first
+    slot = 0xFFFE: the kernel neither gathers nor stores them).  fold: the hubs' slots ride with the tiles as pieces (pgt_ellw.hub_*: one partial row per wavefront, a combine
     launch adds them in a fixed order) at F = 64; otherwise — and at other widths — pgt_spmm_csr_rows_f32 produces exactly those rows
     behind the window kernel.  Ordinary rows bit for bit the reference's roundings, hub rows against fp64 and reproducible, with the
     epilogue and an aliased T (the window kernel must not touch a hub's T row)."""
     n = 5000
     ei, ew = syn.local_graph(n, 4, window=64, seed=0)
     rng = np.random.default_rng(1)
-    hubs = np.array([17, 4000])
-    src = np.concatenate([rng.choice(n, 400, replace=False) for _ in hubs])
-    e2 = np.concatenate([ei, np.stack([src, np.repeat(hubs, 400)])], axis=1)
+    hubs, extra = np.array([17, 4000]), (400, 45)            # a hub, and a junction just over the layout's 32 slots
+    src = np.concatenate([rng.choice(n, k, replace=False) for k in extra])
+    e2 = np.concatenate([ei, np.stack([src, np.repeat(hubs, extra)])], axis=1)
     w2 = np.concatenate([ew, (0.5 + rng.random(src.size)).astype(np.float32)])
     key = np.unique(e2[0].astype(np.int64) * n + e2[1], return_index=True)[1]
     old = ops.USE_HUB_FOLD
@@ -2100,6 +2100,7 @@ def test_spmm_ellw_leaves_hub_rows_out_of_the_layout(backend, fold):
         g = ops.DConvGraph(backend.t(e2[:, key]), backend.t(w2[key]), n)
         csr = g.fwd_o
         assert csr.long_rows is not None and csr.max_len >= 400 and 4 <= csr.short_len <= 8 and csr.halo == 32
+        assert csr.long_rows.tolist() == [17] and sorted(csr.left_rows.tolist()) == [17, 4000]   # > 128 slots / > the layout's 32
         e = ops.ellw_of(csr)
         assert e is not None and e.left_out == 2 and e.width == 8 and e.scale is not None        # P_o: source-scaled
         assert (e.hub_col is not None) == fold and (not fold or e.hub_split * 2 <= e.n_tiles)
@@ -2118,7 +2119,9 @@ def test_spmm_ellw_leaves_hub_rows_out_of_the_layout(backend, fold):
         if not fold:
             Yc = torch.empty_like(Y)
             ops.spmm(csr, X, Yc, ellw=False)                                   # CSR row tiles + the same long-row kernel
-            assert torch.equal(Y.cpu()[~ordinary].nan_to_num(7.0, 8.0, 9.0), Yc.cpu()[~ordinary].nan_to_num(7.0, 8.0, 9.0))
+            assert torch.equal(Y.cpu()[17].nan_to_num(7.0, 8.0, 9.0), Yc.cpu()[17].nan_to_num(7.0, 8.0, 9.0))
+            # (the junction's 49 slots run through the row tiles there, one sequential chain: another order of the same adds)
+            assert_close_with_nonfinite(Y[4000:4001], Yc[4000:4001], 5e-5, 1e-5, "junction row")
         ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0)
         assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "epilogue")
         Tc = T.clone()
@@ -2138,9 +2141,9 @@ def test_spmm_ellw_leaves_hub_rows_out_of_the_layout(backend, fold):
         assert g.bwd_o.long_rows is None and (et is None or et.left_out == 0)
     finally:
         ops.USE_HUB_FOLD = old
-    # a row between the layout's 32 slots and the long-row threshold: neither fits — the operator stays on the CSR kernels
+    # an operator nobody measured (no list of its wide rows): a row wider than the layout's 32 slots keeps it off the layout
     mid = banded_csr(n, 0, 6, 30, seed=6, device=backend.device, heavy_row=40)
-    mid.long_rows, mid.short_len = None, -1
+    mid.long_rows, mid.left_rows, mid.short_len = None, None, -1
     rp = mid.rowptr.cpu()
     assert int((rp[1:] - rp[:-1]).max()) == 300
     assert ops._force_ellw(mid, 32) is None

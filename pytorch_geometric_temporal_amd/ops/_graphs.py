@@ -84,7 +84,7 @@ def measure_locality(csrs):
         c.short_len, c.left_rows = max_len, None
     # an operator whose rows fit the ELLW layout but for a few (a hub, the odd junction with 40 in-edges) keeps the layout: those
     # rows are left out of it and produced separately (Ellw.left_out).  Graph preparation: one more host read, for all of them.
-    wide = [c for c in todo if c.max_len > ELLW_MAX_SLOTS and c.halo > 0]
+    wide = [c for c in todo if c.max_len > ELLW_MAX_SLOTS]
     if wide:
         found = []
         for c in wide:
@@ -245,14 +245,13 @@ def ellw_of(csr):
     if e is None and 0 <= plan_len <= 32 and getattr(csr, "nnz", 0) > 0:
         if getattr(csr, "halo", 0) > 0:
             e = csr.ellw = Ellw(csr, csr.halo)
-        elif hubs:
-            csr.ellw = False               # (compact-tile and renumbered layouts are not built around hubs)
         elif csr.n_rows >= ELLW_MIN_ROWS:
-            cand = Ellw(csr, 32)
+            cand = Ellw(csr, 32)           # (compact tiles: hubs / junctions are left out of this layout like of a band's)
             fam = getattr(csr, "family", None)
             if fam is None:
                 fam = {}
-            if cand.far_csr > ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz and USE_RENUMBER and not fam.get("no_patches"):
+            # (a renumbered layout is not built around left-out rows: such an operator keeps the CSR kernels when its tiles are not compact)
+            if cand.far_csr > ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz and USE_RENUMBER and not hubs and not fam.get("no_patches"):
                 cand = RenumberedEllw(csr, fam.get("order"))
                 if cand.far_csr <= ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz:
                     fam["order"] = cand.order_host          # the graph's other operators lay themselves out in the same patches

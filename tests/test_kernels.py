@@ -569,6 +569,24 @@ def test_spmm_ellw_compact_tiles_of_a_mesh_on_a_space_filling_curve(backend):
         Yc = torch.empty_like(Y)
         ops.spmm(csr, X, Yc, ellw=False)
         assert_close_with_nonfinite(Y, Yc, 1e-5, 1e-5, order)
+    # the same mesh with a junction of 60 more in-edges: the compact-tile layout leaves that row out like a band's would
+    ei, ew = syn.grid2d_graph(side, "hilbert", seed=1)
+    rng = np.random.default_rng(4)
+    src = rng.choice(n, 60, replace=False)
+    e2 = np.concatenate([ei, np.stack([src, np.full(60, 1234)])], axis=1)
+    w2 = np.concatenate([ew, (0.5 + rng.random(60)).astype(np.float32)])
+    key = np.unique(e2[0].astype(np.int64) * n + e2[1], return_index=True)[1]
+    G = ops.DConvGraph(backend.t(e2[:, key]), backend.t(w2[key]), n)
+    csr = G.fwd_o
+    assert csr.halo == 0 and csr.left_rows is not None and csr.left_rows.tolist() == [1234] and csr.long_rows is None
+    Y = torch.full((n, 64), float("nan"), device=backend.device)
+    ops.spmm(csr, X, Y)
+    e = csr.ellw
+    assert e and e.left_out == 1 and e.order is None and e.far_csr <= ops.ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "compact tiles + a junction")
+    ordinary = torch.ones(n, dtype=torch.bool)
+    ordinary[1234] = False
+    assert torch.equal(Y.cpu()[ordinary], source_scaled_reference(csr, X)[ordinary])
 
 
 def test_spmm_ellw_strided_nonfinite_and_fallback_shapes(backend):

@@ -194,7 +194,8 @@ typedef struct pgt_ellw {
    * P = 2 * (threads of the launch shape / 16) = 128 (config 1) / 64 (config 2) slots, piece s of hub h rides with tile
    * h * hub_split + s (entry j of that tile: hub_col / hub_val [(h * hub_split + s) * P + j]; hub_col -1 = unused entry), every
    * wavefront of the tile leaves one partial row in hub_partial and a second, tiny launch adds them in a fixed order.  At other
-   * widths the tables are ignored and the caller produces the hub rows with pgt_spmm_csr_rows_f32, as it does without tables. */
+   * widths the tables are ignored and the caller produces the hub rows with pgt_spmm_csr_rows_f32, as it does without tables.
+   * hub_col and hub_rows name rows of X / Y: the CALLER's numbering, also on a renumbered layout (`order`). */
   const int32_t* hub_col;  /* [n_hub * hub_split * P] */
   const float* hub_val;    /* [n_hub * hub_split * P] */
   const int32_t* hub_rows; /* [n_hub] */

@@ -990,9 +990,8 @@ static int ellw_check(const char* who, const pgt_ellw* op, int64_t n_rows) {
               "%s: operator too large", who);
   PGT_REQUIRE(op->hub_col == nullptr ||
                   (op->hub_val != nullptr && op->hub_rows != nullptr && op->hub_partial != nullptr && op->n_hub >= 1 &&
-                   op->hub_split >= 1 && (int64_t)op->n_hub * op->hub_split <= op->n_tiles && op->order == nullptr && op->config != 3),
-              "%s: hub tables need hub_val, hub_rows, hub_partial, n_hub >= 1 and n_hub * hub_split <= n_tiles on a layout in the "
-              "caller's numbering", who);
+                   op->hub_split >= 1 && (int64_t)op->n_hub * op->hub_split <= op->n_tiles),
+              "%s: hub tables need hub_val, hub_rows, hub_partial, n_hub >= 1 and n_hub * hub_split <= n_tiles", who);
   PGT_REQUIRE(op->far_src == nullptr || (op->far_col != nullptr && op->order != nullptr),
               "%s: far_src restates far_col through order: both must be set", who);
   PGT_REQUIRE(op->far_col == nullptr || op->far_rows == ellw_far_rows(op->config, op->scale != nullptr),
@@ -1075,7 +1074,7 @@ extern "C" int pgt_spmm_ellw_f32(const pgt_ellw* op, const int32_t* rowptr, cons
              (int)op->width, X, (int)ldx, Y, (int)ldy, T, (int)ldt, alpha, beta, flags, op->far_col, op->order, hub, op->far_src)
 #define PGT_ELLW_GO(MODE_, CFG_, W8C_)                                                   \
   do {                                                                                   \
-    if (fold) PGT_ELLW_GO_(MODE_, CFG_, W8C_, (!std::is_same<CFG_, EllwCfgC>::value));    \
+    if (fold) PGT_ELLW_GO_(MODE_, CFG_, W8C_, true);                                     \
     else PGT_ELLW_GO_(MODE_, CFG_, W8C_, false);                                         \
   } while (0)
 #define PGT_ELLW_W(MODE_, CFG_)                                  \

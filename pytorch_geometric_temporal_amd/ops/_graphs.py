@@ -116,7 +116,7 @@ class Ellw:
         if mismatch:
             self._build(lib, csr, dev, False)
         if self.left_out and USE_HUB_FOLD:
-            self._hub_tables(csr, dev)
+            self._hub_tables(self._caller_csr or csr, dev)
 
     def _hub_tables(self, csr, dev):
         """The hubs' slots cut into pieces that ride with the tiles (pgt_ellw.hub_*): piece s of hub h = its slots
@@ -125,7 +125,7 @@ class Ellw:
         hubs = csr.left_rows
         n_hub = int(hubs.numel())
         split = int(self.n_tiles // n_hub)
-        lanes, waves = (64, 16) if self.config == 1 else (32, 8)
+        lanes, waves = (32, 8) if self.config == 2 else (64, 16)
         P = 2 * lanes
         if split < 1:
             return
@@ -175,6 +175,7 @@ class Ellw:
     left_out = 0      # rows the layout leaves out (csr.left_rows): ops.spmm produces them with pgt_spmm_csr_rows_f32 ...
     hub_col = hub_val = hub_rows = hub_partial = None       # ... unless their pieces ride with the tiles (F = 64: _hub_tables)
     hub_split = 0
+    _caller_csr = None   # RenumberedEllw: the operator in the caller's numbering (the layout's own CSR is in layout numbering)
     far_src = None    # a renumbered layout: order[far_col], the outside rows' X rows in the caller's numbering
     csr = None        # the operator in LAYOUT numbering (RenumberedEllw); None: the caller's own CSR serves the layout
 
@@ -188,7 +189,7 @@ class Ellw:
 class _LayoutCsr:
     """The operator of a renumbered layout: rowptr / col / val in layout numbering (what pgt_ellw_build reads and what
     serves a slot that found no place in its tile's table)."""
-    __slots__ = ("rowptr", "col", "val", "n_rows", "max_len", "nnz")
+    __slots__ = ("rowptr", "col", "val", "n_rows", "max_len", "nnz", "left_rows", "short_len")
 
 
 class RenumberedEllw(Ellw):
@@ -204,7 +205,9 @@ class RenumberedEllw(Ellw):
         dev = csr.rowptr.device
         n, nnz = csr.n_rows, int(csr.nnz)
         tr, w, cfg, nt, fr = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
-        lib.call("pgt_ellw_plan", n, 0, int(csr.max_len), 1, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(cfg),
+        left = getattr(csr, "left_rows", None)                       # rows wider than the layout (hubs, junctions): left out of it
+        plan_len = int(csr.short_len) if left is not None else int(csr.max_len)
+        lib.call("pgt_ellw_plan", n, 0, plan_len, 1, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(cfg),
                  ctypes.byref(nt), ctypes.byref(fr))
         rowptr_h = csr.rowptr[:n + 1].cpu().contiguous()            # graph preparation: one round trip per operator
         col_h = csr.col[:nnz].cpu().contiguous()
@@ -219,7 +222,13 @@ class RenumberedEllw(Ellw):
         lay.rowptr, lay.col = rowptr_p.to(dev), col_p.to(dev)
         lay.val = csr.val[:nnz][slot_p[:nnz].to(dev).long()] if nnz else csr.val[:1].clone()
         lay.n_rows, lay.max_len, lay.nnz = n, csr.max_len, nnz
+        lay.left_rows, lay.short_len = None, plan_len
+        if left is not None:                                         # ... by their LAYOUT positions (what pgt_ellw_build sees)
+            inv = torch.empty(n, dtype=torch.int64)
+            inv[order_h.long()] = torch.arange(n)
+            lay.left_rows = inv[left.cpu().long()].to(I32).to(dev)
         self.csr, self.order = lay, order_h.to(dev)
+        self._caller_csr = csr                                       # the hub tables name X / Y rows: the caller's numbering
         super().__init__(lay, 0)
         if self.far_col is not None and USE_FAR_SRC:
             fc = self.far_col.long()
@@ -250,8 +259,7 @@ def ellw_of(csr):
             fam = getattr(csr, "family", None)
             if fam is None:
                 fam = {}
-            # (a renumbered layout is not built around left-out rows: such an operator keeps the CSR kernels when its tiles are not compact)
-            if cand.far_csr > ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz and USE_RENUMBER and not hubs and not fam.get("no_patches"):
+            if cand.far_csr > ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz and USE_RENUMBER and not fam.get("no_patches"):
                 cand = RenumberedEllw(csr, fam.get("order"))
                 if cand.far_csr <= ELLW_COMPACT_MAX_CSR_FRACTION * csr.nnz:
                     fam["order"] = cand.order_host          # the graph's other operators lay themselves out in the same patches

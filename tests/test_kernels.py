@@ -2167,6 +2167,49 @@ def test_spmm_ellw_leaves_hub_rows_out_of_the_layout(backend, fold):
     assert ops._force_ellw(mid, 32) is None
 
 
+def test_spmm_ellw_renumbered_layout_leaves_hub_rows_out(backend):
+    """A graph in an arbitrary numbering (a mesh under a random permutation of its ids) WITH a hub and a junction: the library's
+    patch order carries the ordinary rows (pgt_ellw.order), the two wide rows are left out of the layout by their layout positions
+    and their slots ride with the tiles — the pieces and the combine launch name X / Y rows in the CALLER's numbering.  Ordinary rows
+    bit for bit the reference's roundings, the wide rows against fp64, the epilogue, an aliased T, a width the pieces do not cover."""
+    side = 70 if backend.name == "emu" else 150
+    n = side * side
+    rng = np.random.default_rng(21)
+    ei, ew = syn.grid2d_graph(side, "rowmajor", seed=2)
+    ei = rng.permutation(n)[ei]
+    wide, extra = np.array([n // 3, n - 7]), (300, 40)
+    src = np.concatenate([rng.choice(n, k, replace=False) for k in extra])
+    e2 = np.concatenate([ei, np.stack([src, np.repeat(wide, extra)])], axis=1)
+    w2 = np.concatenate([ew, (0.5 + rng.random(src.size)).astype(np.float32)])
+    key = np.unique(e2[0].astype(np.int64) * n + e2[1], return_index=True)[1]
+    G = ops.DConvGraph(backend.t(e2[:, key]), backend.t(w2[key]), n)
+    csr = G.fwd_o
+    assert csr.halo == 0 and sorted(csr.left_rows.tolist()) == sorted(wide.tolist()) and csr.short_len <= 9
+    gen = torch.Generator().manual_seed(8)
+    X, T = torch.randn(n, 64, generator=gen).to(backend.device), torch.randn(n, 64, generator=gen).to(backend.device)
+    Y = torch.full((n, 64), float("nan"), device=backend.device)
+    ops.spmm(csr, X, Y)
+    e = csr.ellw
+    assert e and e.order is not None and e.config == 3 and e.left_out == 2 and e.hub_col is not None
+    assert sorted(e.order[e.csr.left_rows.long()].tolist()) == sorted(wide.tolist())        # layout positions <-> the caller's rows
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, None, 1.0, 0.0), 5e-5, 1e-5, "renumbered + wide rows")
+    ordinary = torch.ones(n, dtype=torch.bool)
+    ordinary[torch.from_numpy(wide)] = False
+    assert torch.equal(Y.cpu()[ordinary], source_scaled_reference(csr, X)[ordinary])
+    Y2 = torch.full_like(Y, float("nan"))
+    ops.spmm(csr, X, Y2)
+    assert torch.equal(Y, Y2)
+    ops.spmm(csr, X, Y, T=T, alpha=2.0, beta=-1.0)
+    assert_close_with_nonfinite(Y, spmm_reference(csr, X, T, 2.0, -1.0), 5e-5, 1e-5, "epilogue")
+    Tc = T.clone()
+    ops.spmm(csr, X, Tc, T=Tc, alpha=2.0, beta=1.0)
+    assert_close_with_nonfinite(Tc, spmm_reference(csr, X, T, 2.0, 1.0), 5e-5, 1e-5, "aliased T")
+    Xw = torch.randn(n, 128, generator=gen).to(backend.device)
+    Yw = torch.full((n, 128), float("nan"), device=backend.device)
+    ops.spmm(csr, Xw, Yw)
+    assert_close_with_nonfinite(Yw, spmm_reference(csr, Xw, None, 1.0, 0.0), 5e-5, 1e-5, "F = 128")
+
+
 @pytest.mark.gpu
 def test_split_bf16_kernels_reproduce_their_output_bit_for_bit_at_benchmark_size():
     """Round 3's `scripts/bx_determinism_probe.py` as a test (the round-2 `vmcnt` race showed as ~4 differing rows per 200 000

@@ -378,7 +378,10 @@ def spmm_roofline_ns(device, pairs=6, launches=60, only=None):
                            ("local_hubs_20x2000", syn.hub_graph, 8),
                            ("grid2d_hilbert", lambda n_, d_, seed: syn.grid2d_graph(447, "hilbert", seed), 8),
                            ("grid2d_rowmajor", lambda n_, d_, seed: syn.grid2d_graph(447, "rowmajor", seed), 8),
-                           ("grid2d_shuffled", lambda n_, d_, seed: syn.grid2d_graph(447, "shuffled", seed), 8)):
+                           ("grid2d_shuffled", lambda n_, d_, seed: syn.grid2d_graph(447, "shuffled", seed), 8),
+                           # an arbitrary numbering AND a skewed in-degree: the shuffled mesh + 20 rows of 2 000 more slots
+                           ("grid2d_shuf_hubs_20x2000",
+                            lambda n_, d_, seed: syn.hub_graph(n_, d_, seed=seed, base=syn.grid2d_graph(447, "shuffled", seed)), 8)):
         if only is not None and name not in only:
             continue
         n = 447 * 447 if name.startswith("grid2d") else 200_000      # a 447 x 447 mesh: 199 809 nodes

@@ -73,12 +73,13 @@ def local_graph(num_nodes=200_000, degree=8, window=64, seed=0):
     return _row_major(src, dst, w)
 
 
-def hub_graph(num_nodes=200_000, degree=8, hubs=20, hub_degree=2000, seed=0):
-    """local_graph plus `hubs` nodes that also receive `hub_degree` uniformly drawn in-edges (a skewed in-degree
-    distribution: the long rows a row-per-lane-group aggregation kernel chokes on)."""
+def hub_graph(num_nodes=200_000, degree=8, hubs=20, hub_degree=2000, seed=0, base=None):
+    """local_graph (or `base` = (edge_index, edge_weight) of another graph on `num_nodes` nodes) plus `hubs` nodes that also receive
+    `hub_degree` uniformly drawn in-edges (a skewed in-degree distribution: the long rows a row-per-lane-group aggregation kernel
+    chokes on)."""
     rng = np.random.default_rng(seed + 1)
     n = int(num_nodes)
-    ei, ew = local_graph(n, degree, seed=seed)
+    ei, ew = local_graph(n, degree, seed=seed) if base is None else base
     rows = rng.choice(n, hubs, replace=False)
     src = np.concatenate([rng.choice(n, hub_degree, replace=False) for _ in rows])
     dst = np.repeat(rows, hub_degree)

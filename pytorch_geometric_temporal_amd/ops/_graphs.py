@@ -215,6 +215,21 @@ class RenumberedEllw(Ellw):
         order_h = order[0] if given else torch.empty(n, dtype=I32)
         rowptr_p = torch.empty(n + 1, dtype=I32)
         col_p, slot_p = torch.empty(max(nnz, 1), dtype=I32), torch.empty(max(nnz, 1), dtype=I32)
+        if left is not None and not given:
+            # the patches are grown on the operator WITHOUT its wide rows: a hub that joins a patch would pull its thousands of
+            # sources — rows from all over the graph — in behind it; the order found, the full operator is laid out in it below
+            lens = rowptr_h[1:] - rowptr_h[:-1]
+            lens[left.cpu().long()] = 0
+            rowptr_e = torch.zeros(n + 1, dtype=I32)
+            rowptr_e[1:] = torch.cumsum(lens, 0)
+            keep = torch.ones(max(nnz, 1), dtype=torch.bool)
+            for r in left.cpu().tolist():
+                keep[int(rowptr_h[r]):int(rowptr_h[r + 1])] = False
+            col_e = col_h[keep[:nnz]].contiguous() if nnz else col_h
+            scratch = [torch.empty(max(int(col_e.numel()), 1), dtype=I32) for _ in range(2)]
+            lib.call("pgt_tile_order_host", rowptr_e.data_ptr(), col_e.data_ptr(), n, tr.value, 0, order_h.data_ptr(),
+                     rowptr_p.data_ptr(), scratch[0].data_ptr(), scratch[1].data_ptr())
+            given = True
         lib.call("pgt_tile_order_host", rowptr_h.data_ptr(), col_h.data_ptr(), n, tr.value, 1 if given else 0, order_h.data_ptr(),
                  rowptr_p.data_ptr(), col_p.data_ptr(), slot_p.data_ptr())
         self.order_host = (order_h, tr.value)

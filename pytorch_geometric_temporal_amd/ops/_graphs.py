@@ -95,6 +95,9 @@ def measure_locality(csrs):
         for c, (rows, _), m in zip(wide, found, short):
             if 0 < rows.numel() <= max(ELLW_LEFT_MIN, int(c.n_rows * ELLW_LEFT_MAX_FRACTION)):
                 c.left_rows, c.short_len = rows.contiguous(), int(m)
+        hubs = [c.left_rows for c in wide if c.left_rows is not None]
+        if hubs:      # (a hub of one operator is a hub COLUMN of its transpose: the patch order of the graph is grown without any of them)
+            family["hub_nodes"] = torch.unique(torch.cat(hubs).cpu().long())
 
 
 class Ellw:
@@ -215,17 +218,22 @@ class RenumberedEllw(Ellw):
         order_h = order[0] if given else torch.empty(n, dtype=I32)
         rowptr_p = torch.empty(n + 1, dtype=I32)
         col_p, slot_p = torch.empty(max(nnz, 1), dtype=I32), torch.empty(max(nnz, 1), dtype=I32)
-        if left is not None and not given:
-            # the patches are grown on the operator WITHOUT its wide rows: a hub that joins a patch would pull its thousands of
-            # sources — rows from all over the graph — in behind it; the order found, the full operator is laid out in it below
-            lens = rowptr_h[1:] - rowptr_h[:-1]
-            lens[left.cpu().long()] = 0
+        fam = getattr(csr, "family", None) or {}
+        hub_nodes = fam.get("hub_nodes")                             # nodes with a wide row in ANY operator of the graph (host int64)
+        if hub_nodes is None and left is not None:
+            hub_nodes = left.cpu().long()
+        if hub_nodes is not None and hub_nodes.numel() and not given and nnz:
+            # the patches are grown on the operator WITHOUT its hubs, as rows and as sources: a hub that joins a patch would pull its
+            # thousands of neighbours — rows from all over the graph — in behind it (the layout then overflows its tables and is
+            # rejected); the order found, the full operator is laid out in it below
+            is_hub = torch.zeros(n, dtype=torch.bool)
+            is_hub[hub_nodes] = True
+            lens = (rowptr_h[1:] - rowptr_h[:-1]).long()
+            row_of = torch.repeat_interleave(torch.arange(n), lens)
+            keep = ~(is_hub[row_of] | is_hub[col_h.long()])
             rowptr_e = torch.zeros(n + 1, dtype=I32)
-            rowptr_e[1:] = torch.cumsum(lens, 0)
-            keep = torch.ones(max(nnz, 1), dtype=torch.bool)
-            for r in left.cpu().tolist():
-                keep[int(rowptr_h[r]):int(rowptr_h[r + 1])] = False
-            col_e = col_h[keep[:nnz]].contiguous() if nnz else col_h
+            rowptr_e[1:] = torch.cumsum(torch.bincount(row_of[keep], minlength=n), 0)
+            col_e = col_h[keep].contiguous()
             scratch = [torch.empty(max(int(col_e.numel()), 1), dtype=I32) for _ in range(2)]
             lib.call("pgt_tile_order_host", rowptr_e.data_ptr(), col_e.data_ptr(), n, tr.value, 0, order_h.data_ptr(),
                      rowptr_p.data_ptr(), scratch[0].data_ptr(), scratch[1].data_ptr())

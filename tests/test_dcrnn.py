@@ -745,6 +745,52 @@ def test_dconv_on_a_graph_whose_numbering_hides_its_locality(backend):
         assert_close_with_nonfinite(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, what)
 
 
+def test_dconv_on_a_shuffled_graph_with_hubs(backend):
+    """`DConv(64, 64, K=3)` on a mesh in an arbitrary numbering with a hub (300 more in-edges) and a junction (40): the hub is a wide
+    ROW of P_o and of P_i's transpose and a wide COLUMN of the other two operators; all four are laid out in ONE patch order grown
+    without the hub nodes, the wide rows are left out of the layouts and ride with the tiles — output and every gradient equal the CSR
+    kernels' on the caller's numbering."""
+    import numpy as np
+    from pytorch_geometric_temporal_amd import ops
+    side = 70 if backend.name == "emu" else 120
+    n = side * side
+    rng = np.random.default_rng(5)
+    ei, ew = syn.grid2d_graph(side, "shuffled", seed=4)
+    wide, extra = np.array([n // 5, n - 11]), (300, 40)
+    src = np.concatenate([rng.choice(n, k, replace=False) for k in extra])
+    e2 = np.concatenate([ei, np.stack([src, np.repeat(wide, extra)])], axis=1)
+    w2 = np.concatenate([ew, (0.5 + rng.random(src.size)).astype(np.float32)])
+    key = np.unique(e2[0].astype(np.int64) * n + e2[1], return_index=True)[1]
+    ei, ew = backend.t(e2[:, key]), backend.t(w2[key])
+    torch.manual_seed(3)
+    m = DConv(64, 64, 3).to(backend.device)
+    X0 = backend.t(torch.randn(n, 64))
+    outs = []
+    for ellw in (True, False):
+        ops.GRAPH_CACHE.clear()
+        saved, ops.USE_ELLW = ops.USE_ELLW, ellw
+        try:
+            X = X0.clone().requires_grad_(True)
+            m.zero_grad()
+            H = m(X, ei, ew)
+            (H * torch.linspace(-1, 1, 64, device=H.device)).sum().backward()
+            graphs = [v for v in ops.GRAPH_CACHE._d.values() if hasattr(v, "fwd_o")] + \
+                     [w for v in ops.GRAPH_CACHE._d.values() if isinstance(v, tuple) for w in v if hasattr(w, "fwd_o")]
+        finally:
+            ops.USE_ELLW = saved
+        assert graphs
+        g = graphs[0]
+        if ellw:
+            left = [0 if c.ellw.left_out is None else c.ellw.left_out for c in (g.fwd_o, g.fwd_i, g.bwd_o, g.bwd_i)]
+            assert all(c.ellw and c.ellw.order is not None for c in (g.fwd_o, g.fwd_i, g.bwd_o, g.bwd_i)), "four renumbered layouts"
+            assert sorted(left) == [0, 0, 2, 2], left                      # wide rows in two operators, wide columns in the other two
+            for c in (g.fwd_i, g.bwd_o, g.bwd_i):     # one set of patches per tile height (a wider slot block plans lower tiles)
+                assert c.ellw.tile_rows != g.fwd_o.ellw.tile_rows or torch.equal(c.ellw.order, g.fwd_o.ellw.order)
+        outs.append((H.detach(), X.grad.clone(), m.weight.grad.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("H", "dX", "dW")):
+        assert_close_with_nonfinite(a, b, 2e-5 * max(1.0, float(b.abs().max())), 1e-5, what)
+
+
 def test_training_step_gradients_are_bitwise_reproducible_by_default(backend):
     """The reference's CPU path gives the same gradients run after run; so does this one with its default settings: the weight
     gradients are per-slab partial sums added in a fixed order (ops.DETERMINISTIC_WEIGHT_GRADIENTS, on by default), the sequence

@@ -47,7 +47,8 @@ class Csr:
 LONG_ROW = 128         # rows with more slots go to the long-row kernel (one workgroup per row: pgt_spmm_csr_long_f32)
 LONG_ROW_CAP = 4096    # at most this many long rows are listed; an operator with more keeps the plain row tiles
 ELLW_MAX_SLOTS = 32    # the widest row of an ELLW layout (pgt_ellw_plan); longer rows are left out of it when they are few:
-ELLW_LEFT_MIN, ELLW_LEFT_MAX_FRACTION = 64, 1.0 / 256      # at most max(64, n_rows / 256) of them, else the operator keeps the CSR kernels
+ELLW_LEFT_MIN, ELLW_LEFT_MAX_FRACTION = 64, 1.0 / 400      # at most max(64, n_rows / 400) of them — about one per tile, so that each can
+#                                                              ride with a tile — else the operator keeps the CSR kernels
 ELLW_MIN_ROWS = 4096   # below this the whole X fits a CU's L1/L2 slice anyway; keep the CSR row tiles
 # Locality-ordered operators (>= 95 % of the slots within +-32 / +-96 rows, rows of at most 32 slots) take the ELLW
 # layout at F = 64: 21 us against 33 us for the CSR row tiles at N = 200 000, in-degree 8.

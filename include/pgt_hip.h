@@ -191,7 +191,7 @@ typedef struct pgt_ellw {
                              numbering: the kernel reads and writes whole 256-byte rows through `order`, no permutation pass */
   /* Hubs (all NULL / 0: none).  Rows longer than `width` are left out of the layout (pgt_ellw_build info[2]).  With these tables
    * pgt_spmm_ellw_f32 produces them itself at F = 64: the slots of hub h = hub_rows[h] are cut into hub_split pieces of at most
-   * P = 2 * (threads of the launch shape / 16) = 128 (config 1) / 64 (config 2) slots, piece s of hub h rides with tile
+   * P = 2 * (threads of the launch shape / 16) = 128 (config 1, 3) / 64 (config 2) slots, piece s of hub h rides with tile
    * h * hub_split + s (entry j of that tile: hub_col / hub_val [(h * hub_split + s) * P + j]; hub_col -1 = unused entry), every
    * wavefront of the tile leaves one partial row in hub_partial and a second, tiny launch adds them in a fixed order.  At other
    * widths the tables are ignored and the caller produces the hub rows with pgt_spmm_csr_rows_f32, as it does without tables.

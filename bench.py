@@ -403,8 +403,8 @@ def spmm_roofline_ns(device, pairs=6, launches=60, only=None):
                     for i in range(launches):
                         ops.spmm(g.fwd_o, Xs[i % pairs], Ys[i % pairs], ellw=ellw)
             torch.cuda.current_stream(device).wait_stream(side)
-            for _ in range(5):                                 # ~7 ms of launches: clocks out of the idle state
-                graph.replay()
+            for _ in range(25):                                # ~35 ms of launches: clocks out of the idle state and settled (with 5
+                graph.replay()                                 # replays the three timed ones still fell by 2 - 4 % from first to last)
             torch.cuda.synchronize()
             times = []
             for _ in range(3):

@@ -16,9 +16,16 @@ from pytorch_geometric_temporal_amd.dataset import synthetic as syn
 from pytorch_geometric_temporal_amd.graphed import GraphedStep
 
 
-def _time_gpu(fn, reps, warm=3):
-    for _ in range(warm):
+def _time_gpu(fn, reps, warm=3, warm_seconds=0.03):
+    """Mean wall time of `reps` calls behind at least `warm` untimed ones AND `warm_seconds` of them (sub-millisecond steps: three
+    replays leave the clocks where the previous block left them — bench.py's aggregation block read 2 - 4 % high that way)."""
+    t0 = time.perf_counter()
+    k = 0
+    while k < warm or (time.perf_counter() - t0 < warm_seconds and k < 1000):
         fn()
+        k += 1
+        if k >= warm:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):

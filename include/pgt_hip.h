@@ -209,7 +209,7 @@ typedef struct pgt_ellw {
 
 /* Host-only: tile height / slot width / tile count for an operator with `n_rows` rows whose longest row has
  * `max_row_len` slots and whose sources lie (mostly) within `halo` rows of their destination; the tile height fills
- * whole rounds of the resident workgroups (config 1: rows of <= 8 slots; config 2: wider rows) of the current device.
+ * whole rounds of the resident workgroups (config 1: rows of <= 8 slots, <= 16 in source-scale mode; config 2: wider rows) of the current device.
  * `far_rows` = entries per tile of the out-of-window table (what the LDS budget of the launch shape leaves: more in
  * source-scale mode, which has no coefficient block).
  * halo 0 plans the layout of a renumbered operator (config 3: a 400-row window without halo, 208 / 160 table entries).

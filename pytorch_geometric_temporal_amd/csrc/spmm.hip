@@ -949,7 +949,10 @@ extern "C" int pgt_ellw_plan(int64_t n_rows, int32_t halo, int32_t max_row_len, 
               (int)max_row_len, ELLW_WMAX);
   const int W = max_row_len <= 8 ? 8 : (int)pgt_cdiv(max_row_len, 8) * 8;
   // halo 0 = the layout of a renumbered operator (pgt_tile_order_host): launch shape C
-  const int cfg = halo == 0 ? 3 : (g_ellw_cfg == 1 || g_ellw_cfg == 2 ? g_ellw_cfg : ((W <= 8 || halo > 40) ? 1 : 2));
+  // shape A for rows of up to 8 slots, and up to 16 in source-scale mode (no coefficient block: N = 200 000, in-degree 10 - 16, clocks
+  // settled: 26.3 - 26.6 us against 27.2 - 27.4 on shape B; per-slot mode at W = 24: B 31.8 - 32.5 against A 32.9 - 33.7)
+  const int cfg = halo == 0 ? 3 : (g_ellw_cfg == 1 || g_ellw_cfg == 2 ? g_ellw_cfg
+                                   : ((W <= 8 || halo > 40 || (W <= 16 && source_scaled != 0)) ? 1 : 2));
   *config = cfg;
   *far_rows = ellw_far_rows(cfg, source_scaled != 0);
   const int wrmax = ellw_wrmax(cfg), slots_cap = ellw_slots_cap(cfg);

@@ -645,7 +645,7 @@ def test_ellw_plan_fills_whole_rounds_of_the_cus(backend):
         tr, w, cfg, nt, fr = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int32()
         lib.call("pgt_ellw_plan", n, halo, max_len, source_scaled, ctypes.byref(tr), ctypes.byref(w), ctypes.byref(cfg),
                  ctypes.byref(nt), ctypes.byref(fr))
-        assert cfg.value == (1 if (w.value == 8 or halo > 40) else 2)
+        assert cfg.value == (1 if (w.value == 8 or halo > 40 or (w.value == 16 and source_scaled)) else 2)
         # out-of-window table: what the LDS budget of the launch shape leaves next to window, slots (and coefficients)
         assert fr.value == {(1, 1): 128, (1, 0): 32, (2, 1): 48, (2, 0): 12}[(cfg.value, source_scaled)]
         return tr.value, w.value, nt.value
@@ -656,7 +656,8 @@ def test_ellw_plan_fills_whole_rounds_of_the_cus(backend):
         assert plan(200_000, 32, 8, 0) == (392, 8, 511)
         assert plan(200_000, 96, 8) == (264, 8, 758)          # window of 456 rows: 264 + 2 * 96
         assert plan(200_000, 32, 17) == (100, 24, 2000)       # two workgroups per CU, 176 * 16 staged slots: <= 116 rows of 24
-        assert plan(200_000, 32, 16) == (132, 16, 1516)       # 176 window-limited rows -> three rounds of 512
+        assert plan(200_000, 32, 16) == (392, 16, 511)        # source-scale mode: one workgroup per CU up to 16 slots (26.4 vs 27.3 us)
+        assert plan(200_000, 32, 16, 0) == (132, 16, 1516)    # per-slot mode: 176 window-limited rows -> three rounds of 512
         assert plan(200_000, 96, 16) == (264, 16, 758)        # wide halo: one workgroup per CU
         tr, w, nt = plan(50_000, 32, 8)
         assert (tr, w, nt) == (196, 8, 256)                   # one round
